@@ -1,0 +1,119 @@
+/*
+ * intfft.h -- C-ABI of the MI355X-native integer FFT/IFFT engine (libintfft.so).
+ *
+ * Drop-in boundary for the hot path of hukenovs/intfftk: the reference has no software API, so
+ * the boundary is the RTL entity interface of int_fftNk / int_ifftNk
+ * (src/vhdl/fft/int_fftNk.vhd:72-103, src/vhdl/fft/int_ifftNk.vhd:71-102) and of the two
+ * wrappers that call them (src/vhdl/main/int_fft_single_path.vhd:85-113,
+ * src/vhdl/main/int_fft_ifft_pair.vhd:74-107).  Generics become `intfft_params`; the 2-lane
+ * valid-qualified sample stream becomes a frame-major device array; one RTL frame (N/2 beats)
+ * becomes one row of `batch`.
+ *
+ * Plain C: no torch types, no C++ types, no exceptions across the boundary.
+ * Data pointers are HIP device pointers; the caller owns them.
+ */
+#ifndef INTFFT_H
+#define INTFFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: 0 OK, negative = parameter/elaboration errors, positive = hipError_t ---- */
+#define INTFFT_OK               0
+#define INTFFT_ERR_INVALID     (-1) /* parameter out of range (e.g. log2n, orders, direction)         */
+#define INTFFT_ERR_UNSUPPORTED (-2) /* widths for which the RTL does not elaborate: find_delay -> 0,
+                                       int_dif2_fly.vhd:87-116; or results wider than 64 bits        */
+#define INTFFT_ERR_NULL        (-3) /* NULL argument                                                  */
+#define INTFFT_ERR_NO_DEVICE   (-4) /* no HIP device / wrong device index -- there is NO CPU fallback */
+#define INTFFT_ERR_ALLOC       (-5) /* host allocation failed                                         */
+
+/* direction: which core(s) a frame goes through */
+#define INTFFT_FWD  0 /* int_fftNk  : radix-2 DIF forward  (int_fftNk.vhd:72)                     */
+#define INTFFT_INV  1 /* int_ifftNk : radix-2 DIT inverse  (int_ifftNk.vhd:71)                    */
+#define INTFFT_PAIR 2 /* int_fftNk -> int_ifftNk back to back (int_fft_ifft_pair.vhd:209-280)     */
+
+/*
+ * I/O orders: how memory index m of a frame maps to the logical index (time index n for the
+ * input of FWD / output of INV; frequency index k for the output of FWD / input of INV).
+ *   NATURAL      : logical = m                    (int_fft_single_path.vhd:42-47 serial I/O;
+ *                                                  == the interleave-2 stream of iobuf_flow_int2.vhd:18-40)
+ *   BITREV       : logical = bitrev(m)            native int_fftNk output / int_ifftNk input as
+ *                                                  beats (lane0[i], lane1[i]) = (m = 2i, 2i+1)
+ *                                                  (int_fftNk.vhd:18-21, math/fn_radix2.m:182-188)
+ *   HALVES       : logical = (m >> 1) + (m & 1) * N/2   native int_fftNk input / int_ifftNk output
+ *                                                  as beats (lane0[i], lane1[i]) (int_fftNk.vhd:15-17)
+ *   BITREV_LANES : logical = bitrev(2 * (m mod N/2) + m div N/2)   the serial stream
+ *                                                  [lane0 frame ; lane1 frame] of outbuf_half_path.vhd:160-172,
+ *                                                  i.e. what int_bitrev_order.vhd:82-104 turns into NATURAL
+ */
+#define INTFFT_ORDER_NATURAL      0
+#define INTFFT_ORDER_BITREV       1
+#define INTFFT_ORDER_HALVES       2
+#define INTFFT_ORDER_BITREV_LANES 3
+
+/* Mirrors the VHDL generics 1:1 (int_fftNk.vhd:73-84; tb mode names fft_signle_test.vhd:80-112:
+ * "UNSCALED" = format 1, "TRUNCATE" = format 0 rndmode 0, "ROUNDING" = format 0 rndmode 1). */
+typedef struct intfft_params {
+    int32_t log2n;      /* NFFT      : log2 of the length, 3..19 (20 = documented extension)      */
+    int32_t data_width; /* DATA_WIDTH: width of the input samples, 2..64 (wrappers use 8..32)      */
+    int32_t twdl_width; /* TWDL_WIDTH: 4..27 (XSER NEW) / 4..25 (OLD)                              */
+    int32_t format;     /* FORMAT    : 1 unscaled (1 bit growth per stage), 0 scaled              */
+    int32_t rndmode;    /* RNDMODE   : 0 truncate, 1 round-half-up; scaled only                   */
+    int32_t xser;       /* XSER      : 0 "OLD" (DSP48E1), 1 "NEW" (DSP48E2) -- changes results in
+                                       the wide-multiplier and Taylor-twiddle regimes              */
+    int32_t direction;  /* INTFFT_FWD / INTFFT_INV / INTFFT_PAIR                                   */
+    int32_t use_fly;    /* USE_FLY   : 1 normal, 0 bypass butterflies (int_fftNk.vhd:260-277)      */
+    int32_t in_order;   /* INTFFT_ORDER_*                                                          */
+    int32_t out_order;  /* INTFFT_ORDER_*                                                          */
+} intfft_params;
+
+typedef struct intfft_plan intfft_plan;
+
+/* What a plan resolved to; for benchmarks and tests. */
+typedef struct intfft_plan_info {
+    int32_t in_bits, out_bits;           /* DATA_WIDTH, DATA_WIDTH + FORMAT*NFFT (x2 for PAIR)     */
+    int32_t in_container, out_container; /* bytes per real component: 2, 4 or 8                    */
+    int32_t n_passes;                    /* kernel launches per batch chunk                        */
+    int32_t compute_word;                /* bytes of the on-chip word (2 = packed int16 fast path) */
+    int32_t fast_path;                   /* 1 if the packed-int16 wave kernel serves this plan     */
+    int32_t reserved;
+    uint64_t scratch_bytes;              /* plan-owned device scratch                              */
+    char kernel_name[64];                /* dominant kernel symbol (for rocprof matching)          */
+} intfft_plan_info;
+
+/* Widths and containers implied by the generics.  Containers are the smallest of int16/32/64
+ * that hold the width; frames are [batch][N] of interleaved (re, im), sign-extended.  Input
+ * values outside data_width are wrapped on load like conv_std_logic_vector in
+ * fft_signle_test.vhd:163-164. */
+int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *in_container_bytes,
+                     int *out_container_bytes);
+
+/* Elaborates a core on a HIP device: validates the generics the way the RTL elaboration would,
+ * generates the twiddle tables on the device (rom_twiddle_int.vhd + row_twiddle_tay.vhd) and
+ * chooses the kernels.  The plan is immutable afterwards. */
+int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device);
+int intfft_plan_destroy(intfft_plan *plan);
+int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
+
+/* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
+ * (see intfft_io_widths).  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
+ * d_in == d_out is allowed when the containers have equal size.  Re-entrant across plans;
+ * one plan must not be executed concurrently on two streams (plan-owned scratch). */
+int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
+
+/* Parity introspection: the twiddle stream of butterfly stage `stage` (2^stage entries, the
+ * values rom_twiddle_int emits for cnt = 0 .. 2^stage-1) as interleaved int32 (re, im).
+ * h_out may be NULL to query *count. */
+int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count);
+
+const char *intfft_strerror(int status);
+const char *intfft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTFFT_H */

@@ -1,0 +1,191 @@
+// intfft_device.hpp -- device arithmetic of the fixed-point radix-2 butterflies (gfx950).
+//
+// One inline device function per arithmetic block of the reference RTL (hukenovs/intfftk):
+//   int_addsub_dsp48   src/vhdl/math/int_addsub_dsp48.vhd:17-22      -> plain +/-
+//   int_cmult_dsp48    src/vhdl/math/cmult/int_cmult_dsp48.vhd:182-434 -> cmult<T>()
+//   int_dif2_fly       src/vhdl/fft/int_dif2_fly.vhd:144-373          -> dif_fly<T>()
+//   int_dit2_fly       src/vhdl/fft/int_dit2_fly.vhd:142-325          -> dit_fly<T>()
+// T is the on-chip word: int32_t when every width of the plan is <= 32 bits, else int64_t.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace intfft {
+
+enum StageKind : int { KIND_DIF = 0, KIND_DIT = 1 };
+enum RoundKind : int { RND_TRUNC = 0, RND_ROUND = 1, RND_UNSCALED = 2 };
+
+// One butterfly stage as the kernels see it (filled by the host planner).
+struct StageDesc {
+    int kind;    // KIND_DIF / KIND_DIT
+    int s;       // STAGE generic of the butterfly/twiddle (pairs differ in index bit s)
+    int lb;      // tile-local bit that carries index bit s
+    int dtw;     // DTW: width of the stage inputs
+    int wo;      // output width DTW - SCALE + 1
+    int mw;      // width the complex multiplier works at (DIF: wo, DIT: dtw)
+    int rnd;     // RoundKind
+    int sh_a;    // multiplier: per-product pre-shift  (0 in the single-DSP regimes)
+    int sh_b;    // multiplier: post-sum shift
+    unsigned tw_off; // offset of this stage's table in the twiddle buffer (int2 entries)
+};
+
+template <typename T> struct Cx { T re, im; };
+
+template <typename T> __device__ __forceinline__ T wrapw(T v, int w)
+{
+    constexpr int B = sizeof(T) * 8;
+    if (w >= B) return v;
+    using U = typename std::make_unsigned<T>::type;
+    return (T)((U)v << (B - w)) >> (B - w);
+}
+
+// "for positive values use Y = not(X) + 1, for negative values use Y = not(X)"
+// int_dif2_fly.vhd:280-304, int_dit2_fly.vhd:251-276
+template <typename T> __device__ __forceinline__ T neg_quirk(T x, int w)
+{
+    using U = typename std::make_unsigned<T>::type;
+    return x >= 0 ? wrapw<T>((T)((U)0 - (U)x), w) : (T)~x;
+}
+
+// ---- complex multiplier -------------------------------------------------------------------
+// result = wrap_w( ((M2 >> a) -/+ (M1 >> a)) >> b ) with (a, b) per regime:
+//   sngl (0, t-1) int_cmult_dsp48.vhd:189-190 | dbl18 (t-4|t-6, 3|5) int_cmult_dbl18_dsp48.vhd:163,174-175
+//   trpl18 (t-1, 0) int_cmult_trpl18_dsp48.vhd:151-155 | sngl25 (0, t-2) int_cmult_dsp48.vhd:316-317
+//   dbl35 (t-14, 12) int_cmult_dbl35_dsp48.vhd:163-168 | trpl52 (t-2, 0) int_cmult_trpl52_dsp48.vhd:166-170
+// 32-bit words: products fit int64 (|d| < 2^31, |w| < 2^26).
+__device__ __forceinline__ void cmult(int32_t dre, int32_t dim, int32_t wr, int32_t wi, int mw,
+                                      int a, int b, int32_t &ore, int32_t &oim)
+{
+    const int64_t m2r = (int64_t)dre * wr, m1r = (int64_t)dim * wi; // RE: M2 - M1  (:192-207)
+    const int64_t m2i = (int64_t)dre * wi, m1i = (int64_t)dim * wr; // IM: M2 + M1  (:209-224)
+    const int64_t r = ((m2r >> a) - (m1r >> a)) >> b;
+    const int64_t i = ((m2i >> a) + (m1i >> a)) >> b;
+    ore = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)r, mw);
+    oim = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)i, mw);
+}
+
+// 64-bit words: products reach 2^89; keep each product as H*2^32 + L with
+// H = (d >> 32) * w and L = (d & 0xffffffff) * w (both exact in int64), so that
+// floor(M / 2^k) mod 2^64 = (H << (32 - k)) + (L >> k) for 0 <= k <= 32.  Only the low 64 bits of
+// the sums are ever sliced by the RTL (w <= 64), so wrapping uint64 arithmetic is exact.
+struct Prod96 { int64_t h, l; };
+__device__ __forceinline__ Prod96 mul96(int64_t d, int32_t w)
+{
+    Prod96 p;
+    p.h = (d >> 32) * (int64_t)w;
+    p.l = (int64_t)(uint64_t)(uint32_t)d * (int64_t)w;
+    return p;
+}
+__device__ __forceinline__ uint64_t shr96(Prod96 p, int k)
+{
+    return ((uint64_t)p.h << (32 - k)) + (uint64_t)(p.l >> k);
+}
+__device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int32_t wi, int mw,
+                                      int a, int b, int64_t &ore, int64_t &oim)
+{
+    const Prod96 m2r = mul96(dre, wr), m1r = mul96(dim, wi);
+    const Prod96 m2i = mul96(dre, wi), m1i = mul96(dim, wr);
+    uint64_t r, i;
+    if (a == 0) { // exact sum first, then one slice
+        Prod96 sr{m2r.h - m1r.h, m2r.l - m1r.l}, si{m2i.h + m1i.h, m2i.l + m1i.l};
+        r = shr96(sr, b);
+        i = shr96(si, b);
+    } else {
+        r = (uint64_t)((int64_t)(shr96(m2r, a) - shr96(m1r, a)) >> b);
+        i = (uint64_t)((int64_t)(shr96(m2i, a) + shr96(m1i, a)) >> b);
+    }
+    ore = wrapw<int64_t>((int64_t)r, mw);
+    oim = wrapw<int64_t>((int64_t)i, mw);
+}
+
+// ---- sum / difference with the three scaling variants --------------------------------------
+// trunc  : (A >> 1) +/- (B >> 1)   LSB dropped BEFORE the add (int_dif2_fly.vhd:151-154)
+// round  : rhu2(A +/- B) on the exact (DTW+1)-bit sum, wrapped to DTW bits (:173-218); written
+//          without the extra bit: rhu2(A+B) = (A>>1)+(B>>1)+((A|B)&1), rhu2(A-B) = (A>>1)-(B>>1)+(A&~B&1)
+// unscaled: A +/- B, one bit of growth (:222-240)
+template <typename T>
+__device__ __forceinline__ void addsub(T a, T b, int rnd, int wo, T &s, T &d)
+{
+    using U = typename std::make_unsigned<T>::type;
+    if (rnd == RND_TRUNC) {
+        s = (a >> 1) + (b >> 1);
+        d = (a >> 1) - (b >> 1);
+    } else if (rnd == RND_ROUND) {
+        s = wrapw<T>((T)((U)(a >> 1) + (U)(b >> 1) + (U)((a | b) & 1)), wo);
+        d = wrapw<T>((T)((U)(a >> 1) - (U)(b >> 1) + (U)(a & ~b & 1)), wo);
+    } else {
+        s = (T)((U)a + (U)b);
+        d = (T)((U)a - (U)b);
+    }
+}
+
+// int_dif2_fly: X = S, Y = D (STAGE 0) | D * {1, -j} (STAGE 1) | cmult(D, W) (STAGE >= 2)
+template <typename T>
+__device__ __forceinline__ void dif_fly(const StageDesc &st, int odd, Cx<T> a, Cx<T> b, int32_t wr,
+                                        int32_t wi, Cx<T> &x, Cx<T> &y)
+{
+    Cx<T> s, d;
+    addsub<T>(a.re, b.re, st.rnd, st.wo, s.re, d.re);
+    addsub<T>(a.im, b.im, st.rnd, st.wo, s.im, d.im);
+    x = s;
+    if (st.s == 0) { // int_dif2_fly.vhd:245-255
+        y = d;
+    } else if (st.s == 1) { // :259-318
+        if (!odd) {
+            y = d;
+        } else {
+            y.re = d.im;
+            y.im = neg_quirk<T>(d.re, st.wo);
+        }
+    } else { // :322-373
+        cmult(d.re, d.im, wr, wi, st.mw, st.sh_a, st.sh_b, y.re, y.im);
+    }
+}
+
+// int_dit2_fly: T = B (STAGE 0) | B * {1, +j} (STAGE 1) | B * conj(W) via the re/im-swapped
+// multiplier (int_dit2_fly.vhd:304-322), then X = A + T, Y = A - T with the scaling variant.
+template <typename T>
+__device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, Cx<T> b, int32_t wr,
+                                        int32_t wi, Cx<T> &x, Cx<T> &y)
+{
+    Cx<T> t;
+    if (st.s == 0) { // :221-230
+        t = b;
+    } else if (st.s == 1) { // :234-286
+        if (!odd) {
+            t = b;
+        } else {
+            t.im = b.re;
+            t.re = neg_quirk<T>(b.im, st.dtw);
+        }
+    } else {
+        T ore, oim;
+        cmult(b.im, b.re, wr, wi, st.mw, st.sh_a, st.sh_b, ore, oim);
+        t.im = ore;
+        t.re = oim;
+    }
+    addsub<T>(a.re, t.re, st.rnd, st.wo, x.re, y.re);
+    addsub<T>(a.im, t.im, st.rnd, st.wo, x.im, y.im);
+}
+
+// ---- I/O order maps (include/intfft.h) -------------------------------------------------------
+__device__ __forceinline__ unsigned brev_l(unsigned v, int L) { return __brev(v) >> (32 - L); }
+
+// memory index of logical index `idx` for one of the INTFFT_ORDER_* layouts (inverse of the
+// "memory -> logical" maps documented in intfft.h)
+__device__ __forceinline__ unsigned order_to_mem(int order, int L, unsigned idx)
+{
+    const unsigned half = 1u << (L - 1);
+    switch (order) {
+    case 1: return brev_l(idx, L);                                   // BITREV
+    case 2: return ((idx & (half - 1)) << 1) | (idx >> (L - 1));     // HALVES: rotate left
+    case 3: {                                                         // BITREV_LANES
+        const unsigned r = brev_l(idx, L);                            // = 2*(m mod N/2) + m div N/2
+        return (r >> 1) | ((r & 1u) << (L - 1));
+    }
+    default: return idx;                                             // NATURAL
+    }
+}
+
+} // namespace intfft

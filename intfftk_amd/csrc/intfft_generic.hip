@@ -1,0 +1,239 @@
+// intfft_generic.hip -- generic LDS pass kernel + twiddle-generation kernels (gfx950).
+//
+// k_pass<T> evaluates any run of radix-2 stages of int_fftNk / int_ifftNk
+// (src/vhdl/fft/int_fftNk.vhd:184-342, src/vhdl/fft/int_ifftNk.vhd:183-341) on a tile held in LDS,
+// for every width/mode/regime the RTL elaborates.  The cross-commutators
+// (src/vhdl/delay/int_delay_line.vhd:60-104) never materialise: they are what makes the flat
+// in-place index of SURVEY.md section 9.1 valid.  The packed-int16 wave kernel in intfft_fast1024.hip is the
+// speed path for the headline configuration; this kernel is the complete one.
+#include "intfft_internal.hpp"
+
+#include <cmath>
+
+namespace intfft {
+
+// LDS index padding: one element of padding per 32 keeps the bit-reversed / strided tile sweeps
+// of the load and store phases from landing on one bank.
+__device__ __forceinline__ unsigned pad(unsigned e) { return e + (e >> 5); }
+
+template <typename T> __device__ __forceinline__ T load_user(const void *base, int cb, size_t i)
+{
+    if (cb == 2) return (T) reinterpret_cast<const int16_t *>(base)[i];
+    if (cb == 4) return (T) reinterpret_cast<const int32_t *>(base)[i];
+    return (T) reinterpret_cast<const int64_t *>(base)[i];
+}
+
+template <typename T> __device__ __forceinline__ void store_user(void *base, int cb, size_t i, T v)
+{
+    if (cb == 2) reinterpret_cast<int16_t *>(base)[i] = (int16_t)v;
+    else if (cb == 4) reinterpret_cast<int32_t *>(base)[i] = (int32_t)v;
+    else reinterpret_cast<int64_t *>(base)[i] = (int64_t)v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const void *in, void *out,
+                                                       const int2 *__restrict__ tw, size_t nframes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Cx<T> *lds = reinterpret_cast<Cx<T> *>(smem);
+
+    const int L = a.L, U = a.U;
+    const unsigned tiles = 1u << (L - U);
+    const unsigned tile = blockIdx.x % tiles;
+    const size_t f0 = (size_t)(blockIdx.x / tiles) * (size_t)a.fpb;
+    const unsigned nf = (unsigned)min((size_t)a.fpb, nframes - f0);
+    const size_t N = (size_t)1 << L;
+
+    // deposit the tile id into the index bits the tile does not own
+    unsigned tile_bits = 0;
+    {
+        unsigned t = tile;
+        for (int b = 0; b < L; ++b) {
+            const bool owned = (b >= a.pos0 && b < a.pos0 + a.len0) || (b >= a.pos1 && b < a.pos1 + a.len1);
+            if (!owned) {
+                tile_bits |= (t & 1u) << b;
+                t >>= 1;
+            }
+        }
+    }
+    const unsigned m0 = (1u << a.len0) - 1u;
+    auto spread = [&](unsigned u) -> unsigned {
+        return tile_bits | ((u & m0) << a.pos0) | ((u >> a.len0) << a.pos1);
+    };
+    auto swap_runs = [&](unsigned v) -> unsigned { // v enumerates run1 fastest
+        const unsigned m1 = (1u << a.len1) - 1u;
+        return ((v & m1) << a.len0) | (v >> a.len1);
+    };
+
+    const unsigned tile_n = 1u << U;
+    const unsigned total = nf << U;
+
+    // ---- load -------------------------------------------------------------------------------
+    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+        const unsigned f = i >> U, v = i & (tile_n - 1u);
+        const unsigned u = a.ld_swap ? swap_runs(v) : v;
+        const unsigned j = spread(u);
+        Cx<T> c;
+        if (a.in_mode == IO_USER) {
+            const unsigned logical = a.in_rev ? brev_l(j, L) : j;
+            const size_t m = (f0 + f) * N + order_to_mem(a.in_order, L, logical);
+            c.re = load_user<T>(in, a.in_cb, 2 * m);
+            c.im = load_user<T>(in, a.in_cb, 2 * m + 1);
+            if (a.in_zext) {
+                using UT = typename std::make_unsigned<T>::type;
+                const UT mask = (a.in_bits >= (int)(8 * sizeof(T))) ? ~(UT)0 : (((UT)1 << a.in_bits) - 1);
+                c.re = (T)((UT)c.re & mask);
+                c.im = (T)((UT)c.im & mask);
+            } else {
+                c.re = wrapw<T>(c.re, a.in_bits);
+                c.im = wrapw<T>(c.im, a.in_bits);
+            }
+        } else {
+            c = reinterpret_cast<const Cx<T> *>(in)[(f0 + f) * N + j];
+        }
+        lds[pad((f << U) + u)] = c;
+    }
+    __syncthreads();
+
+    // ---- stages -----------------------------------------------------------------------------
+    const unsigned nbf = nf << (U - 1);
+    for (int si = 0; si < a.nstages; ++si) {
+        const StageDesc st = a.st[si];
+        const unsigned lowm = (1u << st.lb) - 1u;
+        const unsigned km = (1u << st.s) - 1u;
+        for (unsigned q = threadIdx.x; q < nbf; q += PASS_THREADS) {
+            const unsigned f = q >> (U - 1), qq = q & ((tile_n >> 1) - 1u);
+            const unsigned u0 = ((qq >> st.lb) << (st.lb + 1)) | (qq & lowm);
+            const unsigned u1 = u0 | (1u << st.lb);
+            const unsigned k = spread(u0) & km; // twiddle counter mod 2^STAGE (rom_twiddle_int.vhd:187-202)
+            int2 w = make_int2(0, 0);
+            if (st.s >= 2) w = tw[st.tw_off + k];
+            const unsigned e0 = pad((f << U) + u0), e1 = pad((f << U) + u1);
+            const Cx<T> A = lds[e0], B = lds[e1];
+            Cx<T> X, Y;
+            if (st.kind == KIND_DIF) dif_fly<T>(st, (int)(k & 1u), A, B, w.x, w.y, X, Y);
+            else dit_fly<T>(st, (int)(k & 1u), A, B, w.x, w.y, X, Y);
+            lds[e0] = X;
+            lds[e1] = Y;
+        }
+        __syncthreads();
+    }
+
+    // ---- store ------------------------------------------------------------------------------
+    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+        const unsigned f = i >> U, v = i & (tile_n - 1u);
+        const unsigned u = a.st_swap ? swap_runs(v) : v;
+        const unsigned j = spread(u);
+        const Cx<T> c = lds[pad((f << U) + u)];
+        if (a.out_mode == IO_USER) {
+            const unsigned logical = a.out_rev ? brev_l(j, L) : j;
+            const size_t m = (f0 + f) * N + order_to_mem(a.out_order, L, logical);
+            store_user<T>(out, a.out_cb, 2 * m, c.re);
+            store_user<T>(out, a.out_cb, 2 * m + 1, c.im);
+        } else {
+            reinterpret_cast<Cx<T> *>(out)[(f0 + f) * N + j] = c;
+        }
+    }
+}
+
+size_t pass_lds_bytes(const PassArgs &a, int word_bytes)
+{
+    const size_t elems = (size_t)a.fpb << a.U;
+    return (elems + (elems >> 5) + 1) * 2 * (size_t)word_bytes;
+}
+
+const char *pass_kernel_name(int word_bytes)
+{
+    return word_bytes == 4 ? "k_pass<int>" : "k_pass<long>";
+}
+
+hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
+                       size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    const size_t groups = (nframes + (size_t)a.fpb - 1) / (size_t)a.fpb;
+    const size_t blocks = groups << (a.L - a.U);
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = pass_lds_bytes(a, word_bytes);
+    if (word_bytes == 4) {
+        static bool attr32 = false;
+        if (!attr32) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass<int32_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr32 = true;
+        }
+        hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(PASS_THREADS), lds, stream, a, in,
+                           out, tw, nframes);
+    } else {
+        static bool attr64 = false;
+        if (!attr64) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass<int64_t>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(PASS_THREADS), lds, stream, a, in,
+                           out, tw, nframes);
+    }
+    return hipGetLastError();
+}
+
+// ---- twiddle generation ---------------------------------------------------------------------
+// k_twiddle_stage: the stream rom_twiddle_int emits for cnt = 0 .. 2^stage-1.
+//   d_rom: the 512-entry quarter-wave ROM (DEPTH = 9) of integer (cos, -sin) at width twd; the
+//   smaller ROMs of STAGE < 11 are exact sub-samplings of it (phi = ii*pi/2^(DEPTH+1),
+//   rom_twiddle_int.vhd:149).  The double-precision cos/sin seeds are computed on the host
+//   (intfft_plan.hip) like the RTL's elaboration-time constants; everything integer happens here.
+__global__ void k_twiddle_stage(const int2 *__restrict__ rom, int stage, int twd, int xs,
+                                long long mathpi, int2 *__restrict__ out)
+{
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << stage)) return;
+    if (stage == 0) {
+        out[0] = rom[0];
+        return;
+    }
+    const unsigned div = k >> (stage - 1);                  // cnt(STAGE-1)      rom_twiddle_int.vhd:189
+    const unsigned addr = k & ((1u << (stage - 1)) - 1u);   // cnt(STAGE-2..0)   :188
+    int2 e;
+    unsigned cnt = 0;
+    if (stage < 11) {
+        e = rom[addr << (10 - stage)];                      // xSTD :205-212
+    } else {
+        e = rom[addr >> (stage - 10)];                      // addrx :221
+        cnt = addr & ((1u << (stage - 10)) - 1u);           // count :225
+    }
+    if (div) { // second quadrant (re, im) <- (im, -re)  :177-183
+        const int re = e.y, im = wrapw<int32_t>(-e.x, twd);
+        e.x = re;
+        e.y = im;
+    }
+    if (stage >= 11) { // row_twiddle_tay.vhd:123-268
+        // xs = XSHIFT (find_widthA :123-133), mathpi = MATHPI (const_pi :135-149): host constants
+        const long long mpi = (mathpi * (long long)cnt) & 0xFFFF; // :208-221
+        const long long mpx = mpi >> 1;                            // :247
+        long long p_re = (long long)e.x * (1ll << xs) + (long long)e.y * mpx; // MULT_SUB: C + A*B
+        long long p_im = (long long)e.y * (1ll << xs) - (long long)e.x * mpx; // MULT_ADD: C - A*B
+        p_re = wrapw<int64_t>(p_re, 48);
+        p_im = wrapw<int64_t>(p_im, 48);
+        const long long r = (p_re >> (xs - 1)), i = (p_im >> (xs - 1));
+        e.x = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)((r >> 1) + (r & 1)), twd); // pr_rnd :176-199
+        e.y = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)((i >> 1) + (i & 1)), twd);
+    }
+    out[k] = e;
+}
+
+hipError_t launch_twiddle_stage(const int2 *d_rom, int stage, int twd, int xser, int2 *d_out,
+                                hipStream_t stream)
+{
+    const unsigned n = 1u << stage;
+    const unsigned threads = 256;
+    const int xs = xser ? 21 : 23;
+    long long mathpi = 0;
+    if (stage >= 11) // INTEGER(MATH_PI * 2.0**(13-ii-del_val)), del_val = 2 (NEW) / 0 (OLD)
+        mathpi = llround(M_PI * ldexp(1.0, 13 - (stage - 11) - (xser ? 2 : 0)));
+    hipLaunchKernelGGL(k_twiddle_stage, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, d_rom,
+                       stage, twd, xs, mathpi, d_out);
+    return hipGetLastError();
+}
+
+} // namespace intfft

@@ -1,0 +1,66 @@
+// intfft_internal.hpp -- host<->kernel contracts inside libintfft.so (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "intfft_device.hpp"
+
+namespace intfft {
+
+constexpr int MAX_STAGES_PER_PASS = 40;
+constexpr int PASS_THREADS = 256;
+
+// Where a pass reads from / writes to.
+enum IoMode : int {
+    IO_SCRATCH = 0, // plan-owned scratch: words of the compute type at the core (in-place) index
+    IO_USER = 1,    // ABI buffer: int16/32/64 containers in one of the INTFFT_ORDER_* layouts
+};
+
+// One kernel launch of the generic LDS pass kernel: a tile of 2^U points per frame is loaded into
+// LDS, `nstages` radix-2 stages are evaluated in place, and the tile is stored.
+//
+// The core index j (0 <= j < 2^L) is the flat in-place index of SURVEY.md section 9.1: a DIF stage with
+// STAGE = s pairs j and j + 2^s and uses twiddle j mod 2^s; after all DIF stages position j holds
+// X[bitrev(j)]; the DIT stages run the mirror.  A tile owns U of the L index bits, given as two
+// runs: tile-local bits [0, len0) sit at index bits [pos0, pos0+len0) and local bits [len0, U) at
+// [pos1, pos1+len1); the block id supplies the remaining L-U bits in ascending order.
+struct PassArgs {
+    int L;        // log2 of the transform length
+    int U;        // log2 of the tile length
+    int len0, pos0, len1, pos1;
+    int fpb;      // frames per block (power of two; > 1 only when U == L)
+    int nstages;
+    int in_mode, out_mode;   // IoMode
+    int in_cb, out_cb;       // container bytes per component (user mode)
+    int in_order, out_order; // INTFFT_ORDER_* (user mode)
+    int in_rev, out_rev;     // user mode: logical index = bitrev(core index)  (frequency side)
+    int in_bits;             // user mode: DATA_WIDTH the samples are wrapped to on load
+    int in_zext;             // user mode: zero-extend instead (USE_FLY='0' unscaled)
+    int ld_swap, st_swap;    // iterate the tile with the two runs swapped (coalescing of run1)
+    StageDesc st[MAX_STAGES_PER_PASS];
+};
+
+// generic kernels (intfft_generic.hip)
+hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
+                       size_t nframes, hipStream_t stream);
+size_t pass_lds_bytes(const PassArgs &a, int word_bytes);
+const char *pass_kernel_name(int word_bytes);
+
+hipError_t launch_twiddle_stage(const int2 *d_rom, int stage, int twd, int xser, int2 *d_out,
+                                hipStream_t stream);
+
+// packed int16 wave kernel for N = 1024 (intfft_fast1024.hip)
+struct Fast1024Args {
+    int twd;        // twiddle width (<= 16)
+    int rnd;        // RoundKind (RND_TRUNC / RND_ROUND)
+    int out_bitrev; // 0: NATURAL output, 1: BITREV output
+};
+bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode,
+                        int direction, int use_fly, int in_order, int out_order);
+hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
+                           const unsigned *tw_off, size_t nframes, hipStream_t stream);
+const char *fast1024_kernel_name();
+
+} // namespace intfft

@@ -1,0 +1,473 @@
+// intfft_plan.hip -- host side of libintfft.so: elaboration checks, twiddle tables, pass planning
+// and the C-ABI of include/intfft.h.
+//
+// The plan plays the role of RTL elaboration: it accepts exactly the generic combinations for
+// which int_fftNk / int_ifftNk elaborate (find_delay != 0, src/vhdl/fft/int_dif2_fly.vhd:87-116;
+// regime conditions src/vhdl/math/cmult/int_cmult_dsp48.vhd:182-434) and fixes the per-stage
+// widths DATA_WIDTH + ii*FORMAT (src/vhdl/fft/int_fftNk.vhd:187-207).
+//
+// There is no CPU execution path in this library: without a HIP device every entry point that
+// would compute returns INTFFT_ERR_NO_DEVICE.
+#include "../../include/intfft.h"
+#include "intfft_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace intfft;
+
+struct intfft_plan {
+    intfft_params p;
+    int device = 0;
+    int L = 0;
+    int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
+    int word = 4; // bytes of the on-chip word of the generic kernel
+    int2 *d_tw = nullptr;
+    unsigned *d_tw_off = nullptr;
+    std::vector<int2> h_tw;
+    std::vector<PassArgs> passes;
+    void *d_scratch = nullptr;
+    size_t scratch_frames = 0, scratch_bytes = 0;
+    bool fast1024 = false;
+    Fast1024Args fargs{};
+    char kernel_name[64] = {0};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int container_bytes(int bits) { return bits <= 16 ? 2 : bits <= 32 ? 4 : 8; }
+
+// (pre-shift a, post-shift b) of the multiplier regime for data width w / twiddle width t,
+// or false where the RTL has no generate branch (int_cmult_dsp48.vhd:182-434).
+bool cmult_shifts(int w, int t, int xser, int &a, int &b)
+{
+    const int l18 = xser ? 28 : 26, h18 = xser ? 45 : 43, t18 = xser ? 79 : 77, td = xser ? 28 : 26;
+    if (t < 19) {
+        if (w < l18) { a = 0; b = t - 1; return true; }                         // sngl   :184-225
+        if (w < h18) { a = xser ? t - 4 : t - 6; b = xser ? 3 : 5; return a >= 0; } // dbl18  :228-264
+        if (w < t18) { a = t - 1; b = 0; return true; }                         // trpl18 :267-303
+        return false;
+    }
+    if (t < td) {
+        if (w < 19) { a = 0; b = t - 2; return true; }                          // sngl25 :309-354
+        if (w < 36) { a = t - 14; b = 12; return true; }                        // dbl35  :357-393
+        if (w < 53) { a = t - 2; b = 0; return true; }                          // trpl52 :396-433
+    }
+    return false;
+}
+
+// stage list of one core: FFT stage ii has STAGE = NFFT-ii-1 (int_fftNk.vhd:192), IFFT stage ii has
+// STAGE = ii (int_ifftNk.vhd:189); DTW = DATA_WIDTH + ii*FORMAT; DIF multiplies at DTW+1-SCALE
+// (int_dif2_fly.vhd:351), DIT at DTW (int_dit2_fly.vhd:307).
+int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<StageDesc> &out)
+{
+    const int L = p.log2n;
+    for (int ii = 0; ii < L; ++ii) {
+        StageDesc st{};
+        st.kind = inverse ? KIND_DIT : KIND_DIF;
+        st.s = inverse ? ii : L - ii - 1;
+        st.lb = 0;
+        st.dtw = dw_in + ii * p.format;
+        st.wo = st.dtw + p.format; // DTW - SCALE + 1
+        st.mw = inverse ? st.dtw : st.wo;
+        st.rnd = p.format ? RND_UNSCALED : (p.rndmode ? RND_ROUND : RND_TRUNC);
+        st.sh_a = st.sh_b = 0;
+        if (st.s >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b))
+            return INTFFT_ERR_UNSUPPORTED;
+        st.tw_off = (1u << st.s) - 1u; // tables of stages 0..s-1 precede: sum 2^i = 2^s - 1
+        out.push_back(st);
+    }
+    return INTFFT_OK;
+}
+
+int validate(const intfft_params &p)
+{
+    if (p.log2n < 3 || p.log2n > 20) return INTFFT_ERR_INVALID;
+    if (p.direction < 0 || p.direction > 2) return INTFFT_ERR_INVALID;
+    if (p.in_order < 0 || p.in_order > 3 || p.out_order < 0 || p.out_order > 3) return INTFFT_ERR_INVALID;
+    if ((p.format | 1) != 1 || (p.rndmode | 1) != 1 || (p.xser | 1) != 1 || (p.use_fly | 1) != 1)
+        return INTFFT_ERR_INVALID;
+    if (p.data_width < 2 || p.data_width > 64) return INTFFT_ERR_INVALID;
+    if (p.twdl_width < 4 || p.twdl_width > 32) return INTFFT_ERR_INVALID;
+    // FORMAT=1 with RNDMODE=1 drives wz_re twice: not elaboratable (int_dif2_fly.vhd:339-346)
+    if (p.format == 1 && p.rndmode == 1) return INTFFT_ERR_UNSUPPORTED;
+    const int growth = p.format ? p.log2n : 0;
+    const int out_bits = p.data_width + (p.direction == INTFFT_PAIR ? 2 * growth : growth);
+    if (out_bits > 64) return INTFFT_ERR_UNSUPPORTED;
+    return INTFFT_OK;
+}
+
+// How the user-side index map at one end of the transform relates to the core index j:
+// true when consecutive memory needs passenger (top) bits in a contiguous-low-bits tile.
+bool scatters(int order, bool rev)
+{
+    // memory = order_to_mem(order, rev ? bitrev(j) : j)
+    if (rev) return order == INTFFT_ORDER_NATURAL || order == INTFFT_ORDER_HALVES;
+    return order == INTFFT_ORDER_BITREV || order == INTFFT_ORDER_BITREV_LANES;
+}
+
+struct Shape {
+    int len0, pos0, len1, pos1;
+    std::vector<StageDesc> st;
+};
+
+int local_bit(const Shape &sh, int s)
+{
+    if (s >= sh.pos0 && s < sh.pos0 + sh.len0) return s - sh.pos0;
+    return sh.len0 + (s - sh.pos1);
+}
+
+// Split one core's stages into LDS passes.  `contig_first`: DIT (stages ascend from bit 0);
+// otherwise DIF (stages descend from bit L-1).  `passengers`: the contiguous pass also owns that
+// many top index bits so that the user-side sweep stays coalesced.
+void split_core(int L, int umax, int cmin, const std::vector<StageDesc> &st, bool contig_first,
+                int passengers, std::vector<Shape> &out)
+{
+    std::vector<Shape> shapes;
+    const int rf = std::min(L, umax - passengers); // bits of the contiguous pass
+    const int strided = L - rf;
+    const int per = umax - cmin;
+    const int ns = strided > 0 ? (strided + per - 1) / per : 0;
+    // contiguous pass: index bits [0, rf) (+ passengers at the top)
+    Shape c{};
+    c.len0 = rf;
+    c.pos0 = 0;
+    c.len1 = std::min(passengers, L - rf);
+    c.pos1 = L - c.len1;
+    // strided passes, from the top of the index downwards
+    int hi = L - 1;
+    for (int i = 0; i < ns; ++i) {
+        const int m = (strided - (L - 1 - hi) + (ns - i) - 1) / (ns - i); // spread evenly
+        Shape s{};
+        s.len1 = m;
+        s.pos1 = hi - m + 1;
+        s.len0 = std::min(umax - m, s.pos1);
+        s.pos0 = 0;
+        shapes.push_back(s);
+        hi -= m;
+    }
+    // attach stages
+    auto owns = [](const Shape &sh, int s) {
+        return (s >= sh.pos1 && s < sh.pos1 + sh.len1);
+    };
+    for (const StageDesc &d : st) {
+        if (d.s < rf) c.st.push_back(d);
+        else
+            for (Shape &sh : shapes)
+                if (owns(sh, d.s)) sh.st.push_back(d);
+    }
+    if (contig_first) {
+        out.push_back(c);
+        for (auto it = shapes.rbegin(); it != shapes.rend(); ++it) out.push_back(*it);
+    } else {
+        for (Shape &sh : shapes) out.push_back(sh);
+        out.push_back(c);
+    }
+}
+
+bool same_tile(const Shape &a, const Shape &b)
+{
+    return a.len0 == b.len0 && a.pos0 == b.pos0 && a.len1 == b.len1 && a.pos1 == b.pos1;
+}
+
+int build_passes(intfft_plan &pl)
+{
+    const intfft_params &p = pl.p;
+    const int L = pl.L;
+    const int umax = pl.word == 4 ? 13 : 12; // 64 KiB tiles
+    const int cmin = pl.word == 4 ? 5 : 4;   // >= 256 B contiguous per strided row
+
+    std::vector<StageDesc> fwd, inv;
+    int rc = INTFFT_OK;
+    if (p.direction == INTFFT_FWD || p.direction == INTFFT_PAIR)
+        if ((rc = core_stages(p, p.data_width, false, fwd)) != INTFFT_OK) return rc;
+    if (p.direction == INTFFT_INV)
+        if ((rc = core_stages(p, p.data_width, true, inv)) != INTFFT_OK) return rc;
+    if (p.direction == INTFFT_PAIR)
+        if ((rc = core_stages(p, p.data_width + p.format * L, true, inv)) != INTFFT_OK) return rc;
+
+    // user-side maps: FWD out and INV in are on the frequency side (logical = bitrev(core index))
+    const bool in_rev = p.direction == INTFFT_INV;
+    const bool out_rev = p.direction == INTFFT_FWD;
+
+    std::vector<Shape> shapes;
+    if (L <= umax) {
+        Shape s{};
+        s.len0 = L;
+        s.st = fwd;
+        s.st.insert(s.st.end(), inv.begin(), inv.end());
+        shapes.push_back(s);
+    } else {
+        if (!fwd.empty()) {
+            const int pass = (p.direction == INTFFT_FWD && scatters(p.out_order, out_rev)) ? 4 : 0;
+            split_core(L, umax, cmin, fwd, false, pass, shapes);
+        }
+        if (!inv.empty()) {
+            const int pass = (p.direction == INTFFT_INV && scatters(p.in_order, in_rev)) ? 4 : 0;
+            std::vector<Shape> is;
+            split_core(L, umax, cmin, inv, true, pass, is);
+            size_t first = 0;
+            if (!shapes.empty() && same_tile(shapes.back(), is[0])) { // fuse DIF tail with DIT head
+                shapes.back().st.insert(shapes.back().st.end(), is[0].st.begin(), is[0].st.end());
+                first = 1;
+            }
+            for (size_t i = first; i < is.size(); ++i) shapes.push_back(is[i]);
+        }
+    }
+
+    for (size_t i = 0; i < shapes.size(); ++i) {
+        Shape &sh = shapes[i];
+        if ((int)sh.st.size() > MAX_STAGES_PER_PASS) return INTFFT_ERR_UNSUPPORTED;
+        PassArgs a{};
+        a.L = L;
+        a.len0 = sh.len0;
+        a.pos0 = sh.pos0;
+        a.len1 = sh.len1;
+        a.pos1 = sh.len1 ? sh.pos1 : L;
+        a.U = sh.len0 + sh.len1;
+        a.fpb = (a.U == L && L < 11) ? (1 << (11 - L)) : 1;
+        a.in_mode = i == 0 ? IO_USER : IO_SCRATCH;
+        a.out_mode = i + 1 == shapes.size() ? IO_USER : IO_SCRATCH;
+        a.in_cb = pl.in_cb;
+        a.out_cb = pl.out_cb;
+        a.in_order = p.in_order;
+        a.out_order = p.out_order;
+        a.in_rev = in_rev;
+        a.out_rev = out_rev;
+        a.in_bits = p.data_width;
+        a.in_zext = (!p.use_fly && p.format) ? 1 : 0;
+        a.ld_swap = (a.in_mode == IO_USER && sh.len1 && scatters(p.in_order, in_rev)) ? 1 : 0;
+        a.st_swap = (a.out_mode == IO_USER && sh.len1 && scatters(p.out_order, out_rev)) ? 1 : 0;
+        a.nstages = 0;
+        if (p.use_fly) {
+            for (StageDesc d : sh.st) {
+                d.lb = local_bit(sh, d.s);
+                a.st[a.nstages++] = d;
+            }
+        }
+        pl.passes.push_back(a);
+    }
+    return INTFFT_OK;
+}
+
+int build_twiddles(intfft_plan &pl, hipStream_t stream)
+{
+    const int L = pl.L, t = pl.p.twdl_width;
+    const size_t total = ((size_t)1 << L) - 1;
+    // quarter-wave ROM seeds, DEPTH = 9: rom_twiddle_int.vhd:135-159
+    std::vector<int2> rom(512);
+    const double mg = (t < 18) ? std::ldexp(1.0, t - 1) - 1.0 : std::ldexp(1.0, t - 2) - 1.0;
+    for (int ii = 0; ii < 512; ++ii) {
+        const double phi = ((double)ii * M_PI) / 1024.0;
+        rom[ii].x = (int)std::llround(mg * std::cos(phi));
+        rom[ii].y = (int)std::llround(mg * std::sin(-phi));
+    }
+    int2 *d_rom = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&d_rom, rom.size() * sizeof(int2))) != hipSuccess) return (int)e;
+    if ((e = hipMalloc((void **)&pl.d_tw, (total + 1) * sizeof(int2))) != hipSuccess) {
+        (void)hipFree(d_rom);
+        return (int)e;
+    }
+    e = hipMemcpyAsync(d_rom, rom.data(), rom.size() * sizeof(int2), hipMemcpyHostToDevice, stream);
+    for (int s = 0; s < L && e == hipSuccess; ++s)
+        e = launch_twiddle_stage(d_rom, s, t, pl.p.xser, pl.d_tw + ((1u << s) - 1u), stream);
+    pl.h_tw.resize(total);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(pl.h_tw.data(), pl.d_tw, total * sizeof(int2), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_rom);
+    if (e != hipSuccess) return (int)e;
+    std::vector<unsigned> off(20);
+    for (int s = 0; s < 20; ++s) off[s] = (1u << s) - 1u;
+    if ((e = hipMalloc((void **)&pl.d_tw_off, off.size() * sizeof(unsigned))) != hipSuccess) return (int)e;
+    e = hipMemcpy(pl.d_tw_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    return (int)e;
+}
+
+} // namespace
+
+extern "C" {
+
+int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *in_cb, int *out_cb)
+{
+    if (!p) return INTFFT_ERR_NULL;
+    const int rc = validate(*p);
+    if (rc != INTFFT_OK) return rc;
+    const int growth = p->format ? p->log2n : 0;
+    const int ob = p->data_width + (p->direction == INTFFT_PAIR ? 2 * growth : growth);
+    if (in_bits) *in_bits = p->data_width;
+    if (out_bits) *out_bits = ob;
+    if (in_cb) *in_cb = container_bytes(p->data_width);
+    if (out_cb) *out_cb = container_bytes(ob);
+    return INTFFT_OK;
+}
+
+int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device)
+{
+    if (!out || !p) return INTFFT_ERR_NULL;
+    *out = nullptr;
+    int rc = validate(*p);
+    if (rc != INTFFT_OK) return rc;
+    // elaboration check of every stage before touching the device
+    {
+        std::vector<StageDesc> tmp;
+        if (p->direction == INTFFT_FWD || p->direction == INTFFT_PAIR)
+            if ((rc = core_stages(*p, p->data_width, false, tmp)) != INTFFT_OK) return rc;
+        if (p->direction == INTFFT_INV)
+            if ((rc = core_stages(*p, p->data_width, true, tmp)) != INTFFT_OK) return rc;
+        if (p->direction == INTFFT_PAIR)
+            if ((rc = core_stages(*p, p->data_width + p->format * p->log2n, true, tmp)) != INTFFT_OK) return rc;
+        const int td = p->xser ? 28 : 26;
+        if (p->twdl_width >= td) return INTFFT_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
+        return INTFFT_ERR_NO_DEVICE;
+    DeviceGuard guard(hip_device);
+    if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
+
+    intfft_plan *pl = new (std::nothrow) intfft_plan();
+    if (!pl) return INTFFT_ERR_ALLOC;
+    pl->p = *p;
+    pl->device = hip_device;
+    pl->L = p->log2n;
+    intfft_io_widths(p, &pl->in_bits, &pl->out_bits, &pl->in_cb, &pl->out_cb);
+    pl->word = pl->out_bits <= 32 ? 4 : 8;
+
+    if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK) {
+        intfft_plan_destroy(pl);
+        return rc;
+    }
+    pl->fast1024 = fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
+                                      p->direction, p->use_fly, p->in_order, p->out_order);
+    if (pl->fast1024) {
+        pl->fargs.twd = p->twdl_width;
+        pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
+        pl->fargs.out_bitrev = p->out_order == INTFFT_ORDER_BITREV;
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024_kernel_name());
+    } else {
+        if ((rc = build_passes(*pl)) != INTFFT_OK) {
+            intfft_plan_destroy(pl);
+            return rc;
+        }
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
+        if (pl->passes.size() > 1) {
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->word;
+            pl->scratch_frames = std::max<size_t>(1, ((size_t)128 << 20) / frame_bytes);
+            pl->scratch_bytes = pl->scratch_frames * frame_bytes;
+            const hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
+            if (e != hipSuccess) {
+                intfft_plan_destroy(pl);
+                return (int)e;
+            }
+        }
+    }
+    *out = pl;
+    return INTFFT_OK;
+}
+
+int intfft_plan_destroy(intfft_plan *plan)
+{
+    if (!plan) return INTFFT_ERR_NULL;
+    {
+        DeviceGuard guard(plan->device);
+        if (plan->d_tw) (void)hipFree(plan->d_tw);
+        if (plan->d_tw_off) (void)hipFree(plan->d_tw_off);
+        if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+    }
+    delete plan;
+    return INTFFT_OK;
+}
+
+int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
+{
+    if (!plan || !info) return INTFFT_ERR_NULL;
+    std::memset(info, 0, sizeof(*info));
+    info->in_bits = plan->in_bits;
+    info->out_bits = plan->out_bits;
+    info->in_container = plan->in_cb;
+    info->out_container = plan->out_cb;
+    info->n_passes = plan->fast1024 ? 1 : (int)plan->passes.size();
+    info->compute_word = plan->fast1024 ? 2 : plan->word;
+    info->fast_path = plan->fast1024 ? 1 : 0;
+    info->scratch_bytes = plan->scratch_bytes;
+    std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
+    return INTFFT_OK;
+}
+
+int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream)
+{
+    if (!plan || (batch && (!d_in || !d_out))) return INTFFT_ERR_NULL;
+    if (batch == 0) return INTFFT_OK;
+    DeviceGuard guard(plan->device);
+    if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->fast1024)
+        return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->d_tw_off, batch, stream);
+
+    const size_t N = (size_t)1 << plan->L;
+    const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
+    const size_t np = plan->passes.size();
+    const size_t chunk = np > 1 ? plan->scratch_frames : batch;
+    for (size_t f = 0; f < batch; f += chunk) {
+        const size_t nf = std::min(chunk, batch - f);
+        const void *src = static_cast<const char *>(d_in) + f * in_frame;
+        void *dst = static_cast<char *>(d_out) + f * out_frame;
+        for (size_t i = 0; i < np; ++i) {
+            const PassArgs &a = plan->passes[i];
+            const void *pin = a.in_mode == IO_USER ? src : plan->d_scratch;
+            void *pout = a.out_mode == IO_USER ? dst : plan->d_scratch;
+            const hipError_t e = launch_pass(a, plan->word, pin, pout, plan->d_tw, nf, stream);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    return INTFFT_OK;
+}
+
+int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count)
+{
+    if (!plan || !count) return INTFFT_ERR_NULL;
+    if (stage < 0 || stage >= plan->L) return INTFFT_ERR_INVALID;
+    const size_t n = (size_t)1 << stage;
+    *count = n;
+    if (h_out) std::memcpy(h_out, plan->h_tw.data() + (n - 1), n * sizeof(int2));
+    return INTFFT_OK;
+}
+
+const char *intfft_strerror(int status)
+{
+    switch (status) {
+    case INTFFT_OK: return "ok";
+    case INTFFT_ERR_INVALID: return "invalid parameter";
+    case INTFFT_ERR_UNSUPPORTED: return "generic combination does not elaborate in the reference RTL";
+    case INTFFT_ERR_NULL: return "null argument";
+    case INTFFT_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case INTFFT_ERR_ALLOC: return "host allocation failed";
+    default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}
+
+const char *intfft_version(void) { return "intfft-mi355x 0.1 (gfx950)"; }
+
+} // extern "C"

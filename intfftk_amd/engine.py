@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's entity interface, on top of the C-ABI (libintfft.so).
+
+The reference has no software API; its public interface is the generic/port list of four VHDL
+entities.  Each gets a constructor here with the generics under their RTL names:
+
+    int_fftNk            src/vhdl/fft/int_fftNk.vhd:72-103          HALVES in  -> BITREV out
+    int_ifftNk           src/vhdl/fft/int_ifftNk.vhd:71-102         BITREV in  -> HALVES out
+    int_fft_single_path  src/vhdl/main/int_fft_single_path.vhd:85-113   NATURAL -> NATURAL
+    int_fft_ifft_pair    src/vhdl/main/int_fft_ifft_pair.vhd:74-107     NATURAL -> NATURAL, FFT then IFFT
+
+A core is called with a device tensor [batch, N, 2] (re, im) in the container dtype of its input
+width and returns a new tensor in the container dtype of its output width.  Torch is used for device
+memory and streams only; all arithmetic happens in the HIP kernels behind intfft_exec.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _capi as capi
+
+_MODES = {"UNSCALED": (1, 0), "TRUNCATE": (0, 0), "ROUNDING": (0, 1)}  # fft_signle_test.vhd:80-112
+_NP_DT = {2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _torch_dtype(nbytes: int):
+    torch = _torch()
+    return {2: torch.int16, 4: torch.int32, 8: torch.int64}[nbytes]
+
+
+def set_mode(mode: str):
+    """tb helper set_mode(): "UNSCALED" | "ROUNDING" | "TRUNCATE" -> (FORMAT, RNDMODE)."""
+    try:
+        return _MODES[mode.upper()]
+    except KeyError:
+        raise ValueError("MODE must be UNSCALED, ROUNDING or TRUNCATE") from None
+
+
+class IntFFTCore:
+    """One elaborated core (an `intfft_plan`).  Immutable; call it on batches of frames."""
+
+    def __init__(self, NFFT: int, DATA_WIDTH: int = 16, TWDL_WIDTH: int = 16, FORMAT: int = 1,
+                 RNDMODE: int = 0, XSER: str = "NEW", direction: str = "FWD", in_order: str = "NATURAL",
+                 out_order: str = "NATURAL", USE_FLY: int = 1, device: Optional[int] = None,
+                 RAMB_TYPE: str = "WRAP", USE_MLT: bool = False):
+        # RAMB_TYPE (strobe tolerance, int_fftNk.vhd:23-37) and USE_MLT (row_twiddle_tay.vhd:206-240)
+        # do not change values; accepted for interface compatibility.
+        if XSER not in ("NEW", "OLD"):
+            raise ValueError('XSER must be "NEW" or "OLD"')
+        if RAMB_TYPE not in ("WRAP", "CONT"):
+            raise ValueError('RAMB_TYPE must be "WRAP" or "CONT"')
+        self.params = capi.Params(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, 1 if XSER == "NEW" else 0,
+                                  capi.DIRECTIONS[direction], USE_FLY, capi.ORDERS[in_order],
+                                  capi.ORDERS[out_order])
+        self.n = 1 << NFFT
+        L = capi.lib()
+        ib, ob, ic, oc = (ctypes.c_int() for _ in range(4))
+        capi.check(L.intfft_io_widths(ctypes.byref(self.params), ib, ob, ic, oc), "intfft_io_widths")
+        self.in_bits, self.out_bits = ib.value, ob.value
+        self.in_container, self.out_container = ic.value, oc.value
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("intfftk_amd needs a HIP device: there is no CPU execution path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._plan = ctypes.c_void_p()
+        capi.check(L.intfft_plan_create(ctypes.byref(self._plan), ctypes.byref(self.params), self.device),
+                   "intfft_plan_create")
+        info = capi.PlanInfo()
+        capi.check(L.intfft_plan_get_info(self._plan, ctypes.byref(info)), "intfft_plan_get_info")
+        self.info = {k: getattr(info, k) for k, _ in info._fields_ if k not in ("reserved", "kernel_name")}
+        self.info["kernel_name"] = info.kernel_name.decode()
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_plan", None) is not None and self._plan.value:
+            capi.lib().intfft_plan_destroy(self._plan)
+            self._plan = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- execution --------------------------------------------------------------------------
+    @property
+    def in_dtype(self):
+        return _torch_dtype(self.in_container)
+
+    @property
+    def out_dtype(self):
+        return _torch_dtype(self.out_container)
+
+    def __call__(self, x, out=None):
+        torch = _torch()
+        if not (x.is_cuda and x.device.index == self.device):
+            raise ValueError("input must live on cuda:%d" % self.device)
+        if x.dtype != self.in_dtype:
+            raise TypeError("input dtype must be %s for DATA_WIDTH=%d" % (self.in_dtype, self.in_bits))
+        if x.dim() != 3 or x.shape[1] != self.n or x.shape[2] != 2:
+            raise ValueError("input must be [batch, %d, 2]" % self.n)
+        x = x.contiguous()
+        batch = x.shape[0]
+        if out is None:
+            out = torch.empty((batch, self.n, 2), dtype=self.out_dtype, device=x.device)
+        elif out.dtype != self.out_dtype or tuple(out.shape) != (batch, self.n, 2) or not out.is_contiguous():
+            raise ValueError("bad `out` tensor")
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        capi.check(capi.lib().intfft_exec(self._plan, x.data_ptr(), out.data_ptr(), batch, stream),
+                   "intfft_exec")
+        return out
+
+    def exec_raw(self, in_ptr: int, out_ptr: int, batch: int, stream: int = 0):
+        """Straight intfft_exec on raw device pointers (bench loop: no tensor bookkeeping)."""
+        capi.check(capi.lib().intfft_exec(self._plan, in_ptr, out_ptr, batch, stream), "intfft_exec")
+
+    def twiddles(self, stage: int) -> np.ndarray:
+        """[2^stage, 2] int32 (re, im): what rom_twiddle_int emits for cnt = 0..2^stage-1."""
+        cnt = ctypes.c_size_t()
+        L = capi.lib()
+        capi.check(L.intfft_twiddles(self._plan, stage, None, ctypes.byref(cnt)), "intfft_twiddles")
+        out = np.empty((cnt.value, 2), dtype=np.int32)
+        capi.check(L.intfft_twiddles(self._plan, stage, out.ctypes.data, ctypes.byref(cnt)), "intfft_twiddles")
+        return out
+
+
+def int_fftNk(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0, XSER="NEW", USE_FLY=1,
+              RAMB_TYPE="WRAP", USE_MLT=False, device=None) -> IntFFTCore:
+    """Forward DIF core with its native stream orders (int_fftNk.vhd:15-21)."""
+    return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSER, "FWD", "HALVES", "BITREV",
+                      USE_FLY, device, RAMB_TYPE, USE_MLT)
+
+
+def int_ifftNk(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0, XSER="NEW", USE_FLY=1,
+               RAMB_TYPE="WRAP", USE_MLT=False, device=None) -> IntFFTCore:
+    """Inverse DIT core with its native stream orders (int_ifftNk.vhd:15-21)."""
+    return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSER, "INV", "BITREV", "HALVES",
+                      USE_FLY, device, RAMB_TYPE, USE_MLT)
+
+
+def int_fft_single_path(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0, XSERIES="NEW",
+                        USE_FLY=1, RAMB_TYPE="CONT", USE_MLT=False, device=None) -> IntFFTCore:
+    """inbuf_half_path -> int_fftNk -> outbuf_half_path -> int_bitrev_order: natural in, natural out
+    (int_fft_single_path.vhd:157-268)."""
+    return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSERIES, "FWD", "NATURAL", "NATURAL",
+                      USE_FLY, device, RAMB_TYPE, USE_MLT)
+
+
+def int_fft_ifft_pair(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0, XSERIES="NEW",
+                      USE_FLY=1, RAMB_TYPE="WRAP", USE_MLT=False, device=None) -> IntFFTCore:
+    """iobuf -> int_fftNk -> int_ifftNk -> iobuf (int_fft_ifft_pair.vhd:161-330); outputs the correct
+    (re, im) per lane, not the reference's mis-wired Q0_IM/Q1_RE (:332-335)."""
+    return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSERIES, "PAIR", "NATURAL", "NATURAL",
+                      USE_FLY, device, RAMB_TYPE, USE_MLT)

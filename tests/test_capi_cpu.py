@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: libintfft.so loads, exports every symbol include/intfft.h
+declares, validates generics like RTL elaboration, and refuses to compute without a HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from intfftk_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "intfft.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(intfft_[a-z_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    declared = _declared_symbols()
+    assert set(declared) == set(capi.SYMBOLS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+
+
+def test_no_oracle_in_product():
+    """The product must not route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "intfftk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle_c" not in src and "oracle_py" not in src and "intfft_oracle" not in src, f
+    # and the shared object does not link the oracle
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def _p(**kw):
+    d = dict(log2n=10, data_width=16, twdl_width=16, format=0, rndmode=0, xser=1, direction=0, use_fly=1,
+             in_order=0, out_order=0)
+    d.update(kw)
+    return capi.Params(*[d[k] for k, _ in capi.Params._fields_])
+
+
+@pytest.mark.parametrize("kw,bits,cont", [
+    (dict(), (16, 16), (2, 2)),
+    (dict(format=1), (16, 26), (2, 4)),
+    (dict(format=1, direction=2), (16, 36), (2, 8)),
+    (dict(log2n=16, data_width=24, twdl_width=24, format=1), (24, 40), (4, 8)),
+    (dict(log2n=20), (16, 16), (2, 2)),
+])
+def test_io_widths(kw, bits, cont):
+    a, b, c, d = (ctypes.c_int() for _ in range(4))
+    p = _p(**kw)
+    assert capi.lib().intfft_io_widths(ctypes.byref(p), a, b, c, d) == capi.OK
+    assert (a.value, b.value) == bits and (c.value, d.value) == cont
+
+
+@pytest.mark.parametrize("kw,code", [
+    (dict(log2n=2), capi.ERR_INVALID),
+    (dict(log2n=21), capi.ERR_INVALID),
+    (dict(direction=3), capi.ERR_INVALID),
+    (dict(in_order=4), capi.ERR_INVALID),
+    (dict(format=1, rndmode=1), capi.ERR_UNSUPPORTED),          # int_dif2_fly.vhd:339-346
+    (dict(twdl_width=28), capi.ERR_UNSUPPORTED),                # find_delay -> 0
+    (dict(twdl_width=26, xser=0), capi.ERR_UNSUPPORTED),
+    (dict(data_width=60, twdl_width=24), capi.ERR_UNSUPPORTED),  # no cmult regime for w >= 53 at t > 18
+    (dict(log2n=19, data_width=32, format=1, direction=2), capi.ERR_UNSUPPORTED),  # > 64-bit results
+])
+def test_plan_create_rejects_like_elaboration(kw, code):
+    plan = ctypes.c_void_p()
+    p = _p(**kw)
+    assert capi.lib().intfft_plan_create(ctypes.byref(plan), ctypes.byref(p), 0) == code
+    assert not plan.value
+
+
+def test_no_device_means_error_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    plan = ctypes.c_void_p()
+    p = _p()
+    rc = capi.lib().intfft_plan_create(ctypes.byref(plan), ctypes.byref(p), 0)
+    assert rc == capi.ERR_NO_DEVICE and "no CPU fallback" in capi.strerror(rc)
+    from intfftk_amd import IntFFTCore
+
+    with pytest.raises(RuntimeError):
+        IntFFTCore(10, 16, 16, 0, 0)
+
+
+def test_null_arguments():
+    L = capi.lib()
+    assert L.intfft_plan_create(None, None, 0) == capi.ERR_NULL
+    assert L.intfft_plan_destroy(None) == capi.ERR_NULL
+    assert L.intfft_exec(None, None, None, 1, None) == capi.ERR_NULL

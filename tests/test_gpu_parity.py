@@ -1,0 +1,192 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (libintfft.so), against the CPU
+oracle on the same seeded inputs.  Bit-exact (integer path): np.array_equal, no tolerance."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as C
+from tests.helpers import chirp_frame, edge_frames, uniform_frames
+
+pytestmark = pytest.mark.gpu
+
+ORD = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
+DIR = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}
+
+
+def run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction="FWD", in_order="NATURAL", out_order="NATURAL",
+            use_fly=1):
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW" if new else "OLD", direction, in_order, out_order, use_fly)
+    xin = torch.from_numpy(np.ascontiguousarray(x.astype({2: np.int16, 4: np.int32, 8: np.int64}[core.in_container])))
+    y = core(xin.cuda())
+    torch.cuda.synchronize()
+    info = core.info
+    core.close()
+    return y.cpu().numpy().astype(np.int64), info
+
+
+def run_ref(x, log2n, dw, tw, fmt, rnd, new, direction="FWD", in_order="NATURAL", out_order="NATURAL",
+            use_fly=1):
+    p = C.make_params(log2n, dw, tw, fmt, rnd, new, use_fly)
+    return C.execute(x, p, DIR[direction], ORD[in_order], ORD[out_order], form=1)
+
+
+def check(x, *cfg, **kw):
+    got, info = run_gpu(x, *cfg, **kw)
+    want = run_ref(x, *cfg, **kw)
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("GPU != oracle for %r %r: %d mismatches, first at %r: got %r want %r"
+                             % (cfg, kw, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
+    return info
+
+
+# (log2n, dw, tw, fmt, rnd, new): every multiplier regime, every rounding mode, both XSER
+CONFIGS = [
+    (3, 16, 16, 0, 0, True), (4, 16, 16, 0, 1, True), (5, 16, 16, 1, 0, True), (6, 16, 16, 0, 0, False),
+    (5, 12, 10, 0, 0, True), (5, 16, 18, 0, 0, True), (5, 16, 17, 1, 0, True), (5, 24, 24, 1, 0, True),
+    (4, 14, 24, 1, 0, True), (6, 32, 24, 1, 0, True), (6, 32, 24, 1, 0, False), (5, 27, 16, 1, 0, True),
+    (5, 25, 16, 1, 0, False), (5, 30, 16, 0, 1, True), (5, 44, 16, 1, 0, True), (4, 42, 16, 1, 0, False),
+    (5, 8, 8, 0, 0, True), (7, 32, 16, 0, 0, True), (7, 32, 16, 0, 1, True), (8, 40, 24, 0, 0, True),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_every_regime_and_mode(cfg, direction):
+    log2n, dw, tw, fmt, rnd, new = cfg
+    p = C.make_params(log2n, dw, tw, fmt, rnd, new)
+    if C.lib().orc_validate(p, DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(37, n, dw, 77 + log2n), edge_frames(n, dw)])
+    check(x, *cfg, direction=direction)
+
+
+@pytest.mark.parametrize("in_order", list(ORD))
+@pytest.mark.parametrize("out_order", list(ORD))
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_io_orders(in_order, out_order, direction):
+    x = uniform_frames(5, 256, 16, 11)
+    check(x, 8, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
+
+
+@pytest.mark.parametrize("log2n", list(range(3, 14)))
+@pytest.mark.parametrize("mode", [(0, 0), (0, 1), (1, 0)])
+def test_all_single_pass_lengths(log2n, mode):
+    fmt, rnd = mode
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(9, n, 16, log2n), edge_frames(n, 16)])
+    for direction in ("FWD", "INV", "PAIR"):
+        check(x, log2n, 16, 16, fmt, rnd, True, direction=direction)
+
+
+@pytest.mark.parametrize("log2n,dw,tw,fmt", [(14, 16, 16, 0), (15, 16, 16, 1), (16, 24, 24, 1), (16, 24, 16, 1),
+                                              (13, 24, 24, 1), (17, 16, 16, 0)])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_multi_pass_lengths(log2n, dw, tw, fmt, direction):
+    """N beyond one LDS tile: strided + contiguous passes through plan scratch; Taylor twiddles."""
+    n = 1 << log2n
+    x = uniform_frames(3, n, dw, 1000 + log2n)
+    for in_o, out_o in [("NATURAL", "NATURAL"), ("HALVES", "BITREV")]:
+        info = check(x, log2n, dw, tw, fmt, 0, True, direction=direction, in_order=in_o, out_order=out_o)
+        assert info["n_passes"] >= 2
+
+
+def test_config4_n_2pow20_taylor_extension():
+    """BASELINE config 4 shape at a reduced batch: N = 2^20, 16-bit scaled, Taylor ii = 8 extension."""
+    x = uniform_frames(2, 1 << 20, 15, 0xC0FFEE04)
+    check(x, 20, 16, 16, 0, 0, True, direction="FWD")
+    check(x[:1], 20, 16, 16, 0, 0, True, direction="FWD", out_order="BITREV")
+
+
+def test_config3_shape_reduced_batch():
+    """BASELINE config 3: N = 65536, 24-bit unscaled (40-bit results in int64), both twiddle widths."""
+    x = np.concatenate([uniform_frames(3, 1 << 16, 23, 0xC0FFEE03), edge_frames(1 << 16, 24)[[1, 4, 5]]])
+    check(x, 16, 24, 24, 1, 0, True)
+    check(x[:2], 16, 24, 16, 1, 0, True)
+
+
+def test_config5_pair_4096():
+    x = np.concatenate([uniform_frames(29, 4096, 15, 0xC0FFEE05), edge_frames(4096, 16)])
+    check(x, 12, 16, 16, 0, 0, True, direction="PAIR")
+
+
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("out_order", ["NATURAL", "BITREV"])
+def test_config2_headline_shape(rnd, out_order):
+    """BASELINE config 2 at a reduced batch incl. the 8 edge frames: N = 1024, 16/16 scaled DIF."""
+    x = np.concatenate([edge_frames(1024, 16), uniform_frames(4096 - 8, 1024, 15, 0xC0FFEE02)])
+    check(x, 10, 16, 16, 0, rnd, True, out_order=out_order)
+
+
+def test_config1_chirp_frame():
+    x = (chirp_frame(1024) * 64)[None]
+    check(x, 10, 16, 16, 0, 0, True)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+def test_use_fly_zero(fmt):
+    x = uniform_frames(3, 512, 16, 5)
+    for direction in ("FWD", "INV", "PAIR"):
+        check(x, 9, 16, 16, fmt, 0, True, direction=direction, use_fly=0, out_order="BITREV")
+
+
+@pytest.mark.parametrize("tw,new", [(16, True), (16, False), (24, True), (24, False), (18, True), (10, True)])
+def test_twiddle_tables_all_stages(tw, new):
+    """k_twiddle_stage (ROM + Taylor) against the oracle for every STAGE 0..19."""
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(20, 16, tw, 0, 0, "NEW" if new else "OLD", "FWD")
+    for s in range(20):
+        got = core.twiddles(s)
+        re, im = C.twiddles(s, tw, new)
+        assert np.array_equal(got[:, 0], re) and np.array_equal(got[:, 1], im), (s, tw, new)
+    core.close()
+
+
+def test_batch_index_independence_and_ragged_batches():
+    """Frames are independent units: any batch split gives the same rows (incl. batch = 1 and
+    batches that do not fill the last block)."""
+    import torch
+
+    from intfftk_amd import int_fft_single_path
+
+    core = int_fft_single_path(7, 16, 16, 0, 0)
+    x = torch.from_numpy(uniform_frames(37, 128, 16, 3).astype(np.int16)).cuda()
+    full = core(x).cpu().numpy()
+    for cut in (1, 5, 16, 36):
+        a = core(x[:cut].contiguous()).cpu().numpy()
+        b = core(x[cut:].contiguous()).cpu().numpy()
+        assert np.array_equal(np.concatenate([a, b]), full)
+    empty = core(x[:0].contiguous())
+    assert empty.shape[0] == 0
+    core.close()
+
+
+def test_errors_mirror_elaboration_failures():
+    from intfftk_amd import ERR_INVALID, ERR_UNSUPPORTED, IntFFTCore, IntFFTError
+
+    for kw, code in [(dict(NFFT=10, FORMAT=1, RNDMODE=1), ERR_UNSUPPORTED),
+                     (dict(NFFT=10, TWDL_WIDTH=28), ERR_UNSUPPORTED),
+                     (dict(NFFT=10, DATA_WIDTH=60, TWDL_WIDTH=24, FORMAT=0), ERR_UNSUPPORTED),
+                     (dict(NFFT=2), ERR_INVALID), (dict(NFFT=21), ERR_INVALID)]:
+        with pytest.raises(IntFFTError) as ei:
+            IntFFTCore(**kw)
+        assert ei.value.status == code
+
+
+def test_in_place_exec():
+    import torch
+
+    from intfftk_amd import int_fft_single_path
+
+    core = int_fft_single_path(10, 16, 16, 0, 0)
+    x = torch.from_numpy(uniform_frames(64, 1024, 15, 9).astype(np.int16)).cuda()
+    want = core(x).clone()
+    got = core(x, out=x)
+    assert torch.equal(got, want)
+    core.close()
