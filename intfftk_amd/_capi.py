@@ -50,6 +50,12 @@ def lib():
             raise RuntimeError(
                 "intfftk_amd: %s is missing -- build it with `python -m intfftk_amd.build` "
                 "(there is no CPU fallback)" % LIB_PATH)
+        # libintfft.so must share ONE HIP runtime with torch (device pointers and streams cross the
+        # boundary): load torch's bundled libamdhip64 first so the library binds to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         pp = ctypes.POINTER(Params)
         ip = ctypes.POINTER(ctypes.c_int)

@@ -59,8 +59,9 @@ struct Fast1024Args {
 };
 bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode,
                         int direction, int use_fly, int in_order, int out_order);
+// tw_all: device twiddle buffer (stage s at offset 2^s - 1); h_tw: the host copy of the same
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
-                           const unsigned *tw_off, size_t nframes, hipStream_t stream);
+                           const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *fast1024_kernel_name();
 
 } // namespace intfft

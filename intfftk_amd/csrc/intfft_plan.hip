@@ -27,7 +27,6 @@ struct intfft_plan {
     int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
     int word = 4; // bytes of the on-chip word of the generic kernel
     int2 *d_tw = nullptr;
-    unsigned *d_tw_off = nullptr;
     std::vector<int2> h_tw;
     std::vector<PassArgs> passes;
     void *d_scratch = nullptr;
@@ -295,11 +294,6 @@ int build_twiddles(intfft_plan &pl, hipStream_t stream)
         e = hipMemcpyAsync(pl.h_tw.data(), pl.d_tw, total * sizeof(int2), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_rom);
-    if (e != hipSuccess) return (int)e;
-    std::vector<unsigned> off(20);
-    for (int s = 0; s < 20; ++s) off[s] = (1u << s) - 1u;
-    if ((e = hipMalloc((void **)&pl.d_tw_off, off.size() * sizeof(unsigned))) != hipSuccess) return (int)e;
-    e = hipMemcpy(pl.d_tw_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice);
     return (int)e;
 }
 
@@ -391,7 +385,6 @@ int intfft_plan_destroy(intfft_plan *plan)
     {
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
-        if (plan->d_tw_off) (void)hipFree(plan->d_tw_off);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
     }
     delete plan;
@@ -422,7 +415,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (plan->fast1024)
-        return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->d_tw_off, batch, stream);
+        return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
