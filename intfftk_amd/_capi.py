@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libintfft.so")
+LIB_PATH = os.environ.get("INTFFT_LIB") or os.path.join(_HERE, "lib", "libintfft.so")
 
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NULL, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3, -4, -5

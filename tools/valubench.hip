@@ -1,0 +1,73 @@
+// valubench.hip -- per-instruction VALU issue rate on gfx950 (diagnostic tool, not product).
+// Each kernel runs ITER x 64 independent copies of one instruction on 8 register sets per wave.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define ITER 2000
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define DEFK(NAME, ASM)                                                                         \
+    __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned seed)                   \
+    {                                                                                           \
+        unsigned a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11,  \
+                 a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19, b = a0 ^ 0x5a5a, c = a0 + 77;        \
+        for (int i = 0; i < ITER; ++i) {                                                        \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                     \
+                asm volatile(ASM(0) "\n\t" ASM(1) "\n\t" ASM(2) "\n\t" ASM(3) "\n\t" ASM(4) "\n\t" ASM(5) \
+                             "\n\t" ASM(6) "\n\t" ASM(7)                                        \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                             : "v"(b), "v"(c), "s"(seed));                                      \
+            }                                                                                   \
+        }                                                                                       \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;            \
+    }
+#define A_PKADD(n) "v_pk_add_u16 %" #n ", %" #n ", %8"
+#define A_PKSUB(n) "v_pk_sub_i16 %" #n ", %" #n ", %8"
+#define A_PKASHR(n) "v_pk_ashrrev_i16 %" #n ", 1, %" #n " op_sel_hi:[0,1]"
+#define A_DOT2(n) "v_dot2_i32_i16 %" #n ", %" #n ", %8, 0"
+#define A_DOT2C(n) "v_dot2c_i32_i16 %" #n ", %8, %9"
+#define A_BFE(n) "v_bfe_i32 %" #n ", %" #n ", 15, 16"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %10"
+#define A_ADD(n) "v_add_u32 %" #n ", %" #n ", %8"
+#define A_LSHL(n) "v_lshlrev_b32 %" #n ", 1, %" #n
+#define A_AND(n) "v_and_b32 %" #n ", %" #n ", %8"
+#define A_FMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9"
+#define A_MAD24(n) "v_mad_i32_i24 %" #n ", %" #n ", %8, %9"
+#define A_ALIGN(n) "v_alignbit_b32 %" #n ", %" #n ", %8, 16"
+#define A_MOV(n) "v_mov_b32 %" #n ", %8"
+#define A_PKMAD(n) "v_pk_mad_i16 %" #n ", %" #n ", %8, %9"
+#define A_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 16, %8"
+#define A_PKLSHL(n) "v_pk_lshlrev_b16 %" #n ", 1, %" #n " op_sel_hi:[0,1]"
+#define A_ADD16(n) "v_add_u16 %" #n ", %" #n ", %8"
+#define A_PKFMA32(n) "v_add_u32 %" #n ", %" #n ", %8"
+DEFK(k_pkadd, A_PKADD) DEFK(k_pksub, A_PKSUB) DEFK(k_pkashr, A_PKASHR) DEFK(k_dot2, A_DOT2) DEFK(k_dot2c, A_DOT2C)
+DEFK(k_bfe, A_BFE) DEFK(k_perm, A_PERM) DEFK(k_add, A_ADD) DEFK(k_lshl, A_LSHL) DEFK(k_and, A_AND) DEFK(k_fma, A_FMA)
+DEFK(k_mad24, A_MAD24) DEFK(k_align, A_ALIGN) DEFK(k_mov, A_MOV) DEFK(k_pkmad, A_PKMAD) DEFK(k_lshladd, A_LSHLADD)
+DEFK(k_pklshl, A_PKLSHL) DEFK(k_add16, A_ADD16)
+
+template <typename K> void run(const char* name, K k, unsigned* out, int blocks)
+{
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 1u);
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, 2u);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    double insts = (double)blocks * 4 * ITER * 64;            // wave-instructions
+    double per_simd_per_clk = insts / (256.0 * 4) / (ms * 1e-3 * 2.4e9);
+    printf("%-10s %.3f ms  %.2f wave-instr/clk/SIMD @2.4GHz  (%.2f clk per instr)\n", name, ms, per_simd_per_clk, 1.0 / per_simd_per_clk);
+}
+int main(int argc, char** argv)
+{
+    int wps = argc > 1 ? atoi(argv[1]) : 4; // waves per SIMD
+    int blocks = 256 * wps;
+    unsigned* out; (void)hipMalloc(&out, (size_t)blocks * 256 * 4);
+    for (int r = 0; r < 2; ++r) {
+    run("pk_add", k_pkadd, out, blocks); run("pk_sub", k_pksub, out, blocks); run("pk_ashr", k_pkashr, out, blocks);
+    run("dot2", k_dot2, out, blocks); run("dot2c", k_dot2c, out, blocks); run("bfe", k_bfe, out, blocks);
+    run("perm", k_perm, out, blocks); run("add_u32", k_add, out, blocks); run("lshl", k_lshl, out, blocks);
+    run("and", k_and, out, blocks); run("fma_f32", k_fma, out, blocks); run("mad_i24", k_mad24, out, blocks);
+    run("alignbit", k_align, out, blocks); run("mov", k_mov, out, blocks); run("pk_mad16", k_pkmad, out, blocks);
+    run("lshl_add", k_lshladd, out, blocks); run("pk_lshl16", k_pklshl, out, blocks); run("add_u16", k_add16, out, blocks);
+    }
+    return 0;
+}
