@@ -59,10 +59,14 @@ def cpu_baseline(x_dev, y_dev):
     dt = max(time.perf_counter() - t0, 1e-5)
     # aim at ~12 s of CPU work (thread-seconds), bounded by the batch
     frames = int(min(x_dev.shape[0], max(calib, calib * (12.0 / threads) / dt)))
-    xs = x_dev[:frames].cpu().numpy()
+    xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy())
+    ref = np.zeros_like(xs)  # pre-touched: page faults are not part of the baseline
+    import ctypes
     t0 = time.perf_counter()
-    ref = C.execute_i16(xs, p, C.FWD, form=1, threads=threads)
+    rc = C.lib().orc_exec_i16(ctypes.byref(p), C.FWD, C.NATURAL, C.NATURAL, xs.ctypes.data, ref.ctypes.data,
+                              frames, 1, threads)
     dt = time.perf_counter() - t0
+    assert rc == 0
     got = y_dev[:frames].cpu().numpy()
     parity = bool(np.array_equal(got, ref))
     return {"value": frames * N / dt / 1e9, "unit": "Gsample/s", "cores": threads, "kind": "port",
@@ -126,11 +130,9 @@ def main():
     t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([t_local], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_all = float(tt.item())
-    else:
-        t_all = t_local
+    from intfftk_amd.sharding import max_over_ranks
+
+    t_all = max_over_ranks(t_local, torch.device("cuda", local_rank))
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
     if rank == 0:
