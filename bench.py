@@ -41,6 +41,17 @@ def make_input(batch: int, rank: int):
     return x
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/, collected by tools/profile.sh on this same command); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_k_fft1024_pmc_digest.json")
+    try:
+        with open(path) as fh:
+            return float(json.load(fh)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(x_dev, y_dev):
     """Times the oracle (a scalar C port of the RTL arithmetic in the reference model's dataflow,
     OpenMP over frames) on a bounded sample of the same workload, and uses the result as a parity
@@ -158,7 +169,8 @@ def main():
                        "kernel": core.info["kernel_name"], "launches_per_step": launches,
                        "clock_prewarm_steps": args.prewarm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic() if args.batch == 65536 else None,
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * args.batch * N,
                          "kernel_ms": kern_ms},
         }
