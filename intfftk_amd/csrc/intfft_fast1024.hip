@@ -3,15 +3,15 @@
 // natural-order input, NATURAL or BITREV output  (src/vhdl/main/int_fft_single_path.vhd:157-268).
 //
 // One wave64 owns one frame: 16 VGPRs of packed (re | im << 16) int16 per lane, persistent loop
-// over frames.  The ten radix-2 DIF stages (src/vhdl/fft/int_dif2_fly.vhd:144-373) are evaluated
-// literally -- per-stage truncation forbids any algebraic stage fusion -- but the DATAFLOW is
-// regrouped so that every butterfly is lane-local:
+// over frames, no barrier.  The ten radix-2 DIF stages (src/vhdl/fft/int_dif2_fly.vhd:144-373) are
+// evaluated literally -- per-stage truncation forbids any algebraic stage fusion -- but the
+// DATAFLOW is regrouped so that every butterfly is lane-local:
 //
 //   index bit:        9 8 7 6 | 5      | 4      | 3 2 1 0
 //   phase 1 (regs)    j3..j0  | lane5  | lane4  | lane3..0     stages 9,8,7,6 in registers
 //   v_permlane32_swap lane5   | j3     |                       stage 5
 //   v_permlane16_swap         |        | j2                    stage 4
-//   LDS transpose (5 KiB/wave, conflict-free b32 writes, b128 reads): regs = bits 3..0
+//   LDS transpose (5 KiB/wave, b32 writes, conflict-free b128 reads): regs = bits 3..0
 //   phase 3 (regs)                                 r3..r0      stages 3,2 (wave-uniform twiddles
 //                                                              in SGPRs), 1, 0 (multiplier-free)
 //
@@ -20,21 +20,29 @@
 // transpose so that every global store instruction writes 256 contiguous bytes.
 //
 // Arithmetic per general butterfly (SURVEY.md section 9.2, 9.4 "sngl" regime, w = 16):
-//   A1 = A >> 1, B1 = B >> 1            v_pk_ashrrev_i16 x2   (LSB dropped BEFORE the add)
+//   A1 = A >> 1, B1 = B >> 1            v_pk_ashrrev_i16 x<=2 (LSB dropped BEFORE the add)
 //   S = A1 + B1, D = A1 - B1            v_pk_add_u16, v_pk_sub_i16
-//   re = D.re*wr - D.im*wi              v_dot2_i32_i16 with W packed as (wr, -wi)   (exact in int32)
-//   im = D.re*wi + D.im*wr              v_dot2_i32_i16 with W packed as (wi,  wr)
-//   Y  = { im[t+14:t-1], re[t+14:t-1] } 2 x v_bfe_i32 + v_perm_b32   (floor, wrap to 16 bits)
-// In truncate mode the next stage only ever reads Y >> 1, so the multiplier emits
-// { sext(im[t+14:t]), sext(re[t+14:t]) } directly and that stage skips its input shift.
+//   re = D.re*wr - D.im*wi              VOP3P v_dot2_i32_i16, W packed as (wr, -wi)  (exact in int32)
+//   im = D.re*wi + D.im*wr              VOP3P v_dot2_i32_i16, W packed as (wi,  wr)
+//   Y  = { im[t+14:t-1], re[t+14:t-1] } floor + wrap to 16 bits
+// Truncate mode only ever reads Y >> 1 downstream, so the multiplier emits
+//   Y >> 1 = { sext(im[t+14:t]), sext(re[t+14:t]) }  directly (2 x v_bfe_i32 + v_perm_b32),
+// and when a frame's samples all carry one guard bit (|re|, |im| <= 2^14: proven below to exclude
+// any 31-bit overflow of re/im at every stage) and t = 16, Y >> 1 is simply the high halves of
+// re and im: ONE v_perm_b32 ("fast extraction").  Every other frame takes the exact extraction.
 //
-// The multiplies are issued from inline asm (VOP3P v_dot2_i32_i16 with an inline-constant 0
-// accumulator; the builtin lowers to v_dot2c + v_mov 0).  hipcc does not pad hazards inside an asm
-// statement, so each statement interleaves TWO butterflies: every DOT result is read >= 3 and
-// overwritten >= 4 instructions after the DOT that produced it (gfx940-class DOT->VALU hazards).
+// VALU issue is the co-bottleneck of this kernel (tools/valubench.hip: every VOP3/VOP3P op used
+// here issues at ~4.3 cycles per wave-instruction on gfx950), hence the attention to op count.
+//
+// Inline asm: the builtin for v_dot2 lowers to v_dot2c + v_mov 0 (+2 ops per butterfly), so the
+// multiplies are issued from asm.  hipcc pads no hazards inside an asm statement; each statement
+// therefore interleaves 2 (exact) or 4 (fast) butterflies so that every DOT result is read >= 3
+// and overwritten >= 4 instructions after the DOT that produced it (gfx940-class DOT -> VALU
+// hazards), and the asm v_permlane*_swap carry their own s_nop 1.
 #include "intfft_internal.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace intfft {
 
@@ -50,7 +58,29 @@ struct Fast1024Consts {
     u32 wa2[4], wb2[4]; // STAGE 2: table index r & 3
 };
 
-// S, D of one butterfly.  PRE: the inputs already hold A >> 1, B >> 1 (truncate mode only).
+// result slicing of the exact 32-bit sums (t = TWDL_WIDTH)
+struct Slice {
+    int off_y;  // t - 1: Y      = sum[t+14 : t-1]
+    int off_y1; // t    : Y >> 1 = sext(sum[t+14 : t])
+    u32 sel;    // v_perm_b32 selector {S0.b1, S0.b0, S1.b1, S1.b0} (exact extraction)
+    u32 sel_hi; // v_perm_b32 selector {S0.b3, S0.b2, S1.b3, S1.b2} (fast extraction)
+};
+
+// per-lane twiddles of the lane-dependent stages.  Truncate mode keeps only the first half of the
+// stage 9/8/7 tables: the second half is the quarter turn W' = (wi, -wr) of the first
+// (rom_twiddle_int.vhd:177-183), i.e. Wa' = Wb and Wb' = -Wa, evaluated as dot(D, Wb), dot(-D, Wa).
+// (-D is exact there: |D| <= 2^15 - 1.  Round mode can produce D = -2^15, so it keeps full tables.)
+template <bool ROUND> struct Twiddles {
+    static constexpr int NQ = ROUND ? 1 : 2;
+    u32 wa9[8 / NQ], wb9[8 / NQ], wa8[4 / NQ], wb8[4 / NQ], wa7[2 / NQ], wb7[2 / NQ];
+    u32 wa6[1], wb6[1], wa5[1], wb5[1], wa4[1], wb4[1];
+};
+
+__device__ __forceinline__ u32 pack_wa(int2 w) { return ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16); }
+__device__ __forceinline__ u32 pack_wb(int2 w) { return ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16); }
+
+// ---- sum / difference ---------------------------------------------------------------------------
+// PRE: the inputs already hold A >> 1, B >> 1 (truncate mode only).
 template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u32 b, u32 &s, u32 &d)
 {
     const v2s A = as_v2s(a), B = as_v2s(b);
@@ -64,78 +94,134 @@ template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u
         d = as_u32((A >> (short)1) - (B >> (short)1) + ((A & ~B) & one));
     }
 }
+// truncate mode with a per-lane shift amount (0 where the lane's registers already hold X >> 1)
+__device__ __forceinline__ void sumdiff_var(u32 a, u32 b, v2s sh, u32 &s, u32 &d)
+{
+    const v2s A1 = as_v2s(a) >> sh, B1 = as_v2s(b) >> sh;
+    s = as_u32(A1 + B1);
+    d = as_u32(A1 - B1);
+}
 
-// Two complex multiplies cmult_{16,t}(D, W) in the single-DSP regime (int_cmult_dsp48.vhd:184-225).
-// off/WIDTH select the result slice of the exact 32-bit sums: (t-1, 16) = Y, (t, 15) = Y >> 1.
-// Twiddles in VGPRs (lane-dependent stages).
-template <int WIDTH>
-__device__ __forceinline__ void cmul2_v(u32 d0, u32 wa0, u32 wb0, u32 d1, u32 wa1, u32 wb1, int off, u32 sel,
-                                        u32 &y0, u32 &y1)
+// ---- complex multiplies: cmult_{16,t}(D, W), single-DSP regime (int_cmult_dsp48.vhd:184-225) ----
+// dr/di are the data operands of the re / im dot products (equal for a table twiddle; (D, -D) with
+// the base twiddle's (Wb, Wa) for a quarter-turn twiddle).  SG: twiddles in SGPRs.
+#define INTFFT_MUL2X_BODY                                                                              \
+    "v_dot2_i32_i16 %[r0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[r1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_bfe_i32 %[y0], %[r0], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[r0], %[i0], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[y1], %[r1], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[i0], %[i1], %[off], %[wd]\n\t"                                                        \
+    "v_perm_b32 %[y0], %[r0], %[y0], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y1], %[i0], %[y1], %[sel]"
+
+// exact extraction, 2 butterflies: (off, WIDTH) = (t-1, 16) -> Y, (t, 15) -> Y >> 1
+template <int WIDTH, bool SG>
+__device__ __forceinline__ void mul2x(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr1, u32 di1, u32 wa1, u32 wb1,
+                                      int off, u32 sel, u32 &y0, u32 &y1)
 {
     u32 r0, i0, r1, i1;
-    asm("v_dot2_i32_i16 %[r0], %[d0], %[wa0], 0\n\t"
-        "v_dot2_i32_i16 %[i0], %[d0], %[wb0], 0\n\t"
-        "v_dot2_i32_i16 %[r1], %[d1], %[wa1], 0\n\t"
-        "v_dot2_i32_i16 %[i1], %[d1], %[wb1], 0\n\t"
-        "v_bfe_i32 %[y0], %[r0], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[r0], %[i0], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[y1], %[r1], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[i0], %[i1], %[off], %[wd]\n\t"
-        "v_perm_b32 %[y0], %[r0], %[y0], %[sel]\n\t"
-        "v_perm_b32 %[y1], %[i0], %[y1], %[sel]"
-        : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
-        : [d0] "v"(d0), [wa0] "v"(wa0), [wb0] "v"(wb0), [d1] "v"(d1), [wa1] "v"(wa1), [wb1] "v"(wb1),
-          [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
-}
-// Twiddles in SGPRs (wave-uniform stages 3 and 2).
-template <int WIDTH>
-__device__ __forceinline__ void cmul2_s(u32 d0, u32 wa0, u32 wb0, u32 d1, u32 wa1, u32 wb1, int off, u32 sel,
-                                        u32 &y0, u32 &y1)
-{
-    u32 r0, i0, r1, i1;
-    asm("v_dot2_i32_i16 %[r0], %[d0], %[wa0], 0\n\t"
-        "v_dot2_i32_i16 %[i0], %[d0], %[wb0], 0\n\t"
-        "v_dot2_i32_i16 %[r1], %[d1], %[wa1], 0\n\t"
-        "v_dot2_i32_i16 %[i1], %[d1], %[wb1], 0\n\t"
-        "v_bfe_i32 %[y0], %[r0], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[r0], %[i0], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[y1], %[r1], %[off], %[wd]\n\t"
-        "v_bfe_i32 %[i0], %[i1], %[off], %[wd]\n\t"
-        "v_perm_b32 %[y0], %[r0], %[y0], %[sel]\n\t"
-        "v_perm_b32 %[y1], %[i0], %[y1], %[sel]"
-        : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
-        : [d0] "v"(d0), [wa0] "s"(wa0), [wb0] "s"(wb0), [d1] "v"(d1), [wa1] "s"(wa1), [wb1] "s"(wb1),
-          [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+    if (SG)
+        asm(INTFFT_MUL2X_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "s"(wa0), [wb0] "s"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
+              [wa1] "s"(wa1), [wb1] "s"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+    else
+        asm(INTFFT_MUL2X_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
+              [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
 }
 
-// Slicing parameters of a plan: truncate mode pre-shifts the multiplier outputs where the consumer
-// stage is register-static (OUT_PRE), round mode never does.
-struct Slice {
-    int off_y;  // t - 1: Y = sum[t+14 : t-1]
-    int off_y1; // t    : Y >> 1 = sext(sum[t+14 : t])
-    u32 sel;    // v_perm_b32 selector {S0.b1, S0.b0, S1.b1, S1.b0}
-};
+#define INTFFT_MUL4F_BODY                                                                              \
+    "v_dot2_i32_i16 %[y0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y2], %[dr2], %[wa2], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i2], %[di2], %[wb2], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y3], %[dr3], %[wa3], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i3], %[di3], %[wb3], 0\n\t"                                                      \
+    "v_perm_b32 %[y0], %[i0], %[y0], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y1], %[i1], %[y1], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y2], %[i2], %[y2], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y3], %[i3], %[y3], %[sel]"
 
-// two general butterflies (a0,b0), (a1,b1): a <- S, b <- cmult(D, W)
-template <bool ROUND, bool IN_PRE, bool OUT_PRE>
-__device__ __forceinline__ void bfly2_v(u32 &a0, u32 &b0, u32 wa0, u32 wb0, u32 &a1, u32 &b1, u32 wa1, u32 wb1,
-                                        const Slice &sl)
+// fast extraction, 4 butterflies, t = 16, no 31-bit overflow: Y >> 1 = { im[31:16], re[31:16] }
+template <bool SG>
+__device__ __forceinline__ void mul4f(const u32 (&dr)[4], const u32 (&di)[4], const u32 (&wa)[4], const u32 (&wb)[4],
+                                      u32 sel, u32 (&y)[4])
 {
-    u32 d0, d1;
-    sumdiff<ROUND, IN_PRE>(a0, b0, a0, d0);
-    sumdiff<ROUND, IN_PRE>(a1, b1, a1, d1);
-    if (OUT_PRE) cmul2_v<15>(d0, wa0, wb0, d1, wa1, wb1, sl.off_y1, sl.sel, b0, b1);
-    else cmul2_v<16>(d0, wa0, wb0, d1, wa1, wb1, sl.off_y, sl.sel, b0, b1);
+    u32 i0, i1, i2, i3;
+    if (SG)
+        asm(INTFFT_MUL4F_BODY
+            : [y0] "=&v"(y[0]), [y1] "=&v"(y[1]), [y2] "=&v"(y[2]), [y3] "=&v"(y[3]), [i0] "=&v"(i0), [i1] "=&v"(i1),
+              [i2] "=&v"(i2), [i3] "=&v"(i3)
+            : [dr0] "v"(dr[0]), [di0] "v"(di[0]), [dr1] "v"(dr[1]), [di1] "v"(di[1]), [dr2] "v"(dr[2]), [di2] "v"(di[2]),
+              [dr3] "v"(dr[3]), [di3] "v"(di[3]), [wa0] "s"(wa[0]), [wb0] "s"(wb[0]), [wa1] "s"(wa[1]), [wb1] "s"(wb[1]),
+              [wa2] "s"(wa[2]), [wb2] "s"(wb[2]), [wa3] "s"(wa[3]), [wb3] "s"(wb[3]), [sel] "s"(sel));
+    else
+        asm(INTFFT_MUL4F_BODY
+            : [y0] "=&v"(y[0]), [y1] "=&v"(y[1]), [y2] "=&v"(y[2]), [y3] "=&v"(y[3]), [i0] "=&v"(i0), [i1] "=&v"(i1),
+              [i2] "=&v"(i2), [i3] "=&v"(i3)
+            : [dr0] "v"(dr[0]), [di0] "v"(di[0]), [dr1] "v"(dr[1]), [di1] "v"(di[1]), [dr2] "v"(dr[2]), [di2] "v"(di[2]),
+              [dr3] "v"(dr[3]), [di3] "v"(di[3]), [wa0] "v"(wa[0]), [wb0] "v"(wb[0]), [wa1] "v"(wa[1]), [wb1] "v"(wb[1]),
+              [wa2] "v"(wa[2]), [wb2] "v"(wb[2]), [wa3] "v"(wa[3]), [wb3] "v"(wb[3]), [sel] "s"(sel));
 }
-template <bool ROUND, bool IN_PRE, bool OUT_PRE>
-__device__ __forceinline__ void bfly2_s(u32 &a0, u32 &b0, u32 wa0, u32 wb0, u32 &a1, u32 &b1, u32 wa1, u32 wb1,
-                                        const Slice &sl)
+
+// ---- a group of four general butterflies (a_i, b_i): a_i <- S, b_i <- cmult(D, W_i) ---------------
+//   FASTX   fast extraction (implies truncate mode and pre-shifted outputs)
+//   QTURN   the twiddles are the quarter turns of the given base twiddles
+//   OUT_PRE emit Y >> 1 (truncate mode)
+//   SG      twiddles in SGPRs
+//   PREMASK bit i: inputs of butterfly i already hold X >> 1;  VARSH: per-lane shift amount instead
+template <bool ROUND, bool FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false>
+__device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
+                                       const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl, v2s shv = v2s{0, 0})
 {
-    u32 d0, d1;
-    sumdiff<ROUND, IN_PRE>(a0, b0, a0, d0);
-    sumdiff<ROUND, IN_PRE>(a1, b1, a1, d1);
-    if (OUT_PRE) cmul2_s<15>(d0, wa0, wb0, d1, wa1, wb1, sl.off_y1, sl.sel, b0, b1);
-    else cmul2_s<16>(d0, wa0, wb0, d1, wa1, wb1, sl.off_y, sl.sel, b0, b1);
+    static_assert(!FASTX || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
+    static_assert(!QTURN || !ROUND, "quarter-turn sharing needs an exact -D");
+    u32 d[4];
+    if (VARSH) {
+        sumdiff_var(a0, b0, shv, a0, d[0]);
+        sumdiff_var(a1, b1, shv, a1, d[1]);
+        sumdiff_var(a2, b2, shv, a2, d[2]);
+        sumdiff_var(a3, b3, shv, a3, d[3]);
+    } else {
+        sumdiff<ROUND, (PREMASK & 1) != 0>(a0, b0, a0, d[0]);
+        sumdiff<ROUND, (PREMASK & 2) != 0>(a1, b1, a1, d[1]);
+        sumdiff<ROUND, (PREMASK & 4) != 0>(a2, b2, a2, d[2]);
+        sumdiff<ROUND, (PREMASK & 8) != 0>(a3, b3, a3, d[3]);
+    }
+    u32 y[4];
+    if (QTURN) {
+        const v2s z = {0, 0};
+        const u32 n[4] = {as_u32(z - as_v2s(d[0])), as_u32(z - as_v2s(d[1])), as_u32(z - as_v2s(d[2])),
+                          as_u32(z - as_v2s(d[3]))};
+        if (FASTX) {
+            mul4f<SG>(d, n, wb, wa, sl.sel_hi, y);
+        } else {
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[0], n[0], wb[0], wa[0], d[1], n[1], wb[1], wa[1],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[2], n[2], wb[2], wa[2], d[3], n[3], wb[3], wa[3],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+        }
+    } else {
+        if (FASTX) {
+            mul4f<SG>(d, d, wa, wb, sl.sel_hi, y);
+        } else {
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+        }
+    }
+    b0 = y[0];
+    b1 = y[1];
+    b2 = y[2];
+    b3 = y[3];
 }
 
 // STAGE 0 and even positions of STAGE 1: Y = D (int_dif2_fly.vhd:245-255, :293-296)
@@ -169,13 +255,152 @@ __device__ __forceinline__ void swap16(u32 &a, u32 &b)
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-__device__ __forceinline__ u32 pack_wa(int2 w) { return ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16); }
-__device__ __forceinline__ u32 pack_wb(int2 w) { return ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16); }
-
 constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B aligned, conflict-free)
 
-template <bool ROUND, bool OUT_BITREV, bool PIPE>
-__global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ tw,
+// ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
+template <bool ROUND, bool OUT_BITREV, bool FASTX>
+__device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
+                                                const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
+                                                const uint4 *rd_base, v2s sh3)
+{
+    // P (truncate mode): multiplier outputs are emitted pre-shifted (Y >> 1); after a stage with
+    // register offset h the registers with (j & h) != 0 hold Y >> 1, the others hold S.
+    constexpr bool P = !ROUND;
+    constexpr bool Q = !ROUND;
+    constexpr int M0 = 0, MH = P ? 0xC : 0, MA = P ? 0xF : 0, MODD = P ? 0xA : 0; // PREMASKs
+
+    // ---- phase 1: stages 9, 8, 7, 6 (register offsets 8, 4, 2, 1) ----
+    if constexpr (Q) {
+        group4<ROUND, FASTX, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], tw.wa9, tw.wb9, sl);
+        group4<ROUND, FASTX, Q, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], tw.wa9, tw.wb9, sl);
+        // stage 8: (j, j+4); kind of the inputs = j & 8
+        {
+            const u32 wa[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[0], tw.wa8[1]}, wb[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[0], tw.wb8[1]};
+            group4<ROUND, FASTX, false, P, false, MH>(v[0], v[4], v[1], v[5], v[8], v[12], v[9], v[13], wa, wb, sl);
+            group4<ROUND, FASTX, Q, P, false, MH>(v[2], v[6], v[3], v[7], v[10], v[14], v[11], v[15], wa, wb, sl);
+        }
+        // stage 7: (j, j+2); kind = j & 4; pairs with j odd use the quarter turn of wa7[0]
+        {
+            const u32 wa[4] = {tw.wa7[0], tw.wa7[0], tw.wa7[0], tw.wa7[0]}, wb[4] = {tw.wb7[0], tw.wb7[0], tw.wb7[0], tw.wb7[0]};
+            group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa, wb, sl);
+            group4<ROUND, FASTX, Q, P, false, MODD>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa, wb, sl);
+        }
+    } else {
+        const u32 wa9a[4] = {tw.wa9[0], tw.wa9[1], tw.wa9[2], tw.wa9[3]}, wb9a[4] = {tw.wb9[0], tw.wb9[1], tw.wb9[2], tw.wb9[3]};
+        const u32 wa9b[4] = {tw.wa9[4 % (8 / Twiddles<ROUND>::NQ)], tw.wa9[5 % (8 / Twiddles<ROUND>::NQ)],
+                             tw.wa9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wa9[7 % (8 / Twiddles<ROUND>::NQ)]};
+        const u32 wb9b[4] = {tw.wb9[4 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[5 % (8 / Twiddles<ROUND>::NQ)],
+                             tw.wb9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[7 % (8 / Twiddles<ROUND>::NQ)]};
+        group4<ROUND, false, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa9a, wb9a, sl);
+        group4<ROUND, false, false, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa9b, wb9b, sl);
+        constexpr int N8 = 4 / Twiddles<ROUND>::NQ, N7 = 2 / Twiddles<ROUND>::NQ;
+        const u32 wa8a[4] = {tw.wa8[0], tw.wa8[1 % N8], tw.wa8[0], tw.wa8[1 % N8]}, wb8a[4] = {tw.wb8[0], tw.wb8[1 % N8], tw.wb8[0], tw.wb8[1 % N8]};
+        const u32 wa8b[4] = {tw.wa8[2 % N8], tw.wa8[3 % N8], tw.wa8[2 % N8], tw.wa8[3 % N8]}, wb8b[4] = {tw.wb8[2 % N8], tw.wb8[3 % N8], tw.wb8[2 % N8], tw.wb8[3 % N8]};
+        group4<ROUND, false, false, P, false, MH>(v[0], v[4], v[1], v[5], v[8], v[12], v[9], v[13], wa8a, wb8a, sl);
+        group4<ROUND, false, false, P, false, MH>(v[2], v[6], v[3], v[7], v[10], v[14], v[11], v[15], wa8b, wb8b, sl);
+        const u32 wa7a[4] = {tw.wa7[0], tw.wa7[0], tw.wa7[0], tw.wa7[0]}, wb7a[4] = {tw.wb7[0], tw.wb7[0], tw.wb7[0], tw.wb7[0]};
+        const u32 wa7b[4] = {tw.wa7[1 % N7], tw.wa7[1 % N7], tw.wa7[1 % N7], tw.wa7[1 % N7]}, wb7b[4] = {tw.wb7[1 % N7], tw.wb7[1 % N7], tw.wb7[1 % N7], tw.wb7[1 % N7]};
+        group4<ROUND, false, false, P, false, MODD>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa7a, wb7a, sl);
+        group4<ROUND, false, false, P, false, MODD>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa7b, wb7b, sl);
+    }
+    { // stage 6: (j, j+1), j even; kind = j & 2; one twiddle per lane
+        const u32 wa[4] = {tw.wa6[0], tw.wa6[0], tw.wa6[0], tw.wa6[0]}, wb[4] = {tw.wb6[0], tw.wb6[0], tw.wb6[0], tw.wb6[0]};
+        group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
+    }
+
+    // ---- lane bit 5 <-> reg bit 3, stage 5: (j, j+8); kind = j & 1 ----
+#pragma unroll
+    for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);
+    {
+        const u32 wa[4] = {tw.wa5[0], tw.wa5[0], tw.wa5[0], tw.wa5[0]}, wb[4] = {tw.wb5[0], tw.wb5[0], tw.wb5[0], tw.wb5[0]};
+        group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa, wb, sl);
+    }
+
+    // ---- lane bit 4 <-> reg bit 2, stage 4: (j, j+4); kind = j & 8 ----
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);
+    {
+        const u32 wa[4] = {tw.wa4[0], tw.wa4[0], tw.wa4[0], tw.wa4[0]}, wb[4] = {tw.wb4[0], tw.wb4[0], tw.wb4[0], tw.wb4[0]};
+        group4<ROUND, FASTX, false, P, false, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MA>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], wa, wb, sl);
+    }
+
+    // ---- LDS transpose: regs become n3..0.  The kind of a value (S or Y >> 1) is now j & 4, and
+    //      reg bit 2 holds n4, which becomes a LANE bit: stage 3 shifts by a per-lane amount ----
+    asm volatile("" ::: "memory"); // keep the previous frame's reads ahead of these writes
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
+        const int row_j = OUT_BITREV ? (8 * j1 + 4 * j0 + 2 * j3 + j2) : (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2);
+        wr_base[ROW_DW * row_j] = v[j];
+    }
+    asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 x = rd_base[q];
+        v[4 * q + 0] = x.x;
+        v[4 * q + 1] = x.y;
+        v[4 * q + 2] = x.z;
+        v[4 * q + 3] = x.w;
+    }
+    asm volatile("" ::: "memory");
+
+    // ---- phase 3: stages 3, 2 (uniform twiddles), 1, 0 ----
+    {
+        const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+        const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+        group4<ROUND, FASTX, false, P, true, M0, P>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, sh3);
+        group4<ROUND, FASTX, false, P, true, M0, P>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, sh3);
+        // stage 2: (r, r+4); kind = r & 8
+        group4<ROUND, FASTX, false, P, true, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+        group4<ROUND, FASTX, false, P, true, MA>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8) { // stage 1: kind = r & 4
+        bfly_triv<ROUND, false>(v[g], v[g + 2]);
+        bfly_mj<ROUND, false>(v[g + 1], v[g + 3]);
+        bfly_triv<ROUND, P>(v[g + 4], v[g + 6]);
+        bfly_mj<ROUND, P>(v[g + 5], v[g + 7]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]);
+
+    // ---- store ----
+    if (OUT_BITREV) {
+        uint4 *dst = reinterpret_cast<uint4 *>(out + f * 1024 + lane * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+        u32 *dst = out + f * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); // rev4
+            __builtin_nontemporal_store(v[r], dst + 64 * rr);
+        }
+    }
+}
+
+// Guard-bit test of one frame (wave-uniform result).  t = x + 0x40004000 has bit 15 / bit 31 clear
+// for every sample iff re in [-2^14, 2^14) and im in [-2^14 - 1, 2^14) (the low half may carry
+// into the high half).  Then |z| <= 23172 for every input sample z.  Through a scaled-truncate
+// stage the complex magnitude M grows by at most 1.42 (floors: <= 0.71 on S and D, twiddle
+// magnitude <= 32767.71, final floor 0.71), so M <= 23187 at every butterfly input, |D| <= M + 0.71,
+// and |re|, |im| of D*W are <= 23188 * 32767.71 < 2^30: bit 31 equals bit 30 in every sum, which is
+// what fast extraction needs.  (The bound that would actually be needed is M <= 32752.)
+__device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16])
+{
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc |= v[j] + 0x40004000u;
+    return __builtin_amdgcn_ballot_w64((acc & 0x80008000u) != 0) == 0;
+}
+
+template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+__global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const Fast1024Consts c, size_t nframes, const Slice sl)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROW_DW];
@@ -184,36 +409,37 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     u32 *lds = lds_all + wv * 64 * ROW_DW;
 
     // ---- per-lane twiddles of the lane-dependent stages (frame invariant) --------------------
-    // stage s table starts at tw + 2^s - 1; index = position mod 2^s (rom_twiddle_int.vhd:187-202)
-    u32 wa9[8], wb9[8], wa8[4], wb8[4], wa7[2], wb7[2], wa6, wb6, wa5, wb5, wa4, wb4;
+    // stage s table starts at twt + 2^s - 1; index = position mod 2^s (rom_twiddle_int.vhd:187-202)
+    Twiddles<ROUND> tw;
+    constexpr int NQ = Twiddles<ROUND>::NQ;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int2 w = tw[511 + 64 * j + lane];
-        wa9[j] = pack_wa(w);
-        wb9[j] = pack_wb(w);
+    for (int j = 0; j < 8 / NQ; ++j) {
+        const int2 w = twt[511 + 64 * j + lane];
+        tw.wa9[j] = pack_wa(w);
+        tw.wb9[j] = pack_wb(w);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int2 w = tw[255 + 64 * j + lane];
-        wa8[j] = pack_wa(w);
-        wb8[j] = pack_wb(w);
+    for (int j = 0; j < 4 / NQ; ++j) {
+        const int2 w = twt[255 + 64 * j + lane];
+        tw.wa8[j] = pack_wa(w);
+        tw.wb8[j] = pack_wb(w);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int2 w = tw[127 + 64 * j + lane];
-        wa7[j] = pack_wa(w);
-        wb7[j] = pack_wb(w);
+    for (int j = 0; j < 2 / NQ; ++j) {
+        const int2 w = twt[127 + 64 * j + lane];
+        tw.wa7[j] = pack_wa(w);
+        tw.wb7[j] = pack_wb(w);
     }
     {
-        int2 w = tw[63 + lane];
-        wa6 = pack_wa(w);
-        wb6 = pack_wb(w);
-        w = tw[31 + (lane & 31)];
-        wa5 = pack_wa(w);
-        wb5 = pack_wb(w);
-        w = tw[15 + (lane & 15)];
-        wa4 = pack_wa(w);
-        wb4 = pack_wb(w);
+        int2 w = twt[63 + lane];
+        tw.wa6[0] = pack_wa(w);
+        tw.wb6[0] = pack_wb(w);
+        w = twt[31 + (lane & 31)];
+        tw.wa5[0] = pack_wa(w);
+        tw.wb5[0] = pack_wb(w);
+        w = twt[15 + (lane & 15)];
+        tw.wa4[0] = pack_wa(w);
+        tw.wb4[0] = pack_wb(w);
     }
 
     // ---- LDS transpose addressing -------------------------------------------------------------
@@ -226,165 +452,44 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
                                    : ROW_DW * (t5 + 2 * t4) + (lane & 15);
     u32 *wr_base = lds + wr_lane;
     const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROW_DW * lane);
+    // stage 3 per-lane shift: lanes whose n4 = 1 hold Y >> 1 already (n4 = row bit 5 / bit 0)
+    const int n4 = OUT_BITREV ? (lane & 1) : (lane >> 5);
+    const v2s sh3 = {(short)(1 - n4), (short)(1 - n4)};
 
-    // ---- one frame: registers v[] (lane = n5..0, j = n9..6) -> transformed frame f in memory ----
-#ifndef INTFFT_ABLATE
-#define INTFFT_ABLATE 0
-#endif
-    const size_t wave0_ = (size_t)blockIdx.x * 4 + wv;
-    (void)wave0_;
-    auto transform_store = [&](u32(&v)[16], size_t f) {
-    // P = truncate mode: multiplier outputs are emitted pre-shifted (Y >> 1) whenever the stage
-            // that consumes them pairs registers of one kind; after a stage with register offset h the
-            // registers with (j & h) != 0 hold Y >> 1, the others hold S.
-            constexpr bool P = !ROUND;
-
-            // ---- phase 1: stages 9, 8, 7, 6 (register offsets 8, 4, 2, 1) ----
-#pragma unroll
-            for (int j = 0; j < 8; j += 2)
-                bfly2_v<ROUND, false, P>(v[j], v[j + 8], wa9[j], wb9[j], v[j + 1], v[j + 9], wa9[j + 1], wb9[j + 1], sl);
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                bfly2_v<ROUND, false, P>(v[j], v[j + 4], wa8[j], wb8[j], v[j + 1], v[j + 5], wa8[j + 1], wb8[j + 1], sl);
-                bfly2_v<ROUND, P, P>(v[8 + j], v[12 + j], wa8[j], wb8[j], v[9 + j], v[13 + j], wa8[j + 1], wb8[j + 1], sl);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; g += 8) {
-                bfly2_v<ROUND, false, P>(v[g], v[g + 2], wa7[0], wb7[0], v[g + 1], v[g + 3], wa7[1], wb7[1], sl);
-                bfly2_v<ROUND, P, P>(v[g + 4], v[g + 6], wa7[0], wb7[0], v[g + 5], v[g + 7], wa7[1], wb7[1], sl);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; g += 4) {
-                u32 d0, d1;
-                sumdiff<ROUND, false>(v[g], v[g + 1], v[g], d0);
-                sumdiff<ROUND, P>(v[g + 2], v[g + 3], v[g + 2], d1);
-                if (P) cmul2_v<15>(d0, wa6, wb6, d1, wa6, wb6, sl.off_y1, sl.sel, v[g + 1], v[g + 3]);
-                else cmul2_v<16>(d0, wa6, wb6, d1, wa6, wb6, sl.off_y, sl.sel, v[g + 1], v[g + 3]);
-            }
-
-            // ---- lane bit 5 <-> reg bit 3, stage 5 (kind of v[j] still given by j & 1) ----
-#pragma unroll
-            for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                u32 d0, d1;
-                sumdiff<ROUND, false>(v[j], v[j + 8], v[j], d0);
-                sumdiff<ROUND, P>(v[j + 1], v[j + 9], v[j + 1], d1);
-                if (P) cmul2_v<15>(d0, wa5, wb5, d1, wa5, wb5, sl.off_y1, sl.sel, v[j + 8], v[j + 9]);
-                else cmul2_v<16>(d0, wa5, wb5, d1, wa5, wb5, sl.off_y, sl.sel, v[j + 8], v[j + 9]);
-            }
-
-            // ---- lane bit 4 <-> reg bit 2, stage 4 (kind given by j & 8); outputs NOT pre-shifted:
-            //      after the transpose their kind would depend on the lane ----
-#pragma unroll
-            for (int g = 0; g < 16; g += 8)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                bfly2_v<ROUND, false, false>(v[j], v[j + 4], wa4, wb4, v[j + 1], v[j + 5], wa4, wb4, sl);
-                bfly2_v<ROUND, P, false>(v[8 + j], v[12 + j], wa4, wb4, v[9 + j], v[13 + j], wa4, wb4, sl);
-            }
-
-            // ---- LDS transpose: regs become n3..0 ----
-            asm volatile("" ::: "memory"); // keep the previous frame's reads ahead of these writes
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
-                const int row_j = OUT_BITREV ? (8 * j1 + 4 * j0 + 2 * j3 + j2) : (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2);
-                wr_base[ROW_DW * row_j] = v[j];
-            }
-            asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 x = rd_base[q];
-                v[4 * q + 0] = x.x;
-                v[4 * q + 1] = x.y;
-                v[4 * q + 2] = x.z;
-                v[4 * q + 3] = x.w;
-            }
-            asm volatile("" ::: "memory");
-
-            // ---- phase 3: stages 3, 2 (uniform twiddles), 1, 0 ----
-#pragma unroll
-            for (int r = 0; r < 8; r += 2)
-                bfly2_s<ROUND, false, P>(v[r], v[r + 8], c.wa3[r], c.wb3[r], v[r + 1], v[r + 9], c.wa3[r + 1],
-                                         c.wb3[r + 1], sl);
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                bfly2_s<ROUND, false, P>(v[r], v[r + 4], c.wa2[r], c.wb2[r], v[r + 1], v[r + 5], c.wa2[r + 1],
-                                         c.wb2[r + 1], sl);
-                bfly2_s<ROUND, P, P>(v[8 + r], v[12 + r], c.wa2[r], c.wb2[r], v[9 + r], v[13 + r], c.wa2[r + 1],
-                                     c.wb2[r + 1], sl);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; g += 8) { // stage 1: kind given by r & 4
-                bfly_triv<ROUND, false>(v[g], v[g + 2]);
-                bfly_mj<ROUND, false>(v[g + 1], v[g + 3]);
-                bfly_triv<ROUND, P>(v[g + 4], v[g + 6]);
-                bfly_mj<ROUND, P>(v[g + 5], v[g + 7]);
-            }
-#pragma unroll
-            for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]);
-
-            // ---- store ----
-#if INTFFT_ABLATE & 2 // diagnostic build: only the last frames are really stored
-            if (f + (size_t)gridDim.x * 4 < nframes) {
-                u32 acc = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc ^= v[r];
-                if (acc == 0x12345679u) out[f] = acc; // keeps the arithmetic live
-                return;
-            }
-#endif
-            if (OUT_BITREV) {
-                uint4 *dst = reinterpret_cast<uint4 *>(out + f * 1024 + lane * 16);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            } else {
-                u32 *dst = out + f * 1024 + lane;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); // rev4
-                    __builtin_nontemporal_store(v[r], dst + 64 * rr);
-                }
-            }
+    auto run = [&](u32(&v)[16], size_t f) {
+        if (FAST_OK && frame_has_guard_bit(v))
+            transform_store<ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3);
+        else
+            transform_store<ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
-#if INTFFT_ABLATE & 1 // diagnostic build: only the first frame is really loaded
-        if (f != wave0_) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = v[j] * 3u + (u32)f;
-            return;
-        }
-#endif
         const u32 *src = in + f * 1024 + lane;
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j);
     };
 
-    // ---- persistent frame loop, software-pipelined: frame f+1 is in flight while f is computed ----
     const size_t wave0 = (size_t)blockIdx.x * 4 + wv;
     const size_t nwaves = (size_t)gridDim.x * 4;
     if (!PIPE) { // one frame at a time: fewer VGPRs, more waves per SIMD
         for (size_t f = wave0; f < nframes; f += nwaves) {
             u32 v[16];
             load_frame(v, f);
-            transform_store(v, f);
+            run(v, f);
         }
         return;
     }
+    // software-pipelined: frame f+1 is in flight while f is computed
     u32 va[16], vb[16];
     size_t f = wave0;
     if (f < nframes) load_frame(va, f);
     while (f < nframes) {
         const size_t f1 = f + nwaves;
         if (f1 < nframes) load_frame(vb, f1);
-        transform_store(va, f);
+        run(va, f);
         if (f1 >= nframes) break;
         f = f1 + nwaves;
         if (f < nframes) load_frame(va, f);
-        transform_store(vb, f1);
+        run(vb, f1);
     }
 }
 
@@ -398,8 +503,14 @@ bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, i
 
 const char *fast1024_kernel_name() { return "k_fft1024_i16"; }
 
-template <bool ROUND, bool OUT_BITREV, bool PIPE>
-static hipError_t launch_p(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream)
 {
     // persistent waves: exactly the resident grid (occupancy x CUs), so no block waits for a slot
@@ -408,30 +519,35 @@ static hipError_t launch_p(const u32 *in, u32 *out, const int2 *tw, const Fast10
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_i16<ROUND, OUT_BITREV, PIPE>, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_i16<ROUND, OUT_BITREV, PIPE, FAST_OK>, 256,
+                                                         0) != hipSuccess ||
             per_cu <= 0)
             per_cu = 4;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+        if (PIPE && per_cu > 4) per_cu = 4; // 2 frames in flight per wave: 4 waves/SIMD saturate HBM and balance 65536 frames
+        const int e = env_int("INTFFT_BLOCKS_PER_CU", 0);
+        if (e > 0) per_cu = e;
     }
     const size_t need = (nframes + 3) / 4;
     const size_t cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
-    hipLaunchKernelGGL((k_fft1024_i16<ROUND, OUT_BITREV, PIPE>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c,
-                       nframes, sl);
+    hipLaunchKernelGGL((k_fft1024_i16<ROUND, OUT_BITREV, PIPE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out,
+                       tw, c, nframes, sl);
     return hipGetLastError();
 }
 
 template <bool ROUND, bool OUT_BITREV>
 static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
-                           const Slice &sl, hipStream_t stream)
+                           const Slice &sl, bool fast_ok, hipStream_t stream)
 {
-    static int pipe = -1; // software-pipelined (2 frames in flight per wave) unless INTFFT_FAST_PIPE=0
-    if (pipe < 0) {
-        const char *e = getenv("INTFFT_FAST_PIPE");
-        pipe = e ? atoi(e) != 0 : 1;
+    static const int pipe = env_int("INTFFT_FAST_PIPE", 1);          // 1: two frames in flight per wave
+    static const int allow_fast = env_int("INTFFT_FAST_EXTRACT", 1); // 0: always the exact extraction
+    if constexpr (!ROUND) {
+        if (fast_ok && allow_fast)
+            return pipe ? launch_k<ROUND, OUT_BITREV, true, true>(in, out, tw, c, nframes, sl, stream)
+                        : launch_k<ROUND, OUT_BITREV, false, true>(in, out, tw, c, nframes, sl, stream);
     }
-    return pipe ? launch_p<ROUND, OUT_BITREV, true>(in, out, tw, c, nframes, sl, stream)
-                : launch_p<ROUND, OUT_BITREV, false>(in, out, tw, c, nframes, sl, stream);
+    return pipe ? launch_k<ROUND, OUT_BITREV, true, false>(in, out, tw, c, nframes, sl, stream)
+                : launch_k<ROUND, OUT_BITREV, false, false>(in, out, tw, c, nframes, sl, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
@@ -449,14 +565,15 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    const Slice sl{a.twd - 1, a.twd, 0x05040100u};
+    const Slice sl{a.twd - 1, a.twd, 0x05040100u, 0x07060302u};
+    const bool fast_ok = a.twd == 16; // high halves == bits [31:16] only for t = 16
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
     if (a.rnd == RND_ROUND)
-        return a.out_bitrev ? launch_t<true, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                            : launch_t<true, false>(pin, pout, tw_all, c, nframes, sl, stream);
-    return a.out_bitrev ? launch_t<false, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                        : launch_t<false, false>(pin, pout, tw_all, c, nframes, sl, stream);
+        return a.out_bitrev ? launch_t<true, true>(pin, pout, tw_all, c, nframes, sl, false, stream)
+                            : launch_t<true, false>(pin, pout, tw_all, c, nframes, sl, false, stream);
+    return a.out_bitrev ? launch_t<false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, stream)
+                        : launch_t<false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
 }
 
 } // namespace intfft

@@ -43,6 +43,30 @@ DEFK(k_pkadd, A_PKADD) DEFK(k_pksub, A_PKSUB) DEFK(k_pkashr, A_PKASHR) DEFK(k_do
 DEFK(k_bfe, A_BFE) DEFK(k_perm, A_PERM) DEFK(k_add, A_ADD) DEFK(k_lshl, A_LSHL) DEFK(k_and, A_AND) DEFK(k_fma, A_FMA)
 DEFK(k_mad24, A_MAD24) DEFK(k_align, A_ALIGN) DEFK(k_mov, A_MOV) DEFK(k_pkmad, A_PKMAD) DEFK(k_lshladd, A_LSHLADD)
 DEFK(k_pklshl, A_PKLSHL) DEFK(k_add16, A_ADD16)
+#define A_MIX1(n) "v_pk_add_u16 %" #n ", %" #n ", %8\n\tv_and_b32 %9, %9, %8"
+#define A_MIX2(n) "v_dot2_i32_i16 %" #n ", %" #n ", %8, 0\n\tv_add_u32 %9, %9, %8"
+#define A_MIX3(n) "v_pk_add_u16 %" #n ", %" #n ", %8\n\tv_dot2_i32_i16 %9, %9, %8, 0"
+#define A_XOR(n) "v_xor_b32 %" #n ", %" #n ", %8"
+#define A_SUB(n) "v_sub_u32 %" #n ", %" #n ", %8"
+#define A_ASHR32(n) "v_ashrrev_i32 %" #n ", 1, %" #n
+#define A_LSHR32(n) "v_lshrrev_b32 %" #n ", 1, %" #n
+#define A_ASHR16(n) "v_ashrrev_i16 %" #n ", 1, %" #n
+#define A_MULLO16(n) "v_mul_lo_u16 %" #n ", %" #n ", %8"
+#define A_BFI(n) "v_bfi_b32 %" #n ", %8, %" #n ", %9"
+#define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9"
+#define A_MAX(n) "v_max_i32 %" #n ", %" #n ", %8"
+#define A_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc"
+#define A_PKFMAF16(n) "v_pk_fma_f16 %" #n ", %" #n ", %8, %9"
+#define A_PKADDF16(n) "v_pk_add_f16 %" #n ", %" #n ", %8"
+#define A_PKMAX(n) "v_pk_max_i16 %" #n ", %" #n ", %8"
+#define A_MADU16(n) "v_mad_u16 %" #n ", %" #n ", %8, %9"
+#define A_SDWA(n) "v_add_u16_sdwa %" #n ", %" #n ", %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
+#define A_MULI24(n) "v_mul_i32_i24 %" #n ", %" #n ", %8"
+#define A_PKFMA32(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %9"
+DEFK(k_mix1, A_MIX1) DEFK(k_mix2, A_MIX2) DEFK(k_mix3, A_MIX3) DEFK(k_xor, A_XOR) DEFK(k_sub, A_SUB) DEFK(k_ashr32, A_ASHR32)
+DEFK(k_lshr32, A_LSHR32) DEFK(k_ashr16, A_ASHR16) DEFK(k_mullo16, A_MULLO16) DEFK(k_bfi, A_BFI) DEFK(k_andor, A_ANDOR)
+DEFK(k_max, A_MAX) DEFK(k_cnd, A_CNDMASK) DEFK(k_pkfmaf16, A_PKFMAF16) DEFK(k_pkaddf16, A_PKADDF16) DEFK(k_pkmax, A_PKMAX)
+DEFK(k_madu16, A_MADU16) DEFK(k_sdwa, A_SDWA) DEFK(k_muli24, A_MULI24)
 
 template <typename K> void run(const char* name, K k, unsigned* out, int blocks)
 {
@@ -54,20 +78,25 @@ template <typename K> void run(const char* name, K k, unsigned* out, int blocks)
     float ms; (void)hipEventElapsedTime(&ms, a, b);
     double insts = (double)blocks * 4 * ITER * 64;            // wave-instructions
     double per_simd_per_clk = insts / (256.0 * 4) / (ms * 1e-3 * 2.4e9);
-    printf("%-10s %.3f ms  %.2f wave-instr/clk/SIMD @2.4GHz  (%.2f clk per instr)\n", name, ms, per_simd_per_clk, 1.0 / per_simd_per_clk);
+    printf("%-26s %.3f ms  %.2f wave-instr/clk/SIMD @2.4GHz  (%.2f clk per instr)\n", name, ms, per_simd_per_clk, 1.0 / per_simd_per_clk);
 }
 int main(int argc, char** argv)
 {
     int wps = argc > 1 ? atoi(argv[1]) : 4; // waves per SIMD
     int blocks = 256 * wps;
     unsigned* out; (void)hipMalloc(&out, (size_t)blocks * 256 * 4);
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 3; ++r) {
     run("pk_add", k_pkadd, out, blocks); run("pk_sub", k_pksub, out, blocks); run("pk_ashr", k_pkashr, out, blocks);
     run("dot2", k_dot2, out, blocks); run("dot2c", k_dot2c, out, blocks); run("bfe", k_bfe, out, blocks);
     run("perm", k_perm, out, blocks); run("add_u32", k_add, out, blocks); run("lshl", k_lshl, out, blocks);
     run("and", k_and, out, blocks); run("fma_f32", k_fma, out, blocks); run("mad_i24", k_mad24, out, blocks);
     run("alignbit", k_align, out, blocks); run("mov", k_mov, out, blocks); run("pk_mad16", k_pkmad, out, blocks);
     run("lshl_add", k_lshladd, out, blocks); run("pk_lshl16", k_pklshl, out, blocks); run("add_u16", k_add16, out, blocks);
+    run("MIX pkadd+and (2 instr)", k_mix1, out, blocks); run("MIX dot2+add (2 instr)", k_mix2, out, blocks); run("MIX pkadd+dot2 (2)", k_mix3, out, blocks);
+    run("xor", k_xor, out, blocks); run("sub_u32", k_sub, out, blocks); run("ashr_i32", k_ashr32, out, blocks); run("lshr_b32", k_lshr32, out, blocks);
+    run("ashr_i16", k_ashr16, out, blocks); run("mul_lo_u16", k_mullo16, out, blocks); run("bfi", k_bfi, out, blocks); run("and_or", k_andor, out, blocks);
+    run("max_i32", k_max, out, blocks); run("cndmask", k_cnd, out, blocks); run("pk_fma_f16", k_pkfmaf16, out, blocks); run("pk_add_f16", k_pkaddf16, out, blocks);
+    run("pk_max_i16", k_pkmax, out, blocks); run("mad_u16", k_madu16, out, blocks); run("add_u16_sdwa", k_sdwa, out, blocks); run("mul_i32_i24", k_muli24, out, blocks);
     }
     return 0;
 }
