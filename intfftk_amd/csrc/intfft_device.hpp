@@ -188,4 +188,16 @@ __device__ __forceinline__ unsigned order_to_mem(int order, int L, unsigned idx)
     }
 }
 
+// logical index stored at memory index m (the maps documented in intfft.h)
+__device__ __forceinline__ unsigned order_from_mem(int order, int L, unsigned m)
+{
+    const unsigned half = 1u << (L - 1);
+    switch (order) {
+    case 1: return brev_l(m, L);                                              // BITREV
+    case 2: return (m >> 1) + (m & 1u) * half;                                // HALVES
+    case 3: return brev_l(2u * (m & (half - 1)) + (m >> (L - 1)), L);         // BITREV_LANES
+    default: return m;                                                        // NATURAL
+    }
+}
+
 } // namespace intfft

@@ -71,12 +71,19 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
     // ---- load -------------------------------------------------------------------------------
     for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
-        const unsigned u = a.ld_swap ? swap_runs(v) : v;
-        const unsigned j = spread(u);
+        unsigned u = a.ld_swap ? swap_runs(v) : v;
+        unsigned j = spread(u);
         Cx<T> c;
         if (a.in_mode == IO_USER) {
-            const unsigned logical = a.in_rev ? brev_l(j, L) : j;
-            const size_t m = (f0 + f) * N + order_to_mem(a.in_order, L, logical);
+            size_t m;
+            if (a.ld_memorder) { // v is the memory index; the tile owns every bit, so u == j
+                const unsigned logical = order_from_mem(a.in_order, L, v);
+                u = j = a.in_rev ? brev_l(logical, L) : logical;
+                m = (f0 + f) * N + v;
+            } else {
+                const unsigned logical = a.in_rev ? brev_l(j, L) : j;
+                m = (f0 + f) * N + order_to_mem(a.in_order, L, logical);
+            }
             c.re = load_user<T>(in, a.in_cb, 2 * m);
             c.im = load_user<T>(in, a.in_cb, 2 * m + 1);
             if (a.in_zext) {
@@ -122,12 +129,21 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
     // ---- store ------------------------------------------------------------------------------
     for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
-        const unsigned u = a.st_swap ? swap_runs(v) : v;
-        const unsigned j = spread(u);
+        unsigned u = a.st_swap ? swap_runs(v) : v;
+        unsigned j = spread(u);
+        size_t m = 0;
+        if (a.out_mode == IO_USER) {
+            if (a.st_memorder) {
+                const unsigned logical = order_from_mem(a.out_order, L, v);
+                u = j = a.out_rev ? brev_l(logical, L) : logical;
+                m = (f0 + f) * N + v;
+            } else {
+                const unsigned logical = a.out_rev ? brev_l(j, L) : j;
+                m = (f0 + f) * N + order_to_mem(a.out_order, L, logical);
+            }
+        }
         const Cx<T> c = lds[pad((f << U) + u)];
         if (a.out_mode == IO_USER) {
-            const unsigned logical = a.out_rev ? brev_l(j, L) : j;
-            const size_t m = (f0 + f) * N + order_to_mem(a.out_order, L, logical);
             store_user<T>(out, a.out_cb, 2 * m, c.re);
             store_user<T>(out, a.out_cb, 2 * m + 1, c.im);
         } else {

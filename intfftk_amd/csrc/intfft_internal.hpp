@@ -39,6 +39,8 @@ struct PassArgs {
     int in_bits;             // user mode: DATA_WIDTH the samples are wrapped to on load
     int in_zext;             // user mode: zero-extend instead (USE_FLY='0' unscaled)
     int ld_swap, st_swap;    // iterate the tile with the two runs swapped (coalescing of run1)
+    int ld_memorder, st_memorder; // U == L only: sweep the frame in MEMORY order (coalesced global side,
+                                  // the permutation is absorbed by the LDS side)
     StageDesc st[MAX_STAGES_PER_PASS];
 };
 
@@ -50,6 +52,13 @@ const char *pass_kernel_name(int word_bytes);
 
 hipError_t launch_twiddle_stage(const int2 *d_rom, int stage, int twd, int xser, int2 *d_out,
                                 hipStream_t stream);
+
+// packed int16 LDS pass kernel (intfft_pass16.hip): scaled, DATA_WIDTH = 16, TWDL_WIDTH <= 16
+bool pass16_supported(int data_width, int twdl_width, int format, int use_fly);
+hipError_t launch_pass16(const PassArgs &a, const void *in, void *out, const uint2 *twf, const uint2 *twi,
+                         size_t nframes, int twd, hipStream_t stream);
+hipError_t launch_pack_twiddles16(const int2 *tw, size_t n, uint2 *f, uint2 *i, hipStream_t stream);
+const char *pass16_kernel_name();
 
 // packed int16 wave kernel for N = 1024 (intfft_fast1024.hip)
 struct Fast1024Args {

@@ -25,8 +25,9 @@ struct intfft_plan {
     int device = 0;
     int L = 0;
     int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
-    int word = 4; // bytes of the on-chip word of the generic kernel
+    int word = 4; // bytes of the on-chip word: 4 / 8 = k_pass<int32/int64>, 2 = packed int16 (k_pass16)
     int2 *d_tw = nullptr;
+    uint2 *d_tw16f = nullptr, *d_tw16i = nullptr; // packed dot-product operand forms (k_pass16)
     std::vector<int2> h_tw;
     std::vector<PassArgs> passes;
     void *d_scratch = nullptr;
@@ -191,8 +192,8 @@ int build_passes(intfft_plan &pl)
 {
     const intfft_params &p = pl.p;
     const int L = pl.L;
-    const int umax = pl.word == 4 ? 13 : 12; // 64 KiB tiles
-    const int cmin = pl.word == 4 ? 5 : 4;   // >= 256 B contiguous per strided row
+    const int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : 12; // 64 KiB tiles
+    const int cmin = pl.word == 2 ? 6 : pl.word == 4 ? 5 : 4;    // >= 256 B contiguous per strided row
 
     std::vector<StageDesc> fwd, inv;
     int rc = INTFFT_OK;
@@ -242,7 +243,9 @@ int build_passes(intfft_plan &pl)
         a.len1 = sh.len1;
         a.pos1 = sh.len1 ? sh.pos1 : L;
         a.U = sh.len0 + sh.len1;
-        a.fpb = (a.U == L && L < 11) ? (1 << (11 - L)) : 1;
+        // frames per block: enough points that every thread owns work in every round
+        const int target = pl.word == 2 ? 13 : 11; // log2 points per block
+        a.fpb = (a.U == L && L < target) ? (1 << (target - L)) : 1;
         a.in_mode = i == 0 ? IO_USER : IO_SCRATCH;
         a.out_mode = i + 1 == shapes.size() ? IO_USER : IO_SCRATCH;
         a.in_cb = pl.in_cb;
@@ -255,6 +258,8 @@ int build_passes(intfft_plan &pl)
         a.in_zext = (!p.use_fly && p.format) ? 1 : 0;
         a.ld_swap = (a.in_mode == IO_USER && sh.len1 && scatters(p.in_order, in_rev)) ? 1 : 0;
         a.st_swap = (a.out_mode == IO_USER && sh.len1 && scatters(p.out_order, out_rev)) ? 1 : 0;
+        a.ld_memorder = (a.in_mode == IO_USER && a.U == L) ? 1 : 0;
+        a.st_memorder = (a.out_mode == IO_USER && a.U == L) ? 1 : 0;
         a.nstages = 0;
         if (p.use_fly) {
             for (StageDesc d : sh.st) {
@@ -346,6 +351,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     pl->L = p->log2n;
     intfft_io_widths(p, &pl->in_bits, &pl->out_bits, &pl->in_cb, &pl->out_cb);
     pl->word = pl->out_bits <= 32 ? 4 : 8;
+    if (pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
 
     if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK) {
         intfft_plan_destroy(pl);
@@ -363,7 +369,19 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             intfft_plan_destroy(pl);
             return rc;
         }
-        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
+                      pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+        if (pl->word == 2) {
+            const size_t total = ((size_t)1 << pl->L) - 1;
+            hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
+            if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
+            if (e == hipSuccess) e = launch_pack_twiddles16(pl->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) {
+                intfft_plan_destroy(pl);
+                return (int)e;
+            }
+        }
         if (pl->passes.size() > 1) {
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->word;
             pl->scratch_frames = std::max<size_t>(1, ((size_t)128 << 20) / frame_bytes);
@@ -386,6 +404,8 @@ int intfft_plan_destroy(intfft_plan *plan)
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        if (plan->d_tw16f) (void)hipFree(plan->d_tw16f);
+        if (plan->d_tw16i) (void)hipFree(plan->d_tw16i);
     }
     delete plan;
     return INTFFT_OK;
@@ -429,7 +449,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             const PassArgs &a = plan->passes[i];
             const void *pin = a.in_mode == IO_USER ? src : plan->d_scratch;
             void *pout = a.out_mode == IO_USER ? dst : plan->d_scratch;
-            const hipError_t e = launch_pass(a, plan->word, pin, pout, plan->d_tw, nf, stream);
+            const hipError_t e = plan->word == 2
+                                     ? launch_pass16(a, pin, pout, plan->d_tw16f, plan->d_tw16i, nf, plan->p.twdl_width, stream)
+                                     : launch_pass(a, plan->word, pin, pout, plan->d_tw, nf, stream);
             if (e != hipSuccess) return (int)e;
         }
     }

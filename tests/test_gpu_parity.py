@@ -84,8 +84,8 @@ def test_all_single_pass_lengths(log2n, mode):
         check(x, log2n, 16, 16, fmt, rnd, True, direction=direction)
 
 
-@pytest.mark.parametrize("log2n,dw,tw,fmt", [(14, 16, 16, 0), (15, 16, 16, 1), (16, 24, 24, 1), (16, 24, 16, 1),
-                                              (13, 24, 24, 1), (17, 16, 16, 0)])
+@pytest.mark.parametrize("log2n,dw,tw,fmt", [(15, 16, 16, 0), (15, 16, 16, 1), (16, 24, 24, 1), (16, 24, 16, 1),
+                                              (13, 24, 24, 1), (17, 16, 16, 0), (14, 20, 16, 0)])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_multi_pass_lengths(log2n, dw, tw, fmt, direction):
     """N beyond one LDS tile: strided + contiguous passes through plan scratch; Taylor twiddles."""

@@ -1,0 +1,64 @@
+"""Secondary measurements (NOT the bench.py contract line): every BASELINE config on one GPU.
+Gsample/s, algorithmic GB/s, roofline fraction, and a parity check of a frame prefix against the oracle."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from intfftk_amd import IntFFTCore
+from oracle import oracle_c as C
+
+CONFIGS = {
+    # name: (log2n, dw, tw, fmt, rnd, direction, batch, bits of the random data, bytes/sample)
+    "C2": (10, 16, 16, 0, 0, "FWD", 65536, 15, 8),
+    "C2r": (10, 16, 16, 0, 1, "FWD", 65536, 15, 8),
+    "C3": (16, 24, 24, 1, 0, "FWD", 4096, 23, 24),
+    "C3t16": (16, 24, 16, 1, 0, "FWD", 4096, 23, 24),
+    "C4": (20, 16, 16, 0, 0, "FWD", 1024, 15, 8),
+    "C5": (12, 16, 16, 0, 0, "PAIR", 16384, 15, 8),
+    "C2inv": (10, 16, 16, 0, 0, "INV", 65536, 15, 8),
+}
+
+
+def run(name, steps=20, check_frames=8):
+    log2n, dw, tw, fmt, rnd, direction, batch, bits, bps = CONFIGS[name]
+    n = 1 << log2n
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0xC0FFEE00 + log2n)
+    x = torch.randint(-(1 << (bits - 1)), 1 << (bits - 1), (batch, n, 2), device="cuda", dtype=core.in_dtype, generator=g)
+    y = torch.empty((batch, n, 2), device="cuda", dtype=core.out_dtype)
+    st = torch.cuda.current_stream().cuda_stream
+    t0 = time.time()
+    while time.time() - t0 < 0.25:  # clock ramp
+        for _ in range(10):
+            core.exec_raw(x.data_ptr(), y.data_ptr(), batch, st)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        core.exec_raw(x.data_ptr(), y.data_ptr(), batch, st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    p = C.make_params(log2n, dw, tw, fmt, rnd, True)
+    want = C.execute(x[:check_frames].cpu().numpy(), p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction])
+    ok = bool(np.array_equal(y[:check_frames].cpu().numpy().astype(np.int64), want))
+    gs = batch * n / ms / 1e6
+    out = {"config": name, "log2n": log2n, "batch": batch, "dir": direction, "ms": ms, "Gsample/s": gs,
+           "GB/s": gs * bps, "roofline_frac": gs * bps / 8000.0, "passes": core.info["n_passes"],
+           "kernel": core.info["kernel_name"], "parity_prefix_ok": ok}
+    core.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CONFIGS)
+    for nm in names:
+        print(json.dumps(run(nm)), flush=True)
