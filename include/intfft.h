@@ -105,6 +105,14 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
  * one plan must not be executed concurrently on two streams (plan-owned scratch). */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
 
+/* Host-resident frames (the "streaming block" use): h_in/h_out are HOST pointers with the same layout
+ * as above.  The batch is cut into chunks of `chunk_frames` frames (0 = library default) that are
+ * staged through two device slots and three HIP streams, so that the upload of chunk i+1, the
+ * transform of chunk i and the download of chunk i-1 overlap -- the software analogue of feeding
+ * the core frames back to back (int_fftNk.vhd:23-37).  Blocking; returns when h_out is complete.
+ * This is NOT a CPU execution path: every frame is transformed on the HIP device. */
+int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames);
+
 /* Parity introspection: the twiddle stream of butterfly stage `stage` (2^stage entries, the
  * values rom_twiddle_int emits for cnt = 0 .. 2^stage-1) as interleaved int32 (re, im).
  * h_out may be NULL to query *count. */

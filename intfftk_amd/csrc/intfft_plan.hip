@@ -34,8 +34,15 @@ struct intfft_plan {
     size_t scratch_frames = 0, scratch_bytes = 0;
     bool fast1024 = false;
     Fast1024Args fargs{};
+    // host-streaming state (intfft_exec_host), created on first use
+    hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
+    void *slot_in[2] = {nullptr, nullptr}, *slot_out[2] = {nullptr, nullptr};
+    size_t slot_frames = 0;
     char kernel_name[64] = {0};
 };
+
+static void free_stream_state(intfft_plan *pl);
 
 namespace {
 
@@ -404,6 +411,7 @@ int intfft_plan_destroy(intfft_plan *plan)
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        free_stream_state(plan);
         if (plan->d_tw16f) (void)hipFree(plan->d_tw16f);
         if (plan->d_tw16i) (void)hipFree(plan->d_tw16i);
     }
@@ -456,6 +464,95 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         }
     }
     return INTFFT_OK;
+}
+
+static void free_stream_state(intfft_plan *pl)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (pl->slot_in[i]) (void)hipFree(pl->slot_in[i]);
+        if (pl->slot_out[i]) (void)hipFree(pl->slot_out[i]);
+        if (pl->ev_up[i]) (void)hipEventDestroy(pl->ev_up[i]);
+        if (pl->ev_comp[i]) (void)hipEventDestroy(pl->ev_comp[i]);
+        if (pl->ev_down[i]) (void)hipEventDestroy(pl->ev_down[i]);
+        pl->slot_in[i] = pl->slot_out[i] = nullptr;
+        pl->ev_up[i] = pl->ev_comp[i] = pl->ev_down[i] = nullptr;
+    }
+    if (pl->s_up) (void)hipStreamDestroy(pl->s_up);
+    if (pl->s_comp) (void)hipStreamDestroy(pl->s_comp);
+    if (pl->s_down) (void)hipStreamDestroy(pl->s_down);
+    pl->s_up = pl->s_comp = pl->s_down = nullptr;
+    pl->slot_frames = 0;
+}
+
+int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames)
+{
+    if (!plan || (batch && (!h_in || !h_out))) return INTFFT_ERR_NULL;
+    if (batch == 0) return INTFFT_OK;
+    DeviceGuard guard(plan->device);
+    if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
+    const size_t N = (size_t)1 << plan->L;
+    const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
+    if (chunk_frames == 0) chunk_frames = std::max<size_t>(1, ((size_t)64 << 20) / std::max(in_frame, out_frame));
+    chunk_frames = std::min(chunk_frames, batch);
+    hipError_t e = hipSuccess;
+#define INTFFT_TRY(x) do { e = (x); if (e != hipSuccess) goto fail; } while (0)
+    if (plan->slot_frames < chunk_frames) {
+        free_stream_state(plan);
+        INTFFT_TRY(hipStreamCreateWithFlags(&plan->s_up, hipStreamNonBlocking));
+        INTFFT_TRY(hipStreamCreateWithFlags(&plan->s_comp, hipStreamNonBlocking));
+        INTFFT_TRY(hipStreamCreateWithFlags(&plan->s_down, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            INTFFT_TRY(hipMalloc(&plan->slot_in[i], chunk_frames * in_frame));
+            INTFFT_TRY(hipMalloc(&plan->slot_out[i], chunk_frames * out_frame));
+            INTFFT_TRY(hipEventCreateWithFlags(&plan->ev_up[i], hipEventDisableTiming));
+            INTFFT_TRY(hipEventCreateWithFlags(&plan->ev_comp[i], hipEventDisableTiming));
+            INTFFT_TRY(hipEventCreateWithFlags(&plan->ev_down[i], hipEventDisableTiming));
+        }
+        plan->slot_frames = chunk_frames;
+    }
+    {
+        // pin the caller's buffers for the duration of the call so the copies are truly asynchronous;
+        // if registration is refused the copies still work (staged by the runtime, less overlap)
+        const bool pin_in = hipHostRegister(const_cast<void *>(h_in), batch * in_frame, hipHostRegisterDefault) == hipSuccess;
+        const bool pin_out = hipHostRegister(h_out, batch * out_frame, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+        size_t i = 0;
+        for (size_t f = 0; f < batch; f += chunk_frames, ++i) {
+            const int slot = (int)(i & 1);
+            const size_t nf = std::min(chunk_frames, batch - f);
+            // upload: the slot's input buffer is free once the transform that last read it is done
+            if (i >= 2) e = hipStreamWaitEvent(plan->s_up, plan->ev_comp[slot], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(plan->slot_in[slot], static_cast<const char *>(h_in) + f * in_frame, nf * in_frame,
+                                   hipMemcpyHostToDevice, plan->s_up);
+            if (e == hipSuccess) e = hipEventRecord(plan->ev_up[slot], plan->s_up);
+            // transform: needs the upload, and the previous download out of this slot's output buffer
+            if (e == hipSuccess) e = hipStreamWaitEvent(plan->s_comp, plan->ev_up[slot], 0);
+            if (e == hipSuccess && i >= 2) e = hipStreamWaitEvent(plan->s_comp, plan->ev_down[slot], 0);
+            if (e == hipSuccess) {
+                const int rc = intfft_exec(plan, plan->slot_in[slot], plan->slot_out[slot], nf, plan->s_comp);
+                if (rc != INTFFT_OK) e = rc > 0 ? (hipError_t)rc : hipErrorUnknown;
+            }
+            if (e == hipSuccess) e = hipEventRecord(plan->ev_comp[slot], plan->s_comp);
+            // download
+            if (e == hipSuccess) e = hipStreamWaitEvent(plan->s_down, plan->ev_comp[slot], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(static_cast<char *>(h_out) + f * out_frame, plan->slot_out[slot], nf * out_frame,
+                                   hipMemcpyDeviceToHost, plan->s_down);
+            if (e == hipSuccess) e = hipEventRecord(plan->ev_down[slot], plan->s_down);
+            if (e != hipSuccess) break;
+        }
+        const hipError_t e2 = hipStreamSynchronize(plan->s_down);
+        const hipError_t e3 = hipStreamSynchronize(plan->s_comp);
+        const hipError_t e4 = hipStreamSynchronize(plan->s_up);
+        if (pin_in) (void)hipHostUnregister(const_cast<void *>(h_in));
+        if (pin_out) (void)hipHostUnregister(h_out);
+        if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4;
+    }
+    if (e == hipSuccess) return INTFFT_OK;
+fail:
+#undef INTFFT_TRY
+    return (int)e;
 }
 
 int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count)

@@ -122,6 +122,17 @@ class IntFFTCore:
         """Straight intfft_exec on raw device pointers (bench loop: no tensor bookkeeping)."""
         capi.check(capi.lib().intfft_exec(self._plan, in_ptr, out_ptr, batch, stream), "intfft_exec")
 
+    def exec_host(self, x: np.ndarray, chunk_frames: int = 0) -> np.ndarray:
+        """Host-resident frames through intfft_exec_host: chunked, double-buffered H2D / transform / D2H
+        on three streams (every frame is still transformed on the GPU)."""
+        x = np.ascontiguousarray(x, dtype=_NP_DT[self.in_container])
+        if x.ndim != 3 or x.shape[1] != self.n or x.shape[2] != 2:
+            raise ValueError("input must be [batch, %d, 2]" % self.n)
+        out = np.empty((x.shape[0], self.n, 2), dtype=_NP_DT[self.out_container])
+        capi.check(capi.lib().intfft_exec_host(self._plan, x.ctypes.data, out.ctypes.data, x.shape[0], chunk_frames),
+                   "intfft_exec_host")
+        return out
+
     def twiddles(self, stage: int) -> np.ndarray:
         """[2^stage, 2] int32 (re, im): what rom_twiddle_int emits for cnt = 0..2^stage-1."""
         cnt = ctypes.c_size_t()
