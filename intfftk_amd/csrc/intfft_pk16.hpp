@@ -1,0 +1,225 @@
+// intfft_pk16.hpp -- packed-int16 butterfly arithmetic shared by the wave / block kernels
+// (intfft_fast1024.hip, intfft_fast4096.hip).  See intfft_fast1024.hip for the derivations:
+// v_dot2 multiplies from hazard-safe asm blocks, pre-shifted outputs, fast extraction under the
+// per-frame guard-bit condition, quarter-turn twiddle sharing.
+#pragma once
+
+#include "intfft_internal.hpp"
+
+namespace intfft {
+
+using u32 = uint32_t;
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s as_v2s(u32 x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x); }
+
+// result slicing of the exact 32-bit sums (t = TWDL_WIDTH)
+struct Slice {
+    int off_y;  // t - 1: Y      = sum[t+14 : t-1]
+    int off_y1; // t    : Y >> 1 = sext(sum[t+14 : t])
+    u32 sel;    // v_perm_b32 selector {S0.b1, S0.b0, S1.b1, S1.b0} (exact extraction)
+    u32 sel_hi; // v_perm_b32 selector {S0.b3, S0.b2, S1.b3, S1.b2} (fast extraction)
+};
+
+__device__ __forceinline__ u32 pack_wa(int2 w) { return ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16); }
+__device__ __forceinline__ u32 pack_wb(int2 w) { return ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16); }
+
+// ---- sum / difference ---------------------------------------------------------------------------
+// PRE: the inputs already hold A >> 1, B >> 1 (truncate mode only).
+template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u32 b, u32 &s, u32 &d)
+{
+    const v2s A = as_v2s(a), B = as_v2s(b);
+    if (!ROUND) { // int_dif2_fly.vhd:144-164
+        const v2s A1 = PRE ? A : A >> (short)1, B1 = PRE ? B : B >> (short)1;
+        s = as_u32(A1 + B1);
+        d = as_u32(A1 - B1);
+    } else { // :167-219  rhu2(A+B) = (A|B) - ((A^B)>>1);  rhu2(A-B) = (A>>1) - (B>>1) + (A & ~B & 1)
+        s = as_u32((A | B) - ((A ^ B) >> (short)1));
+        const v2s one = {1, 1};
+        d = as_u32((A >> (short)1) - (B >> (short)1) + ((A & ~B) & one));
+    }
+}
+// truncate mode with a per-lane shift amount (0 where the lane's registers already hold X >> 1)
+__device__ __forceinline__ void sumdiff_var(u32 a, u32 b, v2s sh, u32 &s, u32 &d)
+{
+    const v2s A1 = as_v2s(a) >> sh, B1 = as_v2s(b) >> sh;
+    s = as_u32(A1 + B1);
+    d = as_u32(A1 - B1);
+}
+
+// ---- complex multiplies: cmult_{16,t}(D, W), single-DSP regime (int_cmult_dsp48.vhd:184-225) ----
+// dr/di are the data operands of the re / im dot products (equal for a table twiddle; (D, -D) with
+// the base twiddle's (Wb, Wa) for a quarter-turn twiddle).  SG: twiddles in SGPRs.
+#define INTFFT_MUL2X_BODY                                                                              \
+    "v_dot2_i32_i16 %[r0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[r1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_bfe_i32 %[y0], %[r0], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[r0], %[i0], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[y1], %[r1], %[off], %[wd]\n\t"                                                        \
+    "v_bfe_i32 %[i0], %[i1], %[off], %[wd]\n\t"                                                        \
+    "v_perm_b32 %[y0], %[r0], %[y0], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y1], %[i0], %[y1], %[sel]"
+
+// exact extraction, 2 butterflies: (off, WIDTH) = (t-1, 16) -> Y, (t, 15) -> Y >> 1
+template <int WIDTH, bool SG>
+__device__ __forceinline__ void mul2x(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr1, u32 di1, u32 wa1, u32 wb1,
+                                      int off, u32 sel, u32 &y0, u32 &y1)
+{
+    u32 r0, i0, r1, i1;
+    if (SG)
+        asm(INTFFT_MUL2X_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "s"(wa0), [wb0] "s"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
+              [wa1] "s"(wa1), [wb1] "s"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+    else
+        asm(INTFFT_MUL2X_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
+              [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+}
+
+#define INTFFT_MUL4F_BODY                                                                              \
+    "v_dot2_i32_i16 %[y0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y2], %[dr2], %[wa2], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i2], %[di2], %[wb2], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[y3], %[dr3], %[wa3], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i3], %[di3], %[wb3], 0\n\t"                                                      \
+    "v_perm_b32 %[y0], %[i0], %[y0], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y1], %[i1], %[y1], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y2], %[i2], %[y2], %[sel]\n\t"                                                       \
+    "v_perm_b32 %[y3], %[i3], %[y3], %[sel]"
+
+// fast extraction, 4 butterflies, t = 16, no 31-bit overflow: Y >> 1 = { im[31:16], re[31:16] }
+template <bool SG>
+__device__ __forceinline__ void mul4f(const u32 (&dr)[4], const u32 (&di)[4], const u32 (&wa)[4], const u32 (&wb)[4],
+                                      u32 sel, u32 (&y)[4])
+{
+    u32 i0, i1, i2, i3;
+    if (SG)
+        asm(INTFFT_MUL4F_BODY
+            : [y0] "=&v"(y[0]), [y1] "=&v"(y[1]), [y2] "=&v"(y[2]), [y3] "=&v"(y[3]), [i0] "=&v"(i0), [i1] "=&v"(i1),
+              [i2] "=&v"(i2), [i3] "=&v"(i3)
+            : [dr0] "v"(dr[0]), [di0] "v"(di[0]), [dr1] "v"(dr[1]), [di1] "v"(di[1]), [dr2] "v"(dr[2]), [di2] "v"(di[2]),
+              [dr3] "v"(dr[3]), [di3] "v"(di[3]), [wa0] "s"(wa[0]), [wb0] "s"(wb[0]), [wa1] "s"(wa[1]), [wb1] "s"(wb[1]),
+              [wa2] "s"(wa[2]), [wb2] "s"(wb[2]), [wa3] "s"(wa[3]), [wb3] "s"(wb[3]), [sel] "s"(sel));
+    else
+        asm(INTFFT_MUL4F_BODY
+            : [y0] "=&v"(y[0]), [y1] "=&v"(y[1]), [y2] "=&v"(y[2]), [y3] "=&v"(y[3]), [i0] "=&v"(i0), [i1] "=&v"(i1),
+              [i2] "=&v"(i2), [i3] "=&v"(i3)
+            : [dr0] "v"(dr[0]), [di0] "v"(di[0]), [dr1] "v"(dr[1]), [di1] "v"(di[1]), [dr2] "v"(dr[2]), [di2] "v"(di[2]),
+              [dr3] "v"(dr[3]), [di3] "v"(di[3]), [wa0] "v"(wa[0]), [wb0] "v"(wb[0]), [wa1] "v"(wa[1]), [wb1] "v"(wb[1]),
+              [wa2] "v"(wa[2]), [wb2] "v"(wb[2]), [wa3] "v"(wa[3]), [wb3] "v"(wb[3]), [sel] "s"(sel));
+}
+
+// ---- a group of four general butterflies (a_i, b_i): a_i <- S, b_i <- cmult(D, W_i) ---------------
+//   FASTX   fast extraction (implies truncate mode and pre-shifted outputs)
+//   QTURN   the twiddles are the quarter turns of the given base twiddles
+//   OUT_PRE emit Y >> 1 (truncate mode)
+//   SG      twiddles in SGPRs
+//   PREMASK bit i: inputs of butterfly i already hold X >> 1;  VARSH: per-lane shift amount instead
+template <bool ROUND, bool FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false>
+__device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
+                                       const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl, v2s shv = v2s{0, 0})
+{
+    static_assert(!FASTX || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
+    static_assert(!QTURN || !ROUND, "quarter-turn sharing needs an exact -D");
+    u32 d[4];
+    if (VARSH) {
+        sumdiff_var(a0, b0, shv, a0, d[0]);
+        sumdiff_var(a1, b1, shv, a1, d[1]);
+        sumdiff_var(a2, b2, shv, a2, d[2]);
+        sumdiff_var(a3, b3, shv, a3, d[3]);
+    } else {
+        sumdiff<ROUND, (PREMASK & 1) != 0>(a0, b0, a0, d[0]);
+        sumdiff<ROUND, (PREMASK & 2) != 0>(a1, b1, a1, d[1]);
+        sumdiff<ROUND, (PREMASK & 4) != 0>(a2, b2, a2, d[2]);
+        sumdiff<ROUND, (PREMASK & 8) != 0>(a3, b3, a3, d[3]);
+    }
+    u32 y[4];
+    if (QTURN) {
+        const v2s z = {0, 0};
+        const u32 n[4] = {as_u32(z - as_v2s(d[0])), as_u32(z - as_v2s(d[1])), as_u32(z - as_v2s(d[2])),
+                          as_u32(z - as_v2s(d[3]))};
+        if (FASTX) {
+            mul4f<SG>(d, n, wb, wa, sl.sel_hi, y);
+        } else {
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[0], n[0], wb[0], wa[0], d[1], n[1], wb[1], wa[1],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[2], n[2], wb[2], wa[2], d[3], n[3], wb[3], wa[3],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+        }
+    } else {
+        if (FASTX) {
+            mul4f<SG>(d, d, wa, wb, sl.sel_hi, y);
+        } else {
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+            mul2x<OUT_PRE ? 15 : 16, SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3],
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+        }
+    }
+    b0 = y[0];
+    b1 = y[1];
+    b2 = y[2];
+    b3 = y[3];
+}
+
+// STAGE 0 and even positions of STAGE 1: Y = D (int_dif2_fly.vhd:245-255, :293-296)
+template <bool ROUND, bool IN_PRE> __device__ __forceinline__ void bfly_triv(u32 &a, u32 &b)
+{
+    u32 s, d;
+    sumdiff<ROUND, IN_PRE>(a, b, s, d);
+    a = s;
+    b = d;
+}
+
+// odd positions of STAGE 1: Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re (int_dif2_fly.vhd:297-304)
+template <bool ROUND, bool IN_PRE> __device__ __forceinline__ void bfly_mj(u32 &a, u32 &b)
+{
+    u32 s, d;
+    sumdiff<ROUND, IN_PRE>(a, b, s, d);
+    a = s;
+    const u32 rot = __builtin_amdgcn_alignbit(d, d, 16); // lo = D.im, hi = D.re
+    const u32 nx = rot ^ 0xFFFF0000u;                     // hi = ~D.re
+    b = nx + ((nx >> 31) << 16);                          // + 1 in the high half iff D.re >= 0
+}
+
+// lane-half / row exchanges; the leading s_nop covers "VALU write -> v_permlane read" (2 wait
+// states) for producers hipcc cannot see (the asm multiplies above)
+__device__ __forceinline__ void swap32(u32 &a, u32 &b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(u32 &a, u32 &b)
+{
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// Guard-bit test of one frame (wave-uniform result).  t = x + 0x40004000 has bit 15 / bit 31 clear
+// for every sample iff re in [-2^14, 2^14) and im in [-2^14 - 1, 2^14) (the low half may carry
+// into the high half).  Then |z| <= 23172 for every input sample z.  Through a scaled-truncate
+// stage the complex magnitude M grows by at most 1.42 (floors: <= 0.71 on S and D, twiddle
+// magnitude <= 32767.71, final floor 0.71), so M <= 23187 at every butterfly input, |D| <= M + 0.71,
+// and |re|, |im| of D*W are <= 23188 * 32767.71 < 2^30: bit 31 equals bit 30 in every sum, which is
+// what fast extraction needs.  (The bound that would actually be needed is M <= 32752.)
+// guard_acc(): per-lane accumulator; a frame is safe iff no lane of any of its waves has a flagged bit
+__device__ __forceinline__ u32 guard_acc(const u32 (&v)[16])
+{
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc |= v[j] + 0x40004000u;
+    return acc & 0x80008000u;
+}
+__device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16])
+{
+    return __builtin_amdgcn_ballot_w64(guard_acc(v) != 0) == 0;
+}
+
+
+} // namespace intfft
