@@ -1,0 +1,195 @@
+// intfft_fast1024x.hip -- packed-int16 wave kernel for N = 1024, inverse core and FFT->IFFT pair:
+// int_ifftNk / int_fft_ifft_pair with NFFT = 10, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate,
+// natural-order input and output (src/vhdl/fft/int_ifftNk.vhd:71-343,
+// src/vhdl/main/int_fft_ifft_pair.vhd:209-280).  (The forward core alone is intfft_fast1024.hip.)
+//
+// Same wave-per-frame mapping as the forward kernel, run in both directions:
+//
+//   L1  reg = n9..6, lane = n5..0                              DIF 9,8,7,6         / DIT 6,7,8,9
+//       v_permlane32_swap (lane5 <-> reg bit 3): stage 5;  v_permlane16_swap (lane4 <-> reg bit 2): stage 4
+//   LC  reg = n3..0, lane = rev6(n9..4)  (via the wave-private LDS transpose)   DIF 3..0 / DIT 0..3
+//
+// The pair stays in LC between the two cores (position n holds X[bitrev(n)], exactly what int_ifftNk
+// expects there: int_fft_ifft_pair.vhd:242-280).  The inverse alone loads into LC with the bit reversal
+// folded into the addressing (256 contiguous bytes per load instruction).  Twiddles are held once, in
+// the DIF packing, and shared by both directions (re/im-swapped multiplier feed, int_dit2_fly.vhd:304-322).
+#include "intfft_pk16.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+constexpr int ROWX = 20;
+
+enum { X_INV = 1, X_PAIR = 2 };
+
+template <int MODE, bool FAST_OK>
+__global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
+                                                      const RoundCConsts c, size_t nframes, const Slice sl)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROWX];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *lds = lds_all + wv * 64 * ROWX;
+
+    // frame-invariant twiddles: stages 9..6 (reg offsets 8,4,2,1; index 64*jj + lane), 5 and 4
+    RoundTw ta;
+    u32 wa5, wb5, wa4, wb4;
+    auto ld = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = twt[idx];
+        wa = pack_wa(w);
+        wb = pack_wb(w);
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld(511 + 64 * j + lane, ta.wa8[j], ta.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld(255 + 64 * j + lane, ta.wa4[j], ta.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld(127 + 64 * j + lane, ta.wa2[j], ta.wb2[j]);
+    ld(63 + lane, ta.wa1[0], ta.wb1[0]);
+    ld(31 + (lane & 31), wa5, wb5);
+    ld(15 + (lane & 15), wa4, wb4);
+    const u32 w5a[4] = {wa5, wa5, wa5, wa5}, w5b[4] = {wb5, wb5, wb5, wb5};
+    const u32 w4a[4] = {wa4, wa4, wa4, wa4}, w4b[4] = {wb4, wb4, wb4, wb4};
+
+    // LDS transpose addressing.  "mid" layout (after / before the lane swaps): lane5 = n9, lane4 = n8,
+    // lane3..0 = n3..0; reg j3 = n5, j2 = n4, j1 = n7, j0 = n6.   LC: reg = n3..0, lane bit i = n(9-i).
+    // forward (mid -> LC): element (lane t, reg j) -> row = LC lane, column = n3..0
+    const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
+    u32 *wr_f = lds + ROWX * (t5 + 2 * t4) + (lane & 15); // + ROWX * (4 j1 + 8 j0 + 16 j3 + 32 j2)
+    // inverse (LC -> mid): element (lane l, reg r) -> row = mid lane (32 n9 + 16 n8 + r), column = mid reg
+    const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1, l4 = (lane >> 4) & 1,
+              l5 = lane >> 5; // l_i = n(9-i)
+    u32 *wr_i = lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
+    const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWX * lane);
+    const short s3 = (short)(1 - (lane >> 5)); // LC: kind = n4 = lane bit 5
+    const v2s sh3 = {s3, s3};
+
+    const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
+    for (size_t f = wave0; f < nframes; f += nwaves) {
+        u32 v[16];
+        const u32 *src = in + f * 1024;
+        if (MODE == X_INV) { // LC: v[r] = X[rev10(n)] = X[64 * rev4(r) + lane]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+                v[r] = __builtin_nontemporal_load(src + 64 * rr + lane);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j + lane);
+        }
+        const bool fast = FAST_OK && frame_has_guard_bit(v);
+
+#define INTFFT_XBODY(FX)                                                                                \
+    {                                                                                                   \
+        if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
+            dif_round<FX, false>(v, ta, sl, sh3);                                                       \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
+            group4<false, FX, false, true, false, 0xA>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
+            group4<false, FX, false, true, false, 0xA>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
+            group4<false, FX, false, true, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
+            group4<false, FX, false, true, false, 0xF>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+            asm volatile("" ::: "memory");                                                              \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
+            {                                                                                           \
+                const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;          \
+                wr_f[ROWX * (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2)] = v[j];                              \
+            }                                                                                           \
+            asm volatile("" ::: "memory");                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+            {                                                                                           \
+                const uint4 x = rd_base[q];                                                             \
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;             \
+            }                                                                                           \
+            asm volatile("" ::: "memory");                                                              \
+            dif_round_c<FX>(v, c, sl, sh3);                                                             \
+        }                                                                                               \
+        /* inverse core: LC -> L1 */                                                                    \
+        dit_round_c<FX>(v, c, sl);                                                                      \
+        asm volatile("" ::: "memory");                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) wr_i[ROWX * r] = v[r];                           \
+        asm volatile("" ::: "memory");                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
+        {                                                                                               \
+            const uint4 x = rd_base[q];                                                                 \
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;                 \
+        }                                                                                               \
+        asm volatile("" ::: "memory");                                                                  \
+        group4_dit<FX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);            \
+        group4_dit<FX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl);      \
+        _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);               \
+        group4_dit<FX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);          \
+        group4_dit<FX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl);        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
+        dit_round<FX>(v, ta, sl);                                                                       \
+    }
+        if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
+        else INTFFT_XBODY(false)
+#undef INTFFT_XBODY
+        u32 *dst = out + f * 1024 + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + 64 * j);
+    }
+}
+
+bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
+                         int use_fly, int in_order, int out_order)
+{
+    return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+           (direction == 1 || direction == 2) && use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
+
+template <int MODE, bool FAST_OK>
+static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
+                          const Slice &sl, hipStream_t stream)
+{
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024x_i16<MODE, FAST_OK>, 256, 0) != hipSuccess ||
+            per_cu <= 0)
+            per_cu = 4;
+        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    }
+    const size_t need = (nframes + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    const unsigned blocks = (unsigned)(need < cap ? need : cap);
+    hipLaunchKernelGGL((k_fft1024x_i16<MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast1024x(int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+                            size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    RoundCConsts c;
+    for (int k = 0; k < 8; ++k) {
+        const int2 w = h_tw[7 + k];
+        c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int2 w = h_tw[3 + k];
+        c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fast_ok = twd == 16 && allow_fast;
+    const u32 *pin = static_cast<const u32 *>(in);
+    u32 *pout = static_cast<u32 *>(out);
+    if (direction == 1)
+        return fast_ok ? launchx<X_INV, true>(pin, pout, tw_all, c, nframes, sl, stream)
+                       : launchx<X_INV, false>(pin, pout, tw_all, c, nframes, sl, stream);
+    return fast_ok ? launchx<X_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
+                   : launchx<X_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
+}
+
+} // namespace intfft

@@ -222,4 +222,145 @@ __device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16])
 }
 
 
+// ---- reusable rounds (four stages in registers) for the wave / block kernels ----------------------
+// wave-uniform twiddles of stages 3 and 2, both packings (kernel argument -> SGPRs)
+struct RoundCConsts {
+    u32 wa3[8], wb3[8]; // STAGE 3: table index r & 7
+    u32 wa2[4], wb2[4]; // STAGE 2: table index r & 3
+};
+
+// frame-invariant per-thread twiddles of one round: stage with register offset 8 / 4 / 2 / 1
+struct RoundTw {
+    u32 wa8[8], wb8[8], wa4[4], wb4[4], wa2[2], wb2[2], wa1[1], wb1[1];
+};
+
+__device__ __forceinline__ constexpr int rev4c(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// ---- DIT group of four general butterflies: a_i <- X, b_i <- Y (int_dit2_fly.vhd:142-162, 290-325) ----
+template <bool FASTX, bool SG>
+__device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
+                                           const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl)
+{
+    const u32 bs[4] = {__builtin_amdgcn_alignbit(b0, b0, 16), __builtin_amdgcn_alignbit(b1, b1, 16),
+                       __builtin_amdgcn_alignbit(b2, b2, 16), __builtin_amdgcn_alignbit(b3, b3, 16)};
+    u32 t[4]; // T >> 1
+    if (FASTX) {
+        mul4f<SG>(bs, bs, wb, wa, sl.sel_hi, t);
+    } else {
+        mul2x<15, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y1, sl.sel, t[0], t[1]);
+        mul2x<15, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y1, sl.sel, t[2], t[3]);
+    }
+    const v2s A0 = as_v2s(a0) >> (short)1, A1 = as_v2s(a1) >> (short)1, A2 = as_v2s(a2) >> (short)1,
+              A3 = as_v2s(a3) >> (short)1;
+    a0 = as_u32(A0 + as_v2s(t[0]));
+    b0 = as_u32(A0 - as_v2s(t[0]));
+    a1 = as_u32(A1 + as_v2s(t[1]));
+    b1 = as_u32(A1 - as_v2s(t[1]));
+    a2 = as_u32(A2 + as_v2s(t[2]));
+    b2 = as_u32(A2 - as_v2s(t[2]));
+    a3 = as_u32(A3 + as_v2s(t[3]));
+    b3 = as_u32(A3 - as_v2s(t[3]));
+}
+
+// DIT STAGE 1, odd positions: T.im = B.re, T.re = B.im >= 0 ? -B.im : ~B.im (int_dit2_fly.vhd:264-276)
+__device__ __forceinline__ void bfly_pj_dit(u32 &a, u32 &b)
+{
+    const u32 rot = __builtin_amdgcn_alignbit(b, b, 16); // lo = B.im, hi = B.re
+    const u32 nx = rot ^ 0x0000FFFFu;                     // lo = ~B.im
+    const v2s add = {(short)((nx >> 15) & 1u), 0};        // + 1 in the low half iff B.im >= 0
+    const u32 t = as_u32(as_v2s(nx) + add);
+    sumdiff<false, false>(a, t, a, b);
+}
+
+// ---- four DIF stages on register offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0) -----------------------
+// kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount
+template <bool FASTX, bool VARSH0>
+__device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl, v2s shv)
+{
+    constexpr int M0 = 0, MA = 0xF;
+    {
+        const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
+        const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
+        group4<false, FASTX, false, true, false, M0, VARSH0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
+        group4<false, FASTX, false, true, false, M0, VARSH0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
+    }
+    // offset 4: pairs (j, j+4); kind = j & 8
+    group4<false, FASTX, false, true, false, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+    group4<false, FASTX, false, true, false, MA>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+    // offset 2: pairs (j, j+2); twiddle j & 1; kind = j & 4
+    {
+        const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
+        group4<false, FASTX, false, true, false, M0>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+    }
+    // offset 1: pairs (j, j+1); kind = j & 2
+    {
+        const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
+        group4<false, FASTX, false, true, false, M0>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+    }
+}
+
+// ---- four DIT stages on register offsets 1, 2, 4, 8 --------------------------------------------------
+template <bool FASTX>
+__device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)
+{
+    {
+        const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
+        group4_dit<FASTX, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
+        group4_dit<FASTX, false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
+    }
+    {
+        const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
+        group4_dit<FASTX, false>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
+        group4_dit<FASTX, false>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
+    }
+    group4_dit<FASTX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+    group4_dit<FASTX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+    {
+        const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
+        const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
+        group4_dit<FASTX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4_dit<FASTX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+    }
+}
+
+// ---- round C: DIF stages 3,2,1,0 / DIT stages 0,1,2,3 on reg = n3..0, uniform twiddles ----------------
+template <bool FASTX> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
+{
+    const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    group4<false, FASTX, false, true, true, 0, true>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
+    group4<false, FASTX, false, true, true, 0, true>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
+    group4<false, FASTX, false, true, true, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+    group4<false, FASTX, false, true, true, 0xF>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8) { // stage 1: kind = r & 4
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_mj<false, false>(v[g + 1], v[g + 3]);
+        bfly_triv<false, true>(v[g + 4], v[g + 6]);
+        bfly_mj<false, true>(v[g + 5], v[g + 7]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
+}
+
+template <bool FASTX> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_pj_dit(v[g + 1], v[g + 3]);
+    }
+    group4_dit<FASTX, true>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+    const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    group4_dit<FASTX, true>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+    group4_dit<FASTX, true>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+}
+
+
 } // namespace intfft

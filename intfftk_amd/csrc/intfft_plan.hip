@@ -34,6 +34,7 @@ struct intfft_plan {
     size_t scratch_frames = 0, scratch_bytes = 0;
     bool fast1024 = false;
     bool fast4096 = false;
+    bool fast1024x = false;
     Fast1024Args fargs{};
     // host-streaming state (intfft_exec_host), created on first use
     hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
@@ -369,8 +370,12 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                                       p->direction, p->use_fly, p->in_order, p->out_order);
     pl->fast4096 = !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
                                                        p->use_fly, p->in_order, p->out_order);
+    pl->fast1024x = fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
+                                        p->use_fly, p->in_order, p->out_order);
     if (pl->fast4096) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096_kernel_name());
+    } else if (pl->fast1024x) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024x_kernel_name());
     } else if (pl->fast1024) {
         pl->fargs.twd = p->twdl_width;
         pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
@@ -432,7 +437,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x;
     info->n_passes = fast ? 1 : (int)plan->passes.size();
     info->compute_word = fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
@@ -450,6 +455,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+    if (plan->fast1024x)
+        return (int)launch_fast1024x(plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(),
+                                     batch, stream);
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(),
                                     batch, stream);
