@@ -31,7 +31,7 @@ template <typename T> __device__ __forceinline__ void store_user(void *base, int
 }
 
 template <typename T>
-__global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const void *in, void *out,
+__global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in, void *out,
                                                        const int2 *__restrict__ tw, size_t nframes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
     const unsigned total = nf << U;
 
     // ---- load -------------------------------------------------------------------------------
-    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+    for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
         unsigned u = a.ld_swap ? swap_runs(v) : v;
         unsigned j = spread(u);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
         const StageDesc st = a.st[si];
         const unsigned lowm = (1u << st.lb) - 1u;
         const unsigned km = (1u << st.s) - 1u;
-        for (unsigned q = threadIdx.x; q < nbf; q += PASS_THREADS) {
+        for (unsigned q = threadIdx.x; q < nbf; q += blockDim.x) {
             const unsigned f = q >> (U - 1), qq = q & ((tile_n >> 1) - 1u);
             const unsigned u0 = ((qq >> st.lb) << (st.lb + 1)) | (qq & lowm);
             const unsigned u1 = u0 | (1u << st.lb);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
     }
 
     // ---- store ------------------------------------------------------------------------------
-    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+    for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
         unsigned u = a.st_swap ? swap_runs(v) : v;
         unsigned j = spread(u);
@@ -150,6 +150,13 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass(const PassArgs a, const v
             reinterpret_cast<Cx<T> *>(out)[(f0 + f) * N + j] = c;
         }
     }
+}
+
+// big tiles leave room for only 2 workgroups per CU: give those workgroups 1024 threads
+unsigned pass_threads(const PassArgs &a)
+{
+    const size_t elems = (size_t)a.fpb << a.U;
+    return elems >= 8192 ? 1024u : elems >= 4096 ? 512u : (unsigned)PASS_THREADS;
 }
 
 size_t pass_lds_bytes(const PassArgs &a, int word_bytes)
@@ -178,7 +185,7 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr32 = true;
         }
-        hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(PASS_THREADS), lds, stream, a, in,
+        hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes);
     } else {
         static bool attr64 = false;
@@ -187,7 +194,7 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr64 = true;
         }
-        hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(PASS_THREADS), lds, stream, a, in,
+        hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes);
     }
     return hipGetLastError();

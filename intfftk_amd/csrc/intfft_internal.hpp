@@ -48,6 +48,7 @@ struct PassArgs {
 hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
                        size_t nframes, hipStream_t stream);
 size_t pass_lds_bytes(const PassArgs &a, int word_bytes);
+unsigned pass_threads(const PassArgs &a);
 const char *pass_kernel_name(int word_bytes);
 
 hipError_t launch_twiddle_stage(const int2 *d_rom, int stage, int twd, int xser, int2 *d_out,

@@ -161,7 +161,7 @@ __device__ __forceinline__ void round16(u32 *lds, unsigned e, int lb_lo, int s_l
     for (int r = 0; r < P; ++r) lds[pad16(e + ((unsigned)r << lb_lo))] = v[r];
 }
 
-__global__ __launch_bounds__(PASS_THREADS) void k_pass16(const PassArgs a, const void *in, void *out,
+__global__ __launch_bounds__(1024) void k_pass16(const PassArgs a, const void *in, void *out,
                                                          const uint2 *__restrict__ twf,
                                                          const uint2 *__restrict__ twi, size_t nframes, int tsh)
 {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass16(const PassArgs a, const
     u32 *uout = reinterpret_cast<u32 *>(out);
 
     // ---- load ----
-    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+    for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
         unsigned u = a.ld_swap ? swap_runs(v) : v;
         const unsigned j = spread(u);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass16(const PassArgs a, const
         const uint2 *tw = st.kind == KIND_DIF ? twf : twi;
         const unsigned ngroups = nf << (U - R);
         const unsigned lowm = (1u << lb_lo) - 1u;
-        for (unsigned g = threadIdx.x; g < ngroups; g += PASS_THREADS) {
+        for (unsigned g = threadIdx.x; g < ngroups; g += blockDim.x) {
             const unsigned f = g >> (U - R), gg = g & ((tile_n >> R) - 1u);
             const unsigned u0 = ((gg >> lb_lo) << (lb_lo + R)) | (gg & lowm);
             const unsigned kb = spread(u0) & ((1u << s_lo) - 1u);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(PASS_THREADS) void k_pass16(const PassArgs a, const
     }
 
     // ---- store ----
-    for (unsigned i = threadIdx.x; i < total; i += PASS_THREADS) {
+    for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
         const unsigned f = i >> U, v = i & (tile_n - 1u);
         unsigned u = a.st_swap ? swap_runs(v) : v;
         const unsigned j = spread(u);
@@ -303,7 +303,7 @@ hipError_t launch_pass16(const PassArgs &a, const void *in, void *out, const uin
                                   160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(k_pass16, dim3((unsigned)blocks), dim3(PASS_THREADS), pass16_lds_bytes(a), stream, a, in, out,
+    hipLaunchKernelGGL(k_pass16, dim3((unsigned)blocks), dim3(pass_threads(a)), pass16_lds_bytes(a), stream, a, in, out,
                        twf, twi, nframes, twd - 1);
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -201,7 +202,10 @@ int build_passes(intfft_plan &pl)
 {
     const intfft_params &p = pl.p;
     const int L = pl.L;
-    const int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : 12; // 64 KiB tiles
+    int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : 12; // 64 KiB tiles
+    // packed multi-pass plans: 16 KiB tiles (many workgroups per CU) beat 64 KiB ones (measured on C4)
+    if (pl.word == 2 && L > umax) umax = 12;
+    if (const char *e = getenv("INTFFT_TILE_LOG2")) umax = atoi(e) >= 8 && atoi(e) <= umax ? atoi(e) : umax; // diagnostics
     const int cmin = pl.word == 2 ? 6 : pl.word == 4 ? 5 : 4;    // >= 256 B contiguous per strided row
 
     std::vector<StageDesc> fwd, inv;
