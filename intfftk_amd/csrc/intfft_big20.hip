@@ -1,0 +1,268 @@
+// intfft_big20.hip -- three-pass packed-int16 kernels for N = 2^20 (BASELINE config 4):
+// int_fftNk with NFFT = 20, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural in -> natural out
+// (stages 19..11 read the Taylor twiddle tables of row_twiddle_tay.vhd, built by k_twiddle_stage).
+//
+// A 2^20-point frame is 4 MiB: three passes through a plan-owned scratch, every global access a full
+// 128-byte line, every butterfly lane-local (same packed arithmetic as intfft_fast1024.hip):
+//
+//   pass 1  stages 19..12   tile = 256 values of n19..12  x  32 consecutive n (128-B rows, stride 4096)
+//                           512 threads, regs = n19..16 -> LDS transpose -> regs = n15..12, in: user, out: scratch
+//   pass 2  stages 11..4    tile = 4096 consecutive n (16 KiB), 256 threads, regs = n11..8 -> LDS -> regs = n7..4
+//                           -> LDS back -> coalesced store, scratch in place; twiddles frame invariant
+//   pass 3  stages 3..0 + bit reversal (int_bitrev_order.vhd:82-104)
+//                           tile = 256 values of n19..12 x 32 consecutive n (n4..0), 512 threads, LDS transpose to
+//                           regs = n3..0, thread = (n4, rev8(n19..12)): every store writes 256 contiguous bytes
+//
+// Values travel between passes in the packed form the next stage consumes: multiplier outputs are
+// emitted as Y >> 1 (truncate mode only ever reads Y >> 1), so an element's "kind" (S or Y >> 1) after
+// pass 1 is index bit 12 and after pass 2 is index bit 4; the consuming pass shifts by a per-thread amount.
+#include "intfft_pk16.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+constexpr int L20 = 20;
+constexpr int ROWB = 17; // LDS row stride in dwords: odd -> conflict-free b32 rows and columns
+
+__device__ __forceinline__ constexpr int rev4b(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+__device__ __forceinline__ void ld_tw(const uint2 *__restrict__ t, unsigned idx, u32 &wa, u32 &wb)
+{
+    const uint2 w = t[idx];
+    wa = w.x;
+    wb = w.y;
+}
+
+// ---- pass 1: stages 19..12 ---------------------------------------------------------------------------
+// grid = 128 chunks x G frame groups; a workgroup keeps its chunk's 30 twiddle pairs in registers and walks
+// the frames g, g + G, ... of the launch (the twiddles depend on the chunk, not on the frame)
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes,
+                                                  unsigned groups, const Slice sl)
+{
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n15..12 (round 1) / n19..16 (round 2)
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..127
+    const unsigned lfull = chunk * 32 + l;                                   // n11..0
+
+    // round 1: stages 19..16; twiddle index = (n mod 2^s) = ((j mod 2^i) * 16 + hx) * 4096 + lfull
+    // round 2: stages 15..12; twiddle index = (reg mod 2^i) * 4096 + lfull
+    RoundTw t1, t2;
+    {
+        const unsigned b = hx * 4096u + lfull;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+        ld_tw(twf, (1u << 16) - 1u + b, t1.wa1[0], t1.wb1[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t2.wa8[j], t2.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t2.wa4[j], t2.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t2.wa2[j], t2.wb2[j]);
+        ld_tw(twf, (1u << 12) - 1u + lfull, t2.wa1[0], t2.wb1[0]);
+    }
+    const v2s none = {0, 0};
+    const short s2 = (short)(1 - (hx & 1)); // round 2: kind of the inputs = n16 = (tid >> 5) & 1
+    const v2s sh2 = {s2, s2};
+
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = in + frame * ((size_t)1 << L20) + lfull;
+        u32 *dst = scr + frame * ((size_t)1 << L20) + lfull;
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 12)); // regs = n19..16
+        // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
+        // the barrier also orders the previous frame's LDS reads before this frame's writes
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+        if (!FAST_OK) __syncthreads();
+        if (fast) dif_round<FAST_OK, false>(v, t1, sl, none);
+        else dif_round<false, false>(v, t1, sl, none);
+        // transpose: (thread (hx = n15..12, l), reg j = n19..16) -> (thread (j, l), reg hx)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lds[ROWB * (32 * j + l) + hx] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * tid + r]; // now tid >> 5 = n19..16, regs = n15..12
+        if (fast) dif_round<FAST_OK, true>(v, t2, sl, sh2);
+        else dif_round<false, true>(v, t2, sl, sh2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << 12] = v[r];
+    }
+}
+
+// ---- pass 2: stages 11..4 on 4096 consecutive points, in place ----------------------------------------
+template <bool FAST_OK>
+__global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restrict__ twt, size_t nblocks4k, const Slice sl)
+{
+    __shared__ u32 lds[2 * 256 * ROWB];
+    u32 *const reg0 = lds, *const reg1 = lds + 256 * ROWB;
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    RoundTw ta, tb;
+    auto ld = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = twt[idx];
+        wa = pack_wa(w);
+        wb = pack_wb(w);
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld(1023 + 256 * j + tid, ta.wa4[j], ta.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld(511 + 256 * j + tid, ta.wa2[j], ta.wb2[j]);
+    ld(255 + tid, ta.wa1[0], ta.wb1[0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
+    ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    const short sb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
+    const v2s sh_b = {sb, sb};
+
+    for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
+        u32 *p = scr + b * 4096;
+        // kind of this block's inputs = n12 = block index bit 0 (pass 1 left Y >> 1 where n12 = 1)
+        const short sa = (short)(1 - (int)(b & 1));
+        const v2s sh_a = {sa, sa};
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
+        // guard-bit vote on this block's own inputs (S-type: |v| < 2^14; Y >> 1 type: |v| < 2^13)
+        bool fast = false;
+        if (FAST_OK) {
+            const u32 addc = (b & 1) ? 0x20002000u : 0x40004000u, maskc = (b & 1) ? 0xC000C000u : 0x80008000u;
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
+            fast = __syncthreads_or((acc & maskc) != 0) == 0;
+        }
+        if (fast) dif_round<FAST_OK, true>(v, ta, sl, sh_a);
+        else dif_round<false, true>(v, ta, sl, sh_a);
+        // LA -> LB: row = 16 j + n3..0, column = n7..4
+#pragma unroll
+        for (int j = 0; j < 16; ++j) reg0[ROWB * (16 * j + lo4) + hi4] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = reg0[ROWB * tid + r]; // LB: regs = n7..4, thread = (n11..8, n3..0)
+        if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_b);
+        else dif_round<false, true>(v, tb, sl, sh_b);
+        // LB -> LA for a coalesced store: element (t' = (n11..8, n3..0), reg j' = n7..4) -> row n7..0 = 16 j' + n3..0,
+        // column n11..8
+#pragma unroll
+        for (int j = 0; j < 16; ++j) reg1[ROWB * (16 * j + lo4) + hi4] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[256 * r + tid] = reg1[ROWB * tid + r];
+        // the next iteration's writes to reg0 / reg1 are ordered behind these reads by its own barriers:
+        // reg0 is rewritten only after every thread passed the second barrier above (all reg0 reads done);
+        // reg1 is rewritten only after the next first barrier (all reg1 reads done).
+    }
+}
+
+// ---- pass 3: stages 3..0 and the bit-reversed (natural-order) store ----------------------------------
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, const RoundCConsts c, size_t nframes, const Slice sl)
+{
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n15..12
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n11..5, 0..127
+    const u32 *src = scr + frame * ((size_t)1 << L20) + mid * 32 + e;
+    u32 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(16 * j + px) << 12]; // reg j = n19..16
+
+    // transpose -> regs = n3..0, thread = (n4, rev8(n19..12)); rev8(16 j + px) = 16 rev4(px) + rev4(j)
+    const int rpx = ((px & 1) << 3) | ((px & 2) << 1) | ((px & 4) >> 1) | ((px & 8) >> 3);
+    {
+        u32 *w = lds + ROWB * ((e >> 4) * 256 + 16 * rpx) + (e & 15);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWB * rev4b(j)] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * tid + r];
+
+    // stages 3..0; kind of the inputs = n4 = tid >> 8 (pass 2 left Y >> 1 where n4 = 1)
+    const short s3 = (short)(1 - (tid >> 8));
+    const v2s sh3 = {s3, s3};
+    bool fast = false;
+    if (FAST_OK) { // vote on the tile's own inputs; the kind (hence the threshold) depends on n4 = tid >> 8
+        const u32 addc = (tid >> 8) ? 0x20002000u : 0x40004000u, maskc = (tid >> 8) ? 0xC000C000u : 0x80008000u;
+        u32 acc = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc |= v[r] + addc;
+        fast = __syncthreads_or((acc & maskc) != 0) == 0;
+    }
+    if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
+    else dif_round_c<false>(v, c, sl, sh3);
+
+    // natural order: X index = rev20(n) = rev4(r) << 16 | rev8(n11..4) << 8 | rev8(n19..12)
+    //   n11..4 = (mid << 1) | n4  ->  rev8 = (n4 << 7) | rev7(mid)
+    const unsigned rmid = __brev(mid) >> 25; // rev7
+    u32 *dst = out + frame * ((size_t)1 << L20) + ((((unsigned)(tid >> 8) << 7) | rmid) << 8) + (tid & 255);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << 16));
+}
+
+bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
+                     int in_order, int out_order)
+{
+    return log2n == 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+           direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *big20_kernel_name() { return "k_big20_p1/p2/p3"; }
+
+hipError_t launch_big20(int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+                        const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    RoundCConsts c;
+    for (int k = 0; k < 8; ++k) {
+        const int2 w = h_tw[7 + k];
+        c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int2 w = h_tw[3 + k];
+        c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    const u32 *pin = static_cast<const u32 *>(in);
+    u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const unsigned groups = (unsigned)(nframes < 16 ? nframes : 16);
+    if (fx) hipLaunchKernelGGL(k_big20_p1<true>, dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+    else hipLaunchKernelGGL(k_big20_p1<false>, dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+    const size_t nb = nframes * 256;
+    static int p2_per_cu = 0;
+    if (!p2_per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2_per_cu, k_big20_p2<true>, 256, 0) != hipSuccess || p2_per_cu <= 0))
+        p2_per_cu = 4;
+    const size_t cap = (size_t)cus * (size_t)p2_per_cu;
+    const unsigned g2 = (unsigned)(nb < cap ? nb : cap), g3 = (unsigned)(nframes * 128);
+    if (fx) {
+        hipLaunchKernelGGL(k_big20_p2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
+        hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl);
+    } else {
+        hipLaunchKernelGGL(k_big20_p2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
+        hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl);
+    }
+    return hipGetLastError();
+}
+
+} // namespace intfft

@@ -36,6 +36,7 @@ struct intfft_plan {
     bool fast1024 = false;
     bool fast4096 = false;
     bool fast1024x = false;
+    bool big20 = false;
     Fast1024Args fargs{};
     // host-streaming state (intfft_exec_host), created on first use
     hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
@@ -390,8 +391,11 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             intfft_plan_destroy(pl);
             return rc;
         }
+        pl->big20 = big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
+                                    p->use_fly, p->in_order, p->out_order) &&
+                    !getenv("INTFFT_NO_BIG20");
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->big20 ? big20_kernel_name() : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -405,7 +409,9 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         }
         if (pl->passes.size() > 1) {
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->word;
-            pl->scratch_frames = std::max<size_t>(1, ((size_t)128 << 20) / frame_bytes);
+            size_t scratch_mb = pl->big20 ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
+            if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
+            pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
             const hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
             if (e != hipSuccess) {
@@ -474,6 +480,12 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
+        if (plan->big20) {
+            const hipError_t e = launch_big20(plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw, plan->d_tw16f,
+                                              plan->h_tw.data(), nf, stream);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
         for (size_t i = 0; i < np; ++i) {
             const PassArgs &a = plan->passes[i];
             const void *pin = a.in_mode == IO_USER ? src : plan->d_scratch;
