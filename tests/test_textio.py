@@ -56,3 +56,19 @@ def test_pair_through_text_files_matches_oracle(tmp_path):
     want = C.execute(x, C.make_params(7, 16, 16, 1, 0, True), C.PAIR)
     assert np.array_equal(textio.read_dout_pair(pout), textio.dout_pair_lines(want, 16 + 14))
     core.close()
+
+
+@pytest.mark.gpu
+def test_cli_single_flow(tmp_path):
+    """python -m intfftk_amd.cli single: di_single.dat -> natural-order spectrum, three tb modes."""
+    from intfftk_amd import cli
+    from oracle import oracle_c as C
+
+    x = uniform_frames(2, 128, 16, 4)
+    pin = str(tmp_path / "di_single.dat")
+    textio.write_di_single(pin, x)
+    for mode, (fmt, rnd) in {"UNSCALED": (1, 0), "TRUNCATE": (0, 0), "ROUNDING": (0, 1)}.items():
+        pout = str(tmp_path / ("out_%s.dat" % mode))
+        assert cli.main(["single", pin, pout, "--nfft", "7", "--mode", mode]) == 0
+        want = C.execute(x, C.make_params(7, 16, 16, fmt, rnd, True), C.FWD)
+        assert np.array_equal(textio.read_di_single(pout, 128), want)
