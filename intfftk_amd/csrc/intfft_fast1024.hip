@@ -180,9 +180,21 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
 
     // ---- store ----
     if (OUT_BITREV) {
-        uint4 *dst = reinterpret_cast<uint4 *>(out + f * 1024 + lane * 16);
+        // memory index = n.  Two lane swaps turn (regs n3..0, lane n9..4) into (regs n9 n8 n1 n0,
+        // lane n3 n2 n7..4): every lane then owns 4 consecutive n and a store instruction covers 1 KiB
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        v4u *dst = reinterpret_cast<v4u *>(out + f * 1024) + (((lane & 15) << 2) | (lane >> 4));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            __builtin_nontemporal_store(x, dst + 64 * q);
+        }
     } else {
         u32 *dst = out + f * 1024 + lane;
 #pragma unroll
@@ -195,7 +207,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
 
 template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                     const Fast1024Consts c, size_t nframes, const Slice sl)
+                                                     const Fast1024Consts c, size_t nframes, const Slice sl, int in_halves)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROW_DW];
     const int lane = threadIdx.x & 63;
@@ -257,6 +269,17 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
             transform_store<ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
+        if (in_halves) { // HALVES: beat i holds (x[i], x[i + 512]) = (v[j], v[j + 8]) for i = 64 j + lane
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *src2 = reinterpret_cast<const v2u *>(in + f * 1024) + lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const v2u w = __builtin_nontemporal_load(src2 + 64 * j);
+                v[j] = w.x;
+                v[j + 8] = w.y;
+            }
+            return;
+        }
         const u32 *src = in + f * 1024 + lane;
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j);
@@ -292,7 +315,7 @@ bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, i
 {
     (void)rndmode;
     return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
-           direction == 0 && use_fly == 1 && in_order == 0 && (out_order == 0 || out_order == 1);
+           direction == 0 && use_fly == 1 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
 }
 
 const char *fast1024_kernel_name() { return "k_fft1024_i16"; }
@@ -305,7 +328,7 @@ static int env_int(const char *name, int dflt)
 
 template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
-                           const Slice &sl, hipStream_t stream)
+                           const Slice &sl, int in_halves, hipStream_t stream)
 {
     // persistent waves: exactly the resident grid (occupancy x CUs), so no block waits for a slot
     static int per_cu = 0, cus = 0;
@@ -325,23 +348,23 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
     const size_t cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
     hipLaunchKernelGGL((k_fft1024_i16<ROUND, OUT_BITREV, PIPE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out,
-                       tw, c, nframes, sl);
+                       tw, c, nframes, sl, in_halves);
     return hipGetLastError();
 }
 
 template <bool ROUND, bool OUT_BITREV>
 static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
-                           const Slice &sl, bool fast_ok, hipStream_t stream)
+                           const Slice &sl, bool fast_ok, int in_halves, hipStream_t stream)
 {
     static const int pipe = env_int("INTFFT_FAST_PIPE", 1);          // 1: two frames in flight per wave
     static const int allow_fast = env_int("INTFFT_FAST_EXTRACT", 1); // 0: always the exact extraction
     if constexpr (!ROUND) {
         if (fast_ok && allow_fast)
-            return pipe ? launch_k<ROUND, OUT_BITREV, true, true>(in, out, tw, c, nframes, sl, stream)
-                        : launch_k<ROUND, OUT_BITREV, false, true>(in, out, tw, c, nframes, sl, stream);
+            return pipe ? launch_k<ROUND, OUT_BITREV, true, true>(in, out, tw, c, nframes, sl, in_halves, stream)
+                        : launch_k<ROUND, OUT_BITREV, false, true>(in, out, tw, c, nframes, sl, in_halves, stream);
     }
-    return pipe ? launch_k<ROUND, OUT_BITREV, true, false>(in, out, tw, c, nframes, sl, stream)
-                : launch_k<ROUND, OUT_BITREV, false, false>(in, out, tw, c, nframes, sl, stream);
+    return pipe ? launch_k<ROUND, OUT_BITREV, true, false>(in, out, tw, c, nframes, sl, in_halves, stream)
+                : launch_k<ROUND, OUT_BITREV, false, false>(in, out, tw, c, nframes, sl, in_halves, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
@@ -364,10 +387,10 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
     if (a.rnd == RND_ROUND)
-        return a.out_bitrev ? launch_t<true, true>(pin, pout, tw_all, c, nframes, sl, false, stream)
-                            : launch_t<true, false>(pin, pout, tw_all, c, nframes, sl, false, stream);
-    return a.out_bitrev ? launch_t<false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, stream)
-                        : launch_t<false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+        return a.out_bitrev ? launch_t<true, true>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream)
+                            : launch_t<true, false>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream);
+    return a.out_bitrev ? launch_t<false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream)
+                        : launch_t<false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream);
 }
 
 } // namespace intfft

@@ -66,6 +66,7 @@ struct Fast1024Args {
     int twd;        // twiddle width (<= 16)
     int rnd;        // RoundKind (RND_TRUNC / RND_ROUND)
     int out_bitrev; // 0: NATURAL output, 1: BITREV output
+    int in_halves;  // 0: NATURAL input, 1: HALVES input (native int_fftNk beats)
 };
 bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode,
                         int direction, int use_fly, int in_order, int out_order);

@@ -385,6 +385,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->fargs.twd = p->twdl_width;
         pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
         pl->fargs.out_bitrev = p->out_order == INTFFT_ORDER_BITREV;
+        pl->fargs.in_halves = p->in_order == INTFFT_ORDER_HALVES;
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024_kernel_name());
     } else {
         if ((rc = build_passes(*pl)) != INTFFT_OK) {

@@ -208,3 +208,14 @@ def test_exec_host_streaming(chunk):
         want = run_ref(x, log2n, dw, tw, fmt, rnd, True, direction=d)
         assert np.array_equal(got, want), (cfg, chunk)
         core.close()
+
+
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("in_order", ["NATURAL", "HALVES"])
+@pytest.mark.parametrize("out_order", ["NATURAL", "BITREV"])
+def test_fast1024_native_orders(rnd, in_order, out_order):
+    """The wave kernel's four order combinations (int_fftNk's native HALVES -> BITREV included),
+    on guard-bit frames (fast extraction) and full-scale frames (exact extraction)."""
+    x = np.concatenate([edge_frames(1024, 16), uniform_frames(600, 1024, 15, 31), uniform_frames(40, 1024, 16, 32)])
+    info = check(x, 10, 16, 16, 0, rnd, True, in_order=in_order, out_order=out_order)
+    assert info["fast_path"] == 1

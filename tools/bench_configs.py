@@ -27,10 +27,15 @@ CONFIGS = {
 }
 
 
+ORDERS = {"C2native": ("HALVES", "BITREV")}
+CONFIGS["C2native"] = (10, 16, 16, 0, 0, "FWD", 65536, 15, 8)
+
+
 def run(name, steps=20, check_frames=8):
     log2n, dw, tw, fmt, rnd, direction, batch, bits, bps = CONFIGS[name]
     n = 1 << log2n
-    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction)
+    in_o, out_o = ORDERS.get(name, ("NATURAL", "NATURAL"))
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o)
     g = torch.Generator(device="cuda")
     g.manual_seed(0xC0FFEE00 + log2n)
     x = torch.randint(-(1 << (bits - 1)), 1 << (bits - 1), (batch, n, 2), device="cuda", dtype=core.in_dtype, generator=g)
@@ -49,7 +54,9 @@ def run(name, steps=20, check_frames=8):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     p = C.make_params(log2n, dw, tw, fmt, rnd, True)
-    want = C.execute(x[:check_frames].cpu().numpy(), p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction])
+    om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES}
+    want = C.execute(x[:check_frames].cpu().numpy(), p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction],
+                     om[in_o], om[out_o])
     ok = bool(np.array_equal(y[:check_frames].cpu().numpy().astype(np.int64), want))
     gs = batch * n / ms / 1e6
     out = {"config": name, "log2n": log2n, "batch": batch, "dir": direction, "ms": ms, "Gsample/s": gs,
