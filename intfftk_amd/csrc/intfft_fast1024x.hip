@@ -25,7 +25,8 @@ enum { X_INV = 1, X_PAIR = 2 };
 
 template <int MODE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                      const RoundCConsts c, size_t nframes, const Slice sl)
+                                                      const RoundCConsts c, size_t nframes, const Slice sl, int in_bitrev,
+                                                      int out_halves)
 {
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROWX];
     const int lane = threadIdx.x & 63;
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     // inverse (LC -> mid): element (lane l, reg r) -> row = mid lane (32 n9 + 16 n8 + r), column = mid reg
     const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1, l4 = (lane >> 4) & 1,
               l5 = lane >> 5; // l_i = n(9-i)
-    u32 *wr_i = lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
+    // NATURAL input: LC lane bit i = n(9-i).  BITREV input (memory index = n): LC lane = n9..n4 (bit i = n(4+i))
+    u32 *wr_i = in_bitrev ? lds + ROWX * (32 * l5 + 16 * l4) + ((l1 << 3) | (l0 << 2) | (l3 << 1) | l2)
+                          : lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
     const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWX * lane);
     const short s3 = (short)(1 - (lane >> 5)); // LC: kind = n4 = lane bit 5
     const v2s sh3 = {s3, s3};
@@ -69,7 +72,25 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     for (size_t f = wave0; f < nframes; f += nwaves) {
         u32 v[16];
         const u32 *src = in + f * 1024;
-        if (MODE == X_INV) { // LC: v[r] = X[rev10(n)] = X[64 * rev4(r) + lane]
+        if (MODE == X_INV && in_bitrev) {
+            // memory index = n: x4 loads give (regs n9 n8 n1 n0, lane n3 n2 n7..4); two lane swaps -> (regs n3..0, lane n9..4)
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            const v4u *s4 = reinterpret_cast<const v4u *>(src) + (((lane & 15) << 2) | (lane >> 4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4u x = __builtin_nontemporal_load(s4 + 64 * q);
+                v[4 * q] = x.x;
+                v[4 * q + 1] = x.y;
+                v[4 * q + 2] = x.z;
+                v[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+        } else if (MODE == X_INV) { // LC: v[r] = X[rev10(n)] = X[64 * rev4(r) + lane]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
@@ -130,9 +151,19 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
         else INTFFT_XBODY(false)
 #undef INTFFT_XBODY
-        u32 *dst = out + f * 1024 + lane;
+        if (out_halves) { // HALVES: beat i = 64 j + lane holds (x[i], x[i + 512]) = (v[j], v[j + 8])
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            v2u *d2 = reinterpret_cast<v2u *>(out + f * 1024) + lane;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + 64 * j);
+            for (int j = 0; j < 8; ++j) {
+                const v2u w = {v[j], v[j + 8]};
+                __builtin_nontemporal_store(w, d2 + 64 * j);
+            }
+        } else {
+            u32 *dst = out + f * 1024 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + 64 * j);
+        }
     }
 }
 
@@ -140,14 +171,16 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
                          int use_fly, int in_order, int out_order)
 {
     return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           (direction == 1 || direction == 2) && use_fly == 1 && in_order == 0 && out_order == 0;
+           use_fly == 1 &&
+           ((direction == 2 && in_order == 0 && out_order == 0) ||
+            (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
 }
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
 
 template <int MODE, bool FAST_OK>
 static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
-                          const Slice &sl, hipStream_t stream)
+                          const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
 {
     static int per_cu = 0, cus = 0;
     if (!per_cu) {
@@ -161,11 +194,12 @@ static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCC
     }
     const size_t need = (nframes + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
-    hipLaunchKernelGGL((k_fft1024x_i16<MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
+    hipLaunchKernelGGL((k_fft1024x_i16<MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
+                       in_bitrev, out_halves);
     return hipGetLastError();
 }
 
-hipError_t launch_fast1024x(int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+hipError_t launch_fast1024x(int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                             size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -186,10 +220,10 @@ hipError_t launch_fast1024x(int direction, int twd, const void *in, void *out, c
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
     if (direction == 1)
-        return fast_ok ? launchx<X_INV, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launchx<X_INV, false>(pin, pout, tw_all, c, nframes, sl, stream);
-    return fast_ok ? launchx<X_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                   : launchx<X_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
+        return fast_ok ? launchx<X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
+                       : launchx<X_INV, false>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    return fast_ok ? launchx<X_PAIR, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream)
+                   : launchx<X_PAIR, false>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
 }
 
 } // namespace intfft

@@ -219,3 +219,30 @@ def test_fast1024_native_orders(rnd, in_order, out_order):
     x = np.concatenate([edge_frames(1024, 16), uniform_frames(600, 1024, 15, 31), uniform_frames(40, 1024, 16, 32)])
     info = check(x, 10, 16, 16, 0, rnd, True, in_order=in_order, out_order=out_order)
     assert info["fast_path"] == 1
+
+
+@pytest.mark.parametrize("in_order", ["NATURAL", "BITREV"])
+@pytest.mark.parametrize("out_order", ["NATURAL", "HALVES"])
+def test_fast1024x_native_orders(in_order, out_order):
+    """The inverse wave kernel's order combinations (int_ifftNk's native BITREV -> HALVES included)."""
+    x = np.concatenate([edge_frames(1024, 16), uniform_frames(300, 1024, 15, 41), uniform_frames(20, 1024, 16, 42)])
+    info = check(x, 10, 16, 16, 0, 0, True, direction="INV", in_order=in_order, out_order=out_order)
+    assert info["fast_path"] == 1
+
+
+def test_native_cores_chain_like_the_pair():
+    """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
+    same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
+    import torch
+
+    from intfftk_amd import int_fft_ifft_pair, int_fftNk, int_ifftNk
+
+    x = torch.from_numpy(uniform_frames(64, 1024, 15, 77).astype(np.int16)).cuda()
+    fwd, inv, pair = int_fftNk(10, 16, 16, 0, 0), int_ifftNk(10, 16, 16, 0, 0), int_fft_ifft_pair(10, 16, 16, 0, 0)
+    # natural -> HALVES beats: mem[2i + l] = x[i + 512 l]
+    halves = torch.stack([x[:, :512], x[:, 512:]], dim=2).reshape(64, 1024, 2).contiguous()
+    y = inv(fwd(halves))
+    nat = torch.cat([y[:, 0::2], y[:, 1::2]], dim=1)
+    assert torch.equal(nat, pair(x))
+    for c in (fwd, inv, pair):
+        c.close()
