@@ -30,6 +30,41 @@ template <typename T> __device__ __forceinline__ void store_user(void *base, int
     else reinterpret_cast<int64_t *>(base)[i] = (int64_t)v;
 }
 
+// 2^R-point sub-transform in registers: element r of the group lives at lds[pad(e + (r << lb_lo))] and
+// carries index bits s_lo .. s_lo+R-1 = r.  Stage s_lo+i pairs r-bit i and uses twiddle
+// kb + ((r mod 2^i) << s_lo) of its table; stage descriptors a.st[si ..] are in processing order.
+template <typename T, int KIND, int R>
+__device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo, int s_lo, unsigned kb,
+                                              const PassArgs &a, int si, const int2 *__restrict__ tw)
+{
+    constexpr int P = 1 << R;
+    Cx<T> v[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) v[r] = lds[pad(e + ((unsigned)r << lb_lo))];
+#pragma unroll
+    for (int ii = 0; ii < R; ++ii) {
+        const int i = KIND == KIND_DIF ? R - 1 - ii : ii;
+        const StageDesc st = a.st[si + ii];
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int h = 1 << i;
+#pragma unroll
+        for (int pr = 0; pr < P / 2; ++pr) {
+            const int r0 = ((pr >> i) << (i + 1)) | (pr & (h - 1));
+            const unsigned k = kb + ((unsigned)(r0 & (h - 1)) << s_lo);
+            int2 w = make_int2(0, 0);
+            if (st.s >= 2) w = tw[st.tw_off + k];
+            Cx<T> X, Y;
+            if (KIND == KIND_DIF) dif_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
+            else dit_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
+            v[r0] = X;
+            v[r0 + h] = Y;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < P; ++r) lds[pad(e + ((unsigned)r << lb_lo))] = v[r];
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in, void *out,
                                                        const int2 *__restrict__ tw, size_t nframes)
@@ -102,28 +137,44 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
     }
     __syncthreads();
 
-    // ---- stages -----------------------------------------------------------------------------
-    const unsigned nbf = nf << (U - 1);
-    for (int si = 0; si < a.nstages; ++si) {
+    // ---- stages: up to RMAX consecutive stages per LDS round trip, evaluated in registers ----------
+    // Stages of one pass act on consecutive tile-local bits (descending for DIF, ascending for DIT), so a run
+    // of R stages is a 2^R-point sub-transform per thread (round_generic<>), each stage with its own widths.
+    constexpr int RMAX = sizeof(T) == 4 ? 4 : 3;
+    int si = 0;
+    while (si < a.nstages) {
         const StageDesc st = a.st[si];
-        const unsigned lowm = (1u << st.lb) - 1u;
-        const unsigned km = (1u << st.s) - 1u;
-        for (unsigned q = threadIdx.x; q < nbf; q += blockDim.x) {
-            const unsigned f = q >> (U - 1), qq = q & ((tile_n >> 1) - 1u);
-            const unsigned u0 = ((qq >> st.lb) << (st.lb + 1)) | (qq & lowm);
-            const unsigned u1 = u0 | (1u << st.lb);
-            const unsigned k = spread(u0) & km; // twiddle counter mod 2^STAGE (rom_twiddle_int.vhd:187-202)
-            int2 w = make_int2(0, 0);
-            if (st.s >= 2) w = tw[st.tw_off + k];
-            const unsigned e0 = pad((f << U) + u0), e1 = pad((f << U) + u1);
-            const Cx<T> A = lds[e0], B = lds[e1];
-            Cx<T> X, Y;
-            if (st.kind == KIND_DIF) dif_fly<T>(st, (int)(k & 1u), A, B, w.x, w.y, X, Y);
-            else dit_fly<T>(st, (int)(k & 1u), A, B, w.x, w.y, X, Y);
-            lds[e0] = X;
-            lds[e1] = Y;
+        int R = 1;
+        while (R < RMAX && si + R < a.nstages && a.st[si + R].kind == st.kind &&
+               a.st[si + R].lb == st.lb + (st.kind == KIND_DIF ? -R : R))
+            ++R;
+        const int lb_lo = st.kind == KIND_DIF ? st.lb - (R - 1) : st.lb;
+        const int s_lo = st.kind == KIND_DIF ? st.s - (R - 1) : st.s;
+        const unsigned ngroups = nf << (U - R);
+        const unsigned lowm = (1u << lb_lo) - 1u;
+        for (unsigned g = threadIdx.x; g < ngroups; g += blockDim.x) {
+            const unsigned f = g >> (U - R), gg = g & ((tile_n >> R) - 1u);
+            const unsigned u0 = ((gg >> lb_lo) << (lb_lo + R)) | (gg & lowm);
+            const unsigned kb = spread(u0) & ((1u << s_lo) - 1u);
+            const unsigned e = (f << U) + u0;
+            if (st.kind == KIND_DIF) {
+                switch (R) {
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIF, 4>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIF, 3>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIF, 2>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIF, 1>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                }
+            } else {
+                switch (R) {
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIT, 4>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIT, 3>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIT, 2>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIT, 1>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                }
+            }
         }
         __syncthreads();
+        si += R;
     }
 
     // ---- store ------------------------------------------------------------------------------

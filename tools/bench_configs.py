@@ -21,6 +21,8 @@ CONFIGS = {
     "C4": (20, 16, 16, 0, 0, "FWD", 1024, 15, 8),
     "C5": (12, 16, 16, 0, 0, "PAIR", 16384, 15, 8),
     "C2inv": (10, 16, 16, 0, 0, "INV", 65536, 15, 8),
+    "C2u": (10, 16, 16, 1, 0, "FWD", 65536, 15, 12),
+    "tb7u": (7, 16, 16, 1, 0, "FWD", 524288, 15, 12),
     "C2pair": (10, 16, 16, 0, 0, "PAIR", 65536, 15, 8),
     "C5fwd": (12, 16, 16, 0, 0, "FWD", 16384, 15, 8),
     "C5inv": (12, 16, 16, 0, 0, "INV", 16384, 15, 8),

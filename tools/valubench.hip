@@ -67,6 +67,29 @@ DEFK(k_mix1, A_MIX1) DEFK(k_mix2, A_MIX2) DEFK(k_mix3, A_MIX3) DEFK(k_xor, A_XOR
 DEFK(k_lshr32, A_LSHR32) DEFK(k_ashr16, A_ASHR16) DEFK(k_mullo16, A_MULLO16) DEFK(k_bfi, A_BFI) DEFK(k_andor, A_ANDOR)
 DEFK(k_max, A_MAX) DEFK(k_cnd, A_CNDMASK) DEFK(k_pkfmaf16, A_PKFMAF16) DEFK(k_pkaddf16, A_PKADDF16) DEFK(k_pkmax, A_PKMAX)
 DEFK(k_madu16, A_MADU16) DEFK(k_sdwa, A_SDWA) DEFK(k_muli24, A_MULI24)
+#define A_MULLO32(n) "v_mul_lo_u32 %" #n ", %" #n ", %8"
+#define A_MULHI32(n) "v_mul_hi_i32 %" #n ", %" #n ", %8"
+#define A_MULHI24(n) "v_mul_hi_i32_i24 %" #n ", %" #n ", %8"
+#define A_MADI16(n) "v_mad_i32_i16 %" #n ", %" #n ", %8, %9"
+#define A_DOT4(n) "v_dot4_i32_i8 %" #n ", %" #n ", %8, %9"
+#define A_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9"
+#define A_ASHR64(n) "v_add_lshl_u32 %" #n ", %" #n ", %8, 1"
+DEFK(k_mullo32, A_MULLO32) DEFK(k_mulhi32, A_MULHI32) DEFK(k_mulhi24, A_MULHI24) DEFK(k_madi16, A_MADI16) DEFK(k_dot4, A_DOT4)
+DEFK(k_add3, A_ADD3) DEFK(k_addlshl, A_ASHR64)
+__global__ __launch_bounds__(256) void k_mad64(unsigned* out, unsigned seed)
+{
+    long long a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    int b = (int)a0 ^ 0x5a5a, c = (int)a0 + 77;
+    for (int i = 0; i < ITER; ++i) {
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+            asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n\tv_mad_i64_i32 %1, vcc, %8, %9, %1\n\tv_mad_i64_i32 %2, vcc, %8, %9, %2\n\t"
+                         "v_mad_i64_i32 %3, vcc, %8, %9, %3\n\tv_mad_i64_i32 %4, vcc, %8, %9, %4\n\tv_mad_i64_i32 %5, vcc, %8, %9, %5\n\t"
+                         "v_mad_i64_i32 %6, vcc, %8, %9, %6\n\tv_mad_i64_i32 %7, vcc, %8, %9, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (unsigned)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
 
 template <typename K> void run(const char* name, K k, unsigned* out, int blocks)
 {
@@ -85,7 +108,7 @@ int main(int argc, char** argv)
     int wps = argc > 1 ? atoi(argv[1]) : 4; // waves per SIMD
     int blocks = 256 * wps;
     unsigned* out; (void)hipMalloc(&out, (size_t)blocks * 256 * 4);
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < 2; ++r) {
     run("pk_add", k_pkadd, out, blocks); run("pk_sub", k_pksub, out, blocks); run("pk_ashr", k_pkashr, out, blocks);
     run("dot2", k_dot2, out, blocks); run("dot2c", k_dot2c, out, blocks); run("bfe", k_bfe, out, blocks);
     run("perm", k_perm, out, blocks); run("add_u32", k_add, out, blocks); run("lshl", k_lshl, out, blocks);
@@ -97,6 +120,8 @@ int main(int argc, char** argv)
     run("ashr_i16", k_ashr16, out, blocks); run("mul_lo_u16", k_mullo16, out, blocks); run("bfi", k_bfi, out, blocks); run("and_or", k_andor, out, blocks);
     run("max_i32", k_max, out, blocks); run("cndmask", k_cnd, out, blocks); run("pk_fma_f16", k_pkfmaf16, out, blocks); run("pk_add_f16", k_pkaddf16, out, blocks);
     run("pk_max_i16", k_pkmax, out, blocks); run("mad_u16", k_madu16, out, blocks); run("add_u16_sdwa", k_sdwa, out, blocks); run("mul_i32_i24", k_muli24, out, blocks);
+    run("mul_lo_u32", k_mullo32, out, blocks); run("mul_hi_i32", k_mulhi32, out, blocks); run("mul_hi_i32_i24", k_mulhi24, out, blocks); run("mad_i32_i16", k_madi16, out, blocks);
+    run("dot4_i32_i8", k_dot4, out, blocks); run("add3_u32", k_add3, out, blocks); run("add_lshl_u32", k_addlshl, out, blocks); run("mad_i64_i32", k_mad64, out, blocks);
     }
     return 0;
 }
