@@ -1,0 +1,281 @@
+// intfft_fast1024u.hip -- UNSCALED (full bit growth) wave kernel for N = 1024:
+// int_fftNk with NFFT = 10, DATA_WIDTH = 16, TWDL_WIDTH <= 16, FORMAT = 1, natural in -> natural out
+// (the reference testbench's primary mode: fft_signle_test.vhd:93-112 "UNSCALED").  16-bit samples in
+// int16 containers, 26-bit results in int32 containers (12 B per complex sample of HBM traffic).
+//
+// Same wave-per-frame choreography as intfft_fast1024.hip (stages 9..6 in registers, two lane swaps for
+// stages 5 and 4, one wave-private LDS transpose, stages 3..0 in registers, bit reversal folded into the
+// transpose), but on unpacked int32 (re, im) registers, because the width grows by one bit per stage
+// (int_fftNk.vhd:187-207: DTW = 16 + ii, outputs 17 + ii bits):
+//   S = A + B, D = A - B                      exact, one bit of growth (int_dif2_fly.vhd:222-240)
+//   re = D.re*wr - D.im*wi, im = D.re*wi + D.im*wr   exact 64-bit sums: 2 x v_mad_i64_i32 each
+//                                             (tools/valubench.hip: same issue rate as any VOP3 op)
+//   Y = wrap_wo(sum >> (t-1))                 v_alignbit_b32 (+ v_bfe_i32 for the wo-bit wrap)
+// The wo-bit wrap only matters when a rotated difference leaves the wo-bit range, i.e. for inputs
+// beyond one guard bit: frames that pass the per-wave guard-bit vote (|re|, |im| <= 2^14: the complex
+// magnitude is <= 2^14.5 * 2^k after k stages, below the 2^(15+k) range, and the per-stage floor adds
+// < 1) skip the wrap; every other frame takes the exact path.  Single-DSP multiplier regime
+// (w <= 26 < 28: int_cmult_dsp48.vhd:184-225).
+#include "intfft_internal.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+using u32 = uint32_t;
+
+struct UConsts {
+    int wr3[8], wi3[8]; // STAGE 3 twiddles (uniform)
+    int wr2[4], wi2[4]; // STAGE 2
+};
+
+constexpr int ROWU = 20; // LDS row stride in dwords, per plane (re plane then im plane)
+
+// one general DIF butterfly, unscaled; WO = output width of the stage
+template <bool WRAP, int WO, bool UNIFORM_W = false>
+__device__ __forceinline__ void ufly(int &are, int &aim, int &bre, int &bim, int wr, int wi, int sh)
+{
+    // wave-uniform twiddles stay in SGPRs; the empty asm keeps the compiler from hoisting their 64-bit sign
+    // extension out of the frame loop (which turns every product into a 3-instruction 64 x 32 multiply)
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    const int dre = are - bre, dim = aim - bim, ndim = bim - aim;
+    are += bre;
+    aim += bim;
+    const long long xr = (long long)dre * wr + (long long)ndim * wi; // M2 - M1 (int_cmult_dsp48.vhd:192-207)
+    const long long xi = (long long)dre * wi + (long long)dim * wr;  // M2 + M1 (:209-224)
+    // low 32 bits of (x >> sh), 1 <= sh <= 15: one v_alignbit_b32
+    int yr = (int)__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)sh);
+    int yi = (int)__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)sh);
+    if (WRAP) {
+        yr = __builtin_amdgcn_sbfe(yr, 0, WO);
+        yi = __builtin_amdgcn_sbfe(yi, 0, WO);
+    }
+    bre = yr;
+    bim = yi;
+}
+// STAGE 0 and even positions of STAGE 1
+__device__ __forceinline__ void ufly_triv(int &are, int &aim, int &bre, int &bim)
+{
+    const int dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dre;
+    bim = dim;
+}
+// odd positions of STAGE 1: Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re  (int_dif2_fly.vhd:297-304)
+__device__ __forceinline__ void ufly_mj(int &are, int &aim, int &bre, int &bim)
+{
+    const int dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dim;
+    bim = (dre >> 31) - dre; // -x for x >= 0, -x - 1 = ~x for x < 0
+}
+
+__device__ __forceinline__ void uswap32(int &a, int &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void uswap16(int &a, int &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+template <bool WRAP>
+__device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const int (&w9r)[8], const int (&w9i)[8],
+                                           const int (&w8r)[4], const int (&w8i)[4], const int (&w7r)[2],
+                                           const int (&w7i)[2], int w6r, int w6i, int w5r, int w5i, int w4r, int w4i,
+                                           const UConsts &c, int sh, u32 *wr_base, const uint4 *rd_base)
+{
+    // stage s has output width WO = 26 - s
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ufly<WRAP, 17>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ufly<WRAP, 18>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ufly<WRAP, 19>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) ufly<WRAP, 20>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, sh);
+    // lane bit 5 <-> reg bit 3, stage 5
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uswap32(re[j], re[j + 8]);
+        uswap32(im[j], im[j + 8]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ufly<WRAP, 21>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, sh);
+    // lane bit 4 <-> reg bit 2, stage 4
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uswap16(re[g + j], re[g + j + 4]);
+            uswap16(im[g + j], im[g + j + 4]);
+        }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ufly<WRAP, 22>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, sh);
+
+    // LDS transpose (re plane, im plane): regs become n3..0, lane bit i = n(9-i)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
+        const int row_j = 4 * j1 + 8 * j0 + 16 * j3 + 32 * j2;
+        wr_base[ROWU * row_j] = (u32)re[j];
+        wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
+        re[4 * q + 0] = (int)x.x;
+        re[4 * q + 1] = (int)x.y;
+        re[4 * q + 2] = (int)x.z;
+        re[4 * q + 3] = (int)x.w;
+        im[4 * q + 0] = (int)y.x;
+        im[4 * q + 1] = (int)y.y;
+        im[4 * q + 2] = (int)y.z;
+        im[4 * q + 3] = (int)y.w;
+    }
+    asm volatile("" ::: "memory");
+
+    // stages 3, 2 (uniform twiddles), 1, 0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ufly<WRAP, 23, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ufly<WRAP, 24, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        ufly_triv(re[g], im[g], re[g + 2], im[g + 2]);
+        ufly_mj(re[g + 1], im[g + 1], re[g + 3], im[g + 3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) ufly_triv(re[g], im[g], re[g + 1], im[g + 1]);
+}
+
+template <bool FAST_OK>
+__global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt, const UConsts c,
+                                                     size_t nframes, int sh)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *lds = lds_all + wv * 2 * 64 * ROWU;
+
+    int w9r[8], w9i[8], w8r[4], w8i[4], w7r[2], w7i[2], w6r, w6i, w5r, w5i, w4r, w4i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int2 w = twt[511 + 64 * j + lane];
+        w9r[j] = w.x;
+        w9i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int2 w = twt[255 + 64 * j + lane];
+        w8r[j] = w.x;
+        w8i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int2 w = twt[127 + 64 * j + lane];
+        w7r[j] = w.x;
+        w7i[j] = w.y;
+    }
+    {
+        int2 w = twt[63 + lane];
+        w6r = w.x;
+        w6i = w.y;
+        w = twt[31 + (lane & 31)];
+        w5r = w.x;
+        w5i = w.y;
+        w = twt[15 + (lane & 15)];
+        w4r = w.x;
+        w4i = w.y;
+    }
+    const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
+    u32 *wr_base = lds + ROWU * (t5 + 2 * t4) + (lane & 15);
+    const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWU * lane);
+
+    const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
+    for (size_t f = wave0; f < nframes; f += nwaves) {
+        const u32 *src = in + f * 1024 + lane;
+        u32 raw[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j);
+        bool fast = false;
+        if (FAST_OK) {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc |= raw[j] + 0x40004000u;
+            fast = __builtin_amdgcn_ballot_w64((acc & 0x80008000u) != 0) == 0;
+        }
+        int re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            re[j] = __builtin_amdgcn_sbfe((int)raw[j], 0, 16);
+            im[j] = (int)raw[j] >> 16;
+        }
+        if (FAST_OK && fast) utransform<false>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
+        else utransform<true>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
+        int2 *dst = out + f * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i y = {re[r], im[r]};
+            __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + 64 * rr));
+        }
+    }
+}
+
+bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
+                         int in_order, int out_order)
+{
+    return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && direction == 0 &&
+           use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *fast1024u_kernel_name() { return "k_fft1024_u32"; }
+
+template <bool FAST_OK>
+static hipError_t launchu(const u32 *in, int2 *out, const int2 *tw, const UConsts &c, size_t nframes, int sh,
+                          hipStream_t stream)
+{
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_u32<FAST_OK>, 256, 0) != hipSuccess || per_cu <= 0)
+            per_cu = 2;
+        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    }
+    const size_t need = (nframes + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    hipLaunchKernelGGL(k_fft1024_u32<FAST_OK>, dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+                       c, nframes, sh);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
+                            hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    UConsts c;
+    for (int k = 0; k < 8; ++k) {
+        c.wr3[k] = h_tw[7 + k].x;
+        c.wi3[k] = h_tw[7 + k].y;
+    }
+    for (int k = 0; k < 4; ++k) {
+        c.wr2[k] = h_tw[3 + k].x;
+        c.wi2[k] = h_tw[3 + k].y;
+    }
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    const u32 *pin = static_cast<const u32 *>(in);
+    int2 *pout = static_cast<int2 *>(out);
+    return allow_fast ? launchu<true>(pin, pout, tw_all, c, nframes, twd - 1, stream)
+                      : launchu<false>(pin, pout, tw_all, c, nframes, twd - 1, stream);
+}
+
+} // namespace intfft

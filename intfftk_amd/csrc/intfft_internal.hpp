@@ -83,6 +83,13 @@ hipError_t launch_fast1024x(int direction, int twd, int in_bitrev, int out_halve
                             size_t nframes, hipStream_t stream);
 const char *fast1024x_kernel_name();
 
+// unscaled int32 wave kernel for N = 1024, 16-bit in -> 26-bit out (intfft_fast1024u.hip)
+bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
+                         int in_order, int out_order);
+hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
+                            hipStream_t stream);
+const char *fast1024u_kernel_name();
+
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order);

@@ -36,6 +36,7 @@ struct intfft_plan {
     bool fast1024 = false;
     bool fast4096 = false;
     bool fast1024x = false;
+    bool fast1024u = false;
     bool big20 = false;
     Fast1024Args fargs{};
     // host-streaming state (intfft_exec_host), created on first use
@@ -377,7 +378,12 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                                                        p->use_fly, p->in_order, p->out_order);
     pl->fast1024x = fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                         p->use_fly, p->in_order, p->out_order);
-    if (pl->fast4096) {
+    pl->fast1024u = fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+                                        p->in_order, p->out_order) &&
+                    !getenv("INTFFT_NO_FAST1024U");
+    if (pl->fast1024u) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024u_kernel_name());
+    } else if (pl->fast4096) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096_kernel_name());
     } else if (pl->fast1024x) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024x_kernel_name());
@@ -448,9 +454,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u;
     info->n_passes = fast ? 1 : (int)plan->passes.size();
-    info->compute_word = fast ? 2 : plan->word;
+    info->compute_word = plan->fast1024u ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -464,6 +470,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->fast1024u)
+        return (int)launch_fast1024u(plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024x)

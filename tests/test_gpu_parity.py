@@ -230,6 +230,34 @@ def test_fast1024x_native_orders(in_order, out_order):
     assert info["fast_path"] == 1
 
 
+@pytest.mark.parametrize("tw,new", [(16, True), (16, False), (12, True), (8, True)])
+def test_fast1024u_unscaled_wave_kernel(tw, new):
+    """The unscaled (bit-growth) wave kernel -- the testbench's "UNSCALED" mode at N = 1024: guard-bit frames
+    (wrap-free path), full-scale frames and the edge patterns (exact path with the per-stage width wrap)."""
+    x = np.concatenate([edge_frames(1024, 16), uniform_frames(300, 1024, 15, 51), uniform_frames(40, 1024, 16, 52),
+                        chirp_frame(1024)[None] * 64])
+    info = check(x, 10, 16, tw, 1, 0, new)
+    assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_u32")
+
+
+@pytest.mark.parametrize("batch", [1, 2, 5, 1027])
+def test_fast1024u_ragged_batches(batch):
+    x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
+    info = check(x, 10, 16, 16, 1, 0, True)
+    assert info["fast_path"] == 1
+
+
+def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
+    """Same plan through the generic k_pass<int32> kernels (INTFFT_NO_FAST1024U=1): the two device paths and
+    the oracle agree on the same frames."""
+    x = np.concatenate([uniform_frames(64, 1024, 16, 61), uniform_frames(64, 1024, 15, 62)])
+    fast, info_f = run_gpu(x, 10, 16, 16, 1, 0, True)
+    monkeypatch.setenv("INTFFT_NO_FAST1024U", "1")
+    slow, info_s = run_gpu(x, 10, 16, 16, 1, 0, True)
+    assert info_f["fast_path"] == 1 and info_s["fast_path"] == 0
+    assert np.array_equal(fast, slow)
+
+
 def test_native_cores_chain_like_the_pair():
     """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
     same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
