@@ -27,6 +27,7 @@ struct StageDesc {
     int rnd;     // RoundKind
     int sh_a;    // multiplier: per-product pre-shift  (0 in the single-DSP regimes)
     int sh_b;    // multiplier: post-sum shift
+    int narrow;  // 64-bit words: mw + TWDL_WIDTH <= 64, every product of the multiplier fits one int64
     unsigned tw_off; // offset of this stage's table in the twiddle buffer (int2 entries)
 };
 
@@ -55,7 +56,7 @@ template <typename T> __device__ __forceinline__ T neg_quirk(T x, int w)
 //   dbl35 (t-14, 12) int_cmult_dbl35_dsp48.vhd:163-168 | trpl52 (t-2, 0) int_cmult_trpl52_dsp48.vhd:166-170
 // 32-bit words: products fit int64 (|d| < 2^31, |w| < 2^26).
 __device__ __forceinline__ void cmult(int32_t dre, int32_t dim, int32_t wr, int32_t wi, int mw,
-                                      int a, int b, int32_t &ore, int32_t &oim)
+                                      int a, int b, int /*narrow*/, int32_t &ore, int32_t &oim)
 {
     const int64_t m2r = (int64_t)dre * wr, m1r = (int64_t)dim * wi; // RE: M2 - M1  (:192-207)
     const int64_t m2i = (int64_t)dre * wi, m1i = (int64_t)dim * wr; // IM: M2 + M1  (:209-224)
@@ -82,8 +83,15 @@ __device__ __forceinline__ uint64_t shr96(Prod96 p, int k)
     return ((uint64_t)p.h << (32 - k)) + (uint64_t)(p.l >> k);
 }
 __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int32_t wi, int mw,
-                                      int a, int b, int64_t &ore, int64_t &oim)
+                                      int a, int b, int narrow, int64_t &ore, int64_t &oim)
 {
+    if (narrow) { // |d| <= 2^(mw-1), |w| <= 2^(t-1), mw + t <= 64: products and their sum are exact in int64
+        const int64_t m2r = dre * (int64_t)wr, m1r = dim * (int64_t)wi;
+        const int64_t m2i = dre * (int64_t)wi, m1i = dim * (int64_t)wr;
+        ore = wrapw<int64_t>(((m2r >> a) - (m1r >> a)) >> b, mw);
+        oim = wrapw<int64_t>(((m2i >> a) + (m1i >> a)) >> b, mw);
+        return;
+    }
     const Prod96 m2r = mul96(dre, wr), m1r = mul96(dim, wi);
     const Prod96 m2i = mul96(dre, wi), m1i = mul96(dim, wr);
     uint64_t r, i;
@@ -139,7 +147,7 @@ __device__ __forceinline__ void dif_fly(const StageDesc &st, int odd, Cx<T> a, C
             y.im = neg_quirk<T>(d.re, st.wo);
         }
     } else { // :322-373
-        cmult(d.re, d.im, wr, wi, st.mw, st.sh_a, st.sh_b, y.re, y.im);
+        cmult(d.re, d.im, wr, wi, st.mw, st.sh_a, st.sh_b, st.narrow, y.re, y.im);
     }
 }
 
@@ -161,7 +169,7 @@ __device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, C
         }
     } else {
         T ore, oim;
-        cmult(b.im, b.re, wr, wi, st.mw, st.sh_a, st.sh_b, ore, oim);
+        cmult(b.im, b.re, wr, wi, st.mw, st.sh_a, st.sh_b, st.narrow, ore, oim);
         t.im = ore;
         t.re = oim;
     }

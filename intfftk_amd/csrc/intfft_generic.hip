@@ -130,6 +130,10 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
                 c.re = wrapw<T>(c.re, a.in_bits);
                 c.im = wrapw<T>(c.im, a.in_bits);
             }
+        } else if (sizeof(T) == 8 && a.scr_in_word == 4) { // written by a narrower (int32) pass
+            const Cx<int32_t> n = reinterpret_cast<const Cx<int32_t> *>(in)[(f0 + f) * N + j];
+            c.re = n.re;
+            c.im = n.im;
         } else {
             c = reinterpret_cast<const Cx<T> *>(in)[(f0 + f) * N + j];
         }

@@ -41,6 +41,8 @@ struct PassArgs {
     int ld_swap, st_swap;    // iterate the tile with the two runs swapped (coalescing of run1)
     int ld_memorder, st_memorder; // U == L only: sweep the frame in MEMORY order (coalesced global side,
                                   // the permutation is absorbed by the LDS side)
+    int word;        // k_pass<T>: bytes of this pass's on-chip word (4 / 8); 0 = the plan's word
+    int scr_in_word; // k_pass<T>: bytes of the scratch words this pass reads (<= word: an earlier, narrower pass)
     StageDesc st[MAX_STAGES_PER_PASS];
 };
 
@@ -89,6 +91,23 @@ bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, 
 hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
                             hipStream_t stream);
 const char *fast1024u_kernel_name();
+
+// two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
+struct WideStage {
+    int sh;            // a + b: bit offset of the result slice in the 64-bit sum
+    unsigned keep;     // ~(2^a - 1): per-product pre-truncation as a mask of the low dword
+    int az;            // a == 0 (exact sum first)
+    int s2, s3;        // 32-bit stages: alignbit amount sh + wo - 32, sign shift 32 - wo
+    int w32;           // 64-bit stages: wo - 32
+};
+struct WideArgs {
+    WideStage st[16];  // processing order: st[ii] is STAGE 15 - ii
+};
+bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                      int out_order);
+hipError_t launch_wide16(const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+                         const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *wide16_kernel_name();
 
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,

@@ -38,6 +38,8 @@ struct intfft_plan {
     bool fast1024x = false;
     bool fast1024u = false;
     bool big20 = false;
+    bool wide16 = false;
+    WideArgs wargs{};
     Fast1024Args fargs{};
     // host-streaming state (intfft_exec_host), created on first use
     hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
@@ -104,6 +106,7 @@ int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<Sta
         st.sh_a = st.sh_b = 0;
         if (st.s >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b))
             return INTFFT_ERR_UNSUPPORTED;
+        st.narrow = (st.mw + p.twdl_width <= 64 && !getenv("INTFFT_NO_NARROW_MUL")) ? 1 : 0;
         st.tw_off = (1u << st.s) - 1u; // tables of stages 0..s-1 precede: sum 2^i = 2^s - 1
         out.push_back(st);
     }
@@ -282,7 +285,25 @@ int build_passes(intfft_plan &pl)
                 a.st[a.nstages++] = d;
             }
         }
+        a.word = a.scr_in_word = pl.word;
         pl.passes.push_back(a);
+    }
+    // Mixed words: bit growth is monotonic, so the leading passes of a 64-bit plan may still fit 32-bit words
+    // (C3: the first 8 of 16 stages have widths <= 32).  Those passes run k_pass<int32> and write 8-byte
+    // scratch samples; the first 64-bit pass widens them on load.  Scratch is reused in place, so this needs the
+    // first 64-bit pass to be the last pass (it reads 8-byte samples and writes the user array).
+    if (pl.word == 8 && pl.passes.size() > 1 && !getenv("INTFFT_NO_MIXED_WORDS")) {
+        size_t k = 0;
+        for (; k < pl.passes.size(); ++k) {
+            const PassArgs &a = pl.passes[k];
+            bool fits = a.nstages > 0 && a.out_mode == IO_SCRATCH && !a.in_zext && (k > 0 || a.in_bits <= 32);
+            for (int i = 0; i < a.nstages && fits; ++i) fits = a.st[i].dtw <= 32 && a.st[i].wo <= 32;
+            if (!fits) break;
+        }
+        if (k + 1 == pl.passes.size()) {
+            for (size_t i = 0; i < k; ++i) pl.passes[i].word = 4, pl.passes[i].scr_in_word = 4;
+            pl.passes[k].scr_in_word = 4;
+        }
     }
     return INTFFT_OK;
 }
@@ -401,8 +422,28 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->big20 = big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
+        pl->wide16 = wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+                                      p->in_order, p->out_order) &&
+                     pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
+        if (pl->wide16) {
+            std::vector<StageDesc> st;
+            if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || st.size() != 16) pl->wide16 = false;
+            for (int ii = 0; ii < 16 && pl->wide16; ++ii) {
+                const StageDesc &d = st[ii];
+                WideStage &w = pl->wargs.st[ii];
+                w.sh = d.sh_a + d.sh_b;
+                w.keep = ~((1u << d.sh_a) - 1u);
+                w.az = d.sh_a == 0;
+                w.s2 = w.sh + d.wo - 32;
+                w.s3 = 32 - d.wo;
+                w.w32 = d.wo - 32;
+                if (d.s != 15 - ii || d.mw + p->twdl_width > 64) pl->wide16 = false;
+                if (d.s >= 2 && ii < 8 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
+                if (d.s >= 2 && ii >= 8 && (w.w32 < 1 || w.sh + w.w32 > 32)) pl->wide16 = false;
+            }
+        }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->big20 ? big20_kernel_name() : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name() : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -415,7 +456,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         if (pl->passes.size() > 1) {
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->word;
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->word == 2 ? 2 : pl->passes[0].word);
             size_t scratch_mb = pl->big20 ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
             if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
@@ -490,6 +531,12 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
+        if (plan->wide16) {
+            const hipError_t e = launch_wide16(plan->wargs, src, dst, plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf,
+                                               stream);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
         if (plan->big20) {
             const hipError_t e = launch_big20(plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw, plan->d_tw16f,
                                               plan->h_tw.data(), nf, stream);
@@ -502,7 +549,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             void *pout = a.out_mode == IO_USER ? dst : plan->d_scratch;
             const hipError_t e = plan->word == 2
                                      ? launch_pass16(a, pin, pout, plan->d_tw16f, plan->d_tw16i, nf, plan->p.twdl_width, stream)
-                                     : launch_pass(a, plan->word, pin, pout, plan->d_tw, nf, stream);
+                                     : launch_pass(a, a.word, pin, pout, plan->d_tw, nf, stream);
             if (e != hipSuccess) return (int)e;
         }
     }

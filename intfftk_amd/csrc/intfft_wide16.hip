@@ -1,0 +1,396 @@
+// intfft_wide16.hip -- two-pass kernels for BASELINE config 3: int_fftNk with NFFT = 16, DATA_WIDTH = 24,
+// FORMAT = 1 (full bit growth: 24-bit samples in int32 containers -> 40-bit results in int64 containers),
+// 16 <= TWDL_WIDTH <= 24, natural order in and out.
+//
+// The sixteen DIF stages split where the growing width crosses 32 bits (int_fftNk.vhd:187-207: stage ii has
+// DTW = 24 + ii inputs and 25 + ii bit outputs):
+//   pass 1  k_wide16_p1   STAGE 15..8  (ii 0..7, widths <= 32)  int32 registers, user array -> plan scratch
+//   pass 2  k_wide16_p2   STAGE 7..0   (ii 8..15, widths 33..40) 64-bit registers, plan scratch -> user array
+// Index n = 256 r + c.  Pass 1 transforms over r (a 256-thread workgroup owns 16 adjacent columns c of one
+// frame: 4096 samples, 16 per thread, 128-byte runs in global memory); pass 2 transforms over c (a workgroup
+// owns the 16 rows r = 16 j + r0, j = 0..15, i.e. the rows whose bit-reversed indices are adjacent, so that
+// each store instruction writes 256-byte runs of the natural-order output brev16(n)).  The scratch layout
+// [r0][j][c] makes the 4096 samples of a pass-2 workgroup contiguous.
+//
+// Each pass = two in-register rounds of four stages (registers carry 4 index bits) with one block-wide LDS
+// transpose between them, like intfft_fast4096.hip; arithmetic on unpacked registers like
+// intfft_fast1024u.hip.  All twiddles that depend on the thread are frame invariant and live in VGPRs
+// (pass 1: a workgroup keeps its column tile over its frame loop).
+//
+// Multiplier (int_cmult_dsp48.vhd:182-434, every regime): result = wrap_w(((M2 >> a) -/+ (M1 >> a)) >> b).
+//   a = 0 : exact sum first -> chained v_mad_i64_i32
+//   a > 0 : (M >> a) << a == M & ~(2^a - 1), so  ((M2 & K) -/+ (M1 & K)) >> (a + b)  with K = ~(2^a - 1)
+// and bits [a+b, a+b+w) of the 64-bit sum are sliced with v_alignbit_b32 (+ v_ashrrev / v_bfe for the sign).
+// 64-bit data d = dH * 2^32 + dL (dL signed): d * w = v_mad_i64_i32(dL, w) + (v_mul_lo_u32(dH, w) << 32),
+// exact because |d| < 2^39 and |w| < 2^23 (width 40 + 24 <= 64).
+#include "intfft_internal.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+using u32 = uint32_t;
+using u64 = unsigned long long;
+using i64 = long long;
+
+constexpr int ROWW = 20;              // LDS row stride in dwords (16 data + 4 pad)
+constexpr int PLANEW = 256 * ROWW;    // dwords per transpose plane
+#ifndef SCHED_GROUP
+#define SCHED_GROUP 2 // butterflies the scheduler may interleave (bounds the live 64-bit products)
+#endif
+
+__device__ __forceinline__ constexpr int rev4w(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// ---- 32-bit butterflies (pass 1) --------------------------------------------------------------------
+// s2 = a + b + wo - 32 (alignbit amount that leaves the wo result bits top-aligned), s3 = 32 - wo
+template <bool AZ>
+__device__ __forceinline__ void wfly32(int &are, int &aim, int &bre, int &bim, int wr, int wi, const WideStage &s)
+{
+    const int dre = are - bre, dim = aim - bim; // unscaled: exact, one bit of growth (int_dif2_fly.vhd:222-240)
+    are += bre;
+    aim += bim;
+    u64 xr, xi;
+    if (AZ) {
+        const int nd = -dim;
+        xr = (u64)((i64)dre * wr + (i64)nd * wi); // M2 - M1
+        xi = (u64)((i64)dre * wi + (i64)dim * wr); // M2 + M1
+    } else {
+        const u64 m2r = (u64)((i64)dre * wr), m1r = (u64)((i64)dim * wi);
+        const u64 m2i = (u64)((i64)dre * wi), m1i = (u64)((i64)dim * wr);
+        const u64 k = 0xFFFFFFFF00000000ull | s.keep;
+        xr = (m2r & k) - (m1r & k);
+        xi = (m2i & k) + (m1i & k);
+    }
+    bre = (int)__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.s2) >> s.s3;
+    bim = (int)__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.s2) >> s.s3;
+}
+
+template <int H, bool AZ>
+__device__ __forceinline__ void wstage32x(int (&re)[16], int (&im)[16], const int (&wr)[H], const int (&wi)[H],
+                                          const WideStage &s)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2 * H)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            wfly32<AZ>(re[g + j], im[g + j], re[g + j + H], im[g + j + H], wr[j], wi[j], s);
+            if (SCHED_GROUP && ((g / 2 + j) % SCHED_GROUP) == SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+template <int H>
+__device__ __forceinline__ void wstage32(int (&re)[16], int (&im)[16], const int (&wr)[H], const int (&wi)[H],
+                                         const WideStage &s)
+{
+    wstage32x<H, false>(re, im, wr, wi, s); // the masked form covers a = 0 too (keep = ~0)
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
+                                                   const WideArgs a, size_t nframes)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    const int tile = blockIdx.x & 15;
+    const int c = 16 * tile + lo4;
+
+    // frame-invariant twiddles; table of STAGE s starts at twt + 2^s - 1, index = n mod 2^s, n = c + 256 r
+    // round 1: thread = (r3..0 = hi4, c3..0), registers r7..4
+    int w15r[8], w15i[8], w14r[4], w14i[4], w13r[2], w13i[2], w12r[1], w12i[1];
+    // round 2: thread = (r7..4, c3..0), registers r3..0: indices depend on c only
+    int w11r[8], w11i[8], w10r[4], w10i[4], w9r[2], w9i[2], w8r[1], w8i[1];
+    {
+        const int base = c + 256 * hi4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int2 w = twt[32767 + base + 4096 * j];
+            w15r[j] = w.x, w15i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int2 w = twt[16383 + base + 4096 * j];
+            w14r[j] = w.x, w14i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int2 w = twt[8191 + base + 4096 * j];
+            w13r[j] = w.x, w13i[j] = w.y;
+        }
+        int2 w = twt[4095 + base];
+        w12r[0] = w.x, w12i[0] = w.y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w = twt[2047 + c + 256 * j];
+            w11r[j] = w.x, w11i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w = twt[1023 + c + 256 * j];
+            w10r[j] = w.x, w10i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w = twt[511 + c + 256 * j];
+            w9r[j] = w.x, w9i[j] = w.y;
+        }
+        w = twt[255 + c];
+        w8r[0] = w.x, w8i[0] = w.y;
+    }
+    // transpose: element (thread (hi4, lo4), register j) -> row 16 j + lo4, column hi4; thread t reads row t
+    u32 *const wr_re = lds + ROWW * lo4 + hi4;
+    u32 *const wr_im = wr_re + PLANEW;
+    const uint4 *const rd_re = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
+    const uint4 *const rd_im = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
+
+    const size_t fstep = gridDim.x >> 4;
+    for (size_t f = blockIdx.x >> 4; f < nframes; f += fstep) {
+        int re[16], im[16];
+        const int2 *src = in + f * 65536 + c + 256 * hi4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(src + 4096 * j));
+            re[j] = __builtin_amdgcn_sbfe(x.x, 0, 24); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
+            im[j] = __builtin_amdgcn_sbfe(x.y, 0, 24);
+        }
+        wstage32<8>(re, im, w15r, w15i, a.st[0]);
+        wstage32<4>(re, im, w14r, w14i, a.st[1]);
+        wstage32<2>(re, im, w13r, w13i, a.st[2]);
+        wstage32<1>(re, im, w12r, w12i, a.st[3]);
+        __syncthreads(); // the previous frame's reads are done
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            wr_re[ROWW * 16 * j] = (u32)re[j];
+            wr_im[ROWW * 16 * j] = (u32)im[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd_re[q], y = rd_im[q];
+            re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
+            im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
+        }
+        wstage32<8>(re, im, w11r, w11i, a.st[4]);
+        wstage32<4>(re, im, w10r, w10i, a.st[5]);
+        wstage32<2>(re, im, w9r, w9i, a.st[6]);
+        wstage32<1>(re, im, w8r, w8i, a.st[7]);
+        // now thread = (r7..4 = hi4, c3..0), register q = r3..0: scratch [r0 = q][j = hi4][c]
+        int2 *dst = scr + f * 65536 + 256 * hi4 + c;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[4096 * q] = make_int2(re[q], im[q]);
+    }
+}
+
+// ---- 64-bit butterflies (pass 2) --------------------------------------------------------------------
+struct W2Consts {
+    int wr3[8], wi3[8]; // STAGE 3 twiddles (wave uniform)
+    int wr2[4], wi2[4]; // STAGE 2
+};
+
+__device__ __forceinline__ u64 mul64x32(int dl, int dh, int w)
+{
+    return (u64)((i64)dl * w) + ((u64)((u32)dh * (u32)w) << 32);
+}
+
+// sh = a + b, w32 = wo - 32 (1..8)
+template <bool AZ, bool UNIFORM_W>
+__device__ __forceinline__ void wfly64(i64 &are, i64 &aim, i64 &bre, i64 &bim, int wr, int wi, const WideStage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
+    const i64 dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    const int rl = (int)dre, rh = (int)(dre >> 32) - (rl >> 31);
+    const int il = (int)dim, ih = (int)(dim >> 32) - (il >> 31);
+    u64 m2r = mul64x32(rl, rh, wr), m1r = mul64x32(il, ih, wi);
+    u64 m2i = mul64x32(rl, rh, wi), m1i = mul64x32(il, ih, wr);
+    if (!AZ) {
+        const u64 k = 0xFFFFFFFF00000000ull | s.keep;
+        m2r &= k, m1r &= k, m2i &= k, m1i &= k;
+    }
+    const u64 xr = m2r - m1r, xi = m2i + m1i;
+    const u32 lr = __builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh);
+    const u32 li = __builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh);
+    const int hr = __builtin_amdgcn_sbfe((int)(xr >> 32), s.sh, s.w32);
+    const int hi = __builtin_amdgcn_sbfe((int)(xi >> 32), s.sh, s.w32);
+    bre = (i64)(((u64)(u32)hr << 32) | lr);
+    bim = (i64)(((u64)(u32)hi << 32) | li);
+}
+__device__ __forceinline__ void wfly64_triv(i64 &are, i64 &aim, i64 &bre, i64 &bim)
+{
+    const i64 dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dre;
+    bim = dim;
+}
+// odd positions of STAGE 1: Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re  (int_dif2_fly.vhd:297-304)
+__device__ __forceinline__ void wfly64_mj(i64 &are, i64 &aim, i64 &bre, i64 &bim)
+{
+    const i64 dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dim;
+    bim = (dre >> 63) - dre;
+}
+
+template <int H, bool AZ, bool UNIFORM_W>
+__device__ __forceinline__ void wstage64x(i64 (&re)[16], i64 (&im)[16], const int (&wr)[H], const int (&wi)[H],
+                                          const WideStage &s)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2 * H)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            wfly64<AZ, UNIFORM_W>(re[g + j], im[g + j], re[g + j + H], im[g + j + H], wr[j], wi[j], s);
+            if (SCHED_GROUP && ((g / 2 + j) % SCHED_GROUP) == SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+template <int H, bool UNIFORM_W = false>
+__device__ __forceinline__ void wstage64(i64 (&re)[16], i64 (&im)[16], const int (&wr)[H], const int (&wi)[H],
+                                         const WideStage &s)
+{
+    wstage64x<H, false, UNIFORM_W>(re, im, wr, wi, s);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
+                                                   const WideArgs a, const W2Consts k, size_t nframes)
+{
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+
+    // round 1: thread = (j = hi4, c3..0 = lo4), registers c7..4: STAGE 7 index 16 jj + lo4, ... STAGE 4 index lo4
+    int w7r[8], w7i[8], w6r[4], w6i[4], w5r[2], w5i[2], w4r[1], w4i[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int2 w = twt[127 + 16 * j + lo4];
+        w7r[j] = w.x, w7i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int2 w = twt[63 + 16 * j + lo4];
+        w6r[j] = w.x, w6i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int2 w = twt[31 + 16 * j + lo4];
+        w5r[j] = w.x, w5i[j] = w.y;
+    }
+    {
+        const int2 w = twt[15 + lo4];
+        w4r[0] = w.x, w4i[0] = w.y;
+    }
+    // transpose: element (thread (j = hi4, c3..0 = lo4), register c7..4 = q) -> row 16 q + j, column c3..0;
+    // thread t reads row t, so afterwards thread = (c7..4 = hi4', j = lo4'), registers c3..0
+    u32 *const wr0 = lds + ROWW * hi4 + lo4;
+    u32 *const wr1 = wr0 + PLANEW;
+    const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
+    const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
+
+    // work unit u = 16 f + r0
+    const size_t units = nframes * 16;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const size_t f = u >> 4;
+        const int r0 = (int)(u & 15);
+        i64 re[16], im[16];
+        const int2 *src = scr + f * 65536 + 4096 * r0 + 256 * hi4 + lo4;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int2 x = src[16 * q];
+            re[q] = x.x;
+            im[q] = x.y;
+        }
+        wstage64<8>(re, im, w7r, w7i, a.st[8]);
+        wstage64<4>(re, im, w6r, w6i, a.st[9]);
+        wstage64<2>(re, im, w5r, w5i, a.st[10]);
+        wstage64<1>(re, im, w4r, w4i, a.st[11]);
+        // 36-bit values through three dword planes: re.lo, im.lo, then (re.hi & 0xFFFF) | (im.hi << 16)
+        u32 hp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hp[q] = ((u32)((u64)re[q] >> 32) & 0xFFFFu) | ((u32)((u64)im[q] >> 32) << 16);
+        u32 rlo[16], ilo[16];
+        __syncthreads(); // the previous unit's reads are done
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wr0[ROWW * 16 * q] = (u32)re[q];
+            wr1[ROWW * 16 * q] = (u32)im[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd0[q], y = rd1[q];
+            rlo[4 * q + 0] = x.x, rlo[4 * q + 1] = x.y, rlo[4 * q + 2] = x.z, rlo[4 * q + 3] = x.w;
+            ilo[4 * q + 0] = y.x, ilo[4 * q + 1] = y.y, ilo[4 * q + 2] = y.z, ilo[4 * q + 3] = y.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wr0[ROWW * 16 * q] = hp[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd0[q];
+            hp[4 * q + 0] = x.x, hp[4 * q + 1] = x.y, hp[4 * q + 2] = x.z, hp[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            re[q] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[q], 0, 16) << 32) | rlo[q]);
+            im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
+        }
+        // round 2: registers c3..0: STAGE 3, 2 (uniform twiddles), 1, 0
+        wstage64<8, true>(re, im, k.wr3, k.wi3, a.st[12]);
+        wstage64<4, true>(re, im, k.wr2, k.wi2, a.st[13]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            wfly64_triv(re[g], im[g], re[g + 2], im[g + 2]);
+            wfly64_mj(re[g + 1], im[g + 1], re[g + 3], im[g + 3]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) wfly64_triv(re[g], im[g], re[g + 1], im[g + 1]);
+        // natural-order output index brev16(256 r + c) = 4096 rev4(c3..0) + 256 rev4(c7..4) + 16 rev4(r0) + rev4(j)
+        typedef i64 v2l __attribute__((ext_vector_type(2)));
+        v2l *dst = reinterpret_cast<v2l *>(out) + f * 65536 + 256 * rev4w(hi4) + 16 * rev4w(r0) + rev4w(lo4);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2l y = {re[q], im[q]};
+            __builtin_nontemporal_store(y, dst + 4096 * rev4w(q));
+        }
+    }
+}
+
+bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                      int out_order)
+{
+    return log2n == 16 && data_width == 24 && twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 &&
+           use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *wide16_kernel_name() { return "k_wide16_p1+p2"; }
+
+hipError_t launch_wide16(const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+                         const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    static int per1 = 0, per2 = 0, cus = 0;
+    if (!per1) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, k_wide16_p1, 256, 0) != hipSuccess || per1 <= 0) per1 = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, k_wide16_p2, 256, 0) != hipSuccess || per2 <= 0) per2 = 2;
+        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per1 = per2 = atoi(e) > 0 ? atoi(e) : per1;
+    }
+    W2Consts k;
+    for (int i = 0; i < 8; ++i) k.wr3[i] = h_tw[7 + i].x, k.wi3[i] = h_tw[7 + i].y;
+    for (int i = 0; i < 4; ++i) k.wr2[i] = h_tw[3 + i].x, k.wi2[i] = h_tw[3 + i].y;
+    const size_t units = nframes * 16;
+    size_t g1 = (size_t)cus * (size_t)per1 & ~(size_t)15; // a multiple of the 16 column tiles
+    if (g1 < 16) g1 = 16;
+    if (g1 > units) g1 = units;
+    size_t g2 = (size_t)cus * (size_t)per2;
+    if (g2 > units) g2 = units;
+    hipLaunchKernelGGL(k_wide16_p1, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in),
+                       static_cast<int2 *>(scratch), tw_all, a, nframes);
+    hipLaunchKernelGGL(k_wide16_p2, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch),
+                       static_cast<i64 *>(out), tw_all, a, k, nframes);
+    return hipGetLastError();
+}
+
+} // namespace intfft

@@ -85,7 +85,7 @@ def test_all_single_pass_lengths(log2n, mode):
 
 
 @pytest.mark.parametrize("log2n,dw,tw,fmt", [(15, 16, 16, 0), (15, 16, 16, 1), (16, 24, 24, 1), (16, 24, 16, 1),
-                                              (13, 24, 24, 1), (17, 16, 16, 0), (14, 20, 16, 0)])
+                                              (13, 24, 24, 1), (17, 16, 16, 0), (14, 20, 16, 0), (17, 20, 16, 1), (18, 18, 24, 1)])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_multi_pass_lengths(log2n, dw, tw, fmt, direction):
     """N beyond one LDS tile: strided + contiguous passes through plan scratch; Taylor twiddles."""
@@ -96,6 +96,18 @@ def test_multi_pass_lengths(log2n, dw, tw, fmt, direction):
     for in_o, out_o in [("NATURAL", "NATURAL"), ("HALVES", "BITREV")]:
         info = check(x, log2n, dw, tw, fmt, 0, True, direction=direction, in_order=in_o, out_order=out_o)
         assert info["n_passes"] >= 2
+
+
+@pytest.mark.parametrize("env", ["INTFFT_NO_MIXED_WORDS", "INTFFT_NO_NARROW_MUL"])
+def test_wide_plan_variants_agree(env, monkeypatch):
+    """64-bit plans: int32 leading passes / single-int64 products are optimisations of the same arithmetic --
+    switching either off gives the same bits (and both equal the oracle)."""
+    x = uniform_frames(3, 1 << 16, 24, 4242)
+    a, _ = run_gpu(x, 16, 24, 24, 1, 0, True)
+    monkeypatch.setenv(env, "1")
+    b, _ = run_gpu(x, 16, 24, 24, 1, 0, True)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, run_ref(x, 16, 24, 24, 1, 0, True))
 
 
 def test_config4_n_2pow20_taylor_extension():
