@@ -67,32 +67,59 @@ template <bool ROUND> struct Twiddles {
 constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B aligned, conflict-free)
 
 // ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
-template <bool ROUND, bool OUT_BITREV, bool FASTX>
+// Frames shorter than 1024 samples (L = log2 N in 6..9): the wave owns a chunk of 1024 consecutive samples
+// = 2^(10-L) whole frames; chunk index bits a9..aL number the frame, a(L-1)..a0 the sample.  The stages of
+// the frame-number bits are skipped (the twiddle index of STAGE s is the position mod 2^s, so the remaining
+// stages are unchanged) and only the I/O permutation differs.  lane_bit<L>(k): the lane bit that carries
+// index bit a_k (k = 4..9) after the LDS transpose.
+//   L = 10: lane bit i = a(9-i), so that X index = rev4(r) * 64 + lane (256-byte runs per store).
+//   L < 10: lane bits 5, 4 = a(L-1), a(L-2): two lane swaps after the last stage bring them into registers,
+//           every lane then owns 4 consecutive outputs (brev_L puts a(L-1), a(L-2) into output bits 0, 1) and
+//           stores them as one dwordx4; lane bits 0.. carry a(L-3), a(L-4).. (output bits 2, 3..), then the
+//           frame bits.
+template <int L> __host__ __device__ constexpr int lane_bit(int k)
+{
+    if (L == 10) return 9 - k;
+    if (k == L - 1) return 5;
+    if (k == L - 2) return 4;
+    if (k < L - 2) return (L - 3) - k;
+    return (L - 6) + (k - L);
+}
+// weight (dwords) of index bit a_k in the natural-order output of a chunk: in-frame bits are bit-reversed
+template <int L> __host__ __device__ constexpr int out_weight(int k) { return k >= L ? (1 << k) : (1 << (L - 1 - k)); }
+
+template <int L, bool ROUND, bool OUT_BITREV, bool FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                                const uint4 *rd_base, v2s sh3)
+                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok)
 {
+    static_assert(L >= 6 && L <= 10, "wave kernel: 64 <= N <= 1024");
+    static_assert(L == 10 || !OUT_BITREV, "BITREV output only for N = 1024");
     // P (truncate mode): multiplier outputs are emitted pre-shifted (Y >> 1); after a stage with
     // register offset h the registers with (j & h) != 0 hold Y >> 1, the others hold S.
     constexpr bool P = !ROUND;
     constexpr bool Q = !ROUND;
-    constexpr int M0 = 0, MH = P ? 0xC : 0, MA = P ? 0xF : 0, MODD = P ? 0xA : 0; // PREMASKs
+    constexpr int M0 = 0, MA = P ? 0xF : 0;                                      // PREMASKs
+    constexpr int MH = (P && L >= 10) ? 0xC : 0;                                 // stage 8 after stage 9
+    constexpr int MODD7 = (P && L >= 9) ? 0xA : 0, MODD6 = (P && L >= 8) ? 0xA : 0, MODD5 = (P && L >= 7) ? 0xA : 0;
 
     // ---- phase 1: stages 9, 8, 7, 6 (register offsets 8, 4, 2, 1) ----
     if constexpr (Q) {
-        group4<ROUND, FASTX, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], tw.wa9, tw.wb9, sl);
-        group4<ROUND, FASTX, Q, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], tw.wa9, tw.wb9, sl);
+        if constexpr (L >= 10) {
+            group4<ROUND, FASTX, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], tw.wa9, tw.wb9, sl);
+            group4<ROUND, FASTX, Q, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], tw.wa9, tw.wb9, sl);
+        }
         // stage 8: (j, j+4); kind of the inputs = j & 8
-        {
+        if constexpr (L >= 9) {
             const u32 wa[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[0], tw.wa8[1]}, wb[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[0], tw.wb8[1]};
             group4<ROUND, FASTX, false, P, false, MH>(v[0], v[4], v[1], v[5], v[8], v[12], v[9], v[13], wa, wb, sl);
             group4<ROUND, FASTX, Q, P, false, MH>(v[2], v[6], v[3], v[7], v[10], v[14], v[11], v[15], wa, wb, sl);
         }
         // stage 7: (j, j+2); kind = j & 4; pairs with j odd use the quarter turn of wa7[0]
-        {
+        if constexpr (L >= 8) {
             const u32 wa[4] = {tw.wa7[0], tw.wa7[0], tw.wa7[0], tw.wa7[0]}, wb[4] = {tw.wb7[0], tw.wb7[0], tw.wb7[0], tw.wb7[0]};
-            group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa, wb, sl);
-            group4<ROUND, FASTX, Q, P, false, MODD>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa, wb, sl);
+            group4<ROUND, FASTX, false, P, false, MODD7>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa, wb, sl);
+            group4<ROUND, FASTX, Q, P, false, MODD7>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa, wb, sl);
         }
     } else {
         const u32 wa9a[4] = {tw.wa9[0], tw.wa9[1], tw.wa9[2], tw.wa9[3]}, wb9a[4] = {tw.wb9[0], tw.wb9[1], tw.wb9[2], tw.wb9[3]};
@@ -100,22 +127,28 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
                              tw.wa9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wa9[7 % (8 / Twiddles<ROUND>::NQ)]};
         const u32 wb9b[4] = {tw.wb9[4 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[5 % (8 / Twiddles<ROUND>::NQ)],
                              tw.wb9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[7 % (8 / Twiddles<ROUND>::NQ)]};
-        group4<ROUND, false, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa9a, wb9a, sl);
-        group4<ROUND, false, false, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa9b, wb9b, sl);
+        if constexpr (L >= 10) {
+            group4<ROUND, false, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa9a, wb9a, sl);
+            group4<ROUND, false, false, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa9b, wb9b, sl);
+        }
         constexpr int N8 = 4 / Twiddles<ROUND>::NQ, N7 = 2 / Twiddles<ROUND>::NQ;
         const u32 wa8a[4] = {tw.wa8[0], tw.wa8[1 % N8], tw.wa8[0], tw.wa8[1 % N8]}, wb8a[4] = {tw.wb8[0], tw.wb8[1 % N8], tw.wb8[0], tw.wb8[1 % N8]};
         const u32 wa8b[4] = {tw.wa8[2 % N8], tw.wa8[3 % N8], tw.wa8[2 % N8], tw.wa8[3 % N8]}, wb8b[4] = {tw.wb8[2 % N8], tw.wb8[3 % N8], tw.wb8[2 % N8], tw.wb8[3 % N8]};
-        group4<ROUND, false, false, P, false, MH>(v[0], v[4], v[1], v[5], v[8], v[12], v[9], v[13], wa8a, wb8a, sl);
-        group4<ROUND, false, false, P, false, MH>(v[2], v[6], v[3], v[7], v[10], v[14], v[11], v[15], wa8b, wb8b, sl);
+        if constexpr (L >= 9) {
+            group4<ROUND, false, false, P, false, MH>(v[0], v[4], v[1], v[5], v[8], v[12], v[9], v[13], wa8a, wb8a, sl);
+            group4<ROUND, false, false, P, false, MH>(v[2], v[6], v[3], v[7], v[10], v[14], v[11], v[15], wa8b, wb8b, sl);
+        }
         const u32 wa7a[4] = {tw.wa7[0], tw.wa7[0], tw.wa7[0], tw.wa7[0]}, wb7a[4] = {tw.wb7[0], tw.wb7[0], tw.wb7[0], tw.wb7[0]};
         const u32 wa7b[4] = {tw.wa7[1 % N7], tw.wa7[1 % N7], tw.wa7[1 % N7], tw.wa7[1 % N7]}, wb7b[4] = {tw.wb7[1 % N7], tw.wb7[1 % N7], tw.wb7[1 % N7], tw.wb7[1 % N7]};
-        group4<ROUND, false, false, P, false, MODD>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa7a, wb7a, sl);
-        group4<ROUND, false, false, P, false, MODD>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa7b, wb7b, sl);
+        if constexpr (L >= 8) {
+            group4<ROUND, false, false, P, false, MODD7>(v[0], v[2], v[4], v[6], v[8], v[10], v[12], v[14], wa7a, wb7a, sl);
+            group4<ROUND, false, false, P, false, MODD7>(v[1], v[3], v[5], v[7], v[9], v[11], v[13], v[15], wa7b, wb7b, sl);
+        }
     }
-    { // stage 6: (j, j+1), j even; kind = j & 2; one twiddle per lane
+    if constexpr (L >= 7) { // stage 6: (j, j+1), j even; kind = j & 2; one twiddle per lane
         const u32 wa[4] = {tw.wa6[0], tw.wa6[0], tw.wa6[0], tw.wa6[0]}, wb[4] = {tw.wb6[0], tw.wb6[0], tw.wb6[0], tw.wb6[0]};
-        group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
-        group4<ROUND, FASTX, false, P, false, MODD>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD6>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD6>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
     }
 
     // ---- lane bit 5 <-> reg bit 3, stage 5: (j, j+8); kind = j & 1 ----
@@ -123,8 +156,8 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);
     {
         const u32 wa[4] = {tw.wa5[0], tw.wa5[0], tw.wa5[0], tw.wa5[0]}, wb[4] = {tw.wb5[0], tw.wb5[0], tw.wb5[0], tw.wb5[0]};
-        group4<ROUND, FASTX, false, P, false, MODD>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa, wb, sl);
-        group4<ROUND, FASTX, false, P, false, MODD>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD5>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa, wb, sl);
+        group4<ROUND, FASTX, false, P, false, MODD5>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa, wb, sl);
     }
 
     // ---- lane bit 4 <-> reg bit 2, stage 4: (j, j+4); kind = j & 8 ----
@@ -144,7 +177,10 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
-        const int row_j = OUT_BITREV ? (8 * j1 + 4 * j0 + 2 * j3 + j2) : (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2);
+        // at this point reg j3 = a5, j2 = a4, j1 = a7, j0 = a6
+        const int row_j = OUT_BITREV ? (8 * j1 + 4 * j0 + 2 * j3 + j2)
+                                     : ((j1 << lane_bit<L>(7)) + (j0 << lane_bit<L>(6)) + (j3 << lane_bit<L>(5)) +
+                                        (j2 << lane_bit<L>(4)));
         wr_base[ROW_DW * row_j] = v[j];
     }
     asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
@@ -195,6 +231,24 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
             const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             __builtin_nontemporal_store(x, dst + 64 * q);
         }
+    } else if constexpr (L < 10) {
+        // regs a3..a0, lane bits 5, 4 = a(L-1), a(L-2): after the swaps reg bit 3 = a(L-1), bit 2 = a(L-2) and the
+        // four registers {q, q+8, q+4, q+12} are four consecutive outputs (q = a1 a0)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        u32 *dst = out + f * 1024 + lane_off;
+        if (st_ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4u x = {v[q], v[q + 8], v[q + 4], v[q + 12]};
+                __builtin_nontemporal_store(x, reinterpret_cast<v4u *>(dst + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
+            }
+        }
     } else {
         u32 *dst = out + f * 1024 + lane;
 #pragma unroll
@@ -205,10 +259,13 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     }
 }
 
-template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+template <int L, bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                     const Fast1024Consts c, size_t nframes, const Slice sl, int in_halves)
+                                                     const Fast1024Consts c, size_t nframes_user, const Slice sl,
+                                                     int in_halves)
 {
+    constexpr int FP = 1 << (10 - L);                         // frames per 1024-sample chunk
+    const size_t nframes = (nframes_user + FP - 1) / FP;      // chunks ("frames" of the wave loop below)
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROW_DW];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: frame addresses stay scalar
@@ -218,28 +275,37 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     // stage s table starts at twt + 2^s - 1; index = position mod 2^s (rom_twiddle_int.vhd:187-202)
     Twiddles<ROUND> tw;
     constexpr int NQ = Twiddles<ROUND>::NQ;
+    if constexpr (L >= 10) {
 #pragma unroll
-    for (int j = 0; j < 8 / NQ; ++j) {
-        const int2 w = twt[511 + 64 * j + lane];
-        tw.wa9[j] = pack_wa(w);
-        tw.wb9[j] = pack_wb(w);
+        for (int j = 0; j < 8 / NQ; ++j) {
+            const int2 w = twt[511 + 64 * j + lane];
+            tw.wa9[j] = pack_wa(w);
+            tw.wb9[j] = pack_wb(w);
+        }
     }
+    if constexpr (L >= 9) {
 #pragma unroll
-    for (int j = 0; j < 4 / NQ; ++j) {
-        const int2 w = twt[255 + 64 * j + lane];
-        tw.wa8[j] = pack_wa(w);
-        tw.wb8[j] = pack_wb(w);
+        for (int j = 0; j < 4 / NQ; ++j) {
+            const int2 w = twt[255 + 64 * j + lane];
+            tw.wa8[j] = pack_wa(w);
+            tw.wb8[j] = pack_wb(w);
+        }
     }
+    if constexpr (L >= 8) {
 #pragma unroll
-    for (int j = 0; j < 2 / NQ; ++j) {
-        const int2 w = twt[127 + 64 * j + lane];
-        tw.wa7[j] = pack_wa(w);
-        tw.wb7[j] = pack_wb(w);
+        for (int j = 0; j < 2 / NQ; ++j) {
+            const int2 w = twt[127 + 64 * j + lane];
+            tw.wa7[j] = pack_wa(w);
+            tw.wb7[j] = pack_wb(w);
+        }
     }
     {
-        int2 w = twt[63 + lane];
-        tw.wa6[0] = pack_wa(w);
-        tw.wb6[0] = pack_wb(w);
+        int2 w;
+        if constexpr (L >= 7) {
+            w = twt[63 + lane];
+            tw.wa6[0] = pack_wa(w);
+            tw.wb6[0] = pack_wb(w);
+        }
         w = twt[31 + (lane & 31)];
         tw.wa5[0] = pack_wa(w);
         tw.wb5[0] = pack_wb(w);
@@ -255,20 +321,42 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     //   BITREV : row = n9..n4        (memory index = n = row * 16 + r)
     const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
     const int wr_lane = OUT_BITREV ? ROW_DW * (32 * t5 + 16 * t4) + (lane & 15)
-                                   : ROW_DW * (t5 + 2 * t4) + (lane & 15);
+                                   : ROW_DW * ((t5 << lane_bit<L>(9)) + (t4 << lane_bit<L>(8))) + (lane & 15);
     u32 *wr_base = lds + wr_lane;
     const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROW_DW * lane);
     // stage 3 per-lane shift: lanes whose n4 = 1 hold Y >> 1 already (n4 = row bit 5 / bit 0)
-    const int n4 = OUT_BITREV ? (lane & 1) : (lane >> 5);
+    const int n4 = OUT_BITREV ? (lane & 1) : ((lane >> lane_bit<L>(4)) & 1);
     const v2s sh3 = {(short)(1 - n4), (short)(1 - n4)};
+    // N < 1024: output offset (dwords) of this lane's dwordx4 stores within the chunk and its frame within
+    // the chunk; after the output swaps lane bit 5 = a3, lane bit 4 = a2, the rest as lane_bit<L>()
+    int lane_off = 0, lane_frame = 0;
+    if constexpr (L < 10) {
+        lane_off = ((lane >> 5) & 1) * out_weight<L>(3) + ((lane >> 4) & 1) * out_weight<L>(2);
+#pragma unroll
+        for (int k = 4; k < 10; ++k) {
+            if (k == L - 1 || k == L - 2) continue;
+            const int bit = (lane >> lane_bit<L>(k)) & 1;
+            lane_off += bit * out_weight<L>(k);
+            if (k >= L) lane_frame += bit << (k - L);
+        }
+    }
 
     auto run = [&](u32(&v)[16], size_t f) {
+        const bool st_ok = L == 10 || f * FP + (size_t)lane_frame < nframes_user; // partial last chunk
         if (FAST_OK && frame_has_guard_bit(v))
-            transform_store<ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok);
         else
-            transform_store<ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3);
+            transform_store<L, ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
+        if (L < 10 && (f + 1) * FP > nframes_user) { // partial last chunk: samples of absent frames read as 0
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const size_t fr = f * FP + (size_t)((64 * j + lane) >> L);
+                v[j] = fr < nframes_user ? in[f * 1024 + 64 * j + lane] : 0u;
+            }
+            return;
+        }
         if (in_halves) { // HALVES: beat i holds (x[i], x[i + 512]) = (v[j], v[j + 8]) for i = 64 j + lane
             typedef u32 v2u __attribute__((ext_vector_type(2)));
             const v2u *src2 = reinterpret_cast<const v2u *>(in + f * 1024) + lane;
@@ -314,8 +402,10 @@ bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, i
                         int use_fly, int in_order, int out_order)
 {
     (void)rndmode;
-    return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
-           direction == 0 && use_fly == 1 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
+    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && direction == 0 && use_fly == 1))
+        return false;
+    if (log2n == 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
+    return log2n >= 6 && log2n < 10 && in_order == 0 && out_order == 0; // 64 <= N < 1024: natural order only
 }
 
 const char *fast1024_kernel_name() { return "k_fft1024_i16"; }
@@ -326,7 +416,7 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+template <int L, bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, int in_halves, hipStream_t stream)
 {
@@ -336,7 +426,7 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_i16<ROUND, OUT_BITREV, PIPE, FAST_OK>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>, 256,
                                                          0) != hipSuccess ||
             per_cu <= 0)
             per_cu = 4;
@@ -344,27 +434,41 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
         const int e = env_int("INTFFT_BLOCKS_PER_CU", 0);
         if (e > 0) per_cu = e;
     }
-    const size_t need = (nframes + 3) / 4;
+    const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L); // 1024-sample chunks, one per wave pass
+    const size_t need = (chunks + 3) / 4;
     const size_t cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
-    hipLaunchKernelGGL((k_fft1024_i16<ROUND, OUT_BITREV, PIPE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out,
+    hipLaunchKernelGGL((k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out,
                        tw, c, nframes, sl, in_halves);
     return hipGetLastError();
 }
 
-template <bool ROUND, bool OUT_BITREV>
+template <int L, bool ROUND, bool OUT_BITREV>
 static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, bool fast_ok, int in_halves, hipStream_t stream)
 {
-    static const int pipe = env_int("INTFFT_FAST_PIPE", 1);          // 1: two frames in flight per wave
+    static const int pipe_env = env_int("INTFFT_FAST_PIPE", 1);      // 1: two frames in flight per wave
     static const int allow_fast = env_int("INTFFT_FAST_EXTRACT", 1); // 0: always the exact extraction
+    constexpr bool ONLY_PIPE = L < 10;                               // short frames: pipelined variant only
+    const bool pipe = ONLY_PIPE || pipe_env;
     if constexpr (!ROUND) {
-        if (fast_ok && allow_fast)
-            return pipe ? launch_k<ROUND, OUT_BITREV, true, true>(in, out, tw, c, nframes, sl, in_halves, stream)
-                        : launch_k<ROUND, OUT_BITREV, false, true>(in, out, tw, c, nframes, sl, in_halves, stream);
+        if (fast_ok && allow_fast) {
+            if constexpr (!ONLY_PIPE)
+                if (!pipe) return launch_k<L, ROUND, OUT_BITREV, false, true>(in, out, tw, c, nframes, sl, in_halves, stream);
+            return launch_k<L, ROUND, OUT_BITREV, true, true>(in, out, tw, c, nframes, sl, in_halves, stream);
+        }
     }
-    return pipe ? launch_k<ROUND, OUT_BITREV, true, false>(in, out, tw, c, nframes, sl, in_halves, stream)
-                : launch_k<ROUND, OUT_BITREV, false, false>(in, out, tw, c, nframes, sl, in_halves, stream);
+    if constexpr (!ONLY_PIPE)
+        if (!pipe) return launch_k<L, ROUND, OUT_BITREV, false, false>(in, out, tw, c, nframes, sl, in_halves, stream);
+    return launch_k<L, ROUND, OUT_BITREV, true, false>(in, out, tw, c, nframes, sl, in_halves, stream);
+}
+
+template <int L>
+static hipError_t launch_short(bool round, const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c,
+                               size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
+{
+    return round ? launch_t<L, true, false>(in, out, tw, c, nframes, sl, false, 0, stream)
+                 : launch_t<L, false, false>(in, out, tw, c, nframes, sl, fast_ok, 0, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
@@ -386,11 +490,19 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
     const bool fast_ok = a.twd == 16; // high halves == bits [31:16] only for t = 16
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    if (a.rnd == RND_ROUND)
-        return a.out_bitrev ? launch_t<true, true>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream)
-                            : launch_t<true, false>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream);
-    return a.out_bitrev ? launch_t<false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream)
-                        : launch_t<false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream);
+    const bool round = a.rnd == RND_ROUND;
+    switch (a.log2n) {
+    case 6: return launch_short<6>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 7: return launch_short<7>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 8: return launch_short<8>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 9: return launch_short<9>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    default: break;
+    }
+    if (round)
+        return a.out_bitrev ? launch_t<10, true, true>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream)
+                            : launch_t<10, true, false>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream);
+    return a.out_bitrev ? launch_t<10, false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream)
+                        : launch_t<10, false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream);
 }
 
 } // namespace intfft

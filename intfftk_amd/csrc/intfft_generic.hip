@@ -8,6 +8,8 @@
 // speed path for the headline configuration; this kernel is the complete one.
 #include "intfft_internal.hpp"
 
+#include <cstdlib>
+
 #include <cmath>
 
 namespace intfft {
@@ -211,6 +213,11 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
 unsigned pass_threads(const PassArgs &a)
 {
     const size_t elems = (size_t)a.fpb << a.U;
+    static const int mode = getenv("INTFFT_PASS_THREADS") ? atoi(getenv("INTFFT_PASS_THREADS")) : 1;
+    if (mode == 1) { // one thread per register round group: 16 points (int32 words) / 8 points (int64 words)
+        const size_t t = elems / (a.word == 4 ? 16 : 8);
+        return (unsigned)(t < 256 ? 256 : t > 1024 ? 1024 : t);
+    }
     return elems >= 8192 ? 1024u : elems >= 4096 ? 512u : (unsigned)PASS_THREADS;
 }
 

@@ -65,6 +65,7 @@ const char *pass16_kernel_name();
 
 // packed int16 wave kernel for N = 1024 (intfft_fast1024.hip)
 struct Fast1024Args {
+    int log2n;      // 6..10: frames shorter than 1024 samples share a wave (2^(10 - log2n) per pass)
     int twd;        // twiddle width (<= 16)
     int rnd;        // RoundKind (RND_TRUNC / RND_ROUND)
     int out_bitrev; // 0: NATURAL output, 1: BITREV output

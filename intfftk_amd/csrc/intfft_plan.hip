@@ -409,6 +409,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     } else if (pl->fast1024x) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024x_kernel_name());
     } else if (pl->fast1024) {
+        pl->fargs.log2n = p->log2n;
         pl->fargs.twd = p->twdl_width;
         pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
         pl->fargs.out_bitrev = p->out_order == INTFFT_ORDER_BITREV;

@@ -288,6 +288,22 @@ def test_native_cores_chain_like_the_pair():
         c.close()
 
 
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9])
+@pytest.mark.parametrize("rnd", [0, 1])
+def test_wave_kernel_short_frames(log2n, rnd):
+    """64 <= N < 1024: 2^(10 - log2n) frames share a wave of the N = 1024 kernel (the reference testbench's own
+    NFFT = 7 is one of them: fft_signle_test.vhd:93).  Guard-bit frames, full-scale frames and edge patterns mixed
+    inside one chunk; batch sizes that leave the last chunk partial."""
+    n = 1 << log2n
+    for batch, seed in [(1, 1), (3, 2), ((1 << (10 - log2n)) + 1, 3), (1000, 4), (4099, 5)]:
+        x = np.concatenate([uniform_frames(batch, n, 15, 300 + seed), edge_frames(n, 16),
+                            uniform_frames(5, n, 16, 400 + seed)])
+        info = check(x, log2n, 16, 16, 0, rnd, True)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_i16")
+    check(uniform_frames(77, n, 15, 9), log2n, 16, 12, 0, rnd, True)  # narrower twiddles: exact extraction
+    check(uniform_frames(77, n, 15, 9), log2n, 16, 16, 0, rnd, False)  # XSER = "OLD"
+
+
 @pytest.mark.parametrize("cfg", [(10, "FWD"), (10, "INV"), (10, "PAIR"), (12, "FWD"), (12, "INV"), (12, "PAIR")])
 @pytest.mark.parametrize("batch", [1, 3, 5, 1027])
 def test_fast_kernels_ragged_batches(cfg, batch):

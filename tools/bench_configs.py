@@ -70,7 +70,22 @@ def run(name, steps=20, check_frames=8):
     return out
 
 
+def adhoc(spec):
+    """spec "L:DW:TW:FMT[:RND[:DIR]]" -> a 256 MiB-input config with that shape, e.g. 11:16:16:0"""
+    f = spec.split(":")
+    log2n, dw, tw, fmt = (int(v) for v in f[:4])
+    rnd = int(f[4]) if len(f) > 4 else 0
+    direction = f[5] if len(f) > 5 else "FWD"
+    in_cb = 2 if dw <= 16 else 4 if dw <= 32 else 8
+    ob = dw + (fmt * log2n) * (2 if direction == "PAIR" else 1)
+    out_cb = 2 if ob <= 16 else 4 if ob <= 32 else 8
+    batch = max(1, (256 << 20) // ((2 * in_cb) << log2n))
+    CONFIGS[spec] = (log2n, dw, tw, fmt, rnd, direction, batch, min(dw, 31) - 1, 2 * (in_cb + out_cb))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CONFIGS)
     for nm in names:
+        if nm not in CONFIGS:
+            adhoc(nm)
         print(json.dumps(run(nm)), flush=True)
