@@ -67,27 +67,6 @@ template <bool ROUND> struct Twiddles {
 constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B aligned, conflict-free)
 
 // ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
-// Frames shorter than 1024 samples (L = log2 N in 6..9): the wave owns a chunk of 1024 consecutive samples
-// = 2^(10-L) whole frames; chunk index bits a9..aL number the frame, a(L-1)..a0 the sample.  The stages of
-// the frame-number bits are skipped (the twiddle index of STAGE s is the position mod 2^s, so the remaining
-// stages are unchanged) and only the I/O permutation differs.  lane_bit<L>(k): the lane bit that carries
-// index bit a_k (k = 4..9) after the LDS transpose.
-//   L = 10: lane bit i = a(9-i), so that X index = rev4(r) * 64 + lane (256-byte runs per store).
-//   L < 10: lane bits 5, 4 = a(L-1), a(L-2): two lane swaps after the last stage bring them into registers,
-//           every lane then owns 4 consecutive outputs (brev_L puts a(L-1), a(L-2) into output bits 0, 1) and
-//           stores them as one dwordx4; lane bits 0.. carry a(L-3), a(L-4).. (output bits 2, 3..), then the
-//           frame bits.
-template <int L> __host__ __device__ constexpr int lane_bit(int k)
-{
-    if (L == 10) return 9 - k;
-    if (k == L - 1) return 5;
-    if (k == L - 2) return 4;
-    if (k < L - 2) return (L - 3) - k;
-    return (L - 6) + (k - L);
-}
-// weight (dwords) of index bit a_k in the natural-order output of a chunk: in-frame bits are bit-reversed
-template <int L> __host__ __device__ constexpr int out_weight(int k) { return k >= L ? (1 << k) : (1 << (L - 1 - k)); }
-
 template <int L, bool ROUND, bool OUT_BITREV, bool FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
@@ -152,6 +131,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     }
 
     // ---- lane bit 5 <-> reg bit 3, stage 5: (j, j+8); kind = j & 1 ----
+    swap_guard(v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);
     {
@@ -161,6 +141,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     }
 
     // ---- lane bit 4 <-> reg bit 2, stage 4: (j, j+4); kind = j & 8 ----
+    swap_guard(v);
 #pragma unroll
     for (int g = 0; g < 16; g += 8)
 #pragma unroll
@@ -218,6 +199,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     if (OUT_BITREV) {
         // memory index = n.  Two lane swaps turn (regs n3..0, lane n9..4) into (regs n9 n8 n1 n0,
         // lane n3 n2 n7..4): every lane then owns 4 consecutive n and a store instruction covers 1 KiB
+        swap_guard(v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
 #pragma unroll
@@ -234,6 +216,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     } else if constexpr (L < 10) {
         // regs a3..a0, lane bits 5, 4 = a(L-1), a(L-2): after the swaps reg bit 3 = a(L-1), bit 2 = a(L-2) and the
         // four registers {q, q+8, q+4, q+12} are four consecutive outputs (q = a1 a0)
+        swap_guard(v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
 #pragma unroll

@@ -29,6 +29,17 @@ struct UConsts {
     int wr2[4], wi2[4]; // STAGE 2
 };
 
+// Short frames (L < 10), 8-byte outputs: ONE lane swap after the last stage (lane bit 5 = a(L-1) <-> reg bit 3)
+// gives every lane two consecutive outputs = one dwordx4 store, and lane bits 0, 1, .. carry a(L-2), a(L-3), ..
+// (output bits 1, 2, ..) so that adjacent lanes write adjacent 16-byte pieces; then the frame bits.
+template <int L> __host__ __device__ constexpr int lane_bit_u(int k)
+{
+    if (L == 10) return 9 - k;
+    if (k == L - 1) return 5;
+    if (k < L - 1) return (L - 2) - k;
+    return (L - 5) + (k - L);
+}
+
 constexpr int ROWU = 20; // LDS row stride in dwords, per plane (re plane then im plane)
 
 // one general DIF butterfly, unscaled; WO = output width of the stage
@@ -72,28 +83,48 @@ __device__ __forceinline__ void ufly_mj(int &are, int &aim, int &bre, int &bim)
     bim = (dre >> 31) - dre; // -x for x >= 0, -x - 1 = ~x for x < 0
 }
 
-__device__ __forceinline__ void uswap32(int &a, int &b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void uswap16(int &a, int &b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void uswap32(int &a, int &b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap((u32)a, (u32)b, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+}
+__device__ __forceinline__ void uswap16(int &a, int &b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((u32)a, (u32)b, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+}
 
-template <bool WRAP>
+template <int L, bool WRAP>
 __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const int (&w9r)[8], const int (&w9i)[8],
                                            const int (&w8r)[4], const int (&w8i)[4], const int (&w7r)[2],
                                            const int (&w7i)[2], int w6r, int w6i, int w5r, int w5i, int w4r, int w4i,
                                            const UConsts &c, int sh, u32 *wr_base, const uint4 *rd_base)
 {
-    // stage s has output width WO = 26 - s
+    // STAGE s is stage ii = L - 1 - s of the pipeline: output width 17 + ii = 16 + L - s (int_fftNk.vhd:187-207)
+    if constexpr (L >= 10) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ufly<WRAP, 17>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], sh);
+        for (int j = 0; j < 8; ++j) ufly<WRAP, 16 + L - 9>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], sh);
+    }
+    if constexpr (L >= 9) {
 #pragma unroll
-    for (int g = 0; g < 16; g += 8)
+        for (int g = 0; g < 16; g += 8)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ufly<WRAP, 18>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], sh);
+            for (int j = 0; j < 4; ++j)
+                ufly<WRAP, 16 + L - 8>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], sh);
+    }
+    if constexpr (L >= 8) {
 #pragma unroll
-    for (int g = 0; g < 16; g += 4)
+        for (int g = 0; g < 16; g += 4)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ufly<WRAP, 19>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], sh);
+            for (int j = 0; j < 2; ++j)
+                ufly<WRAP, 16 + L - 7>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], sh);
+    }
+    if constexpr (L >= 7) {
 #pragma unroll
-    for (int g = 0; g < 16; g += 2) ufly<WRAP, 20>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, sh);
+        for (int g = 0; g < 16; g += 2) ufly<WRAP, 16 + L - 6>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, sh);
+    }
     // lane bit 5 <-> reg bit 3, stage 5
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -101,7 +132,7 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
         uswap32(im[j], im[j + 8]);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ufly<WRAP, 21>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, sh);
+    for (int j = 0; j < 8; ++j) ufly<WRAP, 16 + L - 5>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, sh);
     // lane bit 4 <-> reg bit 2, stage 4
 #pragma unroll
     for (int g = 0; g < 16; g += 8)
@@ -113,14 +144,15 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
 #pragma unroll
     for (int g = 0; g < 16; g += 8)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ufly<WRAP, 22>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, sh);
+        for (int j = 0; j < 4; ++j) ufly<WRAP, 16 + L - 4>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, sh);
 
     // LDS transpose (re plane, im plane): regs become n3..0, lane bit i = n(9-i)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
-        const int row_j = 4 * j1 + 8 * j0 + 16 * j3 + 32 * j2;
+        // reg j3 = a5, j2 = a4, j1 = a7, j0 = a6 here (intfft_fast1024.hip)
+        const int row_j = (j1 << lane_bit_u<L>(7)) + (j0 << lane_bit_u<L>(6)) + (j3 << lane_bit_u<L>(5)) + (j2 << lane_bit_u<L>(4));
         wr_base[ROWU * row_j] = (u32)re[j];
         wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
     }
@@ -141,11 +173,11 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
 
     // stages 3, 2 (uniform twiddles), 1, 0
 #pragma unroll
-    for (int r = 0; r < 8; ++r) ufly<WRAP, 23, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], sh);
+    for (int r = 0; r < 8; ++r) ufly<WRAP, 16 + L - 3, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], sh);
 #pragma unroll
     for (int g = 0; g < 16; g += 8)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ufly<WRAP, 24, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], sh);
+        for (int r = 0; r < 4; ++r) ufly<WRAP, 16 + L - 2, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], sh);
 #pragma unroll
     for (int g = 0; g < 16; g += 4) {
         ufly_triv(re[g], im[g], re[g + 2], im[g + 2]);
@@ -155,38 +187,49 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
     for (int g = 0; g < 16; g += 2) ufly_triv(re[g], im[g], re[g + 1], im[g + 1]);
 }
 
-template <bool FAST_OK>
+template <int L, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt, const UConsts c,
-                                                     size_t nframes, int sh)
+                                                     size_t nframes_user, int sh)
 {
+    constexpr int FP = 1 << (10 - L);                    // frames per 1024-sample chunk (intfft_fast1024.hip)
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32 *lds = lds_all + wv * 2 * 64 * ROWU;
 
-    int w9r[8], w9i[8], w8r[4], w8i[4], w7r[2], w7i[2], w6r, w6i, w5r, w5i, w4r, w4i;
+    int w9r[8] = {}, w9i[8] = {}, w8r[4] = {}, w8i[4] = {}, w7r[2] = {}, w7i[2] = {}, w6r = 0, w6i = 0, w5r, w5i, w4r, w4i;
+    if constexpr (L >= 10) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int2 w = twt[511 + 64 * j + lane];
-        w9r[j] = w.x;
-        w9i[j] = w.y;
+        for (int j = 0; j < 8; ++j) {
+            const int2 w = twt[511 + 64 * j + lane];
+            w9r[j] = w.x;
+            w9i[j] = w.y;
+        }
     }
+    if constexpr (L >= 9) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int2 w = twt[255 + 64 * j + lane];
-        w8r[j] = w.x;
-        w8i[j] = w.y;
+        for (int j = 0; j < 4; ++j) {
+            const int2 w = twt[255 + 64 * j + lane];
+            w8r[j] = w.x;
+            w8i[j] = w.y;
+        }
     }
+    if constexpr (L >= 8) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int2 w = twt[127 + 64 * j + lane];
-        w7r[j] = w.x;
-        w7i[j] = w.y;
+        for (int j = 0; j < 2; ++j) {
+            const int2 w = twt[127 + 64 * j + lane];
+            w7r[j] = w.x;
+            w7i[j] = w.y;
+        }
     }
     {
-        int2 w = twt[63 + lane];
-        w6r = w.x;
-        w6i = w.y;
+        int2 w;
+        if constexpr (L >= 7) {
+            w = twt[63 + lane];
+            w6r = w.x;
+            w6i = w.y;
+        }
         w = twt[31 + (lane & 31)];
         w5r = w.x;
         w5i = w.y;
@@ -195,15 +238,32 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
         w4i = w.y;
     }
     const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
-    u32 *wr_base = lds + ROWU * (t5 + 2 * t4) + (lane & 15);
+    u32 *wr_base = lds + ROWU * ((t5 << lane_bit_u<L>(9)) + (t4 << lane_bit_u<L>(8))) + (lane & 15);
+    int lane_off = 0, lane_frame = 0; // N < 1024: see intfft_fast1024.hip
+    if constexpr (L < 10) {
+        lane_off = ((lane >> 5) & 1) * out_weight<L>(3);
+#pragma unroll
+        for (int k = 4; k < 10; ++k) {
+            if (k == L - 1) continue;
+            const int bit = (lane >> lane_bit_u<L>(k)) & 1;
+            lane_off += bit * out_weight<L>(k);
+            if (k >= L) lane_frame += bit << (k - L);
+        }
+    }
     const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWU * lane);
 
     const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
     for (size_t f = wave0; f < nframes; f += nwaves) {
         const u32 *src = in + f * 1024 + lane;
         u32 raw[16];
+        if (L < 10 && (f + 1) * FP > nframes_user) { // partial last chunk: absent frames read as 0
 #pragma unroll
-        for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j);
+            for (int j = 0; j < 16; ++j)
+                raw[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j] : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j);
+        }
         bool fast = false;
         if (FAST_OK) {
             u32 acc = 0;
@@ -217,15 +277,35 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
             re[j] = __builtin_amdgcn_sbfe((int)raw[j], 0, 16);
             im[j] = (int)raw[j] >> 16;
         }
-        if (FAST_OK && fast) utransform<false>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
-        else utransform<true>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
-        int2 *dst = out + f * 1024 + lane;
+        if (FAST_OK && fast) utransform<L, false>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
+        else utransform<L, true>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
+        if constexpr (L < 10) {
+            // one lane swap per plane: reg bit 3 = a(L-1); registers {q, q+8} are two consecutive outputs
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
-            typedef int v2i __attribute__((ext_vector_type(2)));
-            const v2i y = {re[r], im[r]};
-            __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + 64 * rr));
+            for (int r = 0; r < 8; ++r) {
+                uswap32(re[r], re[r + 8]);
+                uswap32(im[r], im[r + 8]);
+            }
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            int2 *dst = out + f * 1024 + lane_off;
+            if (f * FP + (size_t)lane_frame < nframes_user) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4i y = {re[q], im[q], re[q + 8], im[q + 8]};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v4i *>(dst + (q & 1) * out_weight<L>(0) +
+                                                                           ((q >> 1) & 1) * out_weight<L>(1) +
+                                                                           (q >> 2) * out_weight<L>(2)));
+                }
+            }
+        } else {
+            int2 *dst = out + f * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i y = {re[r], im[r]};
+                __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + 64 * rr));
+            }
         }
     }
 }
@@ -233,13 +313,13 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
 bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                          int in_order, int out_order)
 {
-    return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && direction == 0 &&
+    return log2n >= 6 && log2n <= 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && direction == 0 &&
            use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
 const char *fast1024u_kernel_name() { return "k_fft1024_u32"; }
 
-template <bool FAST_OK>
+template <int L, bool FAST_OK>
 static hipError_t launchu(const u32 *in, int2 *out, const int2 *tw, const UConsts &c, size_t nframes, int sh,
                           hipStream_t stream)
 {
@@ -248,17 +328,25 @@ static hipError_t launchu(const u32 *in, int2 *out, const int2 *tw, const UConst
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_u32<FAST_OK>, 256, 0) != hipSuccess || per_cu <= 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_u32<L, FAST_OK>, 256, 0) != hipSuccess || per_cu <= 0)
             per_cu = 2;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
-    const size_t need = (nframes + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
-    hipLaunchKernelGGL(k_fft1024_u32<FAST_OK>, dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+    const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
+    const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    hipLaunchKernelGGL((k_fft1024_u32<L, FAST_OK>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
                        c, nframes, sh);
     return hipGetLastError();
 }
 
-hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
+template <int L>
+static hipError_t launchu_l(bool fast, const u32 *in, int2 *out, const int2 *tw, const UConsts &c, size_t nframes, int sh,
+                            hipStream_t stream)
+{
+    return fast ? launchu<L, true>(in, out, tw, c, nframes, sh, stream) : launchu<L, false>(in, out, tw, c, nframes, sh, stream);
+}
+
+hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
                             hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -274,8 +362,13 @@ hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_a
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const u32 *pin = static_cast<const u32 *>(in);
     int2 *pout = static_cast<int2 *>(out);
-    return allow_fast ? launchu<true>(pin, pout, tw_all, c, nframes, twd - 1, stream)
-                      : launchu<false>(pin, pout, tw_all, c, nframes, twd - 1, stream);
+    switch (log2n) {
+    case 6: return launchu_l<6>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    case 7: return launchu_l<7>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    case 8: return launchu_l<8>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    case 9: return launchu_l<9>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    default: return launchu_l<10>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    }
 }
 
 } // namespace intfft

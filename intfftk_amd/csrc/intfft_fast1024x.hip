@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     {                                                                                                   \
         if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
             dif_round<FX, false>(v, ta, sl, sh3);                                                       \
+            swap_guard(v);                                                                              \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
             group4<false, FX, false, true, false, 0xA>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
             group4<false, FX, false, true, false, 0xA>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            swap_guard(v);                                                                              \
             _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
             group4<false, FX, false, true, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
@@ -141,10 +143,12 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         asm volatile("" ::: "memory");                                                                  \
         group4_dit<FX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);            \
         group4_dit<FX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl);      \
+        swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);               \
         group4_dit<FX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);          \
         group4_dit<FX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl);        \
+        swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
         dit_round<FX>(v, ta, sl);                                                                       \
     }

@@ -63,6 +63,28 @@ hipError_t launch_pass16(const PassArgs &a, const void *in, void *out, const uin
 hipError_t launch_pack_twiddles16(const int2 *tw, size_t n, uint2 *f, uint2 *i, hipStream_t stream);
 const char *pass16_kernel_name();
 
+// ---- wave kernels (intfft_fast1024.hip, intfft_fast1024u.hip): I/O permutation for short frames ----
+// Frames shorter than 1024 samples (L = log2 N in 6..9): the wave owns a chunk of 1024 consecutive samples
+// = 2^(10-L) whole frames; chunk index bits a9..aL number the frame, a(L-1)..a0 the sample.  The stages of
+// the frame-number bits are skipped (the twiddle index of STAGE s is the position mod 2^s, so the remaining
+// stages are unchanged) and only the I/O permutation differs.  lane_bit<L>(k): the lane bit that carries
+// index bit a_k (k = 4..9) after the LDS transpose.
+//   L = 10: lane bit i = a(9-i), so that X index = rev4(r) * 64 + lane (256-byte runs per store).
+//   L < 10: lane bits 5, 4 = a(L-1), a(L-2): two lane swaps after the last stage bring them into registers,
+//           every lane then owns 4 consecutive outputs (brev_L puts a(L-1), a(L-2) into output bits 0, 1) and
+//           stores them as one dwordx4; lane bits 0.. carry a(L-3), a(L-4).. (output bits 2, 3..), then the
+//           frame bits.
+template <int L> __host__ __device__ constexpr int lane_bit(int k)
+{
+    if (L == 10) return 9 - k;
+    if (k == L - 1) return 5;
+    if (k == L - 2) return 4;
+    if (k < L - 2) return (L - 3) - k;
+    return (L - 6) + (k - L);
+}
+// weight (dwords) of index bit a_k in the natural-order output of a chunk: in-frame bits are bit-reversed
+template <int L> __host__ __device__ constexpr int out_weight(int k) { return k >= L ? (1 << k) : (1 << (L - 1 - k)); }
+
 // packed int16 wave kernel for N = 1024 (intfft_fast1024.hip)
 struct Fast1024Args {
     int log2n;      // 6..10: frames shorter than 1024 samples share a wave (2^(10 - log2n) per pass)
@@ -89,7 +111,7 @@ const char *fast1024x_kernel_name();
 // unscaled int32 wave kernel for N = 1024, 16-bit in -> 26-bit out (intfft_fast1024u.hip)
 bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                          int in_order, int out_order);
-hipError_t launch_fast1024u(int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
+hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
                             hipStream_t stream);
 const char *fast1024u_kernel_name();
 

@@ -190,15 +190,26 @@ template <bool ROUND, bool IN_PRE> __device__ __forceinline__ void bfly_mj(u32 &
     b = nx + ((nx >> 31) << 16);                          // + 1 in the high half iff D.re >= 0
 }
 
-// lane-half / row exchanges; the leading s_nop covers "VALU write -> v_permlane read" (2 wait
-// states) for producers hipcc cannot see (the asm multiplies above)
+// lane-half / row exchanges (gfx950 v_permlane32_swap / v_permlane16_swap).  hipcc pads the hazards it can see;
+// swap_guard() covers "VALU write -> v_permlane read" for producers it cannot see (the asm multiplies above):
+// one s_nop tied to the registers about to be exchanged, once per group of swaps.
 __device__ __forceinline__ void swap32(u32 &a, u32 &b)
 {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
 }
 __device__ __forceinline__ void swap16(u32 &a, u32 &b)
 {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ __forceinline__ void swap_guard(u32 (&v)[16])
+{
+    asm("s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+          "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
 
 // Guard-bit test of one frame (wave-uniform result).  t = x + 0x40004000 has bit 15 / bit 31 clear

@@ -513,7 +513,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (plan->fast1024u)
-        return (int)launch_fast1024u(plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+        return (int)launch_fast1024u(plan->p.log2n, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024x)

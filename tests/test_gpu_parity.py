@@ -252,6 +252,19 @@ def test_fast1024u_unscaled_wave_kernel(tw, new):
     assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_u32")
 
 
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9])
+def test_unscaled_wave_kernel_short_frames(log2n):
+    """The testbench's "UNSCALED" UUT at 64 <= N < 1024 (NFFT = 7 is what fft_signle_test.vhd ships with)."""
+    n = 1 << log2n
+    for batch, seed in [(1, 1), (3, 2), ((1 << (10 - log2n)) + 1, 3), (1000, 4), (4099, 5)]:
+        x = np.concatenate([uniform_frames(batch, n, 15, 500 + seed), edge_frames(n, 16),
+                            uniform_frames(5, n, 16, 600 + seed)])
+        info = check(x, log2n, 16, 16, 1, 0, True)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_u32")
+    check(uniform_frames(77, n, 16, 9), log2n, 16, 12, 1, 0, True)
+    check(uniform_frames(77, n, 16, 9), log2n, 16, 16, 1, 0, False)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
