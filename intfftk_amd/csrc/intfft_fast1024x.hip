@@ -23,11 +23,17 @@ constexpr int ROWX = 20;
 
 enum { X_INV = 1, X_PAIR = 2 };
 
-template <int MODE, bool FAST_OK>
+// L < 10 (64 <= N < 1024, natural order only): 2^(10-L) frames share the wave as in intfft_fast1024.hip -- the
+// stages of the frame-number bits are skipped in both cores.  The pair needs no other change (it loads and stores
+// in the L1 layout); the inverse alone loads X[brev_L(n)] with the mirror image of the forward kernel's
+// short-frame store (dwordx4 loads + two lane swaps, LC lane bits per lane_bit<L>()).
+template <int L, int MODE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                      const RoundCConsts c, size_t nframes, const Slice sl, int in_bitrev,
-                                                      int out_halves)
+                                                      const RoundCConsts c, size_t nframes_user, const Slice sl,
+                                                      int in_bitrev, int out_halves)
 {
+    constexpr int FP = 1 << (10 - L), NS = L - 6;        // frames per chunk; executed stages among 9..6
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROWX];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -41,13 +47,19 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         wa = pack_wa(w);
         wb = pack_wb(w);
     };
+    if constexpr (L >= 10) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ld(511 + 64 * j + lane, ta.wa8[j], ta.wb8[j]);
+        for (int j = 0; j < 8; ++j) ld(511 + 64 * j + lane, ta.wa8[j], ta.wb8[j]);
+    }
+    if constexpr (L >= 9) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ld(255 + 64 * j + lane, ta.wa4[j], ta.wb4[j]);
+        for (int j = 0; j < 4; ++j) ld(255 + 64 * j + lane, ta.wa4[j], ta.wb4[j]);
+    }
+    if constexpr (L >= 8) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ld(127 + 64 * j + lane, ta.wa2[j], ta.wb2[j]);
-    ld(63 + lane, ta.wa1[0], ta.wb1[0]);
+        for (int j = 0; j < 2; ++j) ld(127 + 64 * j + lane, ta.wa2[j], ta.wb2[j]);
+    }
+    if constexpr (L >= 7) ld(63 + lane, ta.wa1[0], ta.wb1[0]);
     ld(31 + (lane & 31), wa5, wb5);
     ld(15 + (lane & 15), wa4, wb4);
     const u32 w5a[4] = {wa5, wa5, wa5, wa5}, w5b[4] = {wb5, wb5, wb5, wb5};
@@ -64,6 +76,19 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     // NATURAL input: LC lane bit i = n(9-i).  BITREV input (memory index = n): LC lane = n9..n4 (bit i = n(4+i))
     u32 *wr_i = in_bitrev ? lds + ROWX * (32 * l5 + 16 * l4) + ((l1 << 3) | (l0 << 2) | (l3 << 1) | l2)
                           : lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
+    int lane_off = 0, lane_frame = 0; // short-frame inverse: see intfft_fast1024.hip
+    if constexpr (L < 10 && MODE == X_INV) {
+        auto a = [&](int k) { return (lane >> lane_bit<L>(k)) & 1; }; // LC lane bit lane_bit<L>(k) = a_k
+        wr_i = lds + ROWX * (32 * a(9) + 16 * a(8)) + ((a(5) << 3) | (a(4) << 2) | (a(7) << 1) | a(6));
+        // while loading (before the swaps) lane bit 5 = a3 and lane bit 4 = a2
+        lane_off = ((lane >> 5) & 1) * out_weight<L>(3) + ((lane >> 4) & 1) * out_weight<L>(2);
+#pragma unroll
+        for (int k = 4; k < 10; ++k) {
+            if (k == L - 1 || k == L - 2) continue;
+            lane_off += a(k) * out_weight<L>(k);
+            if (k >= L) lane_frame += a(k) << (k - L);
+        }
+    }
     const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWX * lane);
     const short s3 = (short)(1 - (lane >> 5)); // LC: kind = n4 = lane bit 5
     const v2s sh3 = {s3, s3};
@@ -72,7 +97,32 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     for (size_t f = wave0; f < nframes; f += nwaves) {
         u32 v[16];
         const u32 *src = in + f * 1024;
-        if (MODE == X_INV && in_bitrev) {
+        const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0, not stored
+        if (L < 10 && MODE == X_INV) {
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4u x = {0u, 0u, 0u, 0u};
+                if (ok)
+                    x = __builtin_nontemporal_load(
+                        reinterpret_cast<const v4u *>(src + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
+                v[q] = x.x;
+                v[q + 8] = x.y;
+                v[q + 4] = x.z;
+                v[q + 12] = x.w;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+        } else if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j + lane] : 0u;
+        } else if (MODE == X_INV && in_bitrev) {
             // memory index = n: x4 loads give (regs n9 n8 n1 n0, lane n3 n2 n7..4); two lane swaps -> (regs n3..0, lane n9..4)
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const v4u *s4 = reinterpret_cast<const v4u *>(src) + (((lane & 15) << 2) | (lane >> 4));
@@ -105,11 +155,11 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 #define INTFFT_XBODY(FX)                                                                                \
     {                                                                                                   \
         if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
-            dif_round<FX, false>(v, ta, sl, sh3);                                                       \
+            dif_round<FX, false, NS>(v, ta, sl, sh3);                                                       \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
-            group4<false, FX, false, true, false, 0xA>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
-            group4<false, FX, false, true, false, 0xA>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            group4<false, FX, false, true, false, (NS >= 1 ? 0xA : 0)>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
+            group4<false, FX, false, true, false, (NS >= 1 ? 0xA : 0)>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
@@ -150,7 +200,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         group4_dit<FX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl);        \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
-        dit_round<FX>(v, ta, sl);                                                                       \
+        dit_round<FX, NS>(v, ta, sl);                                                                       \
     }
         if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
         else INTFFT_XBODY(false)
@@ -163,6 +213,11 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 const v2u w = {v[j], v[j + 8]};
                 __builtin_nontemporal_store(w, d2 + 64 * j);
             }
+        } else if (partial) {
+            u32 *dst = out + f * 1024 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (f * FP + (size_t)((64 * j + lane) >> L) < nframes_user) dst[64 * j] = v[j];
         } else {
             u32 *dst = out + f * 1024 + lane;
 #pragma unroll
@@ -174,15 +229,16 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
                          int use_fly, int in_order, int out_order)
 {
-    return log2n == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           use_fly == 1 &&
-           ((direction == 2 && in_order == 0 && out_order == 0) ||
-            (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
+    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && use_fly == 1))
+        return false;
+    if (log2n >= 6 && log2n < 10) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
+    return log2n == 10 && ((direction == 2 && in_order == 0 && out_order == 0) ||
+                           (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
 }
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
 
-template <int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK>
 static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                           const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
 {
@@ -191,20 +247,32 @@ static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCC
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024x_i16<MODE, FAST_OK>, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024x_i16<L, MODE, FAST_OK>, 256, 0) != hipSuccess ||
             per_cu <= 0)
             per_cu = 4;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
-    const size_t need = (nframes + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
+    const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
-    hipLaunchKernelGGL((k_fft1024x_i16<MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
+    hipLaunchKernelGGL((k_fft1024x_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
                        in_bitrev, out_halves);
     return hipGetLastError();
 }
 
-hipError_t launch_fast1024x(int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                            size_t nframes, hipStream_t stream)
+template <int L>
+static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
+                            size_t nframes, const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
+{
+    if (direction == 1)
+        return fast_ok ? launchx<L, X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
+                       : launchx<L, X_INV, false>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    return fast_ok ? launchx<L, X_PAIR, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream)
+                   : launchx<L, X_PAIR, false>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+}
+
+hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
+                            const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -223,11 +291,13 @@ hipError_t launch_fast1024x(int direction, int twd, int in_bitrev, int out_halve
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    if (direction == 1)
-        return fast_ok ? launchx<X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
-                       : launchx<X_INV, false>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
-    return fast_ok ? launchx<X_PAIR, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream)
-                   : launchx<X_PAIR, false>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    switch (log2n) {
+    case 6: return launchx_l<6>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    case 7: return launchx_l<7>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    case 8: return launchx_l<8>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    case 9: return launchx_l<9>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    default: return launchx_l<10>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    }
 }
 
 } // namespace intfft

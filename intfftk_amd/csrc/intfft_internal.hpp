@@ -103,7 +103,7 @@ const char *fast1024_kernel_name();
 // packed int16 wave kernel for N = 1024, INV / PAIR (intfft_fast1024x.hip)
 bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
                          int use_fly, int in_order, int out_order);
-hipError_t launch_fast1024x(int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
+hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
                             const int2 *tw_all, const int2 *h_tw,
                             size_t nframes, hipStream_t stream);
 const char *fast1024x_kernel_name();

@@ -284,51 +284,57 @@ __device__ __forceinline__ void bfly_pj_dit(u32 &a, u32 &b)
 }
 
 // ---- four DIF stages on register offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0) -----------------------
-// kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount
-template <bool FASTX, bool VARSH0>
+// kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount.
+// NS < 4 runs only the last NS stages (short frames: the leading stages belong to frame-number bits).
+template <bool FASTX, bool VARSH0, int NS = 4>
 __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl, v2s shv)
 {
-    constexpr int M0 = 0, MA = 0xF;
-    {
+    constexpr int M0 = 0;
+    constexpr int MA4 = NS >= 4 ? 0xF : 0, MA2 = NS >= 3 ? 0xF : 0, MA1 = NS >= 2 ? 0xF : 0;
+    if constexpr (NS >= 4) {
         const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
         const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
         group4<false, FASTX, false, true, false, M0, VARSH0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
         group4<false, FASTX, false, true, false, M0, VARSH0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
     }
     // offset 4: pairs (j, j+4); kind = j & 8
-    group4<false, FASTX, false, true, false, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-    group4<false, FASTX, false, true, false, MA>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+    if constexpr (NS >= 3) {
+        group4<false, FASTX, false, true, false, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+        group4<false, FASTX, false, true, false, MA4>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+    }
     // offset 2: pairs (j, j+2); twiddle j & 1; kind = j & 4
-    {
+    if constexpr (NS >= 2) {
         const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
         group4<false, FASTX, false, true, false, M0>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
-        group4<false, FASTX, false, true, false, MA>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA2>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
     }
     // offset 1: pairs (j, j+1); kind = j & 2
-    {
+    if constexpr (NS >= 1) {
         const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
         group4<false, FASTX, false, true, false, M0>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
-        group4<false, FASTX, false, true, false, MA>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA1>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
     }
 }
 
-// ---- four DIT stages on register offsets 1, 2, 4, 8 --------------------------------------------------
-template <bool FASTX>
+// ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------
+template <bool FASTX, int NS = 4>
 __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)
 {
-    {
+    if constexpr (NS >= 1) {
         const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
         group4_dit<FASTX, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
         group4_dit<FASTX, false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
     }
-    {
+    if constexpr (NS >= 2) {
         const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
         group4_dit<FASTX, false>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
         group4_dit<FASTX, false>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
     }
-    group4_dit<FASTX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-    group4_dit<FASTX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
-    {
+    if constexpr (NS >= 3) {
+        group4_dit<FASTX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+        group4_dit<FASTX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+    }
+    if constexpr (NS >= 4) {
         const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
         const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
         group4_dit<FASTX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);

@@ -517,7 +517,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024x)
-        return (int)launch_fast1024x(plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
+        return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
     if (plan->fast4096)

@@ -317,6 +317,19 @@ def test_wave_kernel_short_frames(log2n, rnd):
     check(uniform_frames(77, n, 15, 9), log2n, 16, 16, 0, rnd, False)  # XSER = "OLD"
 
 
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9])
+@pytest.mark.parametrize("direction", ["INV", "PAIR"])
+def test_wave_kernel_short_frames_inverse_and_pair(log2n, direction):
+    """int_ifftNk / int_fft_ifft_pair at 64 <= N < 1024 (fft_double_test.vhd ships with NFFT = 7)."""
+    n = 1 << log2n
+    for batch, seed in [(1, 1), (3, 2), ((1 << (10 - log2n)) + 1, 3), (1000, 4), (4099, 5)]:
+        x = np.concatenate([uniform_frames(batch, n, 15, 700 + seed), edge_frames(n, 16),
+                            uniform_frames(5, n, 16, 800 + seed)])
+        info = check(x, log2n, 16, 16, 0, 0, True, direction=direction)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024x_i16")
+    check(uniform_frames(77, n, 15, 9), log2n, 16, 13, 0, 0, True, direction=direction)
+
+
 @pytest.mark.parametrize("cfg", [(10, "FWD"), (10, "INV"), (10, "PAIR"), (12, "FWD"), (12, "INV"), (12, "PAIR")])
 @pytest.mark.parametrize("batch", [1, 3, 5, 1027])
 def test_fast_kernels_ragged_batches(cfg, batch):
