@@ -49,10 +49,25 @@ constexpr int REGION4K = 256 * ROW4K; // dwords per transpose region
 
 enum { MODE_FWD = 0, MODE_INV = 1, MODE_PAIR = 2 };
 
-template <int MODE, bool FAST_OK>
-__global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                     const RoundCConsts c, size_t nframes, const Slice sl)
+// L = 11 (N = 2048): the workgroup owns a chunk of two frames; index bit n11 numbers the frame and its stage is
+// skipped in both cores (twiddle indices are positions mod 2^s, so nothing else changes).  lc_bit<L>(k): the bit
+// of the LC thread index t'' that carries index bit n_k (k = 4..11): in-frame bits reversed in the low bits,
+// frame bits on top, so that natural-order X of a frame = rev4(r) * 2^(L-4) + (low bits of t'') stays one
+// contiguous run per wave.
+template <int L> __host__ __device__ constexpr int lc_bit(int k) { return k < L ? (L - 1) - k : (L - 4) + (k - L); }
+template <int L> __host__ __device__ constexpr int lc_row_of_reg(int j) // LB register j' = n7..4 -> its LC thread bits
 {
+    return (((j >> 0) & 1) << lc_bit<L>(4)) | (((j >> 1) & 1) << lc_bit<L>(5)) | (((j >> 2) & 1) << lc_bit<L>(6)) |
+           (((j >> 3) & 1) << lc_bit<L>(7));
+}
+
+template <int L, int MODE, bool FAST_OK>
+__global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
+                                                     const RoundCConsts c, size_t nframes_user, const Slice sl)
+{
+    static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
+    constexpr int FP = 1 << (12 - L), NS = L - 8;        // frames per 4096-sample chunk; executed stages of round A
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
     u32 *const reg0 = lds, *const reg1 = lds + REGION4K;
     volatile u32 *const s_unsafe = lds + (ROW4K - 1); // a pad cell of row 0 (columns 16..19 are never transposed)
@@ -68,8 +83,10 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         wa = pack_wa(w);
         wb = pack_wb(w);
     };
+    if constexpr (L >= 12) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
+        for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) ld(1023 + 256 * j + tid, ta.wa4[j], ta.wb4[j]);
 #pragma unroll
@@ -86,27 +103,42 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     // ---- transpose addressing (dword offsets of this thread; register part is compile time) ----
     // LA -> LB and LB -> LA: element (thread x, reg y) -> row 16*y + x3..0, column x7..4
     const int w_ab = ROW4K * lo4 + hi4;
-    // LB -> LC: thread t' = (n11..8, n3..0), reg j' = n7..4 -> row rev4(n11..8) + 16*rev4(j'), column n3..0
-    const int rv_hi = ((hi4 & 1) << 3) | ((hi4 & 2) << 1) | ((hi4 & 4) >> 1) | ((hi4 & 8) >> 3);
-    const int w_bc = ROW4K * rv_hi + lo4;
-    // LC -> LB: thread t'' = rev8(n11..4), reg r = n3..0 -> row 16*rev4(t''3..0) + r, column rev4(t''7..4)
-    const int rv_lo = ((lo4 & 1) << 3) | ((lo4 & 2) << 1) | ((lo4 & 4) >> 1) | ((lo4 & 8) >> 3);
-    const int w_cb = ROW4K * 16 * rv_lo + rv_hi;
+    // LB -> LC: thread t' = (n11..8 = hi4, n3..0 = lo4), reg j' = n7..4 -> row = LC thread t'' (lc_bit<L>), column n3..0
+    const int row_hi = ((hi4 & 1) << lc_bit<L>(8)) | (((hi4 >> 1) & 1) << lc_bit<L>(9)) | (((hi4 >> 2) & 1) << lc_bit<L>(10)) |
+                       (((hi4 >> 3) & 1) << lc_bit<L>(11));
+    const int w_bc = ROW4K * row_hi + lo4; // + ROW4K * lc_row_of_reg<L>(j')
+    // LC -> LB: thread t'' , reg r = n3..0 -> row = LB thread 16 * (n11..8) + r, column = LB register n7..4
+    auto nb = [&](int k) { return (tid >> lc_bit<L>(k)) & 1; };
+    const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
+    const int w_cb = ROW4K * 16 * lb_hi + lb_reg;
     // per-thread shift amounts where the value kind depends on a thread bit after a transpose
-    const short shb = (short)(1 - (hi4 & 1));        // LB: kind = n8 = t'4
-    const short shc = (short)(1 - ((tid >> 7) & 1)); // LC: kind = n4 = t''7
+    const short shb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
+    const short shc = (short)(1 - nb(4));     // LC: kind = n4
     const v2s sh_b = {shb, shb}, sh_c = {shc, shc};
+    // LC <-> natural-order X: index = rev4(r) * 2^(L-4) + lc_off (in-frame bits reversed, frame bits in place)
+    int lc_off = 0, lc_frame = 0;
+#pragma unroll
+    for (int k = 4; k < 12; ++k) {
+        lc_off += nb(k) * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
+        if (k >= L) lc_frame += nb(k) << (k - L);
+    }
 
     for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
         u32 v[16];
         const u32 *src = in + f * 4096;
         u32 *dst = out + f * 4096;
-        if (MODE == MODE_INV) { // LC: v[r] = X[rev12(n)], rev12(n) = 256*rev4(r) + t''
+        const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
+        const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
+        if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + 256 * rev4c(r) + tid);
+            for (int r = 0; r < 16; ++r)
+                v[r] = lc_ok ? __builtin_nontemporal_load(src + (rev4c(r) << (L - 4)) + lc_off) : 0u;
         } else { // LA: v[j] = x[256 j + tid]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 256 * j + tid);
+            for (int j = 0; j < 16; ++j)
+                v[j] = (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)
+                           ? __builtin_nontemporal_load(src + 256 * j + tid)
+                           : 0u;
         }
 
         // guard-bit test of the whole frame (block-uniform)
@@ -122,17 +154,19 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #define INTFFT_BODY(FX)                                                                                 \
     {                                                                                                   \
         if (MODE != MODE_INV) {                                                                         \
-            dif_round<FX, false>(v, ta, sl, sh_b);                                                      \
+            dif_round<FX, false, NS>(v, ta, sl, sh_b);                                                  \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
             dif_round<FX, true>(v, tb, sl, sh_b);                                                       \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * 16 * rev4c(j)] = v[j];   \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L>(j)] = v[j]; \
             INTFFT_X_READ(reg1)                                                                         \
             dif_round_c<FX>(v, c, sl, sh_c);                                                            \
         }                                                                                               \
         if (MODE == MODE_FWD) {                                                                         \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                              \
-                __builtin_nontemporal_store(v[r], dst + 256 * rev4c(r) + tid);                          \
+            if (lc_ok) {                                                                                \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                          \
+                    __builtin_nontemporal_store(v[r], dst + (rev4c(r) << (L - 4)) + lc_off);            \
+            }                                                                                           \
         } else {                                                                                        \
             dit_round_c<FX>(v, c, sl);                                                                  \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
@@ -140,9 +174,10 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             dit_round<FX>(v, tb, sl);                                                                   \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \
-            dit_round<FX>(v, ta, sl);                                                                   \
+            dit_round<FX, NS>(v, ta, sl);                                                               \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
-                __builtin_nontemporal_store(v[j], dst + 256 * j + tid);                                 \
+                if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)                 \
+                    __builtin_nontemporal_store(v[j], dst + 256 * j + tid);                             \
         }                                                                                               \
     }
         if (FAST_OK && fast) INTFFT_BODY(FAST_OK)
@@ -155,13 +190,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int use_fly,
                         int in_order, int out_order)
 {
-    return log2n == 12 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+    return (log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
            use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
 const char *fast4096_kernel_name() { return "k_fft4096_i16"; }
 
-template <int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream)
 {
@@ -170,18 +205,36 @@ static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundC
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_i16<MODE, FAST_OK>, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_i16<L, MODE, FAST_OK>, 256, 0) != hipSuccess ||
             per_cu <= 0)
             per_cu = 2;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
     const size_t cap = (size_t)cus * (size_t)per_cu;
-    const unsigned blocks = (unsigned)(nframes < cap ? nframes : cap);
-    hipLaunchKernelGGL((k_fft4096_i16<MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
+    const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
+    const unsigned blocks = (unsigned)(chunks < cap ? chunks : cap);
+    hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
     return hipGetLastError();
 }
 
-hipError_t launch_fast4096(int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+template <int L>
+static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
+                             size_t nframes, const Slice &sl, hipStream_t stream)
+{
+    switch (direction) {
+    case 0:
+        return fast_ok ? launch4k<L, MODE_FWD, true>(pin, pout, tw_all, c, nframes, sl, stream)
+                       : launch4k<L, MODE_FWD, false>(pin, pout, tw_all, c, nframes, sl, stream);
+    case 1:
+        return fast_ok ? launch4k<L, MODE_INV, true>(pin, pout, tw_all, c, nframes, sl, stream)
+                       : launch4k<L, MODE_INV, false>(pin, pout, tw_all, c, nframes, sl, stream);
+    default:
+        return fast_ok ? launch4k<L, MODE_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
+                       : launch4k<L, MODE_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
+    }
+}
+
+hipError_t launch_fast4096(int log2n, int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                            size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -201,17 +254,8 @@ hipError_t launch_fast4096(int direction, int twd, const void *in, void *out, co
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    switch (direction) {
-    case 0:
-        return fast_ok ? launch4k<MODE_FWD, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launch4k<MODE_FWD, false>(pin, pout, tw_all, c, nframes, sl, stream);
-    case 1:
-        return fast_ok ? launch4k<MODE_INV, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launch4k<MODE_INV, false>(pin, pout, tw_all, c, nframes, sl, stream);
-    default:
-        return fast_ok ? launch4k<MODE_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launch4k<MODE_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
-    }
+    if (log2n == 11) return launch4k_l<11>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream);
+    return launch4k_l<12>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream);
 }
 
 } // namespace intfft

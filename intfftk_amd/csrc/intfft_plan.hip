@@ -521,7 +521,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
     if (plan->fast4096)
-        return (int)launch_fast4096(plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(),
+        return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(),
                                     batch, stream);
 
     const size_t N = (size_t)1 << plan->L;

@@ -283,6 +283,15 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
     assert np.array_equal(fast, slow)
 
 
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_block_kernel_n2048(direction):
+    """N = 2048: two frames share a workgroup of the N = 4096 kernel; guard-bit, full-scale and edge frames."""
+    x = np.concatenate([edge_frames(2048, 16), uniform_frames(301, 2048, 15, 91), uniform_frames(20, 2048, 16, 92)])
+    info = check(x, 11, 16, 16, 0, 0, True, direction=direction)
+    assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16")
+    check(uniform_frames(33, 2048, 15, 93), 11, 16, 14, 0, 0, False, direction=direction)
+
+
 def test_native_cores_chain_like_the_pair():
     """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
     same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
@@ -330,7 +339,8 @@ def test_wave_kernel_short_frames_inverse_and_pair(log2n, direction):
     check(uniform_frames(77, n, 15, 9), log2n, 16, 13, 0, 0, True, direction=direction)
 
 
-@pytest.mark.parametrize("cfg", [(10, "FWD"), (10, "INV"), (10, "PAIR"), (12, "FWD"), (12, "INV"), (12, "PAIR")])
+@pytest.mark.parametrize("cfg", [(10, "FWD"), (10, "INV"), (10, "PAIR"), (12, "FWD"), (12, "INV"), (12, "PAIR"),
+                                 (11, "FWD"), (11, "INV"), (11, "PAIR")])
 @pytest.mark.parametrize("batch", [1, 3, 5, 1027])
 def test_fast_kernels_ragged_batches(cfg, batch):
     """Persistent-grid kernels: batches smaller than the grid, not a multiple of the waves per block, odd."""
