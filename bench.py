@@ -106,11 +106,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # INTFFT_BENCH_SHARE_GPU=1 (diagnostics only): several ranks on one GPU over gloo, to exercise the N > 1
+    # control flow on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
+    share = os.environ.get("INTFFT_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from intfftk_amd import int_fft_single_path
 
@@ -143,7 +151,7 @@ def main():
         dist.barrier()
     from intfftk_amd.sharding import max_over_ranks
 
-    t_all = max_over_ranks(t_local, torch.device("cuda", local_rank))
+    t_all = max_over_ranks(t_local, None if share else torch.device("cuda", local_rank))
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
 
     if rank == 0:
