@@ -115,6 +115,21 @@ hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const
                             hipStream_t stream);
 const char *fast1024u_kernel_name();
 
+// unscaled int32 wave kernel, inverse core and pair (intfft_fast1024ux.hip)
+struct UxStage {
+    int sh;        // a + b of the multiplier regime
+    unsigned keep; // ~(2^a - 1)
+    int w;         // multiplier width (DTW of the DIT stage): T is wrapped to w bits
+};
+struct UxArgs {
+    UxStage st[10]; // by STAGE number of the inverse core
+};
+bool fast1024ux_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
+                          int in_order, int out_order);
+hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a, const void *in, void *out,
+                             const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *fast1024ux_kernel_name();
+
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {
     int sh;            // a + b: bit offset of the result slice in the 64-bit sum

@@ -37,6 +37,8 @@ struct intfft_plan {
     bool fast4096 = false;
     bool fast1024x = false;
     bool fast1024u = false;
+    bool fast1024ux = false;
+    UxArgs uxargs{};
     bool big20 = false;
     bool wide16 = false;
     WideArgs wargs{};
@@ -402,7 +404,23 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     pl->fast1024u = fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_FAST1024U");
-    if (pl->fast1024u) {
+    pl->fast1024ux = fast1024ux_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+                                          p->in_order, p->out_order) &&
+                     !getenv("INTFFT_NO_FAST1024U");
+    if (pl->fast1024ux) { // per-stage multiplier regimes of the inverse core
+        std::vector<StageDesc> st;
+        const int dw_inv = p->direction == INTFFT_PAIR ? p->data_width + p->log2n : p->data_width;
+        if (core_stages(*p, dw_inv, true, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fast1024ux = false;
+        for (size_t i = 0; i < st.size() && pl->fast1024ux; ++i) {
+            const StageDesc &d = st[i];
+            if (d.s != (int)i || d.mw > 31 || d.sh_a + d.sh_b > 31) pl->fast1024ux = false;
+            if (p->direction == INTFFT_INV && d.s >= 2 && d.sh_a != 0) pl->fast1024ux = false; // chained form
+            pl->uxargs.st[i] = UxStage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), d.mw};
+        }
+    }
+    if (pl->fast1024ux) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024ux_kernel_name());
+    } else if (pl->fast1024u) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024u_kernel_name());
     } else if (pl->fast4096) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096_kernel_name());
@@ -496,9 +514,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux;
     info->n_passes = fast ? 1 : (int)plan->passes.size();
-    info->compute_word = plan->fast1024u ? 4 : fast ? 2 : plan->word;
+    info->compute_word = (plan->fast1024u || plan->fast1024ux) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -512,6 +530,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->fast1024ux)
+        return (int)launch_fast1024ux(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->uxargs, d_in, d_out,
+                                      plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024u)
         return (int)launch_fast1024u(plan->p.log2n, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024)

@@ -1,0 +1,184 @@
+// intfft_u32.hpp -- unpacked int32 butterflies and the forward transform of the unscaled wave kernels
+// (intfft_fast1024u.hip: int_fftNk; intfft_fast1024ux.hip: int_ifftNk and the pair).  See intfft_fast1024u.hip
+// for the arithmetic and the reference citations.
+#pragma once
+#include "intfft_internal.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+using u32 = uint32_t;
+
+struct UConsts {
+    int wr3[8], wi3[8]; // STAGE 3 twiddles (uniform)
+    int wr2[4], wi2[4]; // STAGE 2
+};
+
+// Short frames (L < 10), 8-byte outputs: ONE lane swap after the last stage (lane bit 5 = a(L-1) <-> reg bit 3)
+// gives every lane two consecutive outputs = one dwordx4 store, and lane bits 0, 1, .. carry a(L-2), a(L-3), ..
+// (output bits 1, 2, ..) so that adjacent lanes write adjacent 16-byte pieces; then the frame bits.
+template <int L> __host__ __device__ constexpr int lane_bit_u(int k)
+{
+    if (L == 10) return 9 - k;
+    if (k == L - 1) return 5;
+    if (k < L - 1) return (L - 2) - k;
+    return (L - 5) + (k - L);
+}
+
+// LC lane mapping of the transform: MAP 0 = lane_bit_u<L> (forward kernel, store-optimised), MAP 1 = natural
+// (lane bit i = a(9-i): the pair, which never does I/O from LC), MAP 2 = lane_bit<L> (inverse alone: the mirror
+// of the packed kernels' short-frame store, intfft_fast1024.hip)
+template <int L, int MAP> __host__ __device__ constexpr int ulb(int k)
+{
+    return MAP == 0 ? lane_bit_u<L>(k) : MAP == 1 ? 9 - k : lane_bit<L>(k);
+}
+
+constexpr int ROWU = 20; // LDS row stride in dwords, per plane (re plane then im plane)
+
+// one general DIF butterfly, unscaled; WO = output width of the stage
+template <bool WRAP, int WO, bool UNIFORM_W = false>
+__device__ __forceinline__ void ufly(int &are, int &aim, int &bre, int &bim, int wr, int wi, int sh)
+{
+    // wave-uniform twiddles stay in SGPRs; the empty asm keeps the compiler from hoisting their 64-bit sign
+    // extension out of the frame loop (which turns every product into a 3-instruction 64 x 32 multiply)
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    const int dre = are - bre, dim = aim - bim, ndim = bim - aim;
+    are += bre;
+    aim += bim;
+    const long long xr = (long long)dre * wr + (long long)ndim * wi; // M2 - M1 (int_cmult_dsp48.vhd:192-207)
+    const long long xi = (long long)dre * wi + (long long)dim * wr;  // M2 + M1 (:209-224)
+    // low 32 bits of (x >> sh), 1 <= sh <= 15: one v_alignbit_b32
+    int yr = (int)__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)sh);
+    int yi = (int)__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)sh);
+    if (WRAP) {
+        yr = __builtin_amdgcn_sbfe(yr, 0, WO);
+        yi = __builtin_amdgcn_sbfe(yi, 0, WO);
+    }
+    bre = yr;
+    bim = yi;
+}
+// STAGE 0 and even positions of STAGE 1
+__device__ __forceinline__ void ufly_triv(int &are, int &aim, int &bre, int &bim)
+{
+    const int dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dre;
+    bim = dim;
+}
+// odd positions of STAGE 1: Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re  (int_dif2_fly.vhd:297-304)
+__device__ __forceinline__ void ufly_mj(int &are, int &aim, int &bre, int &bim)
+{
+    const int dre = are - bre, dim = aim - bim;
+    are += bre;
+    aim += bim;
+    bre = dim;
+    bim = (dre >> 31) - dre; // -x for x >= 0, -x - 1 = ~x for x < 0
+}
+
+__device__ __forceinline__ void uswap32(int &a, int &b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap((u32)a, (u32)b, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+}
+__device__ __forceinline__ void uswap16(int &a, int &b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((u32)a, (u32)b, false, false);
+    a = (int)r[0];
+    b = (int)r[1];
+}
+
+template <int L, bool WRAP, int MAP = 0>
+__device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const int (&w9r)[8], const int (&w9i)[8],
+                                           const int (&w8r)[4], const int (&w8i)[4], const int (&w7r)[2],
+                                           const int (&w7i)[2], int w6r, int w6i, int w5r, int w5i, int w4r, int w4i,
+                                           const UConsts &c, int sh, u32 *wr_base, const uint4 *rd_base)
+{
+    // STAGE s is stage ii = L - 1 - s of the pipeline: output width 17 + ii = 16 + L - s (int_fftNk.vhd:187-207)
+    if constexpr (L >= 10) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ufly<WRAP, 16 + L - 9>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], sh);
+    }
+    if constexpr (L >= 9) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ufly<WRAP, 16 + L - 8>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], sh);
+    }
+    if constexpr (L >= 8) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 4)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                ufly<WRAP, 16 + L - 7>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], sh);
+    }
+    if constexpr (L >= 7) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) ufly<WRAP, 16 + L - 6>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, sh);
+    }
+    // lane bit 5 <-> reg bit 3, stage 5
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        uswap32(re[j], re[j + 8]);
+        uswap32(im[j], im[j + 8]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ufly<WRAP, 16 + L - 5>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, sh);
+    // lane bit 4 <-> reg bit 2, stage 4
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uswap16(re[g + j], re[g + j + 4]);
+            uswap16(im[g + j], im[g + j + 4]);
+        }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ufly<WRAP, 16 + L - 4>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, sh);
+
+    // LDS transpose (re plane, im plane): regs become n3..0, lane bit i = n(9-i)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
+        // reg j3 = a5, j2 = a4, j1 = a7, j0 = a6 here (intfft_fast1024.hip)
+        const int row_j = (j1 << ulb<L, MAP>(7)) + (j0 << ulb<L, MAP>(6)) + (j3 << ulb<L, MAP>(5)) + (j2 << ulb<L, MAP>(4));
+        wr_base[ROWU * row_j] = (u32)re[j];
+        wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
+        re[4 * q + 0] = (int)x.x;
+        re[4 * q + 1] = (int)x.y;
+        re[4 * q + 2] = (int)x.z;
+        re[4 * q + 3] = (int)x.w;
+        im[4 * q + 0] = (int)y.x;
+        im[4 * q + 1] = (int)y.y;
+        im[4 * q + 2] = (int)y.z;
+        im[4 * q + 3] = (int)y.w;
+    }
+    asm volatile("" ::: "memory");
+
+    // stages 3, 2 (uniform twiddles), 1, 0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ufly<WRAP, 16 + L - 3, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ufly<WRAP, 16 + L - 2, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], sh);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        ufly_triv(re[g], im[g], re[g + 2], im[g + 2]);
+        ufly_mj(re[g + 1], im[g + 1], re[g + 3], im[g + 3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) ufly_triv(re[g], im[g], re[g + 1], im[g + 1]);
+}
+
+} // namespace intfft

@@ -265,6 +265,21 @@ def test_unscaled_wave_kernel_short_frames(log2n):
     check(uniform_frames(77, n, 16, 9), log2n, 16, 16, 1, 0, False)
 
 
+@pytest.mark.parametrize("log2n,direction", [(6, "INV"), (7, "INV"), (8, "INV"), (9, "INV"), (10, "INV"),
+                                             (6, "PAIR"), (7, "PAIR"), (8, "PAIR")])
+def test_unscaled_wave_kernel_inverse_and_pair(log2n, direction):
+    """int_ifftNk / int_fft_ifft_pair with FORMAT = 1 (fft_double_test.vhd:83-88 ships NFFT = 7, FORMAT = 1): bit
+    growth through both cores; the pair's later IFFT stages run the two-DSP multiplier regime."""
+    n = 1 << log2n
+    for batch, seed in [(1, 1), (3, 2), ((1 << (10 - log2n)) + 1, 3), (1000, 4)]:
+        x = np.concatenate([uniform_frames(batch, n, 15, 900 + seed), edge_frames(n, 16),
+                            uniform_frames(5, n, 16, 950 + seed)])
+        info = check(x, log2n, 16, 16, 1, 0, True, direction=direction)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024ux_u32")
+    check(uniform_frames(77, n, 16, 9), log2n, 16, 12, 1, 0, True, direction=direction)
+    check(uniform_frames(77, n, 16, 9), log2n, 16, 16, 1, 0, False, direction=direction)  # XSER "OLD": earlier dbl18
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
