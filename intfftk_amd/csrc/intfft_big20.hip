@@ -1,6 +1,13 @@
-// intfft_big20.hip -- three-pass packed-int16 kernels for N = 2^20 (BASELINE config 4):
-// int_fftNk with NFFT = 20, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural in -> natural out
-// (stages 19..11 read the Taylor twiddle tables of row_twiddle_tay.vhd, built by k_twiddle_stage).
+// intfft_big20.hip -- three-pass packed-int16 kernels for N = 2^13 .. 2^20 (BASELINE config 4 is N = 2^20):
+// int_fftNk with NFFT = 13..20, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural in -> natural out
+// (stages >= 11 read the Taylor twiddle tables of row_twiddle_tay.vhd, built by k_twiddle_stage).
+// The description below is for N = 2^20; shorter frames (template parameter L = log2 N):
+//   pass 1  L >= 17: groups of 2^(20-L) consecutive frames form one virtual 2^20-point frame whose top index bits
+//           number the frame; their stages are skipped (twiddle index = position mod 2^s is unaffected).
+//           L <= 16: groups of 2^(16-L) frames form a virtual 2^16-point frame; stages L-1..12 are one register
+//           round (regs = n15..12 at stride 4096, thread = 512 consecutive n: 2 KiB runs, no LDS).
+//   pass 2  unchanged (4096 consecutive points); pass 3 uses the top 8 in-frame bits n(L-1)..n(L-8) as its 256
+//           rows: brev_L sends them to the 8 lowest output bits (1 KiB runs per store instruction).
 //
 // A 2^20-point frame is 4 MiB: three passes through a plan-owned scratch, every global access a full
 // 128-byte line, every butterfly lane-local (same packed arithmetic as intfft_fast1024.hip):
@@ -37,10 +44,13 @@ __device__ __forceinline__ void ld_tw(const uint2 *__restrict__ t, unsigned idx,
 // ---- pass 1: stages 19..12 ---------------------------------------------------------------------------
 // grid = 128 chunks x G frame groups; a workgroup keeps its chunk's 30 twiddle pairs in registers and walks
 // the frames g, g + G, ... of the launch (the twiddles depend on the chunk, not on the frame)
-template <bool FAST_OK>
-__global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes,
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes_user,
                                                   unsigned groups, const Slice sl)
 {
+    static_assert(L >= 17 && L <= 20, "two-round pass 1");
+    constexpr int NS1 = L - 16, G = 1 << (20 - L);       // executed stages of round 1; frames per virtual frame
+    const size_t nframes = (nframes_user + G - 1) / G;   // virtual 2^20-point frames
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n15..12 (round 1) / n19..16 (round 2)
     const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..127
@@ -51,12 +61,18 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
     RoundTw t1, t2;
     {
         const unsigned b = hx * 4096u + lfull;
+        if constexpr (NS1 >= 4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+        }
+        if constexpr (NS1 >= 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+        }
+        if constexpr (NS1 >= 2) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+        }
         ld_tw(twf, (1u << 16) - 1u + b, t1.wa1[0], t1.wb1[0]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t2.wa8[j], t2.wb8[j]);
@@ -74,14 +90,21 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         const u32 *src = in + frame * ((size_t)1 << L20) + lfull;
         u32 *dst = scr + frame * ((size_t)1 << L20) + lfull;
         u32 v[16];
+        const bool partial = L < 20 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
+        if (partial) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 12)); // regs = n19..16
+            for (int j = 0; j < 16; ++j)
+                v[j] = frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user ? src[(size_t)(16 * j + hx) << 12] : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 12)); // regs = n19..16
+        }
         // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
         // the barrier also orders the previous frame's LDS reads before this frame's writes
         const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
         if (!FAST_OK) __syncthreads();
-        if (fast) dif_round<FAST_OK, false>(v, t1, sl, none);
-        else dif_round<false, false>(v, t1, sl, none);
+        if (fast) dif_round<FAST_OK, false, NS1>(v, t1, sl, none);
+        else dif_round<false, false, NS1>(v, t1, sl, none);
         // transpose: (thread (hx = n15..12, l), reg j = n19..16) -> (thread (j, l), reg hx)
 #pragma unroll
         for (int j = 0; j < 16; ++j) lds[ROWB * (32 * j + l) + hx] = v[j];
@@ -90,8 +113,65 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * tid + r]; // now tid >> 5 = n19..16, regs = n15..12
         if (fast) dif_round<FAST_OK, true>(v, t2, sl, sh2);
         else dif_round<false, true>(v, t2, sl, sh2);
+        if (partial) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << 12] = v[r];
+            for (int r = 0; r < 16; ++r)
+                if (frame * G + (size_t)((16 * hx + r) >> (L - 12)) < nframes_user) dst[(size_t)(16 * hx + r) << 12] = v[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << 12] = v[r];
+        }
+    }
+}
+
+// ---- pass 1 for L <= 16: stages L-1..12 as one register round on a virtual 2^16-point frame ---------------
+// grid = 8 chunks (512 consecutive n11..0 each) x G frame groups; regs = n15..12, no LDS, wave-level guard vote
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes_user,
+                                                  unsigned groups, const Slice sl)
+{
+    static_assert(L >= 13 && L <= 16, "one-round pass 1");
+    constexpr int NS = L - 12, G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G; // virtual 2^16-point frames
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..7
+    const unsigned lfull = chunk * 512 + threadIdx.x;                        // n11..0
+    RoundTw t;
+    if constexpr (NS >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t.wa8[j], t.wb8[j]);
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t.wa4[j], t.wb4[j]);
+    }
+    if constexpr (NS >= 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t.wa2[j], t.wb2[j]);
+    }
+    ld_tw(twf, (1u << 12) - 1u + lfull, t.wa1[0], t.wb1[0]);
+    const v2s none = {0, 0};
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = in + frame * 65536 + lfull;
+        u32 *dst = scr + frame * 65536 + lfull;
+        u32 v[16];
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user;
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = frame * G + (size_t)(j >> (L - 12)) < nframes_user ? src[(size_t)j << 12] : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << 12));
+        }
+        if (FAST_OK && frame_has_guard_bit(v)) dif_round<FAST_OK, false, NS>(v, t, sl, none);
+        else dif_round<false, false, NS>(v, t, sl, none);
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (frame * G + (size_t)(j >> (L - 12)) < nframes_user) dst[(size_t)j << 12] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dst[(size_t)j << 12] = v[j];
+        }
     }
 }
 
@@ -167,16 +247,17 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
 
 // ---- pass 3: stages 3..0 and the bit-reversed (natural-order) store ----------------------------------
 template <bool FAST_OK>
-__global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, const RoundCConsts c, size_t nframes, const Slice sl)
+__global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, const RoundCConsts c, size_t nframes, const Slice sl,
+                                                  int L)
 {
     __shared__ u32 lds[512 * ROWB];
-    const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n15..12
+    const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n(L-5)..n(L-8)
     const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n11..5, 0..127
-    const u32 *src = scr + frame * ((size_t)1 << L20) + mid * 32 + e;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5: L - 13 bits
+    const u32 *src = scr + (frame << L) + mid * 32 + e;
     u32 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(16 * j + px) << 12]; // reg j = n19..16
+    for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(16 * j + px) << (L - 8)]; // reg j = n(L-1)..n(L-4)
 
     // transpose -> regs = n3..0, thread = (n4, rev8(n19..12)); rev8(16 j + px) = 16 rev4(px) + rev4(j)
     const int rpx = ((px & 1) << 3) | ((px & 2) << 1) | ((px & 4) >> 1) | ((px & 8) >> 3);
@@ -203,24 +284,39 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
     if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
     else dif_round_c<false>(v, c, sl, sh3);
 
-    // natural order: X index = rev20(n) = rev4(r) << 16 | rev8(n11..4) << 8 | rev8(n19..12)
-    //   n11..4 = (mid << 1) | n4  ->  rev8 = (n4 << 7) | rev7(mid)
-    const unsigned rmid = __brev(mid) >> 25; // rev7
-    u32 *dst = out + frame * ((size_t)1 << L20) + ((((unsigned)(tid >> 8) << 7) | rmid) << 8) + (tid & 255);
+    // natural order: X index = brev_L(n) = rev4(r) << (L-4) | n4 << (L-5) | brev(mid) << 8 | rev8(n(L-1)..n(L-8))
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    u32 *dst = out + (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << 16));
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
 }
 
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
-    return log2n == 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+    return log2n >= 13 && log2n <= 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
            direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
 const char *big20_kernel_name() { return "k_big20_p1/p2/p3"; }
 
-hipError_t launch_big20(int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+template <int L>
+static void launch_p1(bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream)
+{
+    if constexpr (L >= 17) {
+        const size_t nvf = (nframes + ((size_t)1 << (20 - L)) - 1) >> (20 - L);
+        const unsigned groups = (unsigned)(nvf < 16 ? nvf : 16);
+        if (fx) hipLaunchKernelGGL((k_big20_p1<L, true>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+        else hipLaunchKernelGGL((k_big20_p1<L, false>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+    } else {
+        const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L);
+        const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
+        if (fx) hipLaunchKernelGGL((k_big16_p1<L, true>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+        else hipLaunchKernelGGL((k_big16_p1<L, false>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+    }
+}
+
+hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                         const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -246,21 +342,30 @@ hipError_t launch_big20(int twd, const void *in, void *out, void *scratch, const
     }
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
-    const unsigned groups = (unsigned)(nframes < 16 ? nframes : 16);
-    if (fx) hipLaunchKernelGGL(k_big20_p1<true>, dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
-    else hipLaunchKernelGGL(k_big20_p1<false>, dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
-    const size_t nb = nframes * 256;
+    switch (log2n) {
+    case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 15: launch_p1<15>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 16: launch_p1<16>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 17: launch_p1<17>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 18: launch_p1<18>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    }
+    const size_t nb = nframes << (log2n - 12);
     static int p2_per_cu = 0;
     if (!p2_per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2_per_cu, k_big20_p2<true>, 256, 0) != hipSuccess || p2_per_cu <= 0))
         p2_per_cu = 4;
     const size_t cap = (size_t)cus * (size_t)p2_per_cu;
-    const unsigned g2 = (unsigned)(nb < cap ? nb : cap), g3 = (unsigned)(nframes * 128);
+    const size_t nb3 = nframes << (log2n - 13);
+    if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    const unsigned g2 = (unsigned)(nb < cap ? nb : cap), g3 = (unsigned)nb3;
     if (fx) {
         hipLaunchKernelGGL(k_big20_p2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
-        hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl);
+        hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
     } else {
         hipLaunchKernelGGL(k_big20_p2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
-        hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl);
+        hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
     }
     return hipGetLastError();
 }

@@ -150,7 +150,7 @@ const char *wide16_kernel_name();
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order);
-hipError_t launch_big20(int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                         const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *big20_kernel_name();
 

@@ -474,7 +474,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                 return (int)e;
             }
         }
-        if (pl->passes.size() > 1) {
+        if (pl->passes.size() > 1 || pl->big20) {
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->word == 2 ? 2 : pl->passes[0].word);
             size_t scratch_mb = pl->big20 ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
             if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
@@ -515,7 +515,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux;
-    info->n_passes = fast ? 1 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : (plan->big20 && !plan->wide16) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fast1024u || plan->fast1024ux) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
@@ -548,7 +548,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
     const size_t np = plan->passes.size();
-    const size_t chunk = np > 1 ? plan->scratch_frames : batch;
+    const size_t chunk = (np > 1 || plan->big20) ? plan->scratch_frames : batch;
     for (size_t f = 0; f < batch; f += chunk) {
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
@@ -559,8 +559,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             if (e != hipSuccess) return (int)e;
             continue;
         }
-        if (plan->big20) {
-            const hipError_t e = launch_big20(plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw, plan->d_tw16f,
+        // short single-pass lengths (N = 8192, 16384) keep the one-pass generic kernel for small batches
+        if (plan->big20 && (np > 1 || (nf << plan->L) >= ((size_t)1 << 22))) {
+            const hipError_t e = launch_big20(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw, plan->d_tw16f,
                                               plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
             continue;

@@ -110,6 +110,20 @@ def test_wide_plan_variants_agree(env, monkeypatch):
     assert np.array_equal(a, run_ref(x, 16, 24, 24, 1, 0, True))
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1024), (14, 259), (15, 3), (15, 130), (16, 5), (16, 64), (17, 3),
+                                         (17, 9), (18, 5), (19, 3), (19, 2)])
+def test_three_pass_kernels_n8192_to_n524288(log2n, batch):
+    """N = 2^13 .. 2^19, 16-bit scaled: the three-pass kernels of BASELINE config 4 with frame groups forming
+    virtual 2^16 / 2^20-point frames in pass 1 (partial last groups included), Taylor twiddles for STAGE >= 11."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 2000 + log2n)
+    x[0] = uniform_frames(1, n, 16, 7)[0]  # one full-scale frame: exact extraction in its tiles
+    info = check(x, log2n, 16, 16, 0, 0, True)
+    assert info["kernel_name"].startswith("k_big20") and info["n_passes"] == 3
+    if batch <= 9:
+        check(x, log2n, 16, 13, 0, 0, False)  # narrower twiddles, XSER "OLD"
+
+
 def test_config4_n_2pow20_taylor_extension():
     """BASELINE config 4 shape at a reduced batch: N = 2^20, 16-bit scaled, Taylor ii = 8 extension."""
     x = uniform_frames(2, 1 << 20, 15, 0xC0FFEE04)
