@@ -1,0 +1,37 @@
+"""Coverage matrix: which kernel serves which (N, mode, direction) and how fast (one MI355X, data resident).
+Prints a markdown table; every row is also checked against the oracle on a frame prefix (bench_configs.run)."""
+import json
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from tools import bench_configs as B  # noqa: E402
+
+ROWS = []
+for L in (3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20):
+    ROWS.append(("%d:16:16:0" % L, "16-bit scaled-trunc FWD"))
+for L in (7, 10, 12):
+    ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
+for L in (7, 10, 11, 12, 14):
+    ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
+    ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
+for L in (7, 10, 12):
+    ROWS.append(("%d:16:16:1" % L, "16-bit unscaled FWD"))
+for L in (7, 10):
+    ROWS.append(("%d:16:16:1:0:INV" % L, "16-bit unscaled INV"))
+ROWS.append(("7:16:16:1:0:PAIR", "16-bit unscaled PAIR"))
+ROWS.append(("16:24:24:1", "24-bit unscaled FWD (C3)"))
+ROWS.append(("16:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD"))
+ROWS.append(("10:24:24:1", "24-bit unscaled FWD"))
+ROWS.append(("10:12:16:0", "12-bit scaled FWD"))
+ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
+
+if __name__ == "__main__":
+    print("| N | mode | kernel | passes | Gsample/s | B/sample | GB/s | frac of 8 TB/s | parity prefix |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    for spec, label in ROWS:
+        B.adhoc(spec)
+        r = B.run(spec, steps=10)
+        bps = r["GB/s"] / r["Gsample/s"]
+        print("| 2^%d | %s | `%s` | %d | %.0f | %.0f | %.0f | %.2f | %s |" % (
+            r["log2n"], label, r["kernel"], r["passes"], r["Gsample/s"], bps, r["GB/s"], r["roofline_frac"],
+            "ok" if r["parity_prefix_ok"] else "MISMATCH"), flush=True)
