@@ -1,0 +1,336 @@
+// intfft_fastw32.hip -- general-width wave kernel: int_fftNk for 64 <= N <= 1024 with ANY DATA_WIDTH / TWDL_WIDTH /
+// FORMAT / RNDMODE whose widths stay within 32 bits (DATA_WIDTH + FORMAT * NFFT <= 32, TWDL_WIDTH <= 26), natural
+// order in and out -- e.g. 12- or 14-bit converters, 18/24/32-bit scaled data, 24-bit unscaled short frames.
+// (DATA_WIDTH = 16 with TWDL_WIDTH <= 16 has the tuned kernels intfft_fast1024.hip / intfft_fast1024u.hip.)
+//
+// Same wave mapping as intfft_fast1024u.hip (regs a9..6, two lane swaps, one wave-private LDS transpose of two dword
+// planes, regs a3..0; short frames share a wave) on unpacked int32 registers, with the per-stage arithmetic fully
+// parameterised (wave-uniform W32Stage, from the planner's StageDesc):
+//   sum/difference   trunc (A>>1) +/- (B>>1) | round rhu2(A +/- B) wrapped to DTW bits | unscaled A +/- B
+//                    (int_dif2_fly.vhd:144-241)
+//   multiplier       every regime of int_cmult_dsp48.vhd:182-434 in the masked form of intfft_wide16.hip:
+//                    ((M2 & K) -/+ (M1 & K)) >> (a + b), K = ~(2^a - 1); exact 64-bit sums from v_mad_i64_i32
+//   width wrap       (x << (32 - w)) >> (32 - w), a no-op when w = 32
+// Containers follow the C-ABI: int16 pairs for widths <= 16, int32 pairs above (runtime flags, load/store only).
+#include "intfft_u32.hpp"
+
+namespace intfft {
+
+enum { W_TRUNC = 0, W_ROUND = 1, W_UNSCALED = 2 };
+
+template <int MODE, bool UNIFORM_W = false>
+__device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
+    int dre, dim;
+    if (MODE == W_UNSCALED) {
+        dre = are - bre, dim = aim - bim;
+        are += bre, aim += bim;
+    } else if (MODE == W_TRUNC) {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = ar - br, dim = ai - bi;
+        are = ar + br, aim = ai + bi;
+    } else { // rhu2(A +/- B) on the exact sum, wrapped to DTW bits (int_dif2_fly.vhd:173-218)
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
+        are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
+        aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+    }
+    const unsigned long long m2r = (unsigned long long)((long long)dre * wr), m1r = (unsigned long long)((long long)dim * wi);
+    const unsigned long long m2i = (unsigned long long)((long long)dre * wi), m1i = (unsigned long long)((long long)dim * wr);
+    const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
+    const unsigned long long xr = (m2r & k) - (m1r & k), xi = (m2i & k) + (m1i & k);
+    bre = (int)(__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh) << s.wsh) >> s.wsh;
+    bim = (int)(__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh) << s.wsh) >> s.wsh;
+}
+// STAGE 0 (ODD = false), STAGE 1: even positions Y = D, odd positions Y = -j D with the negation quirk
+template <int MODE, bool ODD>
+__device__ __forceinline__ void gfly_triv(int &are, int &aim, int &bre, int &bim, const W32Stage &s)
+{
+    int dre, dim;
+    if (MODE == W_UNSCALED) {
+        dre = are - bre, dim = aim - bim;
+        are += bre, aim += bim;
+    } else if (MODE == W_TRUNC) {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = ar - br, dim = ai - bi;
+        are = ar + br, aim = ai + bi;
+    } else {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
+        are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
+        aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+    }
+    if (ODD) {
+        bre = dim;
+        bim = (dre >> 31) - dre; // -x for x >= 0 (fits: x < 2^(w-1)), ~x for x < 0   (int_dif2_fly.vhd:297-304)
+    } else {
+        bre = dre;
+        bim = dim;
+    }
+}
+
+template <int L, int MODE>
+__global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
+                                                     const W32Args a, size_t nframes_user)
+{
+    constexpr int FP = 1 << (10 - L);
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 1024 samples
+    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32 *lds = lds_all + wv * 2 * 64 * ROWU;
+
+    int w9r[8] = {}, w9i[8] = {}, w8r[4] = {}, w8i[4] = {}, w7r[2] = {}, w7i[2] = {}, w6r = 0, w6i = 0, w5r, w5i, w4r, w4i;
+    if constexpr (L >= 10) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int2 w = twt[511 + 64 * j + lane];
+            w9r[j] = w.x, w9i[j] = w.y;
+        }
+    }
+    if constexpr (L >= 9) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int2 w = twt[255 + 64 * j + lane];
+            w8r[j] = w.x, w8i[j] = w.y;
+        }
+    }
+    if constexpr (L >= 8) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int2 w = twt[127 + 64 * j + lane];
+            w7r[j] = w.x, w7i[j] = w.y;
+        }
+    }
+    {
+        int2 w;
+        if constexpr (L >= 7) {
+            w = twt[63 + lane];
+            w6r = w.x, w6i = w.y;
+        }
+        w = twt[31 + (lane & 31)];
+        w5r = w.x, w5i = w.y;
+        w = twt[15 + (lane & 15)];
+        w4r = w.x, w4i = w.y;
+    }
+    const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
+    u32 *wr_base = lds + ROWU * ((t5 << lane_bit_u<L>(9)) + (t4 << lane_bit_u<L>(8))) + (lane & 15);
+    const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWU * lane);
+    int lane_off = 0, lane_frame = 0; // N < 1024: see intfft_fast1024u.hip (one output swap level)
+    if constexpr (L < 10) {
+        lane_off = ((lane >> 5) & 1) * out_weight<L>(3);
+#pragma unroll
+        for (int k = 4; k < 10; ++k) {
+            if (k == L - 1) continue;
+            const int bit = (lane >> lane_bit_u<L>(k)) & 1;
+            lane_off += bit * out_weight<L>(k);
+            if (k >= L) lane_frame += bit << (k - L);
+        }
+    }
+
+    const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
+    for (size_t f = wave0; f < nframes; f += nwaves) {
+        const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0
+        int re[16], im[16];
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + f * 1024 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = !partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user;
+                const u32 raw = ok ? __builtin_nontemporal_load(src + 64 * j) : 0u;
+                re[j] = (int)(raw << a.in_sh) >> a.in_sh; // wrap to DATA_WIDTH (conv_std_logic_vector)
+                im[j] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
+            }
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = static_cast<const v2i *>(in) + f * 1024 + lane;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = !partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user;
+                v2i x = {0, 0};
+                if (ok) x = __builtin_nontemporal_load(src + 64 * j);
+                re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh;
+                im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+            }
+        }
+        // ---- stages 9..6 in registers, 5 and 4 after the lane swaps ----
+        if constexpr (L >= 10) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], a.st[9]);
+        }
+        if constexpr (L >= 9) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], a.st[8]);
+        }
+        if constexpr (L >= 8) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 4)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], a.st[7]);
+        }
+        if constexpr (L >= 7) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) gfly<MODE>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, a.st[6]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uswap32(re[j], re[j + 8]);
+            uswap32(im[j], im[j + 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, a.st[5]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uswap16(re[g + j], re[g + j + 4]);
+                uswap16(im[g + j], im[g + j + 4]);
+            }
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, a.st[4]);
+        // ---- LDS transpose: regs become a3..0 ----
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
+            const int row_j = (j1 << lane_bit_u<L>(7)) + (j0 << lane_bit_u<L>(6)) + (j3 << lane_bit_u<L>(5)) + (j2 << lane_bit_u<L>(4));
+            wr_base[ROWU * row_j] = (u32)re[j];
+            wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
+            re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
+            im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
+        }
+        asm volatile("" ::: "memory");
+        // ---- stages 3, 2 (uniform twiddles), 1, 0 ----
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gfly<MODE, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gfly<MODE, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+            gfly_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+
+        // ---- store ----
+        if constexpr (L < 10) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                uswap32(re[r], re[r + 8]);
+                uswap32(im[r], im[r + 8]);
+            }
+            if (f * FP + (size_t)lane_frame < nframes_user) {
+                if (a.out16) {
+                    typedef u32 v2u __attribute__((ext_vector_type(2)));
+                    u32 *dst = static_cast<u32 *>(out) + f * 1024 + lane_off;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const v2u y = {((u32)re[q] & 0xFFFFu) | ((u32)im[q] << 16), ((u32)re[q + 8] & 0xFFFFu) | ((u32)im[q + 8] << 16)};
+                        __builtin_nontemporal_store(y, reinterpret_cast<v2u *>(dst + (q & 1) * out_weight<L>(0) +
+                                                                               ((q >> 1) & 1) * out_weight<L>(1) +
+                                                                               (q >> 2) * out_weight<L>(2)));
+                    }
+                } else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    int2 *dst = static_cast<int2 *>(out) + f * 1024 + lane_off;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const v4i y = {re[q], im[q], re[q + 8], im[q + 8]};
+                        __builtin_nontemporal_store(y, reinterpret_cast<v4i *>(dst + (q & 1) * out_weight<L>(0) +
+                                                                               ((q >> 1) & 1) * out_weight<L>(1) +
+                                                                               (q >> 2) * out_weight<L>(2)));
+                    }
+                }
+            }
+        } else if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + f * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+                __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), dst + 64 * rr);
+            }
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            int2 *dst = static_cast<int2 *>(out) + f * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+                const v2i y = {re[r], im[r]};
+                __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + 64 * rr));
+            }
+        }
+    }
+}
+
+bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                       int out_order)
+{
+    return log2n >= 6 && log2n <= 10 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
+           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *fastw32_kernel_name() { return "k_fft1024_w32"; }
+
+template <int L, int MODE>
+static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
+                          hipStream_t stream)
+{
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_w32<L, MODE>, 256, 0) != hipSuccess || per_cu <= 0)
+            per_cu = 2;
+        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    }
+    const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
+    const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    hipLaunchKernelGGL((k_fft1024_w32<L, MODE>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+                       c, a, nframes);
+    return hipGetLastError();
+}
+
+template <int L>
+static hipError_t launchw_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
+                            size_t nframes, hipStream_t stream)
+{
+    switch (mode) {
+    case W_TRUNC: return launchw<L, W_TRUNC>(in, out, tw, c, a, nframes, stream);
+    case W_ROUND: return launchw<L, W_ROUND>(in, out, tw, c, a, nframes, stream);
+    default: return launchw<L, W_UNSCALED>(in, out, tw, c, a, nframes, stream);
+    }
+}
+
+hipError_t launch_fastw32(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
+                          const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    UConsts c;
+    for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
+    for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
+    switch (log2n) {
+    case 6: return launchw_l<6>(mode, in, out, tw_all, c, a, nframes, stream);
+    case 7: return launchw_l<7>(mode, in, out, tw_all, c, a, nframes, stream);
+    case 8: return launchw_l<8>(mode, in, out, tw_all, c, a, nframes, stream);
+    case 9: return launchw_l<9>(mode, in, out, tw_all, c, a, nframes, stream);
+    default: return launchw_l<10>(mode, in, out, tw_all, c, a, nframes, stream);
+    }
+}
+
+} // namespace intfft

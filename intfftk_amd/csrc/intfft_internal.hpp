@@ -130,6 +130,24 @@ hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a,
                              const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *fast1024ux_kernel_name();
 
+// general-width int32 wave kernel, N = 64..1024 (intfft_fastw32.hip)
+struct W32Stage {
+    int sh;        // a + b of the multiplier regime
+    unsigned keep; // ~(2^a - 1)
+    int wsh;       // 32 - output width of the stage (multiplier output wrap)
+    int wosh;      // 32 - output width (round-mode sum / difference wrap)
+};
+struct W32Args {
+    W32Stage st[10]; // by STAGE number
+    int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
+    int in_sh;       // 32 - DATA_WIDTH
+};
+bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                       int out_order);
+hipError_t launch_fastw32(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
+                          const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *fastw32_kernel_name();
+
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {
     int sh;            // a + b: bit offset of the result slice in the 64-bit sum

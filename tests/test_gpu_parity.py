@@ -294,6 +294,29 @@ def test_unscaled_wave_kernel_inverse_and_pair(log2n, direction):
     check(uniform_frames(77, n, 16, 9), log2n, 16, 16, 1, 0, False, direction=direction)  # XSER "OLD": earlier dbl18
 
 
+W32_CASES = [(12, 16, 0, 0), (12, 16, 0, 1), (14, 18, 0, 0), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0), (32, 16, 0, 0),
+             (32, 16, 0, 1), (8, 8, 0, 0), (20, 16, 1, 0), (22, 24, 1, 0), (10, 12, 1, 0), (16, 18, 0, 0), (16, 24, 1, 0),
+             (26, 26, 0, 0), (5, 10, 1, 0)]
+
+
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10])
+@pytest.mark.parametrize("case", W32_CASES)
+def test_general_width_wave_kernel(log2n, case):
+    """Any DATA_WIDTH / TWDL_WIDTH / FORMAT / RNDMODE within 32 bits at 64 <= N <= 1024: every multiplier regime
+    reachable below 33 bits (sngl, dbl18, sngl25, dbl35), all three sum/difference variants, both containers."""
+    dw, tw, fmt, rnd = case
+    if dw + fmt * log2n > 32:
+        pytest.skip("results exceed 32 bits: served by the 64-bit generic kernel")
+    n = 1 << log2n
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.FWD) != 0:
+            continue
+        x = np.concatenate([edge_frames(n, dw), uniform_frames((1 << (10 - log2n)) + 3, n, dw, 40 + dw),
+                            uniform_frames(70, n, max(2, dw - 1), 41 + dw)])
+        info = check(x, log2n, dw, tw, fmt, rnd, new)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_w32"), info
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
