@@ -1,0 +1,235 @@
+// intfft_fast4096w.hip -- general-width block kernel: int_fftNk for N = 2048 / 4096 with any DATA_WIDTH / TWDL_WIDTH /
+// FORMAT / RNDMODE whose widths stay within 32 bits (e.g. the unscaled 16-bit transform: 28-bit results), natural
+// order in and out.  (DATA_WIDTH = 16 scaled-truncate with TWDL_WIDTH <= 16 has the packed kernel intfft_fast4096.hip.)
+//
+// Workgroup mapping of intfft_fast4096.hip -- 256 threads own 4096 consecutive samples (one frame, or two 2048-point
+// frames whose frame-number stage is skipped), 16 samples per thread, three register rounds of four stages:
+//   LA  reg = n11..8, thread = n7..0            STAGE 11..8
+//   LB  reg = n7..4,  thread = (n11..8, n3..0)  STAGE 7..4
+//   LC  reg = n3..0,  thread = lc_bit<L>()      STAGE 3..0, stored with the bit reversal folded into the mapping
+// with block-wide LDS transposes of two dword planes (re, im) in one 40 KiB region, on unpacked int32 registers with
+// the parameterised butterflies of intfft_u32.hpp (gfly: every multiplier regime, trunc / round / unscaled).
+// Thread-dependent twiddles (30 pairs) are frame invariant and live in VGPRs.
+#include "intfft_u32.hpp"
+
+namespace intfft {
+
+constexpr int ROW4W = 20;
+constexpr int PLANE4W = 256 * ROW4W;
+
+template <int L> __host__ __device__ constexpr int lcw_bit(int k) { return k < L ? (L - 1) - k : (L - 4) + (k - L); }
+template <int L> __host__ __device__ constexpr int lcw_row_of_reg(int j)
+{
+    return (((j >> 0) & 1) << lcw_bit<L>(4)) | (((j >> 1) & 1) << lcw_bit<L>(5)) | (((j >> 2) & 1) << lcw_bit<L>(6)) |
+           (((j >> 3) & 1) << lcw_bit<L>(7));
+}
+__device__ __forceinline__ constexpr int rev4q(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// one register round: stages s0+3 .. s0 on register offsets 8, 4, 2, 1 (only those below L)
+template <int MODE, int L, int S0>
+__device__ __forceinline__ void ground(int (&re)[16], int (&im)[16], const int (&w8r)[8], const int (&w8i)[8],
+                                       const int (&w4r)[4], const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2],
+                                       int w1r, int w1i, const W32Args &a)
+{
+    if constexpr (S0 + 3 < L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j], a.st[S0 + 3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j], a.st[S0 + 2]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j], a.st[S0 + 1]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly<MODE>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
+}
+
+template <int L, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
+                   size_t nframes_user)
+{
+    static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
+    constexpr int FP = 1 << (12 - L);
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 4096 samples
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANE4W];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+
+    // frame-invariant twiddles: round A (thread = n7..0): STAGE 11 index 256 jj + tid .. STAGE 8 index tid;
+    // round B (thread low nibble = n3..0): STAGE 7 index 16 jj + lo4 .. STAGE 4 index lo4
+    int a8r[8] = {}, a8i[8] = {}, a4r[4], a4i[4], a2r[2], a2i[2], a1r, a1i;
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+    {
+        int2 w;
+        if constexpr (L >= 12) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w = twt[2047 + 256 * j + tid], a8r[j] = w.x, a8i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[1023 + 256 * j + tid], a4r[j] = w.x, a4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[511 + 256 * j + tid], a2r[j] = w.x, a2i[j] = w.y;
+        w = twt[255 + tid], a1r = w.x, a1i = w.y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], b2r[j] = w.x, b2i[j] = w.y;
+        w = twt[15 + lo4], b1r = w.x, b1i = w.y;
+    }
+    // LA -> LB: element (thread x, reg y) -> row 16 y + x3..0, column x7..4
+    u32 *const w_ab = lds + ROW4W * lo4 + hi4;
+    // LB -> LC: thread (hi4 = n11..8, lo4 = n3..0), reg j' = n7..4 -> row = LC thread (lcw_bit<L>), column n3..0
+    const int row_hi = ((hi4 & 1) << lcw_bit<L>(8)) | (((hi4 >> 1) & 1) << lcw_bit<L>(9)) | (((hi4 >> 2) & 1) << lcw_bit<L>(10)) |
+                       (((hi4 >> 3) & 1) << lcw_bit<L>(11));
+    u32 *const w_bc = lds + ROW4W * row_hi + lo4;
+    const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROW4W * tid);
+    const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANE4W + ROW4W * tid);
+    // LC <-> natural-order X: index = rev4(r) * 2^(L-4) + lc_off
+    int lc_off = 0, lc_frame = 0;
+#pragma unroll
+    for (int k = 4; k < 12; ++k) {
+        const int bit = (tid >> lcw_bit<L>(k)) & 1;
+        lc_off += bit * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
+        if (k >= L) lc_frame += bit << (k - L);
+    }
+
+    auto transpose_read = [&](int (&re)[16], int (&im)[16]) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd0[q], y = rd1[q];
+            re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
+            im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
+        }
+        __syncthreads(); // the region is rewritten by the next transpose
+    };
+
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
+        int re[16], im[16];
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + f * 4096 + tid;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
+                const u32 raw = ok ? __builtin_nontemporal_load(src + 256 * j) : 0u;
+                re[j] = (int)(raw << a.in_sh) >> a.in_sh;
+                im[j] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
+            }
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = static_cast<const v2i *>(in) + f * 4096 + tid;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
+                v2i x = {0, 0};
+                if (ok) x = __builtin_nontemporal_load(src + 256 * j);
+                re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh;
+                im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+            }
+        }
+        ground<MODE, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            w_ab[ROW4W * 16 * j] = (u32)re[j];
+            w_ab[PLANE4W + ROW4W * 16 * j] = (u32)im[j];
+        }
+        transpose_read(re, im);
+        ground<MODE, 12, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            w_bc[ROW4W * lcw_row_of_reg<L>(j)] = (u32)re[j];
+            w_bc[PLANE4W + ROW4W * lcw_row_of_reg<L>(j)] = (u32)im[j];
+        }
+        transpose_read(re, im);
+        // LC: stages 3, 2 (uniform twiddles), 1, 0
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gfly<MODE, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gfly<MODE, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+            gfly_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+
+        if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+            if (a.out16) {
+                u32 *dst = static_cast<u32 *>(out) + f * 4096 + lc_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), dst + (rev4q(r) << (L - 4)));
+            } else {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                int2 *dst = static_cast<int2 *>(out) + f * 4096 + lc_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const v2i y = {re[r], im[r]};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + (rev4q(r) << (L - 4))));
+                }
+            }
+        }
+    }
+}
+
+bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                         int out_order)
+{
+    return (log2n == 11 || log2n == 12) && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
+           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *fast4096w_kernel_name() { return "k_fft4096_w32"; }
+
+template <int L, int MODE>
+static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
+                           hipStream_t stream)
+{
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_w32<L, MODE>, 256, 0) != hipSuccess || per_cu <= 0)
+            per_cu = 2;
+        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
+    }
+    const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
+    const size_t cap = (size_t)cus * (size_t)per_cu;
+    hipLaunchKernelGGL((k_fft4096_w32<L, MODE>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
+                       tw, c, a, nframes);
+    return hipGetLastError();
+}
+
+template <int L>
+static hipError_t launch4w_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
+                             size_t nframes, hipStream_t stream)
+{
+    switch (mode) {
+    case W_TRUNC: return launch4w<L, W_TRUNC>(in, out, tw, c, a, nframes, stream);
+    case W_ROUND: return launch4w<L, W_ROUND>(in, out, tw, c, a, nframes, stream);
+    default: return launch4w<L, W_UNSCALED>(in, out, tw, c, a, nframes, stream);
+    }
+}
+
+hipError_t launch_fast4096w(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
+                            const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    UConsts c;
+    for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
+    for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
+    return log2n == 11 ? launch4w_l<11>(mode, in, out, tw_all, c, a, nframes, stream)
+                       : launch4w_l<12>(mode, in, out, tw_all, c, a, nframes, stream);
+}
+
+} // namespace intfft

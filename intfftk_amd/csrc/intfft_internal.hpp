@@ -138,7 +138,7 @@ struct W32Stage {
     int wosh;      // 32 - output width (round-mode sum / difference wrap)
 };
 struct W32Args {
-    W32Stage st[10]; // by STAGE number
+    W32Stage st[12]; // by STAGE number
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
 };
@@ -147,6 +147,12 @@ bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, in
 hipError_t launch_fastw32(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
                           const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *fastw32_kernel_name();
+// general-width int32 block kernel, N = 2048 / 4096 (intfft_fast4096w.hip)
+bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                         int out_order);
+hipError_t launch_fast4096w(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
+                            const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *fast4096w_kernel_name();
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

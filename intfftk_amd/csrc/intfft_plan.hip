@@ -39,6 +39,7 @@ struct intfft_plan {
     bool fast1024u = false;
     bool fast1024ux = false;
     bool fastw32 = false;
+    bool fast4096w = false;
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
@@ -424,13 +425,18 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                   fastw32_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                     p->out_order) &&
                   !getenv("INTFFT_NO_FASTW32");
-    if (pl->fastw32) {
+    pl->fast4096w = !pl->fast4096 &&
+                    fast4096w_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+                                        p->in_order, p->out_order) &&
+                    !getenv("INTFFT_NO_FASTW32");
+    if (pl->fastw32 || pl->fast4096w) {
         std::vector<StageDesc> st;
-        if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fastw32 = false;
-        for (size_t i = 0; i < st.size() && pl->fastw32; ++i) {
+        if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != p->log2n)
+            pl->fastw32 = pl->fast4096w = false;
+        for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w); ++i) {
             const StageDesc &d = st[i];
-            if (d.s < 0 || d.s > 9 || d.dtw > 32 || d.wo > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
-                pl->fastw32 = false;
+            if (d.s < 0 || d.s > 11 || d.dtw > 32 || d.wo > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
+                pl->fastw32 = pl->fast4096w = false;
                 break;
             }
             pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.wo, 32 - d.wo};
@@ -438,9 +444,11 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;
         pl->w32args.in_sh = 32 - p->data_width;
-        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = false;
+        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = false;
     }
-    if (pl->fastw32) {
+    if (pl->fast4096w) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096w_kernel_name());
+    } else if (pl->fastw32) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw32_kernel_name());
     } else if (pl->fast1024ux) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024ux_kernel_name());
@@ -538,9 +546,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w;
     info->n_passes = fast ? 1 : (plan->big20 && !plan->wide16) ? 3 : (int)plan->passes.size();
-    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32) ? 4 : fast ? 2 : plan->word;
+    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -554,6 +562,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->fast4096w)
+        return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
+                                     plan->h_tw.data(), batch, stream);
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                    plan->h_tw.data(), batch, stream);

@@ -181,4 +181,62 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
     for (int g = 0; g < 16; g += 2) ufly_triv(re[g], im[g], re[g + 1], im[g + 1]);
 }
 
+// ---- general-width butterflies (intfft_fastw32.hip, intfft_fast4096w.hip) ----------------------------------
+enum { W_TRUNC = 0, W_ROUND = 1, W_UNSCALED = 2 };
+
+template <int MODE, bool UNIFORM_W = false>
+__device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
+    int dre, dim;
+    if (MODE == W_UNSCALED) {
+        dre = are - bre, dim = aim - bim;
+        are += bre, aim += bim;
+    } else if (MODE == W_TRUNC) {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = ar - br, dim = ai - bi;
+        are = ar + br, aim = ai + bi;
+    } else { // rhu2(A +/- B) on the exact sum, wrapped to DTW bits (int_dif2_fly.vhd:173-218)
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
+        are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
+        aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+    }
+    const unsigned long long m2r = (unsigned long long)((long long)dre * wr), m1r = (unsigned long long)((long long)dim * wi);
+    const unsigned long long m2i = (unsigned long long)((long long)dre * wi), m1i = (unsigned long long)((long long)dim * wr);
+    const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
+    const unsigned long long xr = (m2r & k) - (m1r & k), xi = (m2i & k) + (m1i & k);
+    bre = (int)(__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh) << s.wsh) >> s.wsh;
+    bim = (int)(__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh) << s.wsh) >> s.wsh;
+}
+// STAGE 0 (ODD = false), STAGE 1: even positions Y = D, odd positions Y = -j D with the negation quirk
+template <int MODE, bool ODD>
+__device__ __forceinline__ void gfly_triv(int &are, int &aim, int &bre, int &bim, const W32Stage &s)
+{
+    int dre, dim;
+    if (MODE == W_UNSCALED) {
+        dre = are - bre, dim = aim - bim;
+        are += bre, aim += bim;
+    } else if (MODE == W_TRUNC) {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = ar - br, dim = ai - bi;
+        are = ar + br, aim = ai + bi;
+    } else {
+        const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
+        dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
+        are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
+        aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+    }
+    if (ODD) {
+        bre = dim;
+        bim = (dre >> 31) - dre; // -x for x >= 0 (fits: x < 2^(w-1)), ~x for x < 0   (int_dif2_fly.vhd:297-304)
+    } else {
+        bre = dre;
+        bim = dim;
+    }
+}
+
+
 } // namespace intfft

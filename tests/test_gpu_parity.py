@@ -317,6 +317,21 @@ def test_general_width_wave_kernel(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_w32"), info
 
 
+@pytest.mark.parametrize("log2n", [11, 12])
+@pytest.mark.parametrize("case", [(16, 16, 1, 0), (16, 16, 0, 1), (12, 16, 0, 0), (20, 24, 1, 0), (32, 24, 0, 0), (32, 16, 0, 1),
+                                  (18, 18, 0, 0), (14, 12, 1, 0)])
+def test_general_width_block_kernel(log2n, case):
+    """N = 2048 / 4096 with widths within 32 bits: the unscaled 16-bit transform, round mode, other data widths."""
+    dw, tw, fmt, rnd = case
+    n = 1 << log2n
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.FWD) != 0:
+            continue
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(5, n, dw, 60 + dw), uniform_frames(40, n, max(2, dw - 1), 61 + dw)])
+        info = check(x, log2n, dw, tw, fmt, rnd, new)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_w32"), info
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
