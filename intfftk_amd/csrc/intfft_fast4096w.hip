@@ -26,28 +26,28 @@ template <int L> __host__ __device__ constexpr int lcw_row_of_reg(int j)
 __device__ __forceinline__ constexpr int rev4q(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
 // one register round: stages s0+3 .. s0 on register offsets 8, 4, 2, 1 (only those below L)
-template <int MODE, int L, int S0>
+template <int MODE, bool MASKED, int L, int S0>
 __device__ __forceinline__ void ground(int (&re)[16], int (&im)[16], const int (&w8r)[8], const int (&w8i)[8],
                                        const int (&w4r)[4], const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2],
                                        int w1r, int w1i, const W32Args &a)
 {
     if constexpr (S0 + 3 < L) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j], a.st[S0 + 3]);
+        for (int j = 0; j < 8; ++j) gfly<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j], a.st[S0 + 3]);
     }
 #pragma unroll
     for (int g = 0; g < 16; g += 8)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j], a.st[S0 + 2]);
+        for (int j = 0; j < 4; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j], a.st[S0 + 2]);
 #pragma unroll
     for (int g = 0; g < 16; g += 4)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j], a.st[S0 + 1]);
+        for (int j = 0; j < 2; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j], a.st[S0 + 1]);
 #pragma unroll
-    for (int g = 0; g < 16; g += 2) gfly<MODE>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
+    for (int g = 0; g < 16; g += 2) gfly<MODE, false, MASKED>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
 }
 
-template <int L, int MODE>
+template <int L, int MODE, bool MASKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
                    size_t nframes_user)
@@ -133,14 +133,14 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
                 im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
             }
         }
-        ground<MODE, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
+        ground<MODE, MASKED, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             w_ab[ROW4W * 16 * j] = (u32)re[j];
             w_ab[PLANE4W + ROW4W * 16 * j] = (u32)im[j];
         }
         transpose_read(re, im);
-        ground<MODE, 12, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+        ground<MODE, MASKED, 12, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             w_bc[ROW4W * lcw_row_of_reg<L>(j)] = (u32)re[j];
@@ -149,11 +149,11 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
         transpose_read(re, im);
         // LC: stages 3, 2 (uniform twiddles), 1, 0
 #pragma unroll
-        for (int r = 0; r < 8; ++r) gfly<MODE, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+        for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
 #pragma unroll
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gfly<MODE, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+            for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
@@ -190,7 +190,7 @@ bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, 
 
 const char *fast4096w_kernel_name() { return "k_fft4096_w32"; }
 
-template <int L, int MODE>
+template <int L, int MODE, bool MASKED>
 static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                            hipStream_t stream)
 {
@@ -199,13 +199,13 @@ static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UCon
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_w32<L, MODE>, 256, 0) != hipSuccess || per_cu <= 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_w32<L, MODE, MASKED>, 256, 0) != hipSuccess || per_cu <= 0)
             per_cu = 2;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
     const size_t cap = (size_t)cus * (size_t)per_cu;
-    hipLaunchKernelGGL((k_fft4096_w32<L, MODE>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
+    hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
                        tw, c, a, nframes);
     return hipGetLastError();
 }
@@ -214,10 +214,17 @@ template <int L>
 static hipError_t launch4w_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
                              size_t nframes, hipStream_t stream)
 {
+    if (a.masked) {
+        switch (mode) {
+        case W_TRUNC: return launch4w<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
+        case W_ROUND: return launch4w<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
+        default: return launch4w<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+        }
+    }
     switch (mode) {
-    case W_TRUNC: return launch4w<L, W_TRUNC>(in, out, tw, c, a, nframes, stream);
-    case W_ROUND: return launch4w<L, W_ROUND>(in, out, tw, c, a, nframes, stream);
-    default: return launch4w<L, W_UNSCALED>(in, out, tw, c, a, nframes, stream);
+    case W_TRUNC: return launch4w<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
+    case W_ROUND: return launch4w<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
+    default: return launch4w<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
     }
 }
 

@@ -16,7 +16,7 @@
 
 namespace intfft {
 
-template <int L, int MODE>
+template <int L, int MODE, bool MASKED>
 __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
                                                      const W32Args a, size_t nframes_user)
 {
@@ -103,23 +103,23 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
         // ---- stages 9..6 in registers, 5 and 4 after the lane swaps ----
         if constexpr (L >= 10) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], a.st[9]);
+            for (int j = 0; j < 8; ++j) gfly<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], a.st[9]);
         }
         if constexpr (L >= 9) {
 #pragma unroll
             for (int g = 0; g < 16; g += 8)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], a.st[8]);
+                for (int j = 0; j < 4; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w8r[j], w8i[j], a.st[8]);
         }
         if constexpr (L >= 8) {
 #pragma unroll
             for (int g = 0; g < 16; g += 4)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], a.st[7]);
+                for (int j = 0; j < 2; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w7r[j], w7i[j], a.st[7]);
         }
         if constexpr (L >= 7) {
 #pragma unroll
-            for (int g = 0; g < 16; g += 2) gfly<MODE>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, a.st[6]);
+            for (int g = 0; g < 16; g += 2) gfly<MODE, false, MASKED>(re[g], im[g], re[g + 1], im[g + 1], w6r, w6i, a.st[6]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
             uswap32(im[j], im[j + 8]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gfly<MODE>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, a.st[5]);
+        for (int j = 0; j < 8; ++j) gfly<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w5r, w5i, a.st[5]);
 #pragma unroll
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
 #pragma unroll
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gfly<MODE>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, a.st[4]);
+            for (int j = 0; j < 4; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, a.st[4]);
         // ---- LDS transpose: regs become a3..0 ----
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
         asm volatile("" ::: "memory");
         // ---- stages 3, 2 (uniform twiddles), 1, 0 ----
 #pragma unroll
-        for (int r = 0; r < 8; ++r) gfly<MODE, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+        for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
 #pragma unroll
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gfly<MODE, true>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+            for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
@@ -230,7 +230,7 @@ bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, in
 
 const char *fastw32_kernel_name() { return "k_fft1024_w32"; }
 
-template <int L, int MODE>
+template <int L, int MODE, bool MASKED>
 static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                           hipStream_t stream)
 {
@@ -239,13 +239,13 @@ static hipError_t launchw(const void *in, void *out, const int2 *tw, const UCons
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_w32<L, MODE>, 256, 0) != hipSuccess || per_cu <= 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_w32<L, MODE, MASKED>, 256, 0) != hipSuccess || per_cu <= 0)
             per_cu = 2;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
-    hipLaunchKernelGGL((k_fft1024_w32<L, MODE>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+    hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
                        c, a, nframes);
     return hipGetLastError();
 }
@@ -254,10 +254,17 @@ template <int L>
 static hipError_t launchw_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
                             size_t nframes, hipStream_t stream)
 {
+    if (a.masked) {
+        switch (mode) {
+        case W_TRUNC: return launchw<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
+        case W_ROUND: return launchw<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
+        default: return launchw<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+        }
+    }
     switch (mode) {
-    case W_TRUNC: return launchw<L, W_TRUNC>(in, out, tw, c, a, nframes, stream);
-    case W_ROUND: return launchw<L, W_ROUND>(in, out, tw, c, a, nframes, stream);
-    default: return launchw<L, W_UNSCALED>(in, out, tw, c, a, nframes, stream);
+    case W_TRUNC: return launchw<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
+    case W_ROUND: return launchw<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
+    default: return launchw<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
     }
 }
 

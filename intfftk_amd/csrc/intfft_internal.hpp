@@ -141,6 +141,7 @@ struct W32Args {
     W32Stage st[12]; // by STAGE number
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
+    int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
 };
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                        int out_order);

@@ -440,6 +440,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                 break;
             }
             pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.wo, 32 - d.wo};
+            if (d.s >= 2 && d.sh_a != 0) pl->w32args.masked = 1;
         }
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;

@@ -184,7 +184,8 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
 // ---- general-width butterflies (intfft_fastw32.hip, intfft_fast4096w.hip) ----------------------------------
 enum { W_TRUNC = 0, W_ROUND = 1, W_UNSCALED = 2 };
 
-template <int MODE, bool UNIFORM_W = false>
+// MASKED = false: every stage of the plan is in a single-DSP regime (a = 0): exact sum first, chained v_mad_i64_i32
+template <int MODE, bool UNIFORM_W = false, bool MASKED = true>
 __device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
 {
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
@@ -203,10 +204,17 @@ __device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int
         are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
         aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
     }
-    const unsigned long long m2r = (unsigned long long)((long long)dre * wr), m1r = (unsigned long long)((long long)dim * wi);
-    const unsigned long long m2i = (unsigned long long)((long long)dre * wi), m1i = (unsigned long long)((long long)dim * wr);
-    const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
-    const unsigned long long xr = (m2r & k) - (m1r & k), xi = (m2i & k) + (m1i & k);
+    unsigned long long xr, xi;
+    if (MASKED) {
+        const unsigned long long m2r = (unsigned long long)((long long)dre * wr), m1r = (unsigned long long)((long long)dim * wi);
+        const unsigned long long m2i = (unsigned long long)((long long)dre * wi), m1i = (unsigned long long)((long long)dim * wr);
+        const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
+        xr = (m2r & k) - (m1r & k), xi = (m2i & k) + (m1i & k);
+    } else {
+        const int ndim = -dim;
+        xr = (unsigned long long)((long long)dre * wr + (long long)ndim * wi);
+        xi = (unsigned long long)((long long)dre * wi + (long long)dim * wr);
+    }
     bre = (int)(__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh) << s.wsh) >> s.wsh;
     bim = (int)(__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh) << s.wsh) >> s.wsh;
 }
