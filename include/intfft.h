@@ -113,6 +113,15 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
  * This is NOT a CPU execution path: every frame is transformed on the HIP device. */
 int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames);
 
+/* Single-process multi-GPU convenience (frames are independent, so a batch shards
+ * across GPUs with no collective in the data path -- the software analogue of instantiating the core once per
+ * channel).  plans[0..nplans-1] hold identical intfft_params, one per HIP device; d_in / d_out live on the device
+ * of plans[root].  The batch is cut into contiguous shards (remainder to the LAST plans); shard i is copied
+ * root -> device i (hipMemcpyPeerAsync over xGMI), transformed there, and copied back; the root transforms its own
+ * shard in place of the copy.  Blocking.  One-process-per-GPU hosts (torch.distributed / MPI) call intfft_exec on
+ * their own shard instead (intfftk_amd/sharding.py). */
+int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch);
+
 /* Parity introspection: the twiddle stream of butterfly stage `stage` (2^stage entries, the
  * values rom_twiddle_int emits for cnt = 0 .. 2^stage-1) as interleaved int32 (re, im).
  * h_out may be NULL to query *count. */

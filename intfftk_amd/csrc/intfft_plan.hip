@@ -50,6 +50,10 @@ struct intfft_plan {
     hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     void *slot_in[2] = {nullptr, nullptr}, *slot_out[2] = {nullptr, nullptr};
+    // intfft_exec_sharded: this plan's staging buffers (grow only) and stream
+    void *shard_in = nullptr, *shard_out = nullptr;
+    size_t shard_in_bytes = 0, shard_out_bytes = 0;
+    hipStream_t s_shard = nullptr;
     size_t slot_frames = 0;
     char kernel_name[64] = {0};
 };
@@ -531,6 +535,9 @@ int intfft_plan_destroy(intfft_plan *plan)
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        if (plan->shard_in) (void)hipFree(plan->shard_in);
+        if (plan->shard_out) (void)hipFree(plan->shard_out);
+        if (plan->s_shard) (void)hipStreamDestroy(plan->s_shard);
         free_stream_state(plan);
         if (plan->d_tw16f) (void)hipFree(plan->d_tw16f);
         if (plan->d_tw16i) (void)hipFree(plan->d_tw16i);
@@ -705,6 +712,72 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
 fail:
 #undef INTFFT_TRY
     return (int)e;
+}
+
+int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
+{
+    if (!plans || nplans <= 0 || root < 0 || root >= nplans) return INTFFT_ERR_INVALID;
+    for (int i = 0; i < nplans; ++i) {
+        if (!plans[i]) return INTFFT_ERR_NULL;
+        if (std::memcmp(&plans[i]->p, &plans[0]->p, sizeof(intfft_params)) != 0) return INTFFT_ERR_INVALID;
+        for (int j = 0; j < i; ++j)
+            if (plans[j] == plans[i]) return INTFFT_ERR_INVALID; // a plan owns its scratch: one shard at a time
+    }
+    if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
+    if (batch == 0) return INTFFT_OK;
+    intfft_plan *rp = plans[root];
+    const size_t N = (size_t)1 << rp->L;
+    const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
+    const size_t base = batch / (size_t)nplans, rem = batch % (size_t)nplans;
+    hipError_t e = hipSuccess;
+    int rc = INTFFT_OK;
+    {   // the caller's data is ready once the root device's default stream is idle
+        DeviceGuard g(rp->device);
+        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+        e = hipStreamSynchronize(nullptr);
+    }
+    size_t start = 0;
+    for (int i = 0; i < nplans && e == hipSuccess && rc == INTFFT_OK; ++i) {
+        intfft_plan *pl = plans[i];
+        const size_t nf = base + ((size_t)i >= (size_t)nplans - rem ? 1 : 0);
+        const char *src = static_cast<const char *>(d_in) + start * in_frame;
+        char *dst = static_cast<char *>(d_out) + start * out_frame;
+        start += nf;
+        if (nf == 0) continue;
+        DeviceGuard g(pl->device);
+        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+        if (!pl->s_shard) e = hipStreamCreateWithFlags(&pl->s_shard, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        if (i == root) {
+            rc = intfft_exec(pl, src, dst, nf, pl->s_shard);
+            continue;
+        }
+        if (pl->shard_in_bytes < nf * in_frame) {
+            if (pl->shard_in) (void)hipFree(pl->shard_in);
+            pl->shard_in = nullptr, pl->shard_in_bytes = 0;
+            if ((e = hipMalloc(&pl->shard_in, nf * in_frame)) != hipSuccess) break;
+            pl->shard_in_bytes = nf * in_frame;
+        }
+        if (pl->shard_out_bytes < nf * out_frame) {
+            if (pl->shard_out) (void)hipFree(pl->shard_out);
+            pl->shard_out = nullptr, pl->shard_out_bytes = 0;
+            if ((e = hipMalloc(&pl->shard_out, nf * out_frame)) != hipSuccess) break;
+            pl->shard_out_bytes = nf * out_frame;
+        }
+        e = hipMemcpyPeerAsync(pl->shard_in, pl->device, src, rp->device, nf * in_frame, pl->s_shard);
+        if (e != hipSuccess) break;
+        rc = intfft_exec(pl, pl->shard_in, pl->shard_out, nf, pl->s_shard);
+        if (rc != INTFFT_OK) break;
+        e = hipMemcpyPeerAsync(dst, rp->device, pl->shard_out, pl->device, nf * out_frame, pl->s_shard);
+    }
+    for (int i = 0; i < nplans; ++i) { // drain every stream that was used, also after an error
+        if (!plans[i]->s_shard) continue;
+        DeviceGuard g(plans[i]->device);
+        const hipError_t es = hipStreamSynchronize(plans[i]->s_shard);
+        if (e == hipSuccess) e = es;
+    }
+    if (rc != INTFFT_OK) return rc;
+    return e == hipSuccess ? INTFFT_OK : (int)e;
 }
 
 int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count)

@@ -171,3 +171,21 @@ def int_fft_ifft_pair(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0
     (re, im) per lane, not the reference's mis-wired Q0_IM/Q1_RE (:332-335)."""
     return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSERIES, "PAIR", "NATURAL", "NATURAL",
                       USE_FLY, device, RAMB_TYPE, USE_MLT)
+
+
+def exec_sharded(cores, x, root: int = 0):
+    """Single-process multi-GPU transform through intfft_exec_sharded: `cores` are IntFFTCore objects with identical
+    generics (normally one per HIP device), `x` a [batch, N, 2] tensor on the device of cores[root].  Contiguous
+    shards, remainder to the last cores, peer copies over xGMI, no collective.  Blocking."""
+    import torch
+
+    c0 = cores[root]
+    if x.dtype != c0.in_dtype or x.dim() != 3 or x.shape[1] != c0.n or x.shape[2] != 2 or not x.is_contiguous():
+        raise ValueError("input must be a contiguous [batch, %d, 2] %s tensor" % (c0.n, c0.in_dtype))
+    y = torch.empty((x.shape[0], c0.n, 2), dtype=c0.out_dtype, device=x.device)
+    arr = (ctypes.c_void_p * len(cores))(*[c._plan for c in cores])
+    torch.cuda.synchronize(x.device)
+    capi.check(capi.lib().intfft_exec_sharded(arr, len(cores), root, x.data_ptr(), y.data_ptr(), x.shape[0]),
+               "intfft_exec_sharded")
+    return y
+

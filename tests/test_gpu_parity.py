@@ -417,6 +417,34 @@ def test_fast_kernels_ragged_batches(cfg, batch):
     assert info["fast_path"] == 1
 
 
+@pytest.mark.parametrize("nplans,root,batch", [(1, 0, 5), (2, 0, 7), (3, 1, 10), (4, 3, 2), (3, 2, 4099)])
+def test_exec_sharded_c_abi(nplans, root, batch):
+    """intfft_exec_sharded: contiguous shards (remainder to the last plans), peer copies, no collective.  On a
+    one-GPU box every plan sits on device 0 (peer copies degenerate to device copies); the control flow, shard
+    bounds, staging buffers and error paths are the same as across devices."""
+    import torch
+
+    from intfftk_amd import IntFFTCore, exec_sharded
+    from intfftk_amd import _capi as capi
+
+    ndev = torch.cuda.device_count()
+    cores = [IntFFTCore(10, 16, 16, 0, 0, "NEW", "FWD", device=i % ndev) for i in range(nplans)]
+    x = uniform_frames(batch, 1024, 15, 31337 + batch)
+    xd = torch.from_numpy(x.astype(np.int16)).to("cuda:%d" % (root % ndev))
+    y = exec_sharded(cores, xd, root)
+    assert np.array_equal(y.cpu().numpy().astype(np.int64), run_ref(x, 10, 16, 16, 0, 0, True))
+    # error behaviour: mismatching generics, a repeated plan, bad root
+    other = IntFFTCore(10, 16, 16, 0, 1, "NEW", "FWD")
+    import ctypes
+    arr = (ctypes.c_void_p * 2)(cores[0]._plan, other._plan)
+    assert capi.lib().intfft_exec_sharded(arr, 2, 0, xd.data_ptr(), y.data_ptr(), batch) == capi.ERR_INVALID
+    arr = (ctypes.c_void_p * 2)(cores[0]._plan, cores[0]._plan)
+    assert capi.lib().intfft_exec_sharded(arr, 2, 0, xd.data_ptr(), y.data_ptr(), batch) == capi.ERR_INVALID
+    assert capi.lib().intfft_exec_sharded(arr, 2, 5, xd.data_ptr(), y.data_ptr(), batch) == capi.ERR_INVALID
+    for c in cores + [other]:
+        c.close()
+
+
 def test_hip_graph_capture_and_replay():
     """intfft_exec is capturable (no allocation / sync inside): replaying the graph on new input data gives
     the same rows as eager execution -- the launch-bound small-batch regime is where this matters."""
