@@ -340,23 +340,18 @@ def test_fast1024u_ragged_batches(batch):
 
 
 def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
-    """Same plan through the generic k_pass<int32> kernels (INTFFT_NO_FAST1024U=1): the two device paths and
-    the oracle agree on the same frames."""
+    """Same plan through three device paths -- the tuned unscaled wave kernel, the general-width wave kernel
+    (INTFFT_NO_FAST1024U=1) and the generic k_pass<int32> kernels (also INTFFT_NO_FASTW32=1): all agree bit for bit
+    (and with the oracle, test_fast1024u_unscaled_wave_kernel)."""
     x = np.concatenate([uniform_frames(64, 1024, 16, 61), uniform_frames(64, 1024, 15, 62)])
     fast, info_f = run_gpu(x, 10, 16, 16, 1, 0, True)
     monkeypatch.setenv("INTFFT_NO_FAST1024U", "1")
+    mid, info_m = run_gpu(x, 10, 16, 16, 1, 0, True)
+    monkeypatch.setenv("INTFFT_NO_FASTW32", "1")
     slow, info_s = run_gpu(x, 10, 16, 16, 1, 0, True)
-    assert info_f["fast_path"] == 1 and info_s["fast_path"] == 0
-    assert np.array_equal(fast, slow)
-
-
-@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
-def test_block_kernel_n2048(direction):
-    """N = 2048: two frames share a workgroup of the N = 4096 kernel; guard-bit, full-scale and edge frames."""
-    x = np.concatenate([edge_frames(2048, 16), uniform_frames(301, 2048, 15, 91), uniform_frames(20, 2048, 16, 92)])
-    info = check(x, 11, 16, 16, 0, 0, True, direction=direction)
-    assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16")
-    check(uniform_frames(33, 2048, 15, 93), 11, 16, 14, 0, 0, False, direction=direction)
+    assert info_f["kernel_name"].startswith("k_fft1024_u32") and info_m["kernel_name"].startswith("k_fft1024_w32")
+    assert info_s["fast_path"] == 0
+    assert np.array_equal(fast, slow) and np.array_equal(mid, slow)
 
 
 def test_native_cores_chain_like_the_pair():
