@@ -402,16 +402,18 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         intfft_plan_destroy(pl);
         return rc;
     }
-    pl->fast1024 = fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
-                                      p->direction, p->use_fly, p->in_order, p->out_order);
-    pl->fast4096 = !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
+    // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only
+    const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr;
+    pl->fast1024 = !generic_only && fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
+                                                       p->direction, p->use_fly, p->in_order, p->out_order);
+    pl->fast4096 = !generic_only && !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
                                                        p->use_fly, p->in_order, p->out_order);
-    pl->fast1024x = fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
+    pl->fast1024x = !generic_only && fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                         p->use_fly, p->in_order, p->out_order);
-    pl->fast1024u = fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+    pl->fast1024u = !generic_only && fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_FAST1024U");
-    pl->fast1024ux = fast1024ux_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+    pl->fast1024ux = !generic_only && fast1024ux_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                           p->in_order, p->out_order) &&
                      !getenv("INTFFT_NO_FAST1024U");
     if (pl->fast1024ux) { // per-stage multiplier regimes of the inverse core
@@ -425,11 +427,11 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             pl->uxargs.st[i] = UxStage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), d.mw};
         }
     }
-    pl->fastw32 = !pl->fast1024 && !pl->fast1024u && !pl->fast1024ux && !pl->fast1024x &&
+    pl->fastw32 = !generic_only && !pl->fast1024 && !pl->fast1024u && !pl->fast1024ux && !pl->fast1024x &&
                   fastw32_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                     p->out_order) &&
                   !getenv("INTFFT_NO_FASTW32");
-    pl->fast4096w = !pl->fast4096 &&
+    pl->fast4096w = !generic_only && !pl->fast4096 &&
                     fast4096w_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_FASTW32");
@@ -475,10 +477,10 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             intfft_plan_destroy(pl);
             return rc;
         }
-        pl->big20 = big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
+        pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
-        pl->wide16 = wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
+        pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
         if (pl->wide16) {

@@ -354,6 +354,27 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
     assert np.array_equal(fast, slow) and np.array_equal(mid, slow)
 
 
+AB_CASES = [(7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
+            (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
+            (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
+            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD")]
+
+
+@pytest.mark.parametrize("case", AB_CASES)
+def test_dedicated_and_generic_kernels_agree(case, monkeypatch):
+    """A/B on the device: the dedicated kernel of a configuration and the generic LDS pass kernels
+    (INTFFT_GENERIC_ONLY=1) produce identical bits on batches far larger than the oracle-checked ones -- two
+    independent implementations of the same arithmetic, and the generic kernels stay under test."""
+    log2n, dw, tw, fmt, rnd, d = case
+    batch = max(3, (1 << 22) >> log2n) + 1
+    x = uniform_frames(batch, 1 << log2n, dw, 5150 + log2n)
+    a, ia = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=d)
+    monkeypatch.setenv("INTFFT_GENERIC_ONLY", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=d)
+    assert ia["kernel_name"] != ib["kernel_name"] and ib["kernel_name"].startswith("k_pass"), (ia, ib)
+    assert np.array_equal(a, b)
+
+
 def test_native_cores_chain_like_the_pair():
     """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
     same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
