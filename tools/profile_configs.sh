@@ -1,0 +1,27 @@
+#!/bin/bash
+# tools/profile_configs.sh <tag> -- rocprofv3 --kernel-trace --stats over tools/bench_configs.py for the other BASELINE
+# configurations and the new kernel families (run on the GPU box via gpurun); compact per-kernel CSV in gpurun_out/.
+set -u
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_cfg_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python $REPO/tools/bench_configs.py \
+    C3 C4 C5 C5fwd C2inv C2u 7:16:16:0 7:16:16:0:0:PAIR 7:16:16:1 11:16:16:0 16:16:16:0 12:16:16:1 10:12:16:0 > "$OUT/bench.log" 2>&1
+cd "$REPO"
+python - "$OUT" <<'PY'
+import csv, glob, sys, os
+root = sys.argv[1]
+f = glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if "intfft" in r["Name"]]
+with open(os.path.join(root, "kernel_stats_compact.csv"), "w", newline="") as fh:
+    w = csv.writer(fh)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+    for r in rows:
+        name = r["Name"].split("(")[0].replace("void ", "")
+        w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+print(open(os.path.join(root, "kernel_stats_compact.csv")).read())
+PY
+grep -v amdgpu.ids "$OUT/bench.log" | cut -c1-200
