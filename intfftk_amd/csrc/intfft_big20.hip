@@ -175,6 +175,129 @@ __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const
     }
 }
 
+// ---- inverse pass 1 (DIT mirror of pass 1): STAGE 12..L-1 of int_ifftNk, plan scratch -> user array -----------------
+// Same tiles, frame groups and register-resident twiddles as k_big16_p1 / k_big20_p1; the DIT butterflies reuse the
+// DIF twiddle packing through the re/im-swapped multiplier feed (int_dit2_fly.vhd:304-322).  Inputs are full-width
+// values (DIT outputs are never pre-shifted).
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes_user,
+                                                  unsigned groups, const Slice sl)
+{
+    static_assert(L >= 13 && L <= 16, "one-round pass");
+    constexpr int NS = L - 12, G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G;
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const unsigned lfull = chunk * 512 + threadIdx.x;
+    RoundTw t;
+    if constexpr (NS >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t.wa8[j], t.wb8[j]);
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t.wa4[j], t.wb4[j]);
+    }
+    if constexpr (NS >= 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t.wa2[j], t.wb2[j]);
+    }
+    ld_tw(twf, (1u << 12) - 1u + lfull, t.wa1[0], t.wb1[0]);
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = scr + frame * 65536 + lfull;
+        u32 *dst = out + frame * 65536 + lfull;
+        u32 v[16];
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user;
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = frame * G + (size_t)(j >> (L - 12)) < nframes_user ? src[(size_t)j << 12] : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = src[(size_t)j << 12];
+        }
+        if (FAST_OK && frame_has_guard_bit(v)) dit_round<FAST_OK, NS>(v, t, sl);
+        else dit_round<false, NS>(v, t, sl);
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (frame * G + (size_t)(j >> (L - 12)) < nframes_user) dst[(size_t)j << 12] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << 12));
+        }
+    }
+}
+
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes_user,
+                                                  unsigned groups, const Slice sl)
+{
+    static_assert(L >= 17 && L <= 20, "two-round pass");
+    constexpr int NS1 = L - 16, G = 1 << (20 - L);
+    const size_t nframes = (nframes_user + G - 1) / G;
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n19..16 (round 1: regs n15..12) / n15..12 (round 2)
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const unsigned lfull = chunk * 32 + l;
+    RoundTw t1, t2; // t2: STAGE 15..12 (index depends on n11..0 only); t1: STAGE 19..16 with hx = n15..12
+    {
+        const unsigned b = hx * 4096u + lfull;
+        if constexpr (NS1 >= 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+        }
+        if constexpr (NS1 >= 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+        }
+        if constexpr (NS1 >= 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+        }
+        ld_tw(twf, (1u << 16) - 1u + b, t1.wa1[0], t1.wb1[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t2.wa8[j], t2.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t2.wa4[j], t2.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t2.wa2[j], t2.wb2[j]);
+        ld_tw(twf, (1u << 12) - 1u + lfull, t2.wa1[0], t2.wb1[0]);
+    }
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = scr + frame * ((size_t)1 << L20) + lfull;
+        u32 *dst = out + frame * ((size_t)1 << L20) + lfull;
+        const bool partial = L < 20 && (frame + 1) * G > nframes_user;
+        u32 v[16];
+        if (partial) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = frame * G + (size_t)((16 * hx + r) >> (L - 12)) < nframes_user ? src[(size_t)(16 * hx + r) << 12] : 0u;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = src[(size_t)(16 * hx + r) << 12]; // thread hx = n19..16, regs = n15..12
+        }
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // also orders the previous LDS reads
+        if (!FAST_OK) __syncthreads();
+        if (fast) dit_round<FAST_OK>(v, t2, sl);
+        else dit_round<false>(v, t2, sl);
+        // transpose: (thread (hx = n19..16, l), reg r = n15..12) -> (thread (r, l), reg hx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[ROWB * (32 * r + l) + hx] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * tid + j]; // now tid >> 5 = n15..12, regs = n19..16
+        if (fast) dit_round<FAST_OK, NS1>(v, t1, sl);
+        else dit_round<false, NS1>(v, t1, sl);
+        if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user) dst[(size_t)(16 * j + hx) << 12] = v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)(16 * j + hx) << 12));
+        }
+    }
+}
+
 // ---- pass 2: stages 11..4 on 4096 consecutive points, in place ----------------------------------------
 template <bool FAST_OK>
 __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restrict__ twt, size_t nblocks4k, const Slice sl)
@@ -295,7 +418,7 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
                      int in_order, int out_order)
 {
     return log2n >= 13 && log2n <= 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+           (direction == 0 || direction == 2) && use_fly == 1 && in_order == 0 && out_order == 0; // FWD, or the pair
 }
 
 const char *big20_kernel_name() { return "k_big20_p1/p2/p3"; }
@@ -314,6 +437,59 @@ static void launch_p1(bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, siz
         if (fx) hipLaunchKernelGGL((k_big16_p1<L, true>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
         else hipLaunchKernelGGL((k_big16_p1<L, false>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
     }
+}
+
+template <int L>
+static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream)
+{
+    if constexpr (L >= 17) {
+        const size_t nvf = (nframes + ((size_t)1 << (20 - L)) - 1) >> (20 - L);
+        const unsigned groups = (unsigned)(nvf < 16 ? nvf : 16);
+        if (fx) hipLaunchKernelGGL((k_big20_q1<L, true>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+        else hipLaunchKernelGGL((k_big20_q1<L, false>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+    } else {
+        const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L);
+        const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
+        if (fx) hipLaunchKernelGGL((k_big16_q1<L, true>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+        else hipLaunchKernelGGL((k_big16_q1<L, false>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+    }
+}
+
+// FFT -> IFFT pair for N = 2^13 .. 2^20 in three passes: DIF STAGE L-1..12 (pass 1 above), then the whole pair of
+// STAGE 11..0 / 0..11 on every 4096-point block in place (k_fft4096_i16<MODE_MID>: the bit reversal between the cores
+// cancels, int_fft_ifft_pair.vhd:242-280), then DIT STAGE 12..L-1 (k_big16_q1 / k_big20_q1).
+hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+                          const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    const u32 *pin = static_cast<const u32 *>(in);
+    u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    switch (log2n) {
+    case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 15: launch_p1<15>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 16: launch_p1<16>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 17: launch_p1<17>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 18: launch_p1<18>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    }
+    const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream);
+    if (e != hipSuccess) return e;
+    switch (log2n) {
+    case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 14: launch_q1<14>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 15: launch_q1<15>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 16: launch_q1<16>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 17: launch_q1<17>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 18: launch_q1<18>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 19: launch_q1<19>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    default: launch_q1<20>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,

@@ -47,7 +47,9 @@ constexpr int REGION4K = 256 * ROW4K; // dwords per transpose region
         }                                                                                              \
     }
 
-enum { MODE_FWD = 0, MODE_INV = 1, MODE_PAIR = 2 };
+// MODE_MID: the pair on one 4096-point block of a longer frame (middle pass of the N >= 8192 pair, intfft_big20.hip):
+// like MODE_PAIR, but the block's inputs come from the DIF stage 12 of pass 1 (Y >> 1 where n12 = block index bit 0)
+enum { MODE_FWD = 0, MODE_INV = 1, MODE_PAIR = 2, MODE_MID = 3 };
 
 // L = 11 (N = 2048): the workgroup owns a chunk of two frames; index bit n11 numbers the frame and its stage is
 // skipped in both cores (twiddle indices are positions mod 2^s, so nothing else changes).  lc_bit<L>(k): the bit
@@ -143,10 +145,19 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 
         // guard-bit test of the whole frame (block-uniform)
         bool fast = false;
+        const short sm = (short)(1 - (int)(f & 1)); // MODE_MID: shift amount of the first stage's inputs
+        const v2s sh_m = {sm, sm};
         if (FAST_OK) {
             if (tid == 0) *s_unsafe = 0;
             __syncthreads();
-            if (guard_acc(v) != 0) *s_unsafe = 1;
+            bool bad = guard_acc(v) != 0;
+            if (MODE == MODE_MID && (f & 1)) { // Y >> 1 inputs: |v| < 2^13
+                u32 acc = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc |= v[j] + 0x20002000u;
+                bad = (acc & 0xC000C000u) != 0;
+            }
+            if (bad) *s_unsafe = 1;
             __syncthreads();
             fast = *s_unsafe == 0;
         }
@@ -154,7 +165,8 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #define INTFFT_BODY(FX)                                                                                 \
     {                                                                                                   \
         if (MODE != MODE_INV) {                                                                         \
-            dif_round<FX, false, NS>(v, ta, sl, sh_b);                                                  \
+            if (MODE == MODE_MID) dif_round<FX, true, NS>(v, ta, sl, sh_m);                             \
+            else dif_round<FX, false, NS>(v, ta, sl, sh_b);                                             \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
             dif_round<FX, true>(v, tb, sl, sh_b);                                                       \
@@ -215,6 +227,27 @@ static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundC
     const unsigned blocks = (unsigned)(chunks < cap ? chunks : cap);
     hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
     return hipGetLastError();
+}
+
+hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream)
+{
+    if (nblocks4k == 0) return hipSuccess;
+    RoundCConsts c;
+    for (int k = 0; k < 8; ++k) {
+        const int2 w = h_tw[7 + k];
+        c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int2 w = h_tw[3 + k];
+        c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    u32 *p = static_cast<u32 *>(scratch);
+    return (twd == 16 && allow_fast) ? launch4k<12, MODE_MID, true>(p, p, tw_all, c, nblocks4k, sl, stream)
+                                     : launch4k<12, MODE_MID, false>(p, p, tw_all, c, nblocks4k, sl, stream);
 }
 
 template <int L>

@@ -178,6 +178,9 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                         const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *big20_kernel_name();
+hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+                          const int2 *h_tw, size_t nframes, hipStream_t stream);
+hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);
 
 // packed int16 block kernel for N = 4096, FWD / INV / PAIR (intfft_fast4096.hip)
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int use_fly,
