@@ -414,11 +414,99 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
     for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
 }
 
+// ---- inverse pass 3 (mirror of pass 3): bit-reversed load of the natural-order input + DIT STAGE 0..3 -----------------
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const RoundCConsts c, size_t nframes, const Slice sl, int L)
+{
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x;
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5
+    // thread = (n4 = tid >> 8, rev8(n(L-1)..n(L-8)) = tid & 255), regs = n3..0: X index = brev_L(n) (1 KiB runs)
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const u32 *src = in + (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);
+    u32 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + ((size_t)rev4b(r) << (L - 4)));
+    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+    if (fast) dit_round_c<FAST_OK>(v, c, sl);
+    else dit_round_c<false>(v, c, sl);
+    // transpose to thread = (px = n(L-5)..n(L-8), e = n4..0), regs j = n(L-1)..n(L-4): rev8(16 j + px) = tid & 255
+    const int px = rev4b((tid >> 4) & 15), j = rev4b(tid & 15);
+    {
+        u32 *w = lds + ROWB * (32 * px + 16 * (tid >> 8)) + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[ROWB * r] = v[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = lds[ROWB * tid + q];
+    u32 *dst = scr + (frame << L) + mid * 32 + (tid & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dst[(size_t)(16 * q + (tid >> 5)) << (L - 8)] = v[q];
+}
+
+// ---- inverse pass 2 (mirror of pass 2): DIT STAGE 4..11 on 4096 consecutive points, in place ------------------------------
+template <bool FAST_OK>
+__global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restrict__ twt, size_t nblocks4k, const Slice sl)
+{
+    __shared__ u32 lds[2 * 256 * ROWB];
+    u32 *const reg0 = lds, *const reg1 = lds + 256 * ROWB;
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    RoundTw ta, tb;
+    auto ld = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = twt[idx];
+        wa = pack_wa(w);
+        wb = pack_wb(w);
+    };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld(1023 + 256 * j + tid, ta.wa4[j], ta.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld(511 + 256 * j + tid, ta.wa2[j], ta.wb2[j]);
+    ld(255 + tid, ta.wa1[0], ta.wb1[0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
+    ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+
+    for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
+        u32 *p = scr + b * 4096;
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+        if (!FAST_OK) __syncthreads(); // orders the previous block's reg1 reads before this block's writes
+        // LA -> LB: row = 16 j + n3..0, column = n7..4
+#pragma unroll
+        for (int j = 0; j < 16; ++j) reg0[ROWB * (16 * j + lo4) + hi4] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = reg0[ROWB * tid + r]; // LB: regs = n7..4, thread = (n11..8, n3..0)
+        if (fast) dit_round<FAST_OK>(v, tb, sl);
+        else dit_round<false>(v, tb, sl);
+        // LB -> LA: element (t' = (n11..8, n3..0), reg j' = n7..4) -> row n7..0 = 16 j' + n3..0, column n11..8
+#pragma unroll
+        for (int j = 0; j < 16; ++j) reg1[ROWB * (16 * j + lo4) + hi4] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = reg1[ROWB * tid + r]; // LA again
+        if (fast) dit_round<FAST_OK>(v, ta, sl);
+        else dit_round<false>(v, ta, sl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[256 * r + tid] = v[r];
+    }
+}
+
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
     return log2n >= 13 && log2n <= 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           (direction == 0 || direction == 2) && use_fly == 1 && in_order == 0 && out_order == 0; // FWD, or the pair
+           use_fly == 1 && in_order == 0 && out_order == 0; // FWD, INV and the pair
 }
 
 const char *big20_kernel_name() { return "k_big20_p1/p2/p3"; }
@@ -479,6 +567,59 @@ hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *s
     }
     const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream);
     if (e != hipSuccess) return e;
+    switch (log2n) {
+    case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 14: launch_q1<14>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 15: launch_q1<15>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 16: launch_q1<16>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 17: launch_q1<17>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 18: launch_q1<18>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 19: launch_q1<19>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    default: launch_q1<20>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    }
+    return hipGetLastError();
+}
+
+// int_ifftNk for N = 2^13 .. 2^20: the three passes mirrored (k_big20_q3, k_big20_q2, k_big16_q1 / k_big20_q1)
+hipError_t launch_biginv(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+                         const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    RoundCConsts c;
+    for (int k = 0; k < 8; ++k) {
+        const int2 w = h_tw[7 + k];
+        c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int2 w = h_tw[3 + k];
+        c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    const u32 *pin = static_cast<const u32 *>(in);
+    u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
+    static int cus = 0, q2_per_cu = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q2_per_cu, k_big20_q2<true>, 256, 0) != hipSuccess || q2_per_cu <= 0)
+            q2_per_cu = 4;
+    }
+    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
+    if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t cap = (size_t)cus * (size_t)q2_per_cu;
+    const unsigned g2 = (unsigned)(nb < cap ? nb : cap);
+    if (fx) {
+        hipLaunchKernelGGL(k_big20_q3<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        hipLaunchKernelGGL(k_big20_q2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
+    } else {
+        hipLaunchKernelGGL(k_big20_q3<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        hipLaunchKernelGGL(k_big20_q2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
+    }
     switch (log2n) {
     case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;
     case 14: launch_q1<14>(fx, scr, pout, tw16f, nframes, sl, stream); break;

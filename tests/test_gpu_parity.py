@@ -138,6 +138,20 @@ def test_three_pass_pair_n8192_to_n2pow20(log2n, batch):
         check(x, log2n, 16, 13, 0, 0, False, direction="PAIR")
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 3), (15, 130), (16, 5), (17, 3), (17, 9), (18, 5), (19, 3),
+                                         (20, 2)])
+def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
+    """int_ifftNk for N >= 8192: the three passes mirrored (bit-reversed load + DIT 0..3, DIT 4..11 per 4096-point block,
+    DIT 12..L-1 on frame groups)."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 4000 + log2n)
+    x[0] = uniform_frames(1, n, 16, 9)[0]
+    info = check(x, log2n, 16, 16, 0, 0, True, direction="INV")
+    assert info["kernel_name"].startswith("k_big20") and info["n_passes"] == 3
+    if batch <= 9 and log2n < 20:
+        check(x, log2n, 16, 13, 0, 0, False, direction="INV")
+
+
 def test_config4_n_2pow20_taylor_extension():
     """BASELINE config 4 shape at a reduced batch: N = 2^20, 16-bit scaled, Taylor ii = 8 extension."""
     x = uniform_frames(2, 1 << 20, 15, 0xC0FFEE04)
@@ -371,7 +385,7 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
 AB_CASES = [(7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
             (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
             (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
-            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR")]
+            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV")]
 
 
 @pytest.mark.parametrize("case", AB_CASES)
