@@ -509,7 +509,10 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
            use_fly == 1 && in_order == 0 && out_order == 0; // FWD, INV and the pair
 }
 
-const char *big20_kernel_name() { return "k_big20_p1/p2/p3"; }
+const char *big20_kernel_name(int direction)
+{
+    return direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
+}
 
 template <int L>
 static void launch_p1(bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream)

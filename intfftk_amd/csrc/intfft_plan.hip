@@ -501,7 +501,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name() : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));

@@ -11,10 +11,10 @@ for L in (3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20):
     ROWS.append(("%d:16:16:0" % L, "16-bit scaled-trunc FWD"))
 for L in (7, 10, 12):
     ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
-for L in (7, 10, 11, 12, 14):
+for L in (7, 10, 11, 12, 14, 17, 20):
     ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
     ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
-for L in (7, 10, 12):
+for L in (7, 10, 11, 12, 14):
     ROWS.append(("%d:16:16:1" % L, "16-bit unscaled FWD"))
 for L in (7, 10):
     ROWS.append(("%d:16:16:1:0:INV" % L, "16-bit unscaled INV"))
@@ -22,8 +22,13 @@ ROWS.append(("7:16:16:1:0:PAIR", "16-bit unscaled PAIR"))
 ROWS.append(("16:24:24:1", "24-bit unscaled FWD (C3)"))
 ROWS.append(("16:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD"))
 ROWS.append(("10:24:24:1", "24-bit unscaled FWD"))
+ROWS.append(("7:24:24:1", "24-bit unscaled FWD"))
 ROWS.append(("10:12:16:0", "12-bit scaled FWD"))
+ROWS.append(("12:14:16:0:1", "14-bit scaled-round FWD"))
 ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
+ROWS.append(("12:32:24:0", "32-bit scaled FWD"))
+ROWS.append(("10:12:16:0:0:INV", "12-bit scaled INV"))
+ROWS.append(("12:16:16:1:0:INV", "16-bit unscaled INV"))
 
 if __name__ == "__main__":
     print("| N | mode | kernel | passes | Gsample/s | B/sample | GB/s | frac of 8 TB/s | parity prefix |")
