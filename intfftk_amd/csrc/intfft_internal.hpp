@@ -154,6 +154,12 @@ bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, 
 hipError_t launch_fast4096w(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
                             const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *fast4096w_kernel_name();
+// general-width inverse kernels, N = 64..4096 (intfft_w32inv.hip)
+bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                      int out_order);
+hipError_t launch_w32inv(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
+                         const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *w32inv_kernel_name(int log2n);
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

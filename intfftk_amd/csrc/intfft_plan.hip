@@ -40,6 +40,7 @@ struct intfft_plan {
     bool fast1024ux = false;
     bool fastw32 = false;
     bool fast4096w = false;
+    bool w32inv = false;
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
@@ -435,25 +436,31 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                     fast4096w_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_FASTW32");
-    if (pl->fastw32 || pl->fast4096w) {
+    pl->w32inv = !generic_only && !pl->fast1024x && !pl->fast4096 && !pl->fast1024ux &&
+                 w32inv_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
+                                  p->out_order) &&
+                 !getenv("INTFFT_NO_FASTW32");
+    if (pl->fastw32 || pl->fast4096w || pl->w32inv) {
         std::vector<StageDesc> st;
-        if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != p->log2n)
-            pl->fastw32 = pl->fast4096w = false;
-        for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w); ++i) {
+        if (core_stages(*p, p->data_width, p->direction == INTFFT_INV, st) != INTFFT_OK || (int)st.size() != p->log2n)
+            pl->fastw32 = pl->fast4096w = pl->w32inv = false;
+        for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w || pl->w32inv); ++i) {
             const StageDesc &d = st[i];
-            if (d.s < 0 || d.s > 11 || d.dtw > 32 || d.wo > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
-                pl->fastw32 = pl->fast4096w = false;
+            if (d.s < 0 || d.s > 11 || d.dtw > 32 || d.wo > 32 || d.mw > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
+                pl->fastw32 = pl->fast4096w = pl->w32inv = false;
                 break;
             }
-            pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.wo, 32 - d.wo};
+            pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.mw, 32 - d.wo};
             if (d.s >= 2 && d.sh_a != 0) pl->w32args.masked = 1;
         }
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;
         pl->w32args.in_sh = 32 - p->data_width;
-        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = false;
+        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = pl->w32inv = false;
     }
-    if (pl->fast4096w) {
+    if (pl->w32inv) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", w32inv_kernel_name(p->log2n));
+    } else if (pl->fast4096w) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096w_kernel_name());
     } else if (pl->fastw32) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw32_kernel_name());
@@ -556,9 +563,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv;
     info->n_passes = fast ? 1 : (plan->big20 && !plan->wide16) ? 3 : (int)plan->passes.size();
-    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w) ? 4 : fast ? 2 : plan->word;
+    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -572,6 +579,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->w32inv)
+        return (int)launch_w32inv(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
+                                  plan->h_tw.data(), batch, stream);
     if (plan->fast4096w)
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);

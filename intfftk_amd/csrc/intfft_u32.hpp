@@ -247,4 +247,52 @@ __device__ __forceinline__ void gfly_triv(int &are, int &aim, int &bre, int &bim
 }
 
 
+// ---- general-width DIT butterflies (intfft_w32inv.hip): int_dit2_fly.vhd:142-325 ------------------------------------
+// T = B * conj(W) through the re/im-swapped multiplier feed at width DTW (wsh = 32 - DTW), then the sum / difference
+// of (A, T) in the plan's scaling mode (wosh = 32 - output width)
+template <int MODE> __device__ __forceinline__ void gsumdiff(int &are, int &aim, int &bre, int &bim, int tr, int ti, const W32Stage &s)
+{
+    if (MODE == W_UNSCALED) {
+        bre = are - tr, bim = aim - ti;
+        are += tr, aim += ti;
+    } else if (MODE == W_TRUNC) {
+        const int ar = are >> 1, ai = aim >> 1, xr = tr >> 1, xi = ti >> 1;
+        bre = ar - xr, bim = ai - xi;
+        are = ar + xr, aim = ai + xi;
+    } else {
+        const int ar = are >> 1, ai = aim >> 1, xr = tr >> 1, xi = ti >> 1;
+        bre = (int)((u32)(ar - xr + (are & ~tr & 1)) << s.wosh) >> s.wosh;
+        bim = (int)((u32)(ai - xi + (aim & ~ti & 1)) << s.wosh) >> s.wosh;
+        are = (int)((u32)(ar + xr + ((are | tr) & 1)) << s.wosh) >> s.wosh;
+        aim = (int)((u32)(ai + xi + ((aim | ti) & 1)) << s.wosh) >> s.wosh;
+    }
+}
+template <int MODE, bool UNIFORM_W = false, bool MASKED = true>
+__device__ __forceinline__ void gfly_dit(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    unsigned long long xr, xi;
+    if (MASKED) {
+        const unsigned long long m2i = (unsigned long long)((long long)bim * wr), m1i = (unsigned long long)((long long)bre * wi);
+        const unsigned long long m2r = (unsigned long long)((long long)bim * wi), m1r = (unsigned long long)((long long)bre * wr);
+        const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
+        xi = (m2i & k) - (m1i & k); // DO_RE of the swapped feed = T.im
+        xr = (m2r & k) + (m1r & k); // DO_IM = T.re
+    } else {
+        const int nbre = -bre;
+        xi = (unsigned long long)((long long)bim * wr + (long long)nbre * wi);
+        xr = (unsigned long long)((long long)bim * wi + (long long)bre * wr);
+    }
+    const int tr = (int)(__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh) << s.wsh) >> s.wsh;
+    const int ti = (int)(__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh) << s.wsh) >> s.wsh;
+    gsumdiff<MODE>(are, aim, bre, bim, tr, ti, s);
+}
+// STAGE 0 (ODD = false), STAGE 1: even positions T = B, odd positions T = +j B with the negation quirk
+template <int MODE, bool ODD>
+__device__ __forceinline__ void gfly_dit_triv(int &are, int &aim, int &bre, int &bim, const W32Stage &s)
+{
+    const int tr = ODD ? (bim >> 31) - bim : bre, ti = ODD ? bre : bim; // int_dit2_fly.vhd:264-276
+    gsumdiff<MODE>(are, aim, bre, bim, tr, ti, s);
+}
+
 } // namespace intfft

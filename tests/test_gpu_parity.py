@@ -360,6 +360,27 @@ def test_general_width_block_kernel(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_w32"), info
 
 
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("case", [(16, 16, 0, 1), (12, 16, 0, 0), (12, 16, 0, 1), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0),
+                                  (32, 16, 0, 0), (8, 8, 0, 0), (20, 16, 1, 0), (16, 16, 1, 0), (10, 12, 1, 0), (16, 24, 1, 0),
+                                  (26, 26, 0, 0)])
+def test_general_width_inverse_kernels(log2n, case):
+    """int_ifftNk with any widths within 32 bits at 64 <= N <= 4096 (wave kernel up to 1024, block kernel above)."""
+    dw, tw, fmt, rnd = case
+    if dw + fmt * log2n > 32:
+        pytest.skip("results exceed 32 bits")
+    if (dw, tw, fmt, rnd) == (16, 16, 1, 0) and log2n <= 10:
+        pytest.skip("served by the tuned unscaled kernel")
+    n = 1 << log2n
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.INV) != 0:
+            continue
+        fp = 1 << max(0, 10 - log2n)
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 3, n, dw, 70 + dw), uniform_frames(20, n, max(2, dw - 1), 71 + dw)])
+        info = check(x, log2n, dw, tw, fmt, rnd, new, direction="INV")
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_ifft"), info
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
