@@ -28,6 +28,7 @@ template <bool WRAP, bool MASKED, bool UNIFORM_W = false>
 __device__ __forceinline__ void ufly_dit(int &are, int &aim, int &bre, int &bim, int wr, int wi, const UxStage &s)
 {
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    else asm volatile("" : "+v"(wr), "+v"(wi)); // keep the twiddles' sign extension out of loop-invariant hoisting
     unsigned long long xi, xr;
     if (MASKED) {
         const unsigned long long m2i = (unsigned long long)((long long)bim * wr), m1i = (unsigned long long)((long long)bre * wi);

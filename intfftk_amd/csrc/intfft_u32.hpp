@@ -43,6 +43,7 @@ __device__ __forceinline__ void ufly(int &are, int &aim, int &bre, int &bim, int
     // wave-uniform twiddles stay in SGPRs; the empty asm keeps the compiler from hoisting their 64-bit sign
     // extension out of the frame loop (which turns every product into a 3-instruction 64 x 32 multiply)
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    else asm volatile("" : "+v"(wr), "+v"(wi)); // per-lane twiddles: same hazard (seen in the DIT kernels)
     const int dre = are - bre, dim = aim - bim, ndim = bim - aim;
     are += bre;
     aim += bim;
@@ -189,6 +190,7 @@ template <int MODE, bool UNIFORM_W = false, bool MASKED = true>
 __device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
 {
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
+    else asm volatile("" : "+v"(wr), "+v"(wi));            // same for per-lane twiddles (see gfly_dit)
     int dre, dim;
     if (MODE == W_UNSCALED) {
         dre = are - bre, dim = aim - bim;
@@ -270,7 +272,10 @@ template <int MODE> __device__ __forceinline__ void gsumdiff(int &are, int &aim,
 template <int MODE, bool UNIFORM_W = false, bool MASKED = true>
 __device__ __forceinline__ void gfly_dit(int &are, int &aim, int &bre, int &bim, int wr, int wi, const W32Stage &s)
 {
+    // keep hipcc from hoisting the 64-bit sign extension of the (frame-invariant) twiddles out of the frame loop, which
+    // turns each v_mad_i64_i32 into a four-instruction 64 x 32 multiply (seen on the per-lane twiddles of the DIT path)
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    else asm volatile("" : "+v"(wr), "+v"(wi));
     unsigned long long xr, xi;
     if (MASKED) {
         const unsigned long long m2i = (unsigned long long)((long long)bim * wr), m1i = (unsigned long long)((long long)bre * wi);

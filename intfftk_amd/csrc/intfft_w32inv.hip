@@ -106,22 +106,36 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
         // ---- load X[brev_L(n)] into LC ----
         if constexpr (L < 10) {
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
+            // (the container test stays outside the unrolled loops: one batch of loads in flight, not 16 round trips)
+            if (a.in16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                v2u x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const size_t off = f * 1024 + lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) +
-                                   (q >> 2) * out_weight<L>(2);
-                if (a.in16) {
-                    typedef u32 v2u __attribute__((ext_vector_type(2)));
-                    v2u x = {0u, 0u};
-                    if (ok) x = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + off));
-                    re[q] = (int)(x.x << a.in_sh) >> a.in_sh, im[q] = (int)(x.x << (a.in_sh - 16)) >> a.in_sh;
-                    re[q + 8] = (int)(x.y << a.in_sh) >> a.in_sh, im[q + 8] = (int)(x.y << (a.in_sh - 16)) >> a.in_sh;
-                } else {
-                    typedef int v4i __attribute__((ext_vector_type(4)));
-                    v4i x = {0, 0, 0, 0};
-                    if (ok) x = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + off));
-                    re[q] = (int)((u32)x.x << a.in_sh) >> a.in_sh, im[q] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
-                    re[q + 8] = (int)((u32)x.z << a.in_sh) >> a.in_sh, im[q + 8] = (int)((u32)x.w << a.in_sh) >> a.in_sh;
+                for (int q = 0; q < 8; ++q) {
+                    const size_t off = f * 1024 + lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) +
+                                       (q >> 2) * out_weight<L>(2);
+                    x[q] = v2u{0u, 0u};
+                    if (ok) x[q] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + off));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    re[q] = (int)(x[q].x << a.in_sh) >> a.in_sh, im[q] = (int)(x[q].x << (a.in_sh - 16)) >> a.in_sh;
+                    re[q + 8] = (int)(x[q].y << a.in_sh) >> a.in_sh, im[q + 8] = (int)(x[q].y << (a.in_sh - 16)) >> a.in_sh;
+                }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const size_t off = f * 1024 + lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) +
+                                       (q >> 2) * out_weight<L>(2);
+                    x[q] = v4i{0, 0, 0, 0};
+                    if (ok) x[q] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + off));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    re[q] = (int)((u32)x[q].x << a.in_sh) >> a.in_sh, im[q] = (int)((u32)x[q].y << a.in_sh) >> a.in_sh;
+                    re[q + 8] = (int)((u32)x[q].z << a.in_sh) >> a.in_sh, im[q + 8] = (int)((u32)x[q].w << a.in_sh) >> a.in_sh;
                 }
             }
 #pragma unroll
@@ -130,17 +144,23 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
                 uswap32(im[r], im[r + 8]);
             }
         } else {
+            if (a.in16) {
+                const u32 *src = static_cast<const u32 *>(in) + f * 1024 + lane;
+                u32 raw[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t off = f * 1024 + 64 * rev4x(r) + lane;
-                if (a.in16) {
-                    const u32 raw = __builtin_nontemporal_load(static_cast<const u32 *>(in) + off);
-                    re[r] = (int)(raw << a.in_sh) >> a.in_sh, im[r] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
-                } else {
-                    typedef int v2i __attribute__((ext_vector_type(2)));
-                    const v2i x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off));
-                    re[r] = (int)((u32)x.x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
-                }
+                for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + 64 * rev4x(r));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
+            } else {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + f * 1024 + lane);
+                v2i x[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + 64 * rev4x(r));
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
             }
         }
         ground_c_dit<MODE, MASKED>(re, im, c, a);
@@ -203,17 +223,21 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
             for (int j = 0; j < 8; ++j) gfly_dit<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], a.st[9]);
         }
         // ---- store (L1 layout: natural order, coalesced) ----
+        if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + f * 1024 + lane;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (partial && f * FP + (size_t)((64 * j + lane) >> L) >= nframes_user) continue;
-            const size_t off = f * 1024 + 64 * j + lane;
-            if (a.out16) {
-                __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), static_cast<u32 *>(out) + off);
-            } else {
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                const v2i y = {re[j], im[j]};
-                __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(static_cast<int2 *>(out) + off));
-            }
+            for (int j = 0; j < 16; ++j)
+                if (!partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user)
+                    __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), dst + 64 * j);
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + f * 1024 + lane);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user) {
+                    const v2i y = {re[j], im[j]};
+                    __builtin_nontemporal_store(y, dst + 64 * j);
+                }
         }
     }
 }
@@ -243,7 +267,7 @@ __device__ __forceinline__ void ground_dit(int (&re)[16], int (&im)[16], const i
 }
 
 template <int L, int MODE, bool MASKED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L == 12 ? 2 : 3, L == 12 ? 2 : 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
                     size_t nframes_user)
 {
@@ -303,18 +327,27 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
         const bool partial = L < 12 && (f + 1) * FP > nframes_user;
         const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
         int re[16], im[16];
+        // LC: X[brev_L(n)] of the thread's frame (container test outside the unrolled loops)
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + f * 4096 + lc_off;
+            u32 raw[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { // LC: X[brev_L(n)] of the thread's frame
-            const size_t off = f * 4096 + (rev4x(r) << (L - 4)) + lc_off;
-            if (a.in16) {
-                const u32 raw = lc_ok ? __builtin_nontemporal_load(static_cast<const u32 *>(in) + off) : 0u;
-                re[r] = (int)(raw << a.in_sh) >> a.in_sh, im[r] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
-            } else {
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                v2i x = {0, 0};
-                if (lc_ok) x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off));
-                re[r] = (int)((u32)x.x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+            for (int r = 0; r < 16; ++r) raw[r] = lc_ok ? __builtin_nontemporal_load(src + (rev4x(r) << (L - 4))) : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + f * 4096 + lc_off);
+            v2i x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                x[r] = v2i{0, 0};
+                if (lc_ok) x[r] = __builtin_nontemporal_load(src + (rev4x(r) << (L - 4)));
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
         }
         ground_c_dit<MODE, MASKED>(re, im, c, a);
 #pragma unroll
@@ -331,17 +364,21 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
         }
         transpose_read(re, im); // LA: regs = n11..8, thread = n7..0
         ground_dit<MODE, MASKED, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
+        if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + f * 4096 + tid;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (partial && f * FP + (size_t)((256 * j + tid) >> L) >= nframes_user) continue;
-            const size_t off = f * 4096 + 256 * j + tid;
-            if (a.out16) {
-                __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), static_cast<u32 *>(out) + off);
-            } else {
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                const v2i y = {re[j], im[j]};
-                __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(static_cast<int2 *>(out) + off));
-            }
+            for (int j = 0; j < 16; ++j)
+                if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)
+                    __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), dst + 256 * j);
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + f * 4096 + tid);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user) {
+                    const v2i y = {re[j], im[j]};
+                    __builtin_nontemporal_store(y, dst + 256 * j);
+                }
         }
     }
 }

@@ -46,6 +46,7 @@ __device__ __forceinline__ constexpr int rev4w(int r) { return ((r & 1) << 3) | 
 template <bool AZ>
 __device__ __forceinline__ void wfly32(int &are, int &aim, int &bre, int &bim, int wr, int wi, const WideStage &s)
 {
+    asm volatile("" : "+v"(wr), "+v"(wi)); // keep the twiddles' 64-bit sign extension from being hoisted (intfft_u32.hpp)
     const int dre = are - bre, dim = aim - bim; // unscaled: exact, one bit of growth (int_dif2_fly.vhd:222-240)
     are += bre;
     aim += bim;
@@ -195,6 +196,7 @@ template <bool AZ, bool UNIFORM_W>
 __device__ __forceinline__ void wfly64(i64 &are, i64 &aim, i64 &bre, i64 &bim, int wr, int wi, const WideStage &s)
 {
     if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi)); // see intfft_fast1024u.hip
+    else asm volatile("" : "+v"(wr), "+v"(wi));
     const i64 dre = are - bre, dim = aim - bim;
     are += bre;
     aim += bim;
