@@ -48,7 +48,7 @@ __device__ __forceinline__ void ground(int (&re)[16], int (&im)[16], const int (
 }
 
 template <int L, int MODE, bool MASKED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
                    size_t nframes_user)
 {

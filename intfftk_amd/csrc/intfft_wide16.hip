@@ -85,7 +85,7 @@ __device__ __forceinline__ void wstage32(int (&re)[16], int (&im)[16], const int
     wstage32x<H, false>(re, im, wr, wi, s); // the masked form covers a = 0 too (keep = ~0)
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
                                                    const WideArgs a, size_t nframes)
 {
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
