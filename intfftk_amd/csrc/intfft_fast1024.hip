@@ -1,6 +1,8 @@
 // intfft_fast1024.hip -- packed-int16 wave kernel for the headline configuration:
 // int_fftNk with NFFT = 10 (N = 1024), DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled (FORMAT = 0),
-// natural-order input, NATURAL or BITREV output  (src/vhdl/main/int_fft_single_path.vhd:157-268).
+// natural-order input, NATURAL or BITREV output  (src/vhdl/main/int_fft_single_path.vhd:157-268),
+// and, as template instances L = 6..9, for 64 <= N < 1024 in natural order (2^(10-L) frames per wave; see lane_bit<L>()
+// in intfft_internal.hpp; the reference testbench ships NFFT = 7).  The description below is for N = 1024.
 //
 // One wave64 owns one frame: 16 VGPRs of packed (re | im << 16) int16 per lane, persistent loop
 // over frames, no barrier.  The ten radix-2 DIF stages (src/vhdl/fft/int_dif2_fly.vhd:144-373) are

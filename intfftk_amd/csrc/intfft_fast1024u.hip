@@ -1,7 +1,10 @@
-// intfft_fast1024u.hip -- UNSCALED (full bit growth) wave kernel for N = 1024:
-// int_fftNk with NFFT = 10, DATA_WIDTH = 16, TWDL_WIDTH <= 16, FORMAT = 1, natural in -> natural out
-// (the reference testbench's primary mode: fft_signle_test.vhd:93-112 "UNSCALED").  16-bit samples in
-// int16 containers, 26-bit results in int32 containers (12 B per complex sample of HBM traffic).
+// intfft_fast1024u.hip -- UNSCALED (full bit growth) wave kernel for N = 64 .. 1024 (template parameter L = log2 N):
+// int_fftNk with NFFT = 6..10, DATA_WIDTH = 16, TWDL_WIDTH <= 16, FORMAT = 1, natural in -> natural out
+// (the reference testbench's primary mode: fft_signle_test.vhd:93-112 "UNSCALED", shipped with NFFT = 7).
+// 16-bit samples in int16 containers, (16 + L)-bit results in int32 containers (12 B per complex sample of HBM
+// traffic).  The description below is for N = 1024; shorter frames share a wave (2^(10-L) frames per 1024-sample
+// chunk, the stages of the frame-number bits skipped) as in intfft_fast1024.hip, with the store mapping of
+// lane_bit_u<L>() (intfft_u32.hpp).
 //
 // Same wave-per-frame choreography as intfft_fast1024.hip (stages 9..6 in registers, two lane swaps for
 // stages 5 and 4, one wave-private LDS transpose, stages 3..0 in registers, bit reversal folded into the
