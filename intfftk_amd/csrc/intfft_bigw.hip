@@ -1,0 +1,285 @@
+// intfft_bigw.hip -- general-width three-pass kernels for N = 2^13 .. 2^16: int_fftNk with any DATA_WIDTH / TWDL_WIDTH /
+// FORMAT / RNDMODE whose widths stay within 32 bits (e.g. the unscaled 16-bit transform up to N = 65536: 32-bit
+// results), natural order in and out.  The pass structure of intfft_big20.hip on unpacked int32 registers with the
+// parameterised butterflies of intfft_u32.hpp; the plan scratch holds int32 (re, im) pairs at the core index:
+//   pass 1  STAGE L-1..12  groups of 2^(16-L) frames form a virtual 2^16-point frame (frame-number stages skipped);
+//                          regs = n15..12 at stride 4096, thread = 512 consecutive n (4 KiB runs), no LDS
+//   pass 2  STAGE 11..4    every 4096-point block in place: LA (regs n11..8) -> LDS -> LB (regs n7..4) -> LDS -> LA
+//   pass 3  STAGE 3..0     tile = 256 values of n(L-1)..n(L-8) x 32 consecutive n, LDS transpose to regs n3..0 with
+//                          thread = (n4, rev8(top 8 bits)): natural-order stores in 1-2 KiB runs
+// (DATA_WIDTH = 16 scaled-truncate with TWDL_WIDTH <= 16 has the packed kernels of intfft_big20.hip.)
+#include "intfft_u32.hpp"
+
+namespace intfft {
+
+constexpr int ROWG = 17;              // LDS row stride in dwords (odd: conflict-free rows and columns)
+constexpr int PLANEG2 = 256 * ROWG;   // pass 2: 256 threads
+constexpr int PLANEG3 = 512 * ROWG;   // pass 3: 512 threads
+__device__ __forceinline__ constexpr int rev4g(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// four DIF stages s0+3 .. s0 on register offsets 8, 4, 2, 1; only the last NS of them
+template <int MODE, bool MASKED, int NS, int S0>
+__device__ __forceinline__ void gstages(int (&re)[16], int (&im)[16], const int (&w8r)[8], const int (&w8i)[8],
+                                        const int (&w4r)[4], const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2],
+                                        int w1r, int w1i, const W32Args &a)
+{
+    if constexpr (NS >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gfly<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j], a.st[S0 + 3]);
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j], a.st[S0 + 2]);
+    }
+    if constexpr (NS >= 2) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 4)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j], a.st[S0 + 1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly<MODE, false, MASKED>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
+}
+
+// ---- pass 1 ----------------------------------------------------------------------------------------------------
+template <int L, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_p1(const void *in, int2 *scr, const int2 *__restrict__ twt, const W32Args a,
+                                                 size_t nframes_user, unsigned groups)
+{
+    static_assert(L >= 13 && L <= 16, "one-round pass 1");
+    constexpr int NS = L - 12, G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G; // virtual 2^16-point frames
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..7
+    const unsigned lfull = chunk * 512 + threadIdx.x;                        // n11..0
+    int w8r[8] = {}, w8i[8] = {}, w4r[4] = {}, w4i[4] = {}, w2r[2] = {}, w2i[2] = {}, w1r, w1i;
+    {
+        int2 w;
+        if constexpr (NS >= 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w = twt[(1u << 15) - 1u + lfull + (unsigned)j * 4096u], w8r[j] = w.x, w8i[j] = w.y;
+        }
+        if constexpr (NS >= 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w = twt[(1u << 14) - 1u + lfull + (unsigned)j * 4096u], w4r[j] = w.x, w4i[j] = w.y;
+        }
+        if constexpr (NS >= 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w = twt[(1u << 13) - 1u + lfull + (unsigned)j * 4096u], w2r[j] = w.x, w2i[j] = w.y;
+        }
+        w = twt[(1u << 12) - 1u + lfull], w1r = w.x, w1i = w.y;
+    }
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
+        int re[16], im[16];
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + frame * 65536 + lfull;
+            u32 raw[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                raw[j] = (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) ? __builtin_nontemporal_load(src + ((size_t)j << 12)) : 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                re[j] = (int)(raw[j] << a.in_sh) >> a.in_sh, im[j] = (int)(raw[j] << (a.in_sh - 16)) >> a.in_sh;
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + frame * 65536 + lfull);
+            v2i x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                x[j] = v2i{0, 0};
+                if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) x[j] = __builtin_nontemporal_load(src + ((size_t)j << 12));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                re[j] = (int)((u32)x[j].x << a.in_sh) >> a.in_sh, im[j] = (int)((u32)x[j].y << a.in_sh) >> a.in_sh;
+        }
+        gstages<MODE, MASKED, NS, 12>(re, im, w8r, w8i, w4r, w4i, w2r, w2i, w1r, w1i, a);
+        int2 *dst = scr + frame * 65536 + lfull;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) dst[(size_t)j << 12] = make_int2(re[j], im[j]);
+    }
+}
+
+// ---- pass 2 ----------------------------------------------------------------------------------------------------
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(256) void k_bigw_p2(int2 *scr, const int2 *__restrict__ twt, const W32Args a, size_t nblocks4k)
+{
+    __shared__ u32 lds[2 * PLANEG2];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    int a8r[8], a8i[8], a4r[4], a4i[4], a2r[2], a2i[2], a1r, a1i;
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+    {
+        int2 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[2047 + 256 * j + tid], a8r[j] = w.x, a8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[1023 + 256 * j + tid], a4r[j] = w.x, a4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[511 + 256 * j + tid], a2r[j] = w.x, a2i[j] = w.y;
+        w = twt[255 + tid], a1r = w.x, a1i = w.y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], b2r[j] = w.x, b2i[j] = w.y;
+        w = twt[15 + lo4], b1r = w.x, b1i = w.y;
+    }
+    // LA <-> LB (both directions): element (thread x, reg y) -> row 16 y + x3..0, column x7..4; thread t reads row t
+    u32 *const wr = lds + ROWG * lo4 + hi4;
+    const u32 *const rd = lds + ROWG * tid;
+    auto transpose = [&](int (&re)[16], int (&im)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            wr[ROWG * 16 * j] = (u32)re[j];
+            wr[PLANEG2 + ROWG * 16 * j] = (u32)im[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)rd[r], im[r] = (int)rd[PLANEG2 + r];
+        __syncthreads();
+    };
+    for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
+        int2 *p = scr + b * 4096;
+        int re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int2 x = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
+            re[j] = x.x, im[j] = x.y;
+        }
+        gstages<MODE, MASKED, 4, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
+        transpose(re, im); // LB: regs = n7..4, thread = (n11..8, n3..0)
+        gstages<MODE, MASKED, 4, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+        transpose(re, im); // LA again: coalesced store
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[256 * r + tid] = make_int2(re[r], im[r]);
+    }
+}
+
+// ---- pass 3 ----------------------------------------------------------------------------------------------------
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, const UConsts c, const W32Args a, size_t nframes, int L)
+{
+    __shared__ u32 lds[PLANEG3]; // one 34 KiB plane, used for re then im (two planes would exceed 64 KiB)
+    const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n(L-5)..n(L-8)
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5
+    const int2 *src = scr + (frame << L) + mid * 32 + e;
+    int re[16], im[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int2 x = src[(size_t)(16 * j + px) << (L - 8)]; // reg j = n(L-1)..n(L-4)
+        re[j] = x.x, im[j] = x.y;
+    }
+    // transpose -> regs = n3..0, thread = (n4, rev8(top 8 bits)); rev8(16 j + px) = 16 rev4(px) + rev4(j)
+    {
+        u32 *w = lds + ROWG * ((e >> 4) * 256 + 16 * rev4g(px)) + (e & 15);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWG * rev4g(j)] = (u32)re[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)lds[ROWG * tid + r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWG * rev4g(j)] = (u32)im[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) im[r] = (int)lds[ROWG * tid + r];
+    }
+    // stages 3, 2 (uniform twiddles), 1, 0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+        gfly_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+    // natural order: X index = brev_L(n) = rev4(r) << (L-4) | n4 << (L-5) | brev(mid) << 8 | rev8(top 8 bits)
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const size_t off = (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);
+    if (a.out16) {
+        u32 *dst = static_cast<u32 *>(out) + off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), dst + ((size_t)rev4g(r) << (L - 4)));
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const v2i y = {re[r], im[r]};
+            __builtin_nontemporal_store(y, dst + ((size_t)rev4g(r) << (L - 4)));
+        }
+    }
+}
+
+bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                    int out_order)
+{
+    return log2n >= 13 && log2n <= 16 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
+           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+}
+
+const char *bigw_kernel_name() { return "k_bigw_p1/p2/p3"; }
+
+template <int MODE, bool MASKED>
+static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, void *out, int2 *scr, const int2 *tw, const UConsts &c,
+                                size_t nframes, hipStream_t stream)
+{
+    static int cus = 0, p2_per_cu = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2_per_cu, k_bigw_p2<MODE, MASKED>, 256, 0) != hipSuccess || p2_per_cu <= 0)
+            p2_per_cu = 2;
+    }
+    const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+    const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
+    switch (log2n) {
+    case 13: hipLaunchKernelGGL((k_bigw_p1<13, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
+    case 14: hipLaunchKernelGGL((k_bigw_p1<14, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
+    case 15: hipLaunchKernelGGL((k_bigw_p1<15, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
+    default: hipLaunchKernelGGL((k_bigw_p1<16, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
+    }
+    const size_t nb = nframes << (log2n - 12), cap = (size_t)cus * (size_t)p2_per_cu, nb3 = nframes << (log2n - 13);
+    if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_bigw_p2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
+    hipLaunchKernelGGL((k_bigw_p3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, scr, out, c, a, nframes, log2n);
+    return hipGetLastError();
+}
+
+hipError_t launch_bigw(int log2n, int mode, const W32Args &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+                       const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    UConsts c;
+    for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
+    for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
+    int2 *scr = static_cast<int2 *>(scratch);
+    if (a.masked) {
+        switch (mode) {
+        case W_TRUNC: return launch_bigw_m<W_TRUNC, true>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+        case W_ROUND: return launch_bigw_m<W_ROUND, true>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+        default: return launch_bigw_m<W_UNSCALED, true>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+        }
+    }
+    switch (mode) {
+    case W_TRUNC: return launch_bigw_m<W_TRUNC, false>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+    case W_ROUND: return launch_bigw_m<W_ROUND, false>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+    default: return launch_bigw_m<W_UNSCALED, false>(log2n, a, in, out, scr, tw_all, c, nframes, stream);
+    }
+}
+
+} // namespace intfft

@@ -138,7 +138,7 @@ struct W32Stage {
     int wosh;      // 32 - output width (round-mode sum / difference wrap)
 };
 struct W32Args {
-    W32Stage st[12]; // by STAGE number
+    W32Stage st[16]; // by STAGE number
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
@@ -160,6 +160,12 @@ bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int
 hipError_t launch_w32inv(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
                          const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *w32inv_kernel_name(int log2n);
+// general-width three-pass kernels, N = 2^13 .. 2^16 (intfft_bigw.hip)
+bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
+                    int out_order);
+hipError_t launch_bigw(int log2n, int mode, const W32Args &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+                       const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *bigw_kernel_name();
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

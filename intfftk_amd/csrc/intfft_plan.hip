@@ -41,6 +41,7 @@ struct intfft_plan {
     bool fastw32 = false;
     bool fast4096w = false;
     bool w32inv = false;
+    bool bigw = false;
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
@@ -440,14 +441,20 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                  w32inv_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                   p->out_order) &&
                  !getenv("INTFFT_NO_FASTW32");
-    if (pl->fastw32 || pl->fast4096w || pl->w32inv) {
+    pl->bigw = !generic_only &&
+               !big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly,
+                                p->in_order, p->out_order) && // the packed three-pass kernels are faster where they apply
+               bigw_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
+                              p->out_order) &&
+               !getenv("INTFFT_NO_FASTW32");
+    if (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw) {
         std::vector<StageDesc> st;
         if (core_stages(*p, p->data_width, p->direction == INTFFT_INV, st) != INTFFT_OK || (int)st.size() != p->log2n)
-            pl->fastw32 = pl->fast4096w = pl->w32inv = false;
-        for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w || pl->w32inv); ++i) {
+            pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
+        for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw); ++i) {
             const StageDesc &d = st[i];
-            if (d.s < 0 || d.s > 11 || d.dtw > 32 || d.wo > 32 || d.mw > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
-                pl->fastw32 = pl->fast4096w = pl->w32inv = false;
+            if (d.s < 0 || d.s > 15 || d.dtw > 32 || d.wo > 32 || d.mw > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
+                pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
                 break;
             }
             pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.mw, 32 - d.wo};
@@ -456,7 +463,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;
         pl->w32args.in_sh = 32 - p->data_width;
-        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = pl->w32inv = false;
+        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
     }
     if (pl->w32inv) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", w32inv_kernel_name(p->log2n));
@@ -508,7 +515,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name() : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -520,8 +527,9 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                 return (int)e;
             }
         }
-        if (pl->passes.size() > 1 || pl->big20) {
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->word == 2 ? 2 : pl->passes[0].word);
+        if (pl->passes.size() > 1 || pl->big20 || pl->bigw) {
+            // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : pl->word == 2 ? 2 : pl->passes[0].word);
             size_t scratch_mb = pl->big20 ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
             if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
@@ -564,7 +572,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv;
-    info->n_passes = fast ? 1 : (plan->big20 && !plan->wide16) ? 3 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
@@ -606,11 +614,17 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
     const size_t np = plan->passes.size();
-    const size_t chunk = (np > 1 || plan->big20) ? plan->scratch_frames : batch;
+    const size_t chunk = (np > 1 || plan->big20 || plan->bigw) ? plan->scratch_frames : batch;
     for (size_t f = 0; f < batch; f += chunk) {
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
+        if (plan->bigw && (np > 1 || (nf << plan->L) >= ((size_t)1 << 21))) {
+            const hipError_t e = launch_bigw(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, src, dst,
+                                             plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
         if (plan->wide16) {
             const hipError_t e = launch_wide16(plan->wargs, src, dst, plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf,
                                                stream);

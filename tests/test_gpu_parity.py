@@ -152,6 +152,21 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
         check(x, log2n, 16, 13, 0, 0, False, direction="INV")
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 259), (13, 1030), (14, 131), (15, 3), (15, 70), (16, 5), (16, 33)])
+@pytest.mark.parametrize("case", [(16, 16, 1, 0), (16, 16, 0, 1), (12, 16, 0, 0), (18, 24, 0, 0), (10, 18, 1, 0), (32, 16, 0, 0)])
+def test_general_width_three_pass_kernels(log2n, batch, case):
+    """N = 2^13 .. 2^16 with widths within 32 bits (the unscaled 16-bit transform reaches exactly 32 bits at N = 65536):
+    three passes on int32 pairs, frame groups as virtual 2^16-point frames in pass 1."""
+    dw, tw, fmt, rnd = case
+    if dw + fmt * log2n > 32:
+        pytest.skip("results exceed 32 bits")
+    n = 1 << log2n
+    x = uniform_frames(batch, n, dw, 6000 + log2n + dw)
+    x[0] = edge_frames(n, dw)[4]
+    info = check(x, log2n, dw, tw, fmt, rnd, True)
+    assert info["kernel_name"].startswith("k_bigw") and info["n_passes"] == 3, info
+
+
 def test_config4_n_2pow20_taylor_extension():
     """BASELINE config 4 shape at a reduced batch: N = 2^20, 16-bit scaled, Taylor ii = 8 extension."""
     x = uniform_frames(2, 1 << 20, 15, 0xC0FFEE04)
@@ -406,7 +421,7 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
 AB_CASES = [(7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
             (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
             (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
-            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV")]
+            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD")]
 
 
 @pytest.mark.parametrize("case", AB_CASES)
