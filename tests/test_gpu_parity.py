@@ -547,3 +547,55 @@ def test_hip_graph_capture_and_replay():
         want = core(x).clone()
         assert torch.equal(y, want)
         core.close()
+
+
+def _fuzz_cases(count, seed):
+    """Deterministic pseudo-random generics that the reference can elaborate (orc_validate)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        log2n = int(rng.integers(3, 15))
+        fmt = int(rng.integers(0, 2))
+        rnd = 0 if fmt else int(rng.integers(0, 2))
+        dw = int(rng.integers(4, 33))
+        tw = int(rng.integers(8, 27))
+        new = bool(rng.integers(0, 2))
+        d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), DIR[d]) != 0:
+            continue
+        out.append((log2n, dw, tw, fmt, rnd, new, d))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(160, 20260928))
+def test_fuzz_generics_three_way(case, monkeypatch):
+    """Random elaboratable generics: whatever kernel the planner picks, the generic LDS pass kernels and the oracle
+    agree bit for bit (ragged batch sizes, full-range data)."""
+    log2n, dw, tw, fmt, rnd, new, d = case
+    n = 1 << log2n
+    batch = int(3 + (log2n * 7 + dw) % 11)
+    x = uniform_frames(batch, n, dw, 9000 + log2n * 100 + dw)
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+    want = run_ref(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+    assert np.array_equal(got, want), (case, info["kernel_name"])
+    if not info["kernel_name"].startswith("k_pass"):
+        monkeypatch.setenv("INTFFT_GENERIC_ONLY", "1")
+        gen, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+        assert np.array_equal(gen, want), (case, "generic")
+
+
+def _fuzz_order_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    names = list(ORD)
+    out = []
+    for c in _fuzz_cases(count, seed + 1):
+        out.append(c + (names[int(rng.integers(0, 4))], names[int(rng.integers(0, 4))]))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_order_cases(60, 777))
+def test_fuzz_generics_with_orders(case):
+    """Random generics x random I/O orders (HALVES / BITREV / BITREV_LANES / NATURAL on either side)."""
+    log2n, dw, tw, fmt, rnd, new, d, in_o, out_o = case
+    x = uniform_frames(4, 1 << log2n, dw, 12000 + log2n * 10 + dw)
+    check(x, log2n, dw, tw, fmt, rnd, new, direction=d, in_order=in_o, out_order=out_o)
