@@ -72,10 +72,10 @@ constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B al
 template <int L, bool ROUND, bool OUT_BITREV, bool FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok)
+                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
 {
     static_assert(L >= 6 && L <= 10, "wave kernel: 64 <= N <= 1024");
-    static_assert(L == 10 || !OUT_BITREV, "BITREV output only for N = 1024");
+    static_assert(L >= 7 || !OUT_BITREV, "native orders need N >= 128");
     // P (truncate mode): multiplier outputs are emitted pre-shifted (Y >> 1); after a stage with
     // register offset h the registers with (j & h) != 0 hold Y >> 1, the others hold S.
     constexpr bool P = !ROUND;
@@ -212,6 +212,9 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
         v4u *dst = reinterpret_cast<v4u *>(out + f * 1024) + (((lane & 15) << 2) | (lane >> 4));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            // short frames: the vector's frame within the chunk = bits a9..aL of (q, lane & 15); st_ok = "chunk is full"
+            if (L < 10 && !st_ok && f * (size_t)(1 << (10 - L)) + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) >= nframes_user)
+                continue;
             const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             __builtin_nontemporal_store(x, dst + 64 * q);
         }
@@ -327,29 +330,39 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     }
 
     auto run = [&](u32(&v)[16], size_t f) {
-        const bool st_ok = L == 10 || f * FP + (size_t)lane_frame < nframes_user; // partial last chunk
+        // partial last chunk: natural order -> per-lane predicate; BITREV order -> "chunk is full" + the frame count
+        const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
         if (FAST_OK && frame_has_guard_bit(v))
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
         else
-            transform_store<L, ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok);
+            transform_store<L, ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
-        if (L < 10 && (f + 1) * FP > nframes_user) { // partial last chunk: samples of absent frames read as 0
+        const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0
+        if (in_halves) {
+            // HALVES: beat i of a frame holds (x[i], x[i + N/2]).  Beat q = 64 jj + lane of the chunk belongs to frame
+            // q >> (L-1); its two samples are chunk positions a and a + N/2, i.e. lane `lane` of the registers
+            // j0 = (frame << (L-6)) | (i >> 6) and j0 | 2^(L-7)   (N = 1024: (jj, jj + 8))
+            if constexpr (L >= 7) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u *src2 = reinterpret_cast<const v2u *>(in + f * 1024) + lane;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    constexpr int HB = 1 << (L - 7);
+                    const int j0 = ((jj >> (L - 7)) << (L - 6)) | (jj & (HB - 1));
+                    v2u w = {0u, 0u};
+                    if (!partial || f * FP + (size_t)(jj >> (L - 7)) < nframes_user) w = __builtin_nontemporal_load(src2 + 64 * jj);
+                    v[j0] = w.x;
+                    v[j0 | HB] = w.y;
+                }
+            }
+            return;
+        }
+        if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const size_t fr = f * FP + (size_t)((64 * j + lane) >> L);
                 v[j] = fr < nframes_user ? in[f * 1024 + 64 * j + lane] : 0u;
-            }
-            return;
-        }
-        if (in_halves) { // HALVES: beat i holds (x[i], x[i + 512]) = (v[j], v[j + 8]) for i = 64 j + lane
-            typedef u32 v2u __attribute__((ext_vector_type(2)));
-            const v2u *src2 = reinterpret_cast<const v2u *>(in + f * 1024) + lane;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const v2u w = __builtin_nontemporal_load(src2 + 64 * j);
-                v[j] = w.x;
-                v[j + 8] = w.y;
             }
             return;
         }
@@ -389,8 +402,9 @@ bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, i
     (void)rndmode;
     if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && direction == 0 && use_fly == 1))
         return false;
-    if (log2n == 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
-    return log2n >= 6 && log2n < 10 && in_order == 0 && out_order == 0; // 64 <= N < 1024: natural order only
+    // N >= 128: NATURAL or HALVES (native int_fftNk beats) in, NATURAL or BITREV (native) out; N = 64: natural only
+    if (log2n >= 7 && log2n <= 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
+    return log2n == 6 && in_order == 0 && out_order == 0;
 }
 
 const char *fast1024_kernel_name() { return "k_fft1024_i16"; }
@@ -449,11 +463,16 @@ static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast10
 }
 
 template <int L>
-static hipError_t launch_short(bool round, const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c,
-                               size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
+static hipError_t launch_short(bool round, bool out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
+                               const Fast1024Consts &c, size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
 {
-    return round ? launch_t<L, true, false>(in, out, tw, c, nframes, sl, false, 0, stream)
-                 : launch_t<L, false, false>(in, out, tw, c, nframes, sl, fast_ok, 0, stream);
+    if constexpr (L >= 7) {
+        if (out_bitrev)
+            return round ? launch_t<L, true, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                         : launch_t<L, false, true>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
+    }
+    return round ? launch_t<L, true, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                 : launch_t<L, false, false>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
@@ -477,10 +496,10 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
     u32 *pout = static_cast<u32 *>(out);
     const bool round = a.rnd == RND_ROUND;
     switch (a.log2n) {
-    case 6: return launch_short<6>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
-    case 7: return launch_short<7>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
-    case 8: return launch_short<8>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
-    case 9: return launch_short<9>(round, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 6: return launch_short<6>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 7: return launch_short<7>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 8: return launch_short<8>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
+    case 9: return launch_short<9>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
     default: break;
     }
     if (round)

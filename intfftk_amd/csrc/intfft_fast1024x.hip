@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     u32 *wr_i = in_bitrev ? lds + ROWX * (32 * l5 + 16 * l4) + ((l1 << 3) | (l0 << 2) | (l3 << 1) | l2)
                           : lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
     int lane_off = 0, lane_frame = 0; // short-frame inverse: see intfft_fast1024.hip
-    if constexpr (L < 10 && MODE == X_INV) {
+    if (L < 10 && MODE == X_INV && !in_bitrev) {
         auto a = [&](int k) { return (lane >> lane_bit<L>(k)) & 1; }; // LC lane bit lane_bit<L>(k) = a_k
         wr_i = lds + ROWX * (32 * a(9) + 16 * a(8)) + ((a(5) << 3) | (a(4) << 2) | (a(7) << 1) | a(6));
         // while loading (before the swaps) lane bit 5 = a3 and lane bit 4 = a2
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         u32 v[16];
         const u32 *src = in + f * 1024;
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0, not stored
-        if (L < 10 && MODE == X_INV) {
+        if (L < 10 && MODE == X_INV && !in_bitrev) {
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
 #pragma unroll
@@ -118,17 +118,15 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
-        } else if (partial) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j + lane] : 0u;
         } else if (MODE == X_INV && in_bitrev) {
             // memory index = n: x4 loads give (regs n9 n8 n1 n0, lane n3 n2 n7..4); two lane swaps -> (regs n3..0, lane n9..4)
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const v4u *s4 = reinterpret_cast<const v4u *>(src) + (((lane & 15) << 2) | (lane >> 4));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v4u x = __builtin_nontemporal_load(s4 + 64 * q);
+                v4u x = {0u, 0u, 0u, 0u}; // short frames: the vector's frame = bits a9..aL of (q, lane & 15)
+                if (!partial || f * FP + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) < nframes_user)
+                    x = __builtin_nontemporal_load(s4 + 64 * q);
                 v[4 * q] = x.x;
                 v[4 * q + 1] = x.y;
                 v[4 * q + 2] = x.z;
@@ -140,6 +138,10 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+        } else if (partial) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j + lane] : 0u;
         } else if (MODE == X_INV) { // LC: v[r] = X[rev10(n)] = X[64 * rev4(r) + lane]
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -205,13 +207,17 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
         else INTFFT_XBODY(false)
 #undef INTFFT_XBODY
-        if (out_halves) { // HALVES: beat i = 64 j + lane holds (x[i], x[i + 512]) = (v[j], v[j + 8])
-            typedef u32 v2u __attribute__((ext_vector_type(2)));
-            v2u *d2 = reinterpret_cast<v2u *>(out + f * 1024) + lane;
+        if (out_halves) { // HALVES: beat q = 64 jj + lane holds (x[i], x[i + N/2]) = (v[j0], v[j0 | 2^(L-7)]), see the forward kernel
+            if constexpr (L >= 7) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                v2u *d2 = reinterpret_cast<v2u *>(out + f * 1024) + lane;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const v2u w = {v[j], v[j + 8]};
-                __builtin_nontemporal_store(w, d2 + 64 * j);
+                for (int jj = 0; jj < 8; ++jj) {
+                    constexpr int HB = 1 << (L - 7);
+                    const int j0 = ((jj >> (L - 7)) << (L - 6)) | (jj & (HB - 1));
+                    const v2u w = {v[j0], v[j0 | HB]};
+                    if (!partial || f * FP + (size_t)(jj >> (L - 7)) < nframes_user) __builtin_nontemporal_store(w, d2 + 64 * jj);
+                }
             }
         } else if (partial) {
             u32 *dst = out + f * 1024 + lane;
@@ -231,9 +237,11 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
 {
     if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && use_fly == 1))
         return false;
-    if (log2n >= 6 && log2n < 10) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
-    return log2n == 10 && ((direction == 2 && in_order == 0 && out_order == 0) ||
-                           (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
+    if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
+    // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) in and HALVES (native) out
+    return log2n >= 7 && log2n <= 10 &&
+           ((direction == 2 && in_order == 0 && out_order == 0) ||
+            (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
 }
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
@@ -293,9 +301,9 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
     u32 *pout = static_cast<u32 *>(out);
     switch (log2n) {
     case 6: return launchx_l<6>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
-    case 7: return launchx_l<7>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
-    case 8: return launchx_l<8>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
-    case 9: return launchx_l<9>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+    case 7: return launchx_l<7>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    case 8: return launchx_l<8>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    case 9: return launchx_l<9>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
     default: return launchx_l<10>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
     }
 }

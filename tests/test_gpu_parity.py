@@ -439,6 +439,29 @@ def test_dedicated_and_generic_kernels_agree(case, monkeypatch):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("log2n", [7, 8, 9])
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("in_order,out_order", [("HALVES", "BITREV"), ("NATURAL", "BITREV"), ("HALVES", "NATURAL")])
+def test_wave_kernel_short_frames_native_orders(log2n, rnd, in_order, out_order):
+    """int_fftNk's own beat orders (HALVES in, BITREV out) at 128 <= N < 1024, ragged batches."""
+    n = 1 << log2n
+    for batch in (1, (1 << (10 - log2n)) + 1, 517):
+        x = np.concatenate([uniform_frames(batch, n, 15, 81 + batch), edge_frames(n, 16)])
+        info = check(x, log2n, 16, 16, 0, rnd, True, in_order=in_order, out_order=out_order)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_i16")
+
+
+@pytest.mark.parametrize("log2n", [7, 8, 9])
+@pytest.mark.parametrize("in_order,out_order", [("BITREV", "HALVES"), ("NATURAL", "HALVES"), ("BITREV", "NATURAL")])
+def test_inverse_wave_kernel_short_frames_native_orders(log2n, in_order, out_order):
+    """int_ifftNk's own beat orders (BITREV in, HALVES out) at 128 <= N < 1024."""
+    n = 1 << log2n
+    for batch in (1, (1 << (10 - log2n)) + 1, 517):
+        x = np.concatenate([uniform_frames(batch, n, 15, 91 + batch), edge_frames(n, 16)])
+        info = check(x, log2n, 16, 16, 0, 0, True, direction="INV", in_order=in_order, out_order=out_order)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024x_i16")
+
+
 def test_native_cores_chain_like_the_pair():
     """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
     same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
