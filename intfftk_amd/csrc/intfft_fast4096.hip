@@ -56,17 +56,23 @@ enum { MODE_FWD = 0, MODE_INV = 1, MODE_PAIR = 2, MODE_MID = 3 };
 // of the LC thread index t'' that carries index bit n_k (k = 4..11): in-frame bits reversed in the low bits,
 // frame bits on top, so that natural-order X of a frame = rev4(r) * 2^(L-4) + (low bits of t'') stays one
 // contiguous run per wave.
-template <int L> __host__ __device__ constexpr int lc_bit(int k) { return k < L ? (L - 1) - k : (L - 4) + (k - L); }
-template <int L> __host__ __device__ constexpr int lc_row_of_reg(int j) // LB register j' = n7..4 -> its LC thread bits
+// OB (native BITREV order on the LC side: int_fftNk output / int_ifftNk input beats, memory index = core index):
+// LC thread = n11..n4 in natural bit order; two lane swaps then give every lane 4 consecutive samples (dwordx4).
+template <int L, bool OB = false> __host__ __device__ constexpr int lc_bit(int k)
 {
-    return (((j >> 0) & 1) << lc_bit<L>(4)) | (((j >> 1) & 1) << lc_bit<L>(5)) | (((j >> 2) & 1) << lc_bit<L>(6)) |
-           (((j >> 3) & 1) << lc_bit<L>(7));
+    return OB ? k - 4 : (k < L ? (L - 1) - k : (L - 4) + (k - L));
+}
+template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_reg(int j) // LB register j' = n7..4 -> its LC thread bits
+{
+    return (((j >> 0) & 1) << lc_bit<L, OB>(4)) | (((j >> 1) & 1) << lc_bit<L, OB>(5)) | (((j >> 2) & 1) << lc_bit<L, OB>(6)) |
+           (((j >> 3) & 1) << lc_bit<L, OB>(7));
 }
 
-template <int L, int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK, bool OB = false>
 __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                     const RoundCConsts c, size_t nframes_user, const Slice sl)
+                                                     const RoundCConsts c, size_t nframes_user, const Slice sl, int halves)
 {
+    static_assert(!OB || MODE == MODE_FWD || MODE == MODE_INV, "native orders: forward or inverse core alone");
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
     constexpr int FP = 1 << (12 - L), NS = L - 8;        // frames per 4096-sample chunk; executed stages of round A
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
@@ -106,11 +112,11 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     // LA -> LB and LB -> LA: element (thread x, reg y) -> row 16*y + x3..0, column x7..4
     const int w_ab = ROW4K * lo4 + hi4;
     // LB -> LC: thread t' = (n11..8 = hi4, n3..0 = lo4), reg j' = n7..4 -> row = LC thread t'' (lc_bit<L>), column n3..0
-    const int row_hi = ((hi4 & 1) << lc_bit<L>(8)) | (((hi4 >> 1) & 1) << lc_bit<L>(9)) | (((hi4 >> 2) & 1) << lc_bit<L>(10)) |
-                       (((hi4 >> 3) & 1) << lc_bit<L>(11));
+    const int row_hi = ((hi4 & 1) << lc_bit<L, OB>(8)) | (((hi4 >> 1) & 1) << lc_bit<L, OB>(9)) | (((hi4 >> 2) & 1) << lc_bit<L, OB>(10)) |
+                       (((hi4 >> 3) & 1) << lc_bit<L, OB>(11));
     const int w_bc = ROW4K * row_hi + lo4; // + ROW4K * lc_row_of_reg<L>(j')
     // LC -> LB: thread t'' , reg r = n3..0 -> row = LB thread 16 * (n11..8) + r, column = LB register n7..4
-    auto nb = [&](int k) { return (tid >> lc_bit<L>(k)) & 1; };
+    auto nb = [&](int k) { return (tid >> lc_bit<L, OB>(k)) & 1; };
     const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
     const int w_cb = ROW4K * 16 * lb_hi + lb_reg;
     // per-thread shift amounts where the value kind depends on a thread bit after a transpose
@@ -131,10 +137,41 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         u32 *dst = out + f * 4096;
         const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
         const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
-        if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame
+        // OB: x4 unit index of the lane's vector q = (n9 n8): (n11 n10 | q | n7..n4 | n3 n2); its frame = n11..nL
+        const int ob_unit = ((tid >> 6) << 8) | ((tid & 15) << 2) | ((tid >> 4) & 3);
+        if (MODE == MODE_INV && OB) { // memory index = n: x4 loads (regs n9 n8 n1 n0), two lane swaps -> regs n3..0
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            const v4u *s4 = reinterpret_cast<const v4u *>(src) + ob_unit;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4u x = {0u, 0u, 0u, 0u};
+                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) x = __builtin_nontemporal_load(s4 + 64 * q);
+                v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+        } else if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 v[r] = lc_ok ? __builtin_nontemporal_load(src + (rev4c(r) << (L - 4)) + lc_off) : 0u;
+        } else if (MODE == MODE_FWD && halves) {
+            // HALVES: beat q = 256 jj + tid of the chunk holds (x[i], x[i + N/2]) of frame q >> (L-1): thread tid of the
+            // LA registers j0 = (frame << (L-8)) | (i >> 8) and j0 | 2^(L-9)
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *src2 = reinterpret_cast<const v2u *>(src) + tid;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L - 9);
+                const int j0 = ((jj >> (L - 9)) << (L - 8)) | (jj & (HB - 1));
+                v2u w = {0u, 0u};
+                if (!partial || f * FP + (size_t)(jj >> (L - 9)) < nframes_user) w = __builtin_nontemporal_load(src2 + 256 * jj);
+                v[j0] = w.x;
+                v[j0 | HB] = w.y;
+            }
         } else { // LA: v[j] = x[256 j + tid]
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -170,11 +207,24 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
             dif_round<FX, true>(v, tb, sl, sh_b);                                                       \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L>(j)] = v[j]; \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L, OB>(j)] = v[j]; \
             INTFFT_X_READ(reg1)                                                                         \
             dif_round_c<FX>(v, c, sl, sh_c);                                                            \
         }                                                                                               \
-        if (MODE == MODE_FWD) {                                                                         \
+        if (MODE == MODE_FWD && OB) { /* memory index = n: two lane swaps, dwordx4 stores (1 KiB per wave) */ \
+            swap_guard(v);                                                                              \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);                       \
+            _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);           \
+            typedef u32 v4u __attribute__((ext_vector_type(4)));                                        \
+            v4u *d4 = reinterpret_cast<v4u *>(dst) + ob_unit;                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+            {                                                                                           \
+                const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};                     \
+                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user)        \
+                    __builtin_nontemporal_store(x, d4 + 64 * q);                                        \
+            }                                                                                           \
+        } else if (MODE == MODE_FWD) {                                                                  \
             if (lc_ok) {                                                                                \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r)                                          \
                     __builtin_nontemporal_store(v[r], dst + (rev4c(r) << (L - 4)) + lc_off);            \
@@ -187,9 +237,22 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \
             dit_round<FX, NS>(v, ta, sl);                                                               \
+            if (MODE == MODE_INV && halves) { /* HALVES beats, mirror of the forward load */            \
+                typedef u32 v2u __attribute__((ext_vector_type(2)));                                    \
+                v2u *d2 = reinterpret_cast<v2u *>(dst) + tid;                                           \
+                _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)                                        \
+                {                                                                                       \
+                    constexpr int HB = 1 << (L - 9);                                                    \
+                    const int j0 = ((jj >> (L - 9)) << (L - 8)) | (jj & (HB - 1));                      \
+                    const v2u w = {v[j0], v[j0 | HB]};                                                  \
+                    if (!partial || f * FP + (size_t)(jj >> (L - 9)) < nframes_user)                    \
+                        __builtin_nontemporal_store(w, d2 + 256 * jj);                                  \
+                }                                                                                       \
+            } else {                                                                                    \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
                 if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)                 \
                     __builtin_nontemporal_store(v[j], dst + 256 * j + tid);                             \
+            }                                                                                           \
         }                                                                                               \
     }
         if (FAST_OK && fast) INTFFT_BODY(FAST_OK)
@@ -199,25 +262,29 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     }
 }
 
-bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int use_fly,
+bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order)
 {
-    return (log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!((log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+          use_fly == 1))
+        return false;
+    if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
+    if (direction == 1) return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2); // + BITREV in, HALVES out
+    return in_order == 0 && out_order == 0;
 }
 
 const char *fast4096_kernel_name() { return "k_fft4096_i16"; }
 
-template <int L, int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK, bool OB = false>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
-                           const Slice &sl, hipStream_t stream)
+                           const Slice &sl, hipStream_t stream, int halves = 0)
 {
     static int per_cu = 0, cus = 0;
     if (!per_cu) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_i16<L, MODE, FAST_OK>, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_i16<L, MODE, FAST_OK, OB>, 256, 0) != hipSuccess ||
             per_cu <= 0)
             per_cu = 2;
         if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
@@ -225,7 +292,8 @@ static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundC
     const size_t cap = (size_t)cus * (size_t)per_cu;
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
     const unsigned blocks = (unsigned)(chunks < cap ? chunks : cap);
-    hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl);
+    hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK, OB>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
+                       halves);
     return hipGetLastError();
 }
 
@@ -252,22 +320,28 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
 
 template <int L>
 static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
-                             size_t nframes, const Slice &sl, hipStream_t stream)
+                             size_t nframes, const Slice &sl, hipStream_t stream, int lc_bitrev, int halves)
 {
     switch (direction) {
     case 0:
-        return fast_ok ? launch4k<L, MODE_FWD, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launch4k<L, MODE_FWD, false>(pin, pout, tw_all, c, nframes, sl, stream);
+        if (lc_bitrev)
+            return fast_ok ? launch4k<L, MODE_FWD, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                           : launch4k<L, MODE_FWD, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+        return fast_ok ? launch4k<L, MODE_FWD, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                       : launch4k<L, MODE_FWD, false>(pin, pout, tw_all, c, nframes, sl, stream, halves);
     case 1:
-        return fast_ok ? launch4k<L, MODE_INV, true>(pin, pout, tw_all, c, nframes, sl, stream)
-                       : launch4k<L, MODE_INV, false>(pin, pout, tw_all, c, nframes, sl, stream);
+        if (lc_bitrev)
+            return fast_ok ? launch4k<L, MODE_INV, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                           : launch4k<L, MODE_INV, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+        return fast_ok ? launch4k<L, MODE_INV, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                       : launch4k<L, MODE_INV, false>(pin, pout, tw_all, c, nframes, sl, stream, halves);
     default:
         return fast_ok ? launch4k<L, MODE_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
                        : launch4k<L, MODE_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
     }
 }
 
-hipError_t launch_fast4096(int log2n, int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                            size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -287,8 +361,8 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, const void *in, vo
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    if (log2n == 11) return launch4k_l<11>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream);
-    return launch4k_l<12>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream);
+    if (log2n == 11) return launch4k_l<11>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves);
+    return launch4k_l<12>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves);
 }
 
 } // namespace intfft

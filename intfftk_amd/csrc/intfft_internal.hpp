@@ -197,9 +197,9 @@ hipError_t launch_biginv(int log2n, int twd, const void *in, void *out, void *sc
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);
 
 // packed int16 block kernel for N = 4096, FWD / INV / PAIR (intfft_fast4096.hip)
-bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int use_fly,
+bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order);
-hipError_t launch_fast4096(int log2n, int direction, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                            size_t nframes, hipStream_t stream);
 const char *fast4096_kernel_name();
 

@@ -409,7 +409,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     pl->fast1024 = !generic_only && fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
                                                        p->direction, p->use_fly, p->in_order, p->out_order);
     pl->fast4096 = !generic_only && !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
-                                                       p->use_fly, p->in_order, p->out_order);
+                                                       p->direction, p->use_fly, p->in_order, p->out_order);
     pl->fast1024x = !generic_only && fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                         p->use_fly, p->in_order, p->out_order);
     pl->fast1024u = !generic_only && fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
@@ -608,8 +608,12 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
     if (plan->fast4096)
-        return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(),
-                                    batch, stream);
+        return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
+                                    plan->p.direction == INTFFT_FWD ? plan->p.out_order == INTFFT_ORDER_BITREV
+                                                                    : plan->p.in_order == INTFFT_ORDER_BITREV,
+                                    plan->p.direction == INTFFT_FWD ? plan->p.in_order == INTFFT_ORDER_HALVES
+                                                                    : plan->p.out_order == INTFFT_ORDER_HALVES,
+                                    d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;

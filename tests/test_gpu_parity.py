@@ -462,6 +462,18 @@ def test_inverse_wave_kernel_short_frames_native_orders(log2n, in_order, out_ord
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024x_i16")
 
 
+@pytest.mark.parametrize("log2n", [11, 12])
+@pytest.mark.parametrize("direction,in_order,out_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
+                                                          ("FWD", "HALVES", "NATURAL"), ("INV", "BITREV", "HALVES"),
+                                                          ("INV", "NATURAL", "HALVES"), ("INV", "BITREV", "NATURAL")])
+def test_block_kernel_native_orders(log2n, direction, in_order, out_order):
+    """The cores' own beat orders at N = 2048 / 4096 (odd batch: partial chunk at N = 2048)."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(37, n, 15, 131 + log2n), edge_frames(n, 16)])
+    info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
+    assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16")
+
+
 def test_native_cores_chain_like_the_pair():
     """int_fftNk (HALVES -> BITREV) feeding int_ifftNk (BITREV -> HALVES) equals int_fft_ifft_pair on the
     same frames re-ordered (int_fft_ifft_pair.vhd:209-280 wires exactly this chain)."""
