@@ -46,7 +46,7 @@ __device__ __forceinline__ void ld_tw(const uint2 *__restrict__ t, unsigned idx,
 // the frames g, g + G, ... of the launch (the twiddles depend on the chunk, not on the frame)
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes_user,
-                                                  unsigned groups, const Slice sl)
+                                                  unsigned groups, const Slice sl, int halves)
 {
     static_assert(L >= 17 && L <= 20, "two-round pass 1");
     constexpr int NS1 = L - 16, G = 1 << (20 - L);       // executed stages of round 1; frames per virtual frame
@@ -91,7 +91,19 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         u32 *dst = scr + frame * ((size_t)1 << L20) + lfull;
         u32 v[16];
         const bool partial = L < 20 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
-        if (partial) {
+        if (halves) { // HALVES beats (x[i], x[i + N/2]): beat 65536 jj + 4096 hx + n11..0 of the group -> regs (j0, j0 | 2^(L-17))
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *src2 = reinterpret_cast<const v2u *>(in + frame * ((size_t)1 << L20)) + ((size_t)hx << 12) + lfull;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L - 17);
+                const int j0 = ((jj >> (L - 17)) << (L - 16)) | (jj & (HB - 1));
+                v2u w = {0u, 0u};
+                if (!partial || frame * G + (size_t)(jj >> (L - 17)) < nframes_user) w = __builtin_nontemporal_load(src2 + (size_t)jj * 65536);
+                v[j0] = w.x;
+                v[j0 | HB] = w.y;
+            }
+        } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 v[j] = frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user ? src[(size_t)(16 * j + hx) << 12] : 0u;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
 // grid = 8 chunks (512 consecutive n11..0 each) x G frame groups; regs = n15..12, no LDS, wave-level guard vote
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes_user,
-                                                  unsigned groups, const Slice sl)
+                                                  unsigned groups, const Slice sl, int halves)
 {
     static_assert(L >= 13 && L <= 16, "one-round pass 1");
     constexpr int NS = L - 12, G = 1 << (16 - L);
@@ -155,7 +167,19 @@ __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const
         u32 *dst = scr + frame * 65536 + lfull;
         u32 v[16];
         const bool partial = L < 16 && (frame + 1) * G > nframes_user;
-        if (partial) {
+        if (halves) { // HALVES beats: beat 4096 jj + n11..0 of the group -> regs (j0, j0 | 2^(L-13))
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *src2 = reinterpret_cast<const v2u *>(in + frame * 65536) + lfull;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L - 13);
+                const int j0 = ((jj >> (L - 13)) << (L - 12)) | (jj & (HB - 1));
+                v2u w = {0u, 0u};
+                if (!partial || frame * G + (size_t)(jj >> (L - 13)) < nframes_user) w = __builtin_nontemporal_load(src2 + (size_t)jj * 4096);
+                v[j0] = w.x;
+                v[j0 | HB] = w.y;
+            }
+        } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = frame * G + (size_t)(j >> (L - 12)) < nframes_user ? src[(size_t)j << 12] : 0u;
         } else {
@@ -181,7 +205,7 @@ __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const
 // values (DIT outputs are never pre-shifted).
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes_user,
-                                                  unsigned groups, const Slice sl)
+                                                  unsigned groups, const Slice sl, int halves)
 {
     static_assert(L >= 13 && L <= 16, "one-round pass");
     constexpr int NS = L - 12, G = 1 << (16 - L);
@@ -216,7 +240,17 @@ __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, cons
         }
         if (FAST_OK && frame_has_guard_bit(v)) dit_round<FAST_OK, NS>(v, t, sl);
         else dit_round<false, NS>(v, t, sl);
-        if (partial) {
+        if (halves) {
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            v2u *d2 = reinterpret_cast<v2u *>(out + frame * 65536) + lfull;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L - 13);
+                const int j0 = ((jj >> (L - 13)) << (L - 12)) | (jj & (HB - 1));
+                const v2u w = {v[j0], v[j0 | HB]};
+                if (!partial || frame * G + (size_t)(jj >> (L - 13)) < nframes_user) __builtin_nontemporal_store(w, d2 + (size_t)jj * 4096);
+            }
+        } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if (frame * G + (size_t)(j >> (L - 12)) < nframes_user) dst[(size_t)j << 12] = v[j];
@@ -229,7 +263,7 @@ __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, cons
 
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes_user,
-                                                  unsigned groups, const Slice sl)
+                                                  unsigned groups, const Slice sl, int halves)
 {
     static_assert(L >= 17 && L <= 20, "two-round pass");
     constexpr int NS1 = L - 16, G = 1 << (20 - L);
@@ -287,7 +321,17 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
         for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * tid + j]; // now tid >> 5 = n15..12, regs = n19..16
         if (fast) dit_round<FAST_OK, NS1>(v, t1, sl);
         else dit_round<false, NS1>(v, t1, sl);
-        if (partial) {
+        if (halves) {
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            v2u *d2 = reinterpret_cast<v2u *>(out + frame * ((size_t)1 << L20)) + ((size_t)hx << 12) + lfull;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L - 17);
+                const int j0 = ((jj >> (L - 17)) << (L - 16)) | (jj & (HB - 1));
+                const v2u w = {v[j0], v[j0 | HB]};
+                if (!partial || frame * G + (size_t)(jj >> (L - 17)) < nframes_user) __builtin_nontemporal_store(w, d2 + (size_t)jj * 65536);
+            }
+        } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if (frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user) dst[(size_t)(16 * j + hx) << 12] = v[j];
@@ -502,11 +546,72 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
     }
 }
 
+// ---- BITREV order on the frequency side (native int_fftNk output / int_ifftNk input beats): memory index = core index, so
+// the last four DIF stages (or the first four DIT stages) act on 16 consecutive samples.  One wave per 1024 consecutive
+// samples: dwordx4 loads, two lane swaps -> regs n3..0 (lane = n9..n4), stages, two lane swaps, dwordx4 stores.  No LDS.
+template <bool DIT, bool FAST_OK>
+__global__ __launch_bounds__(256) void k_big_c(const u32 *src, u32 *dst, const RoundCConsts c, size_t nchunks, const Slice sl)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const int unit = ((lane & 15) << 2) | (lane >> 4); // x4 unit of the lane's vector q = (n9 n8): (q | n7..n4 | n3 n2)
+    // DIF: pass 2 left Y >> 1 where n4 = 1; after the swaps lane bit 0 = n4
+    const short s3 = (short)(1 - (lane & 1));
+    const v2s sh3 = {s3, s3};
+    for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
+        const v4u *s4 = reinterpret_cast<const v4u *>(src + ch * 1024) + unit;
+        u32 v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4u x = __builtin_nontemporal_load(s4 + 64 * q);
+            v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+        bool fast = false;
+        if (FAST_OK) {
+            u32 acc = 0;
+            const u32 addc = (!DIT && (lane & 1)) ? 0x20002000u : 0x40004000u, maskc = (!DIT && (lane & 1)) ? 0xC000C000u : 0x80008000u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc |= v[r] + addc;
+            fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
+        }
+        if (DIT) {
+            if (fast) dit_round_c<FAST_OK>(v, c, sl);
+            else dit_round_c<false>(v, c, sl);
+        } else {
+            if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
+            else dif_round_c<false>(v, c, sl, sh3);
+        }
+        swap_guard(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+        v4u *d4 = reinterpret_cast<v4u *>(dst + ch * 1024) + unit;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            __builtin_nontemporal_store(x, d4 + 64 * q);
+        }
+    }
+}
+
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
     return log2n >= 13 && log2n <= 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0; // FWD, INV and the pair
+           use_fly == 1 &&
+           (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out
+            : direction == 1 ? (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2) // + BITREV in, HALVES out
+                             : in_order == 0 && out_order == 0);
 }
 
 const char *big20_kernel_name(int direction)
@@ -515,34 +620,36 @@ const char *big20_kernel_name(int direction)
 }
 
 template <int L>
-static void launch_p1(bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream)
+static void launch_p1(bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream,
+                      int halves = 0)
 {
     if constexpr (L >= 17) {
         const size_t nvf = (nframes + ((size_t)1 << (20 - L)) - 1) >> (20 - L);
         const unsigned groups = (unsigned)(nvf < 16 ? nvf : 16);
-        if (fx) hipLaunchKernelGGL((k_big20_p1<L, true>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
-        else hipLaunchKernelGGL((k_big20_p1<L, false>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+        if (fx) hipLaunchKernelGGL((k_big20_p1<L, true>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, halves);
+        else hipLaunchKernelGGL((k_big20_p1<L, false>), dim3(128u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, halves);
     } else {
         const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L);
         const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
-        if (fx) hipLaunchKernelGGL((k_big16_p1<L, true>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
-        else hipLaunchKernelGGL((k_big16_p1<L, false>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl);
+        if (fx) hipLaunchKernelGGL((k_big16_p1<L, true>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, halves);
+        else hipLaunchKernelGGL((k_big16_p1<L, false>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, halves);
     }
 }
 
 template <int L>
-static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream)
+static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, size_t nframes, const Slice &sl, hipStream_t stream,
+                      int halves = 0)
 {
     if constexpr (L >= 17) {
         const size_t nvf = (nframes + ((size_t)1 << (20 - L)) - 1) >> (20 - L);
         const unsigned groups = (unsigned)(nvf < 16 ? nvf : 16);
-        if (fx) hipLaunchKernelGGL((k_big20_q1<L, true>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
-        else hipLaunchKernelGGL((k_big20_q1<L, false>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+        if (fx) hipLaunchKernelGGL((k_big20_q1<L, true>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, halves);
+        else hipLaunchKernelGGL((k_big20_q1<L, false>), dim3(128u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, halves);
     } else {
         const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L);
         const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
-        if (fx) hipLaunchKernelGGL((k_big16_q1<L, true>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
-        else hipLaunchKernelGGL((k_big16_q1<L, false>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl);
+        if (fx) hipLaunchKernelGGL((k_big16_q1<L, true>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, halves);
+        else hipLaunchKernelGGL((k_big16_q1<L, false>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, halves);
     }
 }
 
@@ -584,7 +691,7 @@ hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *s
 }
 
 // int_ifftNk for N = 2^13 .. 2^20: the three passes mirrored (k_big20_q3, k_big20_q2, k_big16_q1 / k_big20_q1)
-hipError_t launch_biginv(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                          const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -616,27 +723,31 @@ hipError_t launch_biginv(int log2n, int twd, const void *in, void *out, void *sc
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t cap = (size_t)cus * (size_t)q2_per_cu;
     const unsigned g2 = (unsigned)(nb < cap ? nb : cap);
+    const size_t nch = nframes << (log2n - 10), ccap = (size_t)cus * 8; // k_big_c: 1024-sample chunks, one per wave pass
+    const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
     if (fx) {
-        hipLaunchKernelGGL(k_big20_q3<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        if (in_bitrev) hipLaunchKernelGGL((k_big_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, c, nch, sl);
+        else hipLaunchKernelGGL(k_big20_q3<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
         hipLaunchKernelGGL(k_big20_q2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
     } else {
-        hipLaunchKernelGGL(k_big20_q3<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        if (in_bitrev) hipLaunchKernelGGL((k_big_c<true, false>), dim3(gc), dim3(256), 0, stream, pin, scr, c, nch, sl);
+        else hipLaunchKernelGGL(k_big20_q3<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
         hipLaunchKernelGGL(k_big20_q2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
     }
     switch (log2n) {
-    case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 14: launch_q1<14>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 15: launch_q1<15>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 16: launch_q1<16>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 17: launch_q1<17>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 18: launch_q1<18>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    case 19: launch_q1<19>(fx, scr, pout, tw16f, nframes, sl, stream); break;
-    default: launch_q1<20>(fx, scr, pout, tw16f, nframes, sl, stream); break;
+    case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 14: launch_q1<14>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 15: launch_q1<15>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 16: launch_q1<16>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 17: launch_q1<17>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 18: launch_q1<18>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    case 19: launch_q1<19>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
+    default: launch_q1<20>(fx, scr, pout, tw16f, nframes, sl, stream, out_halves); break;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                         const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
@@ -663,14 +774,14 @@ hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scr
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
     switch (log2n) {
-    case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 15: launch_p1<15>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 16: launch_p1<16>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 17: launch_p1<17>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 18: launch_p1<18>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream); break;
-    default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream); break;
+    case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 15: launch_p1<15>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 16: launch_p1<16>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 17: launch_p1<17>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 18: launch_p1<18>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
+    default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
     }
     const size_t nb = nframes << (log2n - 12);
     static int p2_per_cu = 0;
@@ -680,12 +791,16 @@ hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scr
     const size_t nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     const unsigned g2 = (unsigned)(nb < cap ? nb : cap), g3 = (unsigned)nb3;
+    const size_t nch = nframes << (log2n - 10), ccap = (size_t)cus * 8;
+    const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
     if (fx) {
         hipLaunchKernelGGL(k_big20_p2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
-        hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
+        if (out_bitrev) hipLaunchKernelGGL((k_big_c<false, true>), dim3(gc), dim3(256), 0, stream, scr, pout, c, nch, sl);
+        else hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
     } else {
         hipLaunchKernelGGL(k_big20_p2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
-        hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
+        if (out_bitrev) hipLaunchKernelGGL((k_big_c<false, false>), dim3(gc), dim3(256), 0, stream, scr, pout, c, nch, sl);
+        else hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
     }
     return hipGetLastError();
 }

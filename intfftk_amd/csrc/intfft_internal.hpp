@@ -187,12 +187,12 @@ const char *wide16_kernel_name();
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order);
-hipError_t launch_big20(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                         const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *big20_kernel_name(int direction);
 hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                           const int2 *h_tw, size_t nframes, hipStream_t stream);
-hipError_t launch_biginv(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
+hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                          const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);
 

@@ -638,12 +638,14 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         // short single-pass lengths (N = 8192, 16384) keep the one-pass generic kernel for small batches
         if (plan->big20 && (np > 1 || (nf << plan->L) >= ((size_t)1 << 22))) {
             const hipError_t e = plan->p.direction == INTFFT_INV
-                                     ? launch_biginv(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
+                                     ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
+                                                     plan->p.out_order == INTFFT_ORDER_HALVES, src, dst, plan->d_scratch, plan->d_tw,
                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream)
                                  : plan->p.direction == INTFFT_PAIR
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
                                                       plan->d_tw16f, plan->h_tw.data(), nf, stream)
-                                     : launch_big20(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
+                                     : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
+                                                    plan->p.out_order == INTFFT_ORDER_BITREV, src, dst, plan->d_scratch, plan->d_tw,
                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
             continue;

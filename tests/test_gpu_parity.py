@@ -167,6 +167,20 @@ def test_general_width_three_pass_kernels(log2n, batch, case):
     assert info["kernel_name"].startswith("k_bigw") and info["n_passes"] == 3, info
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 5), (16, 3), (17, 3), (18, 5), (19, 3), (20, 1)])
+@pytest.mark.parametrize("direction,in_order,out_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
+                                                          ("FWD", "HALVES", "NATURAL"), ("INV", "BITREV", "HALVES"),
+                                                          ("INV", "NATURAL", "HALVES"), ("INV", "BITREV", "NATURAL")])
+def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
+    """The cores' own beat orders for N >= 8192: HALVES beats as 8-byte loads / stores of register pairs in pass 1,
+    BITREV order = the core index, so the last (first) four stages run on 16 consecutive samples (k_big_c)."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 7000 + log2n)
+    x[0] = uniform_frames(1, n, 16, 10)[0]
+    info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
+    assert info["kernel_name"].startswith("k_big20") and info["n_passes"] == 3
+
+
 def test_config4_n_2pow20_taylor_extension():
     """BASELINE config 4 shape at a reduced batch: N = 2^20, 16-bit scaled, Taylor ii = 8 extension."""
     x = uniform_frames(2, 1 << 20, 15, 0xC0FFEE04)
