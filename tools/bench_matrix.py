@@ -14,7 +14,7 @@ for L in (7, 10, 12):
 for L in (7, 10, 11, 12, 14, 17, 20):
     ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
     ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
-for L in (7, 10, 11, 12, 14):
+for L in (7, 10, 11, 12, 14, 16):
     ROWS.append(("%d:16:16:1" % L, "16-bit unscaled FWD"))
 for L in (7, 10):
     ROWS.append(("%d:16:16:1:0:INV" % L, "16-bit unscaled INV"))
@@ -30,11 +30,26 @@ ROWS.append(("12:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("10:12:16:0:0:INV", "12-bit scaled INV"))
 ROWS.append(("12:16:16:1:0:INV", "16-bit unscaled INV"))
 
+NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (native int_fftNk beats)"),
+          ("12:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
+          ("16:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
+          ("7:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out (native int_ifftNk beats)"),
+          ("12:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
+          ("16:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out")]
+
 if __name__ == "__main__":
     print("| N | mode | kernel | passes | Gsample/s | B/sample | GB/s | frac of 8 TB/s | parity prefix |")
     print("|---|---|---|---|---|---|---|---|---|")
     for spec, label in ROWS:
         B.adhoc(spec)
+        r = B.run(spec, steps=10)
+        bps = r["GB/s"] / r["Gsample/s"]
+        print("| 2^%d | %s | `%s` | %d | %.0f | %.0f | %.0f | %.2f | %s |" % (
+            r["log2n"], label, r["kernel"], r["passes"], r["Gsample/s"], bps, r["GB/s"], r["roofline_frac"],
+            "ok" if r["parity_prefix_ok"] else "MISMATCH"), flush=True)
+    for spec, orders, label in NATIVE:
+        B.adhoc(spec)
+        B.ORDERS[spec] = orders
         r = B.run(spec, steps=10)
         bps = r["GB/s"] / r["Gsample/s"]
         print("| 2^%d | %s | `%s` | %d | %.0f | %.0f | %.0f | %.2f | %s |" % (
