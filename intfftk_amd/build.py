@@ -25,16 +25,24 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+        objs.append(o)
+    if jobs:  # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(o)
+
+        workers = max(1, min(len(jobs), int(os.environ.get("INTFFT_BUILD_JOBS", os.cpu_count() or 1))))
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            list(ex.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
