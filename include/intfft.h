@@ -110,6 +110,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
  * staged through two device slots and three HIP streams, so that the upload of chunk i+1, the
  * transform of chunk i and the download of chunk i-1 overlap -- the software analogue of feeding
  * the core frames back to back (int_fftNk.vhd:23-37).  Blocking; returns when h_out is complete.
+ * Pinned buffers (hipHostMalloc, or registered by their owner) make the copies truly asynchronous; pageable buffers
+ * work too (the runtime stages them: less overlap).  The library never registers the caller's memory itself.
  * This is NOT a CPU execution path: every frame is transformed on the HIP device. */
 int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames);
 

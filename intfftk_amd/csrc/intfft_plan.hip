@@ -708,11 +708,11 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
         plan->slot_frames = chunk_frames;
     }
     {
-        // pin the caller's buffers for the duration of the call so the copies are truly asynchronous;
-        // if registration is refused the copies still work (staged by the runtime, less overlap)
-        const bool pin_in = hipHostRegister(const_cast<void *>(h_in), batch * in_frame, hipHostRegisterDefault) == hipSuccess;
-        const bool pin_out = hipHostRegister(h_out, batch * out_frame, hipHostRegisterDefault) == hipSuccess;
-        (void)hipGetLastError();
+        // The caller's buffers are used as they are.  Pinned buffers (hipHostMalloc, or registered by their owner) make
+        // the copies truly asynchronous; pageable buffers still work (the runtime stages them, with less overlap).
+        // This function does NOT hipHostRegister the caller's memory itself: registering malloc-heap memory for the
+        // duration of a call left stale GPU mappings behind on this stack once the allocator recycled those pages, and
+        // later unrelated pageable copies faulted ("Memory access fault by GPU node", found by soaking the test suite).
         size_t i = 0;
         for (size_t f = 0; f < batch; f += chunk_frames, ++i) {
             const int slot = (int)(i & 1);
@@ -742,8 +742,6 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
         const hipError_t e2 = hipStreamSynchronize(plan->s_down);
         const hipError_t e3 = hipStreamSynchronize(plan->s_comp);
         const hipError_t e4 = hipStreamSynchronize(plan->s_up);
-        if (pin_in) (void)hipHostUnregister(const_cast<void *>(h_in));
-        if (pin_out) (void)hipHostUnregister(h_out);
         if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4;
     }
     if (e == hipSuccess) return INTFFT_OK;
