@@ -63,6 +63,13 @@ hipError_t launch_pass16(const PassArgs &a, const void *in, void *out, const uin
 hipError_t launch_pack_twiddles16(const int2 *tw, size_t n, uint2 *f, uint2 *i, hipStream_t stream);
 const char *pass16_kernel_name();
 
+// packed int16 lane-per-frame kernel for N = 8, 16, 32 (intfft_fastsmall.hip)
+bool fastsmall_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
+                         int in_order, int out_order);
+hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, const void *in, void *out, const int2 *h_tw,
+                            size_t nframes, hipStream_t stream);
+const char *fastsmall_kernel_name();
+
 // ---- wave kernels (intfft_fast1024.hip, intfft_fast1024u.hip): I/O permutation for short frames ----
 // Frames shorter than 1024 samples (L = log2 N in 6..9): the wave owns a chunk of 1024 consecutive samples
 // = 2^(10-L) whole frames; chunk index bits a9..aL number the frame, a(L-1)..a0 the sample.  The stages of

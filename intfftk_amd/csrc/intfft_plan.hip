@@ -42,6 +42,7 @@ struct intfft_plan {
     bool fast4096w = false;
     bool w32inv = false;
     bool bigw = false;
+    bool fastsmall = false;
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
@@ -406,6 +407,8 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     }
     // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only
     const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr;
+    pl->fastsmall = !generic_only && fastsmall_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
+                                                         p->use_fly, p->in_order, p->out_order);
     pl->fast1024 = !generic_only && fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
                                                        p->direction, p->use_fly, p->in_order, p->out_order);
     pl->fast4096 = !generic_only && !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
@@ -465,7 +468,9 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->w32args.in_sh = 32 - p->data_width;
         if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
     }
-    if (pl->w32inv) {
+    if (pl->fastsmall) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
+    } else if (pl->w32inv) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", w32inv_kernel_name(p->log2n));
     } else if (pl->fast4096w) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast4096w_kernel_name());
@@ -571,7 +576,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall;
     info->n_passes = fast ? 1 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
@@ -587,6 +592,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->fastsmall)
+        return (int)launch_fastsmall(plan->p.log2n, plan->p.direction, plan->p.rndmode, plan->p.twdl_width, d_in, d_out,
+                                     plan->h_tw.data(), batch, stream);
     if (plan->w32inv)
         return (int)launch_w32inv(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                   plan->h_tw.data(), batch, stream);

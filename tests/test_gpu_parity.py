@@ -432,7 +432,7 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
     assert np.array_equal(fast, slow) and np.array_equal(mid, slow)
 
 
-AB_CASES = [(7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
+AB_CASES = [(4, 16, 16, 0, 0, "PAIR"), (5, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
             (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
             (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
             (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD")]
@@ -486,6 +486,18 @@ def test_block_kernel_native_orders(log2n, direction, in_order, out_order):
     x = np.concatenate([uniform_frames(37, n, 15, 131 + log2n), edge_frames(n, 16)])
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
     assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16")
+
+
+@pytest.mark.parametrize("log2n", [3, 4, 5])
+@pytest.mark.parametrize("direction,rnd", [("FWD", 0), ("FWD", 1), ("INV", 0), ("PAIR", 0)])
+def test_lane_per_frame_kernel_n8_to_n32(log2n, direction, rnd):
+    """N = 8, 16, 32: a whole frame in the registers of one lane (k_fftsmall_i16); ragged batches, edge frames."""
+    n = 1 << log2n
+    for batch, seed in [(1, 1), (63, 2), (257, 3), (100003, 4)]:
+        x = np.concatenate([uniform_frames(batch, n, 16 if seed % 2 else 15, 1300 + seed), edge_frames(n, 16)])
+        info = check(x, log2n, 16, 16, 0, rnd, True, direction=direction)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fftsmall_i16")
+    check(uniform_frames(77, n, 16, 9), log2n, 16, 11, 0, rnd, False, direction=direction)
 
 
 def test_native_cores_chain_like_the_pair():
