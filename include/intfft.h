@@ -78,8 +78,8 @@ typedef struct intfft_plan_info {
     int32_t in_bits, out_bits;           /* DATA_WIDTH, DATA_WIDTH + FORMAT*NFFT (x2 for PAIR)     */
     int32_t in_container, out_container; /* bytes per real component: 2, 4 or 8                    */
     int32_t n_passes;                    /* kernel launches per batch chunk                        */
-    int32_t compute_word;                /* bytes of the on-chip word (2 = packed int16 fast path) */
-    int32_t fast_path;                   /* 1 if the packed-int16 wave kernel serves this plan     */
+    int32_t compute_word;                /* bytes of the on-chip word (2 = packed int16 kernels)   */
+    int32_t fast_path;                   /* 1 if a single dedicated kernel serves this plan        */
     int32_t reserved;
     uint64_t scratch_bytes;              /* plan-owned device scratch                              */
     char kernel_name[64];                /* dominant kernel symbol (for rocprof matching)          */
