@@ -277,6 +277,24 @@ def test_in_place_exec():
     core.close()
 
 
+@pytest.mark.parametrize("log2n,direction,batch", [(4, "FWD", 1000), (5, "PAIR", 77), (7, "FWD", 1001), (7, "INV", 1001), (9, "PAIR", 33),
+                                                   (11, "FWD", 35), (12, "INV", 17), (13, "FWD", 515), (16, "PAIR", 5), (17, "INV", 3)])
+def test_in_place_exec_all_kernel_families(log2n, direction, batch):
+    """d_in == d_out (equal containers) through every packed kernel family, with ragged batches: each kernel reads the
+    whole chunk / tile it is about to overwrite before its first store, multi-pass plans go through the plan scratch."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(log2n, 16, 16, 0, 0, "NEW", direction)
+    x = torch.from_numpy(uniform_frames(batch, 1 << log2n, 15, 77 + log2n).astype(np.int16)).cuda()
+    want = core(x).clone()
+    got = core(x, out=x)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    core.close()
+
+
 @pytest.mark.parametrize("chunk", [0, 1, 7, 64])
 def test_exec_host_streaming(chunk):
     """intfft_exec_host: chunked double-buffered H2D/transform/D2H gives the same rows as one
