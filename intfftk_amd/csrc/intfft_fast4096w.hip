@@ -154,6 +154,20 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+        if (MODE == W_UNSCALED && a.out64) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
+            long long xr[16], xi[16];
+            tail64_unscaled(re, im, xr, xi);
+            if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+                typedef long long v2l __attribute__((ext_vector_type(2)));
+                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const v2l y = {xr[r], xi[r]};
+                    __builtin_nontemporal_store(y, dst + (rev4q(r) << (L - 4)));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
@@ -184,8 +198,10 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
 bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                          int out_order)
 {
-    return (log2n == 11 || log2n == 12) && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
-           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+    const int out_bits = data_width + format * log2n; // unscaled: 33 / 34-bit results through the 64-bit tail stages
+    const bool fits = out_bits <= 32 || (format == 1 && out_bits <= 34);
+    return (log2n == 11 || log2n == 12) && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 &&
+           use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
 const char *fast4096w_kernel_name() { return "k_fft4096_w32"; }

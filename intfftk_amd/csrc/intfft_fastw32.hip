@@ -163,6 +163,19 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+        if (L == 10 && MODE == W_UNSCALED && a.out64) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
+            long long xr[16], xi[16];
+            tail64_unscaled(re, im, xr, xi);
+            typedef long long v2l __attribute__((ext_vector_type(2)));
+            v2l *dst = reinterpret_cast<v2l *>(out) + f * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
+                const v2l y = {xr[r], xi[r]};
+                __builtin_nontemporal_store(y, dst + 64 * rr);
+            }
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
@@ -224,8 +237,11 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                        int out_order)
 {
-    return log2n >= 6 && log2n <= 10 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
-           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+    // N = 1024 unscaled: also 33 / 34-bit results (e.g. DATA_WIDTH = 24): only the two multiplier-free stages exceed 32 bits
+    const int out_bits = data_width + format * log2n;
+    const bool fits = out_bits <= 32 || (log2n == 10 && format == 1 && out_bits <= 34);
+    return log2n >= 6 && log2n <= 10 && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 &&
+           use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
 const char *fastw32_kernel_name() { return "k_fft1024_w32"; }

@@ -148,6 +148,7 @@ struct W32Args {
     W32Stage st[16]; // by STAGE number
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
+    int out64;       // unscaled results of 33 / 34 bits: stages 1, 0 in 64 bits, int64 containers
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
 };
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,

@@ -456,7 +456,11 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
         for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw); ++i) {
             const StageDesc &d = st[i];
-            if (d.s < 0 || d.s > 15 || d.dtw > 32 || d.wo > 32 || d.mw > 32 || d.sh_a + d.sh_b > 31 || d.mw + p->twdl_width > 62) {
+            // stages 1 and 0 may exceed 32 bits (by the 33rd / 34th bit) in unscaled forward plans: 64-bit tail
+            const bool tail = d.s <= 1 && p->format == 1 && p->direction == INTFFT_FWD && d.dtw <= 33 && d.wo <= 34;
+            if (tail && d.wo > 32) pl->w32args.out64 = 1;
+            if (d.s < 0 || d.s > 15 || (!tail && (d.dtw > 32 || d.wo > 32 || d.mw > 32)) || d.sh_a + d.sh_b > 31 ||
+                d.mw + p->twdl_width > 62) {
                 pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
                 break;
             }
@@ -466,7 +470,8 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;
         pl->w32args.in_sh = 32 - p->data_width;
-        if (pl->in_cb > 4 || pl->out_cb > 4) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
+        if (pl->in_cb > 4 || (pl->out_cb > 4) != (pl->w32args.out64 != 0)) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
+        if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
     }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());

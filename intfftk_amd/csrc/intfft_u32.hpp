@@ -300,4 +300,29 @@ __device__ __forceinline__ void gfly_dit_triv(int &are, int &aim, int &bre, int 
     gsumdiff<MODE>(are, aim, bre, bim, tr, ti, s);
 }
 
+// ---- unscaled results of 33 / 34 bits (intfft_fastw32.hip, intfft_fast4096w.hip: W32Args::out64) --------------------
+// When DATA_WIDTH + NFFT exceeds 32 by at most 2, every multiplier stage (STAGE >= 2) still works within 32 bits; only
+// the two multiplier-free stages 1 and 0 produce the 33rd and 34th bit.  They run on sign-extended 64-bit registers
+// (exact sums, no wrap needed: int_dif2_fly.vhd:222-318) and the results are stored in int64 containers.
+__device__ __forceinline__ void tail64_unscaled(const int (&re)[16], const int (&im)[16], long long (&xr)[16], long long (&xi)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xr[r] = re[r], xi[r] = im[r];
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) { // STAGE 1: even positions Y = D; odd positions Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re
+        long long dr = xr[g] - xr[g + 2], di = xi[g] - xi[g + 2];
+        xr[g] += xr[g + 2], xi[g] += xi[g + 2];
+        xr[g + 2] = dr, xi[g + 2] = di;
+        dr = xr[g + 1] - xr[g + 3], di = xi[g + 1] - xi[g + 3];
+        xr[g + 1] += xr[g + 3], xi[g + 1] += xi[g + 3];
+        xr[g + 3] = di, xi[g + 3] = (dr >> 63) - dr;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) { // STAGE 0
+        const long long dr = xr[g] - xr[g + 1], di = xi[g] - xi[g + 1];
+        xr[g] += xr[g + 1], xi[g] += xi[g + 1];
+        xr[g + 1] = dr, xi[g + 1] = di;
+    }
+}
+
 } // namespace intfft

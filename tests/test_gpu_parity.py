@@ -454,6 +454,18 @@ def test_general_width_inverse_kernels(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_ifft"), info
 
 
+@pytest.mark.parametrize("case", [(10, 24, 24), (10, 24, 16), (10, 23, 18), (11, 23, 24), (11, 22, 16), (12, 22, 24), (12, 21, 16)])
+def test_unscaled_results_of_33_and_34_bits(case):
+    """Unscaled plans whose results need 33 / 34 bits (24-bit data at N = 1024, 22-bit at N = 4096): every multiplier stage
+    still fits 32 bits, the two multiplier-free stages run in 64 bits, results in int64 containers."""
+    log2n, dw, tw = case
+    n = 1 << log2n
+    for new in (True, False):
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(9, n, dw, 170 + dw), uniform_frames(30, n, dw - 1, 171 + dw)])
+        info = check(x, log2n, dw, tw, 1, 0, new)
+        assert info["fast_path"] == 1 and info["out_container"] == 8, info
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
@@ -479,7 +491,7 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
 AB_CASES = [(4, 16, 16, 0, 0, "PAIR"), (5, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
             (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
             (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
-            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD")]
+            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD"), (10, 24, 24, 1, 0, "FWD"), (12, 22, 16, 1, 0, "FWD")]
 
 
 @pytest.mark.parametrize("case", AB_CASES)
