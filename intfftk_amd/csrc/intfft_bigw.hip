@@ -224,19 +224,248 @@ __global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, con
     }
 }
 
+// ---- inverse passes (int_ifftNk, mirrors of the three passes above) ------------------------------------------------------
+// four DIT stages s0 .. s0+3 on register offsets 1, 2, 4, 8; only the first NS of them
+template <int MODE, bool MASKED, int NS, int S0>
+__device__ __forceinline__ void gstages_dit(int (&re)[16], int (&im)[16], const int (&w8r)[8], const int (&w8i)[8],
+                                            const int (&w4r)[4], const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2],
+                                            int w1r, int w1i, const W32Args &a)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly_dit<MODE, false, MASKED>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
+    if constexpr (NS >= 2) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 4)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                gfly_dit<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j], a.st[S0 + 1]);
+    }
+    if constexpr (NS >= 3) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                gfly_dit<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j], a.st[S0 + 2]);
+    }
+    if constexpr (NS >= 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gfly_dit<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j], a.st[S0 + 3]);
+    }
+}
+
+// inverse pass 3: bit-reversed load of the natural-order input (1-2 KiB runs) + DIT 0..3, user array -> scratch
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, const UConsts c, const W32Args a, size_t nframes, int L)
+{
+    __shared__ u32 lds[PLANEG3];
+    const int tid = threadIdx.x;
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes);
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const size_t off = (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);
+    int re[16], im[16];
+    if (a.in16) {
+        const u32 *src = static_cast<const u32 *>(in) + off;
+        u32 raw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off);
+        v2i x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
+    }
+    // DIT 0..3 on regs n3..0
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly_dit_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        gfly_dit_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+        gfly_dit_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gfly_dit<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gfly_dit<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+    // transpose to thread = (px = n(L-5)..n(L-8), e = n4..0), regs q = n(L-1)..n(L-4): rev8(16 q + px) = tid & 255
+    const int px = rev4g((tid >> 4) & 15), jq = rev4g(tid & 15);
+    u32 *w = lds + ROWG * (32 * px + 16 * (tid >> 8)) + jq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[ROWG * r] = (u32)re[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) re[q] = (int)lds[ROWG * tid + q];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[ROWG * r] = (u32)im[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) im[q] = (int)lds[ROWG * tid + q];
+    int2 *dst = scr + (frame << L) + mid * 32 + (tid & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dst[(size_t)(16 * q + (tid >> 5)) << (L - 8)] = make_int2(re[q], im[q]);
+}
+
+// inverse pass 2: DIT 4..11 on every 4096-point block, in place
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(256) void k_bigw_q2(int2 *scr, const int2 *__restrict__ twt, const W32Args a, size_t nblocks4k)
+{
+    __shared__ u32 lds[2 * PLANEG2];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    int a8r[8], a8i[8], a4r[4], a4i[4], a2r[2], a2i[2], a1r, a1i;
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+    {
+        int2 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[2047 + 256 * j + tid], a8r[j] = w.x, a8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[1023 + 256 * j + tid], a4r[j] = w.x, a4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[511 + 256 * j + tid], a2r[j] = w.x, a2i[j] = w.y;
+        w = twt[255 + tid], a1r = w.x, a1i = w.y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], b2r[j] = w.x, b2i[j] = w.y;
+        w = twt[15 + lo4], b1r = w.x, b1i = w.y;
+    }
+    u32 *const wr = lds + ROWG * lo4 + hi4;
+    const u32 *const rd = lds + ROWG * tid;
+    auto transpose = [&](int (&re)[16], int (&im)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            wr[ROWG * 16 * j] = (u32)re[j];
+            wr[PLANEG2 + ROWG * 16 * j] = (u32)im[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)rd[r], im[r] = (int)rd[PLANEG2 + r];
+        __syncthreads();
+    };
+    for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
+        int2 *p = scr + b * 4096;
+        int re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int2 x = p[256 * j + tid]; // LA
+            re[j] = x.x, im[j] = x.y;
+        }
+        transpose(re, im); // LB: regs = n7..4
+        gstages_dit<MODE, MASKED, 4, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+        transpose(re, im); // LA: regs = n11..8
+        gstages_dit<MODE, MASKED, 4, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[256 * r + tid] = make_int2(re[r], im[r]);
+    }
+}
+
+// inverse pass 1: DIT 12..L-1 on groups of 2^(16-L) frames, scratch -> user array (natural order)
+template <int L, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_q1(const int2 *scr, void *out, const int2 *__restrict__ twt, const W32Args a,
+                                                 size_t nframes_user, unsigned groups)
+{
+    static_assert(L >= 13 && L <= 16, "one-round pass");
+    constexpr int NS = L - 12, G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G;
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const unsigned lfull = chunk * 512 + threadIdx.x;
+    int w8r[8] = {}, w8i[8] = {}, w4r[4] = {}, w4i[4] = {}, w2r[2] = {}, w2i[2] = {}, w1r, w1i;
+    {
+        int2 w;
+        if constexpr (NS >= 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w = twt[(1u << 15) - 1u + lfull + (unsigned)j * 4096u], w8r[j] = w.x, w8i[j] = w.y;
+        }
+        if constexpr (NS >= 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w = twt[(1u << 14) - 1u + lfull + (unsigned)j * 4096u], w4r[j] = w.x, w4i[j] = w.y;
+        }
+        if constexpr (NS >= 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w = twt[(1u << 13) - 1u + lfull + (unsigned)j * 4096u], w2r[j] = w.x, w2i[j] = w.y;
+        }
+        w = twt[(1u << 12) - 1u + lfull], w1r = w.x, w1i = w.y;
+    }
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user;
+        const int2 *src = scr + frame * 65536 + lfull;
+        int re[16], im[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int2 x = make_int2(0, 0);
+            if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) x = src[(size_t)j << 12];
+            re[j] = x.x, im[j] = x.y;
+        }
+        gstages_dit<MODE, MASKED, NS, 12>(re, im, w8r, w8i, w4r, w4i, w2r, w2i, w1r, w1i, a);
+        if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + frame * 65536 + lfull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user)
+                    __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), dst + ((size_t)j << 12));
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + frame * 65536 + lfull);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) {
+                    const v2i y = {re[j], im[j]};
+                    __builtin_nontemporal_store(y, dst + ((size_t)j << 12));
+                }
+        }
+    }
+}
+
 bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                     int out_order)
 {
     return log2n >= 13 && log2n <= 16 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
-           twdl_width <= 26 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+           twdl_width <= 26 && (direction == 0 || direction == 1) && use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
-const char *bigw_kernel_name() { return "k_bigw_p1/p2/p3"; }
+const char *bigw_kernel_name(int direction) { return direction == 1 ? "k_bigw_q3/q2/q1" : "k_bigw_p1/p2/p3"; }
+
+template <int MODE, bool MASKED>
+static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, void *out, int2 *scr, const int2 *tw, const UConsts &c,
+                                  size_t nframes, hipStream_t stream)
+{
+    static int cus = 0, q2_per_cu = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q2_per_cu, k_bigw_q2<MODE, MASKED>, 256, 0) != hipSuccess || q2_per_cu <= 0)
+            q2_per_cu = 2;
+    }
+    const size_t nb = nframes << (log2n - 12), cap = (size_t)cus * (size_t)q2_per_cu, nb3 = nframes << (log2n - 13);
+    if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_bigw_q3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, c, a, nframes, log2n);
+    hipLaunchKernelGGL((k_bigw_q2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
+    const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+    const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
+    switch (log2n) {
+    case 13: hipLaunchKernelGGL((k_bigw_q1<13, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, scr, out, tw, a, nframes, groups); break;
+    case 14: hipLaunchKernelGGL((k_bigw_q1<14, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, scr, out, tw, a, nframes, groups); break;
+    case 15: hipLaunchKernelGGL((k_bigw_q1<15, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, scr, out, tw, a, nframes, groups); break;
+    default: hipLaunchKernelGGL((k_bigw_q1<16, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, scr, out, tw, a, nframes, groups); break;
+    }
+    return hipGetLastError();
+}
 
 template <int MODE, bool MASKED>
 static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, void *out, int2 *scr, const int2 *tw, const UConsts &c,
                                 size_t nframes, hipStream_t stream)
 {
+    if (a.inverse) return launch_bigw_inv<MODE, MASKED>(log2n, a, in, out, scr, tw, c, nframes, stream);
     static int cus = 0, p2_per_cu = 0;
     if (!cus) {
         int dev = 0;

@@ -148,6 +148,7 @@ struct W32Args {
     W32Stage st[16]; // by STAGE number
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
+    int inverse;     // stage records describe int_ifftNk (DIT)
     int out64;       // unscaled results of 33 / 34 bits: stages 1, 0 in 64 bits, int64 containers
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
 };
@@ -173,7 +174,7 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
                     int out_order);
 hipError_t launch_bigw(int log2n, int mode, const W32Args &a, const void *in, void *out, void *scratch, const int2 *tw_all,
                        const int2 *h_tw, size_t nframes, hipStream_t stream);
-const char *bigw_kernel_name();
+const char *bigw_kernel_name(int direction);
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

@@ -467,6 +467,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             pl->w32args.st[d.s] = W32Stage{d.sh_a + d.sh_b, ~((1u << d.sh_a) - 1u), 32 - d.mw, 32 - d.wo};
             if (d.s >= 2 && d.sh_a != 0) pl->w32args.masked = 1;
         }
+        pl->w32args.inverse = p->direction == INTFFT_INV;
         pl->w32args.in16 = pl->in_cb == 2;
         pl->w32args.out16 = pl->out_cb == 2;
         pl->w32args.in_sh = 32 - p->data_width;
@@ -525,7 +526,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name() : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));

@@ -165,6 +165,9 @@ def test_general_width_three_pass_kernels(log2n, batch, case):
     x[0] = edge_frames(n, dw)[4]
     info = check(x, log2n, dw, tw, fmt, rnd, True)
     assert info["kernel_name"].startswith("k_bigw") and info["n_passes"] == 3, info
+    if batch in (259, 131, 3, 5):  # the inverse through the mirrored passes
+        info = check(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
+        assert info["kernel_name"].startswith("k_bigw_q3") and info["n_passes"] == 3, info
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 5), (16, 3), (17, 3), (18, 5), (19, 3), (20, 1)])
@@ -491,7 +494,7 @@ def test_fast1024u_matches_the_generic_pass_kernel(monkeypatch):
 AB_CASES = [(4, 16, 16, 0, 0, "PAIR"), (5, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "FWD"), (7, 16, 16, 0, 1, "FWD"), (7, 16, 16, 0, 0, "PAIR"), (7, 16, 16, 1, 0, "PAIR"),
             (9, 16, 16, 1, 0, "INV"), (10, 16, 16, 0, 0, "INV"), (11, 16, 16, 0, 0, "PAIR"), (12, 16, 16, 1, 0, "FWD"),
             (12, 16, 16, 0, 1, "FWD"), (10, 14, 18, 0, 0, "FWD"), (13, 16, 16, 0, 0, "FWD"), (15, 16, 16, 0, 0, "FWD"),
-            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD"), (10, 24, 24, 1, 0, "FWD"), (12, 22, 16, 1, 0, "FWD")]
+            (16, 24, 24, 1, 0, "FWD"), (18, 16, 16, 0, 0, "FWD"), (14, 16, 16, 0, 0, "PAIR"), (17, 16, 16, 0, 0, "PAIR"), (13, 16, 16, 0, 0, "INV"), (18, 16, 16, 0, 0, "INV"), (14, 16, 16, 1, 0, "FWD"), (16, 12, 16, 0, 1, "FWD"), (10, 24, 24, 1, 0, "FWD"), (12, 22, 16, 1, 0, "FWD"), (14, 16, 16, 1, 0, "INV"), (15, 12, 16, 0, 0, "INV")]
 
 
 @pytest.mark.parametrize("case", AB_CASES)
