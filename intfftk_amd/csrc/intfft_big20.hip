@@ -44,72 +44,75 @@ __device__ __forceinline__ void ld_tw(const uint2 *__restrict__ t, unsigned idx,
 // ---- pass 1: stages 19..12 ---------------------------------------------------------------------------
 // grid = 128 chunks x G frame groups; a workgroup keeps its chunk's 30 twiddle pairs in registers and walks
 // the frames g, g + G, ... of the launch (the twiddles depend on the chunk, not on the frame)
-template <int L, bool FAST_OK>
+// LOWB = 12: the three-pass split above.  LOWB = 8 (N = 2^13 .. 2^16, two-pass split): the same tile walk on a virtual
+// 2^16-point frame, stages 15..8, rows n15..8 at stride 256, 8 chunks of 32 consecutive n7..0; k_mid_p2 finishes.
+template <int L, bool FAST_OK, int LOWB = 12>
 __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes_user,
                                                   unsigned groups, const Slice sl, int halves)
 {
-    static_assert(L >= 17 && L <= 20, "two-round pass 1");
-    constexpr int NS1 = L - 16, G = 1 << (20 - L);       // executed stages of round 1; frames per virtual frame
+    static_assert(L >= LOWB + 5 && L <= LOWB + 8, "two-round pass 1");
+    constexpr int LV = LOWB + 8, NS1 = L - (LOWB + 4), G = 1 << (LV - L); // virtual frame; executed stages of round 1; frames per virtual frame
+    constexpr unsigned ROW = 1u << LOWB, ROW16 = 16u << LOWB;
     const size_t nframes = (nframes_user + G - 1) / G;   // virtual 2^20-point frames
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n15..12 (round 1) / n19..16 (round 2)
-    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..127
-    const unsigned lfull = chunk * 32 + l;                                   // n11..0
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..2^LOWB/32 - 1
+    const unsigned lfull = chunk * 32 + l;                                   // n(LOWB-1)..0
 
     // round 1: stages 19..16; twiddle index = (n mod 2^s) = ((j mod 2^i) * 16 + hx) * 4096 + lfull
     // round 2: stages 15..12; twiddle index = (reg mod 2^i) * 4096 + lfull
     RoundTw t1, t2;
     {
-        const unsigned b = hx * 4096u + lfull;
+        const unsigned b = hx * ROW + lfull;
         if constexpr (NS1 >= 4) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << (LV - 1)) - 1u + b + (unsigned)j * ROW16, t1.wa8[j], t1.wb8[j]);
         }
         if constexpr (NS1 >= 3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << (LV - 2)) - 1u + b + (unsigned)j * ROW16, t1.wa4[j], t1.wb4[j]);
         }
         if constexpr (NS1 >= 2) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << (LV - 3)) - 1u + b + (unsigned)j * ROW16, t1.wa2[j], t1.wb2[j]);
         }
-        ld_tw(twf, (1u << 16) - 1u + b, t1.wa1[0], t1.wb1[0]);
+        ld_tw(twf, (1u << (LV - 4)) - 1u + b, t1.wa1[0], t1.wb1[0]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t2.wa8[j], t2.wb8[j]);
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << (LOWB + 3)) - 1u + lfull + (unsigned)j * ROW, t2.wa8[j], t2.wb8[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t2.wa4[j], t2.wb4[j]);
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << (LOWB + 2)) - 1u + lfull + (unsigned)j * ROW, t2.wa4[j], t2.wb4[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t2.wa2[j], t2.wb2[j]);
-        ld_tw(twf, (1u << 12) - 1u + lfull, t2.wa1[0], t2.wb1[0]);
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << (LOWB + 1)) - 1u + lfull + (unsigned)j * ROW, t2.wa2[j], t2.wb2[j]);
+        ld_tw(twf, ROW - 1u + lfull, t2.wa1[0], t2.wb1[0]);
     }
     const v2s none = {0, 0};
-    const short s2 = (short)(1 - (hx & 1)); // round 2: kind of the inputs = n16 = (tid >> 5) & 1
+    const short s2 = (short)(1 - (hx & 1)); // round 2: kind of the inputs = n(LOWB+4) = (tid >> 5) & 1
     const v2s sh2 = {s2, s2};
 
     for (size_t frame = grp; frame < nframes; frame += groups) {
-        const u32 *src = in + frame * ((size_t)1 << L20) + lfull;
-        u32 *dst = scr + frame * ((size_t)1 << L20) + lfull;
+        const u32 *src = in + frame * ((size_t)1 << LV) + lfull;
+        u32 *dst = scr + frame * ((size_t)1 << LV) + lfull;
         u32 v[16];
-        const bool partial = L < 20 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
+        const bool partial = L < LV && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
         if (halves) { // HALVES beats (x[i], x[i + N/2]): beat 65536 jj + 4096 hx + n11..0 of the group -> regs (j0, j0 | 2^(L-17))
             typedef u32 v2u __attribute__((ext_vector_type(2)));
-            const v2u *src2 = reinterpret_cast<const v2u *>(in + frame * ((size_t)1 << L20)) + ((size_t)hx << 12) + lfull;
+            const v2u *src2 = reinterpret_cast<const v2u *>(in + frame * ((size_t)1 << LV)) + ((size_t)hx << LOWB) + lfull;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                constexpr int HB = 1 << (L - 17);
-                const int j0 = ((jj >> (L - 17)) << (L - 16)) | (jj & (HB - 1));
+                constexpr int HS = L - (LOWB + 5), HB = 1 << HS;
+                const int j0 = ((jj >> HS) << (HS + 1)) | (jj & (HB - 1));
                 v2u w = {0u, 0u};
-                if (!partial || frame * G + (size_t)(jj >> (L - 17)) < nframes_user) w = __builtin_nontemporal_load(src2 + (size_t)jj * 65536);
+                if (!partial || frame * G + (size_t)(jj >> HS) < nframes_user) w = __builtin_nontemporal_load(src2 + (size_t)jj * ROW16);
                 v[j0] = w.x;
                 v[j0 | HB] = w.y;
             }
         } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user ? src[(size_t)(16 * j + hx) << 12] : 0u;
+                v[j] = frame * G + (size_t)((16 * j + hx) >> (L - LOWB)) < nframes_user ? src[(size_t)(16 * j + hx) << LOWB] : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 12)); // regs = n19..16
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << LOWB)); // regs = n19..16
         }
         // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
         // the barrier also orders the previous frame's LDS reads before this frame's writes
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         if (partial) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (frame * G + (size_t)((16 * hx + r) >> (L - 12)) < nframes_user) dst[(size_t)(16 * hx + r) << 12] = v[r];
+                if (frame * G + (size_t)((16 * hx + r) >> (L - LOWB)) < nframes_user) dst[(size_t)(16 * hx + r) << LOWB] = v[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << 12] = v[r];
+            for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << LOWB] = v[r];
         }
     }
 }
@@ -458,6 +461,74 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
     for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
 }
 
+// ---- two-pass split, N = 2^13 .. 2^16: pass 2 = stages 7..0 and the bit-reversed (natural-order) store --------------
+// After k_big20_p1<L, ., 8> (stages L-1..8) every 256 consecutive points are an independent 256-point DIF whose twiddles
+// depend on n7..0 only.  tile = 32 rows R = n(L-1)..n(L-5) x 256 consecutive n7..0 (mid = n(L-6)..n8 fixed), 512 threads:
+//   round 1  thread = (R, n3..0), regs = n7..4 (64-B runs per row), stages 7..4, twiddles frame- and row-invariant
+//   LDS transpose -> thread = (n7..4, rev5(R)), regs = n3..0, stages 3..0 (constant twiddles)
+//   store    X index = brev_L(n) = rev4(n3..0) << (L-4) | rev4(n7..4) << (L-8) | rev(mid) << 5 | rev5(R): 128-B runs
+// kind of the inputs = n8 (pass 1 left Y >> 1 where n8 = 1) = mid bit 0, or R bit 0 when L = 13.
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const int2 *__restrict__ twt, const RoundCConsts c,
+                                                size_t nframes, const Slice sl, int L)
+{
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-6)..n8: L - 13 bits
+    RoundTw tb;
+    {
+        auto ld = [&](int idx, u32 &wa, u32 &wb) {
+            const int2 w = twt[idx];
+            wa = pack_wa(w);
+            wb = pack_wb(w);
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
+        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    }
+    const u32 *src = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
+    u32 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[16 * j]; // regs = n7..4
+    const int k8 = L > 13 ? (int)(mid & 1u) : (R & 1);
+    const short sa = (short)(1 - k8);
+    const v2s sh_a = {sa, sa};
+    bool fast = false;
+    if (FAST_OK) { // vote on the tile's own inputs (closed under stages 7..0); the threshold depends on the kind
+        const u32 addc = k8 ? 0x20002000u : 0x40004000u, maskc = k8 ? 0xC000C000u : 0x80008000u;
+        u32 acc = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
+        fast = __syncthreads_or((acc & maskc) != 0) == 0;
+    }
+    if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
+    else dif_round<false, true>(v, tb, sl, sh_a);
+    // transpose: (thread (R, n3..0), reg j = n7..4) -> (thread 32 j + rev5(R), reg n3..0)
+    {
+        const int rR = (int)(__brev((unsigned)R) >> 27);
+        u32 *w = lds + ROWB * rR + lo4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWB * 32 * j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * tid + r];
+    const int hi4 = tid >> 5;                     // n7..4
+    const short s3 = (short)(1 - (hi4 & 1));      // kind = n4
+    const v2s sh3 = {s3, s3};
+    if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
+    else dif_round_c<false>(v, c, sl, sh3);
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    u32 *dst = out + (frame << L) + ((size_t)rev4b(hi4) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
+}
+
 // ---- inverse pass 3 (mirror of pass 3): bit-reversed load of the natural-order input + DIT STAGE 0..3 -----------------
 template <bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const RoundCConsts c, size_t nframes, const Slice sl, int L)
@@ -614,9 +685,9 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
                              : in_order == 0 && out_order == 0);
 }
 
-const char *big20_kernel_name(int direction)
+const char *big20_kernel_name(int direction, int two_pass)
 {
-    return direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
+    return two_pass ? "k_big20_p1/k_mid_p2" : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
 }
 
 template <int L>
@@ -709,21 +780,13 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, cons
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
-    static int cus = 0, q2_per_cu = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q2_per_cu, k_big20_q2<true>, 256, 0) != hipSuccess || q2_per_cu <= 0)
-            q2_per_cu = 4;
-    }
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t cap = (size_t)cus * (size_t)q2_per_cu;
+    const size_t cap = resident_blocks(kptr(k_big20_q2<true>), 256, 4, 0, false);
     const unsigned g2 = (unsigned)(nb < cap ? nb : cap);
-    const size_t nch = nframes << (log2n - 10), ccap = (size_t)cus * 8; // k_big_c: 1024-sample chunks, one per wave pass
+    const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8; // k_big_c: 1024-sample chunks, one per wave pass
     const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
     if (fx) {
         if (in_bitrev) hipLaunchKernelGGL((k_big_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, c, nch, sl);
@@ -747,8 +810,8 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, cons
     return hipGetLastError();
 }
 
-hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
-                        const int2 *h_tw, size_t nframes, hipStream_t stream)
+hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int two_pass, const void *in, void *out, void *scratch,
+                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -765,14 +828,27 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    }
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
+    if (two_pass && log2n <= 16 && !out_bitrev) { // two-pass split: stages L-1..8, then stages 7..0 + the bit-reversed store
+        const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+        const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
+        const size_t nb2 = nframes << (log2n - 13);
+        if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
+#define INTFFT_P1A(LL)                                                                                                           \
+    if (fx) hipLaunchKernelGGL((k_big20_p1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, in_halves); \
+    else hipLaunchKernelGGL((k_big20_p1<LL, false, 8>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, in_halves)
+        switch (log2n) {
+        case 13: INTFFT_P1A(13); break;
+        case 14: INTFFT_P1A(14); break;
+        case 15: INTFFT_P1A(15); break;
+        default: INTFFT_P1A(16); break;
+        }
+#undef INTFFT_P1A
+        if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_p2<false>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
+        return hipGetLastError();
+    }
     switch (log2n) {
     case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
     case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
@@ -784,14 +860,11 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const
     default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream, in_halves); break;
     }
     const size_t nb = nframes << (log2n - 12);
-    static int p2_per_cu = 0;
-    if (!p2_per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2_per_cu, k_big20_p2<true>, 256, 0) != hipSuccess || p2_per_cu <= 0))
-        p2_per_cu = 4;
-    const size_t cap = (size_t)cus * (size_t)p2_per_cu;
+    const size_t cap = resident_blocks(kptr(k_big20_p2<true>), 256, 4, 0, false);
     const size_t nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     const unsigned g2 = (unsigned)(nb < cap ? nb : cap), g3 = (unsigned)nb3;
-    const size_t nch = nframes << (log2n - 10), ccap = (size_t)cus * 8;
+    const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
     const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
     if (fx) {
         hipLaunchKernelGGL(k_big20_p2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);

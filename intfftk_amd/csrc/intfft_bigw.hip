@@ -438,15 +438,7 @@ template <int MODE, bool MASKED>
 static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, void *out, int2 *scr, const int2 *tw, const UConsts &c,
                                   size_t nframes, hipStream_t stream)
 {
-    static int cus = 0, q2_per_cu = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q2_per_cu, k_bigw_q2<MODE, MASKED>, 256, 0) != hipSuccess || q2_per_cu <= 0)
-            q2_per_cu = 2;
-    }
-    const size_t nb = nframes << (log2n - 12), cap = (size_t)cus * (size_t)q2_per_cu, nb3 = nframes << (log2n - 13);
+    const size_t nb = nframes << (log2n - 12), cap = resident_blocks(kptr(k_bigw_q2<MODE, MASKED>), 256, 2, 0, false), nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_bigw_q3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, c, a, nframes, log2n);
     hipLaunchKernelGGL((k_bigw_q2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
@@ -466,14 +458,6 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
                                 size_t nframes, hipStream_t stream)
 {
     if (a.inverse) return launch_bigw_inv<MODE, MASKED>(log2n, a, in, out, scr, tw, c, nframes, stream);
-    static int cus = 0, p2_per_cu = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&p2_per_cu, k_bigw_p2<MODE, MASKED>, 256, 0) != hipSuccess || p2_per_cu <= 0)
-            p2_per_cu = 2;
-    }
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
     const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
     switch (log2n) {
@@ -482,7 +466,7 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
     case 15: hipLaunchKernelGGL((k_bigw_p1<15, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
     default: hipLaunchKernelGGL((k_bigw_p1<16, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;
     }
-    const size_t nb = nframes << (log2n - 12), cap = (size_t)cus * (size_t)p2_per_cu, nb3 = nframes << (log2n - 13);
+    const size_t nb = nframes << (log2n - 12), cap = resident_blocks(kptr(k_bigw_p2<MODE, MASKED>), 256, 2, 0, false), nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_bigw_p2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
     hipLaunchKernelGGL((k_bigw_p3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, scr, out, c, a, nframes, log2n);

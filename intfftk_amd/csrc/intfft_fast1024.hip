@@ -420,22 +420,9 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
                            const Slice &sl, int in_halves, hipStream_t stream)
 {
     // persistent waves: exactly the resident grid (occupancy x CUs), so no block waits for a slot
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>, 256,
-                                                         0) != hipSuccess ||
-            per_cu <= 0)
-            per_cu = 4;
-        if (PIPE && per_cu > 4) per_cu = 4; // 2 frames in flight per wave: 4 waves/SIMD saturate HBM and balance 65536 frames
-        const int e = env_int("INTFFT_BLOCKS_PER_CU", 0);
-        if (e > 0) per_cu = e;
-    }
+    const size_t cap = resident_blocks(kptr(k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>), 256, 4, PIPE ? 4 : 0);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L); // 1024-sample chunks, one per wave pass
     const size_t need = (chunks + 3) / 4;
-    const size_t cap = (size_t)cus * (size_t)per_cu;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
     hipLaunchKernelGGL((k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out,
                        tw, c, nframes, sl, in_halves);

@@ -250,18 +250,9 @@ template <int L, int MODE, bool FAST_OK>
 static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                           const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
 {
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024x_i16<L, MODE, FAST_OK>, 256, 0) != hipSuccess ||
-            per_cu <= 0)
-            per_cu = 4;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
+    const size_t cap = resident_blocks(kptr(k_fft1024x_i16<L, MODE, FAST_OK>), 256, 4);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
-    const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    const size_t need = (chunks + 3) / 4;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
     hipLaunchKernelGGL((k_fft1024x_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
                        in_bitrev, out_halves);

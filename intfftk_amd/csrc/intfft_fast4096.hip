@@ -279,17 +279,7 @@ template <int L, int MODE, bool FAST_OK, bool OB = false>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream, int halves = 0)
 {
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_i16<L, MODE, FAST_OK, OB>, 256, 0) != hipSuccess ||
-            per_cu <= 0)
-            per_cu = 2;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
-    const size_t cap = (size_t)cus * (size_t)per_cu;
+    const size_t cap = resident_blocks(kptr(k_fft4096_i16<L, MODE, FAST_OK, OB>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
     const unsigned blocks = (unsigned)(chunks < cap ? chunks : cap);
     hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK, OB>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,

@@ -210,17 +210,8 @@ template <int L, int MODE, bool MASKED>
 static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                            hipStream_t stream)
 {
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft4096_w32<L, MODE, MASKED>, 256, 0) != hipSuccess || per_cu <= 0)
-            per_cu = 2;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
+    const size_t cap = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
-    const size_t cap = (size_t)cus * (size_t)per_cu;
     hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
                        tw, c, a, nframes);
     return hipGetLastError();

@@ -160,16 +160,8 @@ const char *fastsmall_kernel_name() { return "k_fftsmall_i16"; }
 template <int L, int MODE, bool ROUND>
 static hipError_t launch_sm(const u32 *in, u32 *out, const SmallTw &t, size_t nframes, const Slice &sl, hipStream_t stream)
 {
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fftsmall_i16<L, MODE, ROUND>, 256, 0) != hipSuccess || per_cu <= 0)
-            per_cu = 4;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
-    const size_t need = ((nframes + 63) / 64 + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    const size_t cap = resident_blocks(kptr(k_fftsmall_i16<L, MODE, ROUND>), 256, 4);
+    const size_t need = ((nframes + 63) / 64 + 3) / 4;
     hipLaunchKernelGGL((k_fftsmall_i16<L, MODE, ROUND>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, t,
                        nframes, sl);
     return hipGetLastError();

@@ -250,17 +250,9 @@ template <int L, int MODE, bool MASKED>
 static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                           hipStream_t stream)
 {
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft1024_w32<L, MODE, MASKED>, 256, 0) != hipSuccess || per_cu <= 0)
-            per_cu = 2;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
+    const size_t cap = resident_blocks(kptr(k_fft1024_w32<L, MODE, MASKED>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
-    const size_t need = (chunks + 3) / 4, cap = (size_t)cus * (size_t)per_cu;
+    const size_t need = (chunks + 3) / 4;
     hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
                        c, a, nframes);
     return hipGetLastError();

@@ -241,21 +241,11 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = pass_lds_bytes(a, word_bytes);
     if (word_bytes == 4) {
-        static bool attr32 = false;
-        if (!attr32) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass<int32_t>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr32 = true;
-        }
+        allow_max_lds(kptr(&k_pass<int32_t>));
         hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes);
     } else {
-        static bool attr64 = false;
-        if (!attr64) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass<int64_t>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr64 = true;
-        }
+        allow_max_lds(kptr(&k_pass<int64_t>));
         hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes);
     }

@@ -46,6 +46,17 @@ struct PassArgs {
     StageDesc st[MAX_STAGES_PER_PASS];
 };
 
+// ---- launch geometry (intfft_plan.hip) ------------------------------------------------------------------
+// Persistent kernels launch exactly their resident grid.  resident_blocks() = CUs x blocks per CU on the calling
+// thread's current device: the occupancy query for `threads`-wide blocks (`dflt` when it fails), clamped to
+// `max_per_cu` when that is > 0, replaced by INTFFT_BLOCKS_PER_CU when `env_override`.  Results are cached per
+// (kernel, device) under a mutex, so plans on different devices and concurrent callers each see their own entry.
+size_t resident_blocks(const void *kernel, int threads, int dflt, int max_per_cu = 0, bool env_override = true);
+int device_cus(); // CUs of the current device (cached per device)
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB for `kernel`, once per (kernel, device)
+void allow_max_lds(const void *kernel);
+template <typename K> inline const void *kptr(K k) { return reinterpret_cast<const void *>(k); }
+
 // generic kernels (intfft_generic.hip)
 hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
                        size_t nframes, hipStream_t stream);
@@ -196,9 +207,9 @@ const char *wide16_kernel_name();
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order);
-hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
-                        const int2 *h_tw, size_t nframes, hipStream_t stream);
-const char *big20_kernel_name(int direction);
+hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int two_pass, const void *in, void *out, void *scratch,
+                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
+const char *big20_kernel_name(int direction, int two_pass);
 hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
                           const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,

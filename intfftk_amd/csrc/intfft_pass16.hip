@@ -297,12 +297,7 @@ hipError_t launch_pass16(const PassArgs &a, const void *in, void *out, const uin
     const size_t groups = (nframes + (size_t)a.fpb - 1) / (size_t)a.fpb;
     const size_t blocks = groups << (a.L - a.U);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr = true;
-    }
+    allow_max_lds(kptr(&k_pass16));
     hipLaunchKernelGGL(k_pass16, dim3((unsigned)blocks), dim3(pass_threads(a)), pass16_lds_bytes(a), stream, a, in, out,
                        twf, twi, nframes, twd - 1);
     return hipGetLastError();

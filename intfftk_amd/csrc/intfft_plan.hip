@@ -16,8 +16,79 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
+
+namespace intfft {
+
+namespace {
+std::mutex g_geom_mu;
+std::map<std::pair<const void *, int>, int> g_occupancy; // (kernel, device) -> resident blocks per CU (0: query failed)
+std::map<std::pair<const void *, int>, bool> g_max_lds;
+std::map<int, int> g_cus;
+
+int current_device()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+
+int cus_locked(int dev)
+{
+    auto it = g_cus.find(dev);
+    if (it != g_cus.end()) return it->second;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    g_cus[dev] = cus;
+    return cus;
+}
+} // namespace
+
+int device_cus()
+{
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_geom_mu);
+    return cus_locked(dev);
+}
+
+size_t resident_blocks(const void *kernel, int threads, int dflt, int max_per_cu, bool env_override)
+{
+    static const int env = getenv("INTFFT_BLOCKS_PER_CU") ? atoi(getenv("INTFFT_BLOCKS_PER_CU")) : 0;
+    const int dev = current_device();
+    int per_cu, cus;
+    {
+        std::lock_guard<std::mutex> lk(g_geom_mu);
+        cus = cus_locked(dev);
+        const auto key = std::make_pair(kernel, dev);
+        auto it = g_occupancy.find(key);
+        if (it == g_occupancy.end()) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, threads, 0) != hipSuccess || q < 0) q = 0;
+            it = g_occupancy.emplace(key, q).first;
+        }
+        per_cu = it->second;
+    }
+    if (per_cu <= 0) per_cu = dflt;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
+    if (env_override && env > 0) per_cu = env;
+    return (size_t)cus * (size_t)per_cu;
+}
+
+void allow_max_lds(const void *kernel)
+{
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_geom_mu);
+    bool &done = g_max_lds[std::make_pair(kernel, dev)];
+    if (done) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+}
+
+} // namespace intfft
 
 using namespace intfft;
 
@@ -46,6 +117,7 @@ struct intfft_plan {
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
+    bool big_two_pass = false; // N = 2^13 .. 2^16 forward, natural-order output: k_big20_p1<., ., 8> + k_mid_p2
     bool wide16 = false;
     WideArgs wargs{};
     Fast1024Args fargs{};
@@ -505,6 +577,8 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
+        pl->big_two_pass = pl->big20 && p->direction == INTFFT_FWD && p->log2n <= 16 && p->out_order != INTFFT_ORDER_BITREV &&
+                           !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -526,7 +600,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -583,7 +657,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall;
-    info->n_passes = fast ? 1 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : plan->big_two_pass ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
@@ -659,7 +733,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
                                                       plan->d_tw16f, plan->h_tw.data(), nf, stream)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
-                                                    plan->p.out_order == INTFFT_ORDER_BITREV, src, dst, plan->d_scratch, plan->d_tw,
+                                                    plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
             continue;

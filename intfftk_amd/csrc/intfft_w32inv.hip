@@ -396,19 +396,11 @@ template <int L, int MODE, bool MASKED>
 static hipError_t launchxi(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                            hipStream_t stream)
 {
-    static int per_cu = 0, cus = 0;
     constexpr bool BLOCK = L > 10;
-    if (!per_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        hipError_t e;
-        if constexpr (BLOCK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ifft4096_w32<L, MODE, MASKED>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ifft1024_w32<L, MODE, MASKED>, 256, 0);
-        if (e != hipSuccess || per_cu <= 0) per_cu = 2;
-        if (const char *env = getenv("INTFFT_BLOCKS_PER_CU")) per_cu = atoi(env) > 0 ? atoi(env) : per_cu;
-    }
-    const size_t cap = (size_t)cus * (size_t)per_cu;
+    const void *kernel;
+    if constexpr (BLOCK) kernel = kptr(k_ifft4096_w32<L, MODE, MASKED>);
+    else kernel = kptr(k_ifft1024_w32<L, MODE, MASKED>);
+    const size_t cap = resident_blocks(kernel, 256, 2);
     if constexpr (BLOCK) {
         const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
         hipLaunchKernelGGL((k_ifft4096_w32<L, MODE, MASKED>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream,

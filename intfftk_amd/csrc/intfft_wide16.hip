@@ -370,23 +370,14 @@ hipError_t launch_wide16(const WideArgs &a, const void *in, void *out, void *scr
                          const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
-    static int per1 = 0, per2 = 0, cus = 0;
-    if (!per1) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per1, k_wide16_p1, 256, 0) != hipSuccess || per1 <= 0) per1 = 2;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, k_wide16_p2, 256, 0) != hipSuccess || per2 <= 0) per2 = 2;
-        if (const char *e = getenv("INTFFT_BLOCKS_PER_CU")) per1 = per2 = atoi(e) > 0 ? atoi(e) : per1;
-    }
     W2Consts k;
     for (int i = 0; i < 8; ++i) k.wr3[i] = h_tw[7 + i].x, k.wi3[i] = h_tw[7 + i].y;
     for (int i = 0; i < 4; ++i) k.wr2[i] = h_tw[3 + i].x, k.wi2[i] = h_tw[3 + i].y;
     const size_t units = nframes * 16;
-    size_t g1 = (size_t)cus * (size_t)per1 & ~(size_t)15; // a multiple of the 16 column tiles
+    size_t g1 = resident_blocks(kptr(k_wide16_p1), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
     if (g1 < 16) g1 = 16;
     if (g1 > units) g1 = units;
-    size_t g2 = (size_t)cus * (size_t)per2;
+    size_t g2 = resident_blocks(kptr(k_wide16_p2), 256, 2);
     if (g2 > units) g2 = units;
     hipLaunchKernelGGL(k_wide16_p1, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in),
                        static_cast<int2 *>(scratch), tw_all, a, nframes);
