@@ -29,7 +29,6 @@
 
 namespace intfft {
 
-constexpr int L20 = 20;
 constexpr int ROWB = 17; // LDS row stride in dwords: odd -> conflict-free b32 rows and columns
 
 __device__ __forceinline__ constexpr int rev4b(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
@@ -264,12 +263,14 @@ __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, cons
     }
 }
 
-template <int L, bool FAST_OK>
+// LOWB = 8: the inverse two-pass split (N = 2^13 .. 2^16), STAGE 8..L-1 after k_mid_q1
+template <int L, bool FAST_OK, int LOWB = 12>
 __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes_user,
                                                   unsigned groups, const Slice sl, int halves)
 {
-    static_assert(L >= 17 && L <= 20, "two-round pass");
-    constexpr int NS1 = L - 16, G = 1 << (20 - L);
+    static_assert(L >= LOWB + 5 && L <= LOWB + 8, "two-round pass");
+    constexpr int LV = LOWB + 8, NS1 = L - (LOWB + 4), G = 1 << (LV - L);
+    constexpr unsigned ROW = 1u << LOWB, ROW16 = 16u << LOWB;
     const size_t nframes = (nframes_user + G - 1) / G;
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n19..16 (round 1: regs n15..12) / n15..12 (round 2)
@@ -277,40 +278,40 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
     const unsigned lfull = chunk * 32 + l;
     RoundTw t1, t2; // t2: STAGE 15..12 (index depends on n11..0 only); t1: STAGE 19..16 with hx = n15..12
     {
-        const unsigned b = hx * 4096u + lfull;
+        const unsigned b = hx * ROW + lfull;
         if constexpr (NS1 >= 4) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 19) - 1u + b + (unsigned)j * 65536u, t1.wa8[j], t1.wb8[j]);
+            for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << (LV - 1)) - 1u + b + (unsigned)j * ROW16, t1.wa8[j], t1.wb8[j]);
         }
         if constexpr (NS1 >= 3) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 18) - 1u + b + (unsigned)j * 65536u, t1.wa4[j], t1.wb4[j]);
+            for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << (LV - 2)) - 1u + b + (unsigned)j * ROW16, t1.wa4[j], t1.wb4[j]);
         }
         if constexpr (NS1 >= 2) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 17) - 1u + b + (unsigned)j * 65536u, t1.wa2[j], t1.wb2[j]);
+            for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << (LV - 3)) - 1u + b + (unsigned)j * ROW16, t1.wa2[j], t1.wb2[j]);
         }
-        ld_tw(twf, (1u << 16) - 1u + b, t1.wa1[0], t1.wb1[0]);
+        ld_tw(twf, (1u << (LV - 4)) - 1u + b, t1.wa1[0], t1.wb1[0]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << 15) - 1u + lfull + (unsigned)j * 4096u, t2.wa8[j], t2.wb8[j]);
+        for (int j = 0; j < 8; ++j) ld_tw(twf, (1u << (LOWB + 3)) - 1u + lfull + (unsigned)j * ROW, t2.wa8[j], t2.wb8[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << 14) - 1u + lfull + (unsigned)j * 4096u, t2.wa4[j], t2.wb4[j]);
+        for (int j = 0; j < 4; ++j) ld_tw(twf, (1u << (LOWB + 2)) - 1u + lfull + (unsigned)j * ROW, t2.wa4[j], t2.wb4[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << 13) - 1u + lfull + (unsigned)j * 4096u, t2.wa2[j], t2.wb2[j]);
-        ld_tw(twf, (1u << 12) - 1u + lfull, t2.wa1[0], t2.wb1[0]);
+        for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << (LOWB + 1)) - 1u + lfull + (unsigned)j * ROW, t2.wa2[j], t2.wb2[j]);
+        ld_tw(twf, ROW - 1u + lfull, t2.wa1[0], t2.wb1[0]);
     }
     for (size_t frame = grp; frame < nframes; frame += groups) {
-        const u32 *src = scr + frame * ((size_t)1 << L20) + lfull;
-        u32 *dst = out + frame * ((size_t)1 << L20) + lfull;
-        const bool partial = L < 20 && (frame + 1) * G > nframes_user;
+        const u32 *src = scr + frame * ((size_t)1 << LV) + lfull;
+        u32 *dst = out + frame * ((size_t)1 << LV) + lfull;
+        const bool partial = L < LV && (frame + 1) * G > nframes_user;
         u32 v[16];
         if (partial) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                v[r] = frame * G + (size_t)((16 * hx + r) >> (L - 12)) < nframes_user ? src[(size_t)(16 * hx + r) << 12] : 0u;
+                v[r] = frame * G + (size_t)((16 * hx + r) >> (L - LOWB)) < nframes_user ? src[(size_t)(16 * hx + r) << LOWB] : 0u;
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = src[(size_t)(16 * hx + r) << 12]; // thread hx = n19..16, regs = n15..12
+            for (int r = 0; r < 16; ++r) v[r] = src[(size_t)(16 * hx + r) << LOWB]; // thread hx = n19..16, regs = n15..12
         }
         const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // also orders the previous LDS reads
         if (!FAST_OK) __syncthreads();
@@ -326,21 +327,21 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
         else dit_round<false, NS1>(v, t1, sl);
         if (halves) {
             typedef u32 v2u __attribute__((ext_vector_type(2)));
-            v2u *d2 = reinterpret_cast<v2u *>(out + frame * ((size_t)1 << L20)) + ((size_t)hx << 12) + lfull;
+            v2u *d2 = reinterpret_cast<v2u *>(out + frame * ((size_t)1 << LV)) + ((size_t)hx << LOWB) + lfull;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                constexpr int HB = 1 << (L - 17);
-                const int j0 = ((jj >> (L - 17)) << (L - 16)) | (jj & (HB - 1));
+                constexpr int HS = L - (LOWB + 5), HB = 1 << HS;
+                const int j0 = ((jj >> HS) << (HS + 1)) | (jj & (HB - 1));
                 const v2u w = {v[j0], v[j0 | HB]};
-                if (!partial || frame * G + (size_t)(jj >> (L - 17)) < nframes_user) __builtin_nontemporal_store(w, d2 + (size_t)jj * 65536);
+                if (!partial || frame * G + (size_t)(jj >> HS) < nframes_user) __builtin_nontemporal_store(w, d2 + (size_t)jj * ROW16);
             }
         } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if (frame * G + (size_t)((16 * j + hx) >> (L - 12)) < nframes_user) dst[(size_t)(16 * j + hx) << 12] = v[j];
+                if (frame * G + (size_t)((16 * j + hx) >> (L - LOWB)) < nframes_user) dst[(size_t)(16 * j + hx) << LOWB] = v[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)(16 * j + hx) << 12));
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)(16 * j + hx) << LOWB));
         }
     }
 }
@@ -529,6 +530,55 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
     for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
 }
 
+// ---- inverse two-pass split (mirror of k_mid_p2): bit-reversed load of the natural-order input + DIT STAGE 0..7 -------
+// thread = (n7..4, rev5(R)), regs = n3..0 -> STAGE 0..3 -> LDS -> thread = (R, n3..0), regs = n7..4 -> STAGE 4..7 -> scratch
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const int2 *__restrict__ twt, const RoundCConsts c,
+                                                size_t nframes, const Slice sl, int L)
+{
+    __shared__ u32 lds[512 * ROWB];
+    const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4, hi4 = tid >> 5;
+    const size_t frame = blockIdx.x % nframes;
+    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-6)..n8
+    RoundTw tb;
+    {
+        auto ld = [&](int idx, u32 &wa, u32 &wb) {
+            const int2 w = twt[idx];
+            wa = pack_wa(w);
+            wb = pack_wb(w);
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
+        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    }
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const u32 *src = in + (frame << L) + ((size_t)rev4b(hi4) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
+    u32 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + ((size_t)rev4b(r) << (L - 4)));
+    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // the tile is closed under STAGE 0..7
+    if (fast) dit_round_c<FAST_OK>(v, c, sl);
+    else dit_round_c<false>(v, c, sl);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[ROWB * tid + r] = v[r];
+    __syncthreads();
+    {
+        const int rR = (int)(__brev((unsigned)R) >> 27);
+        const u32 *w = lds + ROWB * rR + lo4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = w[ROWB * 32 * j]; // thread = (R, n3..0), regs = n7..4
+    }
+    if (fast) dit_round<FAST_OK>(v, tb, sl);
+    else dit_round<false>(v, tb, sl);
+    u32 *dst = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[16 * j] = v[j];
+}
+
 // ---- inverse pass 3 (mirror of pass 3): bit-reversed load of the natural-order input + DIT STAGE 0..3 -----------------
 template <bool FAST_OK>
 __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const RoundCConsts c, size_t nframes, const Slice sl, int L)
@@ -687,7 +737,7 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 
 const char *big20_kernel_name(int direction, int two_pass)
 {
-    return two_pass ? "k_big20_p1/k_mid_p2" : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
+    return two_pass ? (direction == 1 ? "k_mid_q1/k_big20_q1" : "k_big20_p1/k_mid_p2") : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
 }
 
 template <int L>
@@ -762,8 +812,8 @@ hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *s
 }
 
 // int_ifftNk for N = 2^13 .. 2^20: the three passes mirrored (k_big20_q3, k_big20_q2, k_big16_q1 / k_big20_q1)
-hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
-                         const int2 *h_tw, size_t nframes, hipStream_t stream)
+hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
+                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -784,6 +834,23 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, cons
     const bool fx = twd == 16 && allow_fast;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (two_pass && log2n <= 16 && !in_bitrev) { // two-pass split: bit-reversed load + STAGE 0..7, then STAGE 8..L-1
+        const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+        const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
+        if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_q1<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
+#define INTFFT_Q1A(LL)                                                                                                           \
+    if (fx) hipLaunchKernelGGL((k_big20_q1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, out_halves); \
+    else hipLaunchKernelGGL((k_big20_q1<LL, false, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, out_halves)
+        switch (log2n) {
+        case 13: INTFFT_Q1A(13); break;
+        case 14: INTFFT_Q1A(14); break;
+        case 15: INTFFT_Q1A(15); break;
+        default: INTFFT_Q1A(16); break;
+        }
+#undef INTFFT_Q1A
+        return hipGetLastError();
+    }
     const size_t cap = resident_blocks(kptr(k_big20_q2<true>), 256, 4, 0, false);
     const unsigned g2 = (unsigned)(nb < cap ? nb : cap);
     const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8; // k_big_c: 1024-sample chunks, one per wave pass

@@ -117,7 +117,7 @@ struct intfft_plan {
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
-    bool big_two_pass = false; // N = 2^13 .. 2^16 forward, natural-order output: k_big20_p1<., ., 8> + k_mid_p2
+    bool big_two_pass = false; // N = 2^13 .. 2^16, natural order on the frequency side: k_big20_p1<., ., 8> + k_mid_p2 / k_mid_q1 + k_big20_q1<., ., 8>
     bool wide16 = false;
     WideArgs wargs{};
     Fast1024Args fargs{};
@@ -577,8 +577,9 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
-        pl->big_two_pass = pl->big20 && p->direction == INTFFT_FWD && p->log2n <= 16 && p->out_order != INTFFT_ORDER_BITREV &&
-                           !getenv("INTFFT_NO_TWOPASS");
+        pl->big_two_pass = pl->big20 && p->log2n <= 16 && !getenv("INTFFT_NO_TWOPASS") &&
+                           ((p->direction == INTFFT_FWD && p->out_order != INTFFT_ORDER_BITREV) ||
+                            (p->direction == INTFFT_INV && p->in_order != INTFFT_ORDER_BITREV));
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -727,7 +728,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         if (plan->big20 && (np > 1 || (nf << plan->L) >= ((size_t)1 << 22))) {
             const hipError_t e = plan->p.direction == INTFFT_INV
                                      ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
-                                                     plan->p.out_order == INTFFT_ORDER_HALVES, src, dst, plan->d_scratch, plan->d_tw,
+                                                     plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream)
                                  : plan->p.direction == INTFFT_PAIR
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
