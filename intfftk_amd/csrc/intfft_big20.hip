@@ -725,6 +725,109 @@ __global__ __launch_bounds__(256) void k_big_c(const u32 *src, u32 *dst, const R
     }
 }
 
+// ---- two-pass split with BITREV order on the frequency side, N = 2^13 .. 2^16: the last eight DIF stages (first eight DIT
+// stages) act on 256 consecutive samples.  One wave per 1024 consecutive samples (q = n9 n8 numbers the four 256-point groups):
+//   DIF  regs = n7..4, lane = (q, n3..0): 64-B runs from the scratch; stages 7..4; wave-private LDS transpose to the
+//        k_big_c layout (regs = n3..0, lane = n9..n4); stages 3..0; two lane swaps; dwordx4 stores
+//   DIT  the same walk backwards: dwordx4 loads of the BITREV-ordered input, STAGE 0..3, transpose, STAGE 4..7, scratch
+// kind of the DIF inputs = n8 (k_big20_p1<., ., 8> left Y >> 1 where n8 = 1) = lane bit 4.
+template <bool DIT, bool FAST_OK>
+__global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const int2 *__restrict__ twt, const RoundCConsts c,
+                                               size_t nchunks, const Slice sl)
+{
+    __shared__ u32 lds_all[4 * 64 * ROWB];
+    u32 *const lds = lds_all + (threadIdx.x >> 6) * 64 * ROWB;
+    const int lane = threadIdx.x & 63, lo4 = lane & 15, q = lane >> 4;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const int unit = ((lane & 15) << 2) | (lane >> 4); // as in k_big_c
+    RoundTw tb;
+    {
+        auto ld = [&](int idx, u32 &wa, u32 &wb) {
+            const int2 w = twt[idx];
+            wa = pack_wa(w);
+            wb = pack_wb(w);
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
+        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    }
+    const short sa = (short)(1 - (q & 1)), s3 = (short)(1 - (lane & 1));
+    const v2s sh_a = {sa, sa}, sh3 = {s3, s3};
+    for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
+        u32 v[16];
+        if (!DIT) {
+            const u32 *p = src + ch * 1024 + q * 256 + lo4;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = p[16 * j];
+            bool fast = false;
+            if (FAST_OK) {
+                const u32 addc = (q & 1) ? 0x20002000u : 0x40004000u, maskc = (q & 1) ? 0xC000C000u : 0x80008000u;
+                u32 acc = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
+                fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
+            }
+            if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
+            else dif_round<false, true>(v, tb, sl, sh_a);
+            asm volatile("" ::: "memory"); // keep the previous chunk's reads ahead of these writes
+#pragma unroll
+            for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];
+            asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; // regs = n3..0, lane = n9..n4
+            asm volatile("" ::: "memory");
+            if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
+            else dif_round_c<false>(v, c, sl, sh3);
+            swap_guard(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+            v4u *d4 = reinterpret_cast<v4u *>(dst + ch * 1024) + unit;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v4u x = {v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+                __builtin_nontemporal_store(x, d4 + 64 * k);
+            }
+        } else {
+            const v4u *s4 = reinterpret_cast<const v4u *>(src + ch * 1024) + unit;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v4u x = __builtin_nontemporal_load(s4 + 64 * k);
+                v[4 * k] = x.x, v[4 * k + 1] = x.y, v[4 * k + 2] = x.z, v[4 * k + 3] = x.w;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
+            const bool fast = FAST_OK && frame_has_guard_bit(v); // the 1024 samples are closed under STAGE 0..7
+            if (fast) dit_round_c<FAST_OK>(v, c, sl);
+            else dit_round_c<false>(v, c, sl);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4]; // regs = n7..4, lane = (q, n3..0)
+            asm volatile("" ::: "memory");
+            if (fast) dit_round<FAST_OK>(v, tb, sl);
+            else dit_round<false>(v, tb, sl);
+            u32 *p = dst + ch * 1024 + q * 256 + lo4;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[16 * j] = v[j];
+        }
+    }
+}
+
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
@@ -735,9 +838,11 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
                              : in_order == 0 && out_order == 0);
 }
 
-const char *big20_kernel_name(int direction, int two_pass)
+const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev)
 {
-    return two_pass ? (direction == 1 ? "k_mid_q1/k_big20_q1" : "k_big20_p1/k_mid_p2") : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
+    return two_pass ? (direction == 1 ? (freq_bitrev ? "k_mid_c/k_big20_q1" : "k_mid_q1/k_big20_q1")
+                                      : (freq_bitrev ? "k_big20_p1/k_mid_c" : "k_big20_p1/k_mid_p2"))
+                    : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
 }
 
 template <int L>
@@ -834,10 +939,15 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     const bool fx = twd == 16 && allow_fast;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
-    if (two_pass && log2n <= 16 && !in_bitrev) { // two-pass split: bit-reversed load + STAGE 0..7, then STAGE 8..L-1
+    if (two_pass && log2n <= 16) { // two-pass split: (bit-reversed) load + STAGE 0..7, then STAGE 8..L-1
         const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
-        if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
+        if (in_bitrev) {
+            const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
+            const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+            if (fx) hipLaunchKernelGGL((k_mid_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
+            else hipLaunchKernelGGL((k_mid_c<true, false>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
+        } else if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
         else hipLaunchKernelGGL(k_mid_q1<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
 #define INTFFT_Q1A(LL)                                                                                                           \
     if (fx) hipLaunchKernelGGL((k_big20_q1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, out_halves); \
@@ -897,7 +1007,7 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
-    if (two_pass && log2n <= 16 && !out_bitrev) { // two-pass split: stages L-1..8, then stages 7..0 + the bit-reversed store
+    if (two_pass && log2n <= 16) { // two-pass split: stages L-1..8, then stages 7..0 + the bit-reversed store (or none: BITREV out)
         const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
         const size_t nb2 = nframes << (log2n - 13);
@@ -912,7 +1022,12 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
         default: INTFFT_P1A(16); break;
         }
 #undef INTFFT_P1A
-        if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
+        if (out_bitrev) {
+            const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
+            const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+            if (fx) hipLaunchKernelGGL((k_mid_c<false, true>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
+            else hipLaunchKernelGGL((k_mid_c<false, false>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
+        } else if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
         else hipLaunchKernelGGL(k_mid_p2<false>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
         return hipGetLastError();
     }

@@ -117,7 +117,7 @@ struct intfft_plan {
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
-    bool big_two_pass = false; // N = 2^13 .. 2^16, natural order on the frequency side: k_big20_p1<., ., 8> + k_mid_p2 / k_mid_q1 + k_big20_q1<., ., 8>
+    bool big_two_pass = false; // N = 2^13 .. 2^16 FWD / INV: k_big20_p1<., ., 8> + k_mid_p2 | k_mid_c, k_mid_q1 | k_mid_c + k_big20_q1<., ., 8>
     bool wide16 = false;
     WideArgs wargs{};
     Fast1024Args fargs{};
@@ -577,9 +577,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
-        pl->big_two_pass = pl->big20 && p->log2n <= 16 && !getenv("INTFFT_NO_TWOPASS") &&
-                           ((p->direction == INTFFT_FWD && p->out_order != INTFFT_ORDER_BITREV) ||
-                            (p->direction == INTFFT_INV && p->in_order != INTFFT_ORDER_BITREV));
+        pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -601,7 +599,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass, (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));

@@ -125,18 +125,24 @@ def test_three_pass_kernels_n8192_to_n524288(log2n, batch):
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
-@pytest.mark.parametrize("direction,order", [("FWD", "NATURAL"), ("FWD", "HALVES"), ("INV", "NATURAL"), ("INV", "HALVES")])
-def test_two_pass_vs_three_pass_split(log2n, batch, direction, order, monkeypatch):
-    """N = 2^13 .. 2^16 with natural order on the frequency side: the two-pass split (forward: k_big20_p1<., ., 8> = stages
-    L-1..8 on virtual 2^16-point frames, k_mid_p2 = stages 7..0 + bit-reversed store; inverse: k_mid_q1, k_big20_q1<., ., 8>)
-    against the three-pass split of the same plan (INTFFT_NO_TWOPASS) and the oracle; partial last frame groups, HALVES
-    beats on the time side and one full-scale frame included."""
+@pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "NATURAL", "NATURAL"), ("FWD", "HALVES", "NATURAL"),
+                                                             ("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
+                                                             ("INV", "NATURAL", "NATURAL"), ("INV", "HALVES", "NATURAL"),
+                                                             ("INV", "HALVES", "BITREV"), ("INV", "NATURAL", "BITREV")])
+def test_two_pass_vs_three_pass_split(log2n, batch, direction, time_order, freq_order, monkeypatch):
+    """N = 2^13 .. 2^16: the two-pass split (forward: k_big20_p1<., ., 8> = stages L-1..8 on virtual 2^16-point frames, then
+    k_mid_p2 = stages 7..0 + bit-reversed store, or k_mid_c for BITREV output; inverse: k_mid_q1 / k_mid_c, then
+    k_big20_q1<., ., 8>) against the three-pass split of the same plan (INTFFT_NO_TWOPASS) and the oracle; partial last
+    frame groups, HALVES beats on the time side and one full-scale frame included."""
     n = 1 << log2n
     x = uniform_frames(batch, n, 15, 2100 + log2n)
     x[batch // 2] = uniform_frames(1, n, 16, 9)[0]
-    kw = dict(direction=direction, in_order=order) if direction == "FWD" else dict(direction=direction, out_order=order)
+    kw = (dict(direction=direction, in_order=time_order, out_order=freq_order) if direction == "FWD"
+          else dict(direction=direction, in_order=freq_order, out_order=time_order))
     a, ia = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
-    assert ia["kernel_name"] == ("k_big20_p1/k_mid_p2" if direction == "FWD" else "k_mid_q1/k_big20_q1") and ia["n_passes"] == 2
+    two = {("FWD", "NATURAL"): "k_big20_p1/k_mid_p2", ("FWD", "BITREV"): "k_big20_p1/k_mid_c",
+           ("INV", "NATURAL"): "k_mid_q1/k_big20_q1", ("INV", "BITREV"): "k_mid_c/k_big20_q1"}[(direction, freq_order)]
+    assert ia["kernel_name"] == two and ia["n_passes"] == 2
     monkeypatch.setenv("INTFFT_NO_TWOPASS", "1")
     b, ib = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
     assert ib["kernel_name"] == ("k_big20_p1/p2/p3" if direction == "FWD" else "k_big20_q3/q2/q1") and ib["n_passes"] == 3
@@ -201,7 +207,7 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    two = log2n <= 16 and (out_order if direction == "FWD" else in_order) == "NATURAL"
+    two = log2n <= 16
     assert "k_big20" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 
