@@ -423,8 +423,8 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n(L-5)..n(L-8)
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5: L - 13 bits
+    const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     const u32 *src = scr + (frame << L) + mid * 32 + e;
     u32 v[16];
 #pragma unroll
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-6)..n8: L - 13 bits
+    const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     RoundTw tb;
     {
         auto ld = [&](int idx, u32 &wa, u32 &wb) {
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4, hi4 = tid >> 5;
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-6)..n8
+    const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     RoundTw tb;
     {
         auto ld = [&](int idx, u32 &wa, u32 &wb) {
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x;
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5
+    const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     // thread = (n4 = tid >> 8, rev8(n(L-1)..n(L-8)) = tid & 255), regs = n3..0: X index = brev_L(n) (1 KiB runs)
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     const u32 *src = in + (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);

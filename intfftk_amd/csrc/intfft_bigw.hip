@@ -167,8 +167,8 @@ __global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, con
 {
     __shared__ u32 lds[PLANEG3]; // one 34 KiB plane, used for re then im (two planes would exceed 64 KiB)
     const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n(L-5)..n(L-8)
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes); // n(L-9)..5
+    const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u)); // n(L-9)..5
     const int2 *src = scr + (frame << L) + mid * 32 + e;
     int re[16], im[16];
 #pragma unroll
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, cons
 {
     __shared__ u32 lds[PLANEG3];
     const int tid = threadIdx.x;
-    const size_t frame = blockIdx.x % nframes;
-    const unsigned mid = (unsigned)(blockIdx.x / nframes);
+    const size_t frame = blockIdx.x >> (L - 13);
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     const size_t off = (frame << L) + ((size_t)(tid >> 8) << (L - 5)) + ((size_t)rmid << 8) + (tid & 255);
     int re[16], im[16];
