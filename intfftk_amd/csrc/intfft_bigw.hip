@@ -224,6 +224,183 @@ __global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, con
     }
 }
 
+// ---- two-pass split (forward): 2^16 = 256 x 256, as in intfft_big20.hip (k_big20_p1<., ., 8> + k_mid_p2) ---------------
+// pass A  STAGE L-1..8 on virtual 2^16-point frames: tile = 256 rows n15..8 (stride 256) x 32 consecutive n7..0, 512 threads,
+//         regs = n15..12 -> LDS transpose (one plane, re then im) -> regs = n11..8; both twiddle sets are re-read per
+//         tile (L1 / L2 hits) so that the kernel fits 128 VGPRs = two workgroups per CU
+// pass B  STAGE 7..0 + bit-reversed store: tile = 32 rows n(L-1)..n(L-5) x 256 consecutive n7..0; thread = (R, n3..0), regs =
+//         n7..4 (128-B runs) -> LDS -> thread = (n7..4, rev5(R)), regs = n3..0; the rows are the 5 lowest output bits
+template <int L, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bigw_a(const void *in, int2 *scr, const int2 *__restrict__ twt, const W32Args a,
+                                                size_t nframes_user, unsigned groups)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int NS1 = L - 12, G = 1 << (16 - L);
+    __shared__ u32 lds[PLANEG3];
+    const size_t nframes = (nframes_user + G - 1) / G;
+    const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n11..8 (round 1) / n15..12 (round 2)
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups; // chunk 0..7
+    const unsigned lfull = chunk * 32 + l;                                   // n7..0
+    const unsigned tb1 = (unsigned)hx * 256u + lfull; // round 1: twiddle index = ((j mod 2^i) * 16 + hx) * 256 + lfull
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
+        unsigned lf = lfull, t1 = tb1; // opaque per tile: keeps the (loop-invariant) twiddle loads inside the loop
+        asm volatile("" : "+v"(lf), "+v"(t1));
+        int re[16], im[16];
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + frame * 65536 + lfull;
+            u32 raw[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                raw[j] = (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
+                             ? __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 8))
+                             : 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                re[j] = (int)(raw[j] << a.in_sh) >> a.in_sh, im[j] = (int)(raw[j] << (a.in_sh - 16)) >> a.in_sh;
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + frame * 65536 + lfull);
+            v2i x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                x[j] = v2i{0, 0};
+                if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
+                    x[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 8));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                re[j] = (int)((u32)x[j].x << a.in_sh) >> a.in_sh, im[j] = (int)((u32)x[j].y << a.in_sh) >> a.in_sh;
+        }
+        {
+            int w8r[8] = {}, w8i[8] = {}, w4r[4] = {}, w4i[4] = {}, w2r[2] = {}, w2i[2] = {}, w1r, w1i;
+            int2 w;
+            if constexpr (NS1 >= 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w = twt[(1u << 15) - 1u + t1 + (unsigned)j * 4096u], w8r[j] = w.x, w8i[j] = w.y;
+            }
+            if constexpr (NS1 >= 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w = twt[(1u << 14) - 1u + t1 + (unsigned)j * 4096u], w4r[j] = w.x, w4i[j] = w.y;
+            }
+            if constexpr (NS1 >= 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) w = twt[(1u << 13) - 1u + t1 + (unsigned)j * 4096u], w2r[j] = w.x, w2i[j] = w.y;
+            }
+            w = twt[(1u << 12) - 1u + t1], w1r = w.x, w1i = w.y;
+            gstages<MODE, MASKED, NS1, 12>(re, im, w8r, w8i, w4r, w4i, w2r, w2i, w1r, w1i, a);
+        }
+        // STAGE 11..8 twiddles (index = (reg mod 2^i) * 256 + lfull): issued here, they arrive during the transpose
+        int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+        {
+            int2 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w = twt[2047u + lf + 256u * j], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w = twt[1023u + lf + 256u * j], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w = twt[511u + lf + 256u * j], b2r[j] = w.x, b2i[j] = w.y;
+            w = twt[255u + lf], b1r = w.x, b1i = w.y;
+        }
+        // transpose: (thread (hx = n11..8, l), reg j = n15..12) -> (thread (j, l), reg hx); one plane, re then im
+        {
+            u32 *w = lds + ROWG * l + hx;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[ROWG * 32 * j] = (u32)re[j];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) re[r] = (int)lds[ROWG * tid + r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[ROWG * 32 * j] = (u32)im[j];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) im[r] = (int)lds[ROWG * tid + r];
+            __syncthreads(); // the next tile's writes stay behind these reads
+        }
+        gstages<MODE, MASKED, 4, 8>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+        int2 *dst = scr + frame * 65536 + lfull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (!partial || frame * G + (size_t)((16 * hx + r) >> (L - 8)) < nframes_user) dst[(size_t)(16 * hx + r) << 8] = make_int2(re[r], im[r]);
+    }
+}
+
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_b(const int2 *scr, void *out, const int2 *__restrict__ twt, const UConsts c,
+                                                const W32Args a, size_t nframes, int L)
+{
+    __shared__ u32 lds[PLANEG3];
+    const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
+    const size_t frame = blockIdx.x >> (L - 13);
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u)); // n(L-6)..n8
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+    {
+        int2 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], b2r[j] = w.x, b2i[j] = w.y;
+        w = twt[15 + lo4], b1r = w.x, b1i = w.y;
+    }
+    const int2 *src = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
+    int re[16], im[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int2 x = src[16 * j]; // regs = n7..4
+        re[j] = x.x, im[j] = x.y;
+    }
+    gstages<MODE, MASKED, 4, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+    // transpose: (thread (R, n3..0), reg j = n7..4) -> (thread 32 j + rev5(R), reg n3..0)
+    {
+        u32 *w = lds + ROWG * (int)(__brev((unsigned)R) >> 27) + lo4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWG * 32 * j] = (u32)re[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)lds[ROWG * tid + r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[ROWG * 32 * j] = (u32)im[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) im[r] = (int)lds[ROWG * tid + r];
+    }
+    // stages 3, 2 (uniform twiddles), 1, 0
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        gfly_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+        gfly_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+    // natural order: X index = brev_L(n) = rev4(n3..0) << (L-4) | rev4(n7..4) << (L-8) | brev(mid) << 5 | rev5(R)
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const size_t off = (frame << L) + ((size_t)rev4g(tid >> 5) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
+    if (a.out16) {
+        u32 *dst = static_cast<u32 *>(out) + off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), dst + ((size_t)rev4g(r) << (L - 4)));
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const v2i y = {re[r], im[r]};
+            __builtin_nontemporal_store(y, dst + ((size_t)rev4g(r) << (L - 4)));
+        }
+    }
+}
+
 // ---- inverse passes (int_ifftNk, mirrors of the three passes above) ------------------------------------------------------
 // four DIT stages s0 .. s0+3 on register offsets 1, 2, 4, 8; only the first NS of them
 template <int MODE, bool MASKED, int NS, int S0>
@@ -432,7 +609,10 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
            twdl_width <= 26 && (direction == 0 || direction == 1) && use_fly == 1 && in_order == 0 && out_order == 0;
 }
 
-const char *bigw_kernel_name(int direction) { return direction == 1 ? "k_bigw_q3/q2/q1" : "k_bigw_p1/p2/p3"; }
+const char *bigw_kernel_name(int direction, int two_pass)
+{
+    return direction == 1 ? "k_bigw_q3/q2/q1" : two_pass ? "k_bigw_a/b" : "k_bigw_p1/p2/p3";
+}
 
 template <int MODE, bool MASKED>
 static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, void *out, int2 *scr, const int2 *tw, const UConsts &c,
@@ -459,6 +639,19 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
 {
     if (a.inverse) return launch_bigw_inv<MODE, MASKED>(log2n, a, in, out, scr, tw, c, nframes, stream);
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+    if (a.two_pass) {
+        const unsigned ga = (unsigned)(nvf < 256 ? nvf : 256);
+        const size_t nb2 = nframes << (log2n - 13);
+        if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
+        switch (log2n) {
+        case 13: hipLaunchKernelGGL((k_bigw_a<13, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+        case 14: hipLaunchKernelGGL((k_bigw_a<14, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+        case 15: hipLaunchKernelGGL((k_bigw_a<15, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+        default: hipLaunchKernelGGL((k_bigw_a<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+        }
+        hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, nframes, log2n);
+        return hipGetLastError();
+    }
     const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
     switch (log2n) {
     case 13: hipLaunchKernelGGL((k_bigw_p1<13, MODE, MASKED>), dim3(8u * groups), dim3(512), 0, stream, in, scr, tw, a, nframes, groups); break;

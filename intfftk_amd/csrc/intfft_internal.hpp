@@ -162,6 +162,7 @@ struct W32Args {
     int inverse;     // stage records describe int_ifftNk (DIT)
     int out64;       // unscaled results of 33 / 34 bits: stages 1, 0 in 64 bits, int64 containers
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
+    int two_pass;    // N = 2^13 .. 2^16 forward: k_bigw_a + k_bigw_b instead of the three passes
 };
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                        int out_order);
@@ -185,7 +186,7 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
                     int out_order);
 hipError_t launch_bigw(int log2n, int mode, const W32Args &a, const void *in, void *out, void *scratch, const int2 *tw_all,
                        const int2 *h_tw, size_t nframes, hipStream_t stream);
-const char *bigw_kernel_name(int direction);
+const char *bigw_kernel_name(int direction, int two_pass);
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

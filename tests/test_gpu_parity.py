@@ -180,9 +180,10 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
 
 @pytest.mark.parametrize("log2n,batch", [(13, 259), (13, 1030), (14, 131), (15, 3), (15, 70), (16, 5), (16, 33)])
 @pytest.mark.parametrize("case", [(16, 16, 1, 0), (16, 16, 0, 1), (12, 16, 0, 0), (18, 24, 0, 0), (10, 18, 1, 0), (32, 16, 0, 0)])
-def test_general_width_three_pass_kernels(log2n, batch, case):
+def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
     """N = 2^13 .. 2^16 with widths within 32 bits (the unscaled 16-bit transform reaches exactly 32 bits at N = 65536):
-    three passes on int32 pairs, frame groups as virtual 2^16-point frames in pass 1."""
+    int32 pairs, frame groups as virtual 2^16-point frames in the first pass; forward = the two-pass split k_bigw_a/b,
+    compared with the three passes of the same plan (INTFFT_NO_TWOPASS) and the oracle."""
     dw, tw, fmt, rnd = case
     if dw + fmt * log2n > 32:
         pytest.skip("results exceed 32 bits")
@@ -190,7 +191,11 @@ def test_general_width_three_pass_kernels(log2n, batch, case):
     x = uniform_frames(batch, n, dw, 6000 + log2n + dw)
     x[0] = edge_frames(n, dw)[4]
     info = check(x, log2n, dw, tw, fmt, rnd, True)
-    assert info["kernel_name"].startswith("k_bigw") and info["n_passes"] == 3, info
+    assert info["kernel_name"] == "k_bigw_a/b" and info["n_passes"] == 2, info
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_TWOPASS", "1")
+        info = check(x, log2n, dw, tw, fmt, rnd, True)
+        assert info["kernel_name"] == "k_bigw_p1/p2/p3" and info["n_passes"] == 3, info
     if batch in (259, 131, 3, 5):  # the inverse through the mirrored passes
         info = check(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
         assert info["kernel_name"].startswith("k_bigw_q3") and info["n_passes"] == 3, info
