@@ -602,6 +602,172 @@ __global__ __launch_bounds__(512) void k_bigw_q1(const int2 *scr, void *out, con
     }
 }
 
+// ---- inverse two-pass split (mirrors of k_bigw_b / k_bigw_a) ----------------------------------------------------------------
+// first pass: bit-reversed load of the natural-order input (128-B runs), thread = (n7..4, rev5(R)), regs = n3..0: DIT 0..3,
+// LDS transpose to thread = (R, n3..0), regs = n7..4: DIT 4..7, scratch
+template <int MODE, bool MASKED>
+__global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, const int2 *__restrict__ twt, const UConsts c,
+                                                 const W32Args a, size_t nframes, int L)
+{
+    __shared__ u32 lds[PLANEG3];
+    const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
+    const size_t frame = blockIdx.x >> (L - 13);
+    const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u)); // n(L-6)..n8
+    const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
+    const size_t off = (frame << L) + ((size_t)rev4g(tid >> 5) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
+    int re[16], im[16];
+    if (a.in16) {
+        const u32 *src = static_cast<const u32 *>(in) + off;
+        u32 raw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
+    } else {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off);
+        v2i x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
+    }
+    // DIT 0..3 on regs n3..0
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) gfly_dit_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        gfly_dit_triv<MODE, false>(re[g], im[g], re[g + 2], im[g + 2], a.st[1]);
+        gfly_dit_triv<MODE, true>(re[g + 1], im[g + 1], re[g + 3], im[g + 3], a.st[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gfly_dit<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) gfly_dit<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+    {
+        int2 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], b2r[j] = w.x, b2i[j] = w.y;
+        w = twt[15 + lo4], b1r = w.x, b1i = w.y;
+    }
+    // transpose: (thread 32 hi4 + rev5(R), reg n3..0) -> (thread (R, n3..0), reg j = n7..4)
+    {
+        const u32 *rd = lds + ROWG * (int)(__brev((unsigned)R) >> 27) + lo4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[ROWG * tid + r] = (u32)re[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) re[j] = (int)rd[ROWG * 32 * j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[ROWG * tid + r] = (u32)im[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) im[j] = (int)rd[ROWG * 32 * j];
+    }
+    gstages_dit<MODE, MASKED, 4, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+    int2 *dst = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dst[16 * j] = make_int2(re[j], im[j]);
+}
+
+// second pass: DIT 8..L-1 on virtual 2^16-point frames (tiles, twiddle re-reads and occupancy as k_bigw_a), scratch -> user
+template <int L, int MODE, bool MASKED>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bigw_qa(const int2 *scr, void *out, const int2 *__restrict__ twt, const W32Args a,
+                                                 size_t nframes_user, unsigned groups)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int NS1 = L - 12, G = 1 << (16 - L);
+    __shared__ u32 lds[PLANEG3];
+    const size_t nframes = (nframes_user + G - 1) / G;
+    const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5; // hx = n15..12 (round 1: regs n11..8) / n11..8 (round 2: regs n15..12)
+    const unsigned chunk = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const unsigned lfull = chunk * 32 + l;
+    const unsigned tb1 = (unsigned)hx * 256u + lfull;
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const bool partial = L < 16 && (frame + 1) * G > nframes_user;
+        unsigned lf = lfull, t1 = tb1; // opaque per tile: keeps the twiddle loads inside the loop (see k_bigw_a)
+        asm volatile("" : "+v"(lf), "+v"(t1));
+        const int2 *src = scr + frame * 65536 + lfull;
+        int re[16], im[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int2 x = make_int2(0, 0);
+            if (!partial || frame * G + (size_t)((16 * hx + r) >> (L - 8)) < nframes_user) x = src[(size_t)(16 * hx + r) << 8];
+            re[r] = x.x, im[r] = x.y;
+        }
+        {
+            int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+            int2 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w = twt[2047u + lf + 256u * j], b8r[j] = w.x, b8i[j] = w.y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w = twt[1023u + lf + 256u * j], b4r[j] = w.x, b4i[j] = w.y;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) w = twt[511u + lf + 256u * j], b2r[j] = w.x, b2i[j] = w.y;
+            w = twt[255u + lf], b1r = w.x, b1i = w.y;
+            gstages_dit<MODE, MASKED, 4, 8>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
+        }
+        int w8r[8] = {}, w8i[8] = {}, w4r[4] = {}, w4i[4] = {}, w2r[2] = {}, w2i[2] = {}, w1r, w1i;
+        {
+            int2 w; // STAGE 12..15 twiddles for the thread after the transpose: its tid >> 5 is then n11..8, as tb1 assumes
+            if constexpr (NS1 >= 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w = twt[(1u << 15) - 1u + t1 + (unsigned)j * 4096u], w8r[j] = w.x, w8i[j] = w.y;
+            }
+            if constexpr (NS1 >= 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w = twt[(1u << 14) - 1u + t1 + (unsigned)j * 4096u], w4r[j] = w.x, w4i[j] = w.y;
+            }
+            if constexpr (NS1 >= 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) w = twt[(1u << 13) - 1u + t1 + (unsigned)j * 4096u], w2r[j] = w.x, w2i[j] = w.y;
+            }
+            w = twt[(1u << 12) - 1u + t1], w1r = w.x, w1i = w.y;
+        }
+        // transpose: (thread (hx = n15..12, l), reg r = n11..8) -> (thread (r, l), reg hx)
+        {
+            u32 *w = lds + ROWG * l + hx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[ROWG * 32 * r] = (u32)re[r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) re[j] = (int)lds[ROWG * tid + j];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[ROWG * 32 * r] = (u32)im[r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) im[j] = (int)lds[ROWG * tid + j];
+            __syncthreads();
+        }
+        gstages_dit<MODE, MASKED, NS1, 12>(re, im, w8r, w8i, w4r, w4i, w2r, w2i, w1r, w1i, a); // regs j = n15..12, thread hx = n11..8
+        if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + frame * 65536 + lfull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
+                    __builtin_nontemporal_store(((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), dst + ((size_t)(16 * j + hx) << 8));
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + frame * 65536 + lfull);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) {
+                    const v2i y = {re[j], im[j]};
+                    __builtin_nontemporal_store(y, dst + ((size_t)(16 * j + hx) << 8));
+                }
+        }
+    }
+}
+
 bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                     int out_order)
 {
@@ -611,7 +777,7 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
 
 const char *bigw_kernel_name(int direction, int two_pass)
 {
-    return direction == 1 ? "k_bigw_q3/q2/q1" : two_pass ? "k_bigw_a/b" : "k_bigw_p1/p2/p3";
+    return direction == 1 ? (two_pass ? "k_bigw_qb/qa" : "k_bigw_q3/q2/q1") : two_pass ? "k_bigw_a/b" : "k_bigw_p1/p2/p3";
 }
 
 template <int MODE, bool MASKED>
@@ -620,6 +786,18 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
 {
     const size_t nb = nframes << (log2n - 12), cap = resident_blocks(kptr(k_bigw_q2<MODE, MASKED>), 256, 2, 0, false), nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (a.two_pass) {
+        const size_t nvfa = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+        const unsigned ga = (unsigned)(nvfa < 256 ? nvfa : 256);
+        hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, nframes, log2n);
+        switch (log2n) {
+        case 13: hipLaunchKernelGGL((k_bigw_qa<13, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+        case 14: hipLaunchKernelGGL((k_bigw_qa<14, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+        case 15: hipLaunchKernelGGL((k_bigw_qa<15, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+        default: hipLaunchKernelGGL((k_bigw_qa<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_bigw_q3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, c, a, nframes, log2n);
     hipLaunchKernelGGL((k_bigw_q2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);

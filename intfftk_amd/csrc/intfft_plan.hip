@@ -545,7 +545,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         pl->w32args.in_sh = 32 - p->data_width;
         if (pl->in_cb > 4 || (pl->out_cb > 4) != (pl->w32args.out64 != 0)) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
         if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
-        pl->w32args.two_pass = pl->bigw && p->direction == INTFFT_FWD && !getenv("INTFFT_NO_TWOPASS");
+        pl->w32args.two_pass = pl->bigw && !getenv("INTFFT_NO_TWOPASS");
     }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());

@@ -196,9 +196,13 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
         m.setenv("INTFFT_NO_TWOPASS", "1")
         info = check(x, log2n, dw, tw, fmt, rnd, True)
         assert info["kernel_name"] == "k_bigw_p1/p2/p3" and info["n_passes"] == 3, info
-    if batch in (259, 131, 3, 5):  # the inverse through the mirrored passes
+    if batch in (259, 131, 3, 5, 1030):  # the inverse through the mirrored passes
         info = check(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
-        assert info["kernel_name"].startswith("k_bigw_q3") and info["n_passes"] == 3, info
+        assert info["kernel_name"] == "k_bigw_qb/qa" and info["n_passes"] == 2, info
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_TWOPASS", "1")
+            info = check(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
+            assert info["kernel_name"] == "k_bigw_q3/q2/q1" and info["n_passes"] == 3, info
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 5), (16, 3), (17, 3), (18, 5), (19, 3), (20, 1)])
