@@ -11,7 +11,7 @@ for L in (3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20):
     ROWS.append(("%d:16:16:0" % L, "16-bit scaled-trunc FWD"))
 for L in (7, 10, 12):
     ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
-for L in (7, 10, 11, 12, 14, 17, 20):
+for L in (7, 10, 11, 12, 14, 16, 17, 20):
     ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
     ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
 for L in (7, 10, 11, 12, 14, 16):
@@ -29,6 +29,9 @@ ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("12:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("10:12:16:0:0:INV", "12-bit scaled INV"))
 ROWS.append(("12:16:16:1:0:INV", "16-bit unscaled INV"))
+ROWS.append(("14:16:16:1:0:INV", "16-bit unscaled INV"))
+ROWS.append(("16:16:16:1:0:INV", "16-bit unscaled INV"))
+ROWS.append(("16:32:24:0", "32-bit scaled FWD"))
 
 NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (native int_fftNk beats)"),
           ("12:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
