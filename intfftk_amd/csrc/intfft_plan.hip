@@ -615,7 +615,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : pl->word == 2 ? 2 : pl->passes[0].word);
-            size_t scratch_mb = (pl->big20 || pl->bigw) ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
+            size_t scratch_mb = (pl->big20 || pl->bigw || pl->wide16) ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
             if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
