@@ -711,7 +711,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
-        if (plan->bigw && (np > 1 || (nf << plan->L) >= ((size_t)1 << 21))) {
+        // (also for one-frame batches: a lone N = 8192 frame takes 10 us here, 21-53 us as one workgroup of the generic pass)
+        if (plan->bigw) {
             const hipError_t e = launch_bigw(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, src, dst,
                                              plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
@@ -723,8 +724,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             if (e != hipSuccess) return (int)e;
             continue;
         }
-        // short single-pass lengths (N = 8192, 16384) keep the one-pass generic kernel for small batches
-        if (plan->big20 && (np > 1 || (nf << plan->L) >= ((size_t)1 << 22))) {
+        if (plan->big20) {
             const hipError_t e = plan->p.direction == INTFFT_INV
                                      ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                                      plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,

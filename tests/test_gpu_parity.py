@@ -150,6 +150,26 @@ def test_two_pass_vs_three_pass_split(log2n, batch, direction, time_order, freq_
     assert np.array_equal(a, run_ref(x, log2n, 16, 16, 0, 0, True, **kw))
 
 
+@pytest.mark.parametrize("log2n", [13, 14, 15])
+@pytest.mark.parametrize("batch", [1, 2, 7, 9])
+def test_multi_pass_kernels_small_batches(log2n, batch):
+    """A few frames only (partial virtual 2^16-point frames, grids of a handful of workgroups): the dedicated multi-pass
+    kernels serve every batch size -- a lone N = 8192 frame takes 10 us through them, 21-53 us as one workgroup of the
+    generic pass kernel."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 2500 + log2n + batch)
+    x[0] = uniform_frames(1, n, 16, 11)[0]
+    for direction in ("FWD", "INV", "PAIR"):
+        info = check(x, log2n, 16, 16, 0, 0, True, direction=direction)
+        assert "k_big20" in info["kernel_name"], info
+    for kw in (dict(in_order="HALVES", out_order="BITREV"), dict(direction="INV", in_order="BITREV", out_order="HALVES")):
+        check(x, log2n, 16, 16, 0, 0, True, **kw)
+    for direction in ("FWD", "INV"):  # general widths: unscaled 16-bit, 12-bit scaled-round
+        info = check(x, log2n, 16, 16, 1, 0, True, direction=direction)
+        assert info["kernel_name"].startswith("k_bigw"), info
+        check(x >> 4, log2n, 12, 16, 0, 1, True, direction=direction)
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 3), (15, 130), (16, 5), (17, 3), (17, 9), (18, 5), (19, 3),
                                          (20, 2)])
 def test_three_pass_pair_n8192_to_n2pow20(log2n, batch):
