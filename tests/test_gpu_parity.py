@@ -708,7 +708,8 @@ def test_hip_graph_capture_and_replay():
 
     from intfftk_amd import int_fft_ifft_pair, int_fft_single_path
 
-    for core in (int_fft_single_path(10, 16, 16, 0, 0), int_fft_ifft_pair(12, 16, 16, 0, 0), int_fft_single_path(7, 16, 16, 1, 0)):
+    for core in (int_fft_single_path(10, 16, 16, 0, 0), int_fft_ifft_pair(12, 16, 16, 0, 0), int_fft_single_path(7, 16, 16, 1, 0),
+                 int_fft_single_path(14, 16, 16, 0, 0), int_fft_single_path(13, 16, 16, 1, 0)):  # the last two: two-pass plans
         x = torch.from_numpy(uniform_frames(16, core.n, 15, 3).astype(np.int16)).cuda()
         y = torch.empty((16, core.n, 2), dtype=core.out_dtype, device="cuda")
         core(x, out=y)  # warm: one-time occupancy queries happen outside the capture
