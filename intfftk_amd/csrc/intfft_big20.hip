@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
 
 // ---- pass 3: stages 3..0 and the bit-reversed (natural-order) store ----------------------------------
 template <bool FAST_OK>
-__global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, const RoundCConsts c, size_t nframes, const Slice sl,
+__global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, const RoundCConsts c, const Slice sl,
                                                   int L)
 {
     __shared__ u32 lds[512 * ROWB];
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
 // kind of the inputs = n8 (pass 1 left Y >> 1 where n8 = 1) = mid bit 0, or R bit 0 when L = 13.
 template <bool FAST_OK>
 __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const int2 *__restrict__ twt, const RoundCConsts c,
-                                                size_t nframes, const Slice sl, int L)
+                                                const Slice sl, int L)
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
 // thread = (n7..4, rev5(R)), regs = n3..0 -> STAGE 0..3 -> LDS -> thread = (R, n3..0), regs = n7..4 -> STAGE 4..7 -> scratch
 template <bool FAST_OK>
 __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const int2 *__restrict__ twt, const RoundCConsts c,
-                                                size_t nframes, const Slice sl, int L)
+                                                const Slice sl, int L)
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4, hi4 = tid >> 5;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
 
 // ---- inverse pass 3 (mirror of pass 3): bit-reversed load of the natural-order input + DIT STAGE 0..3 -----------------
 template <bool FAST_OK>
-__global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const RoundCConsts c, size_t nframes, const Slice sl, int L)
+__global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const RoundCConsts c, const Slice sl, int L)
 {
     __shared__ u32 lds[512 * ROWB];
     const int tid = threadIdx.x;
@@ -952,8 +952,8 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
             const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
             if (fx) hipLaunchKernelGGL((k_mid_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
             else hipLaunchKernelGGL((k_mid_c<true, false>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
-        } else if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
-        else hipLaunchKernelGGL(k_mid_q1<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, nframes, sl, log2n);
+        } else if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_q1<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, sl, log2n);
 #define INTFFT_Q1A(LL)                                                                                                           \
     if (fx) hipLaunchKernelGGL((k_big20_q1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, out_halves); \
     else hipLaunchKernelGGL((k_big20_q1<LL, false, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, out_halves)
@@ -972,11 +972,11 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
     if (fx) {
         if (in_bitrev) hipLaunchKernelGGL((k_big_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, c, nch, sl);
-        else hipLaunchKernelGGL(k_big20_q3<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_big20_q3<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, sl, log2n);
         hipLaunchKernelGGL(k_big20_q2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
     } else {
         if (in_bitrev) hipLaunchKernelGGL((k_big_c<true, false>), dim3(gc), dim3(256), 0, stream, pin, scr, c, nch, sl);
-        else hipLaunchKernelGGL(k_big20_q3<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_big20_q3<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, c, sl, log2n);
         hipLaunchKernelGGL(k_big20_q2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
     }
     switch (log2n) {
@@ -1032,8 +1032,8 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
             const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
             if (fx) hipLaunchKernelGGL((k_mid_c<false, true>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
             else hipLaunchKernelGGL((k_mid_c<false, false>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
-        } else if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
-        else hipLaunchKernelGGL(k_mid_p2<false>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, nframes, sl, log2n);
+        } else if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_p2<false>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, sl, log2n);
         return hipGetLastError();
     }
     switch (log2n) {
@@ -1056,11 +1056,11 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     if (fx) {
         hipLaunchKernelGGL(k_big20_p2<true>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
         if (out_bitrev) hipLaunchKernelGGL((k_big_c<false, true>), dim3(gc), dim3(256), 0, stream, scr, pout, c, nch, sl);
-        else hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_big20_p3<true>, dim3(g3), dim3(512), 0, stream, scr, pout, c, sl, log2n);
     } else {
         hipLaunchKernelGGL(k_big20_p2<false>, dim3(g2), dim3(256), 0, stream, scr, tw_all, nb, sl);
         if (out_bitrev) hipLaunchKernelGGL((k_big_c<false, false>), dim3(gc), dim3(256), 0, stream, scr, pout, c, nch, sl);
-        else hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, nframes, sl, log2n);
+        else hipLaunchKernelGGL(k_big20_p3<false>, dim3(g3), dim3(512), 0, stream, scr, pout, c, sl, log2n);
     }
     return hipGetLastError();
 }

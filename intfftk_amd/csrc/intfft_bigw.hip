@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_bigw_p2(int2 *scr, const int2 *__restri
 
 // ---- pass 3 ----------------------------------------------------------------------------------------------------
 template <int MODE, bool MASKED>
-__global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, const UConsts c, const W32Args a, size_t nframes, int L)
+__global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, const UConsts c, const W32Args a, int L)
 {
     __shared__ u32 lds[PLANEG3]; // one 34 KiB plane, used for re then im (two planes would exceed 64 KiB)
     const int tid = threadIdx.x, e = tid & 31, px = tid >> 5; // e = n4..0, px = n(L-5)..n(L-8)
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 template <int MODE, bool MASKED>
 __global__ __launch_bounds__(512) void k_bigw_b(const int2 *scr, void *out, const int2 *__restrict__ twt, const UConsts c,
-                                                const W32Args a, size_t nframes, int L)
+                                                const W32Args a, int L)
 {
     __shared__ u32 lds[PLANEG3];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
@@ -432,7 +432,7 @@ __device__ __forceinline__ void gstages_dit(int (&re)[16], int (&im)[16], const 
 
 // inverse pass 3: bit-reversed load of the natural-order input (1-2 KiB runs) + DIT 0..3, user array -> scratch
 template <int MODE, bool MASKED>
-__global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, const UConsts c, const W32Args a, size_t nframes, int L)
+__global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, const UConsts c, const W32Args a, int L)
 {
     __shared__ u32 lds[PLANEG3];
     const int tid = threadIdx.x;
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(512) void k_bigw_q1(const int2 *scr, void *out, con
 // LDS transpose to thread = (R, n3..0), regs = n7..4: DIT 4..7, scratch
 template <int MODE, bool MASKED>
 __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, const int2 *__restrict__ twt, const UConsts c,
-                                                 const W32Args a, size_t nframes, int L)
+                                                 const W32Args a, int L)
 {
     __shared__ u32 lds[PLANEG3];
     const int tid = threadIdx.x, lo4 = tid & 15, R = tid >> 4;
@@ -789,7 +789,7 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
     if (a.two_pass) {
         const size_t nvfa = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned ga = (unsigned)(nvfa < 256 ? nvfa : 256);
-        hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, nframes, log2n);
+        hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
         switch (log2n) {
         case 13: hipLaunchKernelGGL((k_bigw_qa<13, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
         case 14: hipLaunchKernelGGL((k_bigw_qa<14, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
@@ -798,7 +798,7 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
         }
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((k_bigw_q3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, c, a, nframes, log2n);
+    hipLaunchKernelGGL((k_bigw_q3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, c, a, log2n);
     hipLaunchKernelGGL((k_bigw_q2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
     const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
@@ -827,7 +827,7 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
         case 15: hipLaunchKernelGGL((k_bigw_a<15, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
         default: hipLaunchKernelGGL((k_bigw_a<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
         }
-        hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, nframes, log2n);
+        hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
         return hipGetLastError();
     }
     const unsigned groups = (unsigned)(nvf < 128 ? nvf : 128);
@@ -840,7 +840,7 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
     const size_t nb = nframes << (log2n - 12), cap = resident_blocks(kptr(k_bigw_p2<MODE, MASKED>), 256, 2, 0, false), nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_bigw_p2<MODE, MASKED>), dim3((unsigned)(nb < cap ? nb : cap)), dim3(256), 0, stream, scr, tw, a, nb);
-    hipLaunchKernelGGL((k_bigw_p3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, scr, out, c, a, nframes, log2n);
+    hipLaunchKernelGGL((k_bigw_p3<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, scr, out, c, a, log2n);
     return hipGetLastError();
 }
 
