@@ -351,6 +351,25 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
     }
 }
 
+// twiddles of a four-stage register round from the int2 ROM/Taylor table: STAGE s0+3 .. s0 with regs = n(s0+3)..n(s0) and
+// `low` = n(s0-1)..n0 of the thread (table index = position mod 2^s)
+template <int S0> __device__ __forceinline__ void load_round_tw(const int2 *__restrict__ twt, int low, RoundTw &t)
+{
+    auto ld = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = twt[idx];
+        wa = pack_wa(w);
+        wb = pack_wb(w);
+    };
+    constexpr int R = 1 << S0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ld((8 * R - 1) + R * j + low, t.wa8[j], t.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ld((4 * R - 1) + R * j + low, t.wa4[j], t.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ld((2 * R - 1) + R * j + low, t.wa2[j], t.wb2[j]);
+    ld((R - 1) + low, t.wa1[0], t.wb1[0]);
+}
+
 // ---- pass 2: stages 11..4 on 4096 consecutive points, in place ----------------------------------------
 template <bool FAST_OK>
 __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restrict__ twt, size_t nblocks4k, const Slice sl)
@@ -359,25 +378,8 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
     u32 *const reg0 = lds, *const reg1 = lds + 256 * ROWB;
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
     RoundTw ta, tb;
-    auto ld = [&](int idx, u32 &wa, u32 &wb) {
-        const int2 w = twt[idx];
-        wa = pack_wa(w);
-        wb = pack_wb(w);
-    };
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ld(1023 + 256 * j + tid, ta.wa4[j], ta.wb4[j]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ld(511 + 256 * j + tid, ta.wa2[j], ta.wb2[j]);
-    ld(255 + tid, ta.wa1[0], ta.wb1[0]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
-    ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    load_round_tw<8>(twt, tid, ta);   // STAGE 11..8, low = n7..0
+    load_round_tw<4>(twt, lo4, tb);   // STAGE 7..4, low = n3..0
     const short sb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
     const v2s sh_b = {sb, sb};
 
@@ -483,20 +485,7 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
     const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
     const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     RoundTw tb;
-    {
-        auto ld = [&](int idx, u32 &wa, u32 &wb) {
-            const int2 w = twt[idx];
-            wa = pack_wa(w);
-            wb = pack_wb(w);
-        };
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
-        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
-    }
+    load_round_tw<4>(twt, lo4, tb); // STAGE 7..4, low = n3..0
     const u32 *src = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
     u32 v[16];
 #pragma unroll
@@ -546,20 +535,7 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
     const size_t frame = blockIdx.x >> (L - 13); // frame-major: the tiles of one frame are neighbouring blocks (adjacent rows / runs)
     const unsigned mid = (unsigned)(blockIdx.x & ((1u << (L - 13)) - 1u));
     RoundTw tb;
-    {
-        auto ld = [&](int idx, u32 &wa, u32 &wb) {
-            const int2 w = twt[idx];
-            wa = pack_wa(w);
-            wb = pack_wb(w);
-        };
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
-        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
-    }
+    load_round_tw<4>(twt, lo4, tb); // STAGE 7..4, low = n3..0
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     const u32 *src = in + (frame << L) + ((size_t)rev4b(hi4) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
     u32 v[16];
@@ -624,25 +600,8 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
     u32 *const reg0 = lds, *const reg1 = lds + 256 * ROWB;
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
     RoundTw ta, tb;
-    auto ld = [&](int idx, u32 &wa, u32 &wb) {
-        const int2 w = twt[idx];
-        wa = pack_wa(w);
-        wb = pack_wb(w);
-    };
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ld(2047 + 256 * j + tid, ta.wa8[j], ta.wb8[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ld(1023 + 256 * j + tid, ta.wa4[j], ta.wb4[j]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ld(511 + 256 * j + tid, ta.wa2[j], ta.wb2[j]);
-    ld(255 + tid, ta.wa1[0], ta.wb1[0]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
-    ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    load_round_tw<8>(twt, tid, ta);   // STAGE 11..8, low = n7..0
+    load_round_tw<4>(twt, lo4, tb);   // STAGE 7..4, low = n3..0
 
     for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
         u32 *p = scr + b * 4096;
@@ -747,20 +706,7 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
     typedef u32 v4u __attribute__((ext_vector_type(4)));
     const int unit = ((lane & 15) << 2) | (lane >> 4); // as in k_big_c
     RoundTw tb;
-    {
-        auto ld = [&](int idx, u32 &wa, u32 &wb) {
-            const int2 w = twt[idx];
-            wa = pack_wa(w);
-            wb = pack_wb(w);
-        };
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ld(127 + 16 * j + lo4, tb.wa8[j], tb.wb8[j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ld(63 + 16 * j + lo4, tb.wa4[j], tb.wb4[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
-        ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
-    }
+    load_round_tw<4>(twt, lo4, tb); // STAGE 7..4, low = n3..0
     const short sa = (short)(1 - (q & 1)), s3 = (short)(1 - (lane & 1));
     const v2s sh_a = {sa, sa}, sh3 = {s3, s3};
     for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
