@@ -779,6 +779,58 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
     }
 }
 
+// ---- pair, 256 x 256 split (N = 2^13 .. 2^16): the whole pair of STAGE 7..0 / 0..7 on every 256-point group, in place.
+// k_mid_c's forward and inverse halves back to back: the bit reversal between the cores cancels (int_fft_ifft_pair.vhd:242-280),
+// so the DIF result at core index n is the DIT input at core index n.  One guard-bit vote on the inputs covers all 16 stages.
+template <bool FAST_OK>
+__global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restrict__ twt, const RoundCConsts c, size_t nchunks,
+                                                  const Slice sl)
+{
+    __shared__ u32 lds_all[4 * 64 * ROWB];
+    u32 *const lds = lds_all + (threadIdx.x >> 6) * 64 * ROWB;
+    const int lane = threadIdx.x & 63, lo4 = lane & 15, q = lane >> 4;
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    RoundTw tb;
+    load_round_tw<4>(twt, lo4, tb);
+    const short sa = (short)(1 - (q & 1)), s3 = (short)(1 - (lane & 1)); // kinds: n8 = lane bit 4, then n4 = lane bit 0
+    const v2s sh_a = {sa, sa}, sh3 = {s3, s3};
+    for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
+        u32 *p = scr + ch * 1024 + q * 256 + lo4;
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[16 * j]; // regs = n7..4, lane = (q, n3..0)
+        bool fast = false;
+        if (FAST_OK) {
+            const u32 addc = (q & 1) ? 0x20002000u : 0x40004000u, maskc = (q & 1) ? 0xC000C000u : 0x80008000u;
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
+            fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
+        }
+#define INTFFT_MIDPAIR(FX)                                                                                       \
+    {                                                                                                            \
+        dif_round<FX, true>(v, tb, sl, sh_a);                                                                    \
+        asm volatile("" ::: "memory");                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];                    \
+        asm volatile("" ::: "memory"); /* LDS ops of one wave execute in order */                                \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; /* regs n3..0, lane n9..n4 */ \
+        asm volatile("" ::: "memory");                                                                           \
+        dif_round_c<FX>(v, c, sl, sh3);                                                                          \
+        dit_round_c<FX>(v, c, sl);                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];                              \
+        asm volatile("" ::: "memory");                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4];                    \
+        asm volatile("" ::: "memory");                                                                           \
+        dit_round<FX>(v, tb, sl);                                                                                \
+    }
+        if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK)
+        else INTFFT_MIDPAIR(false)
+#undef INTFFT_MIDPAIR
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p[16 * j] = v[j];
+    }
+}
+
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
@@ -791,7 +843,8 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev)
 {
-    return two_pass ? (direction == 1 ? (freq_bitrev ? "k_mid_c/k_big20_q1" : "k_mid_q1/k_big20_q1")
+    return two_pass ? (direction == 2 ? "k_big20_p1/k_mid_pair/q1"
+                       : direction == 1 ? (freq_bitrev ? "k_mid_c/k_big20_q1" : "k_mid_q1/k_big20_q1")
                                       : (freq_bitrev ? "k_big20_p1/k_mid_c" : "k_big20_p1/k_mid_p2"))
                     : direction == 1 ? "k_big20_q3/q2/q1" : direction == 2 ? "k_big20_p1/k_fft4096_i16<MID>/q1" : "k_big20_p1/p2/p3";
 }
@@ -833,8 +886,8 @@ static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, si
 // FFT -> IFFT pair for N = 2^13 .. 2^20 in three passes: DIF STAGE L-1..12 (pass 1 above), then the whole pair of
 // STAGE 11..0 / 0..11 on every 4096-point block in place (k_fft4096_i16<MODE_MID>: the bit reversal between the cores
 // cancels, int_fft_ifft_pair.vhd:242-280), then DIT STAGE 12..L-1 (k_big16_q1 / k_big20_q1).
-hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
-                          const int2 *h_tw, size_t nframes, hipStream_t stream)
+hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
@@ -842,6 +895,41 @@ hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *s
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
+    if (two_pass && log2n <= 16) { // 256 x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
+        RoundCConsts c;
+        for (int k = 0; k < 8; ++k) {
+            const int2 w = h_tw[7 + k];
+            c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+            c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+        }
+        for (int k = 0; k < 4; ++k) {
+            const int2 w = h_tw[3 + k];
+            c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+            c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+        }
+        const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+        const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
+        const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
+        const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+#define INTFFT_PAIR256(LL)                                                                                                       \
+    if (fx) {                                                                                                                    \
+        hipLaunchKernelGGL((k_big20_p1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, 0); \
+        hipLaunchKernelGGL(k_mid_pair<true>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);                           \
+        hipLaunchKernelGGL((k_big20_q1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, 0); \
+    } else {                                                                                                                     \
+        hipLaunchKernelGGL((k_big20_p1<LL, false, 8>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, 0); \
+        hipLaunchKernelGGL(k_mid_pair<false>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);                          \
+        hipLaunchKernelGGL((k_big20_q1<LL, false, 8>), dim3(8u * groups), dim3(512), 0, stream, scr, pout, tw16f, nframes, groups, sl, 0); \
+    }
+        switch (log2n) {
+        case 13: INTFFT_PAIR256(13) break;
+        case 14: INTFFT_PAIR256(14) break;
+        case 15: INTFFT_PAIR256(15) break;
+        default: INTFFT_PAIR256(16) break;
+        }
+#undef INTFFT_PAIR256
+        return hipGetLastError();
+    }
     switch (log2n) {
     case 13: launch_p1<13>(fx, pin, scr, tw16f, nframes, sl, stream); break;
     case 14: launch_p1<14>(fx, pin, scr, tw16f, nframes, sl, stream); break;

@@ -211,8 +211,8 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int two_pass, const void *in, void *out, void *scratch,
                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev);
-hipError_t launch_bigpair(int log2n, int twd, const void *in, void *out, void *scratch, const int2 *tw_all, const uint2 *tw16f,
-                          const int2 *h_tw, size_t nframes, hipStream_t stream);
+hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
                          const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);

@@ -117,6 +117,7 @@ struct intfft_plan {
     W32Args w32args{};
     UxArgs uxargs{};
     bool big20 = false;
+    bool big_pair256 = false;  // N = 2^13 .. 2^16 pair: k_big20_p1<., ., 8>, k_mid_pair, k_big20_q1<., ., 8> (256 x 256 split)
     bool big_two_pass = false; // N = 2^13 .. 2^16 FWD / INV: k_big20_p1<., ., 8> + k_mid_p2 | k_mid_c, k_mid_q1 | k_mid_c + k_big20_q1<., ., 8>
     bool wide16 = false;
     WideArgs wargs{};
@@ -579,6 +580,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+        pl->big_pair256 = pl->big20 && p->log2n <= 16 && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -600,7 +602,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass, (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass || pl->big_pair256, (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -730,7 +732,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                                      plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream)
                                  : plan->p.direction == INTFFT_PAIR
-                                     ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, src, dst, plan->d_scratch, plan->d_tw,
+                                     ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, plan->d_scratch, plan->d_tw,
                                                       plan->d_tw16f, plan->h_tw.data(), nf, stream)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
                                                     plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,

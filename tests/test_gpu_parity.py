@@ -172,14 +172,21 @@ def test_multi_pass_kernels_small_batches(log2n, batch):
 
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 3), (15, 130), (16, 5), (17, 3), (17, 9), (18, 5), (19, 3),
                                          (20, 2)])
-def test_three_pass_pair_n8192_to_n2pow20(log2n, batch):
+def test_three_pass_pair_n8192_to_n2pow20(log2n, batch, monkeypatch):
     """int_fft_ifft_pair for N >= 8192 in three passes: DIF STAGE L-1..12, the whole pair of STAGE 11..0 / 0..11 on every
-    4096-point block (the bit reversal between the cores cancels), DIT STAGE 12..L-1."""
+    4096-point block (the bit reversal between the cores cancels), DIT STAGE 12..L-1.  N <= 2^16 split 256 x 256 instead
+    (DIF L-1..8, the pair of 7..0 / 0..7 on every 256-point group in k_mid_pair, DIT 8..L-1); both splits are checked."""
     n = 1 << log2n
     x = uniform_frames(batch, n, 15, 3000 + log2n)
     x[0] = uniform_frames(1, n, 16, 8)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
-    assert info["kernel_name"].startswith("k_big20") and info["n_passes"] == 3
+    assert info["kernel_name"] == ("k_big20_p1/k_mid_pair/q1" if log2n <= 16 else "k_big20_p1/k_fft4096_i16<MID>/q1")
+    assert info["n_passes"] == 3
+    if log2n <= 16:
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_TWOPASS", "1")
+            info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
+            assert info["kernel_name"] == "k_big20_p1/k_fft4096_i16<MID>/q1"
     if batch <= 9 and log2n < 20:
         check(x, log2n, 16, 13, 0, 0, False, direction="PAIR")
 
