@@ -3,6 +3,7 @@
 //   forward  k_big20_p1<L, ., LOWB = 8>  stages L-1..8 on virtual 2^16-point frames (the pass-1 kernel below with 8 low bits)
 //            k_mid_p2 (natural order out: stages 7..0 + bit-reversed store) | k_mid_c<DIF> (BITREV out: 256-point groups)
 //   inverse  k_mid_q1 (natural order in) | k_mid_c<DIT> (BITREV in): STAGE 0..7;  k_big20_q1<L, ., 8>: STAGE 8..L-1
+//   pair     k_big20_p1<L, ., 8>, k_mid_pair (STAGE 7..0 / 0..7 on every 256-point group, in place), k_big20_q1<L, ., 8>
 // The three-pass scheme:
 // int_fftNk with NFFT = 13..20, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural in -> natural out
 // (stages >= 11 read the Taylor twiddle tables of row_twiddle_tay.vhd, built by k_twiddle_stage).
