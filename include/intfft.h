@@ -102,7 +102,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 /* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
  * (see intfft_io_widths).  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
  * d_in == d_out is allowed when the containers have equal size.  Re-entrant across plans (launch geometry is cached per
- * kernel on first use and assumes the HIP devices of one process are identical, as on an MI355X node);
+ * (kernel, device) on first use, under a mutex);
  * one plan must not be executed concurrently on two streams (plan-owned scratch). */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
 
