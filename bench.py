@@ -1,18 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on its config: Gsample/s (complex int16) of the batched N=1024
-16/16 scaled DIF FFT (BASELINE config 2, batch 65536 per GPU), natural in -> natural out.
+16/16 scaled DIF FFT (BASELINE config 2, batch 65536 per GPU), natural in -> natural out, with % of the
+HBM roofline, at 1/2/4/8 GPUs.
 
 A "step" is one pass of the hot path (one intfft_exec) over one resident batch of synthetic frames.
-Inputs live in HBM before the timed region; N > 1 shards the batch (independent frames, no data-path
-collective) -> weak scaling, one process per GPU (torch.distributed / RCCL only for barrier + max).
+Inputs live in HBM before the timed region; N > 1 shards the batch (independent frames, NO data-path
+collective) -> weak scaling, one process per GPU over RCCL (torch.distributed backend "nccl"), used for the
+barrier, the max-over-ranks timing rule and -- with --e2e -- the root scatter / gather.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Launch forms:
+  python bench.py                          1 GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N    (the driver's form)
+  python bench.py --gpus N                 no WORLD_SIZE in the environment: spawns its own N ranks (127.0.0.1)
+Options: --config C2|C5 (C5 = N=4096 FFT->IFFT pair, 16384 frames per GPU), --e2e (adds the end-to-end
+scatter -> transform -> gather rate as a separate field; never `value`).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`, plus the
+section-8(d) side figures at N=1: cold-clock and full-scale-input rates, the on-box copy ceiling of the kernel's
+access pattern, a VALU-issue bound, single-thread / stream-form CPU baselines, an Octave probe.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,69 +37,201 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
-LOG2N = 10
-N = 1 << LOG2N
-BYTES_PER_SAMPLE = 8  # int16 (re, im) in + int16 (re, im) out, each touched once
+BYTES_PER_SAMPLE = 8   # int16 (re, im) in + int16 (re, im) out, each touched once
+
+CONFIGS = {
+    # name: (log2n, direction, frames per GPU, seed, workload text)
+    "C2": (10, "FWD", 65536, 0xC0FFEE02,
+           "configs[1]: N=1024, 16-bit data / 16-bit twiddle, scaled-truncate DIF FFT, natural->natural"),
+    "C5": (12, "PAIR", 16384, 0xC0FFEE05,
+           "configs[4]: N=4096, 16-bit scaled FFT->IFFT pair (int_fft_ifft_pair), natural->natural, batch split over the GPUs"),
+}
 
 
-def make_input(batch: int, rank: int):
-    """Config 2 synthetic input: frames 0..7 = edge set, the rest i.i.d. uniform in [-2^14, 2^14)."""
+def make_input(batch: int, n: int, seed: int, rank: int, full_scale: bool = False):
+    """Synthetic input: frames 0..7 = edge set, the rest i.i.d. uniform in [-2^14, 2^14)
+    (full_scale: the whole int16 range -- every frame then fails the guard-bit vote and takes the exact extraction)."""
     import numpy as np
     import torch
 
     from tests.helpers import edge_frames
 
     g = torch.Generator(device="cuda")
-    g.manual_seed(0xC0FFEE02 + rank)
-    x = torch.randint(-(1 << 14), 1 << 14, (batch, N, 2), device="cuda", dtype=torch.int16, generator=g)
-    if batch >= 8:
-        x[:8] = torch.from_numpy(edge_frames(N, 16).astype(np.int16)).cuda()
+    g.manual_seed(seed + rank)
+    lim = 1 << (15 if full_scale else 14)
+    x = torch.randint(-lim, lim, (batch, n, 2), device="cuda", dtype=torch.int16, generator=g)
+    if batch >= 8 and not full_scale:
+        x[:8] = torch.from_numpy(edge_frames(n, 16).astype(np.int16)).cuda()
     return x
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/, collected by tools/profile.sh on this same command); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_k_fft1024_pmc_digest.json")
-    try:
-        with open(path) as fh:
-            return float(json.load(fh)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+def pmc_digest():
+    """The newest committed rocprofv3 PMC digest of the dominant kernel (profiles/rNN_k_fft1024_pmc_digest.json,
+    collected by tools/profile.sh on this same command in separate --pmc passes); (path, dict) or (None, None)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k_fft1024_pmc_digest.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as fh:
+                return os.path.relpath(path, ROOT), json.load(fh)
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(x_dev, y_dev):
-    """Times the oracle (a scalar C port of the RTL arithmetic in the reference model's dataflow,
-    OpenMP over frames) on a bounded sample of the same workload, and uses the result as a parity
-    gate for the GPU output of those frames."""
+# ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
+def cpu_baseline(x_dev, y_dev, log2n, direction):
+    """Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
+    to run) and uses the all-core pass as a parity gate for the GPU output of those frames.  Headline entry: in-place
+    form, all host threads.  Also: single thread, and the stream form (the literal dataflow of math/fn_radix2.m:
+    half-split lanes, per-stage butterflies, fn_rev2rdx commutation) all-core and single-thread."""
     import numpy as np
 
     from oracle import oracle_c as C
 
-    p = C.make_params(LOG2N, 16, 16, 0, 0, True)
+    n = 1 << log2n
+    p = C.make_params(log2n, 16, 16, 0, 0, True)
+    d = {"FWD": C.FWD, "PAIR": C.PAIR}[direction]
     threads = C.num_threads()
-    calib = 512
-    xs = x_dev[:calib].cpu().numpy()
-    C.execute_i16(xs, p, C.FWD, form=1, threads=threads)  # warm the OpenMP team
-    t0 = time.perf_counter()
-    C.execute_i16(xs, p, C.FWD, form=1, threads=threads)
-    dt = max(time.perf_counter() - t0, 1e-5)
-    # aim at ~12 s of CPU work (thread-seconds), bounded by the batch
-    frames = int(min(x_dev.shape[0], max(calib, calib * (12.0 / threads) / dt)))
-    xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy())
-    ref = np.zeros_like(xs)  # pre-touched: page faults are not part of the baseline
-    import ctypes
-    t0 = time.perf_counter()
-    rc = C.lib().orc_exec_i16(ctypes.byref(p), C.FWD, C.NATURAL, C.NATURAL, xs.ctypes.data, ref.ctypes.data,
-                              frames, 1, threads)
-    dt = time.perf_counter() - t0
-    assert rc == 0
-    got = y_dev[:frames].cpu().numpy()
-    parity = bool(np.array_equal(got, ref))
-    return {"value": frames * N / dt / 1e9, "unit": "Gsample/s", "cores": threads, "kind": "port",
-            "sample": "%d frames of the same N=1024 16/16 scaled-truncate workload, oracle in-place form, "
-                      "OpenMP over frames" % frames,
-            "parity_checked_frames": frames, "parity_ok": parity}
+    scale = 1024 // n if n <= 1024 else 1
+    work = (2 if direction == "PAIR" else 1) * max(1, n // 1024)
+
+    def timed(frames, form, nthreads, reps=3):
+        frames = max(8, min(int(frames), x_dev.shape[0]))
+        xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy())
+        ref = np.zeros_like(xs)  # pre-touched: page faults are not part of the baseline
+        best = None
+        for _ in range(reps + 1):  # first pass warms the OpenMP team and the caches
+            t0 = time.perf_counter()
+            rc = C.lib().orc_exec_i16(ctypes.byref(p), d, C.NATURAL, C.NATURAL, xs.ctypes.data, ref.ctypes.data,
+                                      frames, form, nthreads)
+            dt = time.perf_counter() - t0
+            assert rc == 0
+            best = dt if best is None else min(best, dt)
+        return frames, frames * n / best / 1e9, ref
+
+    # fixed sample sizes: ~10-20 s of CPU thread-time in total on a 128-thread host
+    f_sall, v_sall, ref_s = timed(32768 * scale // work, 0, threads)
+    parity_stream = bool(np.array_equal(y_dev[:f_sall].cpu().numpy(), ref_s))
+    f_sone, v_sone, _ = timed(1024 * scale // work, 0, 1, reps=2)
+    f_all, v_all, ref = timed(32768 * scale // work, 1, threads)
+    parity = bool(np.array_equal(y_dev[:f_all].cpu().numpy(), ref))
+    f_one, v_one, _ = timed(1024 * scale // work, 1, 1, reps=2)
+    return {"value": v_sall, "unit": "Gsample/s", "cores": threads, "kind": "port",
+            "sample": "first %d frames of the same workload, oracle STREAM form (the dataflow of math/fn_radix2.m with the RTL's "
+                      "integer butterflies), OpenMP over frames, best of 3 (fixed sample)" % f_sall,
+            "parity_checked_frames": f_sall, "parity_ok": parity_stream and parity,
+            "single_thread": {"value": v_sone, "cores": 1, "sample": "%d frames, stream form" % f_sone},
+            "in_place_form": {"value": v_all, "cores": threads, "sample": "%d frames, flat in-place form" % f_all,
+                              "parity_ok": parity},
+            "in_place_form_single_thread": {"value": v_one, "cores": 1, "sample": "%d frames, flat in-place form" % f_one}}
+
+
+def octave_probe():
+    """the reference model as shipped, if Octave exists on this box.  The model's .m files are
+    reference sources and do not travel with this repository; point INTFFT_REFERENCE_DIR at a checkout to time it."""
+    exe = shutil.which("octave") or shutil.which("octave-cli")
+    if not exe:
+        return {"available": False, "note": "octave: not available on this host"}
+    ref = os.environ.get("INTFFT_REFERENCE_DIR", "")
+    if not ref or not os.path.isdir(os.path.join(ref, "math")):
+        return {"available": True, "note": "octave found; set INTFFT_REFERENCE_DIR to a checkout of hukenovs/intfftk to time "
+                                           "math/fn_radix2.m (reference sources are not shipped here)"}
+    prog = ("addpath('%s'); pkg load signal; N=1024; i=(0:N-1)'; ph=(24*i+0.95*i.*i/2)*2*pi/N; w=sin(i*pi/N);"
+            "Din=round(255*cos(ph).*w)+1j*round(255*sin(ph).*w); fn_radix2(Din,N,'FWD'); tic; for k=1:10,"
+            "fn_radix2(Din,N,'FWD'); end; printf('%%g', toc/10);" % os.path.join(ref, "math"))
+    try:
+        out = subprocess.run([exe, "--no-gui", "--quiet", "--eval", prog], capture_output=True, text=True, timeout=120)
+        sec = float(out.stdout.strip().split()[-1])
+        return {"available": True, "seconds_per_frame": sec, "value": 1024 / sec / 1e9, "unit": "Gsample/s",
+                "sample": "fn_radix2(Din, 1024, 'FWD') on the C1 chirp, mean of 10"}
+    except Exception as exc:  # diagnostics only
+        return {"available": True, "note": "octave run failed: %r" % (exc,)}
+
+
+# ---- on-box ceilings (tools/lib/libintfft_diag.so; diagnostics, never on the measured path) ------------------------
+def diag_lib():
+    path = os.path.join(ROOT, "tools", "lib", "libintfft_diag.so")
+    if not os.path.exists(path):
+        return None
+    L = ctypes.CDLL(path)
+    L.diag_copy_wave_nt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    L.diag_valu_chain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]
+    return L
+
+
+def event_ms(torch, fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def ceilings(torch, x, y, stream, digest):
+    L = diag_lib()
+    if L is None:
+        return {"note": "tools/lib/libintfft_diag.so not built"}
+    out = {}
+    nframes = x.numel() * x.element_size() // 4096
+    copy = lambda: L.diag_copy_wave_nt(x.data_ptr(), y.data_ptr(), nframes, 4, stream)  # noqa: E731
+    for _ in range(50):
+        copy()
+    ms = event_ms(torch, copy, 50)
+    gbs = 2.0 * nframes * 4096 / (ms * 1e-3) / 1e9
+    out["copy_ceiling"] = {"GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "ms": ms,
+                           "what": "non-temporal copy of the same buffers with the kernel's access pattern (one wave per "
+                                   "4 KiB frame, 16 dword loads + 16 dword stores per lane), measured in this run"}
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    scratch = torch.empty(cus * 4 * 256, dtype=torch.int32, device="cuda")
+    n = ctypes.c_ulonglong()
+    rates = {}
+    for slow in (1, 0):
+        chain = lambda: L.diag_valu_chain(slow, 2000, scratch.data_ptr(), ctypes.byref(n), stream)  # noqa: E731
+        for _ in range(3):
+            chain()
+        ms = event_ms(torch, chain, 5)
+        rates[slow] = n.value / (ms * 1e-3)  # wave-instructions per second, whole chip, 4 waves per SIMD
+    clk = torch.cuda.get_device_properties(0).clock_rate * 1e3 if hasattr(torch.cuda.get_device_properties(0), "clock_rate") else 2.4e9
+    insts = None
+    if digest and digest.get("SQ_INSTS_VALU") and digest.get("SQ_WAVES"):
+        insts = float(digest["SQ_INSTS_VALU"]) / 65536.0  # VALU wave-instructions per 1024-sample frame (PMC, per launch / frames)
+    vb = {"slow_class_wave_insts_per_s": rates[1], "fast_class_wave_insts_per_s": rates[0],
+          "slow_class_clk_per_wave_inst_at_nominal_clock": cus * 4 * clk / rates[1],
+          "what": "issue rate of v_pk_add_u16 (the class of v_pk_*, v_dot2_i32_i16, v_perm_b32, v_bfe_i32) and of v_add_u32, "
+                  "4 waves per SIMD on every CU, measured in this run"}
+    if insts:
+        vb["valu_insts_per_frame_wave"] = insts
+        vb["value"] = rates[1] / insts * 1024 / 1e9
+        vb["unit"] = "Gsample/s"
+        vb["note"] = "bound if every VALU instruction of the kernel (SQ_INSTS_VALU of the committed PMC digest) issued at the slow-class rate"
+    out["valu_bound"] = vb
+    return out
+
+
+# ---- self-spawn: `python bench.py --gpus N` without a launcher -----------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), INTFFT_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main():
@@ -91,12 +239,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU (config 2: 65536)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's)")
+    ap.add_argument("--e2e", action="store_true", help="also time root scatter -> transform -> gather (reported apart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the section-8(d) side figures (profiling runs)")
     ap.add_argument("--prewarm", type=int, default=400,
                     help="untimed clock-ramp launches before the W warmup steps (the GPU needs ~300 "
                          "back-to-back launches to reach its steady shader clock; see DESIGN.md)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # one process per GPU, rendezvous on 127.0.0.1
 
     import torch
     import torch.distributed as dist
@@ -104,29 +258,49 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    ndev = torch.cuda.device_count()
     # INTFFT_BENCH_SHARE_GPU=1 (diagnostics only): several ranks on one GPU over gloo, to exercise the N > 1
-    # control flow on a 1-GPU box; the driver's runs use one GPU per rank over RCCL.
-    share = os.environ.get("INTFFT_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    # control flow on a 1-GPU box (RCCL refuses two ranks on one device); the driver's runs use one GPU per rank.
+    share = os.environ.get("INTFFT_BENCH_SHARE_GPU") == "1" and ndev < world
+    if ndev < world and not share:
+        raise SystemExit("bench.py: %d ranks but only %d HIP device(s) visible (INTFFT_BENCH_SHARE_GPU=1 runs the control "
+                         "flow on fewer devices over gloo, for diagnostics)" % (world, ndev))
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    elif args.e2e:  # a one-rank RCCL group so that the scatter / gather code path is the same at N = 1
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        backend = "nccl"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    red_dev = None if (share or world == 1) else device  # where the tiny control tensors live
 
-    from intfftk_amd import int_fft_single_path
+    from intfftk_amd import int_fft_ifft_pair, int_fft_single_path
+    from intfftk_amd.sharding import ShardedTransform, gather_floats, max_over_ranks
 
-    core = int_fft_single_path(NFFT=LOG2N, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, device=local_rank)
-    x = make_input(args.batch, rank)
+    log2n, direction, cfg_batch, seed, workload = CONFIGS[args.config]
+    n = 1 << log2n
+    batch = args.batch or cfg_batch
+    ctor = int_fft_single_path if direction == "FWD" else int_fft_ifft_pair
+    core = ctor(NFFT=log2n, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, device=dev_index)
+    x = make_input(batch, n, seed, rank)
     y = torch.empty_like(x)
     stream = torch.cuda.current_stream().cuda_stream
     in_ptr, out_ptr = x.data_ptr(), y.data_ptr()
+    step = lambda: core.exec_raw(in_ptr, out_ptr, batch, stream)  # noqa: E731
+    alg_bytes = BYTES_PER_SAMPLE * batch * n
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,32 +308,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rccl_ranks = None
+    if world > 1:  # proves the collective layer really spans `world` device ranks
+        t = torch.ones(1, device=device if not share else "cpu")
+        dist.all_reduce(t)
+        rccl_ranks = int(t.item())
+
+    # cold figure: the first K launches from idle clocks (one untimed launch loads the code object)
+    extras = world == 1 and not args.no_extras
+    cold = None
+    if extras:
+        step()
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+        ms = event_ms(torch, step, args.steps)
+        cold = {"kernel_ms": ms, "value": batch * n / ms / 1e6, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "what": "first %d launches from idle clocks, no pre-warm" % args.steps}
+
     for _ in range(args.prewarm):  # untimed: DVFS ramp, not part of W/K
-        core.exec_raw(in_ptr, out_ptr, args.batch, stream)
+        step()
     for _ in range(args.warmup):
-        core.exec_raw(in_ptr, out_ptr, args.batch, stream)
+        step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(args.steps):
-        core.exec_raw(in_ptr, out_ptr, args.batch, stream)
+        step()
     ev1.record()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-    from intfftk_amd.sharding import max_over_ranks
-
-    t_all = max_over_ranks(t_local, None if share else torch.device("cuda", local_rank))
+    t_all = max_over_ranks(t_local, red_dev)
     kern_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    per_gpu_ms = gather_floats(kern_ms, red_dev)
+
+    # end-to-end: the whole batch on rank 0 -> one grouped scatter -> transform -> one grouped gather -> rank 0
+    e2e = None
+    if args.e2e:
+        total = batch * world
+        sh = ShardedTransform(core, n, core.in_dtype, core.out_dtype, device, stage_via_cpu=share)
+        root_x = make_input(total, n, seed, 0) if rank == 0 else None
+        times = []
+        for it in range(3 + 5):
+            barrier()
+            t0 = time.perf_counter()
+            res = sh.run_from_root(root_x, total, 0)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            if it >= 3:
+                times.append(time.perf_counter() - t0)
+        t_e2e = max_over_ranks(sum(times) / len(times), red_dev)
+        ok = None
+        if rank == 0:  # same rows as the resident transform of rank 0's own shard
+            ok = bool(torch.equal(res[:batch], core(root_x[:batch])))
+        e2e = {"value": total * n / t_e2e / 1e9, "unit": "Gsample/s", "ms": t_e2e * 1e3, "frames": total,
+               "bytes_moved_per_peer": (BYTES_PER_SAMPLE // 2) * batch * n,
+               "mode": "root scatter -> transform -> gather, one batch_isend_irecv group each way "
+                       "(%s)" % ("gloo via host staging: diagnostics" if share else "RCCL: ncclGroupStart/ncclSend,Recv/ncclGroupEnd"),
+               "p2p_ops_per_group": sh.last_group_sizes[-2:], "matches_resident": ok}
+        del root_x, res
 
     if rank == 0:
-        samples = float(args.batch) * N * world * args.steps
-        launches = core.info["n_passes"]
-        achieved = BYTES_PER_SAMPLE * args.batch * N / (kern_ms * 1e-3) / 1e9
+        samples = float(batch) * n * world * args.steps
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        digest_path, digest = pmc_digest()
+        traffic = float(digest["hbm_bytes_per_launch"]) if (digest and args.config == "C2" and batch == 65536) else None
+        metric = ("Gsample/s (complex int16) batched N=1024 scaled FFT" if args.config == "C2"
+                  else "Gsample/s (complex int16) batched N=4096 scaled FFT->IFFT pair")
         out = {
-            "metric": "Gsample/s (complex int16) batched N=1024 scaled FFT",
+            "metric": metric,
             "value": samples / t_all / 1e9,
             "unit": "Gsample/s",
             "n_gpus": world,
@@ -171,21 +391,46 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: N=1024, 16-bit data / 16-bit twiddle, scaled-truncate DIF FFT, "
-                                   "natural->natural, batch=%d per GPU" % args.batch,
-                       "batch_per_gpu": args.batch, "n": N, "parallelism": "batch-shard x%d" % world,
-                       "kernel": core.info["kernel_name"], "launches_per_step": launches,
-                       "clock_prewarm_steps": args.prewarm},
+            "config": {"workload": "%s, batch=%d per GPU" % (workload, batch),
+                       "batch_per_gpu": batch, "n": n, "parallelism": "batch-shard x%d" % world,
+                       "kernel": core.info["kernel_name"], "launches_per_step": core.info["n_passes"],
+                       "clock_prewarm_steps": args.prewarm,
+                       "backend": backend, "rccl_ranks": rccl_ranks},
+            "per_gpu": {"kernel_ms": per_gpu_ms,
+                        "Gsample/s": [batch * n / m / 1e6 for m in per_gpu_ms],
+                        "roofline_frac": [alg_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in per_gpu_ms]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic() if args.batch == 65536 else None,
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * args.batch * N,
+                         "traffic": traffic,
+                         "traffic_source": ("%s (static: rocprofv3 --pmc passes of this command, committed; not measured in this run)"
+                                            % digest_path) if traffic else None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": kern_ms},
         }
+        if e2e:
+            out["e2e"] = e2e
+        if extras:
+            out["cold"] = cold
+            xf = make_input(batch, n, seed, rank, full_scale=True)
+            stepf = lambda: core.exec_raw(xf.data_ptr(), out_ptr, batch, stream)  # noqa: E731
+            for _ in range(20):
+                stepf()
+            ms = event_ms(torch, stepf, args.steps)
+            out["full_scale_input"] = {"kernel_ms": ms, "value": batch * n / ms / 1e6,
+                                       "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "what": "input uniform over the whole int16 range: no frame has a guard bit, every frame takes "
+                                               "the exact result extraction (the headline input is uniform in [-2^14, 2^14) as SURVEY 8d names)"}
+            del xf
+            step()  # y := transform(x) again for the parity gate below
+            torch.cuda.synchronize()
+            out.update(ceilings(torch, x, torch.empty_like(x), stream, digest))
+            out["octave"] = octave_probe()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(x, y)
+            step()
+            torch.cuda.synchronize()
+            out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

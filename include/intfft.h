@@ -94,14 +94,16 @@ int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *i
 
 /* Elaborates a core on a HIP device: validates the generics the way the RTL elaboration would,
  * generates the twiddle tables on the device (rom_twiddle_int.vhd + row_twiddle_tay.vhd) and
- * chooses the kernels.  The plan is immutable afterwards. */
+ * chooses the kernels.  intfft_exec never modifies the plan; intfft_exec_host, intfft_shard_prepare and
+ * intfft_exec_sharded create (grow-only) staging state inside it on first use -- see their comments. */
 int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device);
 int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 
 /* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
  * (see intfft_io_widths).  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
- * d_in == d_out is allowed when the containers have equal size.  Re-entrant across plans (launch geometry is cached per
+ * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
+ * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
  * (kernel, device) on first use, under a mutex);
  * one plan must not be executed concurrently on two streams (plan-owned scratch). */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
@@ -120,10 +122,29 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
  * across GPUs with no collective in the data path -- the software analogue of instantiating the core once per
  * channel).  plans[0..nplans-1] hold identical intfft_params, one per HIP device; d_in / d_out live on the device
  * of plans[root].  The batch is cut into contiguous shards (remainder to the LAST plans); shard i is copied
- * root -> device i (hipMemcpyPeerAsync over xGMI), transformed there, and copied back; the root transforms its own
- * shard in place of the copy.  Blocking.  One-process-per-GPU hosts (torch.distributed / MPI) call intfft_exec on
- * their own shard instead (intfftk_amd/sharding.py). */
+ * root -> device i (hipMemcpyPeerAsync over xGMI, peer access enabled where the devices allow it), transformed there,
+ * and copied back; the root transforms its own shard in place of the copy.  Blocking.
+ * Synchronisation contract: on entry the call waits for EVERY stream of the root device (hipDeviceSynchronize), so
+ * d_in may have been produced on any stream of that device; on return d_out is complete.  On an error every stream the
+ * call used is still drained before it returns.
+ * Plan state: the per-shard staging buffers and stream live in the plans (grow only, freed by intfft_plan_destroy) and
+ * are created on first use -- or up front by intfft_shard_prepare, after which intfft_exec_sharded allocates nothing for
+ * batches <= max_batch.  These two calls are the only ones besides intfft_exec_host that modify a plan after create: do
+ * not run them concurrently with any other call on the same plans.
+ * One-process-per-GPU hosts (torch.distributed / MPI over RCCL) call intfft_exec on their own shard instead
+ * (intfftk_amd/sharding.py: grouped ncclSend/ncclRecv scatter and gather). */
+int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t max_batch);
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch);
+
+/* Standalone re-orderer: the stream buffers of src/vhdl/buffers/ as an operator of their own (no plan, no arithmetic).
+ * d_out[f][m_out] = d_in[f][m_in] for every frame f, where m_in (memory index in `from_order`) and m_out (memory index
+ * in `to_order`) denote the same logical index -- e.g. int_bitrev_order.vhd:61-189 = BITREV_LANES -> NATURAL,
+ * inbuf_half_path.vhd:23-28 = NATURAL -> HALVES, outbuf_half_path.vhd:160-172 = BITREV -> BITREV_LANES, and
+ * NATURAL -> BITREV = the bitrevorder() of math/fn_radix2.m:188.  Samples are (re, im) pairs of `container_bytes`
+ * (2 / 4 / 8) each; frames are [batch][2^log2n].  Not in place (overlapping buffers -> INTFFT_ERR_INVALID).
+ * Asynchronous on `hip_stream` of device `hip_device`. */
+int intfft_reorder(int log2n, int container_bytes, int from_order, int to_order, const void *d_in, void *d_out,
+                   size_t batch, int hip_device, void *hip_stream);
 
 /* Parity introspection: the twiddle stream of butterfly stage `stage` (2^stage entries, the
  * values rom_twiddle_int emits for cnt = 0 .. 2^stage-1) as interleaved int32 (re, im).

@@ -16,8 +16,8 @@ DIRECTIONS = {"FWD": 0, "INV": 1, "PAIR": 2}
 
 # every symbol include/intfft.h declares
 SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_destroy", "intfft_plan_get_info",
-           "intfft_exec", "intfft_exec_host", "intfft_exec_sharded", "intfft_twiddles", "intfft_strerror",
-           "intfft_version")
+           "intfft_exec", "intfft_exec_host", "intfft_shard_prepare", "intfft_exec_sharded", "intfft_reorder",
+           "intfft_twiddles", "intfft_strerror", "intfft_version")
 
 
 class Params(ctypes.Structure):
@@ -70,6 +70,9 @@ def lib():
                                        ctypes.c_size_t]
         L.intfft_exec_sharded.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t]
+        L.intfft_shard_prepare.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+        L.intfft_reorder.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         L.intfft_twiddles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_size_t)]
         L.intfft_strerror.restype = ctypes.c_char_p
@@ -77,7 +80,7 @@ def lib():
         L.intfft_version.restype = ctypes.c_char_p
         for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_destroy",
                    "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded",
-                   "intfft_twiddles"):
+                   "intfft_shard_prepare", "intfft_reorder", "intfft_twiddles"):
             getattr(L, fn).restype = ctypes.c_int
         _lib = L
     return _lib

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libintfft.so")
-SOURCES = ["intfft_plan.hip", "intfft_generic.hip", "intfft_pass16.hip", "intfft_fastsmall.hip", "intfft_fast1024.hip", "intfft_fast1024x.hip", "intfft_fast1024u.hip", "intfft_fast1024ux.hip", "intfft_fastw32.hip", "intfft_fast4096w.hip", "intfft_w32inv.hip", "intfft_bigw.hip", "intfft_fast4096.hip", "intfft_big20.hip", "intfft_wide16.hip"]
+SOURCES = ["intfft_plan.hip", "intfft_generic.hip", "intfft_pass16.hip", "intfft_fastsmall.hip", "intfft_fast1024.hip", "intfft_fast1024x.hip", "intfft_fast1024u.hip", "intfft_fast1024ux.hip", "intfft_fastw32.hip", "intfft_fast4096w.hip", "intfft_w32inv.hip", "intfft_bigw.hip", "intfft_fast4096.hip", "intfft_big20.hip", "intfft_wide16.hip", "intfft_reorder.hip"]
 HEADERS = ["intfft_device.hpp", "intfft_internal.hpp", "intfft_pk16.hpp", "intfft_u32.hpp", os.path.join("..", "..", "include", "intfft.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -51,5 +51,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+DIAG_SRC = os.path.join(HERE, "..", "tools", "diag_kernels.hip")
+DIAG_LIB = os.path.join(HERE, "..", "tools", "lib", "libintfft_diag.so")
+
+
+def build_diag(force: bool = False, verbose: bool = False) -> str:
+    """tools/lib/libintfft_diag.so: the on-box ceilings bench.py prints next to its line (copy ceiling of the headline
+    kernel's access pattern, VALU issue rate).  Diagnostics only -- not linked into, or loaded by, libintfft.so."""
+    os.makedirs(os.path.dirname(DIAG_LIB), exist_ok=True)
+    if force or _stale(DIAG_LIB, [DIAG_SRC]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result", "-o", DIAG_LIB, DIAG_SRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_diag(force="--force" in sys.argv, verbose=True))

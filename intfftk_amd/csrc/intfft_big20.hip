@@ -726,13 +726,13 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             }
             if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
             else dif_round<false, true>(v, tb, sl, sh_a);
-            asm volatile("" ::: "memory"); // keep the previous chunk's reads ahead of these writes
+            wave_lds_fence(); // keep the previous chunk's reads ahead of these writes
 #pragma unroll
             for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];
-            asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
+            wave_lds_fence(); // LDS ops of one wave execute in order: no barrier needed
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; // regs = n3..0, lane = n9..n4
-            asm volatile("" ::: "memory");
+            wave_lds_fence();
             if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
             else dif_round_c<false>(v, c, sl, sh3);
             swap_guard(v);
@@ -764,13 +764,13 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             const bool fast = FAST_OK && frame_has_guard_bit(v); // the 1024 samples are closed under STAGE 0..7
             if (fast) dit_round_c<FAST_OK>(v, c, sl);
             else dit_round_c<false>(v, c, sl);
-            asm volatile("" ::: "memory");
+            wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];
-            asm volatile("" ::: "memory");
+            wave_lds_fence();
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4]; // regs = n7..4, lane = (q, n3..0)
-            asm volatile("" ::: "memory");
+            wave_lds_fence();
             if (fast) dit_round<FAST_OK>(v, tb, sl);
             else dit_round<false>(v, tb, sl);
             u32 *p = dst + ch * 1024 + q * 256 + lo4;
@@ -811,17 +811,17 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
 #define INTFFT_MIDPAIR(FX)                                                                                       \
     {                                                                                                            \
         dif_round<FX, true>(v, tb, sl, sh_a);                                                                    \
-        asm volatile("" ::: "memory");                                                                           \
+        wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];                    \
-        asm volatile("" ::: "memory"); /* LDS ops of one wave execute in order */                                \
+        wave_lds_fence(); /* LDS ops of one wave execute in order */                                \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; /* regs n3..0, lane n9..n4 */ \
-        asm volatile("" ::: "memory");                                                                           \
+        wave_lds_fence();                                                                           \
         dif_round_c<FX>(v, c, sl, sh3);                                                                          \
         dit_round_c<FX>(v, c, sl);                                                                               \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];                              \
-        asm volatile("" ::: "memory");                                                                           \
+        wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4];                    \
-        asm volatile("" ::: "memory");                                                                           \
+        wave_lds_fence();                                                                           \
         dit_round<FX>(v, tb, sl);                                                                                \
     }
         if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK)

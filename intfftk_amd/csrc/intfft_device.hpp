@@ -33,6 +33,17 @@ struct StageDesc {
 
 template <typename T> struct Cx { T re, im; };
 
+// Ordering point for a WAVE-PRIVATE LDS tile: lanes of one wave exchange data through LDS (a ds_write, then a ds_read of
+// another lane's word).  A wave's DS instructions issue and complete in order on gfx950; this states the ordering in the
+// memory model instead of relying on that: release the writes at wavefront scope, keep the wave converged, acquire before
+// the reads.  Lowers to no instructions beyond the lgkmcnt waits the compiler places anyway.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename T> __device__ __forceinline__ T wrapw(T v, int w)
 {
     constexpr int B = sizeof(T) * 8;

@@ -156,7 +156,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
 
     // ---- LDS transpose: regs become n3..0.  The kind of a value (S or Y >> 1) is now j & 4, and
     //      reg bit 2 holds n4, which becomes a LANE bit: stage 3 shifts by a per-lane amount ----
-    asm volatile("" ::: "memory"); // keep the previous frame's reads ahead of these writes
+    wave_lds_fence(); // keep the previous frame's reads ahead of these writes
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
                                         (j2 << lane_bit<L>(4)));
         wr_base[ROW_DW * row_j] = v[j];
     }
-    asm volatile("" ::: "memory"); // LDS ops of one wave execute in order: no barrier needed
+    wave_lds_fence(); // LDS ops of one wave execute in order: no barrier needed
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint4 x = rd_base[q];
@@ -175,7 +175,7 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
         v[4 * q + 2] = x.z;
         v[4 * q + 3] = x.w;
     }
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 
     // ---- phase 3: stages 3, 2 (uniform twiddles), 1, 0 ----
     {

@@ -95,20 +95,20 @@ __device__ __forceinline__ void uinverse(int (&re)[16], int (&im)[16], const int
     for (int r = 0; r < 8; ++r) ufly_dit<WRAP, MASKED, true>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
 
     // LC -> mid: element (lane, reg r) -> row = mid lane 32 a9 + 16 a8 + r, column = mid reg (a5 a4 a7 a6)
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         wr_inv[ROWU * r] = (u32)re[r];
         wr_inv[64 * ROWU + ROWU * r] = (u32)im[r];
     }
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
         re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
         im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
     }
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 
     // DIT STAGE 4: reg bit 2 = a4; then lane bit 4 <-> reg bit 2
 #pragma unroll

@@ -167,32 +167,32 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
             group4<false, FX, false, true, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
             group4<false, FX, false, true, false, 0xF>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
-            asm volatile("" ::: "memory");                                                              \
+            wave_lds_fence();                                                              \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
             {                                                                                           \
                 const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;          \
                 wr_f[ROWX * (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2)] = v[j];                              \
             }                                                                                           \
-            asm volatile("" ::: "memory");                                                              \
+            wave_lds_fence();                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
             {                                                                                           \
                 const uint4 x = rd_base[q];                                                             \
                 v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;             \
             }                                                                                           \
-            asm volatile("" ::: "memory");                                                              \
+            wave_lds_fence();                                                              \
             dif_round_c<FX>(v, c, sl, sh3);                                                             \
         }                                                                                               \
         /* inverse core: LC -> L1 */                                                                    \
         dit_round_c<FX>(v, c, sl);                                                                      \
-        asm volatile("" ::: "memory");                                                                  \
+        wave_lds_fence();                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) wr_i[ROWX * r] = v[r];                           \
-        asm volatile("" ::: "memory");                                                                  \
+        wave_lds_fence();                                                                  \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
         {                                                                                               \
             const uint4 x = rd_base[q];                                                                 \
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;                 \
         }                                                                                               \
-        asm volatile("" ::: "memory");                                                                  \
+        wave_lds_fence();                                                                  \
         group4_dit<FX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);            \
         group4_dit<FX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl);      \
         swap_guard(v);                                                                                  \

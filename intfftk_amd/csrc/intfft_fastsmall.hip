@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
             if (f0 + (size_t)fr < nframes) x = __builtin_nontemporal_load(src + 64 * q);
             *reinterpret_cast<v4u *>(lds + fr * ROW + e) = x;
         }
-        asm volatile("" ::: "memory"); // wave-private tile: LDS operations of one wave execute in order
+        wave_lds_fence(); // wave-private tile: LDS operations of one wave execute in order
         u32 v[N];
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
         }
         if (MODE != SM_INV) small_dif<L, ROUND>(v, t, sl);
         if (MODE != SM_FWD) small_dit<L>(v, t, sl);
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
             v4u y;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
                 y = v4u{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
             *reinterpret_cast<v4u *>(lds + lane * ROW + 4 * q) = y;
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
         v4u *dst = reinterpret_cast<v4u *>(out + f0 * N) + lane;
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
             const v4u y = *reinterpret_cast<const v4u *>(lds + fr * ROW + e);
             if (f0 + (size_t)fr < nframes) __builtin_nontemporal_store(y, dst + 64 * q);
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
     }
 }
 

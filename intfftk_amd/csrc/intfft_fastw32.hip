@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) gfly<MODE, false, MASKED>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, a.st[4]);
         // ---- LDS transpose: regs become a3..0 ----
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
@@ -148,14 +148,14 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
             wr_base[ROWU * row_j] = (u32)re[j];
             wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
             re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
             im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
         // ---- stages 3, 2 (uniform twiddles), 1, 0 ----
 #pragma unroll
         for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);

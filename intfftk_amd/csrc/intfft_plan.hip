@@ -130,6 +130,7 @@ struct intfft_plan {
     void *shard_in = nullptr, *shard_out = nullptr;
     size_t shard_in_bytes = 0, shard_out_bytes = 0;
     hipStream_t s_shard = nullptr;
+    int shard_peer = -1; // root device this plan's device has peer access to (-1: not set up yet)
     size_t slot_frames = 0;
     char kernel_name[64] = {0};
 };
@@ -212,6 +213,17 @@ int validate(const intfft_params &p)
     const int growth = p.format ? p.log2n : 0;
     const int out_bits = p.data_width + (p.direction == INTFFT_PAIR ? 2 * growth : growth);
     if (out_bits > 64) return INTFFT_ERR_UNSUPPORTED;
+    // elaboration check of every stage (find_delay != 0, int_dif2_fly.vhd:87-116) and of the twiddle width
+    // (find_twd_25, int_cmult_dsp48.vhd:161-173): intfft_io_widths and intfft_plan_create agree on what elaborates
+    if (p.twdl_width >= (p.xser ? 28 : 26)) return INTFFT_ERR_UNSUPPORTED;
+    std::vector<StageDesc> tmp;
+    int rc = INTFFT_OK;
+    if (p.direction == INTFFT_FWD || p.direction == INTFFT_PAIR)
+        if ((rc = core_stages(p, p.data_width, false, tmp)) != INTFFT_OK) return rc;
+    if (p.direction == INTFFT_INV)
+        if ((rc = core_stages(p, p.data_width, true, tmp)) != INTFFT_OK) return rc;
+    if (p.direction == INTFFT_PAIR)
+        if ((rc = core_stages(p, p.data_width + p.format * p.log2n, true, tmp)) != INTFFT_OK) return rc;
     return INTFFT_OK;
 }
 
@@ -447,18 +459,6 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     *out = nullptr;
     int rc = validate(*p);
     if (rc != INTFFT_OK) return rc;
-    // elaboration check of every stage before touching the device
-    {
-        std::vector<StageDesc> tmp;
-        if (p->direction == INTFFT_FWD || p->direction == INTFFT_PAIR)
-            if ((rc = core_stages(*p, p->data_width, false, tmp)) != INTFFT_OK) return rc;
-        if (p->direction == INTFFT_INV)
-            if ((rc = core_stages(*p, p->data_width, true, tmp)) != INTFFT_OK) return rc;
-        if (p->direction == INTFFT_PAIR)
-            if ((rc = core_stages(*p, p->data_width + p->format * p->log2n, true, tmp)) != INTFFT_OK) return rc;
-        const int td = p->xser ? 28 : 26;
-        if (p->twdl_width >= td) return INTFFT_ERR_UNSUPPORTED;
-    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
         return INTFFT_ERR_NO_DEVICE;
@@ -671,6 +671,13 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
 {
     if (!plan || (batch && (!d_in || !d_out))) return INTFFT_ERR_NULL;
     if (batch == 0) return INTFFT_OK;
+    {   // in place only as d_in == d_out with equal containers; any other overlap of the two byte ranges would let a
+        // block overwrite frames another block has not read yet
+        const size_t n2 = (size_t)2 << plan->L;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_in), a1 = a0 + batch * n2 * (size_t)plan->in_cb;
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(d_out), b1 = b0 + batch * n2 * (size_t)plan->out_cb;
+        if (a0 < b1 && b0 < a1 && (a0 != b0 || plan->in_cb != plan->out_cb)) return INTFFT_ERR_INVALID;
+    }
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -840,7 +847,38 @@ fail:
     return (int)e;
 }
 
-int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
+// staging buffers + stream of one shard plan (grow only); peer access root <-> pl->device
+static hipError_t shard_state(intfft_plan *pl, int root_device, size_t in_bytes, size_t out_bytes)
+{
+    hipError_t e = hipSuccess;
+    if (!pl->s_shard) e = hipStreamCreateWithFlags(&pl->s_shard, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    if (pl->device != root_device && pl->shard_peer != root_device) {
+        int can = 0;
+        if ((e = hipDeviceCanAccessPeer(&can, pl->device, root_device)) != hipSuccess) return e;
+        if (can) { // direct xGMI copies; without it hipMemcpyPeerAsync still works (staged by the runtime)
+            e = hipDeviceEnablePeerAccess(root_device, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(), e = hipSuccess;
+            if (e != hipSuccess) return e;
+        }
+        pl->shard_peer = root_device;
+    }
+    if (pl->shard_in_bytes < in_bytes) {
+        if (pl->shard_in) (void)hipFree(pl->shard_in);
+        pl->shard_in = nullptr, pl->shard_in_bytes = 0;
+        if ((e = hipMalloc(&pl->shard_in, in_bytes)) != hipSuccess) return e;
+        pl->shard_in_bytes = in_bytes;
+    }
+    if (pl->shard_out_bytes < out_bytes) {
+        if (pl->shard_out) (void)hipFree(pl->shard_out);
+        pl->shard_out = nullptr, pl->shard_out_bytes = 0;
+        if ((e = hipMalloc(&pl->shard_out, out_bytes)) != hipSuccess) return e;
+        pl->shard_out_bytes = out_bytes;
+    }
+    return hipSuccess;
+}
+
+static int shard_check(intfft_plan *const *plans, int nplans, int root)
 {
     if (!plans || nplans <= 0 || root < 0 || root >= nplans) return INTFFT_ERR_INVALID;
     for (int i = 0; i < nplans; ++i) {
@@ -849,46 +887,73 @@ int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const v
         for (int j = 0; j < i; ++j)
             if (plans[j] == plans[i]) return INTFFT_ERR_INVALID; // a plan owns its scratch: one shard at a time
     }
+    return INTFFT_OK;
+}
+
+static size_t shard_frames(size_t batch, int nplans, int i)
+{
+    const size_t base = batch / (size_t)nplans, rem = batch % (size_t)nplans;
+    return base + ((size_t)i >= (size_t)nplans - rem ? 1 : 0);
+}
+
+int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t max_batch)
+{
+    const int rc = shard_check(plans, nplans, root);
+    if (rc != INTFFT_OK) return rc;
+    intfft_plan *rp = plans[root];
+    const size_t N = (size_t)1 << rp->L;
+    const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
+    for (int i = 0; i < nplans; ++i) {
+        intfft_plan *pl = plans[i];
+        DeviceGuard g(pl->device);
+        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+        const size_t nf = i == root ? 0 : shard_frames(max_batch, nplans, i);
+        const hipError_t e = shard_state(pl, rp->device, nf * in_frame, nf * out_frame);
+        if (e != hipSuccess) return (int)e;
+        if (i != root && pl->device != rp->device) { // and the reverse direction (the gather writes into the root's memory)
+            DeviceGuard gr(rp->device);
+            int can = 0;
+            if (gr.ok && hipDeviceCanAccessPeer(&can, rp->device, pl->device) == hipSuccess && can)
+                if (hipDeviceEnablePeerAccess(pl->device, 0) == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    return INTFFT_OK;
+}
+
+int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
+{
+    int rc = shard_check(plans, nplans, root);
+    if (rc != INTFFT_OK) return rc;
     if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
     if (batch == 0) return INTFFT_OK;
     intfft_plan *rp = plans[root];
     const size_t N = (size_t)1 << rp->L;
     const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
-    const size_t base = batch / (size_t)nplans, rem = batch % (size_t)nplans;
     hipError_t e = hipSuccess;
-    int rc = INTFFT_OK;
-    {   // the caller's data is ready once the root device's default stream is idle
+    {   // contract (intfft.h): d_in is complete once every stream of the root device is idle
         DeviceGuard g(rp->device);
         if (!g.ok) return INTFFT_ERR_NO_DEVICE;
-        e = hipStreamSynchronize(nullptr);
+        e = hipDeviceSynchronize();
     }
     size_t start = 0;
     for (int i = 0; i < nplans && e == hipSuccess && rc == INTFFT_OK; ++i) {
         intfft_plan *pl = plans[i];
-        const size_t nf = base + ((size_t)i >= (size_t)nplans - rem ? 1 : 0);
+        const size_t nf = shard_frames(batch, nplans, i);
         const char *src = static_cast<const char *>(d_in) + start * in_frame;
         char *dst = static_cast<char *>(d_out) + start * out_frame;
         start += nf;
         if (nf == 0) continue;
         DeviceGuard g(pl->device);
-        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
-        if (!pl->s_shard) e = hipStreamCreateWithFlags(&pl->s_shard, hipStreamNonBlocking);
+        if (!g.ok) {
+            rc = INTFFT_ERR_NO_DEVICE; // fall through to the drain loop: earlier shards are still in flight
+            break;
+        }
+        // no-op after intfft_shard_prepare with max_batch >= batch
+        e = shard_state(pl, rp->device, i == root ? 0 : nf * in_frame, i == root ? 0 : nf * out_frame);
         if (e != hipSuccess) break;
         if (i == root) {
             rc = intfft_exec(pl, src, dst, nf, pl->s_shard);
             continue;
-        }
-        if (pl->shard_in_bytes < nf * in_frame) {
-            if (pl->shard_in) (void)hipFree(pl->shard_in);
-            pl->shard_in = nullptr, pl->shard_in_bytes = 0;
-            if ((e = hipMalloc(&pl->shard_in, nf * in_frame)) != hipSuccess) break;
-            pl->shard_in_bytes = nf * in_frame;
-        }
-        if (pl->shard_out_bytes < nf * out_frame) {
-            if (pl->shard_out) (void)hipFree(pl->shard_out);
-            pl->shard_out = nullptr, pl->shard_out_bytes = 0;
-            if ((e = hipMalloc(&pl->shard_out, nf * out_frame)) != hipSuccess) break;
-            pl->shard_out_bytes = nf * out_frame;
         }
         e = hipMemcpyPeerAsync(pl->shard_in, pl->device, src, rp->device, nf * in_frame, pl->s_shard);
         if (e != hipSuccess) break;

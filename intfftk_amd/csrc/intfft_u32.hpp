@@ -142,7 +142,7 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
         for (int j = 0; j < 4; ++j) ufly<WRAP, 16 + L - 4>(re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r, w4i, sh);
 
     // LDS transpose (re plane, im plane): regs become n3..0, lane bit i = n(9-i)
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
         wr_base[ROWU * row_j] = (u32)re[j];
         wr_base[64 * ROWU + ROWU * row_j] = (u32)im[j];
     }
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
@@ -164,7 +164,7 @@ __device__ __forceinline__ void utransform(int (&re)[16], int (&im)[16], const i
         im[4 * q + 2] = (int)y.z;
         im[4 * q + 3] = (int)y.w;
     }
-    asm volatile("" ::: "memory");
+    wave_lds_fence();
 
     // stages 3, 2 (uniform twiddles), 1, 0
 #pragma unroll

@@ -165,20 +165,20 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
         }
         ground_c_dit<MODE, MASKED>(re, im, c, a);
         // ---- LC -> mid ----
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             wr_inv[ROWU * r] = (u32)re[r];
             wr_inv[64 * ROWU + ROWU * r] = (u32)im[r];
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint4 x = rd_base[q], y = rd_base[q + 16 * ROWU];
             re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
             im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
         }
-        asm volatile("" ::: "memory");
+        wave_lds_fence();
         // DIT 4 (reg bit 2 = a4), lane bit 4 <-> reg bit 2, DIT 5 (reg bit 3 = a5), lane bit 5 <-> reg bit 3
 #pragma unroll
         for (int g = 0; g < 16; g += 8)

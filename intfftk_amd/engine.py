@@ -125,7 +125,10 @@ class IntFFTCore:
     def exec_host(self, x: np.ndarray, chunk_frames: int = 0) -> np.ndarray:
         """Host-resident frames through intfft_exec_host: chunked, double-buffered H2D / transform / D2H
         on three streams (every frame is still transformed on the GPU)."""
-        x = np.ascontiguousarray(x, dtype=_NP_DT[self.in_container])
+        x = np.asarray(x)
+        if x.dtype != _NP_DT[self.in_container]:  # same rule as __call__: no silent narrowing of wider / float arrays
+            raise TypeError("input dtype must be %s for DATA_WIDTH=%d" % (np.dtype(_NP_DT[self.in_container]).name, self.in_bits))
+        x = np.ascontiguousarray(x)
         if x.ndim != 3 or x.shape[1] != self.n or x.shape[2] != 2:
             raise ValueError("input must be [batch, %d, 2]" % self.n)
         out = np.empty((x.shape[0], self.n, 2), dtype=_NP_DT[self.out_container])
@@ -179,7 +182,13 @@ def exec_sharded(cores, x, root: int = 0):
     shards, remainder to the last cores, peer copies over xGMI, no collective.  Blocking."""
     import torch
 
+    if not cores or not 0 <= root < len(cores):
+        raise ValueError("bad cores/root")
     c0 = cores[root]
+    if not (x.is_cuda and x.device.index == c0.device):
+        raise ValueError("input must live on cuda:%d (the device of cores[root])" % c0.device)
+    if len({id(c) for c in cores}) != len(cores):
+        raise ValueError("every shard needs its own core (a plan owns its scratch)")
     if x.dtype != c0.in_dtype or x.dim() != 3 or x.shape[1] != c0.n or x.shape[2] != 2 or not x.is_contiguous():
         raise ValueError("input must be a contiguous [batch, %d, 2] %s tensor" % (c0.n, c0.in_dtype))
     y = torch.empty((x.shape[0], c0.n, 2), dtype=c0.out_dtype, device=x.device)

@@ -1,9 +1,10 @@
 """Batch sharding across the GPUs of one node: one process per GPU, frames are independent units
 (int_fftNk keeps per-frame state only), so the transform itself needs NO collective.
-The only data movement is an optional scatter of a root-resident batch before and a gather after,
-done with point-to-point sends over torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs;
-"gloo" in the CPU tests): the root drives all of its 7 xGMI links concurrently, there is no ring
-and no reduction anywhere.
+The only data movement is an optional scatter of a root-resident batch before and a gather after.  Each is
+ONE group of point-to-point operations (`torch.distributed.batch_isend_irecv`; on the "nccl" backend = RCCL that
+is ncclGroupStart, 7 x ncclSend / ncclRecv, ncclGroupEnd), so the root drives all of its 7 xGMI links
+concurrently (xGMI is point to point: 7 links x ~153 GB/s per GPU); there is no ring and no reduction anywhere.
+"gloo" carries the same code in the CPU tests.
 """
 from __future__ import annotations
 
@@ -25,9 +26,12 @@ def shard_bounds(batch: int, world: int) -> List[Tuple[int, int]]:
 
 class ShardedTransform:
     """scatter -> per-rank transform -> gather.  `transform` maps a local [frames, N, 2] tensor to
-    the local result (an intfftk_amd.IntFFTCore on a GPU rank)."""
+    the local result (an intfftk_amd.IntFFTCore on a GPU rank).
 
-    def __init__(self, transform: Callable, n: int, in_dtype, out_dtype, device, group=None):
+    stage_via_cpu: move the point-to-point payloads through host memory (gloo cannot send device tensors;
+    only the single-GPU diagnostics mode of bench.py needs this -- RCCL sends device memory directly)."""
+
+    def __init__(self, transform: Callable, n: int, in_dtype, out_dtype, device, group=None, stage_via_cpu: bool = False):
         import torch.distributed as dist
 
         self.dist = dist
@@ -38,48 +42,69 @@ class ShardedTransform:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stage_via_cpu = stage_via_cpu
+        self.last_group_sizes: List[int] = []  # p2p operations per issued group (tests / bench introspection)
+
+    # -- one group of point-to-point operations ---------------------------------------------------------
+    def _run_group(self, ops):
+        """ops: list of (kind, tensor, peer).  Issues them as ONE batch_isend_irecv group and waits."""
+        dist = self.dist
+        self.last_group_sizes.append(len(ops))
+        if not ops:
+            return
+        p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, self.group) for kind, t, peer in ops]
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
 
     # -- data movement ------------------------------------------------------------------------
     def scatter(self, root_batch, batch: int, root: int = 0):
         """root_batch: [batch, N, 2] on the root (ignored elsewhere) -> this rank's shard."""
         import torch
 
-        dist = self.dist
         bounds = shard_bounds(batch, self.world)
         lo, hi = bounds[self.rank]
         if self.rank == root:
-            reqs = []
+            ops = []
             for r, (a, b) in enumerate(bounds):
                 if r != root and b > a:
-                    reqs.append(dist.isend(root_batch[a:b].contiguous(), dst=r, group=self.group))
+                    piece = root_batch[a:b]  # contiguous rows of a contiguous batch: no copy
+                    if self.stage_via_cpu:
+                        piece = piece.cpu()
+                    ops.append(("send", piece.contiguous(), r))
             local = root_batch[lo:hi].clone()  # the root keeps its shard by local copy
-            for q in reqs:
-                q.wait()
+            self._run_group(ops)
             return local
-        local = torch.empty((hi - lo, self.n, 2), dtype=self.in_dtype, device=self.device)
-        if hi > lo:
-            dist.recv(local, src=root, group=self.group)
-        return local
+        local = torch.empty((hi - lo, self.n, 2), dtype=self.in_dtype, device="cpu" if self.stage_via_cpu else self.device)
+        self._run_group([("recv", local, root)] if hi > lo else [])
+        return local.to(self.device) if self.stage_via_cpu else local
 
     def gather(self, local, batch: int, root: int = 0):
         """This rank's result shard -> [batch, N, 2] on the root (None elsewhere)."""
         import torch
 
-        dist = self.dist
         bounds = shard_bounds(batch, self.world)
         lo, hi = bounds[self.rank]
         if self.rank != root:
             if hi > lo:
-                dist.send(local.contiguous(), dst=root, group=self.group)
+                piece = local.cpu() if self.stage_via_cpu else local
+                self._run_group([("send", piece.contiguous(), root)])
+            else:
+                self._run_group([])
             return None
         out = torch.empty((batch, self.n, 2), dtype=self.out_dtype, device=self.device)
-        reqs = []
+        ops, staged = [], []
         for r, (a, b) in enumerate(bounds):
             if r != root and b > a:
-                reqs.append(dist.irecv(out[a:b], src=r, group=self.group))
+                if self.stage_via_cpu:
+                    buf = torch.empty((b - a, self.n, 2), dtype=self.out_dtype, device="cpu")
+                    staged.append((a, b, buf))
+                    ops.append(("recv", buf, r))
+                else:
+                    ops.append(("recv", out[a:b], r))  # received straight into its rows of the result
         out[lo:hi] = local
-        for q in reqs:
-            q.wait()
+        self._run_group(ops)
+        for a, b, buf in staged:
+            out[a:b] = buf.to(self.device)
         return out
 
     # -- the three ways to run --------------------------------------------------------------
@@ -104,3 +129,16 @@ def max_over_ranks(seconds: float, device=None, group=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def gather_floats(value: float, device=None, group=None) -> List[float]:
+    """Every rank's `value`, in rank order (per-GPU figures of the bench line)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return [float(o.item()) for o in out]

@@ -57,7 +57,8 @@ int orc_cmult_regime(int w, int t, int xser)
     const int TD = xser ? 28 : 26; /* find_twd_25   :161-173 */
     if (t < 19) {                  /* xGEN_TWD18 :182 */
         if (w < L) return ORC_SNGL;               /* :184 */
-        if (w < H) return ORC_DBL18;              /* :228 */
+        if (w < H)                                /* :228; the product slice starts at bit t-4 (NEW) / t-6 (OLD): */
+            return (xser ? t - 4 : t - 6) >= 0 ? ORC_DBL18 : ORC_UNSUPPORTED; /* a negative index does not elaborate */
         if (w < T) return ORC_TRPL18;             /* :267 */
         return ORC_UNSUPPORTED;
     }
@@ -674,6 +675,320 @@ int orc_exec_i16(const orc_params *p, int direction, int in_order, int out_order
         free(t0);
     }
     tw_free(&tw);
+    (void)threads;
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* N > 512K: the "2D-FFT scheme" (int_fftNk.vhd:11-13, row_twiddle_tay.vhd:31)                 */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference only NAMES the scheme ("For N > 512K you should use 2D-FFT scheme"); its exact   *
+ * arithmetic is undefined there.  This is the extension this project defines (DESIGN.md          *
+ * section 4.5), built from the reference's own blocks:                                           *
+ *   N = N1 * N2, n = n1*N2 + n2, k = k1 + N1*k2, both cores native (log2 N1, log2 N2 in 3..19,   *
+ *   Taylor range ii <= 7):                                                                       *
+ *   FWD  columns: int_fftNk(N1) over n1 for every n2      -> A[k1][n2]                          *
+ *        twiddle: B = int_cmult_dsp48(A, W_N^(k1*n2)) at the column core's output width          *
+ *        rows:    int_fftNk(N2) over n2 for every k1 with DATA_WIDTH = that width -> X[k1+N1*k2] *
+ *   INV  the mirror: rows int_ifftNk(N2), T = D * conj(W) through the re/im-swapped multiplier   *
+ *        feed of int_dit2_fly.vhd:304-322, columns int_ifftNk(N1).                               *
+ * Inter-pass twiddle W_N^m, m in [0, N): the quarter-wave ROM formula of                          *
+ * rom_twiddle_int.vhd:143-152 at full depth (no Taylor step): for a = m mod N/4,                  *
+ * (c, s) = (RN(mg cos(2 pi a / N)), RN(mg sin(-2 pi a / N))), mg as in :143-147; quadrant         *
+ * q = m div N/4 applies (re, im) <- (im, -re) q times (:177-183 is the q = 1 case).               */
+
+void orc_twiddle_2d(int log2n, int twd, size_t m, int64_t *re, int64_t *im)
+{
+    const size_t quarter = (size_t)1 << (log2n - 2);
+    const size_t a = m & (quarter - 1);
+    const int q = (int)((m >> (log2n - 2)) & 3);
+    int64_t c, s;
+    {
+        const double mg = (twd < 18) ? ldexp(1.0, twd - 1) - 1.0 : ldexp(1.0, twd - 2) - 1.0;
+        const double phi = ((double)a * M_PI) / ldexp(1.0, log2n - 1); /* 2 pi a / N */
+        c = rn(mg * cos(phi));
+        s = rn(mg * sin(-phi));
+    }
+    for (int i = 0; i < q; ++i) { /* (re, im) <- (im, -re) */
+        const int64_t t = c;
+        c = s;
+        s = orc_wrap(-t, twd);
+    }
+    *re = c;
+    *im = s;
+}
+
+static int check_2d(const orc_params *p, int l1, int direction)
+{
+    const int L = p->log2n, l2 = L - l1;
+    if (l1 < 3 || l1 > 19 || l2 < 3 || l2 > 19 || L > 24) return -1;
+    if (!p->use_fly) return -1;
+    if (p->data_width < 2 || p->twdl_width < 4) return -1;
+    if ((p->format | 1) != 1 || (p->rndmode | 1) != 1 || (p->format && p->rndmode)) return -1;
+    if (orc_out_width(p, direction) > 64) return -1;
+    orc_params c = *p;
+    int dw = p->data_width;
+    if (direction == ORC_FWD || direction == ORC_PAIR) {
+        c.log2n = l1;
+        if (check_core(&c, dw, 0)) return -1;
+        dw += p->format * l1;
+        if (orc_cmult_regime(dw, p->twdl_width, p->xser) < 0) return -1;
+        c.log2n = l2;
+        if (check_core(&c, dw, 0)) return -1;
+        dw += p->format * l2;
+    }
+    if (direction == ORC_INV || direction == ORC_PAIR) {
+        c.log2n = l2;
+        if (check_core(&c, dw, 1)) return -1;
+        dw += p->format * l2;
+        if (orc_cmult_regime(dw, p->twdl_width, p->xser) < 0) return -1;
+        c.log2n = l1;
+        if (check_core(&c, dw, 1)) return -1;
+    }
+    return 0;
+}
+
+int orc_validate_2d(const orc_params *p, int log2_n1, int direction) { return check_2d(p, log2_n1, direction); }
+
+typedef struct {
+    tw_set tw;          /* per-stage tables, shared by the two cores (a table depends on STAGE only) */
+    int64_t *wre, *wim; /* inter-pass table, N entries */
+} tw2d_set;
+
+static int tw2d_build(tw2d_set *t, const orc_params *p, int l1)
+{
+    const int L = p->log2n, l2 = L - l1;
+    memset(t, 0, sizeof(*t));
+    if (tw_build(&t->tw, l1 > l2 ? l1 : l2, p->twdl_width, p->xser)) return -1;
+    const size_t n = (size_t)1 << L;
+    t->wre = (int64_t *)malloc(n * sizeof(int64_t));
+    t->wim = (int64_t *)malloc(n * sizeof(int64_t));
+    if (!t->wre || !t->wim) return -1;
+    for (size_t m = 0; m < n; ++m) orc_twiddle_2d(L, p->twdl_width, m, &t->wre[m], &t->wim[m]);
+    return 0;
+}
+
+static void tw2d_free(tw2d_set *t)
+{
+    tw_free(&t->tw);
+    free(t->wre);
+    free(t->wim);
+}
+
+/* forward, structural form: literally columns -> twiddle -> rows with the 1-D core functions.
+ * x natural (n = n1*N2 + n2); v[j1*N2 + j2] = X[rev(j1) + N1*rev(j2)] = X[rev_L(j)]. */
+static int fft2d_struct(const orc_params *p, int l1, const tw2d_set *t, const orc_cplx *x, orc_cplx *v, int stream)
+{
+    const int L = p->log2n, l2 = L - l1;
+    const size_t n1 = (size_t)1 << l1, n2 = (size_t)1 << l2, n = n1 * n2;
+    orc_cplx *col = (orc_cplx *)malloc(2 * (n1 > n2 ? n1 : n2) * sizeof(orc_cplx));
+    orc_cplx *a = (orc_cplx *)malloc(n * sizeof(orc_cplx)); /* a[k1*N2 + n2] */
+    if (!col || !a) { free(col); free(a); return -1; }
+    orc_cplx *res = col + (n1 > n2 ? n1 : n2);
+    orc_params c = *p;
+    c.log2n = l1;
+    int rc = 0;
+    for (size_t i2 = 0; i2 < n2 && !rc; ++i2) {
+        for (size_t i1 = 0; i1 < n1; ++i1) col[i1] = x[i1 * n2 + i2];
+        rc = stream ? fft_stream_tw(&c, &t->tw, col, res) : fft_inplace_tw(&c, &t->tw, col, res);
+        for (size_t j1 = 0; j1 < n1; ++j1) a[bitrev(j1, l1) * n2 + i2] = res[j1]; /* res[j1] = A[rev j1] */
+    }
+    const int w1 = p->data_width + p->format * l1;
+    for (size_t k1 = 0; k1 < n1 && !rc; ++k1) {
+        for (size_t i2 = 0; i2 < n2; ++i2) {
+            const size_t m = (k1 * i2) & (n - 1);
+            orc_cplx *e = &a[k1 * n2 + i2];
+            int64_t yr, yi;
+            if (orc_cmult(e->re, e->im, t->wre[m], t->wim[m], w1, p->twdl_width, p->xser, &yr, &yi)) rc = -1;
+            e->re = yr;
+            e->im = yi;
+        }
+        c.log2n = l2;
+        c.data_width = w1;
+        if (!rc) rc = stream ? fft_stream_tw(&c, &t->tw, a + k1 * n2, res) : fft_inplace_tw(&c, &t->tw, a + k1 * n2, res);
+        for (size_t j2 = 0; j2 < n2; ++j2) v[bitrev(k1, l1) * n2 + j2] = res[j2]; /* res[j2] = C[k1][rev j2] */
+    }
+    free(col);
+    free(a);
+    return rc;
+}
+
+/* inverse, structural form: v[j] = X[rev_L j] in, x natural out */
+static int ifft2d_struct(const orc_params *p, int l1, const tw2d_set *t, const orc_cplx *v, orc_cplx *x, int stream)
+{
+    const int L = p->log2n, l2 = L - l1;
+    const size_t n1 = (size_t)1 << l1, n2 = (size_t)1 << l2, n = n1 * n2;
+    orc_cplx *col = (orc_cplx *)malloc(2 * (n1 > n2 ? n1 : n2) * sizeof(orc_cplx));
+    orc_cplx *d = (orc_cplx *)malloc(n * sizeof(orc_cplx)); /* d[j1*N2 + n2], row j1 <-> k1 = rev(j1) */
+    if (!col || !d) { free(col); free(d); return -1; }
+    orc_cplx *res = col + (n1 > n2 ? n1 : n2);
+    orc_params c = *p;
+    int rc = 0;
+    const int w = p->data_width + p->format * l2; /* DIT multiplies at its input width (int_dit2_fly.vhd:307) */
+    for (size_t j1 = 0; j1 < n1 && !rc; ++j1) {
+        c.log2n = l2;
+        c.data_width = p->data_width;
+        rc = stream ? ifft_stream_tw(&c, &t->tw, v + j1 * n2, d + j1 * n2) : ifft_inplace_tw(&c, &t->tw, v + j1 * n2, d + j1 * n2);
+        const size_t k1 = bitrev(j1, l1);
+        for (size_t i2 = 0; i2 < n2 && !rc; ++i2) {
+            const size_t m = (k1 * i2) & (n - 1);
+            orc_cplx *e = &d[j1 * n2 + i2];
+            int64_t ore, oim; /* swapped feed: DI_RE <- B.im, DI_IM <- B.re; DO_RE -> T.im, DO_IM -> T.re */
+            if (orc_cmult(e->im, e->re, t->wre[m], t->wim[m], w, p->twdl_width, p->xser, &ore, &oim)) rc = -1;
+            e->im = ore;
+            e->re = oim;
+        }
+    }
+    c.log2n = l1;
+    c.data_width = w;
+    for (size_t i2 = 0; i2 < n2 && !rc; ++i2) {
+        for (size_t j1 = 0; j1 < n1; ++j1) col[j1] = d[j1 * n2 + i2]; /* bit-reversed in k1: the core's native input */
+        rc = stream ? ifft_stream_tw(&c, &t->tw, col, res) : ifft_inplace_tw(&c, &t->tw, col, res);
+        for (size_t i1 = 0; i1 < n1; ++i1) x[i1 * n2 + i2] = res[i1];
+    }
+    free(col);
+    free(d);
+    return rc;
+}
+
+/* flat form: one array, the column stages on index bits L-1..L2 with the column core's tables (index = position
+ * div N2), one multiply sweep, the row stages on bits L2-1..0 -- what the GPU kernels evaluate */
+static int fft2d_flat(const orc_params *p, int l1, const tw2d_set *t, const orc_cplx *x, orc_cplx *v)
+{
+    const int L = p->log2n, l2 = L - l1;
+    const size_t n = (size_t)1 << L, n2 = (size_t)1 << l2;
+    for (size_t i = 0; i < n; ++i) {
+        v[i].re = orc_wrap(x[i].re, p->data_width);
+        v[i].im = orc_wrap(x[i].im, p->data_width);
+    }
+    for (int ii = 0; ii < L; ++ii) {
+        const int col = ii < l1;
+        const int stage = col ? l1 - ii - 1 : L - ii - 1; /* STAGE generic of the core the stage belongs to */
+        const int sh = col ? l2 : 0;
+        const int dtw = p->data_width + ii * p->format;
+        const size_t h = (size_t)1 << (stage + sh);
+        if (ii == l1) { /* between the cores */
+            const int w1 = p->data_width + p->format * l1;
+            for (size_t j = 0; j < n; ++j) {
+                const size_t m = (bitrev(j >> l2, l1) * (j & (n2 - 1))) & (n - 1);
+                int64_t yr, yi;
+                if (orc_cmult(v[j].re, v[j].im, t->wre[m], t->wim[m], w1, p->twdl_width, p->xser, &yr, &yi)) return -1;
+                v[j].re = yr;
+                v[j].im = yi;
+            }
+        }
+        for (size_t g = 0; g < n; g += 2 * h)
+            for (size_t k = 0; k < h; ++k) {
+                const size_t kt = k >> sh;
+                const int64_t wr = stage >= 2 ? t->tw.re[stage][kt] : 0, wi = stage >= 2 ? t->tw.im[stage][kt] : 0;
+                orc_cplx ox, oy;
+                orc_dif_fly(p, stage, dtw, (int)(kt & 1), v[g + k], v[g + k + h], wr, wi, &ox, &oy);
+                v[g + k] = ox;
+                v[g + k + h] = oy;
+            }
+    }
+    return 0;
+}
+
+static int ifft2d_flat(const orc_params *p, int l1, const tw2d_set *t, const orc_cplx *v, orc_cplx *x)
+{
+    const int L = p->log2n, l2 = L - l1;
+    const size_t n = (size_t)1 << L, n2 = (size_t)1 << l2;
+    for (size_t i = 0; i < n; ++i) {
+        x[i].re = orc_wrap(v[i].re, p->data_width);
+        x[i].im = orc_wrap(v[i].im, p->data_width);
+    }
+    for (int ii = 0; ii < L; ++ii) {
+        const int col = ii >= l2;
+        const int stage = col ? ii - l2 : ii;
+        const int sh = col ? l2 : 0;
+        const int dtw = p->data_width + ii * p->format;
+        const size_t h = (size_t)1 << (stage + sh);
+        if (ii == l2) {
+            for (size_t j = 0; j < n; ++j) {
+                const size_t m = (bitrev(j >> l2, l1) * (j & (n2 - 1))) & (n - 1);
+                int64_t ore, oim;
+                if (orc_cmult(x[j].im, x[j].re, t->wre[m], t->wim[m], dtw, p->twdl_width, p->xser, &ore, &oim)) return -1;
+                x[j].im = ore;
+                x[j].re = oim;
+            }
+        }
+        for (size_t g = 0; g < n; g += 2 * h)
+            for (size_t k = 0; k < h; ++k) {
+                const size_t kt = k >> sh;
+                const int64_t wr = stage >= 2 ? t->tw.re[stage][kt] : 0, wi = stage >= 2 ? t->tw.im[stage][kt] : 0;
+                orc_cplx ox, oy;
+                orc_dit_fly(p, stage, dtw, (int)(kt & 1), x[g + k], x[g + k + h], wr, wi, &ox, &oy);
+                x[g + k] = ox;
+                x[g + k + h] = oy;
+            }
+    }
+    return 0;
+}
+
+/* form: 0 = structural with the stream-form cores, 1 = flat, 2 = structural with the in-place cores */
+static int exec_frame_2d(const orc_params *p, int l1, const tw2d_set *t, int direction, int in_order, int out_order,
+                         const orc_cplx *in, orc_cplx *out, orc_cplx *t0, orc_cplx *t1, int form)
+{
+    const int L = p->log2n;
+    const size_t n = (size_t)1 << L;
+    int rc = 0;
+    if (direction == ORC_FWD || direction == ORC_PAIR) {
+        for (size_t m = 0; m < n; ++m) {
+            t0[orc_order_index(in_order, L, m)].re = orc_wrap(in[m].re, p->data_width);
+            t0[orc_order_index(in_order, L, m)].im = orc_wrap(in[m].im, p->data_width);
+        }
+        rc = form == 1 ? fft2d_flat(p, l1, t, t0, t1) : fft2d_struct(p, l1, t, t0, t1, form == 0);
+        if (rc) return rc;
+        if (direction == ORC_FWD) {
+            for (size_t m = 0; m < n; ++m) out[m] = t1[bitrev(orc_order_index(out_order, L, m), L)];
+            return 0;
+        }
+        orc_params q = *p;
+        q.data_width = p->data_width + p->format * L;
+        rc = form == 1 ? ifft2d_flat(&q, l1, t, t1, t0) : ifft2d_struct(&q, l1, t, t1, t0, form == 0);
+        if (rc) return rc;
+        for (size_t m = 0; m < n; ++m) out[m] = t0[orc_order_index(out_order, L, m)];
+        return 0;
+    }
+    for (size_t m = 0; m < n; ++m) {
+        t0[bitrev(orc_order_index(in_order, L, m), L)].re = orc_wrap(in[m].re, p->data_width);
+        t0[bitrev(orc_order_index(in_order, L, m), L)].im = orc_wrap(in[m].im, p->data_width);
+    }
+    rc = form == 1 ? ifft2d_flat(p, l1, t, t0, t1) : ifft2d_struct(p, l1, t, t0, t1, form == 0);
+    if (rc) return rc;
+    for (size_t m = 0; m < n; ++m) out[m] = t1[orc_order_index(out_order, L, m)];
+    return 0;
+}
+
+int orc_exec_2d(const orc_params *p, int log2_n1, int direction, int in_order, int out_order, const int64_t *in,
+                int64_t *out, size_t batch, int form, int threads)
+{
+    if (check_2d(p, log2_n1, direction)) return -1;
+    const size_t n = (size_t)1 << p->log2n;
+    tw2d_set t;
+    if (tw2d_build(&t, p, log2_n1)) { tw2d_free(&t); return -2; }
+    int err = 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    if ((size_t)threads > batch) threads = (int)(batch ? batch : 1);
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        orc_cplx *t0 = (orc_cplx *)malloc(2 * n * sizeof(orc_cplx));
+        orc_cplx *t1 = t0 ? t0 + n : NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long long f = 0; f < (long long)batch; ++f) {
+            if (!t0) { err = -2; continue; }
+            const orc_cplx *fi = (const orc_cplx *)(in + 2 * n * (size_t)f);
+            orc_cplx *fo = (orc_cplx *)(out + 2 * n * (size_t)f);
+            if (exec_frame_2d(p, log2_n1, &t, direction, in_order, out_order, fi, fo, t0, t1, form)) err = -3;
+        }
+        free(t0);
+    }
+    tw2d_free(&t);
     (void)threads;
     return err;
 }

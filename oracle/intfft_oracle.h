@@ -75,6 +75,15 @@ int orc_exec_i16(const orc_params *p, int direction, int in_order, int out_order
                  const int16_t *in, int16_t *out, size_t batch, int form, int threads);
 int orc_num_threads(void);
 
+/* N > 512K, "2D-FFT scheme" (int_fftNk.vhd:11-13) -- THIS PROJECT'S EXTENSION, the reference only names it:
+ * N = 2^log2n = N1 * N2, N1 = 2^log2_n1 column core first (FWD) / last (INV), both cores native (3..19).
+ * Definition and citations: the comment block in intfft_oracle.c.  form: 0 structural with the stream-form
+ * cores, 1 flat in-place (what the GPU evaluates), 2 structural with the in-place cores; all three must agree. */
+void orc_twiddle_2d(int log2n, int twd, size_t m, int64_t *re, int64_t *im);
+int orc_validate_2d(const orc_params *p, int log2_n1, int direction);
+int orc_exec_2d(const orc_params *p, int log2_n1, int direction, int in_order, int out_order,
+                const int64_t *in, int64_t *out, size_t batch, int form, int threads);
+
 #ifdef __cplusplus
 }
 #endif

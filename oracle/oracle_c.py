@@ -54,6 +54,11 @@ def lib():
                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                ctypes.c_int]
         L.orc_exec_i16.argtypes = L.orc_exec.argtypes
+        L.orc_exec_2d.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
+        L.orc_validate_2d.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_int]
+        L.orc_twiddle_2d.restype = None
+        L.orc_twiddle_2d.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, i64p, i64p]
         _LIB = L
     return _LIB
 
@@ -113,6 +118,26 @@ def execute_i16(x: np.ndarray, p: Params, direction=FWD, in_order=NATURAL, out_o
     if rc:
         raise ValueError("orc_exec_i16 failed rc=%d" % rc)
     return out
+
+
+def execute_2d(x: np.ndarray, p: Params, log2_n1: int, direction=FWD, in_order=NATURAL, out_order=NATURAL,
+               form=1, threads=0) -> np.ndarray:
+    """The N > 512K "2D-FFT scheme" extension (see intfft_oracle.c): p.log2n = log2 N, N1 = 2^log2_n1.
+    form 0 structural (stream cores), 1 flat, 2 structural (in-place cores)."""
+    n = 1 << p.log2n
+    a = np.ascontiguousarray(x, dtype=np.int64).reshape(-1, n, 2)
+    out = np.empty_like(a)
+    rc = lib().orc_exec_2d(ctypes.byref(p), log2_n1, direction, in_order, out_order, a.ctypes.data, out.ctypes.data,
+                           a.shape[0], form, threads)
+    if rc:
+        raise ValueError("orc_exec_2d failed rc=%d" % rc)
+    return out
+
+
+def twiddle_2d(log2n: int, t: int, m: int):
+    re, im = ctypes.c_int64(), ctypes.c_int64()
+    lib().orc_twiddle_2d(log2n, t, m, ctypes.byref(re), ctypes.byref(im))
+    return re.value, im.value
 
 
 def num_threads() -> int:

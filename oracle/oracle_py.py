@@ -44,7 +44,8 @@ def cmult_regime(w: int, t: int, new: bool) -> str | None:
         if w < l18:
             return "sngl"
         if l18 - 1 < w < h18:
-            return "dbl18"
+            # product slice P(pwd-1-(18-t) downto pwd-48-(18-t)): its low index t-4 (NEW) / t-6 (OLD) must exist
+            return "dbl18" if (t - 4 if new else t - 6) >= 0 else None
         if h18 - 1 < w < t18:
             return "trpl18"
         return None

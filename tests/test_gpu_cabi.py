@@ -1,0 +1,288 @@
+"""GPU tests of the C-ABI surface added in round 2: the C driver of INTEGRATION.md (no Python in the loop), the
+standalone re-orderer, the overlap rule of intfft_exec, intfft_shard_prepare, the RCCL ("nccl") backend under
+ShardedTransform, and bench.py's own N-rank launch."""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle_c as C
+from tests.helpers import edge_frames, uniform_frames
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NP_DT = {2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ---- the C driver: compiled here with gcc against include/intfft.h, run as its own process ------------------------
+@pytest.fixture(scope="module")
+def c_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cdrv") / "driver")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I%s/include" % rocm,
+           "-I%s" % os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_driver", "driver.c"), "-o", exe,
+           "-L%s" % os.path.join(ROOT, "intfftk_amd", "lib"), "-lintfft", "-L%s/lib" % rocm, "-lamdhip64"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+@pytest.mark.parametrize("nfft,mode,batch", [(7, 0, 33), (7, 1, 33), (7, 2, 33), (10, 0, 100), (10, 2, 9), (13, 0, 3)])
+def test_c_driver_matches_oracle(c_driver, tmp_path, nfft, mode, batch):
+    """fft_signle_test's three UUTs (TRUNCATE / ROUNDING / UNSCALED, fft_signle_test.vhd:93-112) through the plain-C binding."""
+    n = 1 << nfft
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(max(batch - 8, 1), n, 16, 4242 + nfft + mode)])[-batch:]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    x.astype(np.int16).tofile(fin)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "intfftk_amd", "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    r = subprocess.run([c_driver, fin, fout, str(batch), str(nfft), str(mode)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    fmt, rnd = mode // 2, mode % 2
+    p = C.make_params(nfft, 16, 16, fmt, rnd, True)
+    want = C.execute(x, p, C.FWD)
+    cb = 2 if not fmt else (4 if 16 + nfft <= 32 else 8)
+    got = np.fromfile(fout, dtype=NP_DT[cb]).reshape(batch, n, 2).astype(np.int64)
+    assert np.array_equal(got, want)
+
+
+# ---- intfft_reorder: the buffers/ blocks as an operator ------------------------------------------------------------
+def _order_index(order, log2n):
+    L = C.lib()
+    return np.array([L.orc_order_index(order, log2n, m) for m in range(1 << log2n)], dtype=np.int64)
+
+
+@pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 12, 13, 16])
+@pytest.mark.parametrize("cb", [2, 4, 8])
+def test_reorder_all_order_pairs(log2n, cb):
+    """d_out[m_out] = d_in[m_in] with the same logical index on both sides, for all 16 (from, to) pairs -- among them
+    int_bitrev_order (BITREV_LANES -> NATURAL, int_bitrev_order.vhd:82-104) and bitrevorder (NATURAL <-> BITREV)."""
+    import torch
+
+    from intfftk_amd import _capi as capi
+
+    n = 1 << log2n
+    batch = 3 if log2n >= 12 else 7
+    rng = np.random.default_rng(log2n * 10 + cb)
+    x = rng.integers(-(1 << 14), 1 << 14, size=(batch, n, 2)).astype(NP_DT[cb])
+    xd = torch.from_numpy(x).cuda()
+    maps = {o: _order_index(o, log2n) for o in range(4)}  # memory index -> logical index
+    for fo in range(4):
+        inv_from = np.empty(n, dtype=np.int64)
+        inv_from[maps[fo]] = np.arange(n)  # logical -> memory index of the input
+        for to in range(4):
+            yd = torch.zeros_like(xd)
+            rc = capi.lib().intfft_reorder(log2n, cb, fo, to, xd.data_ptr(), yd.data_ptr(), batch, 0, None)
+            assert rc == 0, capi.strerror(rc)
+            torch.cuda.synchronize()
+            want = x[:, inv_from[maps[to]], :]
+            assert np.array_equal(yd.cpu().numpy(), want), (fo, to)
+
+
+def test_reorder_then_transform_equals_ordered_plan():
+    """The wrappers' composition (int_fft_single_path.vhd:157-268): int_fftNk in its native orders, followed by the
+    BITREV -> NATURAL re-order, equals the NATURAL-order plan; errors are status codes."""
+    import torch
+
+    from intfftk_amd import _capi as capi
+    from intfftk_amd import int_fft_single_path, int_fftNk
+
+    x = uniform_frames(9, 1024, 15, 99).astype(np.int16)
+    xd = torch.from_numpy(x).cuda()
+    halves = torch.empty_like(xd)
+    L = capi.lib()
+    assert L.intfft_reorder(10, 2, capi.ORDER_NATURAL, capi.ORDER_HALVES, xd.data_ptr(), halves.data_ptr(), 9, 0, None) == 0
+    beats = int_fftNk(10, 16, 16, 0, 0)(halves)
+    nat = torch.empty_like(beats)
+    assert L.intfft_reorder(10, 2, capi.ORDER_BITREV, capi.ORDER_NATURAL, beats.data_ptr(), nat.data_ptr(), 9, 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(nat, int_fft_single_path(10, 16, 16, 0, 0)(xd))
+    assert L.intfft_reorder(10, 2, 0, 1, xd.data_ptr(), xd.data_ptr(), 9, 0, None) == capi.ERR_INVALID  # in place
+    assert L.intfft_reorder(10, 3, 0, 1, xd.data_ptr(), nat.data_ptr(), 9, 0, None) == capi.ERR_INVALID
+    assert L.intfft_reorder(2, 2, 0, 1, xd.data_ptr(), nat.data_ptr(), 9, 0, None) == capi.ERR_INVALID
+    assert L.intfft_reorder(10, 2, 0, 4, xd.data_ptr(), nat.data_ptr(), 9, 0, None) == capi.ERR_INVALID
+    assert L.intfft_reorder(10, 2, 0, 1, None, nat.data_ptr(), 9, 0, None) == capi.ERR_NULL
+    assert L.intfft_reorder(10, 2, 0, 1, xd.data_ptr(), nat.data_ptr(), 9, 99, None) == capi.ERR_NO_DEVICE
+
+
+# ---- intfft_exec: in place only as d_in == d_out with equal containers ---------------------------------------------
+def test_exec_rejects_partial_overlap():
+    import torch
+
+    from intfftk_amd import IntFFTCore
+    from intfftk_amd import _capi as capi
+
+    scaled = IntFFTCore(10, 16, 16, 0, 0)
+    x = torch.from_numpy(uniform_frames(8, 1024, 15, 5).astype(np.int16)).cuda()
+    want = scaled(x).clone()
+    L = capi.lib()
+    buf = torch.zeros((9, 1024, 2), dtype=torch.int16, device="cuda")
+    buf[:8] = x
+    assert L.intfft_exec(scaled._plan, buf.data_ptr(), buf.data_ptr() + 4096, 8, None) == capi.ERR_INVALID  # shifted by a frame
+    assert L.intfft_exec(scaled._plan, buf.data_ptr(), buf.data_ptr(), 8, None) == 0                          # in place
+    torch.cuda.synchronize()
+    assert torch.equal(buf[:8], want)
+    unscaled = IntFFTCore(10, 16, 16, 1, 0)  # int16 in, int32 out: in place would overwrite unread frames
+    big = torch.zeros((8, 1024, 2), dtype=torch.int32, device="cuda")
+    assert L.intfft_exec(unscaled._plan, big.data_ptr(), big.data_ptr(), 8, None) == capi.ERR_INVALID
+    assert L.intfft_exec(unscaled._plan, big.data_ptr() + 8 * 1024 * 2 * 2 - 2, big.data_ptr(), 2, None) == capi.ERR_INVALID
+
+
+def test_io_widths_and_plan_create_agree():
+    """validate() is shared: whatever intfft_io_widths accepts, intfft_plan_create elaborates (and the oracle agrees)."""
+    from intfftk_amd import _capi as capi
+
+    L = capi.lib()
+    for (dw, tw, xser, fmt) in [(16, 26, 0, 0), (16, 25, 0, 0), (16, 28, 1, 0), (16, 27, 1, 0), (30, 5, 0, 0), (30, 6, 0, 0),
+                                (30, 5, 1, 0), (50, 16, 1, 1), (60, 16, 1, 0), (40, 24, 1, 0)]:
+        p = capi.Params(6, dw, tw, fmt, 0, xser, capi.FWD, 1, 0, 0)
+        a = L.intfft_io_widths(ctypes.byref(p), None, None, None, None)
+        plan = ctypes.c_void_p()
+        b = L.intfft_plan_create(ctypes.byref(plan), ctypes.byref(p), 0)
+        if plan.value:
+            L.intfft_plan_destroy(plan)
+        oracle_ok = C.lib().orc_validate(ctypes.byref(C.make_params(6, dw, tw, fmt, 0, bool(xser))), C.FWD) == 0
+        assert a == b, (dw, tw, xser, a, b)
+        assert (a == 0) == oracle_ok, (dw, tw, xser, a, oracle_ok)
+
+
+# ---- intfft_shard_prepare ------------------------------------------------------------------------------------------
+def test_shard_prepare_then_exec_sharded():
+    import torch
+
+    from intfftk_amd import IntFFTCore, exec_sharded
+    from intfftk_amd import _capi as capi
+
+    ndev = torch.cuda.device_count()
+    cores = [IntFFTCore(12, 16, 16, 0, 0, "NEW", "PAIR", device=i % ndev) for i in range(3)]
+    arr = (ctypes.c_void_p * 3)(*[c._plan for c in cores])
+    assert capi.lib().intfft_shard_prepare(arr, 3, 1, 64) == 0
+    x = uniform_frames(50, 4096, 15, 8)
+    s = torch.cuda.Stream()  # produced on a side stream: the call waits for the whole root device (contract in intfft.h)
+    with torch.cuda.stream(s):
+        xd = torch.from_numpy(x.astype(np.int16)).to("cuda:%d" % (1 % ndev), non_blocking=True)
+    y = exec_sharded(cores, xd, 1)
+    want = C.execute(x, C.make_params(12, 16, 16, 0, 0, True), C.PAIR)
+    assert np.array_equal(y.cpu().numpy().astype(np.int64), want)
+    assert capi.lib().intfft_shard_prepare(arr, 3, 7, 64) == capi.ERR_INVALID
+    with pytest.raises(ValueError):
+        exec_sharded(cores, xd.cpu(), 1)
+    with pytest.raises(ValueError):
+        exec_sharded([cores[0], cores[0]], xd, 0)
+    for c in cores:
+        c.close()
+
+
+def test_exec_host_rejects_wrong_dtype():
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(7, 16, 16, 0, 0)
+    with pytest.raises(TypeError):
+        core.exec_host(np.zeros((2, 128, 2), dtype=np.int32))
+    with pytest.raises(TypeError):
+        core.exec_host(np.zeros((2, 128, 2), dtype=np.float64))
+    assert core.exec_host(np.zeros((2, 128, 2), dtype=np.int16)).shape == (2, 128, 2)
+
+
+# ---- RCCL under ShardedTransform: world = every visible GPU --------------------------------------------------------
+_NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+from intfftk_amd import int_fft_single_path
+from intfftk_amd.sharding import ShardedTransform, max_over_ranks, gather_floats
+core = int_fft_single_path(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, device=rank)
+sh = ShardedTransform(core, 1024, core.in_dtype, core.out_dtype, dev)
+batch = 37
+g = torch.Generator(device="cpu"); g.manual_seed(7)
+full = torch.randint(-2 ** 14, 2 ** 14, (batch, 1024, 2), dtype=torch.int16, generator=g)
+out = sh.run_from_root(full.to(dev) if rank == 0 else None, batch, 0)
+t = torch.ones(1, device=dev); dist.all_reduce(t)
+assert int(t.item()) == world
+assert abs(max_over_ranks(1.0 + rank, dev) - world) < 1e-12
+assert gather_floats(float(rank), dev) == [float(r) for r in range(world)]
+if rank == 0:
+    torch.save(out.cpu(), os.environ["OUT_FILE"])
+    torch.save(full, os.environ["IN_FILE"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_sharded_transform_on_rccl(tmp_path):
+    """scatter -> transform -> gather with backend "nccl" (= RCCL) at world = device_count: grouped ncclSend / ncclRecv
+    between GPUs where the box has several, the degenerate one-rank group on a 1-GPU box (same code path)."""
+    import torch
+
+    world = torch.cuda.device_count()
+    port = _free_port()
+    script = tmp_path / "w.py"
+    script.write_text(_NCCL_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OUT_FILE=str(tmp_path / "out.pt"), IN_FILE=str(tmp_path / "in.pt"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    full = torch.load(tmp_path / "in.pt").numpy()
+    out = torch.load(tmp_path / "out.pt").numpy()
+    want = C.execute_i16(full, C.make_params(10, 16, 16, 0, 0, True), C.FWD)
+    assert np.array_equal(out, want)
+
+
+# ---- bench.py launches its own ranks -------------------------------------------------------------------------------
+def _bench(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no launcher: two ranks, ONE line, n_gpus = 2.  With fewer than 2 GPUs the ranks
+    share the device over gloo (INTFFT_BENCH_SHARE_GPU=1, diagnostics); with >= 2 GPUs this runs over RCCL."""
+    import torch
+
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "2048", "--e2e", "--no-cpu-baseline"],
+                 {"INTFFT_BENCH_SHARE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2
+    assert out["config"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert len(out["per_gpu"]["kernel_ms"]) == 2 and all(v > 0 for v in out["per_gpu"]["Gsample/s"])
+    assert out["e2e"]["matches_resident"] is True and out["e2e"]["frames"] == 4096
+    assert out["e2e"]["p2p_ops_per_group"] == [1, 1]  # the root's scatter group and gather group: one peer each
+    assert out["scaling"] == "weak" and out["unit"] == "Gsample/s"
+
+
+def test_bench_single_gpu_line_has_the_8d_fields():
+    out = _bench(["--steps", "5", "--warmup", "2", "--prewarm", "20", "--batch", "4096", "--e2e"])
+    assert out["n_gpus"] == 1 and out["metric"].startswith("Gsample/s (complex int16) batched N=1024")
+    for key in ("roofline", "cpu_baseline", "cold", "full_scale_input", "copy_ceiling", "valu_bound", "octave", "e2e", "per_gpu"):
+        assert key in out, key
+    assert out["cpu_baseline"]["parity_ok"] is True and out["cpu_baseline"]["in_place_form"]["parity_ok"] is True
+    assert out["cpu_baseline"]["single_thread"]["cores"] == 1
+    assert out["roofline"]["traffic"] is None  # not BASELINE's batch: no static PMC figure is attached
+    assert out["e2e"]["matches_resident"] is True
+    c5 = _bench(["--config", "C5", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "512", "--no-extras"])
+    assert c5["config"]["n"] == 4096 and c5["cpu_baseline"]["parity_ok"] is True

@@ -50,6 +50,12 @@ def _worker(rank, world, port, batch, q):
         full = torch.from_numpy(rng.integers(-2 ** 14, 2 ** 14, size=(batch, n, 2)).astype(np.int16))
         out = sh.run_from_root(full if rank == 0 else None, batch, root=0)
         ok = True
+        # scatter and gather are ONE point-to-point group each (on RCCL: ncclGroupStart .. ncclGroupEnd), holding one
+        # operation per non-empty peer shard on the root and one operation on every other rank with a shard
+        peers = sum(1 for r, (a, b) in enumerate(shard_bounds(batch, world)) if r != 0 and b > a)
+        lo0, hi0 = shard_bounds(batch, world)[rank]
+        want_ops = peers if rank == 0 else (1 if hi0 > lo0 else 0)
+        ok = ok and sh.last_group_sizes == [want_ops, want_ops]
         if rank == 0:
             want = torch.from_numpy(C.execute_i16(full.numpy(), p, C.FWD))
             ok = torch.equal(out, want)

@@ -1,0 +1,83 @@
+// diag_kernels.hip -- on-box ceilings printed next to the bench line (libintfft_diag.so; NOT part of the product library
+// and never on the measured path).  Two probes, both launched by bench.py, which does the timing with HIP events:
+//   diag_copy_wave_nt   a non-temporal copy with the access pattern of k_fft1024_i16 (one wave per 4 KiB frame, 16 dword
+//                       loads then 16 dword stores per lane): the memory-side ceiling of that kernel's own pattern
+//   diag_valu_chain     N dependent-free packed-int16 adds per lane on 8 register sets: the issue rate of the "slow class"
+//                       VALU instructions (v_pk_*, v_dot2, v_perm, v_bfe) the packed butterflies are made of
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+typedef unsigned u32;
+
+__global__ __launch_bounds__(256) void k_copy_wave_nt(const u32 *in, u32 *out, size_t nframes)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t f = (size_t)blockIdx.x * 4 + wv; f < nframes; f += (size_t)gridDim.x * 4) {
+        const u32 *s = in + f * 1024 + lane;
+        u32 *d = out + f * 1024 + lane;
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(s + 64 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], d + 64 * j);
+    }
+}
+
+#define DIAG_UNROLL 8
+template <int SLOW> __global__ __launch_bounds__(256) void k_valu_chain(u32 *out, u32 seed, int iters)
+{
+    u32 a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    const u32 b = a0 ^ 0x5a5au;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < DIAG_UNROLL; ++u) {
+            if (SLOW)
+                asm volatile("v_pk_add_u16 %0, %0, %8\n\tv_pk_add_u16 %1, %1, %8\n\tv_pk_add_u16 %2, %2, %8\n\tv_pk_add_u16 %3, %3, %8\n\t"
+                             "v_pk_add_u16 %4, %4, %8\n\tv_pk_add_u16 %5, %5, %8\n\tv_pk_add_u16 %6, %6, %8\n\tv_pk_add_u16 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                             : "v"(b));
+            else
+                asm volatile("v_add_u32 %0, %0, %8\n\tv_add_u32 %1, %1, %8\n\tv_add_u32 %2, %2, %8\n\tv_add_u32 %3, %3, %8\n\t"
+                             "v_add_u32 %4, %4, %8\n\tv_add_u32 %5, %5, %8\n\tv_add_u32 %6, %6, %8\n\tv_add_u32 %7, %7, %8"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                             : "v"(b));
+        }
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+extern "C" {
+
+// grid = blocks_per_cu x CUs of the current device; returns a hipError_t
+int diag_copy_wave_nt(const void *d_in, void *d_out, size_t nframes, int blocks_per_cu, void *stream)
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(k_copy_wave_nt, dim3((unsigned)(cus * blocks_per_cu)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32 *)d_in, (u32 *)d_out, nframes);
+    return (int)hipGetLastError();
+}
+
+// launches 4 waves per SIMD on every CU (grid = 4 x CUs blocks of 256); d_out holds >= 4 * CUs * 256 dwords.
+// wave-instructions issued per launch = *n_wave_insts (8 * DIAG_UNROLL * iters per wave)
+int diag_valu_chain(int slow, int iters, void *d_out, unsigned long long *n_wave_insts, void *stream)
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)cus * 4;
+    if (slow) hipLaunchKernelGGL(k_valu_chain<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32 *)d_out, 12345u, iters);
+    else hipLaunchKernelGGL(k_valu_chain<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32 *)d_out, 12345u, iters);
+    if (n_wave_insts) *n_wave_insts = (unsigned long long)grid * 4ull * 8ull * DIAG_UNROLL * (unsigned long long)iters;
+    return (int)hipGetLastError();
+}
+
+int diag_device_cus(void)
+{
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+}
