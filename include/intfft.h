@@ -97,6 +97,20 @@ int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *i
  * chooses the kernels.  intfft_exec never modifies the plan; intfft_exec_host, intfft_shard_prepare and
  * intfft_exec_sharded create (grow-only) staging state inside it on first use -- see their comments. */
 int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device);
+/* N > 512K: the "2D-FFT scheme" the reference names but does not define (int_fftNk.vhd:11-13: "For N > 512K you should
+ * use 2D-FFT scheme"; row_twiddle_tay.vhd:31).  THIS IS AN EXTENSION OF THIS LIBRARY, specified in DESIGN.md section 4.5
+ * and restated in oracle/: N = 2^log2n = N1 * N2 with N1 = 2^log2_n1 and both factors native core lengths (3..19 bits,
+ * log2n <= 24), built from the reference's own blocks --
+ *   forward  N1-point int_fftNk over n1 (n = n1*N2 + n2) for every n2; one int_cmult_dsp48 per sample by the inter-pass
+ *            twiddle W_N^(k1*n2) (the quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full depth, no Taylor
+ *            step) at the width reached there; N2-point int_fftNk over n2 for every k1; X[k1 + N1*k2]
+ *   inverse  the mirror with int_ifftNk and the re/im-swapped multiplier feed (int_dit2_fly.vhd:304-322); pair = both.
+ * Widths, scaling, rounding, XSER, orders and containers mean what they mean for the 1-D cores (DATA_WIDTH + FORMAT*log2n
+ * bits out); `intfft_params.log2n` is the TOTAL length, so the ABI struct is unchanged.  Results differ in the last bits
+ * from a 1-D plan of the same length (different twiddle factorisation); both are within the same distance of the exact
+ * DFT.  use_fly = 0 is not defined for this scheme (INTFFT_ERR_INVALID).  intfft_twiddles(plan, -1, ..) returns the
+ * inter-pass table (N entries), stages 0 .. max(log2 N1, log2 N2) - 1 the per-stage tables shared by the two cores. */
+int intfft_plan_create_2d(intfft_plan **out, const intfft_params *p, int log2_n1, int hip_device);
 int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 

@@ -15,7 +15,7 @@ ORDERS = {"NATURAL": 0, "BITREV": 1, "HALVES": 2, "BITREV_LANES": 3}
 DIRECTIONS = {"FWD": 0, "INV": 1, "PAIR": 2}
 
 # every symbol include/intfft.h declares
-SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_destroy", "intfft_plan_get_info",
+SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy", "intfft_plan_get_info",
            "intfft_exec", "intfft_exec_host", "intfft_shard_prepare", "intfft_exec_sharded", "intfft_reorder",
            "intfft_twiddles", "intfft_strerror", "intfft_version")
 
@@ -62,6 +62,7 @@ def lib():
         ip = ctypes.POINTER(ctypes.c_int)
         L.intfft_io_widths.argtypes = [pp, ip, ip, ip, ip]
         L.intfft_plan_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), pp, ctypes.c_int]
+        L.intfft_plan_create_2d.argtypes = [ctypes.POINTER(ctypes.c_void_p), pp, ctypes.c_int, ctypes.c_int]
         L.intfft_plan_destroy.argtypes = [ctypes.c_void_p]
         L.intfft_plan_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]
         L.intfft_exec.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
@@ -78,7 +79,7 @@ def lib():
         L.intfft_strerror.restype = ctypes.c_char_p
         L.intfft_strerror.argtypes = [ctypes.c_int]
         L.intfft_version.restype = ctypes.c_char_p
-        for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_destroy",
+        for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy",
                    "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded",
                    "intfft_shard_prepare", "intfft_reorder", "intfft_twiddles"):
             getattr(L, fn).restype = ctypes.c_int

@@ -13,13 +13,17 @@
 
 namespace intfft {
 
-enum StageKind : int { KIND_DIF = 0, KIND_DIT = 1 };
+// KIND_TWMUL / KIND_TWMULC: the inter-pass twiddle multiply of the N > 512K "2-D scheme" (DESIGN.md section 4.5):
+// a pointwise Y = cmult(V, W_N^(k1*n2)) (forward) / T = V * conj(W) through the re/im-swapped feed (inverse)
+enum StageKind : int { KIND_DIF = 0, KIND_DIT = 1, KIND_TWMUL = 2, KIND_TWMULC = 3 };
 enum RoundKind : int { RND_TRUNC = 0, RND_ROUND = 1, RND_UNSCALED = 2 };
 
 // One butterfly stage as the kernels see it (filled by the host planner).
 struct StageDesc {
     int kind;    // KIND_DIF / KIND_DIT
-    int s;       // STAGE generic of the butterfly/twiddle (pairs differ in index bit s)
+    int s;       // index bit the butterfly pairs on (1-D plans: = the STAGE generic)
+    int ts;      // STAGE generic of the core the stage belongs to: twiddle table, STAGE 0 / 1 special cases (1-D: = s)
+    int tshift;  // twiddle index = (position mod 2^s) >> tshift (2-D scheme, column core: log2 N2; else 0)
     int lb;      // tile-local bit that carries index bit s
     int dtw;     // DTW: width of the stage inputs
     int wo;      // output width DTW - SCALE + 1
@@ -148,9 +152,9 @@ __device__ __forceinline__ void dif_fly(const StageDesc &st, int odd, Cx<T> a, C
     addsub<T>(a.re, b.re, st.rnd, st.wo, s.re, d.re);
     addsub<T>(a.im, b.im, st.rnd, st.wo, s.im, d.im);
     x = s;
-    if (st.s == 0) { // int_dif2_fly.vhd:245-255
+    if (st.ts == 0) { // int_dif2_fly.vhd:245-255
         y = d;
-    } else if (st.s == 1) { // :259-318
+    } else if (st.ts == 1) { // :259-318
         if (!odd) {
             y = d;
         } else {
@@ -169,9 +173,9 @@ __device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, C
                                         int32_t wi, Cx<T> &x, Cx<T> &y)
 {
     Cx<T> t;
-    if (st.s == 0) { // :221-230
+    if (st.ts == 0) { // :221-230
         t = b;
-    } else if (st.s == 1) { // :234-286
+    } else if (st.ts == 1) { // :234-286
         if (!odd) {
             t = b;
         } else {

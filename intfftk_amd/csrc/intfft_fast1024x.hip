@@ -27,11 +27,13 @@ enum { X_INV = 1, X_PAIR = 2 };
 // stages of the frame-number bits are skipped in both cores.  The pair needs no other change (it loads and stores
 // in the L1 layout); the inverse alone loads X[brev_L(n)] with the mirror image of the forward kernel's
 // short-frame store (dwordx4 loads + two lane swaps, LC lane bits per lane_bit<L>()).
-template <int L, int MODE, bool FAST_OK>
+// ROUND: RNDMODE = 1 (rhu2 sums on full-width values, exact extraction, no pre-shifted outputs)
+template <int L, int MODE, bool FAST_OK, bool ROUND = false>
 __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                       const RoundCConsts c, size_t nframes_user, const Slice sl,
                                                       int in_bitrev, int out_halves)
 {
+    static_assert(!ROUND || !FAST_OK, "round mode uses the exact extraction");
     constexpr int FP = 1 << (10 - L), NS = L - 6;        // frames per chunk; executed stages among 9..6
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROWX];
@@ -157,16 +159,16 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 #define INTFFT_XBODY(FX)                                                                                \
     {                                                                                                   \
         if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
-            dif_round<FX, false, NS>(v, ta, sl, sh3);                                                       \
+            dif_round<FX, false, NS, ROUND>(v, ta, sl, sh3);                                                \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
-            group4<false, FX, false, true, false, (NS >= 1 ? 0xA : 0)>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
-            group4<false, FX, false, true, false, (NS >= 1 ? 0xA : 0)>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0)>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0)>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
-            group4<false, FX, false, true, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
-            group4<false, FX, false, true, false, 0xF>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (ROUND ? 0x0 : 0xF)>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
             wave_lds_fence();                                                              \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
             {                                                                                           \
@@ -180,10 +182,10 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;             \
             }                                                                                           \
             wave_lds_fence();                                                              \
-            dif_round_c<FX>(v, c, sl, sh3);                                                             \
+            dif_round_c<FX, ROUND>(v, c, sl, sh3);                                                      \
         }                                                                                               \
         /* inverse core: LC -> L1 */                                                                    \
-        dit_round_c<FX>(v, c, sl);                                                                      \
+        dit_round_c<FX, ROUND>(v, c, sl);                                                               \
         wave_lds_fence();                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) wr_i[ROWX * r] = v[r];                           \
         wave_lds_fence();                                                                  \
@@ -193,16 +195,16 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;                 \
         }                                                                                               \
         wave_lds_fence();                                                                  \
-        group4_dit<FX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);            \
-        group4_dit<FX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl);      \
+        group4_dit<FX, false, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);     \
+        group4_dit<FX, false, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);               \
-        group4_dit<FX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);          \
-        group4_dit<FX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl);        \
+        group4_dit<FX, false, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);   \
+        group4_dit<FX, false, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
-        dit_round<FX, NS>(v, ta, sl);                                                                       \
+        dit_round<FX, NS, ROUND>(v, ta, sl);                                                            \
     }
         if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
         else INTFFT_XBODY(false)
@@ -235,8 +237,9 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
                          int use_fly, int in_order, int out_order)
 {
-    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && use_fly == 1))
+    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
+    if (rndmode && (in_order != 0 || out_order != 0 || getenv("INTFFT_NO_PACKED_ROUND"))) return false; // ROUNDING: natural order
     if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
     // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) in and HALVES (native) out
     return log2n >= 7 && log2n <= 10 &&
@@ -246,23 +249,26 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
 
-template <int L, int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK, bool ROUND = false>
 static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                           const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
 {
-    const size_t cap = resident_blocks(kptr(k_fft1024x_i16<L, MODE, FAST_OK>), 256, 4);
+    const size_t cap = resident_blocks(kptr(k_fft1024x_i16<L, MODE, FAST_OK, ROUND>), 256, 4);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4;
     const unsigned blocks = (unsigned)(need < cap ? need : cap);
-    hipLaunchKernelGGL((k_fft1024x_i16<L, MODE, FAST_OK>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
+    hipLaunchKernelGGL((k_fft1024x_i16<L, MODE, FAST_OK, ROUND>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
                        in_bitrev, out_halves);
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
-                            size_t nframes, const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
+                            size_t nframes, const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream, int round)
 {
+    if (round)
+        return direction == 1 ? launchx<L, X_INV, false, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream)
+                              : launchx<L, X_PAIR, false, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
     if (direction == 1)
         return fast_ok ? launchx<L, X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
                        : launchx<L, X_INV, false>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
@@ -271,7 +277,7 @@ static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *po
 }
 
 hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
-                            const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream)
+                            const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream, int round)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -291,11 +297,11 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
     switch (log2n) {
-    case 6: return launchx_l<6>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
-    case 7: return launchx_l<7>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
-    case 8: return launchx_l<8>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
-    case 9: return launchx_l<9>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
-    default: return launchx_l<10>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);
+    case 6: return launchx_l<6>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, 0, 0, stream, round);
+    case 7: return launchx_l<7>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream, round);
+    case 8: return launchx_l<8>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream, round);
+    case 9: return launchx_l<9>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream, round);
+    default: return launchx_l<10>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream, round);
     }
 }
 

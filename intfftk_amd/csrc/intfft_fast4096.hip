@@ -68,12 +68,15 @@ template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_re
            (((j >> 3) & 1) << lc_bit<L, OB>(7));
 }
 
-template <int L, int MODE, bool FAST_OK, bool OB = false>
+// ROUND: RNDMODE = 1 (the testbench's "ROUNDING" UUT, fft_signle_test.vhd:93-112): rhu2 sums on full-width values, exact
+// extraction, no pre-shifted outputs (so none of the per-thread shift amounts below apply)
+template <int L, int MODE, bool FAST_OK, bool OB = false, bool ROUND = false>
 __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const RoundCConsts c, size_t nframes_user, const Slice sl, int halves)
 {
     static_assert(!OB || MODE == MODE_FWD || MODE == MODE_INV, "native orders: forward or inverse core alone");
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
+    static_assert(!ROUND || (!FAST_OK && MODE != MODE_MID), "round mode: exact extraction, whole frames");
     constexpr int FP = 1 << (12 - L), NS = L - 8;        // frames per 4096-sample chunk; executed stages of round A
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
@@ -203,13 +206,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     {                                                                                                   \
         if (MODE != MODE_INV) {                                                                         \
             if (MODE == MODE_MID) dif_round<FX, true, NS>(v, ta, sl, sh_m);                             \
-            else dif_round<FX, false, NS>(v, ta, sl, sh_b);                                             \
+            else dif_round<FX, false, NS, ROUND>(v, ta, sl, sh_b);                                      \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
-            dif_round<FX, true>(v, tb, sl, sh_b);                                                       \
+            dif_round<FX, true, 4, ROUND>(v, tb, sl, sh_b);                                             \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L, OB>(j)] = v[j]; \
             INTFFT_X_READ(reg1)                                                                         \
-            dif_round_c<FX>(v, c, sl, sh_c);                                                            \
+            dif_round_c<FX, ROUND>(v, c, sl, sh_c);                                                     \
         }                                                                                               \
         if (MODE == MODE_FWD && OB) { /* memory index = n: two lane swaps, dwordx4 stores (1 KiB per wave) */ \
             swap_guard(v);                                                                              \
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                     __builtin_nontemporal_store(v[r], dst + (rev4c(r) << (L - 4)) + lc_off);            \
             }                                                                                           \
         } else {                                                                                        \
-            dit_round_c<FX>(v, c, sl);                                                                  \
+            dit_round_c<FX, ROUND>(v, c, sl);                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
             INTFFT_X_READ(reg0)                                                                         \
-            dit_round<FX>(v, tb, sl);                                                                   \
+            dit_round<FX, 4, ROUND>(v, tb, sl);                                                         \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \
-            dit_round<FX, NS>(v, ta, sl);                                                               \
+            dit_round<FX, NS, ROUND>(v, ta, sl);                                                        \
             if (MODE == MODE_INV && halves) { /* HALVES beats, mirror of the forward load */            \
                 typedef u32 v2u __attribute__((ext_vector_type(2)));                                    \
                 v2u *d2 = reinterpret_cast<v2u *>(dst) + tid;                                           \
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order)
 {
-    if (!((log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-          use_fly == 1))
+    if (!((log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
+    if (rndmode) return in_order == 0 && out_order == 0 && !getenv("INTFFT_NO_PACKED_ROUND"); // ROUNDING: natural order, all three directions
     if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
     if (direction == 1) return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2); // + BITREV in, HALVES out
     return in_order == 0 && out_order == 0;
@@ -275,14 +278,14 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
 
 const char *fast4096_kernel_name() { return "k_fft4096_i16"; }
 
-template <int L, int MODE, bool FAST_OK, bool OB = false>
+template <int L, int MODE, bool FAST_OK, bool OB = false, bool ROUND = false>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream, int halves = 0)
 {
-    const size_t cap = resident_blocks(kptr(k_fft4096_i16<L, MODE, FAST_OK, OB>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft4096_i16<L, MODE, FAST_OK, OB, ROUND>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
     const unsigned blocks = (unsigned)(chunks < cap ? chunks : cap);
-    hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK, OB>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
+    hipLaunchKernelGGL((k_fft4096_i16<L, MODE, FAST_OK, OB, ROUND>), dim3(blocks), dim3(256), 0, stream, in, out, tw, c, nframes, sl,
                        halves);
     return hipGetLastError();
 }
@@ -310,8 +313,15 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
 
 template <int L>
 static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
-                             size_t nframes, const Slice &sl, hipStream_t stream, int lc_bitrev, int halves)
+                             size_t nframes, const Slice &sl, hipStream_t stream, int lc_bitrev, int halves, int round)
 {
+    if (round) {
+        switch (direction) {
+        case 0: return launch4k<L, MODE_FWD, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
+        case 1: return launch4k<L, MODE_INV, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
+        default: return launch4k<L, MODE_PAIR, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
+        }
+    }
     switch (direction) {
     case 0:
         if (lc_bitrev)
@@ -332,7 +342,7 @@ static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *p
 }
 
 hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream)
+                           size_t nframes, hipStream_t stream, int round)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -351,8 +361,8 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    if (log2n == 11) return launch4k_l<11>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves);
-    return launch4k_l<12>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves);
+    if (log2n == 11) return launch4k_l<11>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves, round);
+    return launch4k_l<12>(direction, fast_ok, pin, pout, tw_all, c, nframes, sl, stream, lc_bitrev, halves, round);
 }
 
 } // namespace intfft

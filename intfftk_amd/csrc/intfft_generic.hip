@@ -53,9 +53,9 @@ __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo,
 #pragma unroll
         for (int pr = 0; pr < P / 2; ++pr) {
             const int r0 = ((pr >> i) << (i + 1)) | (pr & (h - 1));
-            const unsigned k = kb + ((unsigned)(r0 & (h - 1)) << s_lo);
+            const unsigned k = (kb + ((unsigned)(r0 & (h - 1)) << s_lo)) >> st.tshift;
             int2 w = make_int2(0, 0);
-            if (st.s >= 2) w = tw[st.tw_off + k];
+            if (st.ts >= 2) w = tw[st.tw_off + k];
             Cx<T> X, Y;
             if (KIND == KIND_DIF) dif_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
             else dit_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
@@ -69,7 +69,8 @@ __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo,
 
 template <typename T>
 __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in, void *out,
-                                                       const int2 *__restrict__ tw, size_t nframes)
+                                                       const int2 *__restrict__ tw, size_t nframes,
+                                                       const int2 *__restrict__ tw2d)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Cx<T> *lds = reinterpret_cast<Cx<T> *>(smem);
@@ -150,8 +151,30 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
     int si = 0;
     while (si < a.nstages) {
         const StageDesc st = a.st[si];
+        if (st.kind == KIND_TWMUL || st.kind == KIND_TWMULC) {
+            // 2-D scheme, between the cores: element j = (j1, n2) is multiplied by W_N^(rev(j1) * n2), tshift = log2 N2
+            const int l2 = st.tshift, l1 = L - l2;
+            for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+                const unsigned f = i >> U, u = i & (tile_n - 1u);
+                const unsigned j = spread(u);
+                const unsigned m = (brev_l(j >> l2, l1) * (j & ((1u << l2) - 1u))) & ((1u << L) - 1u);
+                const int2 w = tw2d[m];
+                Cx<T> &c = lds[pad((f << U) + u)];
+                T ore, oim;
+                if (st.kind == KIND_TWMUL) {
+                    cmult(c.re, c.im, w.x, w.y, st.mw, st.sh_a, st.sh_b, st.narrow, ore, oim);
+                    c.re = ore, c.im = oim;
+                } else { // swapped feed (int_dit2_fly.vhd:304-322)
+                    cmult(c.im, c.re, w.x, w.y, st.mw, st.sh_a, st.sh_b, st.narrow, ore, oim);
+                    c.im = ore, c.re = oim;
+                }
+            }
+            __syncthreads();
+            ++si;
+            continue;
+        }
         int R = 1;
-        while (R < RMAX && si + R < a.nstages && a.st[si + R].kind == st.kind &&
+        while (R < RMAX && si + R < a.nstages && a.st[si + R].kind == st.kind && a.st[si + R].tshift == st.tshift &&
                a.st[si + R].lb == st.lb + (st.kind == KIND_DIF ? -R : R))
             ++R;
         const int lb_lo = st.kind == KIND_DIF ? st.lb - (R - 1) : st.lb;
@@ -233,7 +256,7 @@ const char *pass_kernel_name(int word_bytes)
 }
 
 hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
-                       size_t nframes, hipStream_t stream)
+                       size_t nframes, hipStream_t stream, const int2 *tw2d)
 {
     if (nframes == 0) return hipSuccess;
     const size_t groups = (nframes + (size_t)a.fpb - 1) / (size_t)a.fpb;
@@ -243,11 +266,11 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
     if (word_bytes == 4) {
         allow_max_lds(kptr(&k_pass<int32_t>));
         hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
-                           out, tw, nframes);
+                           out, tw, nframes, tw2d);
     } else {
         allow_max_lds(kptr(&k_pass<int64_t>));
         hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
-                           out, tw, nframes);
+                           out, tw, nframes, tw2d);
     }
     return hipGetLastError();
 }

@@ -59,7 +59,7 @@ template <typename K> inline const void *kptr(K k) { return reinterpret_cast<con
 
 // generic kernels (intfft_generic.hip)
 hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
-                       size_t nframes, hipStream_t stream);
+                       size_t nframes, hipStream_t stream, const int2 *tw2d = nullptr);
 size_t pass_lds_bytes(const PassArgs &a, int word_bytes);
 unsigned pass_threads(const PassArgs &a);
 const char *pass_kernel_name(int word_bytes);
@@ -123,7 +123,7 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
                          int use_fly, int in_order, int out_order);
 hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
                             const int2 *tw_all, const int2 *h_tw,
-                            size_t nframes, hipStream_t stream);
+                            size_t nframes, hipStream_t stream, int round = 0);
 const char *fast1024x_kernel_name();
 
 // unscaled int32 wave kernel for N = 1024, 16-bit in -> 26-bit out (intfft_fast1024u.hip)
@@ -221,7 +221,7 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order);
 hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream);
+                           size_t nframes, hipStream_t stream, int round = 0);
 const char *fast4096_kernel_name();
 
 } // namespace intfft

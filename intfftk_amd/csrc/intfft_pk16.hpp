@@ -248,12 +248,23 @@ struct RoundTw {
 __device__ __forceinline__ constexpr int rev4c(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
 // ---- DIT group of four general butterflies: a_i <- X, b_i <- Y (int_dit2_fly.vhd:142-162, 290-325) ----
-template <bool FASTX, bool SG>
+template <bool FASTX, bool SG, bool ROUND = false>
 __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
                                            const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl)
 {
     const u32 bs[4] = {__builtin_amdgcn_alignbit(b0, b0, 16), __builtin_amdgcn_alignbit(b1, b1, 16),
                        __builtin_amdgcn_alignbit(b2, b2, 16), __builtin_amdgcn_alignbit(b3, b3, 16)};
+    if constexpr (ROUND) { // RNDMODE = 1 (int_dit2_fly.vhd:164-217): T at full width, then rhu2(A +/- T)
+        static_assert(!FASTX, "fast extraction yields T >> 1 only");
+        u32 tf[4];
+        mul2x<16, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, sl.sel, tf[0], tf[1]);
+        mul2x<16, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, sl.sel, tf[2], tf[3]);
+        sumdiff<true, false>(a0, tf[0], a0, b0);
+        sumdiff<true, false>(a1, tf[1], a1, b1);
+        sumdiff<true, false>(a2, tf[2], a2, b2);
+        sumdiff<true, false>(a3, tf[3], a3, b3);
+        return;
+    }
     u32 t[4]; // T >> 1
     if (FASTX) {
         mul4f<SG>(bs, bs, wb, wa, sl.sel_hi, t);
@@ -274,21 +285,45 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
 }
 
 // DIT STAGE 1, odd positions: T.im = B.re, T.re = B.im >= 0 ? -B.im : ~B.im (int_dit2_fly.vhd:264-276)
-__device__ __forceinline__ void bfly_pj_dit(u32 &a, u32 &b)
+template <bool ROUND = false> __device__ __forceinline__ void bfly_pj_dit(u32 &a, u32 &b)
 {
     const u32 rot = __builtin_amdgcn_alignbit(b, b, 16); // lo = B.im, hi = B.re
     const u32 nx = rot ^ 0x0000FFFFu;                     // lo = ~B.im
     const v2s add = {(short)((nx >> 15) & 1u), 0};        // + 1 in the low half iff B.im >= 0
     const u32 t = as_u32(as_v2s(nx) + add);
-    sumdiff<false, false>(a, t, a, b);
+    sumdiff<ROUND, false>(a, t, a, b);
 }
 
 // ---- four DIF stages on register offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0) -----------------------
 // kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount.
 // NS < 4 runs only the last NS stages (short frames: the leading stages belong to frame-number bits).
-template <bool FASTX, bool VARSH0, int NS = 4>
+template <bool FASTX, bool VARSH0, int NS = 4, bool ROUND = false>
 __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl, v2s shv)
 {
+    if constexpr (ROUND) { // RNDMODE = 1: full-width values everywhere (no pre-shifted outputs), exact extraction
+        static_assert(!FASTX, "round mode uses the exact extraction");
+        if constexpr (NS >= 4) {
+            const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
+            const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
+            group4<true, false, false, false, false, 0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+            group4<true, false, false, false, false, 0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        }
+        if constexpr (NS >= 3) {
+            group4<true, false, false, false, false, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+            group4<true, false, false, false, false, 0>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+        }
+        if constexpr (NS >= 2) {
+            const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
+            group4<true, false, false, false, false, 0>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
+            group4<true, false, false, false, false, 0>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+        }
+        if constexpr (NS >= 1) {
+            const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
+            group4<true, false, false, false, false, 0>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
+            group4<true, false, false, false, false, 0>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+        }
+        return;
+    }
     constexpr int M0 = 0;
     constexpr int MA4 = NS >= 4 ? 0xF : 0, MA2 = NS >= 3 ? 0xF : 0, MA1 = NS >= 2 ? 0xF : 0;
     if constexpr (NS >= 4) {
@@ -317,36 +352,51 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
 }
 
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------
-template <bool FASTX, int NS = 4>
+template <bool FASTX, int NS = 4, bool ROUND = false>
 __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)
 {
     if constexpr (NS >= 1) {
         const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
-        group4_dit<FASTX, false>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
-        group4_dit<FASTX, false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
     }
     if constexpr (NS >= 2) {
         const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
-        group4_dit<FASTX, false>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
-        group4_dit<FASTX, false>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
     }
     if constexpr (NS >= 3) {
-        group4_dit<FASTX, false>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-        group4_dit<FASTX, false>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+        group4_dit<FASTX, false, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+        group4_dit<FASTX, false, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
     }
     if constexpr (NS >= 4) {
         const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
         const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
-        group4_dit<FASTX, false>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-        group4_dit<FASTX, false>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        group4_dit<FASTX, false, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4_dit<FASTX, false, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
     }
 }
 
 // ---- round C: DIF stages 3,2,1,0 / DIT stages 0,1,2,3 on reg = n3..0, uniform twiddles ----------------
-template <bool FASTX> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
+template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
 {
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    if constexpr (ROUND) { // RNDMODE = 1: full-width values, exact extraction; STAGE 1 / 0 on rhu2 sums (int_dif2_fly.vhd:167-219)
+        static_assert(!FASTX, "round mode uses the exact extraction");
+        group4<true, false, false, false, true, 0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4<true, false, false, false, true, 0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        group4<true, false, false, false, true, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+        group4<true, false, false, false, true, 0>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            bfly_triv<true, false>(v[g], v[g + 2]);
+            bfly_mj<true, false>(v[g + 1], v[g + 3]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) bfly_triv<true, false>(v[g], v[g + 1]);
+        return;
+    }
     group4<false, FASTX, false, true, true, 0, true>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
     group4<false, FASTX, false, true, true, 0, true>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
     group4<false, FASTX, false, true, true, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
@@ -362,21 +412,21 @@ template <bool FASTX> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], 
     for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
 }
 
-template <bool FASTX> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
+template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
 {
 #pragma unroll
-    for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]); // STAGE 0: T = B
 #pragma unroll
     for (int g = 0; g < 16; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
-        bfly_triv<false, false>(v[g], v[g + 2]);
-        bfly_pj_dit(v[g + 1], v[g + 3]);
+        bfly_triv<ROUND, false>(v[g], v[g + 2]);
+        bfly_pj_dit<ROUND>(v[g + 1], v[g + 3]);
     }
-    group4_dit<FASTX, true>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
-    group4_dit<FASTX, true>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
-    group4_dit<FASTX, true>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-    group4_dit<FASTX, true>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+    group4_dit<FASTX, true, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+    group4_dit<FASTX, true, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
 }
 
 

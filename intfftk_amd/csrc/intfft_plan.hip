@@ -98,6 +98,9 @@ struct intfft_plan {
     int L = 0;
     int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
     int word = 4; // bytes of the on-chip word: 4 / 8 = k_pass<int32/int64>, 2 = packed int16 (k_pass16)
+    int l1 = 0;               // 2-D scheme (intfft_plan_create_2d): log2 N1 of the column core; 0 = ordinary 1-D plan
+    int2 *d_tw2d = nullptr;   // 2-D scheme: the inter-pass table W_N^m, N entries
+    std::vector<int2> h_tw2d;
     int2 *d_tw = nullptr;
     uint2 *d_tw16f = nullptr, *d_tw16i = nullptr; // packed dot-product operand forms (k_pass16)
     std::vector<int2> h_tw;
@@ -183,7 +186,8 @@ int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<Sta
     for (int ii = 0; ii < L; ++ii) {
         StageDesc st{};
         st.kind = inverse ? KIND_DIT : KIND_DIF;
-        st.s = inverse ? ii : L - ii - 1;
+        st.s = st.ts = inverse ? ii : L - ii - 1;
+        st.tshift = 0;
         st.lb = 0;
         st.dtw = dw_in + ii * p.format;
         st.wo = st.dtw + p.format; // DTW - SCALE + 1
@@ -199,9 +203,62 @@ int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<Sta
     return INTFFT_OK;
 }
 
-int validate(const intfft_params &p)
+// Stage list of the N > 512K "2-D scheme" (this project's extension of int_fftNk.vhd:11-13):
+// N = N1 * N2, forward = N1-point int_fftNk on the top l1 index bits (twiddle index = position div N2), the
+// inter-pass multiply by W_N^(k1*n2), then N2-point int_fftNk on the low l2 bits; inverse = the mirror.
+int core_stages_2d(const intfft_params &p, int l1, int dw_in, bool inverse, std::vector<StageDesc> &out)
 {
-    if (p.log2n < 3 || p.log2n > 20) return INTFFT_ERR_INVALID;
+    const int L = p.log2n, l2 = L - l1;
+    auto butterfly = [&](int ii, int ts, int tshift) -> int {
+        StageDesc st{};
+        st.kind = inverse ? KIND_DIT : KIND_DIF;
+        st.ts = ts;
+        st.tshift = tshift;
+        st.s = ts + tshift;
+        st.dtw = dw_in + ii * p.format;
+        st.wo = st.dtw + p.format;
+        st.mw = inverse ? st.dtw : st.wo;
+        st.rnd = p.format ? RND_UNSCALED : (p.rndmode ? RND_ROUND : RND_TRUNC);
+        if (ts >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b)) return INTFFT_ERR_UNSUPPORTED;
+        st.narrow = (st.mw + p.twdl_width <= 64) ? 1 : 0;
+        st.tw_off = (1u << ts) - 1u;
+        out.push_back(st);
+        return INTFFT_OK;
+    };
+    auto twiddle = [&](int w) -> int { // the multiplier instance between the cores, at the width of the data there
+        StageDesc st{};
+        st.kind = inverse ? KIND_TWMULC : KIND_TWMUL;
+        st.s = l2; // lives in the pass that owns index bit l2 (the column core's lowest bit)
+        st.ts = 2;
+        st.tshift = l2;
+        st.dtw = st.wo = st.mw = w;
+        st.rnd = RND_UNSCALED;
+        if (!cmult_shifts(w, p.twdl_width, p.xser, st.sh_a, st.sh_b)) return INTFFT_ERR_UNSUPPORTED;
+        st.narrow = (w + p.twdl_width <= 64) ? 1 : 0;
+        out.push_back(st);
+        return INTFFT_OK;
+    };
+    int rc;
+    if (!inverse) {
+        for (int ii = 0; ii < l1; ++ii)
+            if ((rc = butterfly(ii, l1 - ii - 1, l2)) != INTFFT_OK) return rc;
+        if ((rc = twiddle(dw_in + l1 * p.format)) != INTFFT_OK) return rc;
+        for (int ii = 0; ii < l2; ++ii)
+            if ((rc = butterfly(l1 + ii, l2 - ii - 1, 0)) != INTFFT_OK) return rc;
+    } else {
+        for (int ii = 0; ii < l2; ++ii)
+            if ((rc = butterfly(ii, ii, 0)) != INTFFT_OK) return rc;
+        if ((rc = twiddle(dw_in + l2 * p.format)) != INTFFT_OK) return rc;
+        for (int ii = 0; ii < l1; ++ii)
+            if ((rc = butterfly(l2 + ii, ii, l2)) != INTFFT_OK) return rc;
+    }
+    return INTFFT_OK;
+}
+
+int validate(const intfft_params &p, int l1 = 0)
+{
+    if (l1 == 0 && (p.log2n < 3 || p.log2n > 20)) return INTFFT_ERR_INVALID;
+    if (l1 != 0 && (l1 < 3 || l1 > 19 || p.log2n - l1 < 3 || p.log2n - l1 > 19 || p.log2n > 24 || !p.use_fly)) return INTFFT_ERR_INVALID;
     if (p.direction < 0 || p.direction > 2) return INTFFT_ERR_INVALID;
     if (p.in_order < 0 || p.in_order > 3 || p.out_order < 0 || p.out_order > 3) return INTFFT_ERR_INVALID;
     if ((p.format | 1) != 1 || (p.rndmode | 1) != 1 || (p.xser | 1) != 1 || (p.use_fly | 1) != 1)
@@ -218,12 +275,13 @@ int validate(const intfft_params &p)
     if (p.twdl_width >= (p.xser ? 28 : 26)) return INTFFT_ERR_UNSUPPORTED;
     std::vector<StageDesc> tmp;
     int rc = INTFFT_OK;
+    auto stages = [&](int dw, bool inverse) { return l1 ? core_stages_2d(p, l1, dw, inverse, tmp) : core_stages(p, dw, inverse, tmp); };
     if (p.direction == INTFFT_FWD || p.direction == INTFFT_PAIR)
-        if ((rc = core_stages(p, p.data_width, false, tmp)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width, false)) != INTFFT_OK) return rc;
     if (p.direction == INTFFT_INV)
-        if ((rc = core_stages(p, p.data_width, true, tmp)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width, true)) != INTFFT_OK) return rc;
     if (p.direction == INTFFT_PAIR)
-        if ((rc = core_stages(p, p.data_width + p.format * p.log2n, true, tmp)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width + p.format * p.log2n, true)) != INTFFT_OK) return rc;
     return INTFFT_OK;
 }
 
@@ -312,12 +370,15 @@ int build_passes(intfft_plan &pl)
 
     std::vector<StageDesc> fwd, inv;
     int rc = INTFFT_OK;
+    auto stages = [&](int dw, bool inverse, std::vector<StageDesc> &o) {
+        return pl.l1 ? core_stages_2d(p, pl.l1, dw, inverse, o) : core_stages(p, dw, inverse, o);
+    };
     if (p.direction == INTFFT_FWD || p.direction == INTFFT_PAIR)
-        if ((rc = core_stages(p, p.data_width, false, fwd)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width, false, fwd)) != INTFFT_OK) return rc;
     if (p.direction == INTFFT_INV)
-        if ((rc = core_stages(p, p.data_width, true, inv)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width, true, inv)) != INTFFT_OK) return rc;
     if (p.direction == INTFFT_PAIR)
-        if ((rc = core_stages(p, p.data_width + p.format * L, true, inv)) != INTFFT_OK) return rc;
+        if ((rc = stages(p.data_width + p.format * L, true, inv)) != INTFFT_OK) return rc;
 
     // user-side maps: FWD out and INV in are on the frequency side (logical = bitrev(core index))
     const bool in_rev = p.direction == INTFFT_INV;
@@ -405,9 +466,33 @@ int build_passes(intfft_plan &pl)
     return INTFFT_OK;
 }
 
-int build_twiddles(intfft_plan &pl, hipStream_t stream)
+// the inter-pass table of the 2-D scheme: rom_twiddle_int.vhd:143-152 at full depth (no Taylor step), quadrants by
+// (re, im) <- (im, -re) (:177-183); double-precision seeds on the host like the RTL's elaboration-time constants
+int build_twiddles_2d(intfft_plan &pl)
 {
     const int L = pl.L, t = pl.p.twdl_width;
+    const size_t n = (size_t)1 << L, quarter = n >> 2;
+    const double mg = (t < 18) ? std::ldexp(1.0, t - 1) - 1.0 : std::ldexp(1.0, t - 2) - 1.0;
+    pl.h_tw2d.resize(n);
+    auto wrap_t = [t](long long v) { return (int)((v << (64 - t)) >> (64 - t)); };
+    for (size_t a = 0; a < quarter; ++a) {
+        const double phi = ((double)a * M_PI) / std::ldexp(1.0, L - 1);
+        int c = (int)std::llround(mg * std::cos(phi)), s = (int)std::llround(mg * std::sin(-phi));
+        for (int q = 0; q < 4; ++q) {
+            pl.h_tw2d[(size_t)q * quarter + a] = make_int2(c, s);
+            const int tmp = c;
+            c = s;
+            s = wrap_t(-(long long)tmp);
+        }
+    }
+    hipError_t e = hipMalloc((void **)&pl.d_tw2d, n * sizeof(int2));
+    if (e == hipSuccess) e = hipMemcpy(pl.d_tw2d, pl.h_tw2d.data(), n * sizeof(int2), hipMemcpyHostToDevice);
+    return (int)e;
+}
+
+int build_twiddles(intfft_plan &pl, hipStream_t stream)
+{
+    const int L = pl.l1 ? std::max(pl.l1, pl.L - pl.l1) : pl.L, t = pl.p.twdl_width;
     const size_t total = ((size_t)1 << L) - 1;
     // quarter-wave ROM seeds, DEPTH = 9: rom_twiddle_int.vhd:135-159
     std::vector<int2> rom(512);
@@ -453,11 +538,24 @@ int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *i
     return INTFFT_OK;
 }
 
+static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hip_device);
+
 int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device)
+{
+    return create_plan(out, p, 0, hip_device);
+}
+
+int intfft_plan_create_2d(intfft_plan **out, const intfft_params *p, int log2_n1, int hip_device)
+{
+    if (log2_n1 == 0) return INTFFT_ERR_INVALID;
+    return create_plan(out, p, log2_n1, hip_device);
+}
+
+static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hip_device)
 {
     if (!out || !p) return INTFFT_ERR_NULL;
     *out = nullptr;
-    int rc = validate(*p);
+    int rc = validate(*p, l1);
     if (rc != INTFFT_OK) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hip_device < 0 || hip_device >= ndev)
@@ -470,16 +568,24 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
     pl->p = *p;
     pl->device = hip_device;
     pl->L = p->log2n;
-    intfft_io_widths(p, &pl->in_bits, &pl->out_bits, &pl->in_cb, &pl->out_cb);
+    pl->l1 = l1;
+    {
+        const int growth = p->format ? p->log2n : 0;
+        pl->in_bits = p->data_width;
+        pl->out_bits = p->data_width + (p->direction == INTFFT_PAIR ? 2 * growth : growth);
+        pl->in_cb = container_bytes(pl->in_bits);
+        pl->out_cb = container_bytes(pl->out_bits);
+    }
     pl->word = pl->out_bits <= 32 ? 4 : 8;
-    if (pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
+    if (!l1 && pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
 
-    if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK) {
+    if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK || (l1 && (rc = build_twiddles_2d(*pl)) != INTFFT_OK)) {
         intfft_plan_destroy(pl);
         return rc;
     }
-    // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only
-    const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr;
+    // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only.
+    // 2-D scheme plans (l1 != 0) run on the generic kernels: their column stages index the twiddle tables differently.
+    const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr || l1 != 0;
     pl->fastsmall = !generic_only && fastsmall_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                                          p->use_fly, p->in_order, p->out_order);
     pl->fast1024 = !generic_only && fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
@@ -603,6 +709,7 @@ int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
                       pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass || pl->big_pair256, (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+        if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -638,6 +745,7 @@ int intfft_plan_destroy(intfft_plan *plan)
     {
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
+        if (plan->d_tw2d) (void)hipFree(plan->d_tw2d);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
         if (plan->shard_in) (void)hipFree(plan->shard_in);
         if (plan->shard_out) (void)hipFree(plan->shard_out);
@@ -703,14 +811,14 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->fast1024x)
         return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
-                                     plan->h_tw.data(), batch, stream);
+                                     plan->h_tw.data(), batch, stream, plan->p.rndmode);
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
                                     plan->p.direction == INTFFT_FWD ? plan->p.out_order == INTFFT_ORDER_BITREV
                                                                     : plan->p.in_order == INTFFT_ORDER_BITREV,
                                     plan->p.direction == INTFFT_FWD ? plan->p.in_order == INTFFT_ORDER_HALVES
                                                                     : plan->p.out_order == INTFFT_ORDER_HALVES,
-                                    d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+                                    d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream, plan->p.rndmode);
 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
@@ -753,7 +861,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             void *pout = a.out_mode == IO_USER ? dst : plan->d_scratch;
             const hipError_t e = plan->word == 2
                                      ? launch_pass16(a, pin, pout, plan->d_tw16f, plan->d_tw16i, nf, plan->p.twdl_width, stream)
-                                     : launch_pass(a, a.word, pin, pout, plan->d_tw, nf, stream);
+                                     : launch_pass(a, a.word, pin, pout, plan->d_tw, nf, stream, plan->d_tw2d);
             if (e != hipSuccess) return (int)e;
         }
     }
@@ -974,7 +1082,13 @@ int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const v
 int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count)
 {
     if (!plan || !count) return INTFFT_ERR_NULL;
-    if (stage < 0 || stage >= plan->L) return INTFFT_ERR_INVALID;
+    if (stage == -1 && plan->l1) { // 2-D scheme: the inter-pass table W_N^m, m = 0 .. N-1
+        *count = plan->h_tw2d.size();
+        if (h_out) std::memcpy(h_out, plan->h_tw2d.data(), plan->h_tw2d.size() * sizeof(int2));
+        return INTFFT_OK;
+    }
+    const int nstages = plan->l1 ? std::max(plan->l1, plan->L - plan->l1) : plan->L;
+    if (stage < 0 || stage >= nstages) return INTFFT_ERR_INVALID;
     const size_t n = (size_t)1 << stage;
     *count = n;
     if (h_out) std::memcpy(h_out, plan->h_tw.data() + (n - 1), n * sizeof(int2));

@@ -50,7 +50,8 @@ class IntFFTCore:
     def __init__(self, NFFT: int, DATA_WIDTH: int = 16, TWDL_WIDTH: int = 16, FORMAT: int = 1,
                  RNDMODE: int = 0, XSER: str = "NEW", direction: str = "FWD", in_order: str = "NATURAL",
                  out_order: str = "NATURAL", USE_FLY: int = 1, device: Optional[int] = None,
-                 RAMB_TYPE: str = "WRAP", USE_MLT: bool = False):
+                 RAMB_TYPE: str = "WRAP", USE_MLT: bool = False, NFFT1: int = 0):
+        # NFFT1 != 0: the N > 512K "2D-FFT scheme" (include/intfft.h: intfft_plan_create_2d): N = 2^NFFT = 2^NFFT1 * 2^(NFFT-NFFT1)
         # RAMB_TYPE (strobe tolerance, int_fftNk.vhd:23-37) and USE_MLT (row_twiddle_tay.vhd:206-240)
         # do not change values; accepted for interface compatibility.
         if XSER not in ("NEW", "OLD"):
@@ -62,17 +63,28 @@ class IntFFTCore:
                                   capi.ORDERS[out_order])
         self.n = 1 << NFFT
         L = capi.lib()
-        ib, ob, ic, oc = (ctypes.c_int() for _ in range(4))
-        capi.check(L.intfft_io_widths(ctypes.byref(self.params), ib, ob, ic, oc), "intfft_io_widths")
-        self.in_bits, self.out_bits = ib.value, ob.value
-        self.in_container, self.out_container = ic.value, oc.value
+        self.nfft1 = int(NFFT1)
+        if self.nfft1:  # lengths beyond the 1-D cores: widths follow the same rule (DATA_WIDTH + FORMAT * NFFT)
+            growth = NFFT * FORMAT * (2 if direction == "PAIR" else 1)
+            self.in_bits, self.out_bits = DATA_WIDTH, DATA_WIDTH + growth
+            cb = lambda b: 2 if b <= 16 else 4 if b <= 32 else 8  # noqa: E731
+            self.in_container, self.out_container = cb(self.in_bits), cb(self.out_bits)
+        else:
+            ib, ob, ic, oc = (ctypes.c_int() for _ in range(4))
+            capi.check(L.intfft_io_widths(ctypes.byref(self.params), ib, ob, ic, oc), "intfft_io_widths")
+            self.in_bits, self.out_bits = ib.value, ob.value
+            self.in_container, self.out_container = ic.value, oc.value
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("intfftk_amd needs a HIP device: there is no CPU execution path")
         self.device = torch.cuda.current_device() if device is None else int(device)
         self._plan = ctypes.c_void_p()
-        capi.check(L.intfft_plan_create(ctypes.byref(self._plan), ctypes.byref(self.params), self.device),
-                   "intfft_plan_create")
+        if self.nfft1:
+            capi.check(L.intfft_plan_create_2d(ctypes.byref(self._plan), ctypes.byref(self.params), self.nfft1, self.device),
+                       "intfft_plan_create_2d")
+        else:
+            capi.check(L.intfft_plan_create(ctypes.byref(self._plan), ctypes.byref(self.params), self.device),
+                       "intfft_plan_create")
         info = capi.PlanInfo()
         capi.check(L.intfft_plan_get_info(self._plan, ctypes.byref(info)), "intfft_plan_get_info")
         self.info = {k: getattr(info, k) for k, _ in info._fields_ if k not in ("reserved", "kernel_name")}
@@ -137,7 +149,8 @@ class IntFFTCore:
         return out
 
     def twiddles(self, stage: int) -> np.ndarray:
-        """[2^stage, 2] int32 (re, im): what rom_twiddle_int emits for cnt = 0..2^stage-1."""
+        """[2^stage, 2] int32 (re, im): what rom_twiddle_int emits for cnt = 0..2^stage-1
+        (2-D scheme plans: stage = -1 returns the inter-pass table W_N^m, [N, 2])."""
         cnt = ctypes.c_size_t()
         L = capi.lib()
         capi.check(L.intfft_twiddles(self._plan, stage, None, ctypes.byref(cnt)), "intfft_twiddles")
@@ -174,6 +187,14 @@ def int_fft_ifft_pair(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0
     (re, im) per lane, not the reference's mis-wired Q0_IM/Q1_RE (:332-335)."""
     return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSERIES, "PAIR", "NATURAL", "NATURAL",
                       USE_FLY, device, RAMB_TYPE, USE_MLT)
+
+
+def int_fft_2d(NFFT=20, NFFT1=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, XSER="NEW", direction="FWD",
+               in_order="NATURAL", out_order="NATURAL", device=None) -> IntFFTCore:
+    """N > 512K: the "2D-FFT scheme" int_fftNk.vhd:11-13 points to, as this library defines it (include/intfft.h,
+    DESIGN.md section 4.5): 2^NFFT1-point cores over the columns, inter-pass twiddle, 2^(NFFT-NFFT1)-point cores over the rows."""
+    return IntFFTCore(NFFT, DATA_WIDTH, TWDL_WIDTH, FORMAT, RNDMODE, XSER, direction, in_order, out_order, 1, device,
+                      NFFT1=NFFT1)
 
 
 def exec_sharded(cores, x, root: int = 0):

@@ -328,6 +328,83 @@ def execute(frame, log2n, dw, t, fmt=0, rnd=0, new=True, direction=FWD, in_order
 
 
 # ------------------------------------------------------------------------------------------------
+# N > 512K: the "2D-FFT scheme" (int_fftNk.vhd:11-13) -- this project's extension, structural definition
+# (see the comment block in intfft_oracle.c): columns -> inter-pass twiddle -> rows with the 1-D cores above
+# ------------------------------------------------------------------------------------------------
+
+def twiddle_2d(log2n: int, t: int, m: int):
+    """W_N^m, m in [0, N): quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full depth, quadrants by
+    (re, im) <- (im, -re) (:177-183)."""
+    quarter = 1 << (log2n - 2)
+    mg = 2.0 ** (t - 1) - 1.0 if t < 18 else 2.0 ** (t - 2) - 1.0
+    a, q = m % quarter, (m // quarter) & 3
+    phi = (float(a) * math.pi) / (2.0 ** (log2n - 1))
+    re, im = _integer(mg * math.cos(phi)), _integer(mg * math.sin(-phi))
+    for _ in range(q):
+        re, im = im, sgn(~re + 1, t)
+    return re, im
+
+
+def fft2d(x, log2n, l1, dw, t, fmt=0, rnd=0, new=True):
+    """natural x -> v with v[j] = X[bitrev_L(j)] (the layout fft_dif returns)."""
+    l2 = log2n - l1
+    n1, n2, n = 1 << l1, 1 << l2, 1 << log2n
+    a = [[None] * n2 for _ in range(n1)]  # a[k1][n2]
+    for i2 in range(n2):
+        col = fft_dif([x[i1 * n2 + i2] for i1 in range(n1)], l1, dw, t, fmt, rnd, new)
+        for j1 in range(n1):
+            a[bitrev(j1, l1)][i2] = col[j1]
+    w1 = dw + fmt * l1
+    v = [None] * n
+    for k1 in range(n1):
+        row = [cmult(a[k1][i2][0], a[k1][i2][1], *twiddle_2d(log2n, t, (k1 * i2) % n), w1, t, new) for i2 in range(n2)]
+        res = fft_dif(row, l2, w1, t, fmt, rnd, new)
+        for j2 in range(n2):
+            v[bitrev(k1, l1) * n2 + j2] = res[j2]
+    return v
+
+
+def ifft2d(v, log2n, l1, dw, t, fmt=0, rnd=0, new=True):
+    """v[j] = X[bitrev_L(j)] -> natural x."""
+    l2 = log2n - l1
+    n1, n2, n = 1 << l1, 1 << l2, 1 << log2n
+    w = dw + fmt * l2
+    d = []
+    for j1 in range(n1):
+        row = ifft_dit(v[j1 * n2:(j1 + 1) * n2], l2, dw, t, fmt, rnd, new)
+        k1 = bitrev(j1, l1)
+        out = []
+        for i2 in range(n2):  # swapped feed: DI_RE <- B.im, DI_IM <- B.re; DO_RE -> T.im, DO_IM -> T.re
+            o_re, o_im = cmult(row[i2][1], row[i2][0], *twiddle_2d(log2n, t, (k1 * i2) % n), w, t, new)
+            out.append((o_im, o_re))
+        d.append(out)
+    x = [None] * n
+    for i2 in range(n2):
+        res = ifft_dit([d[j1][i2] for j1 in range(n1)], l1, w, t, fmt, rnd, new)
+        for i1 in range(n1):
+            x[i1 * n2 + i2] = res[i1]
+    return x
+
+
+def execute_2d(frame, log2n, l1, dw, t, fmt=0, rnd=0, new=True, direction=FWD, in_order=NATURAL, out_order=NATURAL):
+    n = 1 << log2n
+    if direction in (FWD, PAIR):
+        x = [None] * n
+        for m in range(n):
+            x[order_index(in_order, log2n, m)] = (sgn(frame[m][0], dw), sgn(frame[m][1], dw))
+        v = fft2d(x, log2n, l1, dw, t, fmt, rnd, new)
+        if direction == FWD:
+            return [v[bitrev(order_index(out_order, log2n, m), log2n)] for m in range(n)]
+        y = ifft2d(v, log2n, l1, dw + fmt * log2n, t, fmt, rnd, new)
+        return [y[order_index(out_order, log2n, m)] for m in range(n)]
+    v = [None] * n
+    for m in range(n):
+        v[bitrev(order_index(in_order, log2n, m), log2n)] = (sgn(frame[m][0], dw), sgn(frame[m][1], dw))
+    y = ifft2d(v, log2n, l1, dw, t, fmt, rnd, new)
+    return [y[order_index(out_order, log2n, m)] for m in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------
 # double-precision restatement of math/fn_radix2.m (the reference's own model), for the
 # ordering check against numpy.fft
 # ------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "intfft.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(intfft_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(intfft_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -98,3 +98,20 @@ def test_null_arguments():
     assert L.intfft_plan_create(None, None, 0) == capi.ERR_NULL
     assert L.intfft_plan_destroy(None) == capi.ERR_NULL
     assert L.intfft_exec(None, None, None, 1, None) == capi.ERR_NULL
+
+
+def test_plan_create_2d_validates_like_elaboration():
+    """intfft_plan_create_2d: both factors must be native core lengths; elaboration errors come before the device check."""
+    L = capi.lib()
+    plan = ctypes.c_void_p()
+    for l1, want in [(0, capi.ERR_INVALID), (2, capi.ERR_INVALID), (20, capi.ERR_INVALID), (19, capi.ERR_INVALID)]:
+        assert L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=21)), l1, 0) == want, l1
+    assert L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=25)), 12, 0) == capi.ERR_INVALID
+    assert L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=21, use_fly=0)), 10, 0) == capi.ERR_INVALID
+    assert L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=21, format=1, rndmode=1)), 10, 0) == capi.ERR_UNSUPPORTED
+    assert L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=21, data_width=50, format=1)), 10, 0) == capi.ERR_UNSUPPORTED
+    assert L.intfft_plan_create_2d(None, ctypes.byref(_p(log2n=21)), 10, 0) == capi.ERR_NULL
+    rc = L.intfft_plan_create_2d(ctypes.byref(plan), ctypes.byref(_p(log2n=21)), 10, 0)
+    assert rc in (capi.OK, capi.ERR_NO_DEVICE)  # no CPU fallback: without a HIP device nothing is planned
+    if rc == capi.OK:
+        L.intfft_plan_destroy(plan)

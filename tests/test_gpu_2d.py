@@ -1,0 +1,95 @@
+"""GPU parity of the N > 512K "2D-FFT scheme" plans (intfft_plan_create_2d) against the oracle's flat form, bit-exact:
+small lengths over every direction / order / width class, and the lengths the scheme exists for (2^20, 2^21)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as C
+from tests.helpers import edge_frames, to_complex, uniform_frames
+
+pytestmark = pytest.mark.gpu
+ORD = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
+DIR = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}
+NP = {2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction="FWD", in_order="NATURAL", out_order="NATURAL"):
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW" if new else "OLD", direction, in_order, out_order, NFFT1=l1)
+    y = core(torch.from_numpy(np.ascontiguousarray(x.astype(NP[core.in_container]))).cuda())
+    torch.cuda.synchronize()
+    info = core.info
+    core.close()
+    return y.cpu().numpy().astype(np.int64), info
+
+
+def check(x, log2n, l1, dw, tw, fmt, rnd, new, direction="FWD", in_order="NATURAL", out_order="NATURAL"):
+    got, info = run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction, in_order, out_order)
+    want = C.execute_2d(x, C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction], ORD[in_order], ORD[out_order], form=1)
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("2-D GPU != oracle (%r): %d mismatches, first at %r: got %r want %r"
+                             % ((log2n, l1, dw, tw, fmt, rnd, new, direction, in_order, out_order), len(bad), bad[0],
+                                got[tuple(bad[0])], want[tuple(bad[0])]))
+    return info
+
+
+CASES = [(6, 3, 16, 16, 0, 0, True), (7, 3, 16, 16, 0, 1, True), (7, 4, 16, 16, 1, 0, True), (8, 4, 24, 24, 1, 0, True),
+         (8, 5, 16, 16, 0, 0, False), (9, 3, 30, 16, 1, 0, True), (9, 6, 12, 10, 0, 0, True), (10, 5, 16, 18, 0, 0, True),
+         (11, 4, 32, 24, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True),
+         (15, 5, 24, 16, 0, 1, True), (16, 8, 16, 16, 0, 0, True)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("direction", list(DIR))
+def test_2d_every_direction_and_width(case, direction):
+    log2n, l1, dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate_2d(C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction]):
+        pytest.skip("not elaboratable")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(5, n, dw, 31 + log2n), edge_frames(n, dw)])
+    check(x, *case, direction=direction)
+
+
+@pytest.mark.parametrize("in_order", list(ORD))
+@pytest.mark.parametrize("out_order", list(ORD))
+@pytest.mark.parametrize("direction", list(DIR))
+def test_2d_io_orders(in_order, out_order, direction):
+    x = uniform_frames(3, 1 << 13, 16, 9)
+    check(x, 13, 6, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
+
+
+@pytest.mark.parametrize("log2n,l1,frames", [(20, 10, 3), (20, 8, 2), (21, 10, 2), (21, 11, 1), (22, 11, 1)])
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
+    """N = 2^20 .. 2^22 (the reference's cores stop at 2^19): 16-bit scaled, bit-exact to the oracle; the forward result is
+    within log2N + 2 LSB of fft(x)/N."""
+    n = 1 << log2n
+    x = uniform_frames(frames, n, 15, 1234 + log2n)
+    check(x, log2n, l1, 16, 16, 0, 0, True, direction=direction)
+    if direction == "FWD":
+        got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
+        assert info["n_passes"] >= 2
+        assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
+
+
+def test_2d_unscaled_and_pair_at_2pow20():
+    x = uniform_frames(1, 1 << 20, 15, 77)
+    check(x, 20, 10, 16, 16, 1, 0, True, direction="FWD")   # 36-bit results, int64 containers
+    check(x, 20, 10, 16, 16, 0, 0, True, direction="PAIR")
+
+
+def test_2d_twiddle_introspection():
+    from intfftk_amd import int_fft_2d
+
+    core = int_fft_2d(NFFT=12, NFFT1=5, TWDL_WIDTH=16)
+    tab = core.twiddles(-1)
+    assert tab.shape == (4096, 2)
+    want = np.array([C.twiddle_2d(12, 16, m) for m in range(4096)])
+    assert np.array_equal(tab, want)
+    re, im = C.twiddles(6, 16)
+    assert np.array_equal(core.twiddles(6), np.stack([re, im], axis=-1))
+    with pytest.raises(Exception):
+        core.twiddles(7)  # stages exist up to max(log2 N1, log2 N2) - 1 = 6

@@ -137,7 +137,7 @@ def test_exec_rejects_partial_overlap():
     unscaled = IntFFTCore(10, 16, 16, 1, 0)  # int16 in, int32 out: in place would overwrite unread frames
     big = torch.zeros((8, 1024, 2), dtype=torch.int32, device="cuda")
     assert L.intfft_exec(unscaled._plan, big.data_ptr(), big.data_ptr(), 8, None) == capi.ERR_INVALID
-    assert L.intfft_exec(unscaled._plan, big.data_ptr() + 8 * 1024 * 2 * 2 - 2, big.data_ptr(), 2, None) == capi.ERR_INVALID
+    assert L.intfft_exec(unscaled._plan, big.data_ptr() + 2 * 1024 * 2 * 4 - 2, big.data_ptr(), 2, None) == capi.ERR_INVALID  # last input bytes inside the output range
 
 
 def test_io_widths_and_plan_create_agree():

@@ -783,3 +783,22 @@ def test_fuzz_generics_with_orders(case):
     log2n, dw, tw, fmt, rnd, new, d, in_o, out_o = case
     x = uniform_frames(4, 1 << log2n, dw, 12000 + log2n * 10 + dw)
     check(x, log2n, dw, tw, fmt, rnd, new, direction=d, in_order=in_o, out_order=out_o)
+
+
+@pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_rounding_mode_on_the_packed_kernels(log2n, direction, monkeypatch):
+    """RNDMODE = 1 (the testbench's "ROUNDING" UUT, fft_signle_test.vhd:93-112) on the packed wave / block kernels:
+    bit-exact to the oracle incl. the full-scale edge frames (rhu2 of the maximum wraps, int_dif2_fly.vhd:173-218),
+    odd batches, and equal to the general-width kernels they replace (INTFFT_NO_PACKED_ROUND)."""
+    n = 1 << log2n
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(45, n, 16, 600 + log2n)])
+    info = check(x, log2n, 16, 16, 0, 1, True, direction=direction)
+    assert info["fast_path"] == 1 and info["compute_word"] == 2, info
+    monkeypatch.setenv("INTFFT_NO_PACKED_ROUND", "1")
+    got_b, info_b = run_gpu(x, log2n, 16, 16, 0, 1, True, direction=direction)
+    monkeypatch.delenv("INTFFT_NO_PACKED_ROUND")
+    got_a, _ = run_gpu(x, log2n, 16, 16, 0, 1, True, direction=direction)
+    assert np.array_equal(got_a, got_b)
+    if direction != "FWD" or log2n > 10:
+        assert info_b["compute_word"] != 2 or info_b["fast_path"] == 0  # the fallback really is a different kernel
