@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     if constexpr (L >= 7) ld(63 + lane, ta.wa1[0], ta.wb1[0]);
     ld(31 + (lane & 31), wa5, wb5);
     ld(15 + (lane & 15), wa4, wb4);
+    constexpr bool DP = MODE == X_INV; // the inverse core alone: twiddles in the DIT packing (no per-butterfly swap of B)
+    if constexpr (DP) {
+        to_dit_packing(ta);
+        to_dit_packing(wa5, wb5);
+        to_dit_packing(wa4, wb4);
+    }
     const u32 w5a[4] = {wa5, wa5, wa5, wa5}, w5b[4] = {wb5, wb5, wb5, wb5};
     const u32 w4a[4] = {wa4, wa4, wa4, wa4}, w4b[4] = {wb4, wb4, wb4, wb4};
 
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             dif_round_c<FX, ROUND>(v, c, sl, sh3);                                                      \
         }                                                                                               \
         /* inverse core: LC -> L1 */                                                                    \
-        dit_round_c<FX, ROUND>(v, c, sl);                                                               \
+        dit_round_c<FX, ROUND, DP>(v, c, sl);                                                           \
         wave_lds_fence();                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) wr_i[ROWX * r] = v[r];                           \
         wave_lds_fence();                                                                  \
@@ -195,16 +201,16 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;                 \
         }                                                                                               \
         wave_lds_fence();                                                                  \
-        group4_dit<FX, false, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);     \
-        group4_dit<FX, false, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+        group4_dit<FX, false, ROUND, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);     \
+        group4_dit<FX, false, ROUND, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);               \
-        group4_dit<FX, false, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);   \
-        group4_dit<FX, false, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+        group4_dit<FX, false, ROUND, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);   \
+        group4_dit<FX, false, ROUND, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
-        dit_round<FX, NS, ROUND>(v, ta, sl);                                                            \
+        dit_round<FX, NS, ROUND, DP>(v, ta, sl);                                                        \
     }
         if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
         else INTFFT_XBODY(false)
@@ -291,6 +297,7 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
+    if (direction == 1) to_dit_packing_host(c); // X_INV kernels hold their twiddles in the DIT packing
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;

@@ -110,6 +110,11 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #pragma unroll
     for (int j = 0; j < 2; ++j) ld(31 + 16 * j + lo4, tb.wa2[j], tb.wb2[j]);
     ld(15 + lo4, tb.wa1[0], tb.wb1[0]);
+    constexpr bool DP = MODE == MODE_INV; // the inverse core alone: twiddles in the DIT packing (no per-butterfly swap of B)
+    if constexpr (DP) {
+        to_dit_packing(ta);
+        to_dit_packing(tb);
+    }
 
     // ---- transpose addressing (dword offsets of this thread; register part is compile time) ----
     // LA -> LB and LB -> LA: element (thread x, reg y) -> row 16*y + x3..0, column x7..4
@@ -233,13 +238,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                     __builtin_nontemporal_store(v[r], dst + (rev4c(r) << (L - 4)) + lc_off);            \
             }                                                                                           \
         } else {                                                                                        \
-            dit_round_c<FX, ROUND>(v, c, sl);                                                           \
+            dit_round_c<FX, ROUND, DP>(v, c, sl);                                                       \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
             INTFFT_X_READ(reg0)                                                                         \
-            dit_round<FX, 4, ROUND>(v, tb, sl);                                                         \
+            dit_round<FX, 4, ROUND, DP>(v, tb, sl);                                                     \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \
-            dit_round<FX, NS, ROUND>(v, ta, sl);                                                        \
+            dit_round<FX, NS, ROUND, DP>(v, ta, sl);                                                    \
             if (MODE == MODE_INV && halves) { /* HALVES beats, mirror of the forward load */            \
                 typedef u32 v2u __attribute__((ext_vector_type(2)));                                    \
                 v2u *d2 = reinterpret_cast<v2u *>(dst) + tid;                                           \
@@ -356,6 +361,7 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
+    if (direction == 1) to_dit_packing_host(c); // MODE_INV kernels hold their twiddles in the DIT packing
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;

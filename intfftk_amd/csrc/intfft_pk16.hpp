@@ -248,12 +248,18 @@ struct RoundTw {
 __device__ __forceinline__ constexpr int rev4c(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
 // ---- DIT group of four general butterflies: a_i <- X, b_i <- Y (int_dit2_fly.vhd:142-162, 290-325) ----
-template <bool FASTX, bool SG, bool ROUND = false>
+// DITPACK: the twiddle operands are held in the DIT packing {Wc = (wr, wi), Wd = (-wi, wr)} (to_dit_packing below)
+// instead of the DIF packing {Wa, Wb}: T.re = dot(B, Wc), T.im = dot(B, Wd) on the UNSWAPPED B -- one v_alignbit less
+// per butterfly.  Kernels that run only the inverse core use it; the pair shares one DIF-packed set between its cores.
+template <bool FASTX, bool SG, bool ROUND = false, bool DITPACK = false>
 __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
-                                           const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl)
+                                           const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl)
 {
-    const u32 bs[4] = {__builtin_amdgcn_alignbit(b0, b0, 16), __builtin_amdgcn_alignbit(b1, b1, 16),
-                       __builtin_amdgcn_alignbit(b2, b2, 16), __builtin_amdgcn_alignbit(b3, b3, 16)};
+    const u32 bs[4] = {DITPACK ? b0 : __builtin_amdgcn_alignbit(b0, b0, 16), DITPACK ? b1 : __builtin_amdgcn_alignbit(b1, b1, 16),
+                       DITPACK ? b2 : __builtin_amdgcn_alignbit(b2, b2, 16), DITPACK ? b3 : __builtin_amdgcn_alignbit(b3, b3, 16)};
+    // operand of the re / im dot product: (Wb, Wa) on the swapped B, (Wc, Wd) = (wa_in, wb_in) on the unswapped B
+    const u32 (&wb)[4] = DITPACK ? wa_in : wb_in;
+    const u32 (&wa)[4] = DITPACK ? wb_in : wa_in;
     if constexpr (ROUND) { // RNDMODE = 1 (int_dit2_fly.vhd:164-217): T at full width, then rhu2(A +/- T)
         static_assert(!FASTX, "fast extraction yields T >> 1 only");
         u32 tf[4];
@@ -282,6 +288,37 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
     b2 = as_u32(A2 - as_v2s(t[2]));
     a3 = as_u32(A3 + as_v2s(t[3]));
     b3 = as_u32(A3 - as_v2s(t[3]));
+}
+
+// DIF packing -> DIT packing of one twiddle: Wc = (wr, wi) = Wb with its halves swapped, Wd = (-wi, wr) = Wa swapped
+__device__ __forceinline__ void to_dit_packing(u32 &wa, u32 &wb)
+{
+    const u32 c = __builtin_amdgcn_alignbit(wb, wb, 16), d = __builtin_amdgcn_alignbit(wa, wa, 16);
+    wa = c;
+    wb = d;
+}
+__device__ __forceinline__ void to_dit_packing(RoundTw &t)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) to_dit_packing(t.wa8[j], t.wb8[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) to_dit_packing(t.wa4[j], t.wb4[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) to_dit_packing(t.wa2[j], t.wb2[j]);
+    to_dit_packing(t.wa1[0], t.wb1[0]);
+}
+// host side: the wave-uniform twiddles of stages 3 and 2 in the DIT packing
+inline void to_dit_packing_host(RoundCConsts &c)
+{
+    auto rot = [](u32 x) { return (x >> 16) | (x << 16); };
+    for (int k = 0; k < 8; ++k) {
+        const u32 a = c.wa3[k], b = c.wb3[k];
+        c.wa3[k] = rot(b), c.wb3[k] = rot(a);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const u32 a = c.wa2[k], b = c.wb2[k];
+        c.wa2[k] = rot(b), c.wb2[k] = rot(a);
+    }
 }
 
 // DIT STAGE 1, odd positions: T.im = B.re, T.re = B.im >= 0 ? -B.im : ~B.im (int_dit2_fly.vhd:264-276)
@@ -352,28 +389,28 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
 }
 
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------
-template <bool FASTX, int NS = 4, bool ROUND = false>
+template <bool FASTX, int NS = 4, bool ROUND = false, bool DITPACK = false>
 __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)
 {
     if constexpr (NS >= 1) {
         const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
-        group4_dit<FASTX, false, ROUND>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
-        group4_dit<FASTX, false, ROUND>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
     }
     if constexpr (NS >= 2) {
         const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
-        group4_dit<FASTX, false, ROUND>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
-        group4_dit<FASTX, false, ROUND>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[0], v[2], v[1], v[3], v[4], v[6], v[5], v[7], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[8], v[10], v[9], v[11], v[12], v[14], v[13], v[15], wa, wb, sl);
     }
     if constexpr (NS >= 3) {
-        group4_dit<FASTX, false, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-        group4_dit<FASTX, false, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
     }
     if constexpr (NS >= 4) {
         const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
         const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
-        group4_dit<FASTX, false, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-        group4_dit<FASTX, false, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4_dit<FASTX, false, ROUND, DITPACK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
     }
 }
 
@@ -412,7 +449,7 @@ template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dif_ro
     for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
 }
 
-template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
+template <bool FASTX, bool ROUND = false, bool DITPACK = false> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
 {
 #pragma unroll
     for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]); // STAGE 0: T = B
@@ -421,12 +458,12 @@ template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dit_ro
         bfly_triv<ROUND, false>(v[g], v[g + 2]);
         bfly_pj_dit<ROUND>(v[g + 1], v[g + 3]);
     }
-    group4_dit<FASTX, true, ROUND>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
-    group4_dit<FASTX, true, ROUND>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
-    group4_dit<FASTX, true, ROUND>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-    group4_dit<FASTX, true, ROUND>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
 }
 
 

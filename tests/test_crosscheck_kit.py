@@ -1,0 +1,61 @@
+"""The external-pin kit (tools/vivado_crosscheck/): its committed expectations were produced by the GPU engine; here
+(CPU) they are checked against the oracle, and compare.py is exercised on a passing and on a failing dump."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from intfftk_amd import textio
+from oracle import oracle_c as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KIT = os.path.join(ROOT, "tools", "vivado_crosscheck")
+EXP = os.path.join(KIT, "expected")
+
+
+def _cases():
+    return json.load(open(os.path.join(EXP, "manifest.json")))["cases"]
+
+
+def test_kit_expectations_equal_the_oracle():
+    cases = _cases()
+    assert {(c["case"], c["mode"]) for c in cases} >= {("single_n7", "TRUNCATE"), ("single_n7", "ROUNDING"), ("single_n7", "UNSCALED"),
+                                                       ("single_n12", "TRUNCATE"), ("pair_n7", "UNSCALED")}
+    for c in cases:
+        n = 1 << c["nfft"]
+        p = C.make_params(c["nfft"], 16, 16, c["format"], c["rndmode"], True)
+        if c["tb"] == "tb_single_dump":
+            x = textio.read_di_single(os.path.join(EXP, c["stimulus"]), n)
+            got = textio.read_di_single(os.path.join(EXP, c["expected"]), n)
+            want = C.execute(x, p, C.FWD)
+        else:
+            x = textio.read_di_double(os.path.join(EXP, c["stimulus"]), n)
+            a = np.loadtxt(os.path.join(EXP, c["expected"]), dtype=np.int64, ndmin=2)  # Q0_RE Q1_RE Q0_IM Q1_IM per beat
+            got = np.stack([np.stack([a[:, 0], a[:, 2]], -1), np.stack([a[:, 1], a[:, 3]], -1)], 1).reshape(-1, n, 2)
+            want = C.execute(x, p, C.PAIR)
+        assert x.shape[0] == c["frames"]
+        assert np.array_equal(got, want), (c["case"], c["mode"])
+
+
+def test_compare_script_pass_and_fail(tmp_path):
+    cmp_py = os.path.join(KIT, "compare.py")
+    good = os.path.join(EXP, "single_n7_expected_ROUNDING.dat")
+    r = subprocess.run([sys.executable, cmp_py, "single_n7", "ROUNDING", good], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("PASS")
+    a = np.loadtxt(good, dtype=np.int64, ndmin=2)
+    a[1000, 1] += 1
+    bad = tmp_path / "bad.dat"
+    np.savetxt(bad, a, fmt="%d")
+    r = subprocess.run([sys.executable, cmp_py, "single_n7", "ROUNDING", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "line 1001" in r.stdout and "frame 7, position 104" in r.stdout
+    # the pair: an RTL dump carries the reference's slice mix-up (Q0_IM = re of lane 0, Q1_RE = im of lane 1)
+    e = np.loadtxt(os.path.join(EXP, "pair_n7_expected_UNSCALED.dat"), dtype=np.int64, ndmin=2)
+    rtl = e.copy()
+    rtl[:, 2], rtl[:, 1] = e[:, 0], e[:, 3]
+    dump = tmp_path / "pair.dat"
+    np.savetxt(dump, rtl, fmt="%d")
+    assert subprocess.run([sys.executable, cmp_py, "pair_n7", "UNSCALED", str(dump)]).returncode == 0
+    assert subprocess.run([sys.executable, cmp_py, "pair_n7", "UNSCALED", str(dump), "--no-reference-wiring"],
+                          capture_output=True).returncode == 1

@@ -496,7 +496,8 @@ def test_general_width_block_kernel(log2n, case):
             continue
         x = np.concatenate([edge_frames(n, dw), uniform_frames(5, n, dw, 60 + dw), uniform_frames(40, n, max(2, dw - 1), 61 + dw)])
         info = check(x, log2n, dw, tw, fmt, rnd, new)
-        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_w32"), info
+        packed_round = (dw, fmt, rnd) == (16, 0, 1) and tw <= 16  # the "ROUNDING" UUT runs on the packed block kernel
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16" if packed_round else "k_fft4096_w32"), info
 
 
 @pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10, 11, 12])
@@ -517,7 +518,8 @@ def test_general_width_inverse_kernels(log2n, case):
         fp = 1 << max(0, 10 - log2n)
         x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 3, n, dw, 70 + dw), uniform_frames(20, n, max(2, dw - 1), 71 + dw)])
         info = check(x, log2n, dw, tw, fmt, rnd, new, direction="INV")
-        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_ifft"), info
+        packed_round = (dw, fmt, rnd) == (16, 0, 1) and tw <= 16  # packed wave / block kernels (RNDMODE = 1)
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith(("k_fft1024x_i16", "k_fft4096_i16") if packed_round else "k_ifft"), info
 
 
 @pytest.mark.parametrize("case", [(10, 24, 24), (10, 24, 16), (10, 23, 18), (11, 23, 24), (11, 22, 16), (12, 22, 24), (12, 21, 16)])

@@ -30,6 +30,7 @@ CONFIGS = {
 
 
 ORDERS = {"C2native": ("HALVES", "BITREV")}
+NFFT1 = {}  # spec -> log2 N1 of a 2-D scheme plan (spec "L:DW:TW:FMT:RND:DIR:L1")
 CONFIGS["C2native"] = (10, 16, 16, 0, 0, "FWD", 65536, 15, 8)
 
 
@@ -37,7 +38,8 @@ def run(name, steps=20, check_frames=8):
     log2n, dw, tw, fmt, rnd, direction, batch, bits, bps = CONFIGS[name]
     n = 1 << log2n
     in_o, out_o = ORDERS.get(name, ("NATURAL", "NATURAL"))
-    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o)
+    l1 = NFFT1.get(name, 0)
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o, NFFT1=l1)
     g = torch.Generator(device="cuda")
     g.manual_seed(0xC0FFEE00 + log2n)
     x = torch.randint(-(1 << (bits - 1)), 1 << (bits - 1), (batch, n, 2), device="cuda", dtype=core.in_dtype, generator=g)
@@ -57,8 +59,12 @@ def run(name, steps=20, check_frames=8):
     ms = e0.elapsed_time(e1) / steps
     p = C.make_params(log2n, dw, tw, fmt, rnd, True)
     om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES}
-    want = C.execute(x[:check_frames].cpu().numpy(), p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction],
-                     om[in_o], om[out_o])
+    dd = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
+    if l1:
+        check_frames = min(check_frames, 2)
+        want = C.execute_2d(x[:check_frames].cpu().numpy(), p, l1, dd, om[in_o], om[out_o])
+    else:
+        want = C.execute(x[:check_frames].cpu().numpy(), p, dd, om[in_o], om[out_o])
     ok = bool(np.array_equal(y[:check_frames].cpu().numpy().astype(np.int64), want))
     gs = batch * n / ms / 1e6
     out = {"config": name, "log2n": log2n, "batch": batch, "dir": direction, "ms": ms, "Gsample/s": gs,
@@ -71,11 +77,13 @@ def run(name, steps=20, check_frames=8):
 
 
 def adhoc(spec):
-    """spec "L:DW:TW:FMT[:RND[:DIR]]" -> a 256 MiB-input config with that shape, e.g. 11:16:16:0"""
+    """spec "L:DW:TW:FMT[:RND[:DIR[:L1]]]" -> a 256 MiB-input config with that shape, e.g. 11:16:16:0 (L1: 2-D scheme, N1 = 2^L1)"""
     f = spec.split(":")
     log2n, dw, tw, fmt = (int(v) for v in f[:4])
     rnd = int(f[4]) if len(f) > 4 else 0
     direction = f[5] if len(f) > 5 else "FWD"
+    if len(f) > 6:
+        NFFT1[spec] = int(f[6])
     in_cb = 2 if dw <= 16 else 4 if dw <= 32 else 8
     ob = dw + (fmt * log2n) * (2 if direction == "PAIR" else 1)
     out_cb = 2 if ob <= 16 else 4 if ob <= 32 else 8

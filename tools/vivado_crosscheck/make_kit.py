@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates the stimulus files and the engine's expected dumps of the external-pin kit (needs a HIP device).
+
+    python tools/vivado_crosscheck/make_kit.py [--out tools/vivado_crosscheck/expected]
+
+Cases (each: one stimulus file + one expected dump per mode):
+  single_n7     NFFT = 7  (the testbenches' own length, fft_signle_test.vhd:93): 8 edge frames + 24 random frames
+  single_n12    NFFT = 12 (first length whose STAGE 11 twiddles come from row_twiddle_tay): impulse at n = 1 (reads the
+                twiddle tables out), full-scale random, chirp
+  pair_n7       NFFT = 7 int_fft_ifft_pair: di_double.dat beats, full-width expected output for FORMAT 0 and 1
+Modes: TRUNCATE (FORMAT 0, RNDMODE 0), ROUNDING (0, 1), UNSCALED (1, 0)  -- fft_signle_test.vhd:80-112.
+Everything is produced by the GPU engine through the C-ABI (intfftk_amd); the oracle is not involved.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+MODES = {"TRUNCATE": (0, 0), "ROUNDING": (0, 1), "UNSCALED": (1, 0)}
+
+
+def frames_for(nfft, which):
+    from tests.helpers import chirp_frame, edge_frames, uniform_frames
+
+    n = 1 << nfft
+    if which == "full":
+        return np.concatenate([edge_frames(n, 16), uniform_frames(24, n, 16, 0x1F7 + nfft)])
+    imp = np.zeros((1, n, 2), dtype=np.int64)
+    imp[0, 1, 0] = 1 << 14
+    return np.concatenate([imp, uniform_frames(1, n, 16, 0xBEEF), chirp_frame(n)[None] * 64])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tools", "vivado_crosscheck", "expected"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    import torch
+
+    from intfftk_amd import int_fft_ifft_pair, int_fft_single_path, textio
+
+    manifest = {"generated_by": "intfftk_amd GPU engine (libintfft.so)", "cases": []}
+    for name, nfft, which in [("single_n7", 7, "full"), ("single_n12", 12, "taylor")]:
+        x = frames_for(nfft, which)
+        textio.write_di_single(os.path.join(a.out, "%s_di_single.dat" % name), x)
+        for mode, (fmt, rnd) in MODES.items():
+            core = int_fft_single_path(nfft, 16, 16, fmt, rnd, "NEW")
+            y = core(torch.from_numpy(x.astype(np.int16)).cuda()).cpu().numpy()
+            textio.write_di_single(os.path.join(a.out, "%s_expected_%s.dat" % (name, mode)), y)
+            manifest["cases"].append({"case": name, "tb": "tb_single_dump", "nfft": nfft, "mode": mode, "format": fmt, "rndmode": rnd,
+                                      "frames": int(x.shape[0]), "stimulus": "%s_di_single.dat" % name,
+                                      "expected": "%s_expected_%s.dat" % (name, mode), "out_bits": core.out_bits})
+            core.close()
+    x = frames_for(7, "full")
+    textio.write_di_double(os.path.join(a.out, "pair_n7_di_double.dat"), x)
+    for mode, (fmt, rnd) in [("TRUNCATE", (0, 0)), ("UNSCALED", (1, 0))]:
+        core = int_fft_ifft_pair(7, 16, 16, fmt, rnd, "NEW")
+        y = core(torch.from_numpy(x.astype(np.int16)).cuda()).cpu().numpy().astype(np.int64)
+        beats = y.reshape(-1, 2, 2)  # [beat, lane, (re, im)]: Q0_RE Q1_RE Q0_IM Q1_IM as the ports SHOULD carry them
+        np.savetxt(os.path.join(a.out, "pair_n7_expected_%s.dat" % mode),
+                   np.stack([beats[:, 0, 0], beats[:, 1, 0], beats[:, 0, 1], beats[:, 1, 1]], axis=-1), fmt="%d")
+        manifest["cases"].append({"case": "pair_n7", "tb": "tb_pair_dump", "nfft": 7, "mode": mode, "format": fmt, "rndmode": rnd,
+                                  "frames": int(x.shape[0]), "stimulus": "pair_n7_di_double.dat",
+                                  "expected": "pair_n7_expected_%s.dat" % mode, "out_bits": core.out_bits})
+        core.close()
+    with open(os.path.join(a.out, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    print("wrote %d cases to %s" % (len(manifest["cases"]), a.out))
+
+
+if __name__ == "__main__":
+    main()
