@@ -192,6 +192,68 @@ __device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, C
     addsub<T>(a.im, t.im, st.rnd, st.wo, x.im, y.im);
 }
 
+// ---- 2-D scheme: the inter-pass twiddle W_N^m, evaluated on the fly -------------------------------------
+// The quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full depth, (re, im) = (RN(mg cos phi), RN(mg sin(-phi))),
+// phi = 2 pi a / N for a = m mod N/4, rotated by the quadrant rule (re, im) <- (im, -re) of :177-183 (m div N/4 times).  So that
+// every implementation (this one on the GPU and on the host, the C oracle, the Python twin) produces the SAME integers, cos and sin
+// are a fixed sequence of IEEE double operations, each rounded separately (no fused multiply-add): octant reduction to
+// x in [0, pi/4], x = b * (pi * 2^-(L-1)), Taylor polynomials in z = x*x up to z^8 in Horner form (truncation < 3e-18;
+// |error| < 2e-16), RN(v) = floor(v + 0.5) on the non-negative first-octant values.  A table of N entries would cost one random
+// 128-byte line per sample (measured: 3x the time of the whole rest of the plan); this costs ~40 double operations.
+// the two constants of a plan: pi * 2^-(L-1) (M_PI scaled by a power of two: exact) and mg = 2^(t-1) - 1 (t < 18) or 2^(t-2) - 1
+// (rom_twiddle_int.vhd:143-147; exact)
+__host__ __device__ inline void tw2d_consts(int L, int t, double &scale, double &mg)
+{
+#pragma clang fp contract(off)
+    scale = 3.14159265358979323846;
+    for (int i = 0; i < L - 1; ++i) scale = scale * 0.5;
+    mg = 1.0;
+    for (int i = 0; i < (t < 18 ? t - 1 : t - 2); ++i) mg = mg * 2.0;
+    mg = mg - 1.0;
+}
+
+__host__ __device__ inline void tw2d_eval(int L, double scale, double mg, unsigned m, int &re, int &im)
+{
+#pragma clang fp contract(off)
+    const unsigned quarter = 1u << (L - 2);
+    const unsigned a = m & (quarter - 1u), q = (m >> (L - 2)) & 3u;
+    const bool swap = a > (quarter >> 1);
+    const unsigned b = swap ? quarter - a : a;
+    const double x = (double)b * scale;
+    const double z = x * x;
+    double pc = 0x1.ae7f3e733b81fp-45;
+    pc = -0x1.93974a8c07c9dp-37 + z * pc;
+    pc = 0x1.1eed8eff8d898p-29 + z * pc;
+    pc = -0x1.27e4fb7789f5cp-22 + z * pc;
+    pc = 0x1.a01a01a01a01ap-16 + z * pc;
+    pc = -0x1.6c16c16c16c17p-10 + z * pc;
+    pc = 0x1.5555555555555p-5 + z * pc;
+    pc = -0x1.0000000000000p-1 + z * pc;
+    const double cosx = 1.0 + z * pc;
+    double ps = 0x1.952c77030ad4ap-49;
+    ps = -0x1.ae7f3e733b81fp-41 + z * ps;
+    ps = 0x1.6124613a86d09p-33 + z * ps;
+    ps = -0x1.ae64567f544e4p-26 + z * ps;
+    ps = 0x1.71de3a556c734p-19 + z * ps;
+    ps = -0x1.a01a01a01a01ap-13 + z * ps;
+    ps = 0x1.1111111111111p-7 + z * ps;
+    ps = -0x1.5555555555555p-3 + z * ps;
+    const double xz = x * z;
+    const double sinx = x + xz * ps;
+    const double vc = mg * (swap ? sinx : cosx) + 0.5, vs = mg * (swap ? cosx : sinx) + 0.5;
+    int c = (int)(long long)vc, sn = -(int)(long long)vs; // first quadrant: (RN(mg cos), -RN(mg sin))
+    // (re, im) <- (im, -re), q times (|values| <= mg < 2^(t-1): the negation fits t bits)
+    re = q == 0 ? c : q == 1 ? sn : q == 2 ? -c : -sn;
+    im = q == 0 ? sn : q == 1 ? -c : q == 2 ? -sn : c;
+}
+
+__host__ __device__ inline void tw2d_eval(int L, int t, unsigned m, int &re, int &im)
+{
+    double scale, mg;
+    tw2d_consts(L, t, scale, mg);
+    tw2d_eval(L, scale, mg, m, re, im);
+}
+
 // ---- I/O order maps (include/intfft.h) -------------------------------------------------------
 __device__ __forceinline__ unsigned brev_l(unsigned v, int L) { return __brev(v) >> (32 - L); }
 

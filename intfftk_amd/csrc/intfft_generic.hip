@@ -8,6 +8,7 @@
 // speed path for the headline configuration; this kernel is the complete one.
 #include "intfft_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 #include <cmath>
@@ -272,6 +273,86 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
         hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes, tw2d);
     }
+    return hipGetLastError();
+}
+
+// ---- 2-D scheme: the multiplier between the cores ------------------------------------------------------
+// In place on the [k1][n2] layout (element idx: k1 = idx >> l2, n2 = idx mod 2^l2): V <- int_cmult_dsp48(V, W_N^(k1 n2)) at width
+// mw (forward), or T = V * conj(W) through the re/im-swapped multiplier feed of int_dit2_fly.vhd:304-322 (inverse).
+template <typename T, typename PK> struct PairIO; // one (re, im) sample as a single load / store
+template <> struct PairIO<int32_t, uint32_t> { // int16 containers
+    static __device__ __forceinline__ void get(uint32_t v, int32_t &re, int32_t &im) { re = (int16_t)(v & 0xFFFFu), im = (int16_t)(v >> 16); }
+    static __device__ __forceinline__ uint32_t put(int32_t re, int32_t im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
+};
+template <> struct PairIO<int32_t, uint2> {
+    static __device__ __forceinline__ void get(uint2 v, int32_t &re, int32_t &im) { re = (int32_t)v.x, im = (int32_t)v.y; }
+    static __device__ __forceinline__ uint2 put(int32_t re, int32_t im) { return make_uint2((uint32_t)re, (uint32_t)im); }
+};
+template <> struct PairIO<int64_t, ulonglong2> {
+    static __device__ __forceinline__ void get(ulonglong2 v, int64_t &re, int64_t &im) { re = (int64_t)v.x, im = (int64_t)v.y; }
+    static __device__ __forceinline__ ulonglong2 put(int64_t re, int64_t im) { return make_ulonglong2((unsigned long long)re, (unsigned long long)im); }
+};
+
+// One thread owns one position (k1, n2) and walks the frames of the launch: its twiddle is evaluated ONCE (about 40 double
+// operations) and applied to every frame -- per sample the kernel is a 16-bit load, one multiplier and a store.
+template <typename T, typename PK>
+__global__ __launch_bounds__(256) void k_twmul(PK *data, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj, int twd,
+                                               size_t nframes, unsigned fsplit)
+{
+    const unsigned nmask = (1u << L) - 1u, m2 = (1u << l2) - 1u;
+    const size_t n = (size_t)1 << L;
+    const unsigned idx = (blockIdx.x / fsplit) * 256u + threadIdx.x; // position; blocks with the same position share the frames
+    const unsigned part = blockIdx.x % fsplit;
+    if (idx > nmask) return;
+    double scale, mg;
+    tw2d_consts(L, twd, scale, mg);
+    int wr, wi;
+    tw2d_eval(L, scale, mg, ((idx >> l2) * (idx & m2)) & nmask, wr, wi);
+    constexpr int UNR = 8; // independent frames per step: the loads are issued together
+    for (size_t f0 = part; f0 < nframes; f0 += (size_t)fsplit * UNR) {
+        PK d[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const size_t f = f0 + (size_t)u * fsplit;
+            if (f < nframes) d[u] = data[f * n + idx];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const size_t f = f0 + (size_t)u * fsplit;
+            if (f < nframes) {
+                T re, im, ore, oim;
+                PairIO<T, PK>::get(d[u], re, im);
+                if (!conj) {
+                    cmult(re, im, wr, wi, mw, sh_a, sh_b, narrow, ore, oim);
+                    data[f * n + idx] = PairIO<T, PK>::put(ore, oim);
+                } else {
+                    cmult(im, re, wr, wi, mw, sh_a, sh_b, narrow, ore, oim);
+                    data[f * n + idx] = PairIO<T, PK>::put(oim, ore);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj,
+                        int twd, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    const size_t pos_blocks = (((size_t)1 << L) + 255) / 256;
+    // enough blocks to fill the chip: split the frames of a position over `fsplit` blocks when there are few positions
+    unsigned fsplit = 1;
+    const size_t want = (size_t)device_cus() * 16;
+    while (pos_blocks * fsplit < want && fsplit * 2 <= nframes) fsplit *= 2;
+    const unsigned blocks = (unsigned)(pos_blocks * fsplit);
+    if (container_bytes == 2)
+        hipLaunchKernelGGL((k_twmul<int32_t, uint32_t>), dim3(blocks), dim3(256), 0, stream, static_cast<uint32_t *>(data), L, l2, mw, sh_a,
+                           sh_b, narrow, conj, twd, nframes, fsplit);
+    else if (container_bytes == 4)
+        hipLaunchKernelGGL((k_twmul<int32_t, uint2>), dim3(blocks), dim3(256), 0, stream, static_cast<uint2 *>(data), L, l2, mw, sh_a,
+                           sh_b, narrow, conj, twd, nframes, fsplit);
+    else
+        hipLaunchKernelGGL((k_twmul<int64_t, ulonglong2>), dim3(blocks), dim3(256), 0, stream, static_cast<ulonglong2 *>(data), L, l2, mw,
+                           sh_a, sh_b, narrow, conj, twd, nframes, fsplit);
     return hipGetLastError();
 }
 

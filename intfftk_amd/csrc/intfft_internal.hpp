@@ -217,6 +217,14 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
                          const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);
 
+// bit-permutation mover (intfft_reorder.hip): m_in bit in_of_out[b] = m_out bit b; frames of 2^L (re, im) container pairs
+hipError_t launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
+                          hipStream_t stream);
+int order_mem_bit(int order, int L, int j); // memory-index bit that carries logical-index bit j in an INTFFT_ORDER_* layout
+// 2-D scheme (intfft_generic.hip): in place V <- cmult(V, W_N^(k1 * n2)) on the [k1][n2] layout (conj: the inverse's swapped feed)
+hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj,
+                        int twd, size_t nframes, hipStream_t stream);
+
 // packed int16 block kernel for N = 4096, FWD / INV / PAIR (intfft_fast4096.hip)
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order);

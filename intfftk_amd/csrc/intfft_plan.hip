@@ -99,6 +99,12 @@ struct intfft_plan {
     int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
     int word = 4; // bytes of the on-chip word: 4 / 8 = k_pass<int32/int64>, 2 = packed int16 (k_pass16)
     int l1 = 0;               // 2-D scheme (intfft_plan_create_2d): log2 N1 of the column core; 0 = ordinary 1-D plan
+    // 2-D scheme, composite form (the default): layout change / column cores / layout change + multiply / row cores / layout
+    // change, every core an ordinary 1-D sub-plan in natural order (so every dedicated kernel applies); see exec_2d()
+    struct intfft_plan *sub_col_f = nullptr, *sub_row_f = nullptr, *sub_row_i = nullptr, *sub_col_i = nullptr;
+    StageDesc tw_f{}, tw_i{};  // the multiplier between the cores (widths / regime), forward and inverse
+    void *buf2d[2] = {nullptr, nullptr};
+    size_t buf2d_frames = 0;
     int2 *d_tw2d = nullptr;   // 2-D scheme: the inter-pass table W_N^m, N entries
     std::vector<int2> h_tw2d;
     int2 *d_tw = nullptr;
@@ -466,27 +472,17 @@ int build_passes(intfft_plan &pl)
     return INTFFT_OK;
 }
 
-// the inter-pass table of the 2-D scheme: rom_twiddle_int.vhd:143-152 at full depth (no Taylor step), quadrants by
-// (re, im) <- (im, -re) (:177-183); double-precision seeds on the host like the RTL's elaboration-time constants
+// the inter-pass table of the 2-D scheme (tw2d_eval, intfft_device.hpp) as a device array: only the flat form on the generic
+// kernels (INTFFT_2D_GENERIC=1, the A/B reference of the composite form) reads a table; the shipped plans evaluate on the fly
 int build_twiddles_2d(intfft_plan &pl)
 {
-    const int L = pl.L, t = pl.p.twdl_width;
-    const size_t n = (size_t)1 << L, quarter = n >> 2;
-    const double mg = (t < 18) ? std::ldexp(1.0, t - 1) - 1.0 : std::ldexp(1.0, t - 2) - 1.0;
+    const size_t n = (size_t)1 << pl.L;
     pl.h_tw2d.resize(n);
-    auto wrap_t = [t](long long v) { return (int)((v << (64 - t)) >> (64 - t)); };
-    for (size_t a = 0; a < quarter; ++a) {
-        const double phi = ((double)a * M_PI) / std::ldexp(1.0, L - 1);
-        int c = (int)std::llround(mg * std::cos(phi)), s = (int)std::llround(mg * std::sin(-phi));
-        for (int q = 0; q < 4; ++q) {
-            pl.h_tw2d[(size_t)q * quarter + a] = make_int2(c, s);
-            const int tmp = c;
-            c = s;
-            s = wrap_t(-(long long)tmp);
-        }
-    }
+    for (size_t m = 0; m < n; ++m) tw2d_eval(pl.L, pl.p.twdl_width, (unsigned)m, pl.h_tw2d[m].x, pl.h_tw2d[m].y);
     hipError_t e = hipMalloc((void **)&pl.d_tw2d, n * sizeof(int2));
     if (e == hipSuccess) e = hipMemcpy(pl.d_tw2d, pl.h_tw2d.data(), n * sizeof(int2), hipMemcpyHostToDevice);
+    pl.h_tw2d.clear();
+    pl.h_tw2d.shrink_to_fit();
     return (int)e;
 }
 
@@ -579,12 +575,58 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     pl->word = pl->out_bits <= 32 ? 4 : 8;
     if (!l1 && pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
 
-    if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK || (l1 && (rc = build_twiddles_2d(*pl)) != INTFFT_OK)) {
+    if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK ||
+        (l1 && getenv("INTFFT_2D_GENERIC") && (rc = build_twiddles_2d(*pl)) != INTFFT_OK)) {
         intfft_plan_destroy(pl);
         return rc;
     }
+    if (l1 && !getenv("INTFFT_2D_GENERIC")) {
+        // composite 2-D plan: the cores are 1-D sub-plans (NATURAL -> NATURAL) on re-laid-out data
+        const int l2 = p->log2n - l1, F = p->format;
+        auto sub = [&](int log2n, int dw, int direction, intfft_plan **o) {
+            intfft_params q = *p;
+            q.log2n = log2n, q.data_width = dw, q.direction = direction;
+            q.in_order = q.out_order = INTFFT_ORDER_NATURAL;
+            return create_plan(o, &q, 0, hip_device);
+        };
+        std::vector<StageDesc> st;
+        int dw = p->data_width;
+        rc = INTFFT_OK;
+        if (p->direction != INTFFT_INV) {
+            if (rc == INTFFT_OK) rc = sub(l1, dw, INTFFT_FWD, &pl->sub_col_f);
+            if (rc == INTFFT_OK) rc = sub(l2, dw + F * l1, INTFFT_FWD, &pl->sub_row_f);
+            if (rc == INTFFT_OK) rc = core_stages_2d(*p, l1, dw, false, st);
+            for (const StageDesc &d : st)
+                if (d.kind == KIND_TWMUL) pl->tw_f = d;
+            dw += F * p->log2n;
+        }
+        if (p->direction != INTFFT_FWD) {
+            st.clear();
+            if (rc == INTFFT_OK) rc = sub(l2, dw, INTFFT_INV, &pl->sub_row_i);
+            if (rc == INTFFT_OK) rc = sub(l1, dw + F * l2, INTFFT_INV, &pl->sub_col_i);
+            if (rc == INTFFT_OK) rc = core_stages_2d(*p, l1, dw, true, st);
+            for (const StageDesc &d : st)
+                if (d.kind == KIND_TWMULC) pl->tw_i = d;
+        }
+        if (rc == INTFFT_OK) {
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->out_cb;
+            pl->buf2d_frames = std::max<size_t>(1, ((size_t)256 << 20) / frame_bytes);
+            if (const char *e = getenv("INTFFT_2D_CHUNK_FRAMES")) // diagnostics: exercise the chunk loop on small batches
+                if (atoi(e) > 0) pl->buf2d_frames = std::min(pl->buf2d_frames, (size_t)atoi(e));
+            for (int i = 0; i < 2 && rc == INTFFT_OK; ++i) rc = (int)hipMalloc(&pl->buf2d[i], pl->buf2d_frames * frame_bytes);
+        }
+        if (rc != INTFFT_OK) {
+            intfft_plan_destroy(pl);
+            return rc;
+        }
+        const intfft_plan *a = pl->sub_col_f ? pl->sub_col_f : pl->sub_row_i, *b = pl->sub_row_f ? pl->sub_row_f : pl->sub_col_i;
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[%.24s|%.24s]", a->kernel_name, b->kernel_name);
+        *out = pl;
+        return INTFFT_OK;
+    }
     // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only.
-    // 2-D scheme plans (l1 != 0) run on the generic kernels: their column stages index the twiddle tables differently.
+    // 2-D scheme plans in their flat form (INTFFT_2D_GENERIC=1: A/B parity of the composite form) also run on the generic
+    // kernels: their column stages index the twiddle tables differently.
     const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr || l1 != 0;
     pl->fastsmall = !generic_only && fastsmall_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                                          p->use_fly, p->in_order, p->out_order);
@@ -746,6 +788,10 @@ int intfft_plan_destroy(intfft_plan *plan)
         DeviceGuard guard(plan->device);
         if (plan->d_tw) (void)hipFree(plan->d_tw);
         if (plan->d_tw2d) (void)hipFree(plan->d_tw2d);
+        for (void *b : plan->buf2d)
+            if (b) (void)hipFree(b);
+        for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
+            if (sp) intfft_plan_destroy(sp);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
         if (plan->shard_in) (void)hipFree(plan->shard_in);
         if (plan->shard_out) (void)hipFree(plan->shard_out);
@@ -767,12 +813,93 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall;
+    if (plan->buf2d[0]) {
+        intfft_plan_info si;
+        int n = 0;
+        for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
+            if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
+        const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
+        info->n_passes = n + 3 * cores + (cores == 2 ? 0 : 1); // per core pair: layout change + multiply + layout change; ends: one more each
+        info->compute_word = 0;
+        info->fast_path = 0;
+        info->scratch_bytes = 2 * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+        std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
+        return INTFFT_OK;
+    }
     info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
     return INTFFT_OK;
+}
+
+// The 2-D scheme as a sequence of launches.  Layouts are bit permutations of the frame index
+// (launch_bitperm), the cores are 1-D sub-plans over N2 * frames (columns) / N1 * frames (rows) short frames:
+//   forward  user (in_order) -> [n2][n1] | N1-point int_fftNk | [n2][k1] -> [k1][n2] | x W_N^(k1 n2) | N2-point int_fftNk
+//            | [k1][k2] -> user (out_order, X[k1 + N1 k2])
+//   inverse  user (in_order, X) -> [k1][k2] | N2-point int_ifftNk | x conj W | [k1][n2] -> [n2][k1] | N1-point int_ifftNk
+//            | [n2][n1] -> user (out_order)          pair: forward up to [k1][k2], then the inverse from there
+static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch, hipStream_t stream)
+{
+    const int L = pl->L, l1 = pl->l1, l2 = L - l1;
+    const intfft_params &p = pl->p;
+    const size_t in_frame = ((size_t)2 << L) * (size_t)pl->in_cb, out_frame = ((size_t)2 << L) * (size_t)pl->out_cb;
+    int perm[24];
+    hipError_t e = hipSuccess;
+    int rc = INTFFT_OK;
+    for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
+        const size_t nf = std::min(pl->buf2d_frames, batch - f);
+        const void *src = static_cast<const char *>(d_in) + f * in_frame;
+        void *dst = static_cast<char *>(d_out) + f * out_frame;
+        void *cur = pl->buf2d[0], *oth = pl->buf2d[1];
+        int cb = pl->in_cb;
+        if (p.direction != INTFFT_INV) {
+            // user (time side, logical n = n1 N2 + n2) -> [n2][n1]: n2 bit j -> bit l1 + j, n1 bit j -> bit j
+            for (int j = 0; j < L; ++j) perm[j < l2 ? l1 + j : j - l2] = order_mem_bit(p.in_order, L, j);
+            e = launch_bitperm(L, cb, perm, src, cur, nf, stream);
+            if (e != hipSuccess) break;
+            if ((rc = intfft_exec(pl->sub_col_f, cur, oth, nf << l2, stream)) != INTFFT_OK) break;
+            std::swap(cur, oth);
+            cb = pl->sub_col_f->out_cb;
+            // [n2][k1] -> [k1][n2]: out bit b < l2 (n2) <- in bit l1 + b; out bit b >= l2 (k1) <- in bit b - l2
+            for (int b = 0; b < L; ++b) perm[b] = b < l2 ? l1 + b : b - l2;
+            if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
+            std::swap(cur, oth);
+            const StageDesc &t = pl->tw_f;
+            if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 0, p.twdl_width, nf, stream)) != hipSuccess) break;
+            if ((rc = intfft_exec(pl->sub_row_f, cur, oth, nf << l1, stream)) != INTFFT_OK) break;
+            std::swap(cur, oth);
+            cb = pl->sub_row_f->out_cb;
+            if (p.direction == INTFFT_FWD) {
+                // [k1][k2] -> user (frequency side, logical k = k1 + N1 k2): k bit j < l1 sits at in bit l2 + j, else at j - l1
+                for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + j : j - l1;
+                e = launch_bitperm(L, cb, perm, cur, dst, nf, stream);
+                continue;
+            }
+        } else {
+            // user (frequency side, logical k) -> [k1][k2]
+            for (int j = 0; j < L; ++j) perm[j < l1 ? l2 + j : j - l1] = order_mem_bit(p.in_order, L, j);
+            if ((e = launch_bitperm(L, cb, perm, src, cur, nf, stream)) != hipSuccess) break;
+        }
+        if ((rc = intfft_exec(pl->sub_row_i, cur, oth, nf << l1, stream)) != INTFFT_OK) break;
+        std::swap(cur, oth);
+        cb = pl->sub_row_i->out_cb;
+        const StageDesc &t = pl->tw_i;
+        if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 1, p.twdl_width, nf, stream)) != hipSuccess) break;
+        // [k1][n2] -> [n2][k1]: out bit b < l1 (k1) <- in bit l2 + b; out bit b >= l1 (n2) <- in bit b - l1
+        for (int b = 0; b < L; ++b) perm[b] = b < l1 ? l2 + b : b - l1;
+        if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
+        std::swap(cur, oth);
+        if ((rc = intfft_exec(pl->sub_col_i, cur, oth, nf << l2, stream)) != INTFFT_OK) break;
+        std::swap(cur, oth);
+        cb = pl->sub_col_i->out_cb;
+        // [n2][n1] -> user (time side, logical n = n1 N2 + n2): n bit j < l2 sits at in bit l1 + j, else at j - l2
+        for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l2 ? l1 + j : j - l2;
+        e = launch_bitperm(L, cb, perm, cur, dst, nf, stream);
+    }
+    if (rc != INTFFT_OK) return rc;
+    return (int)e;
 }
 
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream)
@@ -789,6 +916,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (plan->buf2d[0]) return exec_2d(plan, d_in, d_out, batch, stream);
     if (plan->fastsmall)
         return (int)launch_fastsmall(plan->p.log2n, plan->p.direction, plan->p.rndmode, plan->p.twdl_width, d_in, d_out,
                                      plan->h_tw.data(), batch, stream);
@@ -1082,9 +1210,11 @@ int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const v
 int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count)
 {
     if (!plan || !count) return INTFFT_ERR_NULL;
-    if (stage == -1 && plan->l1) { // 2-D scheme: the inter-pass table W_N^m, m = 0 .. N-1
-        *count = plan->h_tw2d.size();
-        if (h_out) std::memcpy(h_out, plan->h_tw2d.data(), plan->h_tw2d.size() * sizeof(int2));
+    if (stage == -1 && plan->l1) { // 2-D scheme: the inter-pass twiddles W_N^m, m = 0 .. N-1 (evaluated here, not stored)
+        const size_t n = (size_t)1 << plan->L;
+        *count = n;
+        if (h_out)
+            for (size_t m = 0; m < n; ++m) tw2d_eval(plan->L, plan->p.twdl_width, (unsigned)m, h_out[2 * m], h_out[2 * m + 1]);
         return INTFFT_OK;
     }
     const int nstages = plan->l1 ? std::max(plan->l1, plan->L - plan->l1) : plan->L;

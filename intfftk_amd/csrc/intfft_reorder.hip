@@ -16,14 +16,22 @@
 
 namespace intfft {
 
+typedef unsigned long long rv2u;                             // (re, im) of int32 containers, as one 8-byte word
+typedef unsigned rv4u __attribute__((ext_vector_type(4))); // (re, im) of int64 containers
+
+// Everything index-related is precomputed on the host as OR-masks, so that the kernel does no table look-ups in its
+// loops (its first version indexed bit-position tables held in kernel-argument memory: two dependent scalar loads per
+// bit per element group made it latency-bound at 1.3 TB/s).
+//   element e = 256 i + tid of the LOAD enumeration  (consecutive e = consecutive m_in):
+//       m_in = base_in | OR_k tid_k * t_in[k] | i_in[i],   LDS slot = OR_k tid_k * t_slot[k] | i_slot[i]
+//   element e of the STORE enumeration (consecutive e = consecutive m_out, LDS slot = e):
+//       m_out = base_out | OR_k tid_k * t_out[k] | i_out[i]
+//   tile id bit k contributes r_in[k] / r_out[k] to base_in / base_out
 struct ReorderArgs {
     int L, U;
-    // tile-local bit k (0 <= k < U) of the STORE enumeration sits at m_out bit out_pos[k] (out_pos[k] = k for k < TB);
-    // tile-local bit k of the LOAD enumeration sits at m_out bit ld_pos[k] (the bits feeding m_in bits 0..TB-1 first);
-    // st_of_ld[k]: the store-enumeration bit of load-enumeration bit k (LDS address of a loaded element)
-    signed char out_pos[12], ld_pos[12], st_of_ld[12];
-    signed char rest_pos[20]; // the L - U m_out bits numbered by the block index, ascending
-    signed char in_of_out[20]; // m_out bit b lands at m_in bit in_of_out[b]
+    unsigned t_in[8], t_slot[8], t_out[8];
+    unsigned i_in[16], i_slot[16], i_out[16];
+    unsigned r_in[18], r_out[18];
 };
 
 template <typename E> __global__ __launch_bounds__(256) void k_reorder(const E *in, E *out, const ReorderArgs a, unsigned tiles_per_frame)
@@ -32,31 +40,44 @@ template <typename E> __global__ __launch_bounds__(256) void k_reorder(const E *
     E *lds = reinterpret_cast<E *>(lds_raw);
     const size_t frame = blockIdx.x / tiles_per_frame;
     const unsigned tile = blockIdx.x % tiles_per_frame;
-    unsigned base_out = 0, base_in = 0; // contribution of the block-numbered bits
-    for (int k = 0; k < a.L - a.U; ++k)
+    unsigned base_out = 0, base_in = 0; // contribution of the tile id (wave-uniform: scalar code)
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
         if ((tile >> k) & 1u) {
-            base_out |= 1u << a.rest_pos[k];
-            base_in |= 1u << a.in_of_out[(int)a.rest_pos[k]];
+            base_out |= a.r_out[k];
+            base_in |= a.r_in[k];
         }
-    const E *src = in + (frame << a.L);
-    E *dst = out + (frame << a.L);
-    const unsigned n = 1u << a.U;
-    for (unsigned e = threadIdx.x; e < n; e += 256) { // consecutive e -> consecutive m_in
-        unsigned m_in = base_in, slot = 0;
-        for (int k = 0; k < a.U; ++k)
-            if ((e >> k) & 1u) {
-                m_in |= 1u << a.in_of_out[(int)a.ld_pos[k]];
-                slot |= 1u << a.st_of_ld[k];
-            }
-        lds[slot + (slot >> 5)] = src[m_in]; // + slot / 32: breaks the power-of-two bank stride of the transposing writes
+    const E *src = in + (frame << a.L) + base_in;
+    E *dst = out + (frame << a.L) + base_out;
+    const unsigned tid = threadIdx.x;
+    unsigned t_in = 0, t_slot = 0, t_out = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned bit = 0u - ((tid >> k) & 1u);
+        t_in |= bit & a.t_in[k];
+        t_slot |= bit & a.t_slot[k];
+        t_out |= bit & a.t_out[k];
     }
+    const unsigned iters = a.U > 8 ? 1u << (a.U - 8) : 1u; // <= 16 (U <= 12)
+    const bool active = a.U >= 8 || tid < (1u << a.U);
+    // all loads of the thread are issued before the first LDS write: up to 16 independent requests in flight per lane
+    E v[16];
+#pragma unroll
+    for (unsigned i = 0; i < 16; ++i)
+        if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in | a.i_in[i]));
+#pragma unroll
+    for (unsigned i = 0; i < 16; ++i)
+        if (i < iters && active) {
+            const unsigned slot = t_slot | a.i_slot[i];
+            lds[slot + (slot >> 5)] = v[i]; // + slot / 32: breaks the power-of-two bank stride of the transposing writes
+        }
     __syncthreads();
-    for (unsigned e = threadIdx.x; e < n; e += 256) { // consecutive e -> consecutive m_out
-        unsigned m_out = base_out;
-        for (int k = 0; k < a.U; ++k)
-            if ((e >> k) & 1u) m_out |= 1u << a.out_pos[k];
-        dst[m_out] = lds[e + (e >> 5)];
-    }
+#pragma unroll
+    for (unsigned i = 0; i < 16; ++i)
+        if (i < iters && active) {
+            const unsigned e = tid + 256u * i;
+            __builtin_nontemporal_store(lds[e + (e >> 5)], dst + (t_out | a.i_out[i]));
+        }
 }
 
 namespace {
@@ -92,10 +113,79 @@ template <typename E> hipError_t launch(const ReorderArgs &a, const void *in, vo
 
 using namespace intfft;
 
+// any bit permutation of the frame index: m_in bit in_of_out[b] = m_out bit b (b = 0 .. L-1, L <= 24).  Used by
+// intfft_reorder (pairs of INTFFT_ORDER_* layouts) and by the 2-D scheme plans (layout changes between the cores).
+hipError_t intfft::launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
+                                  hipStream_t stream)
+{
+    int out_of_in[24];
+    for (int b = 0; b < L; ++b) out_of_in[in_of_out[b]] = b;
+    const int TB = std::min(6, L); // 64-element runs: 256 B of int16 pairs
+    bool in_tile[24] = {false};
+    int out_pos[12], ld_pos[12], U = 0;
+    for (int k = 0; k < TB; ++k) { // store enumeration: m_out bits 0..TB-1 first
+        out_pos[U++] = k;
+        in_tile[k] = true;
+    }
+    for (int k = 0; k < TB; ++k) { // then the m_out bits that feed m_in bits 0..TB-1
+        const int b = out_of_in[k];
+        if (!in_tile[b]) {
+            out_pos[U++] = b;
+            in_tile[b] = true;
+        }
+    }
+    // load enumeration: the feeders of m_in bits 0..TB-1 in that order, then the remaining tile bits
+    int nl = 0;
+    bool used[24] = {false};
+    for (int k = 0; k < TB; ++k) {
+        ld_pos[nl++] = out_of_in[k];
+        used[out_of_in[k]] = true;
+    }
+    for (int k = 0; k < U; ++k)
+        if (!used[out_pos[k]]) ld_pos[nl++] = out_pos[k];
+    ReorderArgs a{};
+    a.L = L;
+    a.U = U;
+    auto st_of = [&](int ldk) { // store-enumeration bit of load-enumeration bit ldk
+        for (int q = 0; q < U; ++q)
+            if (out_pos[q] == ld_pos[ldk]) return q;
+        return 0;
+    };
+    for (int k = 0; k < 8 && k < U; ++k) {
+        a.t_in[k] = 1u << in_of_out[ld_pos[k]];
+        a.t_slot[k] = 1u << st_of(k);
+        a.t_out[k] = 1u << out_pos[k];
+    }
+    for (unsigned i = 0; i < 16; ++i)
+        for (int k = 8; k < U; ++k)
+            if ((i >> (k - 8)) & 1u) {
+                a.i_in[i] |= 1u << in_of_out[ld_pos[k]];
+                a.i_slot[i] |= 1u << st_of(k);
+                a.i_out[i] |= 1u << out_pos[k];
+            }
+    // The remaining bits number the tiles.  Consecutive tile ids run concurrently, so the LOW tile-id bits should spread
+    // BOTH sides over the memory channels: order the bits by min(position in m_out, position in m_in).
+    int nr = 0;
+    for (int key = 0; key < L; ++key)
+        for (int b = 0; b < L; ++b)
+            if (!in_tile[b] && std::min(b, in_of_out[b]) == key) {
+                a.r_out[nr] = 1u << b;
+                a.r_in[nr] = 1u << in_of_out[b];
+                ++nr;
+            }
+    switch (container_bytes) {
+    case 2: return launch<uint32_t>(a, d_in, d_out, batch, stream);
+    case 4: return launch<rv2u>(a, d_in, d_out, batch, stream);
+    default: return launch<rv4u>(a, d_in, d_out, batch, stream);
+    }
+}
+
+int intfft::order_mem_bit(int order, int L, int j) { return mem_bit_of_logical(order, L, j); }
+
 extern "C" int intfft_reorder(int log2n, int container_bytes, int from_order, int to_order, const void *d_in, void *d_out,
                               size_t batch, int hip_device, void *hip_stream)
 {
-    if (log2n < 3 || log2n > 20) return INTFFT_ERR_INVALID;
+    if (log2n < 3 || log2n > 24) return INTFFT_ERR_INVALID;
     if (container_bytes != 2 && container_bytes != 4 && container_bytes != 8) return INTFFT_ERR_INVALID;
     if (from_order < 0 || from_order > 3 || to_order < 0 || to_order > 3) return INTFFT_ERR_INVALID;
     if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
@@ -111,54 +201,9 @@ extern "C" int intfft_reorder(int log2n, int container_bytes, int from_order, in
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(hip_device) != hipSuccess) return INTFFT_ERR_NO_DEVICE;
-
-    ReorderArgs a{};
-    a.L = L;
-    // logical bit j: m_in bit mem_bit(from, j) = m_out bit mem_bit(to, j)
-    int out_of_in[20];
-    for (int j = 0; j < L; ++j) {
-        const int bi = mem_bit_of_logical(from_order, L, j), bo = mem_bit_of_logical(to_order, L, j);
-        a.in_of_out[bo] = (signed char)bi;
-        out_of_in[bi] = bo;
-    }
-    const int TB = std::min(6, L); // 64-element runs: 256 B of int16 pairs
-    bool in_tile[20] = {false};
-    int U = 0;
-    for (int k = 0; k < TB; ++k) { // store enumeration: m_out bits 0..TB-1 first
-        a.out_pos[U++] = (signed char)k;
-        in_tile[k] = true;
-    }
-    for (int k = 0; k < TB; ++k) { // then the m_out bits that feed m_in bits 0..TB-1
-        const int b = out_of_in[k];
-        if (!in_tile[b]) {
-            a.out_pos[U++] = (signed char)b;
-            in_tile[b] = true;
-        }
-    }
-    a.U = U;
-    // load enumeration: the feeders of m_in bits 0..TB-1 in that order, then the remaining tile bits
-    int nl = 0;
-    bool used[20] = {false};
-    for (int k = 0; k < TB; ++k) {
-        a.ld_pos[nl++] = (signed char)out_of_in[k];
-        used[out_of_in[k]] = true;
-    }
-    for (int k = 0; k < U; ++k)
-        if (!used[(int)a.out_pos[k]]) a.ld_pos[nl++] = a.out_pos[k];
-    for (int k = 0; k < U; ++k)
-        for (int q = 0; q < U; ++q)
-            if (a.out_pos[q] == a.ld_pos[k]) a.st_of_ld[k] = (signed char)q;
-    int nr = 0;
-    for (int b = 0; b < L; ++b)
-        if (!in_tile[b]) a.rest_pos[nr++] = (signed char)b;
-
-    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
-    hipError_t e;
-    switch (container_bytes) {
-    case 2: e = launch<uint32_t>(a, d_in, d_out, batch, stream); break;
-    case 4: e = launch<uint2>(a, d_in, d_out, batch, stream); break;
-    default: e = launch<uint4>(a, d_in, d_out, batch, stream); break;
-    }
+    int in_of_out[24]; // logical bit j: m_in bit mem_bit(from, j) = m_out bit mem_bit(to, j)
+    for (int j = 0; j < L; ++j) in_of_out[mem_bit_of_logical(to_order, L, j)] = mem_bit_of_logical(from_order, L, j);
+    const hipError_t e = launch_bitperm(L, container_bytes, in_of_out, d_in, d_out, batch, reinterpret_cast<hipStream_t>(hip_stream));
     if (prev >= 0) (void)hipSetDevice(prev);
     return (int)e;
 }

@@ -695,21 +695,48 @@ int orc_exec_i16(const orc_params *p, int direction, int in_order, int out_order
  * Inter-pass twiddle W_N^m, m in [0, N): the quarter-wave ROM formula of                          *
  * rom_twiddle_int.vhd:143-152 at full depth (no Taylor step): for a = m mod N/4,                  *
  * (c, s) = (RN(mg cos(2 pi a / N)), RN(mg sin(-2 pi a / N))), mg as in :143-147; quadrant         *
- * q = m div N/4 applies (re, im) <- (im, -re) q times (:177-183 is the q = 1 case).               */
+ * q = m div N/4 applies (re, im) <- (im, -re) q times (:177-183 is the q = 1 case).  cos / sin are *
+ * a specified sequence of IEEE double operations (orc_twiddle_2d), not a libm call, so that the   *
+ * GPU can evaluate them on the fly and still produce the same integers.                           */
 
 void orc_twiddle_2d(int log2n, int twd, size_t m, int64_t *re, int64_t *im)
 {
+    /* cos / sin as a FIXED sequence of separately rounded IEEE double operations (this file is compiled with
+     * -ffp-contract=off), so that every implementation yields the same integers: octant reduction to x in [0, pi/4],
+     * x = b * (pi * 2^-(L-1)), Taylor polynomials in z = x*x up to z^8 (Horner), RN(v) = floor(v + 0.5). */
     const size_t quarter = (size_t)1 << (log2n - 2);
     const size_t a = m & (quarter - 1);
     const int q = (int)((m >> (log2n - 2)) & 3);
-    int64_t c, s;
-    {
-        const double mg = (twd < 18) ? ldexp(1.0, twd - 1) - 1.0 : ldexp(1.0, twd - 2) - 1.0;
-        const double phi = ((double)a * M_PI) / ldexp(1.0, log2n - 1); /* 2 pi a / N */
-        c = rn(mg * cos(phi));
-        s = rn(mg * sin(-phi));
+    const int swap = a > (quarter >> 1);
+    const size_t b = swap ? quarter - a : a;
+    double scale = 3.14159265358979323846;
+    for (int i = 0; i < log2n - 1; ++i) scale = scale * 0.5;
+    const double x = (double)b * scale;
+    const double z = x * x;
+    static const double C[8] = {-0x1.0000000000000p-1, 0x1.5555555555555p-5, -0x1.6c16c16c16c17p-10, 0x1.a01a01a01a01ap-16,
+                                -0x1.27e4fb7789f5cp-22, 0x1.1eed8eff8d898p-29, -0x1.93974a8c07c9dp-37, 0x1.ae7f3e733b81fp-45};
+    static const double S[8] = {-0x1.5555555555555p-3, 0x1.1111111111111p-7, -0x1.a01a01a01a01ap-13, 0x1.71de3a556c734p-19,
+                                -0x1.ae64567f544e4p-26, 0x1.6124613a86d09p-33, -0x1.ae7f3e733b81fp-41, 0x1.952c77030ad4ap-49};
+    double pc = C[7], ps = S[7];
+    for (int k = 6; k >= 0; --k) {
+        double t = z * pc;
+        pc = C[k] + t;
+        t = z * ps;
+        ps = S[k] + t;
     }
-    for (int i = 0; i < q; ++i) { /* (re, im) <- (im, -re) */
+    double t1 = z * pc;
+    const double cosx = 1.0 + t1;
+    const double xz = x * z;
+    t1 = xz * ps;
+    const double sinx = x + t1;
+    double mg = 1.0; /* rom_twiddle_int.vhd:143-147 */
+    for (int i = 0; i < (twd < 18 ? twd - 1 : twd - 2); ++i) mg = mg * 2.0;
+    mg = mg - 1.0;
+    double vc = mg * (swap ? sinx : cosx), vs = mg * (swap ? cosx : sinx);
+    vc = vc + 0.5;
+    vs = vs + 0.5;
+    int64_t c = (int64_t)vc, s = -(int64_t)vs;
+    for (int i = 0; i < q; ++i) { /* (re, im) <- (im, -re)  rom_twiddle_int.vhd:177-183 */
         const int64_t t = c;
         c = s;
         s = orc_wrap(-t, twd);

@@ -332,14 +332,35 @@ def execute(frame, log2n, dw, t, fmt=0, rnd=0, new=True, direction=FWD, in_order
 # (see the comment block in intfft_oracle.c): columns -> inter-pass twiddle -> rows with the 1-D cores above
 # ------------------------------------------------------------------------------------------------
 
+_COS_C = [float.fromhex(h) for h in ("-0x1.0000000000000p-1", "0x1.5555555555555p-5", "-0x1.6c16c16c16c17p-10", "0x1.a01a01a01a01ap-16",
+                                     "-0x1.27e4fb7789f5cp-22", "0x1.1eed8eff8d898p-29", "-0x1.93974a8c07c9dp-37", "0x1.ae7f3e733b81fp-45")]
+_SIN_C = [float.fromhex(h) for h in ("-0x1.5555555555555p-3", "0x1.1111111111111p-7", "-0x1.a01a01a01a01ap-13", "0x1.71de3a556c734p-19",
+                                     "-0x1.ae64567f544e4p-26", "0x1.6124613a86d09p-33", "-0x1.ae7f3e733b81fp-41", "0x1.952c77030ad4ap-49")]
+
+
 def twiddle_2d(log2n: int, t: int, m: int):
     """W_N^m, m in [0, N): quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full depth, quadrants by
-    (re, im) <- (im, -re) (:177-183)."""
+    (re, im) <- (im, -re) (:177-183).  cos / sin are the specified sequence of separately rounded double operations
+    (octant reduction, Taylor polynomials to z^8 in Horner form; CPython floats are IEEE doubles and never fuse)."""
     quarter = 1 << (log2n - 2)
-    mg = 2.0 ** (t - 1) - 1.0 if t < 18 else 2.0 ** (t - 2) - 1.0
     a, q = m % quarter, (m // quarter) & 3
-    phi = (float(a) * math.pi) / (2.0 ** (log2n - 1))
-    re, im = _integer(mg * math.cos(phi)), _integer(mg * math.sin(-phi))
+    swap = a > quarter // 2
+    b = quarter - a if swap else a
+    scale = 3.14159265358979323846
+    for _ in range(log2n - 1):
+        scale = scale * 0.5
+    x = float(b) * scale
+    z = x * x
+    pc, ps = _COS_C[7], _SIN_C[7]
+    for k in range(6, -1, -1):
+        pc = _COS_C[k] + z * pc
+        ps = _SIN_C[k] + z * ps
+    cosx = 1.0 + z * pc
+    sinx = x + (x * z) * ps
+    mg = 2.0 ** (t - 1) - 1.0 if t < 18 else 2.0 ** (t - 2) - 1.0
+    vc = mg * (sinx if swap else cosx) + 0.5
+    vs = mg * (cosx if swap else sinx) + 0.5
+    re, im = int(vc), -int(vs)
     for _ in range(q):
         re, im = im, sgn(~re + 1, t)
     return re, im

@@ -71,8 +71,48 @@ def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
     check(x, log2n, l1, 16, 16, 0, 0, True, direction=direction)
     if direction == "FWD":
         got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
-        assert info["n_passes"] >= 2
+        assert info["n_passes"] >= 4 and info["kernel_name"].startswith("2d[")
         assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
+
+
+@pytest.mark.parametrize("case", [(13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (16, 8, 16, 16, 0, 1, True),
+                                  (15, 3, 24, 24, 1, 0, False), (17, 4, 16, 16, 0, 0, True), (17, 13, 16, 16, 0, 0, True)])
+@pytest.mark.parametrize("direction", list(DIR))
+def test_2d_composite_equals_flat_form(case, direction, monkeypatch):
+    """The shipped 2-D plans are composites (layout changes + 1-D sub-plans on the dedicated kernels + the multiplier between
+    the cores); INTFFT_2D_GENERIC=1 evaluates the flat form on the generic pass kernels instead.  Same bits, both = oracle."""
+    log2n, l1, dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate_2d(C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction]):
+        pytest.skip("not elaboratable")
+    x = uniform_frames(3, 1 << log2n, dw, 500 + log2n + l1)
+    a, ia = run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction, "HALVES", "BITREV_LANES")
+    monkeypatch.setenv("INTFFT_2D_GENERIC", "1")
+    b, ib = run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction, "HALVES", "BITREV_LANES")
+    monkeypatch.delenv("INTFFT_2D_GENERIC")
+    assert ia["kernel_name"].startswith("2d[") and ib["kernel_name"].startswith("k_pass"), (ia, ib)
+    want = C.execute_2d(x, C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction], C.HALVES, C.BITREV_LANES, form=1)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+
+
+def test_2d_in_place_and_ragged_chunks(monkeypatch):
+    """d_in == d_out with equal containers, and a batch that is not a multiple of the plan's chunk of frames."""
+    import torch
+
+    from intfftk_amd import int_fft_2d
+
+    core = int_fft_2d(NFFT=20, NFFT1=9, direction="PAIR")
+    x = uniform_frames(3, 1 << 20, 15, 4)
+    buf = torch.from_numpy(x.astype(np.int16)).cuda()
+    core(buf, out=buf)
+    torch.cuda.synchronize()
+    want = C.execute_2d(x, C.make_params(20, 16, 16, 0, 0, True), 9, C.PAIR)
+    assert np.array_equal(buf.cpu().numpy().astype(np.int64), want)
+    monkeypatch.setenv("INTFFT_2D_CHUNK_FRAMES", "4")  # 11 frames = two full chunks of scratch + a ragged one
+    small = int_fft_2d(NFFT=13, NFFT1=6)
+    monkeypatch.delenv("INTFFT_2D_CHUNK_FRAMES")
+    y = uniform_frames(11, 1 << 13, 15, 5)
+    got = small(torch.from_numpy(y.astype(np.int16)).cuda()).cpu().numpy().astype(np.int64)
+    assert np.array_equal(got, C.execute_2d(y, C.make_params(13, 16, 16, 0, 0, True), 6, C.FWD))
 
 
 def test_2d_unscaled_and_pair_at_2pow20():
@@ -93,3 +133,7 @@ def test_2d_twiddle_introspection():
     assert np.array_equal(core.twiddles(6), np.stack([re, im], axis=-1))
     with pytest.raises(Exception):
         core.twiddles(7)  # stages exist up to max(log2 N1, log2 N2) - 1 = 6
+    # the library's host-side evaluation == the oracle's on a whole 2^16 circle, 16- and 24-bit twiddles
+    for t in (16, 24):
+        big = int_fft_2d(NFFT=16, NFFT1=8, DATA_WIDTH=16, TWDL_WIDTH=t, FORMAT=1)
+        assert np.array_equal(big.twiddles(-1), np.array([C.twiddle_2d(16, t, m) for m in range(1 << 16)]))

@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
