@@ -169,7 +169,7 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def ceilings(torch, x, y, stream, digest):
+def ceilings(torch, x, y, stream, digest, c2):
     L = diag_lib()
     if L is None:
         return {"note": "tools/lib/libintfft_diag.so not built"}
@@ -195,7 +195,7 @@ def ceilings(torch, x, y, stream, digest):
         rates[slow] = n.value / (ms * 1e-3)  # wave-instructions per second, whole chip, 4 waves per SIMD
     clk = torch.cuda.get_device_properties(0).clock_rate * 1e3 if hasattr(torch.cuda.get_device_properties(0), "clock_rate") else 2.4e9
     insts = None
-    if digest and digest.get("SQ_INSTS_VALU") and digest.get("SQ_WAVES"):
+    if c2 and digest and digest.get("SQ_INSTS_VALU") and digest.get("SQ_WAVES"):
         insts = float(digest["SQ_INSTS_VALU"]) / 65536.0  # VALU wave-instructions per 1024-sample frame (PMC, per launch / frames)
     vb = {"slow_class_wave_insts_per_s": rates[1], "fast_class_wave_insts_per_s": rates[0],
           "slow_class_clk_per_wave_inst_at_nominal_clock": cus * 4 * clk / rates[1],
@@ -423,7 +423,7 @@ def main():
             del xf
             step()  # y := transform(x) again for the parity gate below
             torch.cuda.synchronize()
-            out.update(ceilings(torch, x, torch.empty_like(x), stream, digest))
+            out.update(ceilings(torch, x, torch.empty_like(x), stream, digest, args.config == "C2" and batch == 65536))
             out["octave"] = octave_probe()
         if world == 1 and not args.no_cpu_baseline:
             step()

@@ -286,3 +286,24 @@ def test_bench_single_gpu_line_has_the_8d_fields():
     assert out["e2e"]["matches_resident"] is True
     c5 = _bench(["--config", "C5", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "512", "--no-extras"])
     assert c5["config"]["n"] == 4096 and c5["cpu_baseline"]["parity_ok"] is True
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver's form for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE from the environment, ONE JSON line from rank 0."""
+    import torch
+
+    env = dict(os.environ, INTFFT_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--prewarm", "5", "--batch", "1024"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and "cpu_baseline" not in out
+    assert out["config"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert abs(out["value"] - sum(out["per_gpu"]["Gsample/s"])) / out["value"] < 0.5  # aggregate ~ sum of the ranks
