@@ -220,6 +220,8 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
 // bit-permutation mover (intfft_reorder.hip): m_in bit in_of_out[b] = m_out bit b; frames of 2^L (re, im) container pairs
 hipError_t launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
                           hipStream_t stream);
+hipError_t launch_bitperm_tw(int L, int container_bytes, const int *in_of_out, int l2, int mw, int sh_a, int sh_b, int narrow, int twd,
+                             int conj, const void *d_in, void *d_out, size_t batch, hipStream_t stream);
 int order_mem_bit(int order, int L, int j); // memory-index bit that carries logical-index bit j in an INTFFT_ORDER_* layout
 // 2-D scheme (intfft_generic.hip): in place V <- cmult(V, W_N^(k1 * n2)) on the [k1][n2] layout (conj: the inverse's swapped feed)
 hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj,

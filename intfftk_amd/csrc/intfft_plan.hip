@@ -819,7 +819,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
-        info->n_passes = n + 3 * cores + (cores == 2 ? 0 : 1); // per core pair: layout change + multiply + layout change; ends: one more each
+        info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
         info->compute_word = 0;
         info->fast_path = 0;
         info->scratch_bytes = 2 * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
@@ -848,6 +848,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
     int perm[24];
     hipError_t e = hipSuccess;
     int rc = INTFFT_OK;
+    const bool fuse = getenv("INTFFT_2D_NO_FUSE") == nullptr; // diagnostics: the multiplier as its own launch (k_twmul)
     for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
         const size_t nf = std::min(pl->buf2d_frames, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
@@ -864,10 +865,15 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
             cb = pl->sub_col_f->out_cb;
             // [n2][k1] -> [k1][n2]: out bit b < l2 (n2) <- in bit l1 + b; out bit b >= l2 (k1) <- in bit b - l2
             for (int b = 0; b < L; ++b) perm[b] = b < l2 ? l1 + b : b - l2;
-            if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
-            std::swap(cur, oth);
             const StageDesc &t = pl->tw_f;
-            if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 0, p.twdl_width, nf, stream)) != hipSuccess) break;
+            if (fuse) { // the multiplier between the cores rides on the layout change (applied in its output layout [k1][n2])
+                if ((e = launch_bitperm_tw(L, cb, perm, l2, t.mw, t.sh_a, t.sh_b, t.narrow, p.twdl_width, 0, cur, oth, nf, stream)) != hipSuccess) break;
+                std::swap(cur, oth);
+            } else {
+                if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
+                std::swap(cur, oth);
+                if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 0, p.twdl_width, nf, stream)) != hipSuccess) break;
+            }
             if ((rc = intfft_exec(pl->sub_row_f, cur, oth, nf << l1, stream)) != INTFFT_OK) break;
             std::swap(cur, oth);
             cb = pl->sub_row_f->out_cb;
@@ -886,10 +892,14 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
         std::swap(cur, oth);
         cb = pl->sub_row_i->out_cb;
         const StageDesc &t = pl->tw_i;
-        if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 1, p.twdl_width, nf, stream)) != hipSuccess) break;
         // [k1][n2] -> [n2][k1]: out bit b < l1 (k1) <- in bit l2 + b; out bit b >= l1 (n2) <- in bit b - l1
         for (int b = 0; b < L; ++b) perm[b] = b < l1 ? l2 + b : b - l1;
-        if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
+        if (fuse) { // conj multiply applied in the input layout [k1][n2]
+            if ((e = launch_bitperm_tw(L, cb, perm, l2, t.mw, t.sh_a, t.sh_b, t.narrow, p.twdl_width, 1, cur, oth, nf, stream)) != hipSuccess) break;
+        } else {
+            if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 1, p.twdl_width, nf, stream)) != hipSuccess) break;
+            if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
+        }
         std::swap(cur, oth);
         if ((rc = intfft_exec(pl->sub_col_i, cur, oth, nf << l2, stream)) != INTFFT_OK) break;
         std::swap(cur, oth);

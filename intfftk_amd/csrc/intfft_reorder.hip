@@ -80,6 +80,114 @@ template <typename E> __global__ __launch_bounds__(256) void k_reorder(const E *
         }
 }
 
+// ---- the same mover with the 2-D scheme's multiplier between the cores fused in --------------------------
+// TW = 1: V <- cmult(V, W_N^(k1 n2)) applied to the OUTPUT layout [k1][n2] (forward: [n2][k1] -> [k1][n2]);
+// TW = 2: T = V * conj(W) through the re/im-swapped feed applied to the INPUT layout [k1][n2] (inverse: [k1][n2] -> [n2][k1]).
+// A block owns one tile and walks the frames part, part + fsplit, ...: its 16 twiddles per thread are evaluated once.
+struct TwArgs {
+    int l2, mw, sh_a, sh_b, narrow, twd;
+};
+template <typename E> struct ElemIO;
+template <> struct ElemIO<uint32_t> { // int16 containers
+    typedef int32_t T;
+    static __device__ __forceinline__ void get(uint32_t v, T &re, T &im) { re = (int16_t)(v & 0xFFFFu), im = (int16_t)(v >> 16); }
+    static __device__ __forceinline__ uint32_t put(T re, T im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
+};
+template <> struct ElemIO<rv2u> { // int32 containers
+    typedef int32_t T;
+    static __device__ __forceinline__ void get(rv2u v, T &re, T &im) { re = (int32_t)(uint32_t)v, im = (int32_t)(uint32_t)(v >> 32); }
+    static __device__ __forceinline__ rv2u put(T re, T im) { return (rv2u)(uint32_t)re | ((rv2u)(uint32_t)im << 32); }
+};
+template <> struct ElemIO<rv4u> { // int64 containers
+    typedef int64_t T;
+    static __device__ __forceinline__ void get(rv4u v, T &re, T &im)
+    {
+        re = (int64_t)((uint64_t)v.x | ((uint64_t)v.y << 32));
+        im = (int64_t)((uint64_t)v.z | ((uint64_t)v.w << 32));
+    }
+    static __device__ __forceinline__ rv4u put(T re, T im)
+    {
+        const rv4u r = {(unsigned)(uint64_t)re, (unsigned)((uint64_t)re >> 32), (unsigned)(uint64_t)im, (unsigned)((uint64_t)im >> 32)};
+        return r;
+    }
+};
+
+template <typename E, int TW>
+__global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const ReorderArgs a, const TwArgs w, unsigned tiles, unsigned fsplit,
+                                                    size_t nframes)
+{
+    typedef typename ElemIO<E>::T T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    E *lds = reinterpret_cast<E *>(lds_raw);
+    const unsigned tile = blockIdx.x % tiles, part = blockIdx.x / tiles;
+    unsigned base_out = 0, base_in = 0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k)
+        if ((tile >> k) & 1u) {
+            base_out |= a.r_out[k];
+            base_in |= a.r_in[k];
+        }
+    const unsigned tid = threadIdx.x;
+    unsigned t_in = 0, t_slot = 0, t_out = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned bit = 0u - ((tid >> k) & 1u);
+        t_in |= bit & a.t_in[k];
+        t_slot |= bit & a.t_slot[k];
+        t_out |= bit & a.t_out[k];
+    }
+    const unsigned iters = a.U > 8 ? 1u << (a.U - 8) : 1u;
+    const bool active = a.U >= 8 || tid < (1u << a.U);
+    // this thread's twiddles: positions of its loads (TW = 2) or of its stores (TW = 1) in the [k1][n2] layout
+    int wr[16], wi[16];
+    {
+        double scale, mg;
+        tw2d_consts(a.L, w.twd, scale, mg);
+        const unsigned nmask = (1u << a.L) - 1u, m2 = (1u << w.l2) - 1u;
+#pragma unroll
+        for (unsigned i = 0; i < 16; ++i)
+            if (i < iters) {
+                const unsigned idx = TW == 1 ? (base_out | t_out | a.i_out[i]) : (base_in | t_in | a.i_in[i]);
+                tw2d_eval(a.L, scale, mg, ((idx >> w.l2) * (idx & m2)) & nmask, wr[i], wi[i]);
+            }
+    }
+    for (size_t f = part; f < nframes; f += fsplit) {
+        const E *src = in + (f << a.L) + base_in;
+        E *dst = out + (f << a.L) + base_out;
+        E v[16];
+#pragma unroll
+        for (unsigned i = 0; i < 16; ++i)
+            if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in | a.i_in[i]));
+#pragma unroll
+        for (unsigned i = 0; i < 16; ++i)
+            if (i < iters && active) {
+                if (TW == 2) { // swapped feed: DI_RE <- im, DI_IM <- re; DO_RE -> im, DO_IM -> re (int_dit2_fly.vhd:304-322)
+                    T re, im, ore, oim;
+                    ElemIO<E>::get(v[i], re, im);
+                    cmult(im, re, wr[i], wi[i], w.mw, w.sh_a, w.sh_b, w.narrow, ore, oim);
+                    v[i] = ElemIO<E>::put(oim, ore);
+                }
+                const unsigned slot = t_slot | a.i_slot[i];
+                lds[slot + (slot >> 5)] = v[i];
+            }
+        __syncthreads();
+#pragma unroll
+        for (unsigned i = 0; i < 16; ++i)
+            if (i < iters && active) {
+                const unsigned e = tid + 256u * i;
+                E x = lds[e + (e >> 5)];
+                if (TW == 1) {
+                    T re, im, ore, oim;
+                    ElemIO<E>::get(x, re, im);
+                    cmult(re, im, wr[i], wi[i], w.mw, w.sh_a, w.sh_b, w.narrow, ore, oim);
+                    x = ElemIO<E>::put(ore, oim);
+                }
+                __builtin_nontemporal_store(x, dst + (t_out | a.i_out[i]));
+            }
+        __syncthreads(); // the next frame's LDS writes wait for these reads
+    }
+}
+
 namespace {
 
 // which memory-index bit supplies logical-index bit j in each layout (the maps of include/intfft.h)
@@ -115,8 +223,7 @@ using namespace intfft;
 
 // any bit permutation of the frame index: m_in bit in_of_out[b] = m_out bit b (b = 0 .. L-1, L <= 24).  Used by
 // intfft_reorder (pairs of INTFFT_ORDER_* layouts) and by the 2-D scheme plans (layout changes between the cores).
-hipError_t intfft::launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
-                                  hipStream_t stream)
+static ReorderArgs make_reorder_args(int L, const int *in_of_out)
 {
     int out_of_in[24];
     for (int b = 0; b < L; ++b) out_of_in[in_of_out[b]] = b;
@@ -173,10 +280,52 @@ hipError_t intfft::launch_bitperm(int L, int container_bytes, const int *in_of_o
                 a.r_in[nr] = 1u << in_of_out[b];
                 ++nr;
             }
+    return a;
+}
+
+hipError_t intfft::launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
+                                  hipStream_t stream)
+{
+    const ReorderArgs a = make_reorder_args(L, in_of_out);
     switch (container_bytes) {
     case 2: return launch<uint32_t>(a, d_in, d_out, batch, stream);
     case 4: return launch<rv2u>(a, d_in, d_out, batch, stream);
     default: return launch<rv4u>(a, d_in, d_out, batch, stream);
+    }
+}
+
+template <typename E>
+static hipError_t launch_tw(const ReorderArgs &a, const TwArgs &w, int conj, const void *in, void *out, size_t batch, hipStream_t stream)
+{
+    const size_t lds = (((size_t)1 << a.U) + ((size_t)1 << a.U) / 32 + 1) * sizeof(E);
+    const unsigned tiles = 1u << (a.L - a.U);
+    unsigned fsplit = 1; // blocks per tile: enough blocks to fill the chip, as many frames per block as that leaves
+    const size_t want = (size_t)device_cus() * 8;
+    while ((size_t)tiles * fsplit < want && (size_t)fsplit * 2 <= batch) fsplit *= 2;
+    if (conj) {
+        if (lds > 48 * 1024) allow_max_lds(kptr(k_reorder_tw<E, 2>));
+        hipLaunchKernelGGL((k_reorder_tw<E, 2>), dim3(tiles * fsplit), dim3(256), lds, stream, static_cast<const E *>(in), static_cast<E *>(out),
+                           a, w, tiles, fsplit, batch);
+    } else {
+        if (lds > 48 * 1024) allow_max_lds(kptr(k_reorder_tw<E, 1>));
+        hipLaunchKernelGGL((k_reorder_tw<E, 1>), dim3(tiles * fsplit), dim3(256), lds, stream, static_cast<const E *>(in), static_cast<E *>(out),
+                           a, w, tiles, fsplit, batch);
+    }
+    return hipGetLastError();
+}
+
+// the layout change between the cores of a 2-D scheme plan with the multiplier fused in: conj = 0 multiplies in the OUTPUT
+// layout (which must be [k1][n2]), conj = 1 in the INPUT layout
+hipError_t intfft::launch_bitperm_tw(int L, int container_bytes, const int *in_of_out, int l2, int mw, int sh_a, int sh_b, int narrow,
+                                     int twd, int conj, const void *d_in, void *d_out, size_t batch, hipStream_t stream)
+{
+    if (batch == 0) return hipSuccess;
+    const ReorderArgs a = make_reorder_args(L, in_of_out);
+    const TwArgs w{l2, mw, sh_a, sh_b, narrow, twd};
+    switch (container_bytes) {
+    case 2: return launch_tw<uint32_t>(a, w, conj, d_in, d_out, batch, stream);
+    case 4: return launch_tw<rv2u>(a, w, conj, d_in, d_out, batch, stream);
+    default: return launch_tw<rv4u>(a, w, conj, d_in, d_out, batch, stream);
     }
 }
 

@@ -90,8 +90,11 @@ def test_2d_composite_equals_flat_form(case, direction, monkeypatch):
     b, ib = run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction, "HALVES", "BITREV_LANES")
     monkeypatch.delenv("INTFFT_2D_GENERIC")
     assert ia["kernel_name"].startswith("2d[") and ib["kernel_name"].startswith("k_pass"), (ia, ib)
+    monkeypatch.setenv("INTFFT_2D_NO_FUSE", "1")  # the multiplier between the cores as its own launch instead of fused
+    c, _ = run_gpu(x, log2n, l1, dw, tw, fmt, rnd, new, direction, "HALVES", "BITREV_LANES")
+    monkeypatch.delenv("INTFFT_2D_NO_FUSE")
     want = C.execute_2d(x, C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction], C.HALVES, C.BITREV_LANES, form=1)
-    assert np.array_equal(a, want) and np.array_equal(b, want)
+    assert np.array_equal(a, want) and np.array_equal(b, want) and np.array_equal(c, want)
 
 
 def test_2d_in_place_and_ragged_chunks(monkeypatch):
