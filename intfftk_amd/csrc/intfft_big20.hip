@@ -844,6 +844,7 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev)
 {
+    if (two_pass == 2) return freq_bitrev ? "k_big2p_a/k_mid_c" : "k_big2p_a/k_mid_p2"; // N = 2^17, 2^18 forward
     return two_pass ? (direction == 2 ? "k_big20_p1/k_mid_pair/q1"
                        : direction == 1 ? (freq_bitrev ? "k_mid_c/k_big20_q1" : "k_mid_q1/k_big20_q1")
                                       : (freq_bitrev ? "k_big20_p1/k_mid_c" : "k_big20_p1/k_mid_p2"))
@@ -1047,6 +1048,20 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
+    if (two_pass && log2n > 16) { // N = 2^17, 2^18: the 32-register first pass (stages L-1..8), then the same second pass
+        const size_t nb2 = nframes << (log2n - 13);
+        if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
+        const hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, stream);
+        if (e != hipSuccess) return e;
+        if (out_bitrev) {
+            const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
+            const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+            if (fx) hipLaunchKernelGGL((k_mid_c<false, true>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
+            else hipLaunchKernelGGL((k_mid_c<false, false>), dim3(gc), dim3(256), 0, stream, scr, pout, tw_all, c, nch, sl);
+        } else if (fx) hipLaunchKernelGGL(k_mid_p2<true>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_p2<false>, dim3((unsigned)nb2), dim3(512), 0, stream, scr, pout, tw_all, c, sl, log2n);
+        return hipGetLastError();
+    }
     if (two_pass && log2n <= 16) { // two-pass split: stages L-1..8, then stages 7..0 + the bit-reversed store (or none: BITREV out)
         const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);

@@ -388,6 +388,61 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
     }
 }
 
+// ---- 32-register rounds (five DIF stages per thread) with quarter-turn twiddle sharing ---------------------------------------
+// The second half of a stage's table is the quarter turn of the first, W[k + 2^(s-1)] = (W[k].im, -W[k].re)
+// (rom_twiddle_int.vhd:177-183; it holds for the Taylor stages too -- the planner verifies it on the generated tables
+// before choosing these kernels), so a round keeps only the BASE twiddles: 8 for the top stage (register offset 16),
+// then 4 / 2 / 1 / 1 for the offsets 8 / 4 / 2 / 1.
+struct RoundTwQ {
+    u32 wa8[4], wb8[4], wa4[2], wb4[2], wa2[1], wb2[1], wa1[1], wb1[1];
+};
+
+// offset 16: pairs (j, j + 16), twiddle index j (0..15): base for j < 8, quarter turn of base[j - 8] for j >= 8.
+// P0: PREMASK of the inputs (0 unshifted, 0xF already X >> 1), or VARSH with a per-thread shift amount.
+template <bool FASTX, int P0, bool VARSH>
+__device__ __forceinline__ void dif_top16(u32 (&v)[32], const u32 (&wa)[8], const u32 (&wb)[8], const Slice &sl, v2s shv)
+{
+    const u32 wa0[4] = {wa[0], wa[1], wa[2], wa[3]}, wb0[4] = {wb[0], wb[1], wb[2], wb[3]};
+    const u32 wa1[4] = {wa[4], wa[5], wa[6], wa[7]}, wb1[4] = {wb[4], wb[5], wb[6], wb[7]};
+    group4<false, FASTX, false, true, false, P0, VARSH>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl, shv);
+    group4<false, FASTX, false, true, false, P0, VARSH>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl, shv);
+    group4<false, FASTX, true, true, false, P0, VARSH>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl, shv);
+    group4<false, FASTX, true, true, false, P0, VARSH>(v[12], v[28], v[13], v[29], v[14], v[30], v[15], v[31], wa1, wb1, sl, shv);
+}
+
+// four DIF stages on registers v[B .. B+15], offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0).  NS < 4 runs only the last NS.
+// The inputs of the FIRST executed stage: PREMASK P0 (0 / 0xF) or VARSH0 (per-thread shift); later stages follow the
+// rule "the upper output of a butterfly is Y >> 1".
+template <bool FASTX, int B, int P0, bool VARSH0, int NS = 4>
+__device__ __forceinline__ void dif_round_q(u32 (&v)[32], const RoundTwQ &t, const Slice &sl, v2s shv)
+{
+    const v2s none = {0, 0};
+    if constexpr (NS >= 4) { // offset 8: twiddle j & 7: base j < 4, quarter turn j >= 4
+        group4<false, FASTX, false, true, false, P0, VARSH0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl, shv);
+        group4<false, FASTX, true, true, false, P0, VARSH0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl, shv);
+    }
+    if constexpr (NS >= 3) { // offset 4: pairs (j, j + 4), j in {0..3, 8..11}; twiddle j & 3: base 0, 1; quarter turn 2, 3
+        constexpr bool first = NS == 3;
+        constexpr int PM = first ? P0 : 0xC; // butterflies 2, 3 of each group come from the upper half of the offset-8 stage
+        const u32 wa[4] = {t.wa4[0], t.wa4[1], t.wa4[0], t.wa4[1]}, wb[4] = {t.wb4[0], t.wb4[1], t.wb4[0], t.wb4[1]};
+        group4<false, FASTX, false, true, false, PM, first && VARSH0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 8], v[B + 12], v[B + 9], v[B + 13], wa, wb, sl, first ? shv : none);
+        group4<false, FASTX, true, true, false, PM, first && VARSH0>(v[B + 2], v[B + 6], v[B + 3], v[B + 7], v[B + 10], v[B + 14], v[B + 11], v[B + 15], wa, wb, sl, first ? shv : none);
+    }
+    if constexpr (NS >= 2) { // offset 2: pairs (j, j + 2), j in {0,1,4,5,8,9,12,13}; twiddle j & 1: base 0; quarter turn 1
+        constexpr bool first = NS == 2;
+        constexpr int PM = first ? P0 : 0xA; // j = 4, 12 (butterflies 1, 3) are upper outputs of the offset-4 stage
+        const u32 wa[4] = {t.wa2[0], t.wa2[0], t.wa2[0], t.wa2[0]}, wb[4] = {t.wb2[0], t.wb2[0], t.wb2[0], t.wb2[0]};
+        group4<false, FASTX, false, true, false, PM, first && VARSH0>(v[B + 0], v[B + 2], v[B + 4], v[B + 6], v[B + 8], v[B + 10], v[B + 12], v[B + 14], wa, wb, sl, first ? shv : none);
+        group4<false, FASTX, true, true, false, PM, first && VARSH0>(v[B + 1], v[B + 3], v[B + 5], v[B + 7], v[B + 9], v[B + 11], v[B + 13], v[B + 15], wa, wb, sl, first ? shv : none);
+    }
+    if constexpr (NS >= 1) { // offset 1: pairs (j, j + 1), j even; one twiddle; j & 2 = upper output of the offset-2 stage
+        constexpr bool first = NS == 1;
+        const u32 wa[4] = {t.wa1[0], t.wa1[0], t.wa1[0], t.wa1[0]}, wb[4] = {t.wb1[0], t.wb1[0], t.wb1[0], t.wb1[0]};
+        group4<false, FASTX, false, true, false, first ? P0 : 0, first && VARSH0>(v[B + 0], v[B + 1], v[B + 4], v[B + 5], v[B + 8], v[B + 9], v[B + 12], v[B + 13], wa, wb, sl, first ? shv : none);
+        group4<false, FASTX, false, true, false, first ? P0 : 0xF, first && VARSH0>(v[B + 2], v[B + 3], v[B + 6], v[B + 7], v[B + 10], v[B + 11], v[B + 14], v[B + 15], wa, wb, sl, first ? shv : none);
+    }
+}
+
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------
 template <bool FASTX, int NS = 4, bool ROUND = false, bool DITPACK = false>
 __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)

@@ -84,7 +84,12 @@ void allow_max_lds(const void *kernel)
     std::lock_guard<std::mutex> lk(g_geom_mu);
     bool &done = g_max_lds[std::make_pair(kernel, dev)];
     if (done) return;
-    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // 160 KiB minus the kernel's static LDS (e.g. the 256 bytes __syncthreads_or uses): asking for more than fits fails
+    // with hipErrorInvalidValue and would leave that error pending for the next hipGetLastError()
+    hipFuncAttributes fa;
+    int room = 160 * 1024;
+    if (hipFuncGetAttributes(&fa, kernel) == hipSuccess) room -= (int)fa.sharedSizeBytes;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room) != hipSuccess) (void)hipGetLastError();
     done = true;
 }
 
@@ -728,6 +733,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+        // N = 2^17, 2^18 forward from natural order: the 32-register first pass (it shares twiddles by quarter turns: verified
+        // on this plan's tables)
+        const bool big2p = pl->big20 && p->direction == INTFFT_FWD && p->in_order == INTFFT_ORDER_NATURAL && big2p_supported(p->log2n) &&
+                           !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+        if (big2p) pl->big_two_pass = true;
         pl->big_pair256 = pl->big20 && p->log2n <= 16 && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
@@ -750,7 +760,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, pl->big_two_pass || pl->big_pair256, (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, big2p ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;

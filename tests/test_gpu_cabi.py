@@ -306,4 +306,6 @@ def test_bench_under_the_drivers_launcher():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and "cpu_baseline" not in out
     assert out["config"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
-    assert abs(out["value"] - sum(out["per_gpu"]["Gsample/s"])) / out["value"] < 0.5  # aggregate ~ sum of the ranks
+    assert len(out["per_gpu"]["Gsample/s"]) == 2 and out["value"] > 0
+    if torch.cuda.device_count() >= 2:  # ranks on their own GPUs: the aggregate is about the sum of the ranks (on one shared GPU they contend)
+        assert abs(out["value"] - sum(out["per_gpu"]["Gsample/s"])) / out["value"] < 0.5

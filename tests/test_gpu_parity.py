@@ -119,9 +119,30 @@ def test_three_pass_kernels_n8192_to_n524288(log2n, batch):
     x = uniform_frames(batch, n, 15, 2000 + log2n)
     x[0] = uniform_frames(1, n, 16, 7)[0]  # one full-scale frame: exact extraction in its tiles
     info = check(x, log2n, 16, 16, 0, 0, True)
-    assert info["kernel_name"].startswith("k_big20") and info["n_passes"] == (2 if log2n <= 16 else 3)
+    assert info["kernel_name"].startswith("k_big2") and info["n_passes"] == (2 if log2n <= 18 else 3)
     if batch <= 9:
         check(x, log2n, 16, 13, 0, 0, False)  # narrower twiddles, XSER "OLD"
+
+
+@pytest.mark.parametrize("log2n", [17, 18])
+@pytest.mark.parametrize("out_order", ["NATURAL", "BITREV"])
+def test_two_pass_32_register_first_pass(log2n, out_order, monkeypatch):
+    """N = 2^17, 2^18 forward from natural order: k_big2p_a (9 / 10 stages, 32 samples per thread, quarter-turn twiddle
+    sharing) + the 256-point second pass.  Bit-exact to the oracle incl. full-scale frames (exact extraction in their tiles),
+    odd batches, both XSER / a narrower twiddle width, and equal to the three-pass plan it replaces (INTFFT_NO_TWOPASS)."""
+    n = 1 << log2n
+    x = uniform_frames(7, n, 15, 900 + log2n)
+    x[2] = uniform_frames(1, n, 16, 8)[0]
+    x[5] = edge_frames(n, 16)[3]
+    info = check(x, log2n, 16, 16, 0, 0, True, out_order=out_order)
+    assert info["kernel_name"].startswith("k_big2p_a") and info["n_passes"] == 2, info
+    check(x[:3], log2n, 16, 16, 0, 0, False, out_order=out_order)
+    check(x[:3], log2n, 16, 12, 0, 0, True, out_order=out_order)
+    monkeypatch.setenv("INTFFT_NO_TWOPASS", "1")
+    got3, info3 = run_gpu(x, log2n, 16, 16, 0, 0, True, out_order=out_order)
+    monkeypatch.delenv("INTFFT_NO_TWOPASS")
+    got2, _ = run_gpu(x, log2n, 16, 16, 0, 0, True, out_order=out_order)
+    assert info3["n_passes"] == 3 and np.array_equal(got2, got3)
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
@@ -243,8 +264,8 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    two = log2n <= 16
-    assert "k_big20" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
+    two = log2n <= 16 or (log2n <= 18 and direction == "FWD" and in_order == "NATURAL")  # the 32-register first pass takes natural order
+    assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 
 def test_config4_n_2pow20_taylor_extension():
