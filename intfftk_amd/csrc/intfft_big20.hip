@@ -844,7 +844,9 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
 
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev)
 {
-    if (two_pass == 2) return freq_bitrev ? "k_big2p_a/k_mid_c" : "k_big2p_a/k_mid_p2"; // N = 2^17, 2^18 forward
+    if (two_pass == 2 && direction == 2) return "k_big2p_a/k_mid_pair/k_big2p_q"; // N = 2^17, 2^18
+    if (two_pass == 2)
+        return direction == 1 ? (freq_bitrev ? "k_mid_c/k_big2p_q" : "k_mid_q1/k_big2p_q") : (freq_bitrev ? "k_big2p_a/k_mid_c" : "k_big2p_a/k_mid_p2");
     return two_pass ? (direction == 2 ? "k_big20_p1/k_mid_pair/q1"
                        : direction == 1 ? (freq_bitrev ? "k_mid_c/k_big20_q1" : "k_mid_q1/k_big20_q1")
                                       : (freq_bitrev ? "k_big20_p1/k_mid_c" : "k_big20_p1/k_mid_p2"))
@@ -897,7 +899,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
-    if (two_pass && log2n <= 16) { // 256 x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
+    if (two_pass) { // 2^(L-8) x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
         RoundCConsts c;
         for (int k = 0; k < 8; ++k) {
             const int2 w = h_tw[7 + k];
@@ -909,10 +911,19 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
             c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
             c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
         }
-        const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
+        const int vsh = log2n <= 16 ? 16 - log2n : 0;
+        const size_t nvf = (nframes + ((size_t)1 << vsh) - 1) >> vsh;
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);
         const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
         const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+        if (log2n > 16) { // N = 2^17, 2^18: the 32-register passes on either side
+            hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, stream);
+            if (e != hipSuccess) return e;
+            if (fx) hipLaunchKernelGGL(k_mid_pair<true>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);
+            else hipLaunchKernelGGL(k_mid_pair<false>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            return launch_big2p_q(log2n, fx, scr, pout, tw16f, nframes, sl, 0, stream);
+        }
 #define INTFFT_PAIR256(LL)                                                                                                       \
     if (fx) {                                                                                                                    \
         hipLaunchKernelGGL((k_big20_p1<LL, true, 8>), dim3(8u * groups), dim3(512), 0, stream, pin, scr, tw16f, nframes, groups, sl, 0); \
@@ -980,6 +991,18 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     const bool fx = twd == 16 && allow_fast;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (two_pass && log2n > 16) { // N = 2^17, 2^18: the same first pass, then STAGE 8..L-1 with 32 registers per thread
+        if (in_bitrev) {
+            const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
+            const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
+            if (fx) hipLaunchKernelGGL((k_mid_c<true, true>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
+            else hipLaunchKernelGGL((k_mid_c<true, false>), dim3(gc), dim3(256), 0, stream, pin, scr, tw_all, c, nch, sl);
+        } else if (fx) hipLaunchKernelGGL(k_mid_q1<true>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, sl, log2n);
+        else hipLaunchKernelGGL(k_mid_q1<false>, dim3((unsigned)nb3), dim3(512), 0, stream, pin, scr, tw_all, c, sl, log2n);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_big2p_q(log2n, fx, scr, pout, tw16f, nframes, sl, out_halves, stream);
+    }
     if (two_pass && log2n <= 16) { // two-pass split: (bit-reversed) load + STAGE 0..7, then STAGE 8..L-1
         const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);

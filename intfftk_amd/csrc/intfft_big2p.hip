@@ -1,5 +1,5 @@
-// intfft_big2p.hip -- two-pass plans for N = 2^17 and 2^18 (forward, natural order in): the first pass with 32 registers
-// per thread.  int_fftNk, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate (same packed arithmetic as intfft_fast1024.hip).
+// intfft_big2p.hip -- two-pass plans for N = 2^17 and 2^18: the pass of stages 8..L-1 with 32 registers per thread (forward
+// from natural order: k_big2p_a; inverse: k_big2p_q).  int_fftNk, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate (same packed arithmetic as intfft_fast1024.hip).
 //
 // N = 2^L = 2^(L-8) x 256.  The second pass is the one the N <= 2^16 two-pass plans already use: k_mid_p2 (stages 7..0 and
 // the bit-reversed store on tiles of 32 rows x 256 points) or k_mid_c (BITREV order out).  What was missing for L > 16 is a
@@ -18,6 +18,8 @@
 // L2-resident table in every frame (what fits 128 VGPRs = four waves per SIMD; see the notes in the kernel).
 // L = 17: 512 threads, 68 KiB of LDS -> two workgroups per CU.  L = 18: 1024 threads, 136 KiB -> one.
 // Measured (256 MiB of input): N = 2^17 332 Gsample/s (three passes: 252), N = 2^18 298 (247).
+// k_big2p_q below is the inverse counterpart (DIT STAGE 8..L-1 after k_mid_q1 / k_mid_c): 325 (247) and 307 (243); the pair runs
+// k_big2p_a, k_mid_pair, k_big2p_q: 202 (164) and 181 (162).
 #include "intfft_pk16.hpp"
 
 #include <cstdlib>
@@ -33,8 +35,7 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
     static_assert(L == 17 || L == 18, "9 or 10 stages");
     constexpr int RB = L - 13;        // stages of round 2; thread bits hx
     constexpr int T = 32 << RB;
-    extern __shared__ u32 lds[];      // (32 << RB) rows x ROW2P, then the round-2 twiddles: NT2 slots x 32 columns of {wa, wb}
-    constexpr int NT2 = RB == 5 ? 16 : 8;
+    extern __shared__ u32 lds[];      // (32 << RB) rows x ROW2P, then the round-2 twiddles: 8 (RB = 4) / 16 slots x 32 columns of {wa, wb}
     uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + T * ROW2P + (T * ROW2P & 1));
     const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5;
     const unsigned chunk = blockIdx.x & 7u, grp = blockIdx.x >> 3; // neighbouring blocks = neighbouring columns of one frame
@@ -168,6 +169,144 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
     (void)T;
 }
 
+// ---- the inverse counterpart: DIT STAGE 8..L-1 after k_mid_q1 / k_mid_c<DIT> (which leave STAGE 0..7 done, in place) -----------
+//   round 1 thread = (hx = n(L-1)..n13, l = n4..n0), regs q = n12..n8
+//           L = 18: stages 8..12;  L = 17: two independent 4-stage rounds 8..11 (n12 rides along)
+//   LDS     row rho = n(L-1)..n8 (natural), column l
+//   round 2 thread = (p = n(L-6)..n8, l), regs j = n(L-1)..n(L-5): stages L-5..L-1
+//   store   natural order, or HALVES (n(L-1) is the top register bit: the two halves are registers j and j + 16)
+// Round 1's twiddles depend on the column only (parked in LDS, DIT packing); round 2's are per thread, re-read from the
+// L2-resident table in every frame and converted to the DIT packing on arrival.
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2p_q(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, size_t nframes,
+                                                            unsigned groups, const Slice sl, int halves)
+{
+    static_assert(L == 17 || L == 18, "9 or 10 stages");
+    constexpr int RB = L - 13; // thread bits hx of round 1 = stages of round 1 = thread bits p of round 2
+    constexpr int T = 32 << RB;
+    extern __shared__ u32 lds[];
+    uint2 *const tw1 = reinterpret_cast<uint2 *>(lds + T * ROW2P + (T * ROW2P & 1));
+    const int tid = threadIdx.x, l = tid & 31, hx = tid >> 5;
+    const unsigned chunk = blockIdx.x & 7u, grp = blockIdx.x >> 3;
+    const unsigned lfull = chunk * 32 + l;
+    const unsigned toff = ((unsigned)hx << 13) | lfull; // load side: rows (hx << 5 | q)
+    const unsigned toff2 = ((unsigned)hx << 8) | lfull; // store side and round-2 twiddles: p = tid >> 5
+    // round 1 (stage 8 + b, table index (rr << 8) | lfull): parked in LDS in the DIT packing
+    if (hx == 0) {
+        int slot = 0;
+        auto park = [&](unsigned uniform_idx) {
+            uint2 w = (twf + uniform_idx)[lfull];
+            to_dit_packing(w.x, w.y);
+            tw1[32 * slot++ + l] = w;
+        };
+        park((1u << 8) - 1u);
+        park((1u << 9) - 1u);
+        for (int rr = 0; rr < 2; ++rr) park((1u << 10) - 1u + ((unsigned)rr << 8));
+        for (int rr = 0; rr < 4; ++rr) park((1u << 11) - 1u + ((unsigned)rr << 8));
+        if constexpr (RB == 5)
+            for (int rr = 0; rr < 8; ++rr) park((1u << 12) - 1u + ((unsigned)rr << 8));
+    }
+    u32 *const wr_base = lds + ROW2P * (hx << 5) + l;  // write side: row (hx << 5) + q
+    const u32 *const rd_base = lds + ROW2P * hx + l;   // read side: row (j << RB) + p
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = scr + (frame << L);
+        u32 *dst = out + (frame << L);
+        unsigned toff_l = toff, toff2_l = toff2;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        u32 v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = (src + ((size_t)q << 8))[toff_l];
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc |= v[q] + 0x40004000u;
+            const int bad = __syncthreads_or((acc & 0x80008000u) != 0); // also orders the previous frame's LDS reads
+            fast = FAST_OK && bad == 0;
+        }
+        {
+            RoundTwQ t1;
+            u32 wa16[8], wb16[8];
+            int slot = 0;
+            auto get = [&](u32 &wa, u32 &wb) {
+                const uint2 w = tw1[32 * slot++ + l];
+                wa = w.x;
+                wb = w.y;
+            };
+            get(t1.wa1[0], t1.wb1[0]);
+            get(t1.wa2[0], t1.wb2[0]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) get(t1.wa4[rr], t1.wb4[rr]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) get(t1.wa8[rr], t1.wb8[rr]);
+            if constexpr (RB == 5) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) get(wa16[rr], wb16[rr]);
+            }
+            if (fast) {
+                dit_round_q<FAST_OK, 0>(v, t1, sl);
+                dit_round_q<FAST_OK, 16>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa16, wb16, sl);
+            } else {
+                dit_round_q<false, 0>(v, t1, sl);
+                dit_round_q<false, 16>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<false>(v, wa16, wb16, sl);
+            }
+        }
+        // round 2's per-thread twiddles: stage L-5+b, index (jj << (L-5)) | (p << 8) | lfull
+        RoundTwQ t2;
+        u32 wa16[8], wb16[8];
+        auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
+            const uint2 w = (twf + uniform_idx)[toff2_l];
+            wa = w.x;
+            wb = w.y;
+        };
+        ld((1u << (L - 5)) - 1u, t2.wa1[0], t2.wb1[0]);
+        ld((1u << (L - 4)) - 1u, t2.wa2[0], t2.wb2[0]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld((1u << (L - 3)) - 1u + ((unsigned)jj << (L - 5)), t2.wa4[jj], t2.wb4[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld((1u << (L - 2)) - 1u + ((unsigned)jj << (L - 5)), t2.wa8[jj], t2.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld((1u << (L - 1)) - 1u + ((unsigned)jj << (L - 5)), wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wr_base[ROW2P * q] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = rd_base[ROW2P * (j << RB)];
+        to_dit_packing(t2.wa1[0], t2.wb1[0]);
+        to_dit_packing(t2.wa2[0], t2.wb2[0]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) to_dit_packing(t2.wa4[jj], t2.wb4[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) to_dit_packing(t2.wa8[jj], t2.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) to_dit_packing(wa16[jj], wb16[jj]);
+        if (fast) {
+            dit_round_q<FAST_OK, 0>(v, t2, sl);
+            dit_round_q<FAST_OK, 16>(v, t2, sl);
+            dit_top16<FAST_OK>(v, wa16, wb16, sl);
+        } else {
+            dit_round_q<false, 0>(v, t2, sl);
+            dit_round_q<false, 16>(v, t2, sl);
+            dit_top16<false>(v, wa16, wb16, sl);
+        }
+        if (halves) { // memory index of (n(L-1), rest) = rest * 2 + n(L-1)
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            v2u *d2 = reinterpret_cast<v2u *>(dst);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v2u w = {v[j], v[j + 16]};
+                __builtin_nontemporal_store(w, d2 + ((size_t)j << (L - 5)) + toff2_l);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << (L - 5)) + toff2_l);
+        }
+    }
+    (void)T;
+}
+
 // the quarter-turn relation these kernels rely on, checked on the plan's generated tables (host copy)
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd)
 {
@@ -177,6 +316,7 @@ bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd)
         for (size_t k = 0; k < h; ++k) {
             const int neg = (int)(((long long)(-t[k].x) << (64 - twd)) >> (64 - twd));
             if (t[k + h].x != t[k].y || t[k + h].y != neg) return false;
+            if (t[k].x == -32768 || t[k].y == -32768) return false; // k_big2p_q negates packed 16-bit twiddle halves
         }
     }
     return true;
@@ -202,6 +342,27 @@ hipError_t launch_big2p_a(int log2n, bool fx, const u32 *pin, u32 *scr, const ui
         if (fx) INTFFT_2P_LAUNCH(18, true) else INTFFT_2P_LAUNCH(18, false)
     }
 #undef INTFFT_2P_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_big2p_q(int log2n, bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, size_t nframes, const Slice &sl,
+                          int halves, hipStream_t stream)
+{
+#define INTFFT_2Q_LAUNCH(LL, FX)                                                                                          \
+    {                                                                                                                     \
+        constexpr int TT = 32 << (LL - 13);                                                                               \
+        const size_t ldsb = ((size_t)TT * ROW2P + 1) * sizeof(u32) + (LL == 18 ? 16 : 8) * 32 * sizeof(uint2);             \
+        allow_max_lds(kptr(k_big2p_q<LL, FX>));                                                                           \
+        const size_t per_cu = LL == 17 ? 2 : 1, cap = (size_t)device_cus() * per_cu / 8;                                  \
+        const unsigned groups = (unsigned)(nframes < cap ? nframes : (cap ? cap : 1));                                    \
+        hipLaunchKernelGGL((k_big2p_q<LL, FX>), dim3(8u * groups), dim3(TT), ldsb, stream, scr, pout, tw16f, nframes, groups, sl, halves); \
+    }
+    if (log2n == 17) {
+        if (fx) INTFFT_2Q_LAUNCH(17, true) else INTFFT_2Q_LAUNCH(17, false)
+    } else {
+        if (fx) INTFFT_2Q_LAUNCH(18, true) else INTFFT_2Q_LAUNCH(18, false)
+    }
+#undef INTFFT_2Q_LAUNCH
     return hipGetLastError();
 }
 

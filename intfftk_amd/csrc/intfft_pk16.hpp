@@ -251,15 +251,23 @@ __device__ __forceinline__ constexpr int rev4c(int r) { return ((r & 1) << 3) | 
 // DITPACK: the twiddle operands are held in the DIT packing {Wc = (wr, wi), Wd = (-wi, wr)} (to_dit_packing below)
 // instead of the DIF packing {Wa, Wb}: T.re = dot(B, Wc), T.im = dot(B, Wd) on the UNSWAPPED B -- one v_alignbit less
 // per butterfly.  Kernels that run only the inverse core use it; the pair shares one DIF-packed set between its cores.
-template <bool FASTX, bool SG, bool ROUND = false, bool DITPACK = false>
+// QTURN: the twiddles are the quarter turns W' = (W.im, -W.re) of the given base twiddles: T'.re = -(T.im of the base) and
+// T'.im = T.re of the base, so the re operand is the NEGATED im operand of the base (exact: no table entry is -2^15, the
+// planner checks) and the im operand is the base's re operand.
+template <bool FASTX, bool SG, bool ROUND = false, bool DITPACK = false, bool QTURN = false>
 __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
                                            const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl)
 {
+    static_assert(!QTURN || !SG, "the negated operand lives in a VGPR");
     const u32 bs[4] = {DITPACK ? b0 : __builtin_amdgcn_alignbit(b0, b0, 16), DITPACK ? b1 : __builtin_amdgcn_alignbit(b1, b1, 16),
                        DITPACK ? b2 : __builtin_amdgcn_alignbit(b2, b2, 16), DITPACK ? b3 : __builtin_amdgcn_alignbit(b3, b3, 16)};
     // operand of the re / im dot product: (Wb, Wa) on the swapped B, (Wc, Wd) = (wa_in, wb_in) on the unswapped B
-    const u32 (&wb)[4] = DITPACK ? wa_in : wb_in;
-    const u32 (&wa)[4] = DITPACK ? wb_in : wa_in;
+    const u32 (&wb0)[4] = DITPACK ? wa_in : wb_in;
+    const u32 (&wa0)[4] = DITPACK ? wb_in : wa_in;
+    const v2s z2 = {0, 0};
+    const u32 wb[4] = {QTURN ? as_u32(z2 - as_v2s(wa0[0])) : wb0[0], QTURN ? as_u32(z2 - as_v2s(wa0[1])) : wb0[1],
+                       QTURN ? as_u32(z2 - as_v2s(wa0[2])) : wb0[2], QTURN ? as_u32(z2 - as_v2s(wa0[3])) : wb0[3]};
+    const u32 wa[4] = {QTURN ? wb0[0] : wa0[0], QTURN ? wb0[1] : wa0[1], QTURN ? wb0[2] : wa0[2], QTURN ? wb0[3] : wa0[3]};
     if constexpr (ROUND) { // RNDMODE = 1 (int_dit2_fly.vhd:164-217): T at full width, then rhu2(A +/- T)
         static_assert(!FASTX, "fast extraction yields T >> 1 only");
         u32 tf[4];
@@ -441,6 +449,43 @@ __device__ __forceinline__ void dif_round_q(u32 (&v)[32], const RoundTwQ &t, con
         group4<false, FASTX, false, true, false, first ? P0 : 0, first && VARSH0>(v[B + 0], v[B + 1], v[B + 4], v[B + 5], v[B + 8], v[B + 9], v[B + 12], v[B + 13], wa, wb, sl, first ? shv : none);
         group4<false, FASTX, false, true, false, first ? P0 : 0xF, first && VARSH0>(v[B + 2], v[B + 3], v[B + 6], v[B + 7], v[B + 10], v[B + 11], v[B + 14], v[B + 15], wa, wb, sl, first ? shv : none);
     }
+}
+
+// ---- 32-register DIT rounds with quarter-turn sharing (mirror of dif_round_q / dif_top16); twiddles in the DIT packing ----
+// four DIT stages on registers v[B .. B+15], offsets 1, 2, 4, 8 (stage numbers s0 .. s0+3)
+template <bool FASTX, int B>
+__device__ __forceinline__ void dit_round_q(u32 (&v)[32], const RoundTwQ &t, const Slice &sl)
+{
+    { // offset 1: one twiddle
+        const u32 wa[4] = {t.wa1[0], t.wa1[0], t.wa1[0], t.wa1[0]}, wb[4] = {t.wb1[0], t.wb1[0], t.wb1[0], t.wb1[0]};
+        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 1], v[B + 2], v[B + 3], v[B + 4], v[B + 5], v[B + 6], v[B + 7], wa, wb, sl);
+        group4_dit<FASTX, false, false, true>(v[B + 8], v[B + 9], v[B + 10], v[B + 11], v[B + 12], v[B + 13], v[B + 14], v[B + 15], wa, wb, sl);
+    }
+    { // offset 2: twiddle index j & 1: base 0, quarter turn 1
+        const u32 wa[4] = {t.wa2[0], t.wa2[0], t.wa2[0], t.wa2[0]}, wb[4] = {t.wb2[0], t.wb2[0], t.wb2[0], t.wb2[0]};
+        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 2], v[B + 4], v[B + 6], v[B + 8], v[B + 10], v[B + 12], v[B + 14], wa, wb, sl);
+        group4_dit<FASTX, false, false, true, true>(v[B + 1], v[B + 3], v[B + 5], v[B + 7], v[B + 9], v[B + 11], v[B + 13], v[B + 15], wa, wb, sl);
+    }
+    { // offset 4: twiddle index j & 3: base 0, 1; quarter turn 2, 3
+        const u32 wa[4] = {t.wa4[0], t.wa4[1], t.wa4[0], t.wa4[1]}, wb[4] = {t.wb4[0], t.wb4[1], t.wb4[0], t.wb4[1]};
+        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 8], v[B + 12], v[B + 9], v[B + 13], wa, wb, sl);
+        group4_dit<FASTX, false, false, true, true>(v[B + 2], v[B + 6], v[B + 3], v[B + 7], v[B + 10], v[B + 14], v[B + 11], v[B + 15], wa, wb, sl);
+    }
+    { // offset 8: twiddle index j & 7: base j < 4, quarter turn j >= 4
+        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl);
+        group4_dit<FASTX, false, false, true, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl);
+    }
+}
+// offset 16: pairs (j, j + 16), twiddle index j: base for j < 8, quarter turn of base[j - 8] for j >= 8
+template <bool FASTX>
+__device__ __forceinline__ void dit_top16(u32 (&v)[32], const u32 (&wa)[8], const u32 (&wb)[8], const Slice &sl)
+{
+    const u32 wa0[4] = {wa[0], wa[1], wa[2], wa[3]}, wb0[4] = {wb[0], wb[1], wb[2], wb[3]};
+    const u32 wa1[4] = {wa[4], wa[5], wa[6], wa[7]}, wb1[4] = {wb[4], wb[5], wb[6], wb[7]};
+    group4_dit<FASTX, false, false, true>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl);
+    group4_dit<FASTX, false, false, true>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl);
+    group4_dit<FASTX, false, false, true, true>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl);
+    group4_dit<FASTX, false, false, true, true>(v[12], v[28], v[13], v[29], v[14], v[30], v[15], v[31], wa1, wb1, sl);
 }
 
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------

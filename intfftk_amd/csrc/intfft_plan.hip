@@ -733,12 +733,14 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                                     p->use_fly, p->in_order, p->out_order) &&
                     !getenv("INTFFT_NO_BIG20");
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
-        // N = 2^17, 2^18 forward from natural order: the 32-register first pass (it shares twiddles by quarter turns: verified
-        // on this plan's tables)
-        const bool big2p = pl->big20 && p->direction == INTFFT_FWD && p->in_order == INTFFT_ORDER_NATURAL && big2p_supported(p->log2n) &&
+        // N = 2^17, 2^18 forward from natural order / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
+        // quarter turns: verified on this plan's tables)
+        const bool big2p = pl->big20 && ((p->direction == INTFFT_FWD && p->in_order == INTFFT_ORDER_NATURAL) || p->direction == INTFFT_INV) && big2p_supported(p->log2n) &&
                            !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
-        pl->big_pair256 = pl->big20 && p->log2n <= 16 && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+        const bool big2p_pair = pl->big20 && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
+                                big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+        pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -760,7 +762,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, big2p ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         if (pl->word == 2) {
             const size_t total = ((size_t)1 << pl->L) - 1;

@@ -140,3 +140,25 @@ def test_2d_twiddle_introspection():
     for t in (16, 24):
         big = int_fft_2d(NFFT=16, NFFT1=8, DATA_WIDTH=16, TWDL_WIDTH=t, FORMAT=1)
         assert np.array_equal(big.twiddles(-1), np.array([C.twiddle_2d(16, t, m) for m in range(1 << 16)]))
+
+
+def test_2d_random_configurations():
+    """Seeded fuzz over (N1, N2, widths, mode, XSER, direction, orders): every elaboratable draw is bit-exact to the oracle."""
+    rng = np.random.default_rng(20260928)
+    orders = list(ORD)
+    done = 0
+    for _ in range(120):
+        log2n = int(rng.integers(6, 15))
+        l1 = int(rng.integers(3, log2n - 2))
+        dw = int(rng.choice([8, 12, 16, 18, 24, 30]))
+        tw = int(rng.choice([10, 16, 18, 24]))
+        fmt = int(rng.integers(0, 2))
+        rnd = 0 if fmt else int(rng.integers(0, 2))
+        new = bool(rng.integers(0, 2))
+        direction = str(rng.choice(list(DIR)))
+        if C.lib().orc_validate_2d(C.make_params(log2n, dw, tw, fmt, rnd, new), l1, DIR[direction]):
+            continue
+        x = uniform_frames(int(rng.integers(1, 4)), 1 << log2n, dw, int(rng.integers(1, 1 << 30)))
+        check(x, log2n, l1, dw, tw, fmt, rnd, new, direction, str(rng.choice(orders)), str(rng.choice(orders)))
+        done += 1
+    assert done >= 60

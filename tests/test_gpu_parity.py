@@ -145,6 +145,28 @@ def test_two_pass_32_register_first_pass(log2n, out_order, monkeypatch):
     assert info3["n_passes"] == 3 and np.array_equal(got2, got3)
 
 
+@pytest.mark.parametrize("log2n", [17, 18])
+@pytest.mark.parametrize("in_order,out_order", [("NATURAL", "NATURAL"), ("BITREV", "NATURAL"), ("NATURAL", "HALVES"), ("BITREV", "HALVES")])
+def test_two_pass_32_register_inverse(log2n, in_order, out_order, monkeypatch):
+    """N = 2^17, 2^18 inverse: k_mid_q1 | k_mid_c (STAGE 0..7) + k_big2p_q (STAGE 8..L-1, 32 samples per thread, quarter-turn
+    sharing on DIT-packed twiddles).  Bit-exact to the oracle incl. full-scale and edge frames (exact extraction in their
+    tiles), XSER "OLD", a narrower twiddle width, and equal to the three-pass plan it replaces (INTFFT_NO_TWOPASS)."""
+    n = 1 << log2n
+    x = uniform_frames(7, n, 15, 950 + log2n)
+    x[1] = uniform_frames(1, n, 16, 18)[0]
+    x[4] = edge_frames(n, 16)[3]
+    x[6] = edge_frames(n, 16)[1]
+    kw = dict(direction="INV", in_order=in_order, out_order=out_order)
+    info = check(x, log2n, 16, 16, 0, 0, True, **kw)
+    assert info["kernel_name"].endswith("k_big2p_q") and info["n_passes"] == 2, info
+    check(x[:3], log2n, 16, 16, 0, 0, False, **kw)
+    check(x[:3], log2n, 16, 12, 0, 0, True, **kw)
+    got2, _ = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
+    monkeypatch.setenv("INTFFT_NO_TWOPASS", "1")
+    got3, info3 = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
+    assert info3["n_passes"] == 3 and np.array_equal(got2, got3)
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
 @pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "NATURAL", "NATURAL"), ("FWD", "HALVES", "NATURAL"),
                                                              ("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
@@ -195,15 +217,17 @@ def test_multi_pass_kernels_small_batches(log2n, batch):
                                          (20, 2)])
 def test_three_pass_pair_n8192_to_n2pow20(log2n, batch, monkeypatch):
     """int_fft_ifft_pair for N >= 8192 in three passes: DIF STAGE L-1..12, the whole pair of STAGE 11..0 / 0..11 on every
-    4096-point block (the bit reversal between the cores cancels), DIT STAGE 12..L-1.  N <= 2^16 split 256 x 256 instead
-    (DIF L-1..8, the pair of 7..0 / 0..7 on every 256-point group in k_mid_pair, DIT 8..L-1); both splits are checked."""
+    4096-point block (the bit reversal between the cores cancels), DIT STAGE 12..L-1.  N <= 2^18 split 2^(L-8) x 256 instead
+    (DIF L-1..8, the pair of 7..0 / 0..7 on every 256-point group in k_mid_pair, DIT 8..L-1; N = 2^17, 2^18 through the
+    32-register passes k_big2p_a / k_big2p_q); both splits are checked."""
     n = 1 << log2n
     x = uniform_frames(batch, n, 15, 3000 + log2n)
     x[0] = uniform_frames(1, n, 16, 8)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
-    assert info["kernel_name"] == ("k_big20_p1/k_mid_pair/q1" if log2n <= 16 else "k_big20_p1/k_fft4096_i16<MID>/q1")
+    assert info["kernel_name"] == ("k_big20_p1/k_mid_pair/q1" if log2n <= 16 else "k_big2p_a/k_mid_pair/k_big2p_q" if log2n <= 18
+                                   else "k_big20_p1/k_fft4096_i16<MID>/q1")
     assert info["n_passes"] == 3
-    if log2n <= 16:
+    if log2n <= 18:
         with monkeypatch.context() as m:
             m.setenv("INTFFT_NO_TWOPASS", "1")
             info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
@@ -264,7 +288,8 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    two = log2n <= 16 or (log2n <= 18 and direction == "FWD" and in_order == "NATURAL")  # the 32-register first pass takes natural order
+    # the 32-register passes: forward from natural order, inverse from either order
+    two = log2n <= 16 or (log2n <= 18 and (direction == "INV" or in_order == "NATURAL"))
     assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 

@@ -7,7 +7,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from tools import bench_configs as B  # noqa: E402
 
 ROWS = []
-for L in (3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20):
+for L in (3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 20):
     ROWS.append(("%d:16:16:0" % L, "16-bit scaled-trunc FWD"))
 for L in (7, 10, 12):
     ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
@@ -19,7 +19,7 @@ for L, L1 in ((20, 10), (21, 10), (22, 11), (24, 12)):
 ROWS.append(("20:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^10"))
 ROWS.append(("20:16:16:0:0:PAIR:10", "16-bit scaled-trunc PAIR, 2-D scheme 2^10 x 2^10"))
 ROWS.append(("20:16:16:1:0:FWD:10", "16-bit unscaled FWD, 2-D scheme 2^10 x 2^10 (36-bit results)"))
-for L in (7, 10, 11, 12, 14, 16, 17, 20):
+for L in (7, 10, 11, 12, 14, 16, 17, 18, 20):
     ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
     ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
 for L in (7, 10, 11, 12, 14, 16):
