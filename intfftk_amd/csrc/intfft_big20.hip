@@ -917,7 +917,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
         const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
         const unsigned gc = (unsigned)((nch + 3) / 4 < ccap ? (nch + 3) / 4 : ccap);
         if (log2n > 16) { // N = 2^17, 2^18: the 32-register passes on either side
-            hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, stream);
+            hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, 0, stream);
             if (e != hipSuccess) return e;
             if (fx) hipLaunchKernelGGL(k_mid_pair<true>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);
             else hipLaunchKernelGGL(k_mid_pair<false>, dim3(gc), dim3(256), 0, stream, scr, tw_all, c, nch, sl);
@@ -1074,7 +1074,7 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the 32-register first pass (stages L-1..8), then the same second pass
         const size_t nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
-        const hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, stream);
+        const hipError_t e = launch_big2p_a(log2n, fx, pin, scr, tw16f, nframes, sl, in_halves, stream);
         if (e != hipSuccess) return e;
         if (out_bitrev) {
             const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;

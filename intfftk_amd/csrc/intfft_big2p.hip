@@ -30,7 +30,7 @@ constexpr int ROW2P = 33; // LDS row stride in dwords (32 columns + 1): conflict
 
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2p_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes,
-                                                            unsigned groups, const Slice sl)
+                                                            unsigned groups, const Slice sl, int halves)
 {
     static_assert(L == 17 || L == 18, "9 or 10 stages");
     constexpr int RB = L - 13;        // stages of round 2; thread bits hx
@@ -113,8 +113,19 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         unsigned toff_l = toff, toff2_l = toff2;
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
+        if (halves) { // HALVES order in: memory index = 2 * (n without n(L-1)) + n(L-1); registers j and j + 16 are one 8-byte load
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *s2 = reinterpret_cast<const v2u *>(src);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 8)) + toff_l); // regs = n(L-1)..n(L-5)
+            for (int j = 0; j < 16; ++j) {
+                const v2u w = __builtin_nontemporal_load(s2 + ((size_t)j << (RB + 8)) + toff_l);
+                v[j] = w.x;
+                v[j + 16] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 8)) + toff_l); // regs = n(L-1)..n(L-5)
+        }
         round1_tw(toff_l);
         // guard-bit vote of the tile (closed under stages L-1..8); the barrier also orders the previous frame's LDS reads
         bool fast = false;
@@ -325,7 +336,7 @@ bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd)
 bool big2p_supported(int log2n) { return (log2n == 17 || log2n == 18) && !getenv("INTFFT_NO_BIG2P"); }
 
 hipError_t launch_big2p_a(int log2n, bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl,
-                          hipStream_t stream)
+                          int halves, hipStream_t stream)
 {
 #define INTFFT_2P_LAUNCH(LL, FX)                                                                                          \
     {                                                                                                                     \
@@ -334,7 +345,7 @@ hipError_t launch_big2p_a(int log2n, bool fx, const u32 *pin, u32 *scr, const ui
         allow_max_lds(kptr(k_big2p_a<LL, FX>));                                                                           \
         const size_t per_cu = LL == 17 ? 2 : 1, cap = (size_t)device_cus() * per_cu / 8;                                  \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : (cap ? cap : 1));                                    \
-        hipLaunchKernelGGL((k_big2p_a<LL, FX>), dim3(8u * groups), dim3(TT), ldsb, stream, pin, scr, tw16f, nframes, groups, sl); \
+        hipLaunchKernelGGL((k_big2p_a<LL, FX>), dim3(8u * groups), dim3(TT), ldsb, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
     }
     if (log2n == 17) {
         if (fx) INTFFT_2P_LAUNCH(17, true) else INTFFT_2P_LAUNCH(17, false)

@@ -219,7 +219,7 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
 bool big2p_supported(int log2n);
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd);
 hipError_t launch_big2p_a(int log2n, bool fx, const uint32_t *pin, uint32_t *scr, const uint2 *tw16f, size_t nframes, const struct Slice &sl,
-                          hipStream_t stream);
+                          int halves, hipStream_t stream);
 hipError_t launch_big2p_q(int log2n, bool fx, const uint32_t *scr, uint32_t *pout, const uint2 *tw16f, size_t nframes, const struct Slice &sl,
                           int halves, hipStream_t stream);
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);

@@ -245,7 +245,7 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
     x = uniform_frames(batch, n, 15, 4000 + log2n)
     x[0] = uniform_frames(1, n, 16, 9)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction="INV")
-    assert ("k_big20" in info["kernel_name"]) and info["n_passes"] == (2 if log2n <= 16 else 3)
+    assert ("k_big2" in info["kernel_name"]) and info["n_passes"] == (2 if log2n <= 18 else 3)
     if batch <= 9 and log2n < 20:
         check(x, log2n, 16, 13, 0, 0, False, direction="INV")
 
@@ -288,8 +288,7 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    # the 32-register passes: forward from natural order, inverse from either order
-    two = log2n <= 16 or (log2n <= 18 and (direction == "INV" or in_order == "NATURAL"))
+    two = log2n <= 18  # N = 2^17, 2^18: the 32-register passes take the native orders too
     assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 
