@@ -419,9 +419,10 @@ template <int L, bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, int in_halves, hipStream_t stream)
 {
-    // persistent waves: exactly the resident grid (occupancy x CUs), so no block waits for a slot.  The pipelined variant
-    // now fits 8 blocks per CU (56 VGPRs, 20 KiB of LDS per block); measured 8 / 6 / 4 blocks per CU: 90.2-91.3 / 91.7-91.8 /
-    // 93.0-93.4 us per 65536 frames (round 1 capped it at 4, when the kernel needed more registers)
+    // persistent waves: the resident grid (occupancy x CUs), so no block waits for a slot.  Neither the grid size nor the
+    // occupancy is a lever any more: 4 (= resident, 105 VGPRs) / 5 / 6 / 8 / 12 / 16 / 32 blocks per CU all measure 90-94 us per
+    // 65536 frames, inside the run-to-run spread (tools/tune_headline.sh, INTFFT_BLOCKS_PER_CU), and a variant with every
+    // per-lane twiddle parked in LDS (90 VGPRs, five waves per SIMD) measured 91.2-91.5 us against 91.1-91.5
     const size_t cap = resident_blocks(kptr(k_fft1024_i16<L, ROUND, OUT_BITREV, PIPE, FAST_OK>), 256, 4, PIPE ? 8 : 0);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L); // 1024-sample chunks, one per wave pass
     const size_t need = (chunks + 3) / 4;
