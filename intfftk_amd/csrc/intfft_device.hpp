@@ -126,6 +126,7 @@ __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int3
 // trunc  : (A >> 1) +/- (B >> 1)   LSB dropped BEFORE the add (int_dif2_fly.vhd:151-154)
 // round  : rhu2(A +/- B) on the exact (DTW+1)-bit sum, wrapped to DTW bits (:173-218); written
 //          without the extra bit: rhu2(A+B) = (A>>1)+(B>>1)+((A|B)&1), rhu2(A-B) = (A>>1)-(B>>1)+(A&~B&1)
+//          (the dedicated kernels use the shorter forms (A|B) - T, (A&~B) - T with T = (A^B) >> 1: intfft_pk16.hpp)
 // unscaled: A +/- B, one bit of growth (:222-240)
 template <typename T>
 __device__ __forceinline__ void addsub(T a, T b, int rnd, int wo, T &s, T &d)

@@ -34,10 +34,14 @@ template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u
         const v2s A1 = PRE ? A : A >> (short)1, B1 = PRE ? B : B >> (short)1;
         s = as_u32(A1 + B1);
         d = as_u32(A1 - B1);
-    } else { // :167-219  rhu2(A+B) = (A|B) - ((A^B)>>1);  rhu2(A-B) = (A>>1) - (B>>1) + (A & ~B & 1)
-        s = as_u32((A | B) - ((A ^ B) >> (short)1));
-        const v2s one = {1, 1};
-        d = as_u32((A >> (short)1) - (B >> (short)1) + ((A & ~B) & one));
+    } else { // :167-219  rhu2(x) = floor((x + 1) / 2).  With T = (A ^ B) >> 1 (arithmetic):
+        //   A + B = 2 (A | B) - (A ^ B)               ->  rhu2(A + B) = (A | B) - T
+        //   A - B + 1 = A + ~B + 2, floor((A + ~B) / 2) = (A & ~B) + ((A ^ ~B) >> 1) = (A & ~B) - T - 1
+        //                                              ->  rhu2(A - B) = (A & ~B) - T
+        // exact over the integers, hence also modulo 2^16 (the RTL's 16-bit wrap); six operations for both results
+        const v2s T = (A ^ B) >> (short)1;
+        s = as_u32((A | B) - T);
+        d = as_u32((A & ~B) - T);
     }
 }
 // truncate mode with a per-lane shift amount (0 where the lane's registers already hold X >> 1)
