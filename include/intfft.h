@@ -26,7 +26,9 @@ extern "C" {
 #define INTFFT_OK               0
 #define INTFFT_ERR_INVALID     (-1) /* parameter out of range (e.g. log2n, orders, direction)         */
 #define INTFFT_ERR_UNSUPPORTED (-2) /* widths for which the RTL does not elaborate: find_delay -> 0,
-                                       int_dif2_fly.vhd:87-116; or results wider than 64 bits        */
+                                       int_dif2_fly.vhd:87-116; a trpl18 multiplier whose product slice
+                                       leaves P (MAW + MBW > 80 | 78, int_cmult_trpl18_dsp48.vhd:151-152);
+                                       2-D scheme plans with results wider than 64 bits              */
 #define INTFFT_ERR_NULL        (-3) /* NULL argument                                                  */
 #define INTFFT_ERR_NO_DEVICE   (-4) /* no HIP device / wrong device index -- there is NO CPU fallback */
 #define INTFFT_ERR_ALLOC       (-5) /* host allocation failed                                         */
@@ -76,7 +78,7 @@ typedef struct intfft_plan intfft_plan;
 /* What a plan resolved to; for benchmarks and tests. */
 typedef struct intfft_plan_info {
     int32_t in_bits, out_bits;           /* DATA_WIDTH, DATA_WIDTH + FORMAT*NFFT (x2 for PAIR)     */
-    int32_t in_container, out_container; /* bytes per real component: 2, 4 or 8                    */
+    int32_t in_container, out_container; /* bytes per real component: 2, 4, 8 (16 out: see below)  */
     int32_t n_passes;                    /* kernel launches per batch chunk                        */
     int32_t compute_word;                /* bytes of the on-chip word (2 = packed int16 kernels)   */
     int32_t fast_path;                   /* 1 if a single dedicated kernel serves this plan        */
@@ -88,7 +90,10 @@ typedef struct intfft_plan_info {
 /* Widths and containers implied by the generics.  Containers are the smallest of int16/32/64
  * that hold the width; frames are [batch][N] of interleaved (re, im), sign-extended.  Input
  * values outside data_width are wrapped on load like conv_std_logic_vector in
- * fft_signle_test.vhd:163-164. */
+ * fft_signle_test.vhd:163-164.  Results wider than 64 bits (bit growth into the trpl18 multiplier
+ * tail, int_cmult_dsp48.vhd:267-303: at most 74 bits) come in 16-byte containers: one little-endian
+ * two's-complement 128-bit integer per component (low 64-bit word first), 32 bytes per sample.
+ * Inputs never need them (data_width <= 64). */
 int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *in_container_bytes,
                      int *out_container_bytes);
 

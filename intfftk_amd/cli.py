@@ -43,6 +43,10 @@ def main(argv=None) -> int:
         core = int_fft_ifft_pair(a.nfft, a.data_width, a.twdl_width, fmt, rnd, a.xseries)
     dt = {2: np.int16, 4: np.int32, 8: np.int64}[core.in_container]
     y = core(torch.from_numpy(x.astype(dt)).cuda()).cpu().numpy()
+    if core.out_container == 16:  # results beyond 64 bits: Python integers (the text formats are width-agnostic)
+        from .engine import wide_to_int
+
+        y = wide_to_int(y)
     if a.flow == "single":
         textio.write_di_single(a.outfile, y)
     else:

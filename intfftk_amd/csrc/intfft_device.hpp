@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace intfft {
 
 // KIND_TWMUL / KIND_TWMULC: the inter-pass twiddle multiply of the N > 512K "2-D scheme" (DESIGN.md section 4.5):
@@ -31,11 +33,20 @@ struct StageDesc {
     int rnd;     // RoundKind
     int sh_a;    // multiplier: per-product pre-shift  (0 in the single-DSP regimes)
     int sh_b;    // multiplier: post-sum shift
-    int narrow;  // 64-bit words: mw + TWDL_WIDTH <= 64, every product of the multiplier fits one int64
+    int narrow;  // 1: 64-bit words with mw + TWDL_WIDTH <= 64, every product of the multiplier fits one int64;
+                 // 59 / 61: trpl18 regime with mw beyond the multiplier's A port: the data operand is cut to that many bits first
+                 // (SXT(M_AA, AWD), int_cmult_trpl18_dsp48.vhd:161-162); 0: neither
     unsigned tw_off; // offset of this stage's table in the twiddle buffer (int2 entries)
 };
 
 template <typename T> struct Cx { T re, im; };
+
+// on-chip words: int32_t / int64_t, and __int128 for plans whose results exceed 64 bits (the trpl18 / trpl52 tails of
+// int_cmult_dsp48.vhd:267-303, 396-433 with bit growth).  std::make_unsigned knows nothing of __int128 under -std=c++17.
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+template <typename T> struct UWord { using type = typename std::make_unsigned<T>::type; };
+template <> struct UWord<i128> { using type = u128; };
 
 // Ordering point for a WAVE-PRIVATE LDS tile: lanes of one wave exchange data through LDS (a ds_write, then a ds_read of
 // another lane's word).  A wave's DS instructions issue and complete in order on gfx950; this states the ordering in the
@@ -52,7 +63,7 @@ template <typename T> __device__ __forceinline__ T wrapw(T v, int w)
 {
     constexpr int B = sizeof(T) * 8;
     if (w >= B) return v;
-    using U = typename std::make_unsigned<T>::type;
+    using U = typename UWord<T>::type;
     return (T)((U)v << (B - w)) >> (B - w);
 }
 
@@ -60,7 +71,7 @@ template <typename T> __device__ __forceinline__ T wrapw(T v, int w)
 // int_dif2_fly.vhd:280-304, int_dit2_fly.vhd:251-276
 template <typename T> __device__ __forceinline__ T neg_quirk(T x, int w)
 {
-    using U = typename std::make_unsigned<T>::type;
+    using U = typename UWord<T>::type;
     return x >= 0 ? wrapw<T>((T)((U)0 - (U)x), w) : (T)~x;
 }
 
@@ -100,7 +111,11 @@ __device__ __forceinline__ uint64_t shr96(Prod96 p, int k)
 __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int32_t wi, int mw,
                                       int a, int b, int narrow, int64_t &ore, int64_t &oim)
 {
-    if (narrow) { // |d| <= 2^(mw-1), |w| <= 2^(t-1), mw + t <= 64: products and their sum are exact in int64
+    if (narrow > 1) { // trpl18 beyond its A port: the operand is cut to `narrow` bits
+        dre = wrapw<int64_t>(dre, narrow);
+        dim = wrapw<int64_t>(dim, narrow);
+    }
+    if (narrow == 1) { // |d| <= 2^(mw-1), |w| <= 2^(t-1), mw + t <= 64: products and their sum are exact in int64
         const int64_t m2r = dre * (int64_t)wr, m1r = dim * (int64_t)wi;
         const int64_t m2i = dre * (int64_t)wi, m1i = dim * (int64_t)wr;
         ore = wrapw<int64_t>(((m2r >> a) - (m1r >> a)) >> b, mw);
@@ -122,6 +137,20 @@ __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int3
     oim = wrapw<int64_t>((int64_t)i, mw);
 }
 
+// 128-bit words: |d| < 2^(mw-1) with mw <= 96, |w| < 2^27: every product and sum is exact in 128 bits
+__device__ __forceinline__ void cmult(i128 dre, i128 dim, int32_t wr, int32_t wi, int mw, int a, int b, int narrow,
+                                      i128 &ore, i128 &oim)
+{
+    if (narrow > 1) { // trpl18 beyond its A port (see StageDesc::narrow)
+        dre = wrapw<i128>(dre, narrow);
+        dim = wrapw<i128>(dim, narrow);
+    }
+    const i128 m2r = dre * (i128)wr, m1r = dim * (i128)wi;
+    const i128 m2i = dre * (i128)wi, m1i = dim * (i128)wr;
+    ore = wrapw<i128>(((m2r >> a) - (m1r >> a)) >> b, mw);
+    oim = wrapw<i128>(((m2i >> a) + (m1i >> a)) >> b, mw);
+}
+
 // ---- sum / difference with the three scaling variants --------------------------------------
 // trunc  : (A >> 1) +/- (B >> 1)   LSB dropped BEFORE the add (int_dif2_fly.vhd:151-154)
 // round  : rhu2(A +/- B) on the exact (DTW+1)-bit sum, wrapped to DTW bits (:173-218); written
@@ -131,7 +160,7 @@ __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int3
 template <typename T>
 __device__ __forceinline__ void addsub(T a, T b, int rnd, int wo, T &s, T &d)
 {
-    using U = typename std::make_unsigned<T>::type;
+    using U = typename UWord<T>::type;
     if (rnd == RND_TRUNC) {
         s = (a >> 1) + (b >> 1);
         d = (a >> 1) - (b >> 1);

@@ -23,6 +23,7 @@ template <typename T> __device__ __forceinline__ T load_user(const void *base, i
 {
     if (cb == 2) return (T) reinterpret_cast<const int16_t *>(base)[i];
     if (cb == 4) return (T) reinterpret_cast<const int32_t *>(base)[i];
+    if (cb == 16) return (T) reinterpret_cast<const i128 *>(base)[i];
     return (T) reinterpret_cast<const int64_t *>(base)[i];
 }
 
@@ -30,6 +31,7 @@ template <typename T> __device__ __forceinline__ void store_user(void *base, int
 {
     if (cb == 2) reinterpret_cast<int16_t *>(base)[i] = (int16_t)v;
     else if (cb == 4) reinterpret_cast<int32_t *>(base)[i] = (int32_t)v;
+    else if (cb == 16) reinterpret_cast<i128 *>(base)[i] = (i128)v; // little-endian two's complement, low word first
     else reinterpret_cast<int64_t *>(base)[i] = (int64_t)v;
 }
 
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
             c.re = load_user<T>(in, a.in_cb, 2 * m);
             c.im = load_user<T>(in, a.in_cb, 2 * m + 1);
             if (a.in_zext) {
-                using UT = typename std::make_unsigned<T>::type;
+                using UT = typename UWord<T>::type;
                 const UT mask = (a.in_bits >= (int)(8 * sizeof(T))) ? ~(UT)0 : (((UT)1 << a.in_bits) - 1);
                 c.re = (T)((UT)c.re & mask);
                 c.im = (T)((UT)c.im & mask);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
     // ---- stages: up to RMAX consecutive stages per LDS round trip, evaluated in registers ----------
     // Stages of one pass act on consecutive tile-local bits (descending for DIF, ascending for DIT), so a run
     // of R stages is a 2^R-point sub-transform per thread (round_generic<>), each stage with its own widths.
-    constexpr int RMAX = sizeof(T) == 4 ? 4 : 3;
+    constexpr int RMAX = sizeof(T) == 4 ? 4 : sizeof(T) == 8 ? 3 : 2;
     int si = 0;
     while (si < a.nstages) {
         const StageDesc st = a.st[si];
@@ -239,7 +241,7 @@ unsigned pass_threads(const PassArgs &a)
     const size_t elems = (size_t)a.fpb << a.U;
     static const int mode = getenv("INTFFT_PASS_THREADS") ? atoi(getenv("INTFFT_PASS_THREADS")) : 1;
     if (mode == 1) { // one thread per register round group: 16 points (int32 words) / 8 points (int64 words)
-        const size_t t = elems / (a.word == 4 ? 16 : 8);
+        const size_t t = elems / (a.word == 4 ? 16 : a.word == 8 ? 8 : 4);
         return (unsigned)(t < 256 ? 256 : t > 1024 ? 1024 : t);
     }
     return elems >= 8192 ? 1024u : elems >= 4096 ? 512u : (unsigned)PASS_THREADS;
@@ -253,7 +255,7 @@ size_t pass_lds_bytes(const PassArgs &a, int word_bytes)
 
 const char *pass_kernel_name(int word_bytes)
 {
-    return word_bytes == 4 ? "k_pass<int>" : "k_pass<long>";
+    return word_bytes == 4 ? "k_pass<int>" : word_bytes == 8 ? "k_pass<long>" : "k_pass<__int128>";
 }
 
 hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *out, const int2 *tw,
@@ -268,6 +270,9 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
         allow_max_lds(kptr(&k_pass<int32_t>));
         hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
                            out, tw, nframes, tw2d);
+    } else if (word_bytes == 16) {
+        allow_max_lds(kptr(&k_pass<i128>));
+        hipLaunchKernelGGL(k_pass<i128>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in, out, tw, nframes, tw2d);
     } else {
         allow_max_lds(kptr(&k_pass<int64_t>));
         hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,

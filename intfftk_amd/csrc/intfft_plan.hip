@@ -102,7 +102,7 @@ struct intfft_plan {
     int device = 0;
     int L = 0;
     int in_bits = 0, out_bits = 0, in_cb = 0, out_cb = 0;
-    int word = 4; // bytes of the on-chip word: 4 / 8 = k_pass<int32/int64>, 2 = packed int16 (k_pass16)
+    int word = 4; // bytes of the on-chip word: 4 / 8 / 16 = k_pass<int32 / int64 / __int128>, 2 = packed int16 (k_pass16)
     int l1 = 0;               // 2-D scheme (intfft_plan_create_2d): log2 N1 of the column core; 0 = ordinary 1-D plan
     // 2-D scheme, composite form (the default): layout change / column cores / layout change + multiply / row cores / layout
     // change, every core an ordinary 1-D sub-plan in natural order (so every dedicated kernel applies); see exec_2d()
@@ -167,17 +167,29 @@ struct DeviceGuard {
     }
 };
 
-int container_bytes(int bits) { return bits <= 16 ? 2 : bits <= 32 ? 4 : 8; }
+int container_bytes(int bits) { return bits <= 16 ? 2 : bits <= 32 ? 4 : bits <= 64 ? 8 : 16; }
 
 // (pre-shift a, post-shift b) of the multiplier regime for data width w / twiddle width t,
 // or false where the RTL has no generate branch (int_cmult_dsp48.vhd:182-434).
-bool cmult_shifts(int w, int t, int xser, int &a, int &b)
+// clip: trpl18 with MAW beyond the A port (AWD = 61 / 59 bits): the port is SXT(M_AA, AWD), which CUTS a longer operand to
+// its low AWD bits (int_cmult_trpl18_dsp48.vhd:161-162; the block is written for "data width from 42/44 to 59/61",
+// int_cmult_dsp48.vhd:266).  And its product slice P(MAW+MBW-2 downto MBW-1) (:151-152) must lie inside the PWD = 79 / 77
+// bits of P, or the slice does not elaborate: MAW + MBW <= PWD + 1.
+bool cmult_shifts(int w, int t, int xser, int &a, int &b, int *clip = nullptr)
 {
     const int l18 = xser ? 28 : 26, h18 = xser ? 45 : 43, t18 = xser ? 79 : 77, td = xser ? 28 : 26;
+    if (clip) *clip = 0;
     if (t < 19) {
         if (w < l18) { a = 0; b = t - 1; return true; }                         // sngl   :184-225
         if (w < h18) { a = xser ? t - 4 : t - 6; b = xser ? 3 : 5; return a >= 0; } // dbl18  :228-264
-        if (w < t18) { a = t - 1; b = 0; return true; }                         // trpl18 :267-303
+        if (w < t18) {                                                          // trpl18 :267-303
+            const int pwd = xser ? 79 : 77, awd = xser ? 61 : 59;
+            if (w + t > pwd + 1) return false;
+            a = t - 1;
+            b = 0;
+            if (clip && w > awd) *clip = awd;
+            return true;
+        }
         return false;
     }
     if (t < td) {
@@ -205,9 +217,10 @@ int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<Sta
         st.mw = inverse ? st.dtw : st.wo;
         st.rnd = p.format ? RND_UNSCALED : (p.rndmode ? RND_ROUND : RND_TRUNC);
         st.sh_a = st.sh_b = 0;
-        if (st.s >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b))
+        int clip = 0;
+        if (st.s >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b, &clip))
             return INTFFT_ERR_UNSUPPORTED;
-        st.narrow = (st.mw + p.twdl_width <= 64 && !getenv("INTFFT_NO_NARROW_MUL")) ? 1 : 0;
+        st.narrow = clip ? clip : (st.mw + p.twdl_width <= 64 && !getenv("INTFFT_NO_NARROW_MUL")) ? 1 : 0;
         st.tw_off = (1u << st.s) - 1u; // tables of stages 0..s-1 precede: sum 2^i = 2^s - 1
         out.push_back(st);
     }
@@ -230,8 +243,9 @@ int core_stages_2d(const intfft_params &p, int l1, int dw_in, bool inverse, std:
         st.wo = st.dtw + p.format;
         st.mw = inverse ? st.dtw : st.wo;
         st.rnd = p.format ? RND_UNSCALED : (p.rndmode ? RND_ROUND : RND_TRUNC);
-        if (ts >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b)) return INTFFT_ERR_UNSUPPORTED;
-        st.narrow = (st.mw + p.twdl_width <= 64) ? 1 : 0;
+        int clip = 0;
+        if (ts >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b, &clip)) return INTFFT_ERR_UNSUPPORTED;
+        st.narrow = clip ? clip : (st.mw + p.twdl_width <= 64) ? 1 : 0;
         st.tw_off = (1u << ts) - 1u;
         out.push_back(st);
         return INTFFT_OK;
@@ -244,8 +258,9 @@ int core_stages_2d(const intfft_params &p, int l1, int dw_in, bool inverse, std:
         st.tshift = l2;
         st.dtw = st.wo = st.mw = w;
         st.rnd = RND_UNSCALED;
-        if (!cmult_shifts(w, p.twdl_width, p.xser, st.sh_a, st.sh_b)) return INTFFT_ERR_UNSUPPORTED;
-        st.narrow = (w + p.twdl_width <= 64) ? 1 : 0;
+        int clip = 0;
+        if (!cmult_shifts(w, p.twdl_width, p.xser, st.sh_a, st.sh_b, &clip)) return INTFFT_ERR_UNSUPPORTED;
+        st.narrow = clip ? clip : (w + p.twdl_width <= 64) ? 1 : 0;
         out.push_back(st);
         return INTFFT_OK;
     };
@@ -280,7 +295,9 @@ int validate(const intfft_params &p, int l1 = 0)
     if (p.format == 1 && p.rndmode == 1) return INTFFT_ERR_UNSUPPORTED;
     const int growth = p.format ? p.log2n : 0;
     const int out_bits = p.data_width + (p.direction == INTFFT_PAIR ? 2 * growth : growth);
-    if (out_bits > 64) return INTFFT_ERR_UNSUPPORTED;
+    // results beyond 64 bits (the trpl18 / trpl52 tails with bit growth, int_cmult_dsp48.vhd:267-303, 396-433): 128-bit words
+    // and containers in the 1-D plans; the stage check below bounds the widths by what the multiplier elaborates (< 78 bits)
+    if (out_bits > (l1 ? 64 : 96)) return INTFFT_ERR_UNSUPPORTED;
     // elaboration check of every stage (find_delay != 0, int_dif2_fly.vhd:87-116) and of the twiddle width
     // (find_twd_25, int_cmult_dsp48.vhd:161-173): intfft_io_widths and intfft_plan_create agree on what elaborates
     if (p.twdl_width >= (p.xser ? 28 : 26)) return INTFFT_ERR_UNSUPPORTED;
@@ -373,11 +390,11 @@ int build_passes(intfft_plan &pl)
 {
     const intfft_params &p = pl.p;
     const int L = pl.L;
-    int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : 12; // 64 KiB tiles
+    int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : pl.word == 8 ? 12 : 11; // 64 KiB tiles
     // packed multi-pass plans: 16 KiB tiles (many workgroups per CU) beat 64 KiB ones (measured on C4)
     if (pl.word == 2 && L > umax) umax = 12;
     if (const char *e = getenv("INTFFT_TILE_LOG2")) umax = atoi(e) >= 8 && atoi(e) <= umax ? atoi(e) : umax; // diagnostics
-    const int cmin = pl.word == 2 ? 6 : pl.word == 4 ? 5 : 4;    // >= 256 B contiguous per strided row
+    const int cmin = pl.word == 2 ? 6 : pl.word == 4 ? 5 : pl.word == 8 ? 4 : 3; // >= 256 B contiguous per strided row
 
     std::vector<StageDesc> fwd, inv;
     int rc = INTFFT_OK;
@@ -577,7 +594,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->in_cb = container_bytes(pl->in_bits);
         pl->out_cb = container_bytes(pl->out_bits);
     }
-    pl->word = pl->out_bits <= 32 ? 4 : 8;
+    pl->word = pl->out_bits <= 32 ? 4 : pl->out_bits <= 64 ? 8 : 16;
     if (!l1 && pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
 
     if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK ||

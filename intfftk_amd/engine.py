@@ -22,7 +22,17 @@ import numpy as np
 from . import _capi as capi
 
 _MODES = {"UNSCALED": (1, 0), "TRUNCATE": (0, 0), "ROUNDING": (0, 1)}  # fft_signle_test.vhd:80-112
-_NP_DT = {2: np.int16, 4: np.int32, 8: np.int64}
+_NP_DT = {2: np.int16, 4: np.int32, 8: np.int64, 16: np.int64}  # 16: two int64 words per component (low, high)
+
+
+def wide_to_int(a) -> np.ndarray:
+    """[..., 2] int64 words (low, high) of 16-byte containers -> object array of Python ints (results beyond 64 bits:
+    include/intfft.h, "containers").  Little-endian two's complement: value = high * 2^64 + (low mod 2^64)."""
+    a = np.asarray(a)
+    if a.dtype != np.int64 or a.shape[-1] != 2:
+        raise ValueError("expected [..., 2] int64 words")
+    lo = a[..., 0].astype(object) & ((1 << 64) - 1)
+    return a[..., 1].astype(object) * (1 << 64) + lo
 
 
 def _torch():
@@ -33,7 +43,7 @@ def _torch():
 
 def _torch_dtype(nbytes: int):
     torch = _torch()
-    return {2: torch.int16, 4: torch.int32, 8: torch.int64}[nbytes]
+    return {2: torch.int16, 4: torch.int32, 8: torch.int64, 16: torch.int64}[nbytes]
 
 
 def set_mode(mode: str):
@@ -111,6 +121,11 @@ class IntFFTCore:
     def out_dtype(self):
         return _torch_dtype(self.out_container)
 
+    def out_shape(self, batch: int):
+        """[batch, N, 2], or [batch, N, 2, 2] int64 words (low, high) when the results need 16-byte containers
+        (wide_to_int() turns those into Python ints)."""
+        return (batch, self.n, 2) + ((2,) if self.out_container == 16 else ())
+
     def __call__(self, x, out=None):
         torch = _torch()
         if not (x.is_cuda and x.device.index == self.device):
@@ -122,8 +137,8 @@ class IntFFTCore:
         x = x.contiguous()
         batch = x.shape[0]
         if out is None:
-            out = torch.empty((batch, self.n, 2), dtype=self.out_dtype, device=x.device)
-        elif out.dtype != self.out_dtype or tuple(out.shape) != (batch, self.n, 2) or not out.is_contiguous():
+            out = torch.empty(self.out_shape(batch), dtype=self.out_dtype, device=x.device)
+        elif out.dtype != self.out_dtype or tuple(out.shape) != self.out_shape(batch) or not out.is_contiguous():
             raise ValueError("bad `out` tensor")
         stream = torch.cuda.current_stream(x.device).cuda_stream
         capi.check(capi.lib().intfft_exec(self._plan, x.data_ptr(), out.data_ptr(), batch, stream),
@@ -143,7 +158,7 @@ class IntFFTCore:
         x = np.ascontiguousarray(x)
         if x.ndim != 3 or x.shape[1] != self.n or x.shape[2] != 2:
             raise ValueError("input must be [batch, %d, 2]" % self.n)
-        out = np.empty((x.shape[0], self.n, 2), dtype=_NP_DT[self.out_container])
+        out = np.empty(self.out_shape(x.shape[0]), dtype=_NP_DT[self.out_container])
         capi.check(capi.lib().intfft_exec_host(self._plan, x.ctypes.data, out.ctypes.data, x.shape[0], chunk_frames),
                    "intfft_exec_host")
         return out
@@ -212,7 +227,7 @@ def exec_sharded(cores, x, root: int = 0):
         raise ValueError("every shard needs its own core (a plan owns its scratch)")
     if x.dtype != c0.in_dtype or x.dim() != 3 or x.shape[1] != c0.n or x.shape[2] != 2 or not x.is_contiguous():
         raise ValueError("input must be a contiguous [batch, %d, 2] %s tensor" % (c0.n, c0.in_dtype))
-    y = torch.empty((x.shape[0], c0.n, 2), dtype=c0.out_dtype, device=x.device)
+    y = torch.empty(c0.out_shape(x.shape[0]), dtype=c0.out_dtype, device=x.device)
     arr = (ctypes.c_void_p * len(cores))(*[c._plan for c in cores])
     torch.cuda.synchronize(x.device)
     capi.check(capi.lib().intfft_exec_sharded(arr, len(cores), root, x.data_ptr(), y.data_ptr(), x.shape[0]),

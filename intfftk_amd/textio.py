@@ -27,8 +27,14 @@ def read_di_single(path: str, n: int | None = None) -> np.ndarray:
     return a.reshape(-1, n, 2)
 
 
+def _ints(a) -> np.ndarray:
+    """int64, or an object array of Python ints left as it is (results beyond 64 bits: engine.wide_to_int)."""
+    a = np.asarray(a)
+    return a if a.dtype == object else a.astype(np.int64)
+
+
 def write_di_single(path: str, frames: np.ndarray) -> None:
-    np.savetxt(path, np.asarray(frames, dtype=np.int64).reshape(-1, 2), fmt="%d")
+    np.savetxt(path, _ints(frames).reshape(-1, 2), fmt="%d")
 
 
 def read_di_double(path: str, n: int) -> np.ndarray:
@@ -45,21 +51,23 @@ def read_di_double(path: str, n: int) -> np.ndarray:
 
 
 def write_di_double(path: str, frames: np.ndarray) -> None:
-    x = np.asarray(frames, dtype=np.int64).reshape(-1, 2, 2)  # [beat, lane, (re, im)]
+    x = _ints(frames).reshape(-1, 2, 2)  # [beat, lane, (re, im)]
     np.savetxt(path, np.stack([x[:, 0, 0], x[:, 1, 0], x[:, 0, 1], x[:, 1, 1]], axis=-1), fmt="%d")
 
 
 def top_bits(v: np.ndarray, width: int, keep: int = 17) -> np.ndarray:
     """q(width-1 downto width-keep) read as a signed integer (fft_double_test.vhd:208-214)."""
-    v = np.asarray(v, dtype=np.int64)
-    return v >> (width - keep) if width > keep else v
+    v = _ints(v)
+    if width <= keep:
+        return v
+    return (v >> (width - keep)).astype(np.int64)  # 17 bits: fits whatever the width was
 
 
 def dout_pair_lines(frames: np.ndarray, width: int, reference_wiring: bool = False) -> np.ndarray:
     """[beats, 4] = Q0_RE Q1_RE Q0_IM Q1_IM (top 17 bits) of natural-order pair outputs.
     reference_wiring=True reproduces the slice mix-up of int_fft_ifft_pair.vhd:332-335 (Q0_IM carries the
     REAL part of lane 0, Q1_RE the IMAGINARY part of lane 1) for comparison with a dump of the unfixed RTL."""
-    x = np.asarray(frames, dtype=np.int64).reshape(-1, 2, 2)  # [beat, lane, (re, im)]
+    x = _ints(frames).reshape(-1, 2, 2)  # [beat, lane, (re, im)]
     q0_re, q0_im, q1_re, q1_im = x[:, 0, 0], x[:, 0, 1], x[:, 1, 0], x[:, 1, 1]
     if reference_wiring:
         q0_im, q1_re = q0_re, q1_im

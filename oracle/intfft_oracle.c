@@ -59,8 +59,9 @@ int orc_cmult_regime(int w, int t, int xser)
         if (w < L) return ORC_SNGL;               /* :184 */
         if (w < H)                                /* :228; the product slice starts at bit t-4 (NEW) / t-6 (OLD): */
             return (xser ? t - 4 : t - 6) >= 0 ? ORC_DBL18 : ORC_UNSUPPORTED; /* a negative index does not elaborate */
-        if (w < T) return ORC_TRPL18;             /* :267 */
-        return ORC_UNSUPPORTED;
+        if (w < T)                                /* :267; the product slice P(MAW+MBW-2 downto MBW-1) of               */
+            return w + t <= T + 1 ? ORC_TRPL18 : ORC_UNSUPPORTED; /* int_cmult_trpl18_dsp48.vhd:151-152 must lie inside the */
+        return ORC_UNSUPPORTED;                   /* PWD = 79 / 77 bits of P, or the slice does not elaborate            */
     }
     if (t < TD) {                  /* xGEN_TWD25 :307 */
         if (w < 19) return ORC_SNGL25;            /* :309 */
@@ -126,6 +127,10 @@ int orc_cmult(int64_t d_re, int64_t d_im, int64_t wr, int64_t wi, int w, int t, 
         *o_re = orc_wrap((d_re * wr - d_im * wi) >> sh, w);
         *o_im = orc_wrap((d_re * wi + d_im * wr) >> sh, w);
         return 0;
+    }
+    if (regime == ORC_TRPL18 && w > (xser ? 61 : 59)) { /* the A port is SXT(M_AA, AWD), AWD = 61 / 59: a longer operand is CUT */
+        d_re = orc_wrap(d_re, xser ? 61 : 59);           /* to its low AWD bits (int_cmult_trpl18_dsp48.vhd:161-162; the block is  */
+        d_im = orc_wrap(d_im, xser ? 61 : 59);           /* written for "data width from 42/44 to 59/61", int_cmult_dsp48.vhd:266)  */
     }
     *o_re = combine((i128)d_re * wr, (i128)d_im * wi, -1, regime, w, t, xser);
     *o_im = combine((i128)d_re * wi, (i128)d_im * wr, +1, regime, w, t, xser);

@@ -47,7 +47,9 @@ def cmult_regime(w: int, t: int, new: bool) -> str | None:
             # product slice P(pwd-1-(18-t) downto pwd-48-(18-t)): its low index t-4 (NEW) / t-6 (OLD) must exist
             return "dbl18" if (t - 4 if new else t - 6) >= 0 else None
         if h18 - 1 < w < t18:
-            return "trpl18"
+            # the product slice P(MAW+MBW-2 downto MBW-1) (int_cmult_trpl18_dsp48.vhd:151-152) must lie inside the PWD = 79 / 77
+            # bits of P, or it does not elaborate
+            return "trpl18" if w + t <= t18 + 1 else None
         return None
     if 18 < t < twd:
         if w < 19:
@@ -100,6 +102,10 @@ def cmult(d_re: int, d_im: int, wr: int, wi: int, w: int, t: int, new: bool = Tr
     regime = cmult_regime(w, t, new)
     if regime is None:
         raise ValueError("unsupported widths w=%d t=%d" % (w, t))
+    if regime == "trpl18":  # dspA <= SXT(M_AA, AWD), AWD = 61 / 59 (int_cmult_trpl18_dsp48.vhd:161-162): a longer operand is cut
+        awd = 61 if new else 59
+        if w > awd:
+            d_re, d_im = sgn(d_re, awd), sgn(d_im, awd)
     re = _half(d_re * wr, d_im * wi, True, regime, w, t, new)
     im = _half(d_re * wi, d_im * wr, False, regime, w, t, new)
     return re, im

@@ -52,6 +52,8 @@ def _p(**kw):
     (dict(format=1, direction=2), (16, 36), (2, 8)),
     (dict(log2n=16, data_width=24, twdl_width=24, format=1), (24, 40), (4, 8)),
     (dict(log2n=20), (16, 16), (2, 2)),
+    (dict(log2n=10, data_width=60, twdl_width=12, format=1), (60, 70), (8, 16)),  # results beyond 64 bits: 16-byte containers
+    (dict(log2n=17, data_width=32, twdl_width=15, format=1, direction=2), (32, 66), (4, 16)),  # (the trpl18 tail, int_cmult_dsp48.vhd:267-303)
 ])
 def test_io_widths(kw, bits, cont):
     a, b, c, d = (ctypes.c_int() for _ in range(4))
@@ -69,7 +71,9 @@ def test_io_widths(kw, bits, cont):
     (dict(twdl_width=28), capi.ERR_UNSUPPORTED),                # find_delay -> 0
     (dict(twdl_width=26, xser=0), capi.ERR_UNSUPPORTED),
     (dict(data_width=60, twdl_width=24), capi.ERR_UNSUPPORTED),  # no cmult regime for w >= 53 at t > 18
-    (dict(log2n=19, data_width=32, format=1, direction=2), capi.ERR_UNSUPPORTED),  # > 64-bit results
+    (dict(log2n=10, data_width=57, format=1), capi.ERR_UNSUPPORTED),  # a 65 x 16 multiplier: its product slice leaves the 79 bits of P (int_cmult_trpl18_dsp48.vhd:151-152)
+    (dict(log2n=17, data_width=32, format=1, direction=2), capi.ERR_UNSUPPORTED),  # the pair's last DIT multiplier: 65 x 16
+    (dict(log2n=20, data_width=64, format=1, direction=2), capi.ERR_UNSUPPORTED),  # 104-bit results
 ])
 def test_plan_create_rejects_like_elaboration(kw, code):
     plan = ctypes.c_void_p()

@@ -189,3 +189,29 @@ def test_i16_entry_matches_i64_entry():
     a = C.execute(x, p)
     b = C.execute_i16(x.astype(np.int16), p)
     assert np.array_equal(a, b.astype(np.int64))
+
+
+def test_trpl18_a_port_and_product_slice():
+    """int_cmult_trpl18_dsp48: the A port is SXT(M_AA, 61 | 59) -- an operand beyond that is CUT to its low bits (:161-162) -- and
+    the product slice P(MAW+MBW-2 downto MBW-1) must lie inside the 79 | 77 bits of P (:151-152), i.e. MAW + MBW <= 80 | 78.
+    Both restatements agree on the bound and on the cut (full-range operands differ from the uncut product)."""
+    assert C.cmult_regime(64, 16, True) == P.cmult_regime(64, 16, True) == "trpl18"
+    assert C.cmult_regime(65, 16, True) is None and P.cmult_regime(65, 16, True) is None
+    assert C.cmult_regime(62, 16, False) == P.cmult_regime(62, 16, False) == "trpl18"
+    assert C.cmult_regime(63, 16, False) is None and P.cmult_regime(63, 16, False) is None
+    assert C.cmult_regime(72, 8, True) == P.cmult_regime(72, 8, True) == "trpl18"
+    rng = np.random.default_rng(61)
+    differs = 0
+    for new, w, t in ((True, 64, 16), (True, 62, 18), (False, 62, 16), (False, 60, 18), (True, 61, 16), (False, 59, 17)):
+        awd = 61 if new else 59
+        for _ in range(200):
+            d = [int(v) for v in rng.integers(-(1 << (w - 1)), (1 << (w - 1)) - 1, size=2, endpoint=True)]
+            ww = [int(v) for v in rng.integers(-(1 << (t - 1)) + 1, (1 << (t - 1)) - 1, size=2, endpoint=True)]
+            got = C.cmult(d[0], d[1], ww[0], ww[1], w, t, new)
+            assert got == P.cmult(d[0], d[1], ww[0], ww[1], w, t, new)
+            exact = (P.sgn((d[0] * ww[0] >> (t - 1)) - (d[1] * ww[1] >> (t - 1)), w), P.sgn((d[0] * ww[1] >> (t - 1)) + (d[1] * ww[0] >> (t - 1)), w))
+            if w <= awd:
+                assert got == exact  # inside the port: the plain truncated product
+            else:
+                differs += got != exact
+    assert differs > 100
