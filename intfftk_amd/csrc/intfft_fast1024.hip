@@ -69,7 +69,7 @@ template <bool ROUND> struct Twiddles {
 constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B aligned, conflict-free)
 
 // ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
-template <int L, bool ROUND, bool OUT_BITREV, bool FASTX>
+template <int L, bool ROUND, bool OUT_BITREV, int FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
                                                 const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
         const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
         if (FAST_OK && frame_has_guard_bit(v))
             transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-        else
-            transform_store<L, ROUND, OUT_BITREV, false>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+        else // a FAST_OK kernel is launched for 16-bit twiddles only: its exact path is the t = 16 form (mul2x_t16)
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0

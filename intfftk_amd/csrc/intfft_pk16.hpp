@@ -85,6 +85,40 @@ __device__ __forceinline__ void mul2x(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr
               [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
 }
 
+// exact extraction of Y >> 1 for t = 16 without v_bfe: Y >> 1 = sext(sum[30:16]) is the high half of the sum with its bit 15
+// (= sum[31], which differs from sum[30] exactly when the fast path's precondition fails) replaced by bit 14.  One v_perm_b32
+// takes both high halves, then P' = (P & 0x7FFF7FFF) | ((P << 1) & 0x80008000): a VOP2 shift and one v_bfi_b32 for the two
+// components together -- 2 dot + 1 perm + 1 bfi + 1 shift per butterfly instead of 2 dot + 2 bfe + 1 perm.
+#define INTFFT_MUL2X_T16_BODY                                                                          \
+    "v_dot2_i32_i16 %[r0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[r1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_perm_b32 %[y0], %[i0], %[r0], %[selh]\n\t"                                                      \
+    "v_lshlrev_b32 %[r0], 1, %[y0]\n\t"                                                                \
+    "v_perm_b32 %[y1], %[i1], %[r1], %[selh]\n\t"                                                      \
+    "v_lshlrev_b32 %[r1], 1, %[y1]\n\t"                                                                \
+    "v_bfi_b32 %[y0], %[msk], %[r0], %[y0]\n\t"                                                        \
+    "v_bfi_b32 %[y1], %[msk], %[r1], %[y1]"
+
+template <bool SG>
+__device__ __forceinline__ void mul2x_t16(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr1, u32 di1, u32 wa1, u32 wb1, u32 selh, u32 &y0,
+                                          u32 &y1)
+{
+    u32 r0, i0, r1, i1;
+    const u32 msk = 0x80008000u;
+    if (SG)
+        asm(INTFFT_MUL2X_T16_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "s"(wa0), [wb0] "s"(wb0), [dr1] "v"(dr1), [di1] "v"(di1), [wa1] "s"(wa1),
+              [wb1] "s"(wb1), [selh] "s"(selh), [msk] "s"(msk));
+    else
+        asm(INTFFT_MUL2X_T16_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1), [wa1] "v"(wa1),
+              [wb1] "v"(wb1), [selh] "s"(selh), [msk] "s"(msk));
+}
+
 #define INTFFT_MUL4F_BODY                                                                              \
     "v_dot2_i32_i16 %[y0], %[dr0], %[wa0], 0\n\t"                                                      \
     "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
@@ -122,16 +156,17 @@ __device__ __forceinline__ void mul4f(const u32 (&dr)[4], const u32 (&di)[4], co
 }
 
 // ---- a group of four general butterflies (a_i, b_i): a_i <- S, b_i <- cmult(D, W_i) ---------------
-//   FASTX   fast extraction (implies truncate mode and pre-shifted outputs)
+//   FASTX   1: fast extraction (implies truncate mode and pre-shifted outputs); 2: exact extraction specialised for t = 16
+//           (mul2x_t16; kernels launched only for 16-bit twiddles use it on the frames that fail the guard test); 0: exact
 //   QTURN   the twiddles are the quarter turns of the given base twiddles
 //   OUT_PRE emit Y >> 1 (truncate mode)
 //   SG      twiddles in SGPRs
 //   PREMASK bit i: inputs of butterfly i already hold X >> 1;  VARSH: per-lane shift amount instead
-template <bool ROUND, bool FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false>
+template <bool ROUND, int FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false>
 __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
                                        const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl, v2s shv = v2s{0, 0})
 {
-    static_assert(!FASTX || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
+    static_assert(FASTX == 0 || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
     static_assert(!QTURN || !ROUND, "quarter-turn sharing needs an exact -D");
     u32 d[4];
     if (VARSH) {
@@ -150,8 +185,11 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
         const v2s z = {0, 0};
         const u32 n[4] = {as_u32(z - as_v2s(d[0])), as_u32(z - as_v2s(d[1])), as_u32(z - as_v2s(d[2])),
                           as_u32(z - as_v2s(d[3]))};
-        if (FASTX) {
+        if (FASTX == 1) {
             mul4f<SG>(d, n, wb, wa, sl.sel_hi, y);
+        } else if (FASTX == 2) {
+            mul2x_t16<SG>(d[0], n[0], wb[0], wa[0], d[1], n[1], wb[1], wa[1], sl.sel_hi, y[0], y[1]);
+            mul2x_t16<SG>(d[2], n[2], wb[2], wa[2], d[3], n[3], wb[3], wa[3], sl.sel_hi, y[2], y[3]);
         } else {
             mul2x<OUT_PRE ? 15 : 16, SG>(d[0], n[0], wb[0], wa[0], d[1], n[1], wb[1], wa[1],
                                          OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
@@ -159,8 +197,11 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
                                          OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
         }
     } else {
-        if (FASTX) {
+        if (FASTX == 1) {
             mul4f<SG>(d, d, wa, wb, sl.sel_hi, y);
+        } else if (FASTX == 2) {
+            mul2x_t16<SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.sel_hi, y[0], y[1]);
+            mul2x_t16<SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.sel_hi, y[2], y[3]);
         } else {
             mul2x<OUT_PRE ? 15 : 16, SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1],
                                          OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
