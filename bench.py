@@ -329,6 +329,10 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    import gc
+
+    gc.collect()
+    gc.disable()  # no collector pause inside the K timed steps (a 50-step region is only ~5 ms long)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -338,6 +342,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         dist.barrier()
     t_all = max_over_ranks(t_local, red_dev)

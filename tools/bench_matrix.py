@@ -41,7 +41,7 @@ ROWS.append(("14:16:16:1:0:INV", "16-bit unscaled INV"))
 ROWS.append(("16:16:16:1:0:INV", "16-bit unscaled INV"))
 ROWS.append(("16:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("10:56:16:1", "56-bit unscaled FWD (66-bit results, 16-byte containers)"))
-ROWS.append(("10:60:12:1:0:INV", "60-bit unscaled INV, 12-bit twiddles (70-bit results)"))
+ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit results)"))
 
 NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (native int_fftNk beats)"),
           ("12:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
