@@ -147,6 +147,28 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
             w_bc[PLANE4W + ROW4W * lcw_row_of_reg<L>(j)] = (u32)im[j];
         }
         transpose_read(re, im);
+        if (MODE == W_UNSCALED && a.out64 == 2) { // 35 / 36-bit results: the whole round LC in 64 bits (gfly64, intfft_u32.hpp)
+            long long xr[16], xi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[r] = re[r], xi[r] = im[r];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gfly64<MASKED>(xr[r], xi[r], xr[r + 8], xi[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gfly64<MASKED>(xr[g + r], xi[g + r], xr[g + r + 4], xi[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
+            tail64_stages10(xr, xi);
+            if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+                typedef long long v2l __attribute__((ext_vector_type(2)));
+                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const v2l y = {xr[r], xi[r]};
+                    __builtin_nontemporal_store(y, dst + (rev4q(r) << (L - 4)));
+                }
+            }
+            continue;
+        }
         // LC: stages 3, 2 (uniform twiddles), 1, 0
 #pragma unroll
         for (int r = 0; r < 8; ++r) gfly<MODE, true, MASKED>(re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r], a.st[3]);
@@ -198,8 +220,9 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
 bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                          int out_order)
 {
-    const int out_bits = data_width + format * log2n; // unscaled: 33 / 34-bit results through the 64-bit tail stages
-    const bool fits = out_bits <= 32 || (format == 1 && out_bits <= 34);
+    const int out_bits = data_width + format * log2n; // unscaled: 33 / 34-bit results through the 64-bit tail stages,
+    // up to 40 bits with the whole last round in 64 bits as long as STAGE 4 still fits 32 (e.g. 24-bit data: 35 / 36-bit results)
+    const bool fits = out_bits <= 32 || (format == 1 && out_bits <= 34) || (format == 1 && data_width + log2n - 4 <= 32 && out_bits <= 40);
     return (log2n == 11 || log2n == 12) && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 &&
            use_fly == 1 && in_order == 0 && out_order == 0;
 }

@@ -160,7 +160,8 @@ struct W32Args {
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
     int inverse;     // stage records describe int_ifftNk (DIT)
-    int out64;       // unscaled results of 33 / 34 bits: stages 1, 0 in 64 bits, int64 containers
+    int out64;       // 1: unscaled results of 33 / 34 bits: stages 1, 0 in 64 bits, int64 containers;
+                     // 2 (N = 2048 / 4096): results of 35 / 36 bits: the whole last register round (STAGE 3..0) in 64 bits
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
     int two_pass;    // N = 2^13 .. 2^16 forward: k_bigw_a + k_bigw_b instead of the three passes
 };
@@ -197,11 +198,12 @@ struct WideStage {
     int w32;           // 64-bit stages: wo - 32
 };
 struct WideArgs {
-    WideStage st[16];  // processing order: st[ii] is STAGE 15 - ii
+    WideStage st[16];  // processing order: st[ii] is STAGE NFFT - 1 - ii
+    int dw;            // DATA_WIDTH (wrap on load)
 };
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order);
-hipError_t launch_wide16(const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
                          const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *wide16_kernel_name();
 

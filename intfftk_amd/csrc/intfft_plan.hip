@@ -700,10 +700,18 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         for (size_t i = 0; i < st.size() && (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw); ++i) {
             const StageDesc &d = st[i];
             // stages 1 and 0 may exceed 32 bits (by the 33rd / 34th bit) in unscaled forward plans: 64-bit tail
-            const bool tail = d.s <= 1 && p->format == 1 && p->direction == INTFFT_FWD && d.dtw <= 33 && d.wo <= 34;
-            if (tail && d.wo > 32) pl->w32args.out64 = 1;
+            bool tail = d.s <= 1 && p->format == 1 && p->direction == INTFFT_FWD && d.dtw <= 33 && d.wo <= 34;
+            if (tail && d.wo > 32 && !pl->w32args.out64) pl->w32args.out64 = 1;
+            // N = 2048 / 4096 block kernel: the whole last register round (STAGE 3..0) may run in 64 bits (out64 = 2) as long as
+            // STAGE 4 still fits 32: 35 / 36-bit results (24-bit unscaled data at these lengths)
+            const bool tail4 = pl->fast4096w && d.s <= 3 && p->format == 1 && p->direction == INTFFT_FWD &&
+                               p->data_width + p->log2n - 4 <= 32 && d.wo <= 40 && d.mw + p->twdl_width <= 63;
+            if (tail4 && !tail && (d.wo > 32 || d.dtw > 32)) {
+                pl->w32args.out64 = 2;
+                tail = true;
+            }
             if (d.s < 0 || d.s > 15 || (!tail && (d.dtw > 32 || d.wo > 32 || d.mw > 32)) || d.sh_a + d.sh_b > 31 ||
-                d.mw + p->twdl_width > 62) {
+                d.mw + p->twdl_width > (tail ? 63 : 62)) {
                 pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
                 break;
             }
@@ -716,6 +724,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->w32args.in_sh = 32 - p->data_width;
         if (pl->in_cb > 4 || (pl->out_cb > 4) != (pl->w32args.out64 != 0)) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
         if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
+        if (pl->w32args.out64 == 2) pl->fastw32 = false;        // the 64-bit last round: the block kernel only
         pl->w32args.two_pass = pl->bigw && !getenv("INTFFT_NO_TWOPASS");
     }
     if (pl->fastsmall) {
@@ -763,8 +772,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
         if (pl->wide16) {
             std::vector<StageDesc> st;
-            if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || st.size() != 16) pl->wide16 = false;
-            for (int ii = 0; ii < 16 && pl->wide16; ++ii) {
+            const int LL = p->log2n; // 13 .. 16: STAGE LL-1 .. 8 in pass 1 (int32), 7 .. 0 in pass 2 (64-bit)
+            if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
+            pl->wargs.dw = p->data_width;
+            for (int ii = 0; ii < LL && pl->wide16; ++ii) {
                 const StageDesc &d = st[ii];
                 WideStage &w = pl->wargs.st[ii];
                 w.sh = d.sh_a + d.sh_b;
@@ -773,9 +784,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 w.s2 = w.sh + d.wo - 32;
                 w.s3 = 32 - d.wo;
                 w.w32 = d.wo - 32;
-                if (d.s != 15 - ii || d.mw + p->twdl_width > 64) pl->wide16 = false;
-                if (d.s >= 2 && ii < 8 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
-                if (d.s >= 2 && ii >= 8 && (w.w32 < 1 || w.sh + w.w32 > 32)) pl->wide16 = false;
+                if (d.s != LL - 1 - ii || d.mw + p->twdl_width > 64) pl->wide16 = false;
+                if (d.s >= 8 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
+                // pass 2: widths beyond 32 use v_alignbit + v_bfe (slice inside one dword pair), the others the general form
+                if (d.s >= 2 && d.s < 8 && w.w32 >= 1 && w.sh + w.w32 > 32) pl->wide16 = false;
+                if (d.s < 8 && (d.wo > 40 || w.sh + d.wo > 64)) pl->wide16 = false;
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
@@ -1003,7 +1016,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             continue;
         }
         if (plan->wide16) {
-            const hipError_t e = launch_wide16(plan->wargs, src, dst, plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf,
+            const hipError_t e = launch_wide16(plan->p.log2n, plan->wargs, src, dst, plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf,
                                                stream);
             if (e != hipSuccess) return (int)e;
             continue;

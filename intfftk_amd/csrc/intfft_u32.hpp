@@ -304,10 +304,15 @@ __device__ __forceinline__ void gfly_dit_triv(int &are, int &aim, int &bre, int 
 // When DATA_WIDTH + NFFT exceeds 32 by at most 2, every multiplier stage (STAGE >= 2) still works within 32 bits; only
 // the two multiplier-free stages 1 and 0 produce the 33rd and 34th bit.  They run on sign-extended 64-bit registers
 // (exact sums, no wrap needed: int_dif2_fly.vhd:222-318) and the results are stored in int64 containers.
+__device__ __forceinline__ void tail64_stages10(long long (&xr)[16], long long (&xi)[16]);
 __device__ __forceinline__ void tail64_unscaled(const int (&re)[16], const int (&im)[16], long long (&xr)[16], long long (&xi)[16])
 {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xr[r] = re[r], xi[r] = im[r];
+    tail64_stages10(xr, xi);
+}
+__device__ __forceinline__ void tail64_stages10(long long (&xr)[16], long long (&xi)[16])
+{
 #pragma unroll
     for (int g = 0; g < 16; g += 4) { // STAGE 1: even positions Y = D; odd positions Y.re = D.im, Y.im = D.re >= 0 ? -D.re : ~D.re
         long long dr = xr[g] - xr[g + 2], di = xi[g] - xi[g + 2];
@@ -323,6 +328,36 @@ __device__ __forceinline__ void tail64_unscaled(const int (&re)[16], const int (
         xr[g] += xr[g + 1], xi[g] += xi[g + 1];
         xr[g + 1] = dr, xi[g + 1] = di;
     }
+}
+
+// ---- unscaled results of 35 / 36 bits (intfft_fast4096w.hip: W32Args::out64 = 2) -----------------------------------------------
+// DATA_WIDTH + NFFT - 4 <= 32: every stage down to STAGE 4 still fits 32-bit registers; the whole last register round
+// (STAGE 3, 2 with wave-uniform twiddles, then 1, 0) runs on 64-bit registers.  A general butterfly of that round: exact
+// 64-bit products d * w = mad_i64_i32(dL, w) + (mul_lo(dH, w) << 32) (|d| < 2^39, |w| < 2^23: width + TWDL_WIDTH <= 63),
+// the regime's truncation points as in gfly (masked form for a > 0), the wo-bit slice of the sum by two 64-bit shifts.
+__device__ __forceinline__ unsigned long long mul64x32(int dl, int dh, int w)
+{
+    return (unsigned long long)((long long)dl * w) + ((unsigned long long)((u32)dh * (u32)w) << 32);
+}
+template <bool MASKED>
+__device__ __forceinline__ void gfly64(long long &are, long long &aim, long long &bre, long long &bim, int wr, int wi, const W32Stage &s)
+{
+    asm volatile("" : "+s"(wr), "+s"(wi)); // wave-uniform twiddles: see intfft_fast1024u.hip
+    const long long dre = are - bre, dim = aim - bim; // unscaled: exact (int_dif2_fly.vhd:222-240)
+    are += bre;
+    aim += bim;
+    const int rl = (int)dre, rh = (int)(dre >> 32) - (rl >> 31);
+    const int il = (int)dim, ih = (int)(dim >> 32) - (il >> 31);
+    unsigned long long m2r = mul64x32(rl, rh, wr), m1r = mul64x32(il, ih, wi);
+    unsigned long long m2i = mul64x32(rl, rh, wi), m1i = mul64x32(il, ih, wr);
+    if (MASKED) {
+        const unsigned long long k = 0xFFFFFFFF00000000ull | s.keep;
+        m2r &= k, m1r &= k, m2i &= k, m1i &= k;
+    }
+    const unsigned long long xr = m2r - m1r, xi = m2i + m1i;
+    const int wo = 32 - s.wsh; // the multiplier's width (33 .. 38 here)
+    bre = (long long)(xr << (64 - s.sh - wo)) >> (64 - wo);
+    bim = (long long)(xi << (64 - s.sh - wo)) >> (64 - wo);
 }
 
 } // namespace intfft

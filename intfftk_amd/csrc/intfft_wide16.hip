@@ -12,6 +12,13 @@
 // each store instruction writes 256-byte runs of the natural-order output brev16(n)).  The scratch layout
 // [r0][j][c] makes the 4096 samples of a pass-2 workgroup contiguous.
 //
+// N = 2^13 .. 2^15 (template L; round 2): the same two kernels on VIRTUAL 2^16-point frames of G = 2^(16-L) consecutive real
+// frames.  The top 16 - L bits of r are then frame-number bits g: their stages (STAGE >= L) are skipped, the twiddle index
+// of every other stage (position mod 2^s) is unchanged.  A pass-2 unit is (g, low) with r = g 2^(L-8) + t4 2^(L-12) + low:
+// its 16 rows t4 = 0..15 are the rows of ONE real frame whose bit-reversed indices are adjacent, scratch layout
+// [g, low][t4][c].  Pass-2 stages whose width is still <= 32 (24 + L - 7 .. at the short lengths) take the general form
+// of the result slice (two 64-bit shifts instead of v_alignbit + v_bfe).  DATA_WIDTH is a kernel argument.
+//
 // Each pass = two in-register rounds of four stages (registers carry 4 index bits) with one block-wide LDS
 // transpose between them, like intfft_fast4096.hip; arithmetic on unpacked registers like
 // intfft_fast1024u.hip.  All twiddles that depend on the thread are frame invariant and live in VGPRs
@@ -85,9 +92,14 @@ __device__ __forceinline__ void wstage32(int (&re)[16], int (&im)[16], const int
     wstage32x<H, false>(re, im, wr, wi, s); // the masked form covers a = 0 too (keep = ~0)
 }
 
+template <int L>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
-                                                   const WideArgs a, size_t nframes)
+                                                   const WideArgs a, size_t nframes_user)
 {
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int G = 1 << (16 - L);                     // real frames per virtual frame
+    const size_t nframes = (nframes_user + G - 1) / G;   // virtual frames
+    constexpr int X = L - 16;                            // a.st[] is indexed by L - 1 - STAGE: STAGE 15 - k is entry X + k
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
     const int tile = blockIdx.x & 15;
@@ -100,20 +112,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int w11r[8], w11i[8], w10r[4], w10i[4], w9r[2], w9i[2], w8r[1], w8i[1];
     {
         const int base = c + 256 * hi4;
+        // (the index of STAGE s is n mod 2^s: frame-number bits of r above bit s - 8 do not enter; stages >= L have no table)
+        if constexpr (L > 15) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int2 w = twt[32767 + base + 4096 * j];
-            w15r[j] = w.x, w15i[j] = w.y;
+            for (int j = 0; j < 8; ++j) {
+                const int2 w = twt[32767 + base + 4096 * j];
+                w15r[j] = w.x, w15i[j] = w.y;
+            }
         }
+        if constexpr (L > 14) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int2 w = twt[16383 + base + 4096 * j];
-            w14r[j] = w.x, w14i[j] = w.y;
+            for (int j = 0; j < 4; ++j) {
+                const int2 w = twt[16383 + ((base + 4096 * j) & 16383)];
+                w14r[j] = w.x, w14i[j] = w.y;
+            }
         }
+        if constexpr (L > 13) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int2 w = twt[8191 + base + 4096 * j];
-            w13r[j] = w.x, w13i[j] = w.y;
+            for (int j = 0; j < 2; ++j) {
+                const int2 w = twt[8191 + ((base + 4096 * j) & 8191)];
+                w13r[j] = w.x, w13i[j] = w.y;
+            }
         }
         int2 w = twt[4095 + base];
         w12r[0] = w.x, w12i[0] = w.y;
@@ -145,17 +164,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (size_t f = blockIdx.x >> 4; f < nframes; f += fstep) {
         int re[16], im[16];
         const int2 *src = in + f * 65536 + c + 256 * hi4;
+        const bool partial = L < 16 && (f + 1) * G > nframes_user; // last group: rows of absent frames read as 0, are not stored
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        if (!partial) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            typedef int v2i __attribute__((ext_vector_type(2)));
-            const v2i x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(src + 4096 * j));
-            re[j] = __builtin_amdgcn_sbfe(x.x, 0, 24); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
-            im[j] = __builtin_amdgcn_sbfe(x.y, 0, 24);
+            for (int j = 0; j < 16; ++j) {
+                const v2i x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(src + 4096 * j));
+                re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
+                im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { // r = 16 j + hi4: real frame g = r >> (L - 8) = j >> (L - 12)
+                v2i x = {0, 0};
+                if (f * G + (size_t)(j >> (L - 12)) < nframes_user) x = *reinterpret_cast<const v2i *>(src + 4096 * j);
+                re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw);
+                im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            }
         }
-        wstage32<8>(re, im, w15r, w15i, a.st[0]);
-        wstage32<4>(re, im, w14r, w14i, a.st[1]);
-        wstage32<2>(re, im, w13r, w13i, a.st[2]);
-        wstage32<1>(re, im, w12r, w12i, a.st[3]);
+        if constexpr (L > 15) wstage32<8>(re, im, w15r, w15i, a.st[X + 0]);
+        if constexpr (L > 14) wstage32<4>(re, im, w14r, w14i, a.st[X + 1]);
+        if constexpr (L > 13) wstage32<2>(re, im, w13r, w13i, a.st[X + 2]);
+        wstage32<1>(re, im, w12r, w12i, a.st[X + 3]);
         __syncthreads(); // the previous frame's reads are done
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -169,14 +199,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
             im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
         }
-        wstage32<8>(re, im, w11r, w11i, a.st[4]);
-        wstage32<4>(re, im, w10r, w10i, a.st[5]);
-        wstage32<2>(re, im, w9r, w9i, a.st[6]);
-        wstage32<1>(re, im, w8r, w8i, a.st[7]);
-        // now thread = (r7..4 = hi4, c3..0), register q = r3..0: scratch [r0 = q][j = hi4][c]
-        int2 *dst = scr + f * 65536 + 256 * hi4 + c;
+        wstage32<8>(re, im, w11r, w11i, a.st[X + 4]);
+        wstage32<4>(re, im, w10r, w10i, a.st[X + 5]);
+        wstage32<2>(re, im, w9r, w9i, a.st[X + 6]);
+        wstage32<1>(re, im, w8r, w8i, a.st[X + 7]);
+        // now thread = (r7..4 = hi4, c3..0), register q = r3..0, r = 16 hi4 + q = g 2^(L-8) + t4 2^(L-12) + low:
+        // scratch [unit = (g, low)][t4][c]   (L = 16: [r0 = q][j = hi4][c])
+        // with r = 16 hi4 + q: g = hi4 >> (L-12), t4 = ((hi4 << (16-L)) & 15) | (q >> (L-12)), low = q mod 2^(L-12): a thread part
+        // plus a compile-time part per register
+        const int g = hi4 >> (L - 12);
+        if (partial && f * G + (size_t)g >= nframes_user) continue; // uniform per (L-12 .. 3 bits of hi4): the barriers above are passed
+        int2 *dst = scr + f * 65536 + c + 4096 * (g << (L - 12)) + 256 * ((hi4 << (16 - L)) & 15);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dst[4096 * q] = make_int2(re[q], im[q]);
+        for (int q = 0; q < 16; ++q) dst[4096 * (q & ((1 << (L - 12)) - 1)) + 256 * (q >> (L - 12))] = make_int2(re[q], im[q]);
     }
 }
 
@@ -209,6 +244,12 @@ __device__ __forceinline__ void wfly64(i64 &are, i64 &aim, i64 &bre, i64 &bim, i
         m2r &= k, m1r &= k, m2i &= k, m1i &= k;
     }
     const u64 xr = m2r - m1r, xi = m2i + m1i;
+    if (s.w32 < 1) { // width <= 32 (the leading pass-2 stages of the shorter lengths): the general form of the slice
+        const int wo = 32 + s.w32;
+        bre = (i64)(xr << (64 - s.sh - wo)) >> (64 - wo);
+        bim = (i64)(xi << (64 - s.sh - wo)) >> (64 - wo);
+        return;
+    }
     const u32 lr = __builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh);
     const u32 li = __builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh);
     const int hr = __builtin_amdgcn_sbfe((int)(xr >> 32), s.sh, s.w32);
@@ -253,9 +294,13 @@ __device__ __forceinline__ void wstage64(i64 (&re)[16], i64 (&im)[16], const int
     wstage64x<H, false, UNIFORM_W>(re, im, wr, wi, s);
 }
 
+template <int L>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
-                                                   const WideArgs a, const W2Consts k, size_t nframes)
+                                                   const WideArgs a, const W2Consts k, size_t nframes_user)
 {
+    constexpr int G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
+    constexpr int X = L - 16;                          // a.st[] entry of STAGE 15 - k is X + k
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
 
@@ -287,11 +332,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
     const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
 
-    // work unit u = 16 f + r0
+    // work unit u = 16 f + (g, low)
     const size_t units = nframes * 16;
     for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
         const size_t f = u >> 4;
         const int r0 = (int)(u & 15);
+        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
+        if (L < 16 && real >= nframes_user) continue;
         i64 re[16], im[16];
         const int2 *src = scr + f * 65536 + 4096 * r0 + 256 * hi4 + lo4;
 #pragma unroll
@@ -300,10 +348,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             re[q] = x.x;
             im[q] = x.y;
         }
-        wstage64<8>(re, im, w7r, w7i, a.st[8]);
-        wstage64<4>(re, im, w6r, w6i, a.st[9]);
-        wstage64<2>(re, im, w5r, w5i, a.st[10]);
-        wstage64<1>(re, im, w4r, w4i, a.st[11]);
+        wstage64<8>(re, im, w7r, w7i, a.st[X + 8]);
+        wstage64<4>(re, im, w6r, w6i, a.st[X + 9]);
+        wstage64<2>(re, im, w5r, w5i, a.st[X + 10]);
+        wstage64<1>(re, im, w4r, w4i, a.st[X + 11]);
         // 36-bit values through three dword planes: re.lo, im.lo, then (re.hi & 0xFFFF) | (im.hi << 16)
         u32 hp[16];
 #pragma unroll
@@ -337,8 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
         }
         // round 2: registers c3..0: STAGE 3, 2 (uniform twiddles), 1, 0
-        wstage64<8, true>(re, im, k.wr3, k.wi3, a.st[12]);
-        wstage64<4, true>(re, im, k.wr2, k.wi2, a.st[13]);
+        wstage64<8, true>(re, im, k.wr3, k.wi3, a.st[X + 12]);
+        wstage64<4, true>(re, im, k.wr2, k.wi2, a.st[X + 13]);
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             wfly64_triv(re[g], im[g], re[g + 2], im[g + 2]);
@@ -346,13 +394,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
 #pragma unroll
         for (int g = 0; g < 16; g += 2) wfly64_triv(re[g], im[g], re[g + 1], im[g + 1]);
-        // natural-order output index brev16(256 r + c) = 4096 rev4(c3..0) + 256 rev4(c7..4) + 16 rev4(r0) + rev4(j)
+        // natural-order output index within the real frame: brev_L(256 r' + c), r' = 2^(L-12) t4 + low
+        //   = 2^(L-4) rev4(c3..0) + 2^(L-8) rev4(c7..4) + 16 brev_(L-12)(low) + rev4(t4)      (L = 16: low = r0, t4 = j)
         typedef i64 v2l __attribute__((ext_vector_type(2)));
-        v2l *dst = reinterpret_cast<v2l *>(out) + f * 65536 + 256 * rev4w(hi4) + 16 * rev4w(r0) + rev4w(lo4);
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
+        v2l *dst = reinterpret_cast<v2l *>(out) + (real << L) + (rev4w(hi4) << (L - 8)) + 16 * rlow + rev4w(lo4);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const v2l y = {re[q], im[q]};
-            __builtin_nontemporal_store(y, dst + 4096 * rev4w(q));
+            __builtin_nontemporal_store(y, dst + ((size_t)rev4w(q) << (L - 4)));
         }
     }
 }
@@ -360,30 +410,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order)
 {
-    return log2n == 16 && data_width == 24 && twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    // int32 containers in (DATA_WIDTH 17..32), pass 1 within 32 bits (DATA_WIDTH + NFFT - 8 <= 32), results in int64 containers
+    // of at most 40 bits (the 64-bit products and the three-plane transpose of pass 2)
+    return log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width + log2n - 8 <= 32 && data_width + log2n > 32 &&
+           data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 && use_fly == 1 &&
+           in_order == 0 && out_order == 0;
 }
 
 const char *wide16_kernel_name() { return "k_wide16_p1+p2"; }
 
-hipError_t launch_wide16(const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
+template <int L>
+static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void *in, void *out, void *scratch, const int2 *tw_all,
+                                size_t nframes, hipStream_t stream)
+{
+    const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L); // virtual 2^16-point frames
+    const size_t units = nvf * 16;
+    size_t g1 = resident_blocks(kptr(k_wide16_p1<L>), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
+    if (g1 < 16) g1 = 16;
+    if (g1 > units) g1 = units;
+    size_t g2 = resident_blocks(kptr(k_wide16_p2<L>), 256, 2);
+    if (g2 > units) g2 = units;
+    hipLaunchKernelGGL(k_wide16_p1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in),
+                       static_cast<int2 *>(scratch), tw_all, a, nframes);
+    hipLaunchKernelGGL(k_wide16_p2<L>, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch),
+                       static_cast<i64 *>(out), tw_all, a, k, nframes);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
                          const int2 *h_tw, size_t nframes, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
     W2Consts k;
     for (int i = 0; i < 8; ++i) k.wr3[i] = h_tw[7 + i].x, k.wi3[i] = h_tw[7 + i].y;
     for (int i = 0; i < 4; ++i) k.wr2[i] = h_tw[3 + i].x, k.wi2[i] = h_tw[3 + i].y;
-    const size_t units = nframes * 16;
-    size_t g1 = resident_blocks(kptr(k_wide16_p1), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
-    if (g1 < 16) g1 = 16;
-    if (g1 > units) g1 = units;
-    size_t g2 = resident_blocks(kptr(k_wide16_p2), 256, 2);
-    if (g2 > units) g2 = units;
-    hipLaunchKernelGGL(k_wide16_p1, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in),
-                       static_cast<int2 *>(scratch), tw_all, a, nframes);
-    hipLaunchKernelGGL(k_wide16_p2, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch),
-                       static_cast<i64 *>(out), tw_all, a, k, nframes);
-    return hipGetLastError();
+    switch (log2n) {
+    case 13: return launch_wide_l<13>(a, k, in, out, scratch, tw_all, nframes, stream);
+    case 14: return launch_wide_l<14>(a, k, in, out, scratch, tw_all, nframes, stream);
+    case 15: return launch_wide_l<15>(a, k, in, out, scratch, tw_all, nframes, stream);
+    default: return launch_wide_l<16>(a, k, in, out, scratch, tw_all, nframes, stream);
+    }
 }
 
 } // namespace intfft

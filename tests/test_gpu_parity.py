@@ -579,6 +579,50 @@ def test_unscaled_results_of_33_and_34_bits(case):
         assert info["fast_path"] == 1 and info["out_container"] == 8, info
 
 
+@pytest.mark.parametrize("case", [(12, 24, 24), (12, 24, 16), (12, 23, 18), (12, 23, 25), (11, 24, 24), (11, 25, 16), (11, 25, 20),
+                                  (12, 24, 10)])
+def test_unscaled_results_of_35_and_36_bits(case, monkeypatch):
+    """24-bit unscaled data at N = 2048 / 4096 (the lengths below BASELINE config 3's): STAGE 4 still fits 32 bits, the whole
+    last register round of k_fft4096_w32 (STAGE 3, 2 with their multipliers, then 1, 0) runs in 64 bits (gfly64); every
+    multiplier regime the widths reach, both XSER, odd batches incl. the two-frames-per-block form at N = 2048; and equal to
+    the generic kernel it replaces."""
+    log2n, dw, tw = case
+    n = 1 << log2n
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), C.FWD) != 0:
+            continue
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(7, n, dw, 270 + dw), uniform_frames(12, n, dw - 1, 271 + dw)])
+        info = check(x, log2n, dw, tw, 1, 0, new)
+        assert info["fast_path"] == 1 and info["out_container"] == 8 and info["kernel_name"] == "k_fft4096_w32", info
+        assert info["out_bits"] == dw + log2n and 35 <= info["out_bits"] <= 36
+    x = uniform_frames(5, n, dw, 99)
+    a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    monkeypatch.setenv("INTFFT_NO_FASTW32", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    assert ib["kernel_name"] == "k_pass<long>" and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(13, 24, 24, 9), (13, 24, 16, 8), (14, 24, 24, 5), (14, 24, 18, 4), (15, 24, 24, 3), (15, 24, 16, 1),
+                                               (16, 24, 24, 2), (13, 27, 24, 3), (14, 20, 16, 6), (15, 18, 24, 2), (16, 18, 16, 1), (15, 25, 20, 2),
+                                               (13, 20, 24, 17)])
+def test_wide_two_pass_kernels_n8192_to_n65536(log2n, dw, tw, batch, monkeypatch):
+    """BASELINE config 3's kernel pair (int32 first pass, 64-bit second pass) at N = 2^13 .. 2^16 and DATA_WIDTH 17 .. 27:
+    shorter lengths run as virtual 2^16-point frames (batches that do not fill the last group included), second-pass stages
+    of at most 32 bits take the general slice form.  Bit-exact to the oracle incl. the edge frames, and equal to the generic
+    kernels it replaces."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 300 + log2n + dw), edge_frames(n, dw)[[0, 1, 4]]])[:max(batch, 1) + (2 if log2n < 15 else 0)]
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), C.FWD) != 0:
+            continue
+        info = check(x, log2n, dw, tw, 1, 0, new)
+        assert info["kernel_name"] == "k_wide16_p1+p2" and info["n_passes"] == 2 and info["out_container"] == 8, info
+    a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    monkeypatch.setenv("INTFFT_NO_WIDE16", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    assert ib["kernel_name"] != "k_wide16_p1+p2" and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)

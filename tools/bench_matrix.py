@@ -29,6 +29,8 @@ for L in (7, 10):
 ROWS.append(("7:16:16:1:0:PAIR", "16-bit unscaled PAIR"))
 ROWS.append(("16:24:24:1", "24-bit unscaled FWD (C3)"))
 ROWS.append(("16:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD"))
+for L in (11, 12, 13, 14, 15):
+    ROWS.append(("%d:24:24:1" % L, "24-bit unscaled FWD"))
 ROWS.append(("10:24:24:1", "24-bit unscaled FWD"))
 ROWS.append(("7:24:24:1", "24-bit unscaled FWD"))
 ROWS.append(("10:12:16:0", "12-bit scaled FWD"))
