@@ -84,12 +84,19 @@ template <typename T> __device__ __forceinline__ T neg_quirk(T x, int w)
 __device__ __forceinline__ void cmult(int32_t dre, int32_t dim, int32_t wr, int32_t wi, int mw,
                                       int a, int b, int /*narrow*/, int32_t &ore, int32_t &oim)
 {
-    const int64_t m2r = (int64_t)dre * wr, m1r = (int64_t)dim * wi; // RE: M2 - M1  (:192-207)
-    const int64_t m2i = (int64_t)dre * wi, m1i = (int64_t)dim * wr; // IM: M2 + M1  (:209-224)
-    const int64_t r = ((m2r >> a) - (m1r >> a)) >> b;
-    const int64_t i = ((m2i >> a) + (m1i >> a)) >> b;
-    ore = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)r, mw);
-    oim = wrapw<int32_t>((int32_t)(uint32_t)(uint64_t)i, mw);
+    uint64_t m2r = (uint64_t)((int64_t)dre * wr), m1r = (uint64_t)((int64_t)dim * wi); // RE: M2 - M1  (:192-207)
+    uint64_t m2i = (uint64_t)((int64_t)dre * wi), m1i = (uint64_t)((int64_t)dim * wr); // IM: M2 + M1  (:209-224)
+    // (M >> a) << a == M & ~(2^a - 1), so ((M2 >> a) -/+ (M1 >> a)) >> b == ((M2 & K) -/+ (M1 & K)) >> (a + b) exactly; the
+    // mw result bits start at bit a + b <= 26 of the sum: one v_alignbit_b32 and one v_bfe_i32 instead of three 64-bit shifts
+    if (a) {
+        const uint64_t k = 0xFFFFFFFF00000000ull | ~((1u << a) - 1u);
+        m2r &= k, m1r &= k, m2i &= k, m1i &= k;
+    }
+    const uint64_t xr = m2r - m1r, xi = m2i + m1i;
+    const uint32_t lr = __builtin_amdgcn_alignbit((uint32_t)(xr >> 32), (uint32_t)xr, (uint32_t)(a + b));
+    const uint32_t li = __builtin_amdgcn_alignbit((uint32_t)(xi >> 32), (uint32_t)xi, (uint32_t)(a + b));
+    ore = wrapw<int32_t>((int32_t)lr, mw);
+    oim = wrapw<int32_t>((int32_t)li, mw);
 }
 
 // 64-bit words: products reach 2^89; keep each product as H*2^32 + L with
