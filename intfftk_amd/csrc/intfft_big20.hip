@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
     const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
     RoundTw tb;
     load_round_tw<4>(twt, lo4, tb);
+    to_dit_packing(tb); // both cores run here: DIT packing, the forward core on D with exchanged halves (group4's DPK form)
     const short sa = (short)(1 - (q & 1)), s3 = (short)(1 - (lane & 1)); // kinds: n8 = lane bit 4, then n4 = lane bit 0
     const v2s sh_a = {sa, sa}, sh3 = {s3, s3};
     for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
@@ -810,19 +811,19 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
         }
 #define INTFFT_MIDPAIR(FX)                                                                                       \
     {                                                                                                            \
-        dif_round<FX, true>(v, tb, sl, sh_a);                                                                    \
+        dif_round<FX, true, 4, false, true>(v, tb, sl, sh_a);                                                    \
         wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];                    \
         wave_lds_fence(); /* LDS ops of one wave execute in order */                                \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; /* regs n3..0, lane n9..n4 */ \
         wave_lds_fence();                                                                           \
-        dif_round_c<FX>(v, c, sl, sh3);                                                                          \
-        dit_round_c<FX>(v, c, sl);                                                                               \
+        dif_round_c<FX, false, true>(v, c, sl, sh3);                                                             \
+        dit_round_c<FX, false, true>(v, c, sl);                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];                              \
         wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4];                    \
         wave_lds_fence();                                                                           \
-        dit_round<FX>(v, tb, sl);                                                                                \
+        dit_round<FX, 4, false, true>(v, tb, sl);                                                                \
     }
         if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK)
         else INTFFT_MIDPAIR(false)
@@ -911,6 +912,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
             c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
             c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
         }
+        to_dit_packing_host(c); // k_mid_pair holds its twiddles in the DIT packing
         const int vsh = log2n <= 16 ? 16 - log2n : 0;
         const size_t nvf = (nframes + ((size_t)1 << vsh) - 1) >> vsh;
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     if constexpr (L >= 7) ld(63 + lane, ta.wa1[0], ta.wb1[0]);
     ld(31 + (lane & 31), wa5, wb5);
     ld(15 + (lane & 15), wa4, wb4);
-    constexpr bool DP = MODE == X_INV; // the inverse core alone: twiddles in the DIT packing (no per-butterfly swap of B)
+    // twiddles in the DIT packing: the inverse core multiplies the unswapped B; in a (truncate-mode) pair the forward core
+    // produces D with its halves exchanged instead (free: op_sel of the packed subtract; group4's DPK form)
+    constexpr bool DP = MODE == X_INV || !ROUND;
     if constexpr (DP) {
         to_dit_packing(ta);
         to_dit_packing(wa5, wb5);
@@ -165,16 +167,16 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 #define INTFFT_XBODY(FX)                                                                                \
     {                                                                                                   \
         if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
-            dif_round<FX, false, NS, ROUND>(v, ta, sl, sh3);                                                \
+            dif_round<FX, false, NS, ROUND, DP>(v, ta, sl, sh3);                                                \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
-            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0)>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
-            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0)>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0), false, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0), false, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
-            group4<ROUND, FX, false, !ROUND, false, 0x0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
-            group4<ROUND, FX, false, !ROUND, false, (ROUND ? 0x0 : 0xF)>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, 0x0, false, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
+            group4<ROUND, FX, false, !ROUND, false, (ROUND ? 0x0 : 0xF), false, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
             wave_lds_fence();                                                              \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
             {                                                                                           \
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;             \
             }                                                                                           \
             wave_lds_fence();                                                              \
-            dif_round_c<FX, ROUND>(v, c, sl, sh3);                                                      \
+            dif_round_c<FX, ROUND, DP>(v, c, sl, sh3);                                                      \
         }                                                                                               \
         /* inverse core: LC -> L1 */                                                                    \
         dit_round_c<FX, ROUND, DP>(v, c, sl);                                                           \
@@ -297,7 +299,7 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    if (direction == 1) to_dit_packing_host(c); // X_INV kernels hold their twiddles in the DIT packing
+    if (direction == 1 || !round) to_dit_packing_host(c); // kernels with DP (see k_fft1024x_i16) hold their twiddles in the DIT packing
     const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;

@@ -27,13 +27,22 @@ __device__ __forceinline__ u32 pack_wb(int2 w) { return ((u32)w.y & 0xFFFFu) | (
 
 // ---- sum / difference ---------------------------------------------------------------------------
 // PRE: the inputs already hold A >> 1, B >> 1 (truncate mode only).
-template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u32 b, u32 &s, u32 &d)
+// SW: the difference comes out with its halves exchanged, (D.im, D.re) -- op_sel of the packed subtract, no extra instruction
+// (group4's DPK form multiplies the swapped D by DIT-packed twiddles)
+template <bool SW> __device__ __forceinline__ u32 pk_sub(v2s x, v2s y)
+{
+    if (!SW) return as_u32(x - y);
+    u32 r;
+    asm("v_pk_sub_i16 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0]" : "=v"(r) : "v"(as_u32(x)), "v"(as_u32(y)));
+    return r;
+}
+template <bool ROUND, bool PRE, bool SW = false> __device__ __forceinline__ void sumdiff(u32 a, u32 b, u32 &s, u32 &d)
 {
     const v2s A = as_v2s(a), B = as_v2s(b);
     if (!ROUND) { // int_dif2_fly.vhd:144-164
         const v2s A1 = PRE ? A : A >> (short)1, B1 = PRE ? B : B >> (short)1;
         s = as_u32(A1 + B1);
-        d = as_u32(A1 - B1);
+        d = pk_sub<SW>(A1, B1);
     } else { // :167-219  rhu2(x) = floor((x + 1) / 2).  With T = (A ^ B) >> 1 (arithmetic):
         //   A + B = 2 (A | B) - (A ^ B)               ->  rhu2(A + B) = (A | B) - T
         //   A - B + 1 = A + ~B + 2, floor((A + ~B) / 2) = (A & ~B) + ((A ^ ~B) >> 1) = (A & ~B) - T - 1
@@ -41,15 +50,15 @@ template <bool ROUND, bool PRE> __device__ __forceinline__ void sumdiff(u32 a, u
         // exact over the integers, hence also modulo 2^16 (the RTL's 16-bit wrap); six operations for both results
         const v2s T = (A ^ B) >> (short)1;
         s = as_u32((A | B) - T);
-        d = as_u32((A & ~B) - T);
+        d = pk_sub<SW>(A & ~B, T);
     }
 }
 // truncate mode with a per-lane shift amount (0 where the lane's registers already hold X >> 1)
-__device__ __forceinline__ void sumdiff_var(u32 a, u32 b, v2s sh, u32 &s, u32 &d)
+template <bool SW = false> __device__ __forceinline__ void sumdiff_var(u32 a, u32 b, v2s sh, u32 &s, u32 &d)
 {
     const v2s A1 = as_v2s(a) >> sh, B1 = as_v2s(b) >> sh;
     s = as_u32(A1 + B1);
-    d = as_u32(A1 - B1);
+    d = pk_sub<SW>(A1, B1);
 }
 
 // ---- complex multiplies: cmult_{16,t}(D, W), single-DSP regime (int_cmult_dsp48.vhd:184-225) ----
@@ -162,23 +171,29 @@ __device__ __forceinline__ void mul4f(const u32 (&dr)[4], const u32 (&di)[4], co
 //   OUT_PRE emit Y >> 1 (truncate mode)
 //   SG      twiddles in SGPRs
 //   PREMASK bit i: inputs of butterfly i already hold X >> 1;  VARSH: per-lane shift amount instead
-template <bool ROUND, int FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false>
+//   DPK     the twiddles come in the DIT packing (wa, wb) = (Wc, Wd) = ((wr, wi), (-wi, wr)) -- what a kernel that runs BOTH
+//           cores shares with its DIT half (group4_dit<.., DITPACK>).  D is then produced with its halves exchanged (free:
+//           op_sel of the packed subtract) and Y.re = dot(Dsw, Wd), Y.im = dot(Dsw, Wc); a quarter turn is
+//           Y.re = dot(Dsw, Wc), Y.im = dot(-Dsw, Wd): the code below with the roles of (wa, wb) exchanged
+template <bool ROUND, int FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false, bool DPK = false>
 __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
-                                       const u32 (&wa)[4], const u32 (&wb)[4], const Slice &sl, v2s shv = v2s{0, 0})
+                                       const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl, v2s shv = v2s{0, 0})
 {
     static_assert(FASTX == 0 || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
     static_assert(!QTURN || !ROUND, "quarter-turn sharing needs an exact -D");
+    const u32 (&wa)[4] = DPK ? wb_in : wa_in;
+    const u32 (&wb)[4] = DPK ? wa_in : wb_in;
     u32 d[4];
     if (VARSH) {
-        sumdiff_var(a0, b0, shv, a0, d[0]);
-        sumdiff_var(a1, b1, shv, a1, d[1]);
-        sumdiff_var(a2, b2, shv, a2, d[2]);
-        sumdiff_var(a3, b3, shv, a3, d[3]);
+        sumdiff_var<DPK>(a0, b0, shv, a0, d[0]);
+        sumdiff_var<DPK>(a1, b1, shv, a1, d[1]);
+        sumdiff_var<DPK>(a2, b2, shv, a2, d[2]);
+        sumdiff_var<DPK>(a3, b3, shv, a3, d[3]);
     } else {
-        sumdiff<ROUND, (PREMASK & 1) != 0>(a0, b0, a0, d[0]);
-        sumdiff<ROUND, (PREMASK & 2) != 0>(a1, b1, a1, d[1]);
-        sumdiff<ROUND, (PREMASK & 4) != 0>(a2, b2, a2, d[2]);
-        sumdiff<ROUND, (PREMASK & 8) != 0>(a3, b3, a3, d[3]);
+        sumdiff<ROUND, (PREMASK & 1) != 0, DPK>(a0, b0, a0, d[0]);
+        sumdiff<ROUND, (PREMASK & 2) != 0, DPK>(a1, b1, a1, d[1]);
+        sumdiff<ROUND, (PREMASK & 4) != 0, DPK>(a2, b2, a2, d[2]);
+        sumdiff<ROUND, (PREMASK & 8) != 0, DPK>(a3, b3, a3, d[3]);
     }
     u32 y[4];
     if (QTURN) {
@@ -387,7 +402,7 @@ template <bool ROUND = false> __device__ __forceinline__ void bfly_pj_dit(u32 &a
 // ---- four DIF stages on register offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0) -----------------------
 // kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount.
 // NS < 4 runs only the last NS stages (short frames: the leading stages belong to frame-number bits).
-template <bool FASTX, bool VARSH0, int NS = 4, bool ROUND = false>
+template <bool FASTX, bool VARSH0, int NS = 4, bool ROUND = false, bool DPK = false>
 __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl, v2s shv)
 {
     if constexpr (ROUND) { // RNDMODE = 1: full-width values everywhere (no pre-shifted outputs), exact extraction
@@ -395,22 +410,22 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
         if constexpr (NS >= 4) {
             const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
             const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
-            group4<true, false, false, false, false, 0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-            group4<true, false, false, false, false, 0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
         }
         if constexpr (NS >= 3) {
-            group4<true, false, false, false, false, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-            group4<true, false, false, false, false, 0>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
         }
         if constexpr (NS >= 2) {
             const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
-            group4<true, false, false, false, false, 0>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
-            group4<true, false, false, false, false, 0>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
         }
         if constexpr (NS >= 1) {
             const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
-            group4<true, false, false, false, false, 0>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
-            group4<true, false, false, false, false, 0>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
+            group4<true, false, false, false, false, 0, false, DPK>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
         }
         return;
     }
@@ -419,25 +434,25 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
     if constexpr (NS >= 4) {
         const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
         const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
-        group4<false, FASTX, false, true, false, M0, VARSH0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
-        group4<false, FASTX, false, true, false, M0, VARSH0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
+        group4<false, FASTX, false, true, false, M0, VARSH0, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
+        group4<false, FASTX, false, true, false, M0, VARSH0, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
     }
     // offset 4: pairs (j, j+4); kind = j & 8
     if constexpr (NS >= 3) {
-        group4<false, FASTX, false, true, false, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-        group4<false, FASTX, false, true, false, MA4>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+        group4<false, FASTX, false, true, false, M0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+        group4<false, FASTX, false, true, false, MA4, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
     }
     // offset 2: pairs (j, j+2); twiddle j & 1; kind = j & 4
     if constexpr (NS >= 2) {
         const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
-        group4<false, FASTX, false, true, false, M0>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
-        group4<false, FASTX, false, true, false, MA2>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+        group4<false, FASTX, false, true, false, M0, false, DPK>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA2, false, DPK>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
     }
     // offset 1: pairs (j, j+1); kind = j & 2
     if constexpr (NS >= 1) {
         const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
-        group4<false, FASTX, false, true, false, M0>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
-        group4<false, FASTX, false, true, false, MA1>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+        group4<false, FASTX, false, true, false, M0, false, DPK>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
+        group4<false, FASTX, false, true, false, MA1, false, DPK>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
     }
 }
 
@@ -560,16 +575,16 @@ __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const
 }
 
 // ---- round C: DIF stages 3,2,1,0 / DIT stages 0,1,2,3 on reg = n3..0, uniform twiddles ----------------
-template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
+template <bool FASTX, bool ROUND = false, bool DPK = false> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
 {
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
     if constexpr (ROUND) { // RNDMODE = 1: full-width values, exact extraction; STAGE 1 / 0 on rhu2 sums (int_dif2_fly.vhd:167-219)
         static_assert(!FASTX, "round mode uses the exact extraction");
-        group4<true, false, false, false, true, 0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-        group4<true, false, false, false, true, 0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
-        group4<true, false, false, false, true, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
-        group4<true, false, false, false, true, 0>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+        group4<true, false, false, false, true, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4<true, false, false, false, true, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        group4<true, false, false, false, true, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+        group4<true, false, false, false, true, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
             bfly_triv<true, false>(v[g], v[g + 2]);
@@ -579,10 +594,10 @@ template <bool FASTX, bool ROUND = false> __device__ __forceinline__ void dif_ro
         for (int g = 0; g < 16; g += 2) bfly_triv<true, false>(v[g], v[g + 1]);
         return;
     }
-    group4<false, FASTX, false, true, true, 0, true>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
-    group4<false, FASTX, false, true, true, 0, true>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
-    group4<false, FASTX, false, true, true, 0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
-    group4<false, FASTX, false, true, true, 0xF>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+    group4<false, FASTX, false, true, true, 0, true, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
+    group4<false, FASTX, false, true, true, 0, true, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl, shv);
+    group4<false, FASTX, false, true, true, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+    group4<false, FASTX, false, true, true, 0xF, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
 #pragma unroll
     for (int g = 0; g < 16; g += 8) { // stage 1: kind = r & 4
         bfly_triv<false, false>(v[g], v[g + 2]);
