@@ -325,14 +325,14 @@ def main():
         cold = {"kernel_ms": ms, "value": batch * n / ms / 1e6, "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "what": "first %d launches from idle clocks, no pre-warm" % args.steps}
 
+    import gc
+
+    gc.collect()  # BEFORE the clock ramp: a collection takes ~20 ms, and a GPU left idle that long drops its clocks again
+    gc.disable()  # no collector pause inside the K timed steps (a 50-step region is only ~5 ms long)
     for _ in range(args.prewarm):  # untimed: DVFS ramp, not part of W/K
         step()
     for _ in range(args.warmup):
         step()
-    import gc
-
-    gc.collect()
-    gc.disable()  # no collector pause inside the K timed steps (a 50-step region is only ~5 ms long)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
