@@ -123,10 +123,36 @@ __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int3
         dim = wrapw<int64_t>(dim, narrow);
     }
     if (narrow == 1) { // |d| <= 2^(mw-1), |w| <= 2^(t-1), mw + t <= 64: products and their sum are exact in int64
-        const int64_t m2r = dre * (int64_t)wr, m1r = dim * (int64_t)wi;
-        const int64_t m2i = dre * (int64_t)wi, m1i = dim * (int64_t)wr;
-        ore = wrapw<int64_t>(((m2r >> a) - (m1r >> a)) >> b, mw);
-        oim = wrapw<int64_t>(((m2i >> a) + (m1i >> a)) >> b, mw);
+        // d = dH 2^32 + dL (dL signed): d * w = mad_i64_i32(dL, w) + (mul_lo(dH, w) << 32), exact modulo 2^64; the truncation points
+        // as a mask ((M >> a) << a == M & ~(2^a - 1)); the mw result bits start at bit a + b <= 26 of the sum and are cut out
+        // with v_alignbit_b32 / v_bfe_i32 where they lie inside one dword pair (else two 64-bit shifts)
+        auto mul = [](int64_t d, int32_t w) -> uint64_t {
+            const int32_t dl = (int32_t)d, dh = (int32_t)(d >> 32) - (dl >> 31);
+            return (uint64_t)((int64_t)dl * w) + ((uint64_t)((uint32_t)dh * (uint32_t)w) << 32);
+        };
+        uint64_t m2r = mul(dre, wr), m1r = mul(dim, wi), m2i = mul(dre, wi), m1i = mul(dim, wr);
+        if (a) {
+            const uint64_t k = 0xFFFFFFFF00000000ull | ~((1u << a) - 1u);
+            m2r &= k, m1r &= k, m2i &= k, m1i &= k;
+        }
+        const uint64_t xr = m2r - m1r, xi = m2i + m1i;
+        const int sh = a + b;
+        if (mw <= 32) {
+            const uint32_t lr = __builtin_amdgcn_alignbit((uint32_t)(xr >> 32), (uint32_t)xr, (uint32_t)sh);
+            const uint32_t li = __builtin_amdgcn_alignbit((uint32_t)(xi >> 32), (uint32_t)xi, (uint32_t)sh);
+            ore = wrapw<int32_t>((int32_t)lr, mw);
+            oim = wrapw<int32_t>((int32_t)li, mw);
+        } else if (sh + mw <= 64 && sh + (mw - 32) <= 32) {
+            const uint32_t lr = __builtin_amdgcn_alignbit((uint32_t)(xr >> 32), (uint32_t)xr, (uint32_t)sh);
+            const uint32_t li = __builtin_amdgcn_alignbit((uint32_t)(xi >> 32), (uint32_t)xi, (uint32_t)sh);
+            const int32_t hr = __builtin_amdgcn_sbfe((int32_t)(xr >> 32), sh, mw - 32);
+            const int32_t hi = __builtin_amdgcn_sbfe((int32_t)(xi >> 32), sh, mw - 32);
+            ore = (int64_t)(((uint64_t)(uint32_t)hr << 32) | lr);
+            oim = (int64_t)(((uint64_t)(uint32_t)hi << 32) | li);
+        } else {
+            ore = wrapw<int64_t>((int64_t)xr >> sh, mw);
+            oim = wrapw<int64_t>((int64_t)xi >> sh, mw);
+        }
         return;
     }
     const Prod96 m2r = mul96(dre, wr), m1r = mul96(dim, wi);
@@ -164,10 +190,12 @@ __device__ __forceinline__ void cmult(i128 dre, i128 dim, int32_t wr, int32_t wi
 //          without the extra bit: rhu2(A+B) = (A>>1)+(B>>1)+((A|B)&1), rhu2(A-B) = (A>>1)-(B>>1)+(A&~B&1)
 //          (the dedicated kernels use the shorter forms (A|B) - T, (A&~B) - T with T = (A^B) >> 1: intfft_pk16.hpp)
 // unscaled: A +/- B, one bit of growth (:222-240)
-template <typename T>
-__device__ __forceinline__ void addsub(T a, T b, int rnd, int wo, T &s, T &d)
+// RNDC: the rounding kind when the caller knows it at compile time (k_pass<T, RND>: one kind per plan), else -1
+template <typename T, int RNDC = -1>
+__device__ __forceinline__ void addsub(T a, T b, int rnd_rt, int wo, T &s, T &d)
 {
     using U = typename UWord<T>::type;
+    const int rnd = RNDC >= 0 ? RNDC : rnd_rt;
     if (rnd == RND_TRUNC) {
         s = (a >> 1) + (b >> 1);
         d = (a >> 1) - (b >> 1);
@@ -181,17 +209,18 @@ __device__ __forceinline__ void addsub(T a, T b, int rnd, int wo, T &s, T &d)
 }
 
 // int_dif2_fly: X = S, Y = D (STAGE 0) | D * {1, -j} (STAGE 1) | cmult(D, W) (STAGE >= 2)
-template <typename T>
+// CLS: what the caller knows about the stage at compile time: 0 nothing, 1 STAGE < 2 (no multiplier), 2 STAGE >= 2
+template <typename T, int RNDC = -1, int CLS = 0>
 __device__ __forceinline__ void dif_fly(const StageDesc &st, int odd, Cx<T> a, Cx<T> b, int32_t wr,
                                         int32_t wi, Cx<T> &x, Cx<T> &y)
 {
     Cx<T> s, d;
-    addsub<T>(a.re, b.re, st.rnd, st.wo, s.re, d.re);
-    addsub<T>(a.im, b.im, st.rnd, st.wo, s.im, d.im);
+    addsub<T, RNDC>(a.re, b.re, st.rnd, st.wo, s.re, d.re);
+    addsub<T, RNDC>(a.im, b.im, st.rnd, st.wo, s.im, d.im);
     x = s;
-    if (st.ts == 0) { // int_dif2_fly.vhd:245-255
+    if (CLS != 2 && st.ts == 0) { // int_dif2_fly.vhd:245-255
         y = d;
-    } else if (st.ts == 1) { // :259-318
+    } else if (CLS != 2 && (CLS == 1 || st.ts == 1)) { // :259-318
         if (!odd) {
             y = d;
         } else {
@@ -205,14 +234,14 @@ __device__ __forceinline__ void dif_fly(const StageDesc &st, int odd, Cx<T> a, C
 
 // int_dit2_fly: T = B (STAGE 0) | B * {1, +j} (STAGE 1) | B * conj(W) via the re/im-swapped
 // multiplier (int_dit2_fly.vhd:304-322), then X = A + T, Y = A - T with the scaling variant.
-template <typename T>
+template <typename T, int RNDC = -1, int CLS = 0>
 __device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, Cx<T> b, int32_t wr,
                                         int32_t wi, Cx<T> &x, Cx<T> &y)
 {
     Cx<T> t;
-    if (st.ts == 0) { // :221-230
+    if (CLS != 2 && st.ts == 0) { // :221-230
         t = b;
-    } else if (st.ts == 1) { // :234-286
+    } else if (CLS != 2 && (CLS == 1 || st.ts == 1)) { // :234-286
         if (!odd) {
             t = b;
         } else {
@@ -225,8 +254,8 @@ __device__ __forceinline__ void dit_fly(const StageDesc &st, int odd, Cx<T> a, C
         t.im = ore;
         t.re = oim;
     }
-    addsub<T>(a.re, t.re, st.rnd, st.wo, x.re, y.re);
-    addsub<T>(a.im, t.im, st.rnd, st.wo, x.im, y.im);
+    addsub<T, RNDC>(a.re, t.re, st.rnd, st.wo, x.re, y.re);
+    addsub<T, RNDC>(a.im, t.im, st.rnd, st.wo, x.im, y.im);
 }
 
 // ---- 2-D scheme: the inter-pass twiddle W_N^m, evaluated on the fly -------------------------------------

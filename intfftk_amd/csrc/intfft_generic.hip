@@ -38,7 +38,7 @@ template <typename T> __device__ __forceinline__ void store_user(void *base, int
 // 2^R-point sub-transform in registers: element r of the group lives at lds[pad(e + (r << lb_lo))] and
 // carries index bits s_lo .. s_lo+R-1 = r.  Stage s_lo+i pairs r-bit i and uses twiddle
 // kb + ((r mod 2^i) << s_lo) of its table; stage descriptors a.st[si ..] are in processing order.
-template <typename T, int KIND, int R>
+template <typename T, int KIND, int R, int RND>
 __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo, int s_lo, unsigned kb,
                                               const PassArgs &a, int si, const int2 *__restrict__ tw)
 {
@@ -53,24 +53,38 @@ __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo,
         constexpr int dummy = 0;
         (void)dummy;
         const int h = 1 << i;
+        // the kind of the stage (multiplier / STAGE 1 / STAGE 0) is uniform: one branch per stage, straight-line butterflies inside
+        if (st.ts >= 2) {
 #pragma unroll
-        for (int pr = 0; pr < P / 2; ++pr) {
-            const int r0 = ((pr >> i) << (i + 1)) | (pr & (h - 1));
-            const unsigned k = (kb + ((unsigned)(r0 & (h - 1)) << s_lo)) >> st.tshift;
-            int2 w = make_int2(0, 0);
-            if (st.ts >= 2) w = tw[st.tw_off + k];
-            Cx<T> X, Y;
-            if (KIND == KIND_DIF) dif_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
-            else dit_fly<T>(st, (int)(k & 1u), v[r0], v[r0 + h], w.x, w.y, X, Y);
-            v[r0] = X;
-            v[r0 + h] = Y;
+            for (int pr = 0; pr < P / 2; ++pr) {
+                const int r0 = ((pr >> i) << (i + 1)) | (pr & (h - 1));
+                const int2 w = tw[st.tw_off + ((kb + ((unsigned)(r0 & (h - 1)) << s_lo)) >> st.tshift)];
+                Cx<T> X, Y;
+                if (KIND == KIND_DIF) dif_fly<T, RND, 2>(st, 0, v[r0], v[r0 + h], w.x, w.y, X, Y);
+                else dit_fly<T, RND, 2>(st, 0, v[r0], v[r0 + h], w.x, w.y, X, Y);
+                v[r0] = X;
+                v[r0 + h] = Y;
+            }
+        } else {
+#pragma unroll
+            for (int pr = 0; pr < P / 2; ++pr) {
+                const int r0 = ((pr >> i) << (i + 1)) | (pr & (h - 1));
+                const unsigned k = (kb + ((unsigned)(r0 & (h - 1)) << s_lo)) >> st.tshift;
+                Cx<T> X, Y;
+                if (KIND == KIND_DIF) dif_fly<T, RND, 1>(st, (int)(k & 1u), v[r0], v[r0 + h], 0, 0, X, Y);
+                else dit_fly<T, RND, 1>(st, (int)(k & 1u), v[r0], v[r0 + h], 0, 0, X, Y);
+                v[r0] = X;
+                v[r0 + h] = Y;
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < P; ++r) lds[pad(e + ((unsigned)r << lb_lo))] = v[r];
 }
 
-template <typename T>
+// RND: the rounding kind of the plan's butterflies (one per plan: FORMAT / RNDMODE) as a template parameter -- a third of the
+// sum / difference code per instantiation, no run-time mode branches in the register rounds
+template <typename T, int RND>
 __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in, void *out,
                                                        const int2 *__restrict__ tw, size_t nframes,
                                                        const int2 *__restrict__ tw2d)
@@ -150,7 +164,8 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
     // ---- stages: up to RMAX consecutive stages per LDS round trip, evaluated in registers ----------
     // Stages of one pass act on consecutive tile-local bits (descending for DIF, ascending for DIT), so a run
     // of R stages is a 2^R-point sub-transform per thread (round_generic<>), each stage with its own widths.
-    constexpr int RMAX = sizeof(T) == 4 ? 4 : sizeof(T) == 8 ? 3 : 2;
+    // (int32 round mode: four stages of 16 points with the rhu2 temporaries spill under the 128-register bound of 1024 threads)
+    constexpr int RMAX = sizeof(T) == 4 ? (RND == RND_ROUND ? 3 : 4) : sizeof(T) == 8 ? 3 : 2;
     int si = 0;
     while (si < a.nstages) {
         const StageDesc st = a.st[si];
@@ -191,17 +206,17 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
             const unsigned e = (f << U) + u0;
             if (st.kind == KIND_DIF) {
                 switch (R) {
-                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIF, 4>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 3: round_generic<T, KIND_DIF, 3>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 2: round_generic<T, KIND_DIF, 2>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                default: round_generic<T, KIND_DIF, 1>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIF, 4, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIF, 3, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIF, 2, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIF, 1, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
                 }
             } else {
                 switch (R) {
-                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIT, 4>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 3: round_generic<T, KIND_DIT, 3>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 2: round_generic<T, KIND_DIT, 2>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                default: round_generic<T, KIND_DIT, 1>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIT, 4, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIT, 3, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIT, 2, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIT, 1, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
                 }
             }
         }
@@ -266,18 +281,25 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
     const size_t blocks = groups << (a.L - a.U);
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = pass_lds_bytes(a, word_bytes);
-    if (word_bytes == 4) {
-        allow_max_lds(kptr(&k_pass<int32_t>));
-        hipLaunchKernelGGL(k_pass<int32_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
-                           out, tw, nframes, tw2d);
-    } else if (word_bytes == 16) {
-        allow_max_lds(kptr(&k_pass<i128>));
-        hipLaunchKernelGGL(k_pass<i128>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in, out, tw, nframes, tw2d);
-    } else {
-        allow_max_lds(kptr(&k_pass<int64_t>));
-        hipLaunchKernelGGL(k_pass<int64_t>, dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in,
-                           out, tw, nframes, tw2d);
+    int rnd = RND_UNSCALED; // the butterflies of a plan share one kind (the 2-D scheme's multiplier stages carry none)
+    for (int i = 0; i < a.nstages; ++i)
+        if (a.st[i].kind == KIND_DIF || a.st[i].kind == KIND_DIT) rnd = a.st[i].rnd;
+#define INTFFT_LAUNCH_PASS(T, R)                                                                                          \
+    {                                                                                                                     \
+        allow_max_lds(kptr(&k_pass<T, R>));                                                                               \
+        hipLaunchKernelGGL((k_pass<T, R>), dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in, out, tw, nframes, tw2d); \
     }
+#define INTFFT_LAUNCH_PASS_T(T)                                                                                           \
+    {                                                                                                                     \
+        if (rnd == RND_TRUNC) INTFFT_LAUNCH_PASS(T, RND_TRUNC)                                                            \
+        else if (rnd == RND_ROUND) INTFFT_LAUNCH_PASS(T, RND_ROUND)                                                       \
+        else INTFFT_LAUNCH_PASS(T, RND_UNSCALED)                                                                          \
+    }
+    if (word_bytes == 4) INTFFT_LAUNCH_PASS_T(int32_t)
+    else if (word_bytes == 16) INTFFT_LAUNCH_PASS(i128, RND_UNSCALED) // results beyond 64 bits exist with bit growth only
+    else INTFFT_LAUNCH_PASS_T(int64_t)
+#undef INTFFT_LAUNCH_PASS_T
+#undef INTFFT_LAUNCH_PASS
     return hipGetLastError();
 }
 
