@@ -556,9 +556,17 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
     }
     if (fast) dit_round<FAST_OK>(v, tb, sl);
     else dit_round<false>(v, tb, sl);
-    u32 *dst = scr + (frame << L) + ((size_t)R << (L - 5)) + mid * 256 + lo4;
+    // thread = (R, n3..0), regs n7..4: a store instruction would write four 64-byte pieces of four rows.  Two lane swaps
+    // (reg bit 0 = n4 <-> lane bit 4 = R bit 0, reg bit 1 = n5 <-> lane bit 5 = R bit 1) make the lanes n5..0: 256-byte runs
+    swap_guard(v);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dst[16 * j] = v[j];
+    for (int j = 0; j < 16; j += 2) swap16(v[j], v[j + 1]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (!(j & 2)) swap32(v[j], v[j + 2]);
+    u32 *dst = scr + (frame << L) + ((size_t)(R & ~3) << (L - 5)) + mid * 256 + (tid & 63);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[((size_t)(r & 3) << (L - 5)) + ((r >> 2) << 6)] = v[r]; // row (R & ~3) | (r & 3), n7..6 = r >> 2
 }
 
 // ---- inverse pass 3 (mirror of pass 3): bit-reversed load of the natural-order input + DIT STAGE 0..3 -----------------
