@@ -623,6 +623,30 @@ def test_wide_two_pass_kernels_n8192_to_n65536(log2n, dw, tw, batch, monkeypatch
     assert ib["kernel_name"] != "k_wide16_p1+p2" and np.array_equal(a, b)
 
 
+def test_wide_family_random_configurations():
+    """Seeded fuzz over the unscaled plans with int64 results (N = 2^10 .. 2^16, DATA_WIDTH 17 .. 30, TWDL_WIDTH 10 .. 25, both
+    XSER): whichever kernel the planner picks (k_fft1024_w32 / k_fft4096_w32 with 64-bit tails, k_wide16_p1+p2<L>, k_pass<long>),
+    the result is the oracle's, bit for bit."""
+    rng = np.random.default_rng(20260929)
+    seen, done = set(), 0
+    for _ in range(400):
+        log2n = int(rng.integers(10, 17))
+        dw = int(rng.integers(17, 31))
+        tw = int(rng.integers(10, 26))
+        new = bool(rng.integers(0, 2))
+        if dw + log2n <= 32 or dw + log2n > 44 or C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), C.FWD) != 0:
+            continue
+        n = 1 << log2n
+        batch = int(rng.integers(1, 6)) if log2n >= 13 else int(rng.integers(1, 20))
+        x = np.concatenate([uniform_frames(batch, n, dw, int(rng.integers(1, 1 << 30))), edge_frames(n, dw)[[1, 3]]])
+        info = check(x, log2n, dw, tw, 1, 0, new)
+        seen.add(info["kernel_name"])
+        done += 1
+        if done >= 48:
+            break
+    assert done >= 40 and {"k_wide16_p1+p2", "k_fft4096_w32", "k_pass<long>"} <= seen, (done, seen)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])
 def test_fast1024u_ragged_batches(batch):
     x = uniform_frames(batch, 1024, 16 if batch % 2 else 15, 200 + batch)
