@@ -58,7 +58,10 @@ def main():
     # wide-multiplier regimes and XSER dependence, small N
     for (log2n, dw, tw, fmt, new) in [(4, 24, 24, 1, True), (4, 30, 16, 1, True), (4, 30, 16, 1, False),
                                       (4, 44, 16, 1, True), (5, 32, 24, 1, True), (4, 14, 24, 1, True),
-                                      (4, 16, 18, 0, True)]:
+                                      (4, 16, 18, 0, True),
+                                      # trpl18 beyond its A port (SXT(M_AA, 61 | 59) cuts the operand, int_cmult_trpl18_dsp48.vhd:161-162),
+                                      # at the widest multiplier that elaborates with 16-bit twiddles (MAW + MBW = 80 | 78, :151-152)
+                                      (4, 64, 16, 0, True), (4, 62, 16, 0, False)]:
         x = frames_for(1 << log2n, dw, 7)
         for direction, dname in ((P.FWD, "FWD"), (P.INV, "INV")):
             y = np.array([P.execute(to_list(f), log2n, dw, tw, fmt, 0, new, direction) for f in x], dtype=np.int64)
@@ -106,6 +109,13 @@ def main():
             [-30000, 29999, 2965820, -2965820, 17, 24, True, "sngl25", -1, 42425],
             [-123456789, 98765432, 2965820, -2965820, 30, 24, True, "dbl35", -17459422, 157134796],
             [-123456789012, 98765432101, -2965820, -2965820, 40, 24, True, "trpl52", 157134797054, 17459421194],
+            # trpl18 beyond its A port (round 2, from reading int_cmult_trpl18_dsp48.vhd:161-162: dspA <= SXT(M_AA, 61 | 59) keeps the
+            # low 61 | 59 bits): 2^62 has none of them set -> the product is 0; 2^60 + 5 reads as -2^60 + 5 and -2^61 as 0;
+            # OLD: 2^58 + 7 reads as -2^58 + 7; a 61-bit operand passes unchanged
+            [4611686018427387904, 0, 32767, 0, 64, 16, True, "trpl18", 0, 0],
+            [1152921504606846981, -2305843009213693952, 30273, -12539, 64, 16, True, "trpl18", -1065136496245211132, 441176841621864446],
+            [288230376151711751, 3, 23170, -23170, 62, 16, False, "trpl18", -203805475324559353, 203805475324559357],
+            [576460752303423487, -576460752303423488, 32767, 0, 61, 16, True, "trpl18", 576443160117379071, -576443160117379072],
         ],
         "frames": [
             {"log2n": 3, "dw": 16, "tw": 16, "fmt": 0, "rnd": 0, "dir": "FWD",
