@@ -22,10 +22,19 @@ def _cases():
 def test_kit_expectations_equal_the_oracle():
     cases = _cases()
     assert {(c["case"], c["mode"]) for c in cases} >= {("single_n7", "TRUNCATE"), ("single_n7", "ROUNDING"), ("single_n7", "UNSCALED"),
-                                                       ("single_n12", "TRUNCATE"), ("pair_n7", "UNSCALED")}
+                                                       ("single_n12", "TRUNCATE"), ("pair_n7", "UNSCALED"),
+                                                       ("single_n7_w24t24", "UNSCALED"), ("single_n7_w30t16", "TRUNCATE"),
+                                                       ("single_n7_w30t16old", "TRUNCATE"), ("single_n7_w20t24", "ROUNDING"),
+                                                       ("single_n7_w14t24", "UNSCALED")}
+    regimes = set()
+    for c in cases:  # the kit reaches every multiplier family that fits a VHDL integer
+        for ii in range(c["nfft"]):
+            w = c.get("data_width", 16) + ii * c["format"] + c["format"]
+            regimes.add(C.cmult_regime(w, c.get("twdl_width", 16), c.get("xser", "NEW") == "NEW"))
+    assert {"sngl", "dbl18", "sngl25", "dbl35"} <= regimes
     for c in cases:
         n = 1 << c["nfft"]
-        p = C.make_params(c["nfft"], 16, 16, c["format"], c["rndmode"], True)
+        p = C.make_params(c["nfft"], c.get("data_width", 16), c.get("twdl_width", 16), c["format"], c["rndmode"], c.get("xser", "NEW") == "NEW")
         if c["tb"] == "tb_single_dump":
             x = textio.read_di_single(os.path.join(EXP, c["stimulus"]), n)
             got = textio.read_di_single(os.path.join(EXP, c["expected"]), n)

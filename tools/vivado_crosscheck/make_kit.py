@@ -8,6 +8,9 @@ Cases (each: one stimulus file + one expected dump per mode):
   single_n12    NFFT = 12 (first length whose STAGE 11 twiddles come from row_twiddle_tay): impulse at n = 1 (reads the
                 twiddle tables out), full-scale random, chirp
   pair_n7       NFFT = 7 int_fft_ifft_pair: di_double.dat beats, full-width expected output for FORMAT 0 and 1
+  single_n7_w24t24 / _w30t16 / _w30t16old / _w20t24 / _w14t24   NFFT = 7 at other widths, so that the other multiplier regimes meet the RTL too:
+                24 x 24 unscaled (sngl25 -> dbl35, 31-bit results), 30 x 16 scaled (dbl18; XSER NEW and OLD differ there),
+                20 x 24 scaled (dbl35), 14 x 24 unscaled (sngl25 -> dbl35).  Every value still fits a VHDL integer, which is what the testbench reads and writes.
 Modes: TRUNCATE (FORMAT 0, RNDMODE 0), ROUNDING (0, 1), UNSCALED (1, 0)  -- fft_signle_test.vhd:80-112.
 Everything is produced by the GPU engine through the C-ABI (intfftk_amd); the oracle is not involved.
 """
@@ -55,6 +58,24 @@ def main():
                                       "frames": int(x.shape[0]), "stimulus": "%s_di_single.dat" % name,
                                       "expected": "%s_expected_%s.dat" % (name, mode), "out_bits": core.out_bits})
             core.close()
+    for name, dw, tw, mode, xser in [("single_n7_w24t24", 24, 24, "UNSCALED", "NEW"), ("single_n7_w30t16", 30, 16, "TRUNCATE", "NEW"),
+                                     ("single_n7_w30t16old", 30, 16, "TRUNCATE", "OLD"), ("single_n7_w20t24", 20, 24, "ROUNDING", "NEW"),
+                                     ("single_n7_w14t24", 14, 24, "UNSCALED", "NEW")]:
+        from tests.helpers import edge_frames, uniform_frames
+
+        fmt, rnd = MODES[mode]
+        x = np.concatenate([edge_frames(128, dw), uniform_frames(8, 128, dw, 0x5EED + dw)])
+        textio.write_di_single(os.path.join(a.out, "%s_di_single.dat" % name), x)
+        core = int_fft_single_path(7, dw, tw, fmt, rnd, xser)
+        dt = {2: np.int16, 4: np.int32, 8: np.int64}[core.in_container]
+        y = core(torch.from_numpy(x.astype(dt)).cuda()).cpu().numpy()
+        assert core.out_bits <= 32
+        textio.write_di_single(os.path.join(a.out, "%s_expected_%s.dat" % (name, mode)), y)
+        manifest["cases"].append({"case": name, "tb": "tb_single_dump", "nfft": 7, "mode": mode, "format": fmt, "rndmode": rnd,
+                                  "data_width": dw, "twdl_width": tw, "xser": xser, "frames": int(x.shape[0]),
+                                  "stimulus": "%s_di_single.dat" % name, "expected": "%s_expected_%s.dat" % (name, mode),
+                                  "out_bits": core.out_bits})
+        core.close()
     x = frames_for(7, "full")
     textio.write_di_double(os.path.join(a.out, "pair_n7_di_double.dat"), x)
     for mode, (fmt, rnd) in [("TRUNCATE", (0, 0)), ("UNSCALED", (1, 0))]:
