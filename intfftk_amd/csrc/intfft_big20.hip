@@ -317,7 +317,8 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
                 v[r] = frame * G + (size_t)((16 * hx + r) >> (L - LOWB)) < nframes_user ? src[(size_t)(16 * hx + r) << LOWB] : 0u;
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = src[(size_t)(16 * hx + r) << LOWB]; // thread hx = n19..16, regs = n15..12
+            for (int r = 0; r < 16; ++r) // thread hx = n19..16, regs = n15..12; (two-pass split: non-temporal loads +3 %, three-pass: -2 %)
+                v[r] = LOWB == 8 ? __builtin_nontemporal_load(src + ((size_t)(16 * hx + r) << LOWB)) : src[(size_t)(16 * hx + r) << LOWB];
         }
         const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // also orders the previous LDS reads
         if (!FAST_OK) __syncthreads();
