@@ -10,7 +10,7 @@
 // bits {0..TB-1} of m_in (contiguous loads): 2^U elements, TB <= U <= 2 TB, through LDS -- the classic tiled bit reversal,
 // 256-byte runs on both sides for every pair of orders.  HBM-bound data movement, no arithmetic.
 #include "../../include/intfft.h"
-#include "intfft_internal.hpp"
+#include "intfft_pk16.hpp"
 
 #include <algorithm>
 
@@ -86,6 +86,7 @@ template <typename E> __global__ __launch_bounds__(256) void k_reorder(const E *
 // A block owns one tile and walks the frames part, part + fsplit, ...: its 16 twiddles per thread are evaluated once.
 struct TwArgs {
     int l2, mw, sh_a, sh_b, narrow, twd;
+    int packed; // int16 containers, 16-bit data, twiddles of at most 16 bits (single-DSP regime): the packed multiplier of intfft_pk16.hpp
 };
 template <typename E> struct ElemIO;
 template <> struct ElemIO<uint32_t> { // int16 containers
@@ -149,8 +150,22 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
             if (i < iters) {
                 const unsigned idx = TW == 1 ? (base_out | t_out | a.i_out[i]) : (base_in | t_in | a.i_in[i]);
                 tw2d_eval(a.L, scale, mg, ((idx >> w.l2) * (idx & m2)) & nmask, wr[i], wi[i]);
+                if (sizeof(E) == 4 && w.packed) { // forward: {Wa = (wr, -wi), Wb = (wi, wr)}; conjugate feed: {Wc = (wr, wi), Wd = (-wi, wr)}
+                    const unsigned r16 = (unsigned)wr[i] & 0xFFFFu, i16 = (unsigned)wi[i] & 0xFFFFu, n16 = (unsigned)(-wi[i]) & 0xFFFFu;
+                    const unsigned first = TW == 1 ? (r16 | (n16 << 16)) : (r16 | (i16 << 16));
+                    const unsigned second = TW == 1 ? (i16 | (r16 << 16)) : (n16 | (r16 << 16));
+                    wr[i] = (int)first, wi[i] = (int)second;
+                }
             }
     }
+    const Slice sl{w.twd - 1, w.twd, 0x05040100u, 0x07060302u};
+    // one sample through the packed multiplier: Y = sum[t+14 : t-1] of the two dot products (mul2x<16>, two samples per call)
+    auto pk_mul2 = [&](uint32_t &x0, uint32_t &x1, int i0, int i1) {
+        uint32_t y0, y1;
+        mul2x<16, false>(x0, x0, (uint32_t)wr[i0], (uint32_t)wi[i0], x1, x1, (uint32_t)wr[i1], (uint32_t)wi[i1], sl.off_y, sl.sel, y0, y1);
+        x0 = y0, x1 = y1;
+    };
+    (void)pk_mul2;
     for (size_t f = part; f < nframes; f += fsplit) {
         const E *src = in + (f << a.L) + base_in;
         E *dst = out + (f << a.L) + base_out;
@@ -158,10 +173,22 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
             if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in | a.i_in[i]));
+        if constexpr (TW == 2 && sizeof(E) == 4) {
+            if (w.packed && active) { // T.re = dot(V, Wc), T.im = dot(V, Wd): the swapped feed needs no swap in this packing
+#pragma unroll
+                for (unsigned i = 0; i < 16; i += 2)
+                    if (i < iters) {
+                        uint32_t x0 = (uint32_t)v[i], x1 = (uint32_t)v[(i + 1) & 15];
+                        pk_mul2(x0, x1, (int)i, (int)((i + 1) & 15));
+                        v[i] = (E)x0;
+                        if (i + 1 < iters) v[(i + 1) & 15] = (E)x1;
+                    }
+            }
+        }
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
             if (i < iters && active) {
-                if (TW == 2) { // swapped feed: DI_RE <- im, DI_IM <- re; DO_RE -> im, DO_IM -> re (int_dit2_fly.vhd:304-322)
+                if (TW == 2 && !(sizeof(E) == 4 && w.packed)) { // swapped feed: DI_RE <- im, DI_IM <- re; DO_RE -> im, DO_IM -> re (int_dit2_fly.vhd:304-322)
                     T re, im, ore, oim;
                     ElemIO<E>::get(v[i], re, im);
                     cmult(im, re, wr[i], wi[i], w.mw, w.sh_a, w.sh_b, w.narrow, ore, oim);
@@ -171,6 +198,21 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
                 lds[slot + (slot >> 5)] = v[i];
             }
         __syncthreads();
+        if constexpr (TW == 1 && sizeof(E) == 4) {
+            if (w.packed && active) {
+#pragma unroll
+                for (unsigned i = 0; i < 16; i += 2)
+                    if (i < iters) {
+                        const unsigned e0 = tid + 256u * i, e1 = tid + 256u * ((i + 1) & 15);
+                        uint32_t x0 = (uint32_t)lds[e0 + (e0 >> 5)], x1 = i + 1 < iters ? (uint32_t)lds[e1 + (e1 >> 5)] : 0u;
+                        pk_mul2(x0, x1, (int)i, (int)((i + 1) & 15));
+                        __builtin_nontemporal_store((E)x0, dst + (t_out | a.i_out[i]));
+                        if (i + 1 < iters) __builtin_nontemporal_store((E)x1, dst + (t_out | a.i_out[(i + 1) & 15]));
+                    }
+                __syncthreads();
+                continue;
+            }
+        }
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
             if (i < iters && active) {
@@ -321,7 +363,8 @@ hipError_t intfft::launch_bitperm_tw(int L, int container_bytes, const int *in_o
 {
     if (batch == 0) return hipSuccess;
     const ReorderArgs a = make_reorder_args(L, in_of_out);
-    const TwArgs w{l2, mw, sh_a, sh_b, narrow, twd};
+    static const int no_packed = getenv("INTFFT_2D_NO_PACKED_TW") ? 1 : 0; // A/B: the general multiplier on int16 containers too
+    const TwArgs w{l2, mw, sh_a, sh_b, narrow, twd, (container_bytes == 2 && mw == 16 && twd <= 16 && sh_a == 0 && sh_b == twd - 1 && !no_packed) ? 1 : 0};
     switch (container_bytes) {
     case 2: return launch_tw<uint32_t>(a, w, conj, d_in, d_out, batch, stream);
     case 4: return launch_tw<rv2u>(a, w, conj, d_in, d_out, batch, stream);
