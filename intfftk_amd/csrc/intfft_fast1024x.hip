@@ -20,6 +20,11 @@
 namespace intfft {
 
 constexpr int ROWX = 20;
+// Row r of the wave's 64 x 16 transpose tile starts at dword rowx(r): 20-dword rows (conflict-free b128 row reads) plus 16
+// dwords per block of 16 rows -- 16 * ROWX = 0 mod 64 banks, and the inverse core's column writes have the block number
+// (n9, n8) in lane bits: without the pad those four lanes share a bank (4-way conflict on every write).
+constexpr int XBLK = 16 * ROWX + 16, XWAVE = 4 * XBLK;
+__device__ __forceinline__ constexpr int rowx(int r) { return ROWX * r + 16 * (r >> 4); }
 
 enum { X_INV = 1, X_PAIR = 2 };
 
@@ -36,10 +41,10 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     static_assert(!ROUND || !FAST_OK, "round mode uses the exact extraction");
     constexpr int FP = 1 << (10 - L), NS = L - 6;        // frames per chunk; executed stages among 9..6
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
-    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROWX];
+    __shared__ __attribute__((aligned(16))) u32 lds_all[4 * XWAVE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u32 *lds = lds_all + wv * 64 * ROWX;
+    u32 *lds = lds_all + wv * XWAVE;
 
     // frame-invariant twiddles: stages 9..6 (reg offsets 8,4,2,1; index 64*jj + lane), 5 and 4
     RoundTw ta;
@@ -79,17 +84,17 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
     // lane3..0 = n3..0; reg j3 = n5, j2 = n4, j1 = n7, j0 = n6.   LC: reg = n3..0, lane bit i = n(9-i).
     // forward (mid -> LC): element (lane t, reg j) -> row = LC lane, column = n3..0
     const int t5 = lane >> 5, t4 = (lane >> 4) & 1;
-    u32 *wr_f = lds + ROWX * (t5 + 2 * t4) + (lane & 15); // + ROWX * (4 j1 + 8 j0 + 16 j3 + 32 j2)
+    u32 *wr_f = lds + ROWX * (t5 + 2 * t4) + (lane & 15); // + rowx(4 j1 + 8 j0 + 16 j3 + 32 j2)
     // inverse (LC -> mid): element (lane l, reg r) -> row = mid lane (32 n9 + 16 n8 + r), column = mid reg
     const int l0 = lane & 1, l1 = (lane >> 1) & 1, l2 = (lane >> 2) & 1, l3 = (lane >> 3) & 1, l4 = (lane >> 4) & 1,
               l5 = lane >> 5; // l_i = n(9-i)
     // NATURAL input: LC lane bit i = n(9-i).  BITREV input (memory index = n): LC lane = n9..n4 (bit i = n(4+i))
-    u32 *wr_i = in_bitrev ? lds + ROWX * (32 * l5 + 16 * l4) + ((l1 << 3) | (l0 << 2) | (l3 << 1) | l2)
-                          : lds + ROWX * (32 * l0 + 16 * l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
+    u32 *wr_i = in_bitrev ? lds + XBLK * (2 * l5 + l4) + ((l1 << 3) | (l0 << 2) | (l3 << 1) | l2)
+                          : lds + XBLK * (2 * l0 + l1) + ((l4 << 3) | (l5 << 2) | (l2 << 1) | l3); // + ROWX * r
     int lane_off = 0, lane_frame = 0; // short-frame inverse: see intfft_fast1024.hip
     if (L < 10 && MODE == X_INV && !in_bitrev) {
         auto a = [&](int k) { return (lane >> lane_bit<L>(k)) & 1; }; // LC lane bit lane_bit<L>(k) = a_k
-        wr_i = lds + ROWX * (32 * a(9) + 16 * a(8)) + ((a(5) << 3) | (a(4) << 2) | (a(7) << 1) | a(6));
+        wr_i = lds + XBLK * (2 * a(9) + a(8)) + ((a(5) << 3) | (a(4) << 2) | (a(7) << 1) | a(6));
         // while loading (before the swaps) lane bit 5 = a3 and lane bit 4 = a2
         lane_off = ((lane >> 5) & 1) * out_weight<L>(3) + ((lane >> 4) & 1) * out_weight<L>(2);
 #pragma unroll
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             if (k >= L) lane_frame += a(k) << (k - L);
         }
     }
-    const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + ROWX * lane);
+    const uint4 *rd_base = reinterpret_cast<const uint4 *>(lds + rowx(lane));
     const short s3 = (short)(1 - (lane >> 5)); // LC: kind = n4 = lane bit 5
     const v2s sh3 = {s3, s3};
 
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
             {                                                                                           \
                 const int j0 = j & 1, j1 = (j >> 1) & 1, j2 = (j >> 2) & 1, j3 = (j >> 3) & 1;          \
-                wr_f[ROWX * (4 * j1 + 8 * j0 + 16 * j3 + 32 * j2)] = v[j];                              \
+                wr_f[rowx(4 * j1 + 8 * j0 + 16 * j3 + 32 * j2)] = v[j];                                    \
             }                                                                                           \
             wave_lds_fence();                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \

@@ -48,16 +48,25 @@ constexpr int REGION4K = 256 * ROW4K; // dwords per transpose region
     }
 
 // The LC -> LB transpose (inverse core) writes row 16 * (n11..8) + r, column n7..4 with the lanes of a wave = (n11..8: 16 values,
-// n7..6: 4 values).  With 16-byte aligned rows (b128 reads) 16 * ROW4K = 0 mod 64 banks puts the 16 rows of a column on ONE
-// bank: 11x the bank conflicts of the forward kernel (PMC), 129 vs 112 us per 2^26 samples.  This one transpose therefore uses
-// rows of 17 dwords and 16 b32 reads: 16 * 17 = 16 mod 64 spreads a column over four banks (4-way instead of 16-way writes,
-// conflict-free reads), in the same region.
-constexpr int ROW17 = 17;
-#define INTFFT_X_READ17(region)                                                                        \
+// n7..6: 4 values).  With rows at ROW4K * row, 16 * ROW4K = 0 mod 64 banks puts the 16 rows of a column on ONE bank: 11x the
+// bank conflicts of the forward kernel (PMC), 129 vs 112 us per 2^26 samples.  This one transpose therefore packs the blocks
+// of 16 rows BLK_CB = 316 dwords apart (a block's last row needs no pad: 15 * 20 + 16) and stores column n7..4 at position
+// n6 + 2 n7 + 4 n4 + 8 n5: 316 = -4 mod 64, so the wave's 64 writes land on banks (n6 + 2 n7) - 4 (n11..8) + const -- all
+// distinct (N = 2048, where the wave holds n10..8 and n7..5: 2-way).  Rows stay 16-byte aligned for the b128 reads, whose
+// registers come back in the permuted order; 16 * 316 dwords fit the region.
+constexpr int BLK_CB = 316;
+#define INTFFT_X_READ_CB(region)                                                                       \
     {                                                                                                  \
         __syncthreads();                                                                               \
-        const u32 *rp = (region) + ROW17 * tid;                                                        \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) v[q] = rp[q];                                   \
+        const uint4 *rp = reinterpret_cast<const uint4 *>((region) + BLK_CB * (tid >> 4) + ROW4K * (tid & 15)); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+        {                                                                                              \
+            const uint4 x = rp[q];                                                                     \
+            v[q] = x.x;                                                                                \
+            v[q + 4] = x.y;                                                                            \
+            v[q + 8] = x.z;                                                                            \
+            v[q + 12] = x.w;                                                                           \
+        }                                                                                              \
     }
 
 // MODE_MID: the pair on one 4096-point block of a longer frame (middle pass of the N >= 8192 pair, intfft_big20.hip):
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
     u32 *const reg0 = lds, *const reg1 = lds + REGION4K;
-    volatile u32 *const s_unsafe = lds + (REGION4K - 1); // the last pad cell of region 0 (columns 16..19 are never transposed; beyond the 17-dword rows too)
+    volatile u32 *const s_unsafe = lds + (REGION4K - 1); // the last pad cell of region 0 (columns 16..19 are never transposed; beyond the 16 x 316 dwords of the LC -> LB transpose too)
     const int tid = threadIdx.x;
     const int lo4 = tid & 15, hi4 = tid >> 4;
 
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     // LC -> LB: thread t'' , reg r = n3..0 -> row = LB thread 16 * (n11..8) + r, column = LB register n7..4
     auto nb = [&](int k) { return (tid >> lc_bit<L, OB>(k)) & 1; };
     const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
-    const int w_cb = ROW17 * 16 * lb_hi + lb_reg; // rows of 17 dwords (see INTFFT_X_READ17)
+    const int w_cb = BLK_CB * lb_hi + (lb_reg >> 2) + 4 * (lb_reg & 3); // see INTFFT_X_READ_CB
     // per-thread shift amounts where the value kind depends on a thread bit after a transpose
     const short shb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
     const short shc = (short)(1 - nb(4));     // LC: kind = n4
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             }                                                                                           \
         } else {                                                                                        \
             dit_round_c<FX, ROUND, DP>(v, c, sl);                                                       \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW17 * r] = v[r];               \
-            INTFFT_X_READ17(reg0)                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
+            INTFFT_X_READ_CB(reg0)                                                                      \
             dit_round<FX, 4, ROUND, DP>(v, tb, sl);                                                     \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \

@@ -301,17 +301,32 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
     // LC thread t'' carries n_k on bit lcx_bit<L>(k); LC -> LB: row = LB thread 16 (n11..8) + r, column = n7..4
     auto nb = [&](int k) { return (tid >> lcx_bit<L>(k)) & 1; };
     const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
-    u32 *const w_cb = lds + ROW4X * 16 * lb_hi + lb_reg;
+    // blocks of 16 rows 316 dwords apart and columns in the order n6 + 2 n7 + 4 n4 + 8 n5: the wave's 64 writes (n11..8, n7..6
+    // in its lane bits) go to 64 different banks -- with blocks at 16 * ROW4X = 0 mod 64 they shared four (intfft_fast4096.hip)
+    constexpr int BLK_CB = 316;
+    u32 *const w_cb = lds + BLK_CB * lb_hi + (lb_reg >> 2) + 4 * (lb_reg & 3);
     // LB -> LA: element (thread (n11..8 = hi4, n3..0 = lo4), reg n7..4) -> row n7..0 = 16 j' + lo4, column n11..8 = hi4
     u32 *const w_ba = lds + ROW4X * lo4 + hi4;
     const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROW4X * tid);
     const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANE4X + ROW4X * tid);
+    const uint4 *const rc0 = reinterpret_cast<const uint4 *>(lds + BLK_CB * hi4 + ROW4X * lo4);
+    const uint4 *const rc1 = reinterpret_cast<const uint4 *>(lds + PLANE4X + BLK_CB * hi4 + ROW4X * lo4);
     int lc_off = 0, lc_frame = 0;
 #pragma unroll
     for (int k = 4; k < 12; ++k) {
         lc_off += nb(k) * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
         if (k >= L) lc_frame += nb(k) << (k - L);
     }
+    auto transpose_read_cb = [&](int (&re)[16], int (&im)[16]) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rc0[q], y = rc1[q];
+            re[q] = (int)x.x, re[q + 4] = (int)x.y, re[q + 8] = (int)x.z, re[q + 12] = (int)x.w;
+            im[q] = (int)y.x, im[q + 4] = (int)y.y, im[q + 8] = (int)y.z, im[q + 12] = (int)y.w;
+        }
+        __syncthreads();
+    };
     auto transpose_read = [&](int (&re)[16], int (&im)[16]) {
         __syncthreads();
 #pragma unroll
@@ -355,7 +370,7 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
             w_cb[ROW4X * r] = (u32)re[r];
             w_cb[PLANE4X + ROW4X * r] = (u32)im[r];
         }
-        transpose_read(re, im); // LB: regs = n7..4
+        transpose_read_cb(re, im); // LB: regs = n7..4
         ground_dit<MODE, MASKED, 12, 4>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
