@@ -47,8 +47,12 @@ __device__ __forceinline__ void ground(int (&re)[16], int (&im)[16], const int (
     for (int g = 0; g < 16; g += 2) gfly<MODE, false, MASKED>(re[g], im[g], re[g + 1], im[g + 1], w1r, w1i, a.st[S0]);
 }
 
-template <int L, int MODE, bool MASKED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// OUT64 (unscaled only): 0 = results within 32 bits; 1 = 33 / 34-bit results (stages 1, 0 in 64 bits); 2 = up to 40 bits (the
+// whole last round in 64 bits).  A template parameter, not a runtime branch: the 64-bit rounds hold 64 more live dwords, and
+// compiled into the 32-bit kernel they cost it 120 spilled dwords per lane under the 128-VGPR cap of four waves per SIMD
+// (16-bit unscaled N = 4096: 139 Gsample/s).  The 64-bit variants run three waves per SIMD instead.
+template <int L, int MODE, bool MASKED, int OUT64>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OUT64 ? 3 : 4, OUT64 ? 3 : 4)))
 void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
                    size_t nframes_user)
 {
@@ -147,7 +151,7 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
             w_bc[PLANE4W + ROW4W * lcw_row_of_reg<L>(j)] = (u32)im[j];
         }
         transpose_read(re, im);
-        if (MODE == W_UNSCALED && a.out64 == 2) { // 35 / 36-bit results: the whole round LC in 64 bits (gfly64, intfft_u32.hpp)
+        if constexpr (MODE == W_UNSCALED && OUT64 == 2) { // 35 / 36-bit results: the whole round LC in 64 bits (gfly64, intfft_u32.hpp)
             long long xr[16], xi[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) xr[r] = re[r], xi[r] = im[r];
@@ -176,7 +180,7 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
-        if (MODE == W_UNSCALED && a.out64) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
+        if constexpr (MODE == W_UNSCALED && OUT64 == 1) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
             long long xr[16], xi[16];
             tail64_unscaled(re, im, xr, xi);
             if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
@@ -229,13 +233,13 @@ bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, 
 
 const char *fast4096w_kernel_name() { return "k_fft4096_w32"; }
 
-template <int L, int MODE, bool MASKED>
+template <int L, int MODE, bool MASKED, int OUT64 = 0>
 static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                            hipStream_t stream)
 {
-    const size_t cap = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED, OUT64>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
-    hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
+    hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED, OUT64>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
                        tw, c, a, nframes);
     return hipGetLastError();
 }
@@ -248,13 +252,19 @@ static hipError_t launch4w_l(int mode, const void *in, void *out, const int2 *tw
         switch (mode) {
         case W_TRUNC: return launch4w<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
         case W_ROUND: return launch4w<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
-        default: return launch4w<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+        default:
+            return a.out64 == 2   ? launch4w<L, W_UNSCALED, true, 2>(in, out, tw, c, a, nframes, stream)
+                   : a.out64 == 1 ? launch4w<L, W_UNSCALED, true, 1>(in, out, tw, c, a, nframes, stream)
+                                  : launch4w<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
         }
     }
     switch (mode) {
     case W_TRUNC: return launch4w<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
     case W_ROUND: return launch4w<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
-    default: return launch4w<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
+    default:
+        return a.out64 == 2   ? launch4w<L, W_UNSCALED, false, 2>(in, out, tw, c, a, nframes, stream)
+               : a.out64 == 1 ? launch4w<L, W_UNSCALED, false, 1>(in, out, tw, c, a, nframes, stream)
+                              : launch4w<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
     }
 }
 
