@@ -155,8 +155,10 @@ __device__ __forceinline__ void uinverse(int (&re)[16], int (&im)[16], const int
     }
 }
 
+// four waves per SIMD (the 40 KiB of LDS admit four workgroups): without the hint the N = 256 pair takes 172 VGPRs
+// (116 with it, no spills: 289 -> 310 Gsample/s); the other instantiations are unchanged within noise
 template <int L, int MODE, bool FAST_OK>
-__global__ __launch_bounds__(256) void k_fft1024ux_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4 : 2))) void k_fft1024ux_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt,
                                                        const UConsts c, const UxArgs a, size_t nframes_user, int sh)
 {
     constexpr int FP = 1 << (10 - L);

@@ -16,7 +16,9 @@
 
 namespace intfft {
 
-template <int L, int MODE, bool MASKED>
+// OUT64 (L = 10, unscaled): 33 / 34-bit results, stages 1, 0 in 64 bits -- a template parameter, so that the 32-bit unscaled
+// kernel does not carry the 64-bit tail's registers (192 VGPRs with the runtime branch, two waves per SIMD)
+template <int L, int MODE, bool MASKED, bool OUT64 = false>
 __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
                                                      const W32Args a, size_t nframes_user)
 {
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
         for (int g = 0; g < 16; g += 8)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gfly<MODE, true, MASKED>(re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r], a.st[2]);
-        if (L == 10 && MODE == W_UNSCALED && a.out64) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
+        if constexpr (L == 10 && MODE == W_UNSCALED && OUT64) { // 33 / 34-bit results: stages 1, 0 in 64 bits, int64 containers
             long long xr[16], xi[16];
             tail64_unscaled(re, im, xr, xi);
             typedef long long v2l __attribute__((ext_vector_type(2)));
@@ -246,14 +248,14 @@ bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, in
 
 const char *fastw32_kernel_name() { return "k_fft1024_w32"; }
 
-template <int L, int MODE, bool MASKED>
+template <int L, int MODE, bool MASKED, bool OUT64 = false>
 static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                           hipStream_t stream)
 {
-    const size_t cap = resident_blocks(kptr(k_fft1024_w32<L, MODE, MASKED>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft1024_w32<L, MODE, MASKED, OUT64>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4;
-    hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+    hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED, OUT64>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
                        c, a, nframes);
     return hipGetLastError();
 }
@@ -266,13 +268,19 @@ static hipError_t launchw_l(int mode, const void *in, void *out, const int2 *tw,
         switch (mode) {
         case W_TRUNC: return launchw<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
         case W_ROUND: return launchw<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
-        default: return launchw<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+        default:
+            if constexpr (L == 10)
+                if (a.out64) return launchw<L, W_UNSCALED, true, true>(in, out, tw, c, a, nframes, stream);
+            return launchw<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
         }
     }
     switch (mode) {
     case W_TRUNC: return launchw<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
     case W_ROUND: return launchw<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
-    default: return launchw<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
+    default:
+        if constexpr (L == 10)
+            if (a.out64) return launchw<L, W_UNSCALED, false, true>(in, out, tw, c, a, nframes, stream);
+        return launchw<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
     }
 }
 
