@@ -113,7 +113,9 @@ template <> struct ElemIO<rv4u> { // int64 containers
     }
 };
 
-template <typename E, int TW>
+// PK (int16 containers only): the packed multiplier (TwArgs::packed) -- a template parameter, because both multipliers compiled
+// into one kernel cost it 161 VGPRs (three waves per SIMD); the packed kernel alone takes half of that.
+template <typename E, int TW, bool PK = false>
 __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const ReorderArgs a, const TwArgs w, unsigned tiles, unsigned fsplit,
                                                     size_t nframes)
 {
@@ -150,12 +152,13 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
             if (i < iters) {
                 const unsigned idx = TW == 1 ? (base_out | t_out | a.i_out[i]) : (base_in | t_in | a.i_in[i]);
                 tw2d_eval(a.L, scale, mg, ((idx >> w.l2) * (idx & m2)) & nmask, wr[i], wi[i]);
-                if (sizeof(E) == 4 && w.packed) { // forward: {Wa = (wr, -wi), Wb = (wi, wr)}; conjugate feed: {Wc = (wr, wi), Wd = (-wi, wr)}
+                if constexpr (PK) { // forward: {Wa = (wr, -wi), Wb = (wi, wr)}; conjugate feed: {Wc = (wr, wi), Wd = (-wi, wr)}
                     const unsigned r16 = (unsigned)wr[i] & 0xFFFFu, i16 = (unsigned)wi[i] & 0xFFFFu, n16 = (unsigned)(-wi[i]) & 0xFFFFu;
                     const unsigned first = TW == 1 ? (r16 | (n16 << 16)) : (r16 | (i16 << 16));
                     const unsigned second = TW == 1 ? (i16 | (r16 << 16)) : (n16 | (r16 << 16));
                     wr[i] = (int)first, wi[i] = (int)second;
                 }
+                __builtin_amdgcn_sched_barrier(0); // one evaluation at a time: interleaved, the 16 double-precision chains set the kernel's VGPR count
             }
     }
     const Slice sl{w.twd - 1, w.twd, 0x05040100u, 0x07060302u};
@@ -169,12 +172,16 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
     for (size_t f = part; f < nframes; f += fsplit) {
         const E *src = in + (f << a.L) + base_in;
         E *dst = out + (f << a.L) + base_out;
+        // opaque copies of the loop-invariant thread offsets: otherwise LICM keeps 32 64-bit addresses (64 VGPRs) across the
+        // frame loop; recomputing one costs an OR and the address add
+        unsigned t_in_l = t_in, t_slot_l = t_slot, t_out_l = t_out;
+        asm volatile("" : "+v"(t_in_l), "+v"(t_slot_l), "+v"(t_out_l));
         E v[16];
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
-            if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in | a.i_in[i]));
-        if constexpr (TW == 2 && sizeof(E) == 4) {
-            if (w.packed && active) { // T.re = dot(V, Wc), T.im = dot(V, Wd): the swapped feed needs no swap in this packing
+            if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in_l | a.i_in[i]));
+        if constexpr (TW == 2 && PK) {
+            if (active) { // T.re = dot(V, Wc), T.im = dot(V, Wd): the swapped feed needs no swap in this packing
 #pragma unroll
                 for (unsigned i = 0; i < 16; i += 2)
                     if (i < iters) {
@@ -188,43 +195,43 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
             if (i < iters && active) {
-                if (TW == 2 && !(sizeof(E) == 4 && w.packed)) { // swapped feed: DI_RE <- im, DI_IM <- re; DO_RE -> im, DO_IM -> re (int_dit2_fly.vhd:304-322)
+                if constexpr (TW == 2 && !PK) { // swapped feed: DI_RE <- im, DI_IM <- re; DO_RE -> im, DO_IM -> re (int_dit2_fly.vhd:304-322)
                     T re, im, ore, oim;
                     ElemIO<E>::get(v[i], re, im);
                     cmult(im, re, wr[i], wi[i], w.mw, w.sh_a, w.sh_b, w.narrow, ore, oim);
                     v[i] = ElemIO<E>::put(oim, ore);
                 }
-                const unsigned slot = t_slot | a.i_slot[i];
+                const unsigned slot = t_slot_l | a.i_slot[i];
                 lds[slot + (slot >> 5)] = v[i];
             }
         __syncthreads();
-        if constexpr (TW == 1 && sizeof(E) == 4) {
-            if (w.packed && active) {
+        if constexpr (TW == 1 && PK) {
+            if (active) {
 #pragma unroll
                 for (unsigned i = 0; i < 16; i += 2)
                     if (i < iters) {
                         const unsigned e0 = tid + 256u * i, e1 = tid + 256u * ((i + 1) & 15);
                         uint32_t x0 = (uint32_t)lds[e0 + (e0 >> 5)], x1 = i + 1 < iters ? (uint32_t)lds[e1 + (e1 >> 5)] : 0u;
                         pk_mul2(x0, x1, (int)i, (int)((i + 1) & 15));
-                        __builtin_nontemporal_store((E)x0, dst + (t_out | a.i_out[i]));
-                        if (i + 1 < iters) __builtin_nontemporal_store((E)x1, dst + (t_out | a.i_out[(i + 1) & 15]));
+                        __builtin_nontemporal_store((E)x0, dst + (t_out_l | a.i_out[i]));
+                        if (i + 1 < iters) __builtin_nontemporal_store((E)x1, dst + (t_out_l | a.i_out[(i + 1) & 15]));
                     }
-                __syncthreads();
-                continue;
             }
+            __syncthreads();
+            continue;
         }
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
             if (i < iters && active) {
                 const unsigned e = tid + 256u * i;
                 E x = lds[e + (e >> 5)];
-                if (TW == 1) {
+                if constexpr (TW == 1 && !PK) {
                     T re, im, ore, oim;
                     ElemIO<E>::get(x, re, im);
                     cmult(re, im, wr[i], wi[i], w.mw, w.sh_a, w.sh_b, w.narrow, ore, oim);
                     x = ElemIO<E>::put(ore, oim);
                 }
-                __builtin_nontemporal_store(x, dst + (t_out | a.i_out[i]));
+                __builtin_nontemporal_store(x, dst + (t_out_l | a.i_out[i]));
             }
         __syncthreads(); // the next frame's LDS writes wait for these reads
     }
@@ -344,15 +351,20 @@ static hipError_t launch_tw(const ReorderArgs &a, const TwArgs &w, int conj, con
     unsigned fsplit = 1; // blocks per tile: enough blocks to fill the chip, as many frames per block as that leaves
     const size_t want = (size_t)device_cus() * 8;
     while ((size_t)tiles * fsplit < want && (size_t)fsplit * 2 <= batch) fsplit *= 2;
-    if (conj) {
-        if (lds > 48 * 1024) allow_max_lds(kptr(k_reorder_tw<E, 2>));
-        hipLaunchKernelGGL((k_reorder_tw<E, 2>), dim3(tiles * fsplit), dim3(256), lds, stream, static_cast<const E *>(in), static_cast<E *>(out),
-                           a, w, tiles, fsplit, batch);
-    } else {
-        if (lds > 48 * 1024) allow_max_lds(kptr(k_reorder_tw<E, 1>));
-        hipLaunchKernelGGL((k_reorder_tw<E, 1>), dim3(tiles * fsplit), dim3(256), lds, stream, static_cast<const E *>(in), static_cast<E *>(out),
-                           a, w, tiles, fsplit, batch);
+    auto go = [&](auto kernel) {
+        if (lds > 48 * 1024) allow_max_lds(kptr(kernel));
+        hipLaunchKernelGGL(kernel, dim3(tiles * fsplit), dim3(256), lds, stream, static_cast<const E *>(in), static_cast<E *>(out), a, w,
+                           tiles, fsplit, batch);
+    };
+    if constexpr (sizeof(E) == 4) {
+        if (w.packed) {
+            if (conj) go(k_reorder_tw<E, 2, true>);
+            else go(k_reorder_tw<E, 1, true>);
+            return hipGetLastError();
+        }
     }
+    if (conj) go(k_reorder_tw<E, 2>);
+    else go(k_reorder_tw<E, 1>);
     return hipGetLastError();
 }
 
