@@ -164,15 +164,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         if (k >= L) lc_frame += nb(k) << (k - L);
     }
 
-    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
-        u32 v[16];
+    // OB: x4 unit index of the lane's vector q = (n9 n8): (n11 n10 | q | n7..n4 | n3 n2); its frame = n11..nL
+    const int ob_unit = ((tid >> 6) << 8) | ((tid & 15) << 2) | ((tid >> 4) & 3);
+    auto load_frame = [&](u32(&v)[16], size_t f) { // global loads only (the prefetch below keeps them in flight)
         const u32 *src = in + f * 4096;
-        u32 *dst = out + f * 4096;
         const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
         const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
-        // OB: x4 unit index of the lane's vector q = (n9 n8): (n11 n10 | q | n7..n4 | n3 n2); its frame = n11..nL
-        const int ob_unit = ((tid >> 6) << 8) | ((tid & 15) << 2) | ((tid >> 4) & 3);
-        if (MODE == MODE_INV && OB) { // memory index = n: x4 loads (regs n9 n8 n1 n0), two lane swaps -> regs n3..0
+        if (MODE == MODE_INV && OB) { // memory index = n: x4 loads (regs n9 n8 n1 n0); two lane swaps follow
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const v4u *s4 = reinterpret_cast<const v4u *>(src) + ob_unit;
 #pragma unroll
@@ -181,16 +179,15 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                 if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) x = __builtin_nontemporal_load(s4 + 64 * q);
                 v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
             }
+        } else if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame (one test around the 16 loads:
+            // tested one by one they are issued one by one)
+            if (lc_ok) {
 #pragma unroll
-            for (int g = 0; g < 16; g += 8)
+                for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + (rev4c(r) << (L - 4)) + lc_off);
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
-        } else if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                v[r] = lc_ok ? __builtin_nontemporal_load(src + (rev4c(r) << (L - 4)) + lc_off) : 0u;
+                for (int r = 0; r < 16; ++r) v[r] = 0u;
+            }
         } else if (MODE == MODE_FWD && halves) {
             // HALVES: beat q = 256 jj + tid of the chunk holds (x[i], x[i + N/2]) of frame q >> (L-1): thread tid of the
             // LA registers j0 = (frame << (L-8)) | (i >> 8) and j0 | 2^(L-9)
@@ -205,12 +202,41 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                 v[j0] = w.x;
                 v[j0 | HB] = w.y;
             }
-        } else { // LA: v[j] = x[256 j + tid]
+        } else if (!partial) { // LA: v[j] = x[256 j + tid]
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 256 * j + tid);
+        } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)
-                           ? __builtin_nontemporal_load(src + 256 * j + tid)
-                           : 0u;
+                v[j] = f * FP + (size_t)((256 * j + tid) >> L) < nframes_user ? __builtin_nontemporal_load(src + 256 * j + tid) : 0u;
+        }
+    };
+    // Round mode, one core, N = 4096: the workgroup's next frame is loaded into 16 more registers while this one is computed (the
+    // barriers of the transposes wait for LDS only, so the loads stay in flight): +5..7 %.  The truncate-mode kernels gain nothing
+    // from it (and the N = 2048 ones pass 128 VGPRs with it), the pair has no registers to spare.
+    constexpr bool PIPE = ROUND && L == 12 && (MODE == MODE_FWD || MODE == MODE_INV);
+    u32 pre[16];
+    if (PIPE && blockIdx.x < nframes) load_frame(pre, blockIdx.x);
+
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        u32 v[16];
+        u32 *dst = out + f * 4096;
+        const bool partial = L < 12 && (f + 1) * FP > nframes_user;
+        const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
+        if (PIPE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = pre[j];
+            if (f + gridDim.x < nframes) load_frame(pre, f + gridDim.x);
+        } else {
+            load_frame(v, f);
+        }
+        if (MODE == MODE_INV && OB) { // -> regs n3..0
+#pragma unroll
+            for (int g = 0; g < 16; g += 8)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
         }
 
         // guard-bit test of the whole frame (block-uniform)
