@@ -332,10 +332,16 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     auto run = [&](u32(&v)[16], size_t f) {
         // partial last chunk: natural order -> per-lane predicate; BITREV order -> "chunk is full" + the frame count
         const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
-        if (FAST_OK && frame_has_guard_bit(v))
+        if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) {
             transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-        else // a FAST_OK kernel is launched for 16-bit twiddles only: its exact path is the t = 16 form (mul2x_t16)
+        } else if (sl.wd == 16) { // a FAST_OK kernel is launched for 16-bit twiddles only: its exact path is the t = 16 form (mul2x_t16)
             transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+        } else { // DATA_WIDTH < 16 (truncate mode): containers wrapped to w bits, w-bit exact extraction
+            if constexpr (!ROUND) {
+                wrap_inputs(v, sl.wd);
+                transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+            }
+        }
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0
@@ -396,11 +402,16 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     }
 }
 
+bool packed_width_ok(int data_width, int format, int rndmode)
+{
+    static const bool narrow = getenv("INTFFT_NO_NARROW16") == nullptr;
+    return data_width == 16 || (narrow && data_width >= 9 && data_width <= 15 && format == 0 && rndmode == 0);
+}
+
 bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
                         int use_fly, int in_order, int out_order)
 {
-    (void)rndmode;
-    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && direction == 0 && use_fly == 1))
+    if (!(packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && direction == 0 && use_fly == 1))
         return false;
     // N >= 128: NATURAL or HALVES (native int_fftNk beats) in, NATURAL or BITREV (native) out; N = 64: natural only
     if (log2n >= 7 && log2n <= 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
@@ -480,7 +491,8 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    const Slice sl{a.twd - 1, a.twd, 0x05040100u, 0x07060302u};
+    Slice sl{a.twd - 1, a.twd, 0x05040100u, 0x07060302u};
+    if (a.dw != 16) sl.set_width(a.dw);
     const bool fast_ok = a.twd == 16; // high halves == bits [31:16] only for t = 16
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j + lane);
         }
-        const bool fast = FAST_OK && frame_has_guard_bit(v);
+        const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask);
+        if (!ROUND && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact path)
 
 #define INTFFT_XBODY(FX)                                                                                \
     {                                                                                                   \
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
                          int use_fly, int in_order, int out_order)
 {
-    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
+    if (!(packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
     if (rndmode && (in_order != 0 || out_order != 0 || getenv("INTFFT_NO_PACKED_ROUND"))) return false; // ROUNDING: natural order
     if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
@@ -290,7 +291,7 @@ static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *po
 }
 
 hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
-                            const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream, int round)
+                            const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream, int round, int data_width)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -305,7 +306,8 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
     if (direction == 1 || !round) to_dit_packing_host(c); // kernels with DP (see k_fft1024x_i16) hold their twiddles in the DIT packing
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         if (FAST_OK) {
             if (tid == 0) *s_unsafe = 0;
             __syncthreads();
-            bool bad = guard_acc(v) != 0;
+            bool bad = guard_acc(v, sl.gbias, sl.gmask) != 0;
             if (MODE == MODE_MID && (f & 1)) { // Y >> 1 inputs: |v| < 2^13
                 u32 acc = 0;
 #pragma unroll
@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             __syncthreads();
             fast = *s_unsafe == 0;
         }
+        if (!ROUND && MODE != MODE_MID && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits
 
 #define INTFFT_BODY(FX)                                                                                 \
     {                                                                                                   \
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order)
 {
-    if (!((log2n == 12 || log2n == 11) && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
+    if (!((log2n == 12 || log2n == 11) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
     if (rndmode) return in_order == 0 && out_order == 0 && !getenv("INTFFT_NO_PACKED_ROUND"); // ROUNDING: natural order, all three directions
     if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
@@ -399,7 +400,7 @@ static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *p
 }
 
 hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream, int round)
+                           size_t nframes, hipStream_t stream, int round, int data_width)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -414,7 +415,8 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
     if (direction == 1 || (direction == 2 && !round)) to_dit_packing_host(c); // kernels with DP (see k_fft4096_i16) hold the DIT packing
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);

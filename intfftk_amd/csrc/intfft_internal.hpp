@@ -104,7 +104,11 @@ template <int L> __host__ __device__ constexpr int lane_bit(int k)
 template <int L> __host__ __device__ constexpr int out_weight(int k) { return k >= L ? (1 << k) : (1 << (L - 1 - k)); }
 
 // packed int16 wave kernel for N = 1024 (intfft_fast1024.hip)
+// DATA_WIDTH of the packed int16 kernels (intfft_fast1024*.hip, intfft_fast4096.hip): 16, or 9 .. 15 in truncate mode -- narrow data
+// runs in the same 16-bit lanes (Slice::set_width, intfft_pk16.hpp); INTFFT_NO_NARROW16 sends it back to the 32-bit kernels
+bool packed_width_ok(int data_width, int format, int rndmode);
 struct Fast1024Args {
+    int dw = 16;    // DATA_WIDTH (9 .. 16)
     int log2n;      // 6..10: frames shorter than 1024 samples share a wave (2^(10 - log2n) per pass)
     int twd;        // twiddle width (<= 16)
     int rnd;        // RoundKind (RND_TRUNC / RND_ROUND)
@@ -123,7 +127,7 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
                          int use_fly, int in_order, int out_order);
 hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, int out_halves, const void *in, void *out,
                             const int2 *tw_all, const int2 *h_tw,
-                            size_t nframes, hipStream_t stream, int round = 0);
+                            size_t nframes, hipStream_t stream, int round = 0, int data_width = 16);
 const char *fast1024x_kernel_name();
 
 // unscaled int32 wave kernel for N = 1024, 16-bit in -> 26-bit out (intfft_fast1024u.hip)
@@ -240,7 +244,7 @@ hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, 
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order);
 hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream, int round = 0);
+                           size_t nframes, hipStream_t stream, int round = 0, int data_width = 16);
 const char *fast4096_kernel_name();
 
 } // namespace intfft

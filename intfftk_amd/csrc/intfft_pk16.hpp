@@ -16,10 +16,23 @@ __device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x)
 
 // result slicing of the exact 32-bit sums (t = TWDL_WIDTH)
 struct Slice {
-    int off_y;  // t - 1: Y      = sum[t+14 : t-1]
-    int off_y1; // t    : Y >> 1 = sext(sum[t+14 : t])
+    int off_y;  // t - 1: Y      = sum[t+w-2 : t-1]
+    int off_y1; // t    : Y >> 1 = sext(sum[t+w-2 : t])
     u32 sel;    // v_perm_b32 selector {S0.b1, S0.b0, S1.b1, S1.b0} (exact extraction)
     u32 sel_hi; // v_perm_b32 selector {S0.b3, S0.b2, S1.b3, S1.b2} (fast extraction)
+    // DATA_WIDTH w = 9 .. 16 in int16 containers (set_width()).  Narrow data runs in the same 16-bit lanes: sums and differences of
+    // sign-extended w-bit values are exact there, the exact extraction takes w (or w - 1) bits of the dot products -- the RTL's
+    // w-bit wrap, then sign-extended -- and the guard-bit test of the fast path scales to |re|, |im| < 2^(w-2).
+    int wd = 16;             // width of the exact extraction (v_bfe_i32)
+    u32 gbias = 0x40004000u; // guard test: (x + gbias) & gmask == 0 for both halves <=> -2^(w-2) <= re, im < 2^(w-2)
+    u32 gmask = 0x80008000u;
+    __host__ __device__ void set_width(int w)
+    {
+        wd = w;
+        const u32 b = 1u << (w - 2), m = (0xFFFFu << (w - 1)) & 0xFFFFu;
+        gbias = b | (b << 16);
+        gmask = m | (m << 16);
+    }
 };
 
 __device__ __forceinline__ u32 pack_wa(int2 w) { return ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16); }
@@ -77,21 +90,24 @@ template <bool SW = false> __device__ __forceinline__ void sumdiff_var(u32 a, u3
     "v_perm_b32 %[y1], %[i0], %[y1], %[sel]"
 
 // exact extraction, 2 butterflies: (off, WIDTH) = (t-1, 16) -> Y, (t, 15) -> Y >> 1
+// The width comes in a VGPR (two SGPR operands exceed gfx9's constant-bus limit): w for Y, w - 1 for Y >> 1, w = Slice::wd
 template <int WIDTH, bool SG>
 __device__ __forceinline__ void mul2x(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr1, u32 di1, u32 wa1, u32 wb1,
-                                      int off, u32 sel, u32 &y0, u32 &y1)
+                                      int off, u32 sel, u32 &y0, u32 &y1, int wd_full = 16)
 {
+    static_assert(WIDTH == 16 || WIDTH == 15, "Y or Y >> 1");
+    const int wdv = wd_full - (16 - WIDTH);
     u32 r0, i0, r1, i1;
     if (SG)
         asm(INTFFT_MUL2X_BODY
             : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
             : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "s"(wa0), [wb0] "s"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
-              [wa1] "s"(wa1), [wb1] "s"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+              [wa1] "s"(wa1), [wb1] "s"(wb1), [off] "s"(off), [wd] "v"(wdv), [sel] "s"(sel));
     else
         asm(INTFFT_MUL2X_BODY
             : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
             : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
-              [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "n"(WIDTH), [sel] "s"(sel));
+              [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "v"(wdv), [sel] "s"(sel));
 }
 
 // exact extraction of Y >> 1 for t = 16 without v_bfe: Y >> 1 = sext(sum[30:16]) is the high half of the sum with its bit 15
@@ -207,9 +223,9 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
             mul2x_t16<SG>(d[2], n[2], wb[2], wa[2], d[3], n[3], wb[3], wa[3], sl.sel_hi, y[2], y[3]);
         } else {
             mul2x<OUT_PRE ? 15 : 16, SG>(d[0], n[0], wb[0], wa[0], d[1], n[1], wb[1], wa[1],
-                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1], sl.wd);
             mul2x<OUT_PRE ? 15 : 16, SG>(d[2], n[2], wb[2], wa[2], d[3], n[3], wb[3], wa[3],
-                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3], sl.wd);
         }
     } else {
         if (FASTX == 1) {
@@ -219,9 +235,9 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
             mul2x_t16<SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.sel_hi, y[2], y[3]);
         } else {
             mul2x<OUT_PRE ? 15 : 16, SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1],
-                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1]);
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[0], y[1], sl.wd);
             mul2x<OUT_PRE ? 15 : 16, SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3],
-                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3]);
+                                         OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3], sl.wd);
         }
     }
     b0 = y[0];
@@ -280,16 +296,26 @@ __device__ __forceinline__ void swap_guard(u32 (&v)[16])
 // and |re|, |im| of D*W are <= 23188 * 32767.71 < 2^30: bit 31 equals bit 30 in every sum, which is
 // what fast extraction needs.  (The bound that would actually be needed is M <= 32752.)
 // guard_acc(): per-lane accumulator; a frame is safe iff no lane of any of its waves has a flagged bit
-__device__ __forceinline__ u32 guard_acc(const u32 (&v)[16])
+// Narrow data (Slice::set_width): the same argument scaled to w bits -- |z| <= 2^(w-1.5), M <= that + 17 through twelve stages,
+// needed M < 2^(w-1) - 16: holds for w >= 9.
+__device__ __forceinline__ u32 guard_acc(const u32 (&v)[16], u32 gbias = 0x40004000u, u32 gmask = 0x80008000u)
 {
     u32 acc = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc |= v[j] + 0x40004000u;
-    return acc & 0x80008000u;
+    for (int j = 0; j < 16; ++j) acc |= v[j] + gbias;
+    return acc & gmask;
 }
-__device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16])
+__device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16], u32 gbias = 0x40004000u, u32 gmask = 0x80008000u)
 {
-    return __builtin_amdgcn_ballot_w64(guard_acc(v) != 0) == 0;
+    return __builtin_amdgcn_ballot_w64(guard_acc(v, gbias, gmask) != 0) == 0;
+}
+// input wrap to DATA_WIDTH (conv_std_logic_vector) of int16 containers that hold more than w bits: exact path of narrow plans
+__device__ __forceinline__ void wrap_inputs(u32 (&v)[16], int w)
+{
+    const short sh = (short)(16 - w);
+    const v2s shv = {sh, sh};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = as_u32((as_v2s(v[j]) << shv) >> shv);
 }
 
 
@@ -331,8 +357,8 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
     if constexpr (ROUND) { // RNDMODE = 1 (int_dit2_fly.vhd:164-217): T at full width, then rhu2(A +/- T)
         static_assert(!FASTX, "fast extraction yields T >> 1 only");
         u32 tf[4];
-        mul2x<16, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, sl.sel, tf[0], tf[1]);
-        mul2x<16, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, sl.sel, tf[2], tf[3]);
+        mul2x<16, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, sl.sel, tf[0], tf[1], sl.wd);
+        mul2x<16, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, sl.sel, tf[2], tf[3], sl.wd);
         sumdiff<true, false>(a0, tf[0], a0, b0);
         sumdiff<true, false>(a1, tf[1], a1, b1);
         sumdiff<true, false>(a2, tf[2], a2, b2);
@@ -343,8 +369,8 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
     if (FASTX) {
         mul4f<SG>(bs, bs, wb, wa, sl.sel_hi, t);
     } else {
-        mul2x<15, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y1, sl.sel, t[0], t[1]);
-        mul2x<15, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y1, sl.sel, t[2], t[3]);
+        mul2x<15, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y1, sl.sel, t[0], t[1], sl.wd);
+        mul2x<15, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y1, sl.sel, t[2], t[3], sl.wd);
     }
     const v2s A0 = as_v2s(a0) >> (short)1, A1 = as_v2s(a1) >> (short)1, A2 = as_v2s(a2) >> (short)1,
               A3 = as_v2s(a3) >> (short)1;

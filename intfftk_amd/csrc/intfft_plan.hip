@@ -745,6 +745,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     } else if (pl->fast1024x) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024x_kernel_name());
     } else if (pl->fast1024) {
+        pl->fargs.dw = p->data_width;
         pl->fargs.log2n = p->log2n;
         pl->fargs.twd = p->twdl_width;
         pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
@@ -992,14 +993,14 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->fast1024x)
         return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
-                                     plan->h_tw.data(), batch, stream, plan->p.rndmode);
+                                     plan->h_tw.data(), batch, stream, plan->p.rndmode, plan->p.data_width);
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
                                     plan->p.direction == INTFFT_FWD ? plan->p.out_order == INTFFT_ORDER_BITREV
                                                                     : plan->p.in_order == INTFFT_ORDER_BITREV,
                                     plan->p.direction == INTFFT_FWD ? plan->p.in_order == INTFFT_ORDER_HALVES
                                                                     : plan->p.out_order == INTFFT_ORDER_HALVES,
-                                    d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream, plan->p.rndmode);
+                                    d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream, plan->p.rndmode, plan->p.data_width);
 
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;

@@ -506,6 +506,11 @@ def test_unscaled_wave_kernel_inverse_and_pair(log2n, direction):
     check(uniform_frames(77, n, 16, 9), log2n, 16, 16, 1, 0, False, direction=direction)  # XSER "OLD": earlier dbl18
 
 
+def narrow_packed(dw, tw, fmt, rnd):
+    """DATA_WIDTH 9 .. 15, truncate mode, twiddles of at most 16 bits: served by the packed int16 kernels (intfft_pk16.hpp)"""
+    return 9 <= dw <= 15 and (fmt, rnd) == (0, 0) and 8 <= tw <= 16
+
+
 W32_CASES = [(12, 16, 0, 0), (12, 16, 0, 1), (14, 18, 0, 0), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0), (32, 16, 0, 0),
              (32, 16, 0, 1), (8, 8, 0, 0), (20, 16, 1, 0), (22, 24, 1, 0), (10, 12, 1, 0), (16, 18, 0, 0), (16, 24, 1, 0),
              (26, 26, 0, 0), (5, 10, 1, 0)]
@@ -526,7 +531,7 @@ def test_general_width_wave_kernel(log2n, case):
         x = np.concatenate([edge_frames(n, dw), uniform_frames((1 << (10 - log2n)) + 3, n, dw, 40 + dw),
                             uniform_frames(70, n, max(2, dw - 1), 41 + dw)])
         info = check(x, log2n, dw, tw, fmt, rnd, new)
-        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_w32"), info
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft1024_i16" if narrow_packed(*case) else "k_fft1024_w32"), info
 
 
 @pytest.mark.parametrize("log2n", [11, 12])
@@ -541,7 +546,7 @@ def test_general_width_block_kernel(log2n, case):
             continue
         x = np.concatenate([edge_frames(n, dw), uniform_frames(5, n, dw, 60 + dw), uniform_frames(40, n, max(2, dw - 1), 61 + dw)])
         info = check(x, log2n, dw, tw, fmt, rnd, new)
-        packed_round = (dw, fmt, rnd) == (16, 0, 1) and tw <= 16  # the "ROUNDING" UUT runs on the packed block kernel
+        packed_round = ((dw, fmt, rnd) == (16, 0, 1) and tw <= 16) or narrow_packed(*case)  # the "ROUNDING" UUT runs on the packed block kernel
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16" if packed_round else "k_fft4096_w32"), info
 
 
@@ -563,8 +568,31 @@ def test_general_width_inverse_kernels(log2n, case):
         fp = 1 << max(0, 10 - log2n)
         x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 3, n, dw, 70 + dw), uniform_frames(20, n, max(2, dw - 1), 71 + dw)])
         info = check(x, log2n, dw, tw, fmt, rnd, new, direction="INV")
-        packed_round = (dw, fmt, rnd) == (16, 0, 1) and tw <= 16  # packed wave / block kernels (RNDMODE = 1)
+        packed_round = ((dw, fmt, rnd) == (16, 0, 1) and tw <= 16) or narrow_packed(*case)  # packed wave / block kernels
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(("k_fft1024x_i16", "k_fft4096_i16") if packed_round else "k_ifft"), info
+
+
+@pytest.mark.parametrize("log2n", [6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("dw", [9, 12, 14, 15])
+@pytest.mark.parametrize("tw", [16, 12])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction):
+    """DATA_WIDTH 9 .. 15 (12 / 14-bit converters) in truncate mode run on the packed int16 kernels: guard-safe frames
+    (|re|, |im| < 2^(w-2): fast extraction with 16-bit twiddles), full-scale w-bit frames (w-bit exact extraction) and
+    containers that hold more than w bits (wrapped to DATA_WIDTH on load), mixed in one batch."""
+    n = 1 << log2n
+    fp = 1 << max(0, 10 - log2n)
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 0, 0, new), DIR[direction]) != 0:
+            continue
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 5, n, dw - 1, 300 + dw), uniform_frames(7, n, dw, 301 + dw),
+                            uniform_frames(3, n, 16, 302 + dw), uniform_frames(2 * fp + 1, n, dw - 1, 303 + dw)])
+        info = check(x, log2n, dw, tw, 0, 0, new, direction=direction)
+        want = "k_fft1024_i16" if direction == "FWD" and log2n <= 10 else "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16"
+        assert info["fast_path"] == 1 and info["kernel_name"].startswith(want), info
+    for in_order, out_order in ([("HALVES", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES")] if direction == "INV" else []):
+        if log2n >= 7:
+            check(uniform_frames(fp + 2, n, dw, 310 + dw), log2n, dw, tw, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
 
 
 @pytest.mark.parametrize("case", [(10, 24, 24), (10, 24, 16), (10, 23, 18), (11, 23, 24), (11, 22, 16), (12, 22, 24), (12, 21, 16)])
