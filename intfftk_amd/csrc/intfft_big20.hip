@@ -121,7 +121,9 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         }
         // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
         // the barrier also orders the previous frame's LDS reads before this frame's writes
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dif_round<FAST_OK, false, NS1>(v, t1, sl, none);
         else dif_round<false, false, NS1>(v, t1, sl, none);
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << 12));
         }
-        if (FAST_OK && frame_has_guard_bit(v)) dif_round<FAST_OK, false, NS>(v, t, sl, none);
+        const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask);
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+        if (fast) dif_round<FAST_OK, false, NS>(v, t, sl, none);
         else dif_round<false, false, NS>(v, t, sl, none);
         if (partial) {
 #pragma unroll
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, cons
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = src[(size_t)j << 12];
         }
-        if (FAST_OK && frame_has_guard_bit(v)) dit_round<FAST_OK, NS>(v, t, sl);
+        if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) dit_round<FAST_OK, NS>(v, t, sl);
         else dit_round<false, NS>(v, t, sl);
         if (halves) {
             typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -320,7 +324,9 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
             for (int r = 0; r < 16; ++r) // thread hx = n19..16, regs = n15..12; (two-pass split: non-temporal loads +3 %, three-pass: -2 %)
                 v[r] = LOWB == 8 ? __builtin_nontemporal_load(src + ((size_t)(16 * hx + r) << LOWB)) : src[(size_t)(16 * hx + r) << LOWB];
         }
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // also orders the previous LDS reads
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0; // also orders the previous LDS reads
+    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dit_round<FAST_OK>(v, t2, sl);
         else dit_round<false>(v, t2, sl);
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
         // guard-bit vote on this block's own inputs (S-type: |v| < 2^14; Y >> 1 type: |v| < 2^13)
         bool fast = false;
         if (FAST_OK) {
-            const u32 addc = (b & 1) ? 0x20002000u : 0x40004000u, maskc = (b & 1) ? 0xC000C000u : 0x80008000u;
+            const u32 addc = (b & 1) ? sl.gbias1 : sl.gbias, maskc = (b & 1) ? sl.gmask1 : sl.gmask;
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
     const v2s sh3 = {s3, s3};
     bool fast = false;
     if (FAST_OK) { // vote on the tile's own inputs; the kind (hence the threshold) depends on n4 = tid >> 8
-        const u32 addc = (tid >> 8) ? 0x20002000u : 0x40004000u, maskc = (tid >> 8) ? 0xC000C000u : 0x80008000u;
+        const u32 addc = (tid >> 8) ? sl.gbias1 : sl.gbias, maskc = (tid >> 8) ? sl.gmask1 : sl.gmask;
         u32 acc = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc |= v[r] + addc;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
     const v2s sh_a = {sa, sa};
     bool fast = false;
     if (FAST_OK) { // vote on the tile's own inputs (closed under stages 7..0); the threshold depends on the kind
-        const u32 addc = k8 ? 0x20002000u : 0x40004000u, maskc = k8 ? 0xC000C000u : 0x80008000u;
+        const u32 addc = k8 ? sl.gbias1 : sl.gbias, maskc = k8 ? sl.gmask1 : sl.gmask;
         u32 acc = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
@@ -543,7 +549,8 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
     u32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + ((size_t)rev4b(r) << (L - 4)));
-    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0; // the tile is closed under STAGE 0..7
+    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0; // the tile is closed under STAGE 0..7
+    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
     else dit_round_c<false>(v, c, sl);
 #pragma unroll
@@ -584,7 +591,8 @@ __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const
     u32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + ((size_t)rev4b(r) << (L - 4)));
-    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
     else dit_round_c<false>(v, c, sl);
     // transpose to thread = (px = n(L-5)..n(L-8), e = n4..0), regs j = n(L-1)..n(L-4): rev8(16 j + px) = tid & 255
@@ -618,7 +626,9 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
         u32 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v) != 0) == 0;
+        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads(); // orders the previous block's reg1 reads before this block's writes
         // LA -> LB: row = 16 j + n3..0, column = n7..4
 #pragma unroll
@@ -671,11 +681,12 @@ __global__ __launch_bounds__(256) void k_big_c(const u32 *src, u32 *dst, const R
         bool fast = false;
         if (FAST_OK) {
             u32 acc = 0;
-            const u32 addc = (!DIT && (lane & 1)) ? 0x20002000u : 0x40004000u, maskc = (!DIT && (lane & 1)) ? 0xC000C000u : 0x80008000u;
+            const u32 addc = (!DIT && (lane & 1)) ? sl.gbias1 : sl.gbias, maskc = (!DIT && (lane & 1)) ? sl.gmask1 : sl.gmask;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc |= v[r] + addc;
             fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
         }
+        if (DIT && !fast && sl.wd != 16) wrap_inputs(v, sl.wd);
         if (DIT) {
             if (fast) dit_round_c<FAST_OK>(v, c, sl);
             else dit_round_c<false>(v, c, sl);
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             for (int j = 0; j < 16; ++j) v[j] = p[16 * j];
             bool fast = false;
             if (FAST_OK) {
-                const u32 addc = (q & 1) ? 0x20002000u : 0x40004000u, maskc = (q & 1) ? 0xC000C000u : 0x80008000u;
+                const u32 addc = (q & 1) ? sl.gbias1 : sl.gbias, maskc = (q & 1) ? sl.gmask1 : sl.gmask;
                 u32 acc = 0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
@@ -770,7 +781,8 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
                 for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) swap32(v[r], v[r + 8]);
-            const bool fast = FAST_OK && frame_has_guard_bit(v); // the 1024 samples are closed under STAGE 0..7
+            const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask); // the 1024 samples are closed under STAGE 0..7
+            if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
             if (fast) dit_round_c<FAST_OK>(v, c, sl);
             else dit_round_c<false>(v, c, sl);
             wave_lds_fence();
@@ -812,7 +824,7 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
         for (int j = 0; j < 16; ++j) v[j] = p[16 * j]; // regs = n7..4, lane = (q, n3..0)
         bool fast = false;
         if (FAST_OK) {
-            const u32 addc = (q & 1) ? 0x20002000u : 0x40004000u, maskc = (q & 1) ? 0xC000C000u : 0x80008000u;
+            const u32 addc = (q & 1) ? sl.gbias1 : sl.gbias, maskc = (q & 1) ? sl.gmask1 : sl.gmask;
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
@@ -845,7 +857,7 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
-    return log2n >= 13 && log2n <= 20 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+    return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
            use_fly == 1 &&
            (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out
             : direction == 1 ? (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2) // + BITREV in, HALVES out
@@ -901,10 +913,11 @@ static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, si
 // STAGE 11..0 / 0..11 on every 4096-point block in place (k_fft4096_i16<MODE_MID>: the bit reversal between the cores
 // cancels, int_fft_ifft_pair.vhd:242-280), then DIT STAGE 12..L-1 (k_big16_q1 / k_big20_q1).
 hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
-                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width)
 {
     if (nframes == 0) return hipSuccess;
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
@@ -964,7 +977,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream); break;
     default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream); break;
     }
-    const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream);
+    const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream, data_width);
     if (e != hipSuccess) return e;
     switch (log2n) {
     case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;
@@ -981,7 +994,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
 
 // int_ifftNk for N = 2^13 .. 2^20: the three passes mirrored (k_big20_q3, k_big20_q2, k_big16_q1 / k_big20_q1)
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
-                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
+                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -995,7 +1008,8 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
@@ -1063,7 +1077,7 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
 }
 
 hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int two_pass, const void *in, void *out, void *scratch,
-                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream)
+                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -1077,7 +1091,8 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;

@@ -132,10 +132,11 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         {
             u32 acc = 0;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) acc |= v[j] + 0x40004000u;
-            const int bad = __syncthreads_or((acc & 0x80008000u) != 0);
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
             fast = FAST_OK && bad == 0;
         }
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 #define INTFFT_2P_ROUND1(FX)                                                                                  \
     {                                                                                                         \
         dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                     \
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         {
             u32 acc = 0;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) acc |= v[q] + 0x40004000u;
-            const int bad = __syncthreads_or((acc & 0x80008000u) != 0); // also orders the previous frame's LDS reads
+            for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
             fast = FAST_OK && bad == 0;
         }
         {

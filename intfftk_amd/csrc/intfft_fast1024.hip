@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
 
 bool packed_width_ok(int data_width, int format, int rndmode)
 {
-    static const bool narrow = getenv("INTFFT_NO_NARROW16") == nullptr;
+    const bool narrow = getenv("INTFFT_NO_NARROW16") == nullptr; // read per plan: the tests switch it
     return data_width == 16 || (narrow && data_width >= 9 && data_width <= 15 && format == 0 && rndmode == 0);
 }
 

@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             if (MODE == MODE_MID && (f & 1)) { // Y >> 1 inputs: |v| < 2^13
                 u32 acc = 0;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc |= v[j] + 0x20002000u;
-                bad = (acc & 0xC000C000u) != 0;
+                for (int j = 0; j < 16; ++j) acc |= v[j] + sl.gbias1;
+                bad = (acc & sl.gmask1) != 0;
             }
             if (bad) *s_unsafe = 1;
             __syncthreads();
@@ -347,7 +347,8 @@ static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundC
     return hipGetLastError();
 }
 
-hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream)
+hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream,
+                               int data_width)
 {
     if (nblocks4k == 0) return hipSuccess;
     RoundCConsts c;
@@ -362,7 +363,8 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
     to_dit_packing_host(c); // MODE_MID runs both cores: DIT packing (see the kernel)
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     u32 *p = static_cast<u32 *>(scratch);
     return (twd == 16 && allow_fast) ? launch4k<12, MODE_MID, true>(p, p, tw_all, c, nblocks4k, sl, stream)

@@ -215,12 +215,12 @@ const char *wide16_kernel_name();
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order);
 hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int two_pass, const void *in, void *out, void *scratch,
-                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
+                        const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16);
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev);
 hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
-                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16);
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
-                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream);
+                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16);
 // two-pass plans for N = 2^17, 2^18 forward: 32-register first pass (intfft_big2p.hip) + k_mid_p2 / k_mid_c
 bool big2p_supported(int log2n);
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd);
@@ -228,7 +228,8 @@ hipError_t launch_big2p_a(int log2n, bool fx, const uint32_t *pin, uint32_t *scr
                           int halves, hipStream_t stream);
 hipError_t launch_big2p_q(int log2n, bool fx, const uint32_t *scr, uint32_t *pout, const uint2 *tw16f, size_t nframes, const struct Slice &sl,
                           int halves, hipStream_t stream);
-hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream);
+hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream,
+                               int data_width = 16);
 
 // bit-permutation mover (intfft_reorder.hip): m_in bit in_of_out[b] = m_out bit b; frames of 2^L (re, im) container pairs
 hipError_t launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,

@@ -26,12 +26,15 @@ struct Slice {
     int wd = 16;             // width of the exact extraction (v_bfe_i32)
     u32 gbias = 0x40004000u; // guard test: (x + gbias) & gmask == 0 for both halves <=> -2^(w-2) <= re, im < 2^(w-2)
     u32 gmask = 0x80008000u;
+    u32 gbias1 = 0x20002000u, gmask1 = 0xC000C000u; // the same test for values of the Y >> 1 kind (one bit less)
     __host__ __device__ void set_width(int w)
     {
         wd = w;
         const u32 b = 1u << (w - 2), m = (0xFFFFu << (w - 1)) & 0xFFFFu;
         gbias = b | (b << 16);
         gmask = m | (m << 16);
+        gbias1 = gbias >> 1;
+        gmask1 = gmask | ((gmask >> 1) & 0x7FFF7FFFu);
     }
 };
 
@@ -310,12 +313,12 @@ __device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16], u32 gbia
     return __builtin_amdgcn_ballot_w64(guard_acc(v, gbias, gmask) != 0) == 0;
 }
 // input wrap to DATA_WIDTH (conv_std_logic_vector) of int16 containers that hold more than w bits: exact path of narrow plans
-__device__ __forceinline__ void wrap_inputs(u32 (&v)[16], int w)
+template <int NV> __device__ __forceinline__ void wrap_inputs(u32 (&v)[NV], int w)
 {
     const short sh = (short)(16 - w);
     const v2s shv = {sh, sh};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = as_u32((as_v2s(v[j]) << shv) >> shv);
+    for (int j = 0; j < NV; ++j) v[j] = as_u32((as_v2s(v[j]) << shv) >> shv);
 }
 
 

@@ -796,7 +796,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
                       pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
-        if (pl->word == 2) {
+        // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
+        const bool narrow_big = pl->big20 && p->data_width != 16;
+        if (pl->word == 2 || narrow_big) {
             const size_t total = ((size_t)1 << pl->L) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
@@ -809,7 +811,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : pl->word == 2 ? 2 : pl->passes[0].word);
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             size_t scratch_mb = (pl->big20 || pl->bigw || pl->wide16) ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
             if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
@@ -871,7 +873,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         return INTFFT_OK;
     }
     info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
-    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : fast ? 2 : plan->word;
+    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -1027,13 +1029,13 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             const hipError_t e = plan->p.direction == INTFFT_INV
                                      ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                                      plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
-                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream)
+                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width)
                                  : plan->p.direction == INTFFT_PAIR
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, plan->d_scratch, plan->d_tw,
-                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream)
+                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
                                                     plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
-                                                    plan->d_tw16f, plan->h_tw.data(), nf, stream);
+                                                    plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width);
             if (e != hipSuccess) return (int)e;
             continue;
         }

@@ -259,6 +259,7 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
     dw, tw, fmt, rnd = case
     if dw + fmt * log2n > 32:
         pytest.skip("results exceed 32 bits")
+    monkeypatch.setenv("INTFFT_NO_NARROW16", "1")  # 12-bit truncate-mode data would otherwise take the packed int16 kernels
     n = 1 << log2n
     x = uniform_frames(batch, n, dw, 6000 + log2n + dw)
     x[0] = edge_frames(n, dw)[4]
@@ -576,7 +577,7 @@ def test_general_width_inverse_kernels(log2n, case):
 @pytest.mark.parametrize("dw", [9, 12, 14, 15])
 @pytest.mark.parametrize("tw", [16, 12])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
-def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction):
+def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
     """DATA_WIDTH 9 .. 15 (12 / 14-bit converters) in truncate mode run on the packed int16 kernels: guard-safe frames
     (|re|, |im| < 2^(w-2): fast extraction with 16-bit twiddles), full-scale w-bit frames (w-bit exact extraction) and
     containers that hold more than w bits (wrapped to DATA_WIDTH on load), mixed in one batch."""
@@ -590,9 +591,32 @@ def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction):
         info = check(x, log2n, dw, tw, 0, 0, new, direction=direction)
         want = "k_fft1024_i16" if direction == "FWD" and log2n <= 10 else "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16"
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(want), info
+        if new and dw == 12:  # the 32-bit kernels serve the same plan with INTFFT_NO_NARROW16 (A/B against the same oracle)
+            with monkeypatch.context() as m:
+                m.setenv("INTFFT_NO_NARROW16", "1")
+                info = check(x, log2n, dw, tw, 0, 0, new, direction=direction)
+                assert "_i16" not in info["kernel_name"], info
     for in_order, out_order in ([("HALVES", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES")] if direction == "INV" else []):
         if log2n >= 7:
             check(uniform_frames(fp + 2, n, dw, 310 + dw), log2n, dw, tw, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
+
+
+@pytest.mark.parametrize("log2n,batch", [(13, 37), (14, 9), (15, 5), (16, 5), (17, 3), (18, 2), (19, 1), (20, 1)])
+@pytest.mark.parametrize("dw,tw", [(12, 16), (14, 16), (9, 16), (12, 12)])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_narrow_data_multi_pass(log2n, batch, dw, tw, direction):
+    """DATA_WIDTH 9 .. 15 at N >= 8192: the packed multi-pass kernels (every pass votes its guard condition at w bits; exact
+    paths extract w bits; first passes wrap containers that hold more than w bits)."""
+    if (dw, tw) != (12, 16) and log2n in (15, 19, 20):
+        pytest.skip("long frames: one width is enough")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw - 1, 400 + dw), uniform_frames(2, n, dw, 401 + dw), uniform_frames(1, n, 16, 402 + dw),
+                        uniform_frames(1, n, dw - 1, 403 + dw)])
+    info = check(x, log2n, dw, tw, 0, 0, True, direction=direction)
+    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big", "k_mid")), info
+    if log2n in (13, 16):
+        for in_order, out_order in ([("HALVES", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES")] if direction == "INV" else []):
+            check(x[:batch + 2], log2n, dw, tw, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
 
 
 @pytest.mark.parametrize("case", [(10, 24, 24), (10, 24, 16), (10, 23, 18), (11, 23, 24), (11, 22, 16), (12, 22, 24), (12, 21, 16)])
