@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
                 v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
             }
         }
+        if (!ROUND && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact w-bit extraction below)
         if (MODE != SM_INV) small_dif<L, ROUND>(v, t, sl);
         if (MODE != SM_FWD) small_dit<L>(v, t, sl);
         wave_lds_fence();
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
 bool fastsmall_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                          int in_order, int out_order)
 {
-    return log2n >= 3 && log2n <= 5 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1 &&
+    return log2n >= 3 && log2n <= 5 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1 &&
            in_order == 0 && out_order == 0 && (direction == 0 || rndmode == 0);
 }
 
@@ -177,7 +178,7 @@ static hipError_t launch_sm_l(int direction, bool round, const u32 *in, u32 *out
 }
 
 hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, const void *in, void *out, const int2 *h_tw,
-                            size_t nframes, hipStream_t stream)
+                            size_t nframes, hipStream_t stream, int data_width)
 {
     if (nframes == 0) return hipSuccess;
     SmallTw t{};
@@ -192,7 +193,8 @@ hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, co
     pack(2, t.wa2, t.wb2);
     pack(3, t.wa3, t.wb3);
     pack(4, t.wa4, t.wb4);
-    const Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
     switch (log2n) {

@@ -78,7 +78,7 @@ const char *pass16_kernel_name();
 bool fastsmall_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                          int in_order, int out_order);
 hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, const void *in, void *out, const int2 *h_tw,
-                            size_t nframes, hipStream_t stream);
+                            size_t nframes, hipStream_t stream, int data_width = 16);
 const char *fastsmall_kernel_name();
 
 // ---- wave kernels (intfft_fast1024.hip, intfft_fast1024u.hip): I/O permutation for short frames ----

@@ -975,7 +975,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->buf2d[0]) return exec_2d(plan, d_in, d_out, batch, stream);
     if (plan->fastsmall)
         return (int)launch_fastsmall(plan->p.log2n, plan->p.direction, plan->p.rndmode, plan->p.twdl_width, d_in, d_out,
-                                     plan->h_tw.data(), batch, stream);
+                                     plan->h_tw.data(), batch, stream, plan->p.data_width);
     if (plan->w32inv)
         return (int)launch_w32inv(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                   plan->h_tw.data(), batch, stream);

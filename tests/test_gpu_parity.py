@@ -573,7 +573,7 @@ def test_general_width_inverse_kernels(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(("k_fft1024x_i16", "k_fft4096_i16") if packed_round else "k_ifft"), info
 
 
-@pytest.mark.parametrize("log2n", [6, 7, 9, 10, 11, 12])
+@pytest.mark.parametrize("log2n", [3, 4, 5, 6, 7, 9, 10, 11, 12])
 @pytest.mark.parametrize("dw", [9, 12, 14, 15])
 @pytest.mark.parametrize("tw", [16, 12])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
@@ -589,7 +589,8 @@ def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
         x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 5, n, dw - 1, 300 + dw), uniform_frames(7, n, dw, 301 + dw),
                             uniform_frames(3, n, 16, 302 + dw), uniform_frames(2 * fp + 1, n, dw - 1, 303 + dw)])
         info = check(x, log2n, dw, tw, 0, 0, new, direction=direction)
-        want = "k_fft1024_i16" if direction == "FWD" and log2n <= 10 else "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16"
+        want = ("k_fftsmall_i16" if log2n <= 5 else "k_fft1024_i16" if direction == "FWD" and log2n <= 10 else
+                "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16")
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(want), info
         if new and dw == 12:  # the 32-bit kernels serve the same plan with INTFFT_NO_NARROW16 (A/B against the same oracle)
             with monkeypatch.context() as m:
