@@ -33,7 +33,14 @@ for L in (11, 12, 13, 14, 15):
     ROWS.append(("%d:24:24:1" % L, "24-bit unscaled FWD"))
 ROWS.append(("10:24:24:1", "24-bit unscaled FWD"))
 ROWS.append(("7:24:24:1", "24-bit unscaled FWD"))
-ROWS.append(("10:12:16:0", "12-bit scaled FWD"))
+ROWS.append(("10:12:16:0", "12-bit scaled FWD (narrow data on the packed kernels)"))
+ROWS.append(("10:12:16:0:0:PAIR", "12-bit scaled PAIR"))
+ROWS.append(("12:14:16:0", "14-bit scaled FWD"))
+ROWS.append(("12:14:16:0:0:PAIR", "14-bit scaled PAIR"))
+ROWS.append(("16:12:16:0", "12-bit scaled FWD"))
+ROWS.append(("20:12:16:0", "12-bit scaled FWD"))
+ROWS.append(("10:18:18:0", "18-bit scaled FWD"))
+ROWS.append(("10:18:18:0:0:INV", "18-bit scaled INV"))
 ROWS.append(("12:14:16:0:1", "14-bit scaled-round FWD"))
 ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("12:32:24:0", "32-bit scaled FWD"))
