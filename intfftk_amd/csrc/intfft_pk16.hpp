@@ -27,6 +27,7 @@ struct Slice {
     u32 gbias = 0x40004000u; // guard test: (x + gbias) & gmask == 0 for both halves <=> -2^(w-2) <= re, im < 2^(w-2)
     u32 gmask = 0x80008000u;
     u32 gbias1 = 0x20002000u, gmask1 = 0xC000C000u; // the same test for values of the Y >> 1 kind (one bit less)
+    int round = 0; // multi-pass kernels (intfft_big20.hip): RNDMODE = 1 on the exact-path instantiations (a runtime switch there)
     __host__ __device__ void set_width(int w)
     {
         wd = w;

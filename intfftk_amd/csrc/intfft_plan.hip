@@ -763,7 +763,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         // N = 2^17, 2^18 forward / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
         // quarter turns: verified on this plan's tables)
-        const bool big2p = pl->big20 && (p->direction == INTFFT_FWD || p->direction == INTFFT_INV) && big2p_supported(p->log2n) &&
+        const bool big2p = pl->big20 && !p->rndmode && (p->direction == INTFFT_FWD || p->direction == INTFFT_INV) && big2p_supported(p->log2n) &&
                            !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
         const bool big2p_pair = pl->big20 && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
@@ -1029,13 +1029,13 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
             const hipError_t e = plan->p.direction == INTFFT_INV
                                      ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                                      plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
-                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width)
+                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode)
                                  : plan->p.direction == INTFFT_PAIR
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, plan->d_scratch, plan->d_tw,
                                                       plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
                                                     plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
-                                                    plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width);
+                                                    plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode);
             if (e != hipSuccess) return (int)e;
             continue;
         }

@@ -602,6 +602,26 @@ def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
             check(uniform_frames(fp + 2, n, dw, 310 + dw), log2n, dw, tw, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 37), (13, 515), (14, 9), (15, 5), (16, 5), (16, 33), (17, 3), (18, 2), (19, 1), (20, 1)])
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("tw", [16, 12])
+def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
+    """RNDMODE = 1 (the testbench's "ROUNDING" UUT) at N >= 8192 on the packed multi-pass kernels: plain values between the
+    passes, rhu2 sums, exact extraction; two-pass and three-pass splits of the same plan against the oracle."""
+    if tw != 16 and log2n > 16:
+        pytest.skip("long frames: one twiddle width is enough")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, 16, 500 + log2n), edge_frames(n, 16)[3:6], uniform_frames(2, n, 15, 501 + log2n)])
+    info = check(x, log2n, 16, tw, 0, 1, True, direction=direction)
+    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big20", "k_mid")), info
+    assert info["n_passes"] == (2 if log2n <= 16 else 3), info
+    if log2n <= 16:
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_TWOPASS", "1")
+            info = check(x[:batch + 2], log2n, 16, tw, 0, 1, True, direction=direction)
+            assert info["n_passes"] == 3, info
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (14, 9), (15, 5), (16, 5), (17, 3), (18, 2), (19, 1), (20, 1)])
 @pytest.mark.parametrize("dw,tw", [(12, 16), (14, 16), (9, 16), (12, 12)])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
