@@ -253,7 +253,7 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
 {
     if (!(packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
-    if (rndmode && (in_order != 0 || out_order != 0 || getenv("INTFFT_NO_PACKED_ROUND"))) return false; // ROUNDING: natural order
+    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: the same orders as truncate mode
     if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
     // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) in and HALVES (native) out
     return log2n >= 7 && log2n <= 10 &&
@@ -281,7 +281,7 @@ static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *po
                             size_t nframes, const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream, int round)
 {
     if (round)
-        return direction == 1 ? launchx<L, X_INV, false, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream)
+        return direction == 1 ? launchx<L, X_INV, false, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
                               : launchx<L, X_PAIR, false, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
     if (direction == 1)
         return fast_ok ? launchx<L, X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)

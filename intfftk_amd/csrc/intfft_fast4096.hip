@@ -327,7 +327,7 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
 {
     if (!((log2n == 12 || log2n == 11) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
-    if (rndmode) return in_order == 0 && out_order == 0 && !getenv("INTFFT_NO_PACKED_ROUND"); // ROUNDING: natural order, all three directions
+    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: all three directions, the cores' native orders too
     if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
     if (direction == 1) return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2); // + BITREV in, HALVES out
     return in_order == 0 && out_order == 0;
@@ -377,8 +377,12 @@ static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *p
 {
     if (round) {
         switch (direction) {
-        case 0: return launch4k<L, MODE_FWD, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
-        case 1: return launch4k<L, MODE_INV, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
+        case 0:
+            return lc_bitrev ? launch4k<L, MODE_FWD, false, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                             : launch4k<L, MODE_FWD, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+        case 1:
+            return lc_bitrev ? launch4k<L, MODE_INV, false, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                             : launch4k<L, MODE_INV, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
         default: return launch4k<L, MODE_PAIR, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
         }
     }

@@ -469,6 +469,21 @@ def test_fast1024x_native_orders(in_order, out_order):
     assert info["fast_path"] == 1
 
 
+@pytest.mark.parametrize("log2n", [7, 9, 10, 11, 12])
+@pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
+                                                              ("FWD", "HALVES", "NATURAL"), ("INV", "HALVES", "BITREV"),
+                                                              ("INV", "NATURAL", "BITREV"), ("INV", "HALVES", "NATURAL")])
+def test_round_mode_native_orders(log2n, direction, time_order, freq_order):
+    """RNDMODE = 1 with the cores' own beat orders (int_fftNk: HALVES in / BITREV out, int_ifftNk: BITREV in / HALVES out) on the
+    packed single-pass kernels."""
+    n = 1 << log2n
+    fp = 1 << max(0, 10 - log2n)
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(fp + 3, n, 16, 600 + log2n), uniform_frames(2 * fp + 1, n, 15, 601 + log2n)])
+    kw = dict(in_order=time_order, out_order=freq_order) if direction == "FWD" else dict(in_order=freq_order, out_order=time_order)
+    info = check(x, log2n, 16, 16, 0, 1, True, direction=direction, **kw)
+    assert info["fast_path"] == 1 and "_i16" in info["kernel_name"], info
+
+
 @pytest.mark.parametrize("tw,new", [(16, True), (16, False), (12, True), (8, True)])
 def test_fast1024u_unscaled_wave_kernel(tw, new):
     """The unscaled (bit-growth) wave kernel -- the testbench's "UNSCALED" mode at N = 1024: guard-bit frames
@@ -620,6 +635,11 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
             m.setenv("INTFFT_NO_TWOPASS", "1")
             info = check(x[:batch + 2], log2n, 16, tw, 0, 1, True, direction=direction)
             assert info["n_passes"] == 3, info
+    if batch <= 37:  # the cores' native beat orders (HALVES on the time side, BITREV on the frequency side) and the mixed ones
+        t_o, f_o = ("in_order", "out_order") if direction == "FWD" else ("out_order", "in_order")
+        for time_order, freq_order in (("HALVES", "BITREV"), ("NATURAL", "BITREV"), ("HALVES", "NATURAL")):
+            info = check(x[:batch + 3], log2n, 16, tw, 0, 1, True, direction=direction, **{t_o: time_order, f_o: freq_order})
+            assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (14, 9), (15, 5), (16, 5), (17, 3), (18, 2), (19, 1), (20, 1)])
