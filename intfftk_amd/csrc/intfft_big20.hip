@@ -836,7 +836,10 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
     const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
     RoundTw tb;
     load_round_tw<4>(twt, lo4, tb);
-    to_dit_packing(tb); // both cores run here: DIT packing, the forward core on D with exchanged halves (group4's DPK form)
+    // both cores run here: DIT packing, the forward core on D with exchanged halves (group4's DPK form); round mode keeps the DIF
+    // packing (its forward core needs the unswapped D), as in the single-pass pair kernels
+    const bool rnd = !FAST_OK && sl.round;
+    if (!rnd) to_dit_packing(tb);
     const short sa = (short)(1 - (q & 1)), s3 = (short)(1 - (lane & 1)); // kinds: n8 = lane bit 4, then n4 = lane bit 0
     const v2s sh_a = {sa, sa}, sh3 = {s3, s3};
     for (size_t ch = wave0; ch < nchunks; ch += nwaves) {
@@ -852,24 +855,25 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
             for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
             fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
         }
-#define INTFFT_MIDPAIR(FX)                                                                                       \
+#define INTFFT_MIDPAIR(FX, RD, DP)                                                                               \
     {                                                                                                            \
-        dif_round<FX, true, 4, false, true>(v, tb, sl, sh_a);                                                    \
+        dif_round<FX, true, 4, RD, DP>(v, tb, sl, sh_a);                                                         \
         wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) lds[ROWB * (16 * q + j) + lo4] = v[j];                    \
         wave_lds_fence(); /* LDS ops of one wave execute in order */                                \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; /* regs n3..0, lane n9..n4 */ \
         wave_lds_fence();                                                                           \
-        dif_round_c<FX, false, true>(v, c, sl, sh3);                                                             \
-        dit_round_c<FX, false, true>(v, c, sl);                                                                  \
+        dif_round_c<FX, RD, DP>(v, c, sl, sh3);                                                                  \
+        dit_round_c<FX, RD, DP>(v, c, sl);                                                                       \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) lds[ROWB * lane + r] = v[r];                              \
         wave_lds_fence();                                                                           \
         _Pragma("unroll") for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4];                    \
         wave_lds_fence();                                                                           \
-        dit_round<FX, 4, false, true>(v, tb, sl);                                                                \
+        dit_round<FX, 4, RD, DP>(v, tb, sl);                                                                     \
     }
-        if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK)
-        else INTFFT_MIDPAIR(false)
+        if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK, false, true)
+        else if (rnd) INTFFT_MIDPAIR(false, true, false)
+        else INTFFT_MIDPAIR(false, false, true)
 #undef INTFFT_MIDPAIR
 #pragma unroll
         for (int j = 0; j < 16; ++j) p[16 * j] = v[j];
@@ -879,8 +883,9 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
-    // RNDMODE = 1: the forward and the inverse core (16-bit data), natural or native orders; the pair stays on the generic kernels
-    if (rndmode && (direction == 2 || data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false;
+    // RNDMODE = 1 (16-bit data): the forward and the inverse core, natural or native orders; the pair up to N = 65536
+    if (rndmode && (data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false;
+    if (rndmode && direction == 2 && (log2n > 16 || getenv("INTFFT_NO_TWOPASS"))) return false; // round-mode pair: the 256 x 256 split only
     return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            use_fly == 1 &&
            (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out
@@ -937,7 +942,7 @@ static void launch_q1(bool fx, const u32 *scr, u32 *pout, const uint2 *tw16f, si
 // STAGE 11..0 / 0..11 on every 4096-point block in place (k_fft4096_i16<MODE_MID>: the bit reversal between the cores
 // cancels, int_fft_ifft_pair.vhd:242-280), then DIT STAGE 12..L-1 (k_big16_q1 / k_big20_q1).
 hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
-                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width)
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width, int rndmode)
 {
     if (nframes == 0) return hipSuccess;
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
@@ -945,7 +950,8 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
-    const bool fx = twd == 16 && allow_fast;
+    const bool fx = twd == 16 && allow_fast && !rndmode;
+    sl.round = rndmode;
     if (two_pass) { // 2^(L-8) x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
         RoundCConsts c;
         for (int k = 0; k < 8; ++k) {
@@ -958,7 +964,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
             c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
             c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
         }
-        to_dit_packing_host(c); // k_mid_pair holds its twiddles in the DIT packing
+        if (!rndmode) to_dit_packing_host(c); // k_mid_pair holds its twiddles in the DIT packing (round mode: DIF packing)
         const int vsh = log2n <= 16 ? 16 - log2n : 0;
         const size_t nvf = (nframes + ((size_t)1 << vsh) - 1) >> vsh;
         const unsigned groups = (unsigned)(nvf < 256 ? nvf : 256);

@@ -218,7 +218,7 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
                         const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16, int rndmode = 0);
 const char *big20_kernel_name(int direction, int two_pass, int freq_bitrev);
 hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void *out, void *scratch, const int2 *tw_all,
-                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16);
+                          const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16, int rndmode = 0);
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
                          const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16, int rndmode = 0);
 // two-pass plans for N = 2^17, 2^18 forward: 32-register first pass (intfft_big2p.hip) + k_mid_p2 / k_mid_c

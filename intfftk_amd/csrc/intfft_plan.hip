@@ -1032,7 +1032,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode)
                                  : plan->p.direction == INTFFT_PAIR
                                      ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, plan->d_scratch, plan->d_tw,
-                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width)
+                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
                                                     plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode);

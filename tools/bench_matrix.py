@@ -44,6 +44,7 @@ for L in (14, 16, 20):
     ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
 ROWS.append(("16:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("20:16:16:0:1:INV", "16-bit scaled-round INV"))
+ROWS.append(("14:16:16:0:1:PAIR", "16-bit scaled-round PAIR"))
 ROWS.append(("10:18:18:0:0:INV", "18-bit scaled INV"))
 ROWS.append(("12:14:16:0:1", "14-bit scaled-round FWD"))
 ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
