@@ -883,9 +883,8 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
-    // RNDMODE = 1 (16-bit data): the forward and the inverse core, natural or native orders; the pair up to N = 65536
+    // RNDMODE = 1 (16-bit data): every direction; the 32-register two-pass plans of N = 2^17 / 2^18 are truncate-mode only (planner)
     if (rndmode && (data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false;
-    if (rndmode && direction == 2 && (log2n > 16 || getenv("INTFFT_NO_TWOPASS"))) return false; // round-mode pair: the 256 x 256 split only
     return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            use_fly == 1 &&
            (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out
@@ -1007,7 +1006,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     case 19: launch_p1<19>(fx, pin, scr, tw16f, nframes, sl, stream); break;
     default: launch_p1<20>(fx, pin, scr, tw16f, nframes, sl, stream); break;
     }
-    const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream, data_width);
+    const hipError_t e = launch_fast4096_mid(twd, scr, nframes << (log2n - 12), tw_all, h_tw, stream, data_width, rndmode);
     if (e != hipSuccess) return e;
     switch (log2n) {
     case 13: launch_q1<13>(fx, scr, pout, tw16f, nframes, sl, stream); break;

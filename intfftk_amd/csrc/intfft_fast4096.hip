@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 {
     static_assert(!OB || MODE == MODE_FWD || MODE == MODE_INV, "native orders: forward or inverse core alone");
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
-    static_assert(!ROUND || (!FAST_OK && MODE != MODE_MID), "round mode: exact extraction, whole frames");
+    static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int FP = 1 << (12 - L), NS = L - 8;        // frames per 4096-sample chunk; executed stages of round A
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #define INTFFT_BODY(FX)                                                                                 \
     {                                                                                                   \
         if (MODE != MODE_INV) {                                                                         \
-            if (MODE == MODE_MID) dif_round<FX, true, NS, false, DP>(v, ta, sl, sh_m);                             \
+            if (MODE == MODE_MID) dif_round<FX, true, NS, ROUND, DP>(v, ta, sl, sh_m); /* round mode: plain inputs */ \
             else dif_round<FX, false, NS, ROUND, DP>(v, ta, sl, sh_b);                                      \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
@@ -348,7 +348,7 @@ static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundC
 }
 
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream,
-                               int data_width)
+                               int data_width, int rndmode)
 {
     if (nblocks4k == 0) return hipSuccess;
     RoundCConsts c;
@@ -362,11 +362,12 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
         c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
         c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
     }
-    to_dit_packing_host(c); // MODE_MID runs both cores: DIT packing (see the kernel)
+    if (!rndmode) to_dit_packing_host(c); // MODE_MID runs both cores: DIT packing (see the kernel); round mode: DIF packing
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     if (data_width != 16) sl.set_width(data_width);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     u32 *p = static_cast<u32 *>(scratch);
+    if (rndmode) return launch4k<12, MODE_MID, false, false, true>(p, p, tw_all, c, nblocks4k, sl, stream);
     return (twd == 16 && allow_fast) ? launch4k<12, MODE_MID, true>(p, p, tw_all, c, nblocks4k, sl, stream)
                                      : launch4k<12, MODE_MID, false>(p, p, tw_all, c, nblocks4k, sl, stream);
 }

@@ -229,7 +229,7 @@ hipError_t launch_big2p_a(int log2n, bool fx, const uint32_t *pin, uint32_t *scr
 hipError_t launch_big2p_q(int log2n, bool fx, const uint32_t *scr, uint32_t *pout, const uint2 *tw16f, size_t nframes, const struct Slice &sl,
                           int halves, hipStream_t stream);
 hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const int2 *tw_all, const int2 *h_tw, hipStream_t stream,
-                               int data_width = 16);
+                               int data_width = 16, int rndmode = 0);
 
 // bit-permutation mover (intfft_reorder.hip): m_in bit in_of_out[b] = m_out bit b; frames of 2^L (re, im) container pairs
 hipError_t launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,

@@ -766,7 +766,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const bool big2p = pl->big20 && !p->rndmode && (p->direction == INTFFT_FWD || p->direction == INTFFT_INV) && big2p_supported(p->log2n) &&
                            !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
-        const bool big2p_pair = pl->big20 && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
+        const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
                                 big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
