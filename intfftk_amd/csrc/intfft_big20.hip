@@ -883,8 +883,8 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                      int in_order, int out_order)
 {
-    // RNDMODE = 1 (16-bit data): every direction; the 32-register two-pass plans of N = 2^17 / 2^18 are truncate-mode only (planner)
-    if (rndmode && (data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false;
+    // RNDMODE = 1: every direction; the 32-register two-pass plans of N = 2^17 / 2^18 are truncate-mode only (planner)
+    if (rndmode && (data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false; // narrow data in round mode: 32-bit kernels
     return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            use_fly == 1 &&
            (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out

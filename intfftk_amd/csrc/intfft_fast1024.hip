@@ -69,8 +69,9 @@ template <bool ROUND> struct Twiddles {
 constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B aligned, conflict-free)
 
 // ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
-template <int L, bool ROUND, bool OUT_BITREV, int FASTX>
-__device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<ROUND> &tw,
+// ROUND: 0 truncate, 1 round, 2 round on narrow data (the w-bit wraps of intfft_pk16.hpp)
+template <int L, int ROUND, bool OUT_BITREV, int FASTX>
+__device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
                                                 const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
 {
@@ -104,15 +105,15 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
         }
     } else {
         const u32 wa9a[4] = {tw.wa9[0], tw.wa9[1], tw.wa9[2], tw.wa9[3]}, wb9a[4] = {tw.wb9[0], tw.wb9[1], tw.wb9[2], tw.wb9[3]};
-        const u32 wa9b[4] = {tw.wa9[4 % (8 / Twiddles<ROUND>::NQ)], tw.wa9[5 % (8 / Twiddles<ROUND>::NQ)],
-                             tw.wa9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wa9[7 % (8 / Twiddles<ROUND>::NQ)]};
-        const u32 wb9b[4] = {tw.wb9[4 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[5 % (8 / Twiddles<ROUND>::NQ)],
-                             tw.wb9[6 % (8 / Twiddles<ROUND>::NQ)], tw.wb9[7 % (8 / Twiddles<ROUND>::NQ)]};
+        const u32 wa9b[4] = {tw.wa9[4 % (8 / Twiddles<(ROUND != 0)>::NQ)], tw.wa9[5 % (8 / Twiddles<(ROUND != 0)>::NQ)],
+                             tw.wa9[6 % (8 / Twiddles<(ROUND != 0)>::NQ)], tw.wa9[7 % (8 / Twiddles<(ROUND != 0)>::NQ)]};
+        const u32 wb9b[4] = {tw.wb9[4 % (8 / Twiddles<(ROUND != 0)>::NQ)], tw.wb9[5 % (8 / Twiddles<(ROUND != 0)>::NQ)],
+                             tw.wb9[6 % (8 / Twiddles<(ROUND != 0)>::NQ)], tw.wb9[7 % (8 / Twiddles<(ROUND != 0)>::NQ)]};
         if constexpr (L >= 10) {
             group4<ROUND, false, false, P, false, M0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa9a, wb9a, sl);
             group4<ROUND, false, false, P, false, M0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa9b, wb9b, sl);
         }
-        constexpr int N8 = 4 / Twiddles<ROUND>::NQ, N7 = 2 / Twiddles<ROUND>::NQ;
+        constexpr int N8 = 4 / Twiddles<(ROUND != 0)>::NQ, N7 = 2 / Twiddles<(ROUND != 0)>::NQ;
         const u32 wa8a[4] = {tw.wa8[0], tw.wa8[1 % N8], tw.wa8[0], tw.wa8[1 % N8]}, wb8a[4] = {tw.wb8[0], tw.wb8[1 % N8], tw.wb8[0], tw.wb8[1 % N8]};
         const u32 wa8b[4] = {tw.wa8[2 % N8], tw.wa8[3 % N8], tw.wa8[2 % N8], tw.wa8[3 % N8]}, wb8b[4] = {tw.wb8[2 % N8], tw.wb8[3 % N8], tw.wb8[2 % N8], tw.wb8[3 % N8]};
         if constexpr (L >= 9) {
@@ -187,15 +188,19 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
         group4<ROUND, FASTX, false, P, true, M0>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
         group4<ROUND, FASTX, false, P, true, MA>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
     }
+    if constexpr (ROUND) {
+        round_stages10<16, ROUND == 2>(v, sl);
+    } else {
 #pragma unroll
-    for (int g = 0; g < 16; g += 8) { // stage 1: kind = r & 4
-        bfly_triv<ROUND, false>(v[g], v[g + 2]);
-        bfly_mj<ROUND, false>(v[g + 1], v[g + 3]);
-        bfly_triv<ROUND, P>(v[g + 4], v[g + 6]);
-        bfly_mj<ROUND, P>(v[g + 5], v[g + 7]);
+        for (int g = 0; g < 16; g += 8) { // stage 1: kind = r & 4
+            bfly_triv<(ROUND != 0), false>(v[g], v[g + 2]);
+            bfly_mj<(ROUND != 0), false>(v[g + 1], v[g + 3]);
+            bfly_triv<(ROUND != 0), P>(v[g + 4], v[g + 6]);
+            bfly_mj<(ROUND != 0), P>(v[g + 5], v[g + 7]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) bfly_triv<(ROUND != 0), false>(v[g], v[g + 1]);
     }
-#pragma unroll
-    for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]);
 
     // ---- store ----
     if (OUT_BITREV) {
@@ -247,7 +252,8 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     }
 }
 
-template <int L, bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+// ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
+template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const Fast1024Consts c, size_t nframes_user, const Slice sl,
                                                      int in_halves)
@@ -261,8 +267,8 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
 
     // ---- per-lane twiddles of the lane-dependent stages (frame invariant) --------------------
     // stage s table starts at twt + 2^s - 1; index = position mod 2^s (rom_twiddle_int.vhd:187-202)
-    Twiddles<ROUND> tw;
-    constexpr int NQ = Twiddles<ROUND>::NQ;
+    Twiddles<(ROUND != 0)> tw;
+    constexpr int NQ = Twiddles<(ROUND != 0)>::NQ;
     if constexpr (L >= 10) {
 #pragma unroll
         for (int j = 0; j < 8 / NQ; ++j) {
@@ -334,14 +340,15 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
         const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
         if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) {
             transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-        } else if (sl.wd == 16) { // a FAST_OK kernel is launched for 16-bit twiddles only: its exact path is the t = 16 form (mul2x_t16)
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-        } else { // DATA_WIDTH < 16 (truncate mode): containers wrapped to w bits, w-bit exact extraction
-            if constexpr (!ROUND) {
-                wrap_inputs(v, sl.wd);
-                transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-            }
+            return;
         }
+        // exact path.  DATA_WIDTH < 16: containers wrapped to w bits, w-bit exact extraction (and w-bit rhu2 wraps in round mode).
+        // A FAST_OK kernel is launched for 16-bit twiddles only: its 16-bit exact path is the t = 16 form (mul2x_t16).
+        if (sl.wd != 16) wrap_inputs(v, sl.wd);
+        if (FAST_OK && sl.wd == 16)
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+        else
+            transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0
@@ -405,7 +412,8 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
 bool packed_width_ok(int data_width, int format, int rndmode)
 {
     const bool narrow = getenv("INTFFT_NO_NARROW16") == nullptr; // read per plan: the tests switch it
-    return data_width == 16 || (narrow && data_width >= 9 && data_width <= 15 && format == 0 && rndmode == 0);
+    (void)rndmode; // both sum / difference modes
+    return data_width == 16 || (narrow && data_width >= 9 && data_width <= 15 && format == 0);
 }
 
 bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction,
@@ -426,7 +434,7 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <int L, bool ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, int in_halves, hipStream_t stream)
 {
@@ -443,7 +451,7 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
     return hipGetLastError();
 }
 
-template <int L, bool ROUND, bool OUT_BITREV>
+template <int L, int ROUND, bool OUT_BITREV>
 static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, bool fast_ok, int in_halves, hipStream_t stream)
 {
@@ -464,16 +472,18 @@ static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast10
 }
 
 template <int L>
-static hipError_t launch_short(bool round, bool out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
+static hipError_t launch_short(int round, bool out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
                                const Fast1024Consts &c, size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
 {
     if constexpr (L >= 7) {
         if (out_bitrev)
-            return round ? launch_t<L, true, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-                         : launch_t<L, false, true>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
+            return round == 2   ? launch_t<L, 2, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                   : round == 1 ? launch_t<L, 1, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                                : launch_t<L, 0, true>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
     }
-    return round ? launch_t<L, true, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-                 : launch_t<L, false, false>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
+    return round == 2   ? launch_t<L, 2, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+           : round == 1 ? launch_t<L, 1, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                        : launch_t<L, 0, false>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,
@@ -496,7 +506,7 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
     const bool fast_ok = a.twd == 16; // high halves == bits [31:16] only for t = 16
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
-    const bool round = a.rnd == RND_ROUND;
+    const int round = a.rnd == RND_ROUND ? (a.dw != 16 ? 2 : 1) : 0; // round mode on narrow data: its own instantiation
     switch (a.log2n) {
     case 6: return launch_short<6>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
     case 7: return launch_short<7>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
@@ -504,11 +514,7 @@ hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, con
     case 9: return launch_short<9>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
     default: break;
     }
-    if (round)
-        return a.out_bitrev ? launch_t<10, true, true>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream)
-                            : launch_t<10, true, false>(pin, pout, tw_all, c, nframes, sl, false, a.in_halves, stream);
-    return a.out_bitrev ? launch_t<10, false, true>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream)
-                        : launch_t<10, false, false>(pin, pout, tw_all, c, nframes, sl, fast_ok, a.in_halves, stream);
+    return launch_short<10>(round, a.out_bitrev, a.in_halves, pin, pout, tw_all, c, nframes, sl, fast_ok, stream);
 }
 
 } // namespace intfft

@@ -33,7 +33,7 @@ enum { X_INV = 1, X_PAIR = 2 };
 // in the L1 layout); the inverse alone loads X[brev_L(n)] with the mirror image of the forward kernel's
 // short-frame store (dwordx4 loads + two lane swaps, LC lane bits per lane_bit<L>()).
 // ROUND: RNDMODE = 1 (rhu2 sums on full-width values, exact extraction, no pre-shifted outputs)
-template <int L, int MODE, bool FAST_OK, bool ROUND = false>
+template <int L, int MODE, bool FAST_OK, int ROUND = 0>
 __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                       const RoundCConsts c, size_t nframes_user, const Slice sl,
                                                       int in_bitrev, int out_halves)
@@ -168,21 +168,21 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j + lane);
         }
         const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask);
-        if (!ROUND && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact path)
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact path)
 
-#define INTFFT_XBODY(FX)                                                                                \
+#define INTFFT_XBODY(FX, RD)                                                                             \
     {                                                                                                   \
         if (MODE == X_PAIR) { /* forward core: L1 -> LC */                                              \
-            dif_round<FX, false, NS, ROUND, DP>(v, ta, sl, sh3);                                                \
+            dif_round<FX, false, NS, RD, DP>(v, ta, sl, sh3);                                                \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                       \
-            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0), false, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
-            group4<ROUND, FX, false, !ROUND, false, (NS >= 1 && !ROUND ? 0xA : 0), false, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+            group4<RD, FX, false, !RD, false, (NS >= 1 && !RD ? 0xA : 0), false, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl); \
+            group4<RD, FX, false, !RD, false, (NS >= 1 && !RD ? 0xA : 0), false, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
             swap_guard(v);                                                                              \
             _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                           \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);           \
-            group4<ROUND, FX, false, !ROUND, false, 0x0, false, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
-            group4<ROUND, FX, false, !ROUND, false, (ROUND ? 0x0 : 0xF), false, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+            group4<RD, FX, false, !RD, false, 0x0, false, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl); \
+            group4<RD, FX, false, !RD, false, (RD ? 0x0 : 0xF), false, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
             wave_lds_fence();                                                              \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
             {                                                                                           \
@@ -196,10 +196,10 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
                 v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;             \
             }                                                                                           \
             wave_lds_fence();                                                              \
-            dif_round_c<FX, ROUND, DP>(v, c, sl, sh3);                                                      \
+            dif_round_c<FX, RD, DP>(v, c, sl, sh3);                                                      \
         }                                                                                               \
         /* inverse core: LC -> L1 */                                                                    \
-        dit_round_c<FX, ROUND, DP>(v, c, sl);                                                           \
+        dit_round_c<FX, RD, DP>(v, c, sl);                                                           \
         wave_lds_fence();                                                                  \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) wr_i[ROWX * r] = v[r];                           \
         wave_lds_fence();                                                                  \
@@ -209,19 +209,19 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;                 \
         }                                                                                               \
         wave_lds_fence();                                                                  \
-        group4_dit<FX, false, ROUND, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);     \
-        group4_dit<FX, false, ROUND, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
+        group4_dit<FX, false, RD, DP>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], w4a, w4b, sl);     \
+        group4_dit<FX, false, RD, DP>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], w4a, w4b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int g = 0; g < 16; g += 8)                                               \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) swap16(v[g + j], v[g + j + 4]);               \
-        group4_dit<FX, false, ROUND, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);   \
-        group4_dit<FX, false, ROUND, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
+        group4_dit<FX, false, RD, DP>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], w5a, w5b, sl);   \
+        group4_dit<FX, false, RD, DP>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], w5a, w5b, sl); \
         swap_guard(v);                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) swap32(v[j], v[j + 8]);                           \
-        dit_round<FX, NS, ROUND, DP>(v, ta, sl);                                                        \
+        dit_round<FX, NS, RD, DP>(v, ta, sl);                                                        \
     }
-        if (FAST_OK && fast) INTFFT_XBODY(FAST_OK)
-        else INTFFT_XBODY(false)
+        if (FAST_OK && fast) INTFFT_XBODY(FAST_OK, ROUND)
+        else INTFFT_XBODY(false, ROUND)
 #undef INTFFT_XBODY
         if (out_halves) { // HALVES: beat q = 64 jj + lane holds (x[i], x[i + N/2]) = (v[j0], v[j0 | 2^(L-7)]), see the forward kernel
             if constexpr (L >= 7) {
@@ -263,7 +263,7 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }
 
-template <int L, int MODE, bool FAST_OK, bool ROUND = false>
+template <int L, int MODE, bool FAST_OK, int ROUND = 0>
 static hipError_t launchx(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                           const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream)
 {
@@ -281,8 +281,10 @@ static hipError_t launchx_l(int direction, bool fast_ok, const u32 *pin, u32 *po
                             size_t nframes, const Slice &sl, int in_bitrev, int out_halves, hipStream_t stream, int round)
 {
     if (round)
-        return direction == 1 ? launchx<L, X_INV, false, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
-                              : launchx<L, X_PAIR, false, true>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
+        return sl.wd != 16 ? (direction == 1 ? launchx<L, X_INV, false, 2>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
+                                             : launchx<L, X_PAIR, false, 2>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream))
+               : direction == 1 ? launchx<L, X_INV, false, 1>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
+                                : launchx<L, X_PAIR, false, 1>(pin, pout, tw_all, c, nframes, sl, 0, 0, stream);
     if (direction == 1)
         return fast_ok ? launchx<L, X_INV, true>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream)
                        : launchx<L, X_INV, false>(pin, pout, tw_all, c, nframes, sl, in_bitrev, out_halves, stream);

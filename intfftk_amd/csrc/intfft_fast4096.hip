@@ -92,7 +92,8 @@ template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_re
 
 // ROUND: RNDMODE = 1 (the testbench's "ROUNDING" UUT, fft_signle_test.vhd:93-112): rhu2 sums on full-width values, exact
 // extraction, no pre-shifted outputs (so none of the per-thread shift amounts below apply)
-template <int L, int MODE, bool FAST_OK, bool OB = false, bool ROUND = false>
+// ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
+template <int L, int MODE, bool FAST_OK, bool OB = false, int ROUND = 0>
 __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const RoundCConsts c, size_t nframes_user, const Slice sl, int halves)
 {
@@ -257,19 +258,19 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             __syncthreads();
             fast = *s_unsafe == 0;
         }
-        if (!ROUND && MODE != MODE_MID && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits
+        if (MODE != MODE_MID && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits
 
-#define INTFFT_BODY(FX)                                                                                 \
+#define INTFFT_BODY(FX, RD)                                                                              \
     {                                                                                                   \
         if (MODE != MODE_INV) {                                                                         \
-            if (MODE == MODE_MID) dif_round<FX, true, NS, ROUND, DP>(v, ta, sl, sh_m); /* round mode: plain inputs */ \
-            else dif_round<FX, false, NS, ROUND, DP>(v, ta, sl, sh_b);                                      \
+            if (MODE == MODE_MID) dif_round<FX, true, NS, RD, DP>(v, ta, sl, sh_m); /* round mode: plain inputs */ \
+            else dif_round<FX, false, NS, RD, DP>(v, ta, sl, sh_b);                                      \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg0)                                                                         \
-            dif_round<FX, true, 4, ROUND, DP>(v, tb, sl, sh_b);                                             \
+            dif_round<FX, true, 4, RD, DP>(v, tb, sl, sh_b);                                             \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L, OB>(j)] = v[j]; \
             INTFFT_X_READ(reg1)                                                                         \
-            dif_round_c<FX, ROUND, DP>(v, c, sl, sh_c);                                                     \
+            dif_round_c<FX, RD, DP>(v, c, sl, sh_c);                                                     \
         }                                                                                               \
         if (MODE == MODE_FWD && OB) { /* memory index = n: two lane swaps, dwordx4 stores (1 KiB per wave) */ \
             swap_guard(v);                                                                              \
@@ -290,13 +291,13 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                     __builtin_nontemporal_store(v[r], dst + (rev4c(r) << (L - 4)) + lc_off);            \
             }                                                                                           \
         } else {                                                                                        \
-            dit_round_c<FX, ROUND, DP>(v, c, sl);                                                       \
+            dit_round_c<FX, RD, DP>(v, c, sl);                                                       \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
             INTFFT_X_READ_CB(reg0)                                                                      \
-            dit_round<FX, 4, ROUND, DP>(v, tb, sl);                                                     \
+            dit_round<FX, 4, RD, DP>(v, tb, sl);                                                     \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
             INTFFT_X_READ(reg1)                                                                         \
-            dit_round<FX, NS, ROUND, DP>(v, ta, sl);                                                    \
+            dit_round<FX, NS, RD, DP>(v, ta, sl);                                                    \
             if (MODE == MODE_INV && halves) { /* HALVES beats, mirror of the forward load */            \
                 typedef u32 v2u __attribute__((ext_vector_type(2)));                                    \
                 v2u *d2 = reinterpret_cast<v2u *>(dst) + tid;                                           \
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             }                                                                                           \
         }                                                                                               \
     }
-        if (FAST_OK && fast) INTFFT_BODY(FAST_OK)
-        else INTFFT_BODY(false)
+        if (FAST_OK && fast) INTFFT_BODY(FAST_OK, ROUND)
+        else INTFFT_BODY(false, ROUND)
 #undef INTFFT_BODY
         __syncthreads(); // region reuse by the next frame (and s_unsafe)
     }
@@ -335,7 +336,7 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
 
 const char *fast4096_kernel_name() { return "k_fft4096_i16"; }
 
-template <int L, int MODE, bool FAST_OK, bool OB = false, bool ROUND = false>
+template <int L, int MODE, bool FAST_OK, bool OB = false, int ROUND = 0>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream, int halves = 0)
 {
@@ -367,7 +368,7 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
     if (data_width != 16) sl.set_width(data_width);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     u32 *p = static_cast<u32 *>(scratch);
-    if (rndmode) return launch4k<12, MODE_MID, false, false, true>(p, p, tw_all, c, nblocks4k, sl, stream);
+    if (rndmode) return launch4k<12, MODE_MID, false, false, 1>(p, p, tw_all, c, nblocks4k, sl, stream);
     return (twd == 16 && allow_fast) ? launch4k<12, MODE_MID, true>(p, p, tw_all, c, nblocks4k, sl, stream)
                                      : launch4k<12, MODE_MID, false>(p, p, tw_all, c, nblocks4k, sl, stream);
 }
@@ -379,12 +380,20 @@ static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *p
     if (round) {
         switch (direction) {
         case 0:
-            return lc_bitrev ? launch4k<L, MODE_FWD, false, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                             : launch4k<L, MODE_FWD, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+            if (sl.wd != 16)
+                return lc_bitrev ? launch4k<L, MODE_FWD, false, true, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                                 : launch4k<L, MODE_FWD, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+            return lc_bitrev ? launch4k<L, MODE_FWD, false, true, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                             : launch4k<L, MODE_FWD, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves);
         case 1:
-            return lc_bitrev ? launch4k<L, MODE_INV, false, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                             : launch4k<L, MODE_INV, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-        default: return launch4k<L, MODE_PAIR, false, false, true>(pin, pout, tw_all, c, nframes, sl, stream);
+            if (sl.wd != 16)
+                return lc_bitrev ? launch4k<L, MODE_INV, false, true, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                                 : launch4k<L, MODE_INV, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+            return lc_bitrev ? launch4k<L, MODE_INV, false, true, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves)
+                             : launch4k<L, MODE_INV, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+        default:
+            return sl.wd != 16 ? launch4k<L, MODE_PAIR, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream)
+                               : launch4k<L, MODE_PAIR, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream);
         }
     }
     switch (direction) {

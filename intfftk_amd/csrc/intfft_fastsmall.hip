@@ -29,7 +29,7 @@ template <int L> __host__ __device__ constexpr int brev_small(int i)
 // butterfly b of STAGE S (b = 0 .. N/2 - 1): first register index and twiddle index
 template <int S> __host__ __device__ constexpr int bf_reg(int b) { return ((b >> S) << (S + 1)) | (b & ((1 << S) - 1)); }
 
-template <int L, int S, bool ROUND>
+template <int L, int S, int ROUND>
 __device__ __forceinline__ void small_dif_stage(u32 (&v)[1 << L], const u32 *wa_t, const u32 *wb_t, const Slice &sl)
 {
     constexpr int N = 1 << L, H = 1 << S, M = H - 1;
@@ -54,19 +54,23 @@ __device__ __forceinline__ void small_dit_stage(u32 (&v)[1 << L], const u32 *wa_
     }
 }
 
-template <int L, bool ROUND> __device__ __forceinline__ void small_dif(u32 (&v)[1 << L], const SmallTw &t, const Slice &sl)
+template <int L, int ROUND> __device__ __forceinline__ void small_dif(u32 (&v)[1 << L], const SmallTw &t, const Slice &sl)
 {
     constexpr int N = 1 << L;
     if constexpr (L >= 5) small_dif_stage<L, 4, ROUND>(v, t.wa4, t.wb4, sl);
     if constexpr (L >= 4) small_dif_stage<L, 3, ROUND>(v, t.wa3, t.wb3, sl);
     small_dif_stage<L, 2, ROUND>(v, t.wa2, t.wb2, sl);
-#pragma unroll
-    for (int g = 0; g < N; g += 4) { // STAGE 1: even positions Y = D, odd positions Y = -j D (negation quirk)
-        bfly_triv<ROUND, false>(v[g], v[g + 2]);
-        bfly_mj<ROUND, false>(v[g + 1], v[g + 3]);
+    if constexpr (ROUND) {
+        round_stages10<N, ROUND == 2>(v, sl);
+        return;
     }
 #pragma unroll
-    for (int g = 0; g < N; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]); // STAGE 0
+    for (int g = 0; g < N; g += 4) { // STAGE 1: even positions Y = D, odd positions Y = -j D (negation quirk)
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_mj<false, false>(v[g + 1], v[g + 3]);
+    }
+#pragma unroll
+    for (int g = 0; g < N; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0
 }
 template <int L> __device__ __forceinline__ void small_dit(u32 (&v)[1 << L], const SmallTw &t, const Slice &sl)
 {
@@ -87,7 +91,7 @@ template <int L> __device__ __forceinline__ void small_dit(u32 (&v)[1 << L], con
 // 1 KiB of consecutive memory (lane l takes bytes 16 l of the instruction's KiB); the tile [64 frames][N + 4 dwords] is
 // written row-major as loaded and each lane reads back its own frame (and the reverse for the stores).  Letting each
 // lane access its own 4 N contiguous bytes directly thrashed the L1: N = 32 ran at half the speed of the generic kernel.
-template <int L, int MODE, bool ROUND>
+template <int L, int MODE, int ROUND>
 __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, const SmallTw t, size_t nframes, const Slice sl)
 {
     constexpr int N = 1 << L, ROW = N + 4; // dwords per LDS row (16-byte aligned rows, padded against bank conflicts)
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
                 v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
             }
         }
-        if (!ROUND && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact w-bit extraction below)
+        if (sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact w-bit extraction below)
         if (MODE != SM_INV) small_dif<L, ROUND>(v, t, sl);
         if (MODE != SM_FWD) small_dit<L>(v, t, sl);
         wave_lds_fence();
@@ -158,7 +162,7 @@ bool fastsmall_supported(int log2n, int data_width, int twdl_width, int format, 
 
 const char *fastsmall_kernel_name() { return "k_fftsmall_i16"; }
 
-template <int L, int MODE, bool ROUND>
+template <int L, int MODE, int ROUND>
 static hipError_t launch_sm(const u32 *in, u32 *out, const SmallTw &t, size_t nframes, const Slice &sl, hipStream_t stream)
 {
     const size_t cap = resident_blocks(kptr(k_fftsmall_i16<L, MODE, ROUND>), 256, 4);
@@ -174,7 +178,8 @@ static hipError_t launch_sm_l(int direction, bool round, const u32 *in, u32 *out
 {
     if (direction == 1) return launch_sm<L, SM_INV, false>(in, out, t, nframes, sl, stream);
     if (direction == 2) return launch_sm<L, SM_PAIR, false>(in, out, t, nframes, sl, stream);
-    return round ? launch_sm<L, SM_FWD, true>(in, out, t, nframes, sl, stream) : launch_sm<L, SM_FWD, false>(in, out, t, nframes, sl, stream);
+    return round ? (sl.wd != 16 ? launch_sm<L, SM_FWD, 2>(in, out, t, nframes, sl, stream) : launch_sm<L, SM_FWD, 1>(in, out, t, nframes, sl, stream))
+                 : launch_sm<L, SM_FWD, 0>(in, out, t, nframes, sl, stream);
 }
 
 hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, const void *in, void *out, const int2 *h_tw,

@@ -70,6 +70,16 @@ template <bool ROUND, bool PRE, bool SW = false> __device__ __forceinline__ void
         d = pk_sub<SW>(A & ~B, T);
     }
 }
+// Round mode on narrow data (DATA_WIDTH w < 16 in 16-bit lanes): rhu2(A - B) reaches +2^(w-1) when A = 2^(w-1) - 1, B = -2^(w-1),
+// where the RTL's w-bit result wraps to -2^(w-1) (int_dif2_fly.vhd:173-218); nothing else leaves the w-bit range.  The callers
+// wrap the differences in their ROUND == 2 instantiations (tested per group behind a wave-uniform branch the 16-bit round-mode
+// kernels lost 2..7 %); the kernels select that body once per frame (Slice::wd != 16).
+__device__ __forceinline__ u32 wrap_w(u32 x, int w)
+{
+    const short sh = (short)(16 - w);
+    const v2s shv = {sh, sh};
+    return as_u32((as_v2s(x) << shv) >> shv);
+}
 // truncate mode with a per-lane shift amount (0 where the lane's registers already hold X >> 1)
 template <bool SW = false> __device__ __forceinline__ void sumdiff_var(u32 a, u32 b, v2s sh, u32 &s, u32 &d)
 {
@@ -195,7 +205,7 @@ __device__ __forceinline__ void mul4f(const u32 (&dr)[4], const u32 (&di)[4], co
 //           cores shares with its DIT half (group4_dit<.., DITPACK>).  D is then produced with its halves exchanged (free:
 //           op_sel of the packed subtract) and Y.re = dot(Dsw, Wd), Y.im = dot(Dsw, Wc); a quarter turn is
 //           Y.re = dot(Dsw, Wc), Y.im = dot(-Dsw, Wd): the code below with the roles of (wa, wb) exchanged
-template <bool ROUND, int FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false, bool DPK = false>
+template <int ROUND, int FASTX, bool QTURN, bool OUT_PRE, bool SG, int PREMASK, bool VARSH = false, bool DPK = false>
 __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
                                        const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl, v2s shv = v2s{0, 0})
 {
@@ -210,10 +220,16 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
         sumdiff_var<DPK>(a2, b2, shv, a2, d[2]);
         sumdiff_var<DPK>(a3, b3, shv, a3, d[3]);
     } else {
-        sumdiff<ROUND, (PREMASK & 1) != 0, DPK>(a0, b0, a0, d[0]);
-        sumdiff<ROUND, (PREMASK & 2) != 0, DPK>(a1, b1, a1, d[1]);
-        sumdiff<ROUND, (PREMASK & 4) != 0, DPK>(a2, b2, a2, d[2]);
-        sumdiff<ROUND, (PREMASK & 8) != 0, DPK>(a3, b3, a3, d[3]);
+        sumdiff<(ROUND != 0), (PREMASK & 1) != 0, DPK>(a0, b0, a0, d[0]);
+        sumdiff<(ROUND != 0), (PREMASK & 2) != 0, DPK>(a1, b1, a1, d[1]);
+        sumdiff<(ROUND != 0), (PREMASK & 4) != 0, DPK>(a2, b2, a2, d[2]);
+        sumdiff<(ROUND != 0), (PREMASK & 8) != 0, DPK>(a3, b3, a3, d[3]);
+    }
+    if constexpr (ROUND) {
+        if constexpr (ROUND == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = wrap_w(d[i], sl.wd);
+        }
     }
     u32 y[4];
     if (QTURN) {
@@ -268,6 +284,34 @@ template <bool ROUND, bool IN_PRE> __device__ __forceinline__ void bfly_mj(u32 &
     const u32 rot = __builtin_amdgcn_alignbit(d, d, 16); // lo = D.im, hi = D.re
     const u32 nx = rot ^ 0xFFFF0000u;                     // hi = ~D.re
     b = nx + ((nx >> 31) << 16);                          // + 1 in the high half iff D.re >= 0
+}
+
+// RNDMODE = 1, DIF STAGE 1 and 0 on NV registers (pairs (g, g + 2), (g + 1, g + 3), then (g, g + 1)): bfly_triv / bfly_mj with the
+// w-bit wrap of the differences (wrap_w) between the rhu2 sums and the -j rotation
+template <int NV, bool NARROW> __device__ __forceinline__ void round_stages10(u32 (&v)[NV], const Slice &sl)
+{
+#pragma unroll
+    for (int g = 0; g < NV; g += 4) {
+        sumdiff<true, false>(v[g], v[g + 2], v[g], v[g + 2]);
+        sumdiff<true, false>(v[g + 1], v[g + 3], v[g + 1], v[g + 3]);
+    }
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int g = 0; g < NV; g += 4) v[g + 2] = wrap_w(v[g + 2], sl.wd), v[g + 3] = wrap_w(v[g + 3], sl.wd);
+    }
+#pragma unroll
+    for (int g = 0; g < NV; g += 4) { // odd positions: Y = -j D with the negation quirk (bfly_mj)
+        const u32 d = v[g + 3];
+        const u32 rot = __builtin_amdgcn_alignbit(d, d, 16);
+        const u32 nx = rot ^ 0xFFFF0000u;
+        v[g + 3] = nx + ((nx >> 31) << 16);
+    }
+#pragma unroll
+    for (int g = 0; g < NV; g += 2) sumdiff<true, false>(v[g], v[g + 1], v[g], v[g + 1]);
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int g = 1; g < NV; g += 2) v[g] = wrap_w(v[g], sl.wd);
+    }
 }
 
 // lane-half / row exchanges (gfx950 v_permlane32_swap / v_permlane16_swap).  hipcc pads the hazards it can see;
@@ -344,7 +388,7 @@ __device__ __forceinline__ constexpr int rev4c(int r) { return ((r & 1) << 3) | 
 // QTURN: the twiddles are the quarter turns W' = (W.im, -W.re) of the given base twiddles: T'.re = -(T.im of the base) and
 // T'.im = T.re of the base, so the re operand is the NEGATED im operand of the base (exact: no table entry is -2^15, the
 // planner checks) and the im operand is the base's re operand.
-template <bool FASTX, bool SG, bool ROUND = false, bool DITPACK = false, bool QTURN = false>
+template <bool FASTX, bool SG, int ROUND = 0, bool DITPACK = false, bool QTURN = false>
 __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &a2, u32 &b2, u32 &a3, u32 &b3,
                                            const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl)
 {
@@ -367,6 +411,7 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
         sumdiff<true, false>(a1, tf[1], a1, b1);
         sumdiff<true, false>(a2, tf[2], a2, b2);
         sumdiff<true, false>(a3, tf[3], a3, b3);
+        if constexpr (ROUND == 2) b0 = wrap_w(b0, sl.wd), b1 = wrap_w(b1, sl.wd), b2 = wrap_w(b2, sl.wd), b3 = wrap_w(b3, sl.wd);
         return;
     }
     u32 t[4]; // T >> 1
@@ -432,7 +477,7 @@ template <bool ROUND = false> __device__ __forceinline__ void bfly_pj_dit(u32 &a
 // ---- four DIF stages on register offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0) -----------------------
 // kinds: inputs of the first stage are S-type (unshifted) unless VARSH0 gives a per-thread shift amount.
 // NS < 4 runs only the last NS stages (short frames: the leading stages belong to frame-number bits).
-template <bool FASTX, bool VARSH0, int NS = 4, bool ROUND = false, bool DPK = false>
+template <bool FASTX, bool VARSH0, int NS = 4, int ROUND = 0, bool DPK = false>
 __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl, v2s shv)
 {
     if constexpr (ROUND) { // RNDMODE = 1: full-width values everywhere (no pre-shifted outputs), exact extraction
@@ -440,22 +485,22 @@ __device__ __forceinline__ void dif_round(u32 (&v)[16], const RoundTw &tw, const
         if constexpr (NS >= 4) {
             const u32 wa0[4] = {tw.wa8[0], tw.wa8[1], tw.wa8[2], tw.wa8[3]}, wb0[4] = {tw.wb8[0], tw.wb8[1], tw.wb8[2], tw.wb8[3]};
             const u32 wa1[4] = {tw.wa8[4], tw.wa8[5], tw.wa8[6], tw.wa8[7]}, wb1[4] = {tw.wb8[4], tw.wb8[5], tw.wb8[6], tw.wb8[7]};
-            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-            group4<true, false, false, false, false, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
         }
         if constexpr (NS >= 3) {
-            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
-            group4<true, false, false, false, false, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], tw.wa4, tw.wb4, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], tw.wa4, tw.wb4, sl);
         }
         if constexpr (NS >= 2) {
             const u32 wa[4] = {tw.wa2[0], tw.wa2[1], tw.wa2[0], tw.wa2[1]}, wb[4] = {tw.wb2[0], tw.wb2[1], tw.wb2[0], tw.wb2[1]};
-            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
-            group4<true, false, false, false, false, 0, false, DPK>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[0], v[2], v[1], v[3], v[8], v[10], v[9], v[11], wa, wb, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[4], v[6], v[5], v[7], v[12], v[14], v[13], v[15], wa, wb, sl);
         }
         if constexpr (NS >= 1) {
             const u32 wa[4] = {tw.wa1[0], tw.wa1[0], tw.wa1[0], tw.wa1[0]}, wb[4] = {tw.wb1[0], tw.wb1[0], tw.wb1[0], tw.wb1[0]};
-            group4<true, false, false, false, false, 0, false, DPK>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
-            group4<true, false, false, false, false, 0, false, DPK>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[0], v[1], v[4], v[5], v[8], v[9], v[12], v[13], wa, wb, sl);
+            group4<ROUND, false, false, false, false, 0, false, DPK>(v[2], v[3], v[6], v[7], v[10], v[11], v[14], v[15], wa, wb, sl);
         }
         return;
     }
@@ -579,7 +624,7 @@ __device__ __forceinline__ void dit_top16(u32 (&v)[32], const u32 (&wa)[8], cons
 }
 
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------
-template <bool FASTX, int NS = 4, bool ROUND = false, bool DITPACK = false>
+template <bool FASTX, int NS = 4, int ROUND = 0, bool DITPACK = false>
 __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const Slice &sl)
 {
     if constexpr (NS >= 1) {
@@ -605,23 +650,17 @@ __device__ __forceinline__ void dit_round(u32 (&v)[16], const RoundTw &tw, const
 }
 
 // ---- round C: DIF stages 3,2,1,0 / DIT stages 0,1,2,3 on reg = n3..0, uniform twiddles ----------------
-template <bool FASTX, bool ROUND = false, bool DPK = false> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
+template <bool FASTX, int ROUND = 0, bool DPK = false> __device__ __forceinline__ void dif_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl, v2s shv)
 {
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
     if constexpr (ROUND) { // RNDMODE = 1: full-width values, exact extraction; STAGE 1 / 0 on rhu2 sums (int_dif2_fly.vhd:167-219)
         static_assert(!FASTX, "round mode uses the exact extraction");
-        group4<true, false, false, false, true, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
-        group4<true, false, false, false, true, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
-        group4<true, false, false, false, true, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
-        group4<true, false, false, false, true, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
-#pragma unroll
-        for (int g = 0; g < 16; g += 4) {
-            bfly_triv<true, false>(v[g], v[g + 2]);
-            bfly_mj<true, false>(v[g + 1], v[g + 3]);
-        }
-#pragma unroll
-        for (int g = 0; g < 16; g += 2) bfly_triv<true, false>(v[g], v[g + 1]);
+        group4<ROUND, false, false, false, true, 0, false, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl);
+        group4<ROUND, false, false, false, true, 0, false, DPK>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa1, wb1, sl);
+        group4<ROUND, false, false, false, true, 0, false, DPK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
+        group4<ROUND, false, false, false, true, 0, false, DPK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);
+        round_stages10<16, ROUND == 2>(v, sl);
         return;
     }
     group4<false, FASTX, false, true, true, 0, true, DPK>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa0, wb0, sl, shv);
@@ -639,14 +678,26 @@ template <bool FASTX, bool ROUND = false, bool DPK = false> __device__ __forcein
     for (int g = 0; g < 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
 }
 
-template <bool FASTX, bool ROUND = false, bool DITPACK = false> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
+template <bool FASTX, int ROUND = 0, bool DITPACK = false> __device__ __forceinline__ void dit_round_c(u32 (&v)[16], const RoundCConsts &c, const Slice &sl)
 {
 #pragma unroll
-    for (int g = 0; g < 16; g += 2) bfly_triv<ROUND, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    for (int g = 0; g < 16; g += 2) bfly_triv<(ROUND != 0), false>(v[g], v[g + 1]); // STAGE 0: T = B
+    if constexpr (ROUND) {
+        if constexpr (ROUND == 2) {
+#pragma unroll
+            for (int g = 1; g < 16; g += 2) v[g] = wrap_w(v[g], sl.wd);
+        }
+    }
 #pragma unroll
     for (int g = 0; g < 16; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
-        bfly_triv<ROUND, false>(v[g], v[g + 2]);
-        bfly_pj_dit<ROUND>(v[g + 1], v[g + 3]);
+        bfly_triv<(ROUND != 0), false>(v[g], v[g + 2]);
+        bfly_pj_dit<(ROUND != 0)>(v[g + 1], v[g + 3]);
+    }
+    if constexpr (ROUND) {
+        if constexpr (ROUND == 2) {
+#pragma unroll
+            for (int g = 0; g < 16; g += 4) v[g + 2] = wrap_w(v[g + 2], sl.wd), v[g + 3] = wrap_w(v[g + 3], sl.wd);
+        }
     }
     group4_dit<FASTX, true, ROUND, DITPACK>(v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7], c.wa2, c.wb2, sl);
     group4_dit<FASTX, true, ROUND, DITPACK>(v[8], v[12], v[9], v[13], v[10], v[14], v[11], v[15], c.wa2, c.wb2, sl);

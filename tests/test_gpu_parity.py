@@ -642,6 +642,32 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
             assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
+@pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 11, 12, 13, 16, 17])
+@pytest.mark.parametrize("dw", [9, 12, 14, 15])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_narrow_data_round_mode(log2n, dw, direction):
+    """RNDMODE = 1 on narrow data (e.g. a 14-bit converter with rounding): the packed kernels with the w-bit wrap of the rhu2
+    differences (+2^(w-1) wraps to -2^(w-1), int_dif2_fly.vhd:173-218).  The edge frames hold the operands that reach it
+    (alternating +full / -full scale, most negative value everywhere); containers with more than w bits are wrapped on load."""
+    n = 1 << log2n
+    fp = 1 << max(0, 10 - log2n)
+    nb = 3 if log2n >= 13 else fp + 5
+    for tw in (16, 11):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 0, 1, True), DIR[direction]) != 0:
+            continue
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(nb, n, dw, 800 + dw), uniform_frames(2, n, 16, 801 + dw),
+                            uniform_frames(nb, n, dw - 1, 802 + dw)])
+        # +max next to -min in both orders and both components: the rhu2 difference that needs the wrap, at every stage distance
+        hi, lo = (1 << (dw - 1)) - 1, -(1 << (dw - 1))
+        x[-1, 0::2, :] = hi
+        x[-1, 1::2, :] = lo
+        x[-2, : n // 2, :] = hi
+        x[-2, n // 2 :, :] = lo
+        info = check(x, log2n, dw, tw, 0, 1, True, direction=direction)
+        if (6 <= log2n <= 12) or (log2n < 6 and direction == "FWD"):  # N >= 8192: the 32-bit / generic kernels
+            assert "_i16" in info["kernel_name"], info
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (13, 259), (14, 9), (15, 5), (16, 5), (16, 19), (17, 3), (18, 2), (19, 1), (20, 1)])
 @pytest.mark.parametrize("tw", [16, 12])
 def test_round_mode_pair_multi_pass(log2n, batch, tw, monkeypatch):

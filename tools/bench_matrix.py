@@ -47,6 +47,9 @@ ROWS.append(("20:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("14:16:16:0:1:PAIR", "16-bit scaled-round PAIR"))
 ROWS.append(("10:18:18:0:0:INV", "18-bit scaled INV"))
 ROWS.append(("12:14:16:0:1", "14-bit scaled-round FWD"))
+ROWS.append(("12:14:16:0:1:PAIR", "14-bit scaled-round PAIR"))
+ROWS.append(("10:12:16:0:1", "12-bit scaled-round FWD"))
+ROWS.append(("12:18:18:0:1", "18-bit scaled-round FWD"))
 ROWS.append(("10:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("12:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("10:12:16:0:0:INV", "12-bit scaled INV"))
