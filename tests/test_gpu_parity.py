@@ -260,6 +260,7 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
     if dw + fmt * log2n > 32:
         pytest.skip("results exceed 32 bits")
     monkeypatch.setenv("INTFFT_NO_NARROW16", "1")  # 12-bit truncate-mode data would otherwise take the packed int16 kernels
+    monkeypatch.setenv("INTFFT_NO_PACKED_ROUND", "1")  # and 16-bit round mode the packed multi-pass kernels
     n = 1 << log2n
     x = uniform_frames(batch, n, dw, 6000 + log2n + dw)
     x[0] = edge_frames(n, dw)[4]
@@ -523,8 +524,8 @@ def test_unscaled_wave_kernel_inverse_and_pair(log2n, direction):
 
 
 def narrow_packed(dw, tw, fmt, rnd):
-    """DATA_WIDTH 9 .. 15, truncate mode, twiddles of at most 16 bits: served by the packed int16 kernels (intfft_pk16.hpp)"""
-    return 9 <= dw <= 15 and (fmt, rnd) == (0, 0) and 8 <= tw <= 16
+    """DATA_WIDTH 9 .. 15, scaled, twiddles of at most 16 bits: served by the packed int16 kernels (intfft_pk16.hpp)"""
+    return 9 <= dw <= 15 and fmt == 0 and 8 <= tw <= 16  # both sum / difference modes (single-pass kernels)
 
 
 W32_CASES = [(12, 16, 0, 0), (12, 16, 0, 1), (14, 18, 0, 0), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0), (32, 16, 0, 0),
