@@ -589,8 +589,8 @@ def test_general_width_inverse_kernels(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(("k_fft1024x_i16", "k_fft4096_i16") if packed_round else "k_ifft"), info
 
 
-@pytest.mark.parametrize("log2n", [3, 4, 5, 6, 7, 9, 10, 11, 12])
-@pytest.mark.parametrize("dw", [9, 12, 14, 15])
+@pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 11, 12])
+@pytest.mark.parametrize("dw", [9, 12, 15])
 @pytest.mark.parametrize("tw", [16, 12])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
@@ -643,8 +643,8 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
             assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
-@pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 11, 12, 13, 16, 17])
-@pytest.mark.parametrize("dw", [9, 12, 14, 15])
+@pytest.mark.parametrize("log2n", [3, 5, 7, 10, 11, 12, 13, 17])
+@pytest.mark.parametrize("dw", [9, 14, 15])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_round_mode(log2n, dw, direction):
     """RNDMODE = 1 on narrow data (e.g. a 14-bit converter with rounding): the packed kernels with the w-bit wrap of the rhu2
@@ -688,7 +688,7 @@ def test_round_mode_pair_multi_pass(log2n, batch, tw, monkeypatch):
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (14, 9), (15, 5), (16, 5), (17, 3), (18, 2), (19, 1), (20, 1)])
-@pytest.mark.parametrize("dw,tw", [(12, 16), (14, 16), (9, 16), (12, 12)])
+@pytest.mark.parametrize("dw,tw", [(12, 16), (9, 16), (14, 12)])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_multi_pass(log2n, batch, dw, tw, direction):
     """DATA_WIDTH 9 .. 15 at N >= 8192: the packed multi-pass kernels (every pass votes its guard condition at w bits; exact
