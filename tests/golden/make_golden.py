@@ -69,6 +69,25 @@ def main():
                                             "NEW" if new else "OLD")
             cases[key + "_in"] = x.astype(np.int64)
             cases[key + "_out"] = y
+    # narrow data in int16 containers (DATA_WIDTH 9 .. 15: 12- / 14-bit converters), both scaled modes: w-bit product slices, the
+    # w-bit wrap of the rhu2 difference (+2^(w-1) -> -2^(w-1): the "hi / lo" frames reach it), containers that hold more than w bits
+    for (log2n, dw, tw, mode) in [(7, 12, 16, "TRUNCATE"), (7, 12, 16, "ROUNDING"), (7, 14, 12, "ROUNDING"), (5, 9, 16, "ROUNDING"),
+                                  (10, 14, 16, "ROUNDING"), (10, 12, 16, "TRUNCATE")]:
+        n = 1 << log2n
+        fmt, rnd = MODES[mode]
+        x = frames_for(n, dw, 31 + dw)
+        hi, lo = (1 << (dw - 1)) - 1, -(1 << (dw - 1))
+        alt = np.empty((2, n, 2), dtype=np.int64)
+        alt[0, 0::2], alt[0, 1::2] = hi, lo
+        alt[1, : n // 2], alt[1, n // 2 :] = hi, lo
+        x = np.concatenate([x[:3] if log2n == 10 else x, alt, uniform_frames(1, n, 16, 77 + dw)])
+        for direction, dname in ((P.FWD, "FWD"), (P.INV, "INV"), (P.PAIR, "PAIR")):
+            if log2n == 10 and direction != P.FWD:
+                continue
+            y = np.array([P.execute(to_list(f), log2n, dw, tw, fmt, rnd, True, direction) for f in x], dtype=np.int64)
+            key = "n%d_%s_%s_w%d_t%d_NEW" % (n, mode, dname, dw, tw)
+            cases[key + "_in"] = x.astype(np.int64)
+            cases[key + "_out"] = y
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **cases)
 
     # twiddle streams: full tables up to STAGE 12; beyond that a strided sample + CRC32 of the table
