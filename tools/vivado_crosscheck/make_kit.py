@@ -60,7 +60,9 @@ def main():
             core.close()
     for name, dw, tw, mode, xser in [("single_n7_w24t24", 24, 24, "UNSCALED", "NEW"), ("single_n7_w30t16", 30, 16, "TRUNCATE", "NEW"),
                                      ("single_n7_w30t16old", 30, 16, "TRUNCATE", "OLD"), ("single_n7_w20t24", 20, 24, "ROUNDING", "NEW"),
-                                     ("single_n7_w14t24", 14, 24, "UNSCALED", "NEW")]:
+                                     ("single_n7_w14t24", 14, 24, "UNSCALED", "NEW"),
+                                     # narrow data on the packed int16 kernels (12- / 14-bit converters), both scaled modes
+                                     ("single_n7_w12t16", 12, 16, "TRUNCATE", "NEW"), ("single_n7_w14t16", 14, 16, "ROUNDING", "NEW")]:
         from tests.helpers import edge_frames, uniform_frames
 
         fmt, rnd = MODES[mode]
