@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dif_round<FAST_OK, false, NS1>(v, t1, sl, none);
-        else if (!FAST_OK && sl.round) dif_round<false, false, NS1, true>(v, t1, sl, none); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dif_round<false, false, NS1, 1>(v, t1, sl, none); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dif_round<false, false, NS1, 2>(v, t1, sl, none); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dif_round<false, false, NS1>(v, t1, sl, none);
         // transpose: (thread (hx = n15..12, l), reg j = n19..16) -> (thread (j, l), reg hx)
 #pragma unroll
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * tid + r]; // now tid >> 5 = n19..16, regs = n15..12
         if (fast) dif_round<FAST_OK, true>(v, t2, sl, sh2);
-        else if (!FAST_OK && sl.round) dif_round<false, true, 4, true>(v, t2, sl, sh2); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, t2, sl, sh2); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dif_round<false, true, 4, 2>(v, t2, sl, sh2); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dif_round<false, true>(v, t2, sl, sh2);
         if (partial) {
 #pragma unroll
@@ -201,7 +203,8 @@ __global__ __launch_bounds__(512) void k_big16_p1(const u32 *in, u32 *scr, const
         const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask);
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (fast) dif_round<FAST_OK, false, NS>(v, t, sl, none);
-        else if (!FAST_OK && sl.round) dif_round<false, false, NS, true>(v, t, sl, none); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dif_round<false, false, NS, 1>(v, t, sl, none); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dif_round<false, false, NS, 2>(v, t, sl, none); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dif_round<false, false, NS>(v, t, sl, none);
         if (partial) {
 #pragma unroll
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(512) void k_big16_q1(const u32 *scr, u32 *out, cons
             for (int j = 0; j < 16; ++j) v[j] = src[(size_t)j << 12];
         }
         if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) dit_round<FAST_OK, NS>(v, t, sl);
-        else if (!FAST_OK && sl.round) dit_round<false, NS, true>(v, t, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dit_round<false, NS, 1>(v, t, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dit_round<false, NS, 2>(v, t, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dit_round<false, NS>(v, t, sl);
         if (halves) {
             typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dit_round<FAST_OK>(v, t2, sl);
-        else if (!FAST_OK && sl.round) dit_round<false, 4, true>(v, t2, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dit_round<false, 4, 1>(v, t2, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dit_round<false, 4, 2>(v, t2, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dit_round<false>(v, t2, sl);
         // transpose: (thread (hx = n19..16, l), reg r = n15..12) -> (thread (r, l), reg hx)
 #pragma unroll
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * tid + j]; // now tid >> 5 = n15..12, regs = n19..16
         if (fast) dit_round<FAST_OK, NS1>(v, t1, sl);
-        else if (!FAST_OK && sl.round) dit_round<false, NS1, true>(v, t1, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dit_round<false, NS1, 1>(v, t1, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dit_round<false, NS1, 2>(v, t1, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dit_round<false, NS1>(v, t1, sl);
         if (halves) {
             typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -415,7 +421,8 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
             fast = __syncthreads_or((acc & maskc) != 0) == 0;
         }
         if (fast) dif_round<FAST_OK, true>(v, ta, sl, sh_a);
-        else if (!FAST_OK && sl.round) dif_round<false, true, 4, true>(v, ta, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, ta, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dif_round<false, true, 4, 2>(v, ta, sl, sh_a); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dif_round<false, true>(v, ta, sl, sh_a);
         // LA -> LB: row = 16 j + n3..0, column = n7..4
 #pragma unroll
@@ -424,7 +431,8 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = reg0[ROWB * tid + r]; // LB: regs = n7..4, thread = (n11..8, n3..0)
         if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_b);
-        else if (!FAST_OK && sl.round) dif_round<false, true, 4, true>(v, tb, sl, sh_b); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, tb, sl, sh_b); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dif_round<false, true, 4, 2>(v, tb, sl, sh_b); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dif_round<false, true>(v, tb, sl, sh_b);
         // LB -> LA for a coalesced store: element (t' = (n11..8, n3..0), reg j' = n7..4) -> row n7..0 = 16 j' + n3..0,
         // column n11..8
@@ -476,7 +484,8 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
         fast = __syncthreads_or((acc & maskc) != 0) == 0;
     }
     if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
-    else if (!FAST_OK && sl.round) dif_round_c<false, true>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dif_round_c<false, 1>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dif_round_c<false, 2>(v, c, sl, sh3); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dif_round_c<false>(v, c, sl, sh3);
 
     // natural order: X index = brev_L(n) = rev4(r) << (L-4) | n4 << (L-5) | brev(mid) << 8 | rev8(n(L-1)..n(L-8))
@@ -519,7 +528,8 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
         fast = __syncthreads_or((acc & maskc) != 0) == 0;
     }
     if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
-    else if (!FAST_OK && sl.round) dif_round<false, true, 4, true>(v, tb, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, tb, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dif_round<false, true, 4, 2>(v, tb, sl, sh_a); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dif_round<false, true>(v, tb, sl, sh_a);
     // transpose: (thread (R, n3..0), reg j = n7..4) -> (thread 32 j + rev5(R), reg n3..0)
     {
@@ -535,7 +545,8 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
     const short s3 = (short)(1 - (hi4 & 1));      // kind = n4
     const v2s sh3 = {s3, s3};
     if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
-    else if (!FAST_OK && sl.round) dif_round_c<false, true>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dif_round_c<false, 1>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dif_round_c<false, 2>(v, c, sl, sh3); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dif_round_c<false>(v, c, sl, sh3);
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     u32 *dst = out + (frame << L) + ((size_t)rev4b(hi4) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
@@ -563,7 +574,8 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
     const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0; // the tile is closed under STAGE 0..7
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
-    else if (!FAST_OK && sl.round) dit_round_c<false, true>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dit_round_c<false, 2>(v, c, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dit_round_c<false>(v, c, sl);
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[ROWB * tid + r] = v[r];
@@ -575,7 +587,8 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
         for (int j = 0; j < 16; ++j) v[j] = w[ROWB * 32 * j]; // thread = (R, n3..0), regs = n7..4
     }
     if (fast) dit_round<FAST_OK>(v, tb, sl);
-    else if (!FAST_OK && sl.round) dit_round<false, 4, true>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dit_round<false, 4, 1>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dit_round<false, 4, 2>(v, tb, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dit_round<false>(v, tb, sl);
     // thread = (R, n3..0), regs n7..4: a store instruction would write four 64-byte pieces of four rows.  Two lane swaps
     // (reg bit 0 = n4 <-> lane bit 4 = R bit 0, reg bit 1 = n5 <-> lane bit 5 = R bit 1) make the lanes n5..0: 256-byte runs
@@ -607,7 +620,8 @@ __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const
     const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
-    else if (!FAST_OK && sl.round) dit_round_c<false, true>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+    else if (!FAST_OK && sl.round == 2) dit_round_c<false, 2>(v, c, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dit_round_c<false>(v, c, sl);
     // transpose to thread = (px = n(L-5)..n(L-8), e = n4..0), regs j = n(L-1)..n(L-4): rev8(16 j + px) = tid & 255
     const int px = rev4b((tid >> 4) & 15), j = rev4b(tid & 15);
@@ -651,7 +665,8 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = reg0[ROWB * tid + r]; // LB: regs = n7..4, thread = (n11..8, n3..0)
         if (fast) dit_round<FAST_OK>(v, tb, sl);
-        else if (!FAST_OK && sl.round) dit_round<false, 4, true>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dit_round<false, 4, 1>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dit_round<false, 4, 2>(v, tb, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dit_round<false>(v, tb, sl);
         // LB -> LA: element (t' = (n11..8, n3..0), reg j' = n7..4) -> row n7..0 = 16 j' + n3..0, column n11..8
 #pragma unroll
@@ -660,7 +675,8 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = reg1[ROWB * tid + r]; // LA again
         if (fast) dit_round<FAST_OK>(v, ta, sl);
-        else if (!FAST_OK && sl.round) dit_round<false, 4, true>(v, ta, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 1) dit_round<false, 4, 1>(v, ta, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+        else if (!FAST_OK && sl.round == 2) dit_round<false, 4, 2>(v, ta, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
         else dit_round<false>(v, ta, sl);
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[256 * r + tid] = v[r];
@@ -705,11 +721,13 @@ __global__ __launch_bounds__(256) void k_big_c(const u32 *src, u32 *dst, const R
         if (DIT && !fast && sl.wd != 16) wrap_inputs(v, sl.wd);
         if (DIT) {
             if (fast) dit_round_c<FAST_OK>(v, c, sl);
-            else if (!FAST_OK && sl.round) dit_round_c<false, true>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dit_round_c<false, 2>(v, c, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dit_round_c<false>(v, c, sl);
         } else {
             if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
-            else if (!FAST_OK && sl.round) dif_round_c<false, true>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dif_round_c<false, 1>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dif_round_c<false, 2>(v, c, sl, sh3); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dif_round_c<false>(v, c, sl, sh3);
         }
         swap_guard(v);
@@ -763,7 +781,8 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
                 fast = __builtin_amdgcn_ballot_w64((acc & maskc) != 0) == 0;
             }
             if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
-            else if (!FAST_OK && sl.round) dif_round<false, true, 4, true>(v, tb, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, tb, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dif_round<false, true, 4, 2>(v, tb, sl, sh_a); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dif_round<false, true>(v, tb, sl, sh_a);
             wave_lds_fence(); // keep the previous chunk's reads ahead of these writes
 #pragma unroll
@@ -773,7 +792,8 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             for (int r = 0; r < 16; ++r) v[r] = lds[ROWB * lane + r]; // regs = n3..0, lane = n9..n4
             wave_lds_fence();
             if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
-            else if (!FAST_OK && sl.round) dif_round_c<false, true>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dif_round_c<false, 1>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dif_round_c<false, 2>(v, c, sl, sh3); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dif_round_c<false>(v, c, sl, sh3);
             swap_guard(v);
 #pragma unroll
@@ -804,7 +824,8 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask); // the 1024 samples are closed under STAGE 0..7
             if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
             if (fast) dit_round_c<FAST_OK>(v, c, sl);
-            else if (!FAST_OK && sl.round) dit_round_c<false, true>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dit_round_c<false, 2>(v, c, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dit_round_c<false>(v, c, sl);
             wave_lds_fence();
 #pragma unroll
@@ -814,7 +835,8 @@ __global__ __launch_bounds__(256) void k_mid_c(const u32 *src, u32 *dst, const i
             for (int j = 0; j < 16; ++j) v[j] = lds[ROWB * (16 * q + j) + lo4]; // regs = n7..4, lane = (q, n3..0)
             wave_lds_fence();
             if (fast) dit_round<FAST_OK>(v, tb, sl);
-            else if (!FAST_OK && sl.round) dit_round<false, 4, true>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 1) dit_round<false, 4, 1>(v, tb, sl); // RNDMODE = 1: plain values in every pass, exact extraction
+            else if (!FAST_OK && sl.round == 2) dit_round<false, 4, 2>(v, tb, sl); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
             else dit_round<false>(v, tb, sl);
             u32 *p = dst + ch * 1024 + q * 256 + lo4;
 #pragma unroll
@@ -872,7 +894,8 @@ __global__ __launch_bounds__(256) void k_mid_pair(u32 *scr, const int2 *__restri
         dit_round<FX, 4, RD, DP>(v, tb, sl);                                                                     \
     }
         if (FAST_OK && fast) INTFFT_MIDPAIR(FAST_OK, false, true)
-        else if (rnd) INTFFT_MIDPAIR(false, true, false)
+        else if (rnd && sl.round == 2) INTFFT_MIDPAIR(false, 2, false)
+        else if (rnd) INTFFT_MIDPAIR(false, 1, false)
         else INTFFT_MIDPAIR(false, false, true)
 #undef INTFFT_MIDPAIR
 #pragma unroll
@@ -884,7 +907,8 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
                      int in_order, int out_order)
 {
     // RNDMODE = 1: every direction; the 32-register two-pass plans of N = 2^17 / 2^18 are truncate-mode only (planner)
-    if (rndmode && (data_width != 16 || getenv("INTFFT_NO_PACKED_ROUND"))) return false; // narrow data in round mode: 32-bit kernels
+    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false;
+    if (rndmode && data_width != 16 && direction == 2 && log2n > 16) return false; // narrow round-mode pair beyond N = 65536: generic kernels
     return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            use_fly == 1 &&
            (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)   // + HALVES in, BITREV out
@@ -950,7 +974,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode;
-    sl.round = rndmode;
+    sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     if (two_pass) { // 2^(L-8) x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
         RoundCConsts c;
         for (int k = 0; k < 8; ++k) {
@@ -1043,7 +1067,7 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
-    sl.round = rndmode;
+    sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the same first pass, then STAGE 8..L-1 with 32 registers per thread
@@ -1127,7 +1151,7 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
-    sl.round = rndmode;
+    sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the 32-register first pass (stages L-1..8), then the same second pass
         const size_t nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;

@@ -643,7 +643,7 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
             assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
-@pytest.mark.parametrize("log2n", [3, 5, 7, 10, 11, 12, 13, 17])
+@pytest.mark.parametrize("log2n", [3, 5, 7, 10, 11, 12, 13, 16, 17])
 @pytest.mark.parametrize("dw", [9, 14, 15])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_round_mode(log2n, dw, direction):
@@ -665,8 +665,10 @@ def test_narrow_data_round_mode(log2n, dw, direction):
         x[-2, : n // 2, :] = hi
         x[-2, n // 2 :, :] = lo
         info = check(x, log2n, dw, tw, 0, 1, True, direction=direction)
-        if (6 <= log2n <= 12) or (log2n < 6 and direction == "FWD"):  # N >= 8192: the 32-bit / generic kernels
+        if (6 <= log2n <= 12) or (log2n < 6 and direction == "FWD"):
             assert "_i16" in info["kernel_name"], info
+        elif log2n >= 13 and not (direction == "PAIR" and log2n > 16):  # the multi-pass kernels in their ROUND = 2 forms
+            assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (13, 259), (14, 9), (15, 5), (16, 5), (16, 19), (17, 3), (18, 2), (19, 1), (20, 1)])
