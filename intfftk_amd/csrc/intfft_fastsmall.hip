@@ -41,7 +41,7 @@ __device__ __forceinline__ void small_dif_stage(u32 (&v)[1 << L], const u32 *wa_
         group4<ROUND, false, false, false, true, 0>(v[i0], v[i0 + H], v[i1], v[i1 + H], v[i2], v[i2 + H], v[i3], v[i3 + H], wa, wb, sl);
     }
 }
-template <int L, int S>
+template <int L, int S, int ROUND = 0>
 __device__ __forceinline__ void small_dit_stage(u32 (&v)[1 << L], const u32 *wa_t, const u32 *wb_t, const Slice &sl)
 {
     constexpr int N = 1 << L, H = 1 << S, M = H - 1;
@@ -50,7 +50,7 @@ __device__ __forceinline__ void small_dit_stage(u32 (&v)[1 << L], const u32 *wa_
         const int i0 = bf_reg<S>(g), i1 = bf_reg<S>(g + 1), i2 = bf_reg<S>(g + 2), i3 = bf_reg<S>(g + 3);
         const u32 wa[4] = {wa_t[g & M], wa_t[(g + 1) & M], wa_t[(g + 2) & M], wa_t[(g + 3) & M]};
         const u32 wb[4] = {wb_t[g & M], wb_t[(g + 1) & M], wb_t[(g + 2) & M], wb_t[(g + 3) & M]};
-        group4_dit<false, true>(v[i0], v[i0 + H], v[i1], v[i1 + H], v[i2], v[i2 + H], v[i3], v[i3 + H], wa, wb, sl);
+        group4_dit<false, true, ROUND>(v[i0], v[i0 + H], v[i1], v[i1 + H], v[i2], v[i2 + H], v[i3], v[i3 + H], wa, wb, sl);
     }
 }
 
@@ -72,19 +72,27 @@ template <int L, int ROUND> __device__ __forceinline__ void small_dif(u32 (&v)[1
 #pragma unroll
     for (int g = 0; g < N; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0
 }
-template <int L> __device__ __forceinline__ void small_dit(u32 (&v)[1 << L], const SmallTw &t, const Slice &sl)
+template <int L, int ROUND = 0> __device__ __forceinline__ void small_dit(u32 (&v)[1 << L], const SmallTw &t, const Slice &sl)
 {
     constexpr int N = 1 << L;
 #pragma unroll
-    for (int g = 0; g < N; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    for (int g = 0; g < N; g += 2) bfly_triv<(ROUND != 0), false>(v[g], v[g + 1]); // STAGE 0: T = B
+    if constexpr (ROUND == 2) { // round mode on narrow data: the w-bit wrap of the rhu2 differences (intfft_pk16.hpp)
+#pragma unroll
+        for (int g = 1; g < N; g += 2) v[g] = wrap_w(v[g], sl.wd);
+    }
 #pragma unroll
     for (int g = 0; g < N; g += 4) { // STAGE 1
-        bfly_triv<false, false>(v[g], v[g + 2]);
-        bfly_pj_dit(v[g + 1], v[g + 3]);
+        bfly_triv<(ROUND != 0), false>(v[g], v[g + 2]);
+        bfly_pj_dit<(ROUND != 0)>(v[g + 1], v[g + 3]);
     }
-    small_dit_stage<L, 2>(v, t.wa2, t.wb2, sl);
-    if constexpr (L >= 4) small_dit_stage<L, 3>(v, t.wa3, t.wb3, sl);
-    if constexpr (L >= 5) small_dit_stage<L, 4>(v, t.wa4, t.wb4, sl);
+    if constexpr (ROUND == 2) {
+#pragma unroll
+        for (int g = 0; g < N; g += 4) v[g + 2] = wrap_w(v[g + 2], sl.wd), v[g + 3] = wrap_w(v[g + 3], sl.wd);
+    }
+    small_dit_stage<L, 2, ROUND>(v, t.wa2, t.wb2, sl);
+    if constexpr (L >= 4) small_dit_stage<L, 3, ROUND>(v, t.wa3, t.wb3, sl);
+    if constexpr (L >= 5) small_dit_stage<L, 4, ROUND>(v, t.wa4, t.wb4, sl);
 }
 
 // Global access is coalesced through a wave-private LDS tile: every dwordx4 load / store instruction of a wave covers
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
         }
         if (sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact w-bit extraction below)
         if (MODE != SM_INV) small_dif<L, ROUND>(v, t, sl);
-        if (MODE != SM_FWD) small_dit<L>(v, t, sl);
+        if (MODE != SM_FWD) small_dit<L, ROUND>(v, t, sl);
         wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < N / 4; ++q) {
@@ -157,7 +165,7 @@ bool fastsmall_supported(int log2n, int data_width, int twdl_width, int format, 
                          int in_order, int out_order)
 {
     return log2n >= 3 && log2n <= 5 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1 &&
-           in_order == 0 && out_order == 0 && (direction == 0 || rndmode == 0);
+           in_order == 0 && out_order == 0;
 }
 
 const char *fastsmall_kernel_name() { return "k_fftsmall_i16"; }
@@ -176,10 +184,14 @@ template <int L>
 static hipError_t launch_sm_l(int direction, bool round, const u32 *in, u32 *out, const SmallTw &t, size_t nframes, const Slice &sl,
                               hipStream_t stream)
 {
-    if (direction == 1) return launch_sm<L, SM_INV, false>(in, out, t, nframes, sl, stream);
-    if (direction == 2) return launch_sm<L, SM_PAIR, false>(in, out, t, nframes, sl, stream);
-    return round ? (sl.wd != 16 ? launch_sm<L, SM_FWD, 2>(in, out, t, nframes, sl, stream) : launch_sm<L, SM_FWD, 1>(in, out, t, nframes, sl, stream))
-                 : launch_sm<L, SM_FWD, 0>(in, out, t, nframes, sl, stream);
+    const int rd = round ? (sl.wd != 16 ? 2 : 1) : 0; // round mode on narrow data: its own instantiation (the w-bit wraps)
+#define INTFFT_SM(MODE)                                                                                          \
+    return rd == 2 ? launch_sm<L, MODE, 2>(in, out, t, nframes, sl, stream)                                      \
+                   : rd == 1 ? launch_sm<L, MODE, 1>(in, out, t, nframes, sl, stream) : launch_sm<L, MODE, 0>(in, out, t, nframes, sl, stream);
+    if (direction == 1) { INTFFT_SM(SM_INV) }
+    if (direction == 2) { INTFFT_SM(SM_PAIR) }
+    INTFFT_SM(SM_FWD)
+#undef INTFFT_SM
 }
 
 hipError_t launch_fastsmall(int log2n, int direction, int rnd_round, int twd, const void *in, void *out, const int2 *h_tw,

@@ -665,7 +665,7 @@ def test_narrow_data_round_mode(log2n, dw, direction):
         x[-2, : n // 2, :] = hi
         x[-2, n // 2 :, :] = lo
         info = check(x, log2n, dw, tw, 0, 1, True, direction=direction)
-        if (6 <= log2n <= 12) or (log2n < 6 and direction == "FWD"):
+        if log2n <= 12:
             assert "_i16" in info["kernel_name"], info
         elif log2n >= 13 and not (direction == "PAIR" and log2n > 16):  # the multi-pass kernels in their ROUND = 2 forms
             assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
@@ -1038,6 +1038,18 @@ def test_fuzz_generics_with_orders(case):
     log2n, dw, tw, fmt, rnd, new, d, in_o, out_o = case
     x = uniform_frames(4, 1 << log2n, dw, 12000 + log2n * 10 + dw)
     check(x, log2n, dw, tw, fmt, rnd, new, direction=d, in_order=in_o, out_order=out_o)
+
+
+@pytest.mark.parametrize("log2n", [3, 4, 5])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+@pytest.mark.parametrize("dw", [16, 12])
+def test_rounding_mode_short_frames(log2n, direction, dw):
+    """RNDMODE = 1 at N = 8 .. 32, every direction, on k_fftsmall_i16 (one frame per lane, exact extraction)."""
+    n = 1 << log2n
+    for tw in (16, 10):
+        x = np.concatenate([edge_frames(n, dw), uniform_frames(1000, n, dw, 900 + log2n + dw), uniform_frames(65, n, 16, 901 + log2n)])
+        info = check(x, log2n, dw, tw, 0, 1, True, direction=direction)
+        assert info["fast_path"] == 1 and info["kernel_name"] == "k_fftsmall_i16", info
 
 
 @pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10, 11, 12])
