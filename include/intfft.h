@@ -173,7 +173,7 @@ int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *
 /* Environment: the library reads a few INTFFT_* variables at plan creation / first launch.  They are DIAGNOSTIC switches
  * (A/B parity of kernel families in the tests, tuning experiments); none changes results, none is needed in normal use:
  *   INTFFT_GENERIC_ONLY, INTFFT_NO_FAST1024U, INTFFT_NO_FASTW32, INTFFT_NO_BIG20, INTFFT_NO_BIG2P, INTFFT_NO_WIDE16, INTFFT_NO_TWOPASS,
- *   INTFFT_NO_PACKED_ROUND, INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_PACKED_TW (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed
+ *   INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_PACKED_TW (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed
  *   kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS, INTFFT_NO_MIXED_WORDS,
  *   INTFFT_NO_NARROW_MUL (launch geometry / scratch / generic-kernel knobs).  README.md describes each. */
 const char *intfft_strerror(int status);
