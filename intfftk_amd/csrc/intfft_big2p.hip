@@ -236,6 +236,8 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
             fast = FAST_OK && bad == 0;
         }
+        const int rnd = FAST_OK ? 0 : sl.round; // RNDMODE = 1 on the exact-path instantiation (2: narrow data)
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // (first pass after k_mid_q1: already w-bit values; harmless)
         {
             RoundTwQ t1;
             u32 wa16[8], wb16[8];
@@ -259,6 +261,14 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
                 dit_round_q<FAST_OK, 0>(v, t1, sl);
                 dit_round_q<FAST_OK, 16>(v, t1, sl);
                 if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa16, wb16, sl);
+            } else if (rnd == 1) {
+                dit_round_q<false, 0, 1>(v, t1, sl);
+                dit_round_q<false, 16, 1>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<false, 1>(v, wa16, wb16, sl);
+            } else if (rnd == 2) {
+                dit_round_q<false, 0, 2>(v, t1, sl);
+                dit_round_q<false, 16, 2>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<false, 2>(v, wa16, wb16, sl);
             } else {
                 dit_round_q<false, 0>(v, t1, sl);
                 dit_round_q<false, 16>(v, t1, sl);
@@ -298,6 +308,14 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             dit_round_q<FAST_OK, 0>(v, t2, sl);
             dit_round_q<FAST_OK, 16>(v, t2, sl);
             dit_top16<FAST_OK>(v, wa16, wb16, sl);
+        } else if (rnd == 1) {
+            dit_round_q<false, 0, 1>(v, t2, sl);
+            dit_round_q<false, 16, 1>(v, t2, sl);
+            dit_top16<false, 1>(v, wa16, wb16, sl);
+        } else if (rnd == 2) {
+            dit_round_q<false, 0, 2>(v, t2, sl);
+            dit_round_q<false, 16, 2>(v, t2, sl);
+            dit_top16<false, 2>(v, wa16, wb16, sl);
         } else {
             dit_round_q<false, 0>(v, t2, sl);
             dit_round_q<false, 16>(v, t2, sl);

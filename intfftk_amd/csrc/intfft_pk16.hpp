@@ -588,39 +588,39 @@ __device__ __forceinline__ void dif_round_q(u32 (&v)[32], const RoundTwQ &t, con
 
 // ---- 32-register DIT rounds with quarter-turn sharing (mirror of dif_round_q / dif_top16); twiddles in the DIT packing ----
 // four DIT stages on registers v[B .. B+15], offsets 1, 2, 4, 8 (stage numbers s0 .. s0+3)
-template <bool FASTX, int B>
+template <bool FASTX, int B, int ROUND = 0>
 __device__ __forceinline__ void dit_round_q(u32 (&v)[32], const RoundTwQ &t, const Slice &sl)
 {
     { // offset 1: one twiddle
         const u32 wa[4] = {t.wa1[0], t.wa1[0], t.wa1[0], t.wa1[0]}, wb[4] = {t.wb1[0], t.wb1[0], t.wb1[0], t.wb1[0]};
-        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 1], v[B + 2], v[B + 3], v[B + 4], v[B + 5], v[B + 6], v[B + 7], wa, wb, sl);
-        group4_dit<FASTX, false, false, true>(v[B + 8], v[B + 9], v[B + 10], v[B + 11], v[B + 12], v[B + 13], v[B + 14], v[B + 15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true>(v[B + 0], v[B + 1], v[B + 2], v[B + 3], v[B + 4], v[B + 5], v[B + 6], v[B + 7], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true>(v[B + 8], v[B + 9], v[B + 10], v[B + 11], v[B + 12], v[B + 13], v[B + 14], v[B + 15], wa, wb, sl);
     }
     { // offset 2: twiddle index j & 1: base 0, quarter turn 1
         const u32 wa[4] = {t.wa2[0], t.wa2[0], t.wa2[0], t.wa2[0]}, wb[4] = {t.wb2[0], t.wb2[0], t.wb2[0], t.wb2[0]};
-        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 2], v[B + 4], v[B + 6], v[B + 8], v[B + 10], v[B + 12], v[B + 14], wa, wb, sl);
-        group4_dit<FASTX, false, false, true, true>(v[B + 1], v[B + 3], v[B + 5], v[B + 7], v[B + 9], v[B + 11], v[B + 13], v[B + 15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true>(v[B + 0], v[B + 2], v[B + 4], v[B + 6], v[B + 8], v[B + 10], v[B + 12], v[B + 14], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true, true>(v[B + 1], v[B + 3], v[B + 5], v[B + 7], v[B + 9], v[B + 11], v[B + 13], v[B + 15], wa, wb, sl);
     }
     { // offset 4: twiddle index j & 3: base 0, 1; quarter turn 2, 3
         const u32 wa[4] = {t.wa4[0], t.wa4[1], t.wa4[0], t.wa4[1]}, wb[4] = {t.wb4[0], t.wb4[1], t.wb4[0], t.wb4[1]};
-        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 8], v[B + 12], v[B + 9], v[B + 13], wa, wb, sl);
-        group4_dit<FASTX, false, false, true, true>(v[B + 2], v[B + 6], v[B + 3], v[B + 7], v[B + 10], v[B + 14], v[B + 11], v[B + 15], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 8], v[B + 12], v[B + 9], v[B + 13], wa, wb, sl);
+        group4_dit<FASTX, false, ROUND, true, true>(v[B + 2], v[B + 6], v[B + 3], v[B + 7], v[B + 10], v[B + 14], v[B + 11], v[B + 15], wa, wb, sl);
     }
     { // offset 8: twiddle index j & 7: base j < 4, quarter turn j >= 4
-        group4_dit<FASTX, false, false, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl);
-        group4_dit<FASTX, false, false, true, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl);
+        group4_dit<FASTX, false, ROUND, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl);
+        group4_dit<FASTX, false, ROUND, true, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl);
     }
 }
 // offset 16: pairs (j, j + 16), twiddle index j: base for j < 8, quarter turn of base[j - 8] for j >= 8
-template <bool FASTX>
+template <bool FASTX, int ROUND = 0>
 __device__ __forceinline__ void dit_top16(u32 (&v)[32], const u32 (&wa)[8], const u32 (&wb)[8], const Slice &sl)
 {
     const u32 wa0[4] = {wa[0], wa[1], wa[2], wa[3]}, wb0[4] = {wb[0], wb[1], wb[2], wb[3]};
     const u32 wa1[4] = {wa[4], wa[5], wa[6], wa[7]}, wb1[4] = {wb[4], wb[5], wb[6], wb[7]};
-    group4_dit<FASTX, false, false, true>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl);
-    group4_dit<FASTX, false, false, true>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl);
-    group4_dit<FASTX, false, false, true, true>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl);
-    group4_dit<FASTX, false, false, true, true>(v[12], v[28], v[13], v[29], v[14], v[30], v[15], v[31], wa1, wb1, sl);
+    group4_dit<FASTX, false, ROUND, true>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl);
+    group4_dit<FASTX, false, ROUND, true>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl);
+    group4_dit<FASTX, false, ROUND, true, true>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl);
+    group4_dit<FASTX, false, ROUND, true, true>(v[12], v[28], v[13], v[29], v[14], v[30], v[15], v[31], wa1, wb1, sl);
 }
 
 // ---- four DIT stages on register offsets 1, 2, 4, 8 (NS < 4: only the first NS) ---------------------

@@ -763,7 +763,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
         // N = 2^17, 2^18 forward / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
         // quarter turns: verified on this plan's tables)
-        const bool big2p = pl->big20 && !p->rndmode && (p->direction == INTFFT_FWD || p->direction == INTFFT_INV) && big2p_supported(p->log2n) &&
+        // round mode: the inverse's 32-register pass only (the forward one has no registers left for a second set of bodies)
+        const bool big2p = pl->big20 && (p->direction == INTFFT_INV || (p->direction == INTFFT_FWD && !p->rndmode)) && big2p_supported(p->log2n) &&
                            !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
         const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&

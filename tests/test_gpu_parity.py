@@ -630,7 +630,8 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
     x = np.concatenate([uniform_frames(batch, n, 16, 500 + log2n), edge_frames(n, 16)[3:6], uniform_frames(2, n, 15, 501 + log2n)])
     info = check(x, log2n, 16, tw, 0, 1, True, direction=direction)
     assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big20", "k_mid")), info
-    assert info["n_passes"] == (2 if log2n <= 16 else 3), info
+    # N = 2^17, 2^18: the inverse takes the 32-register pass (quarter turns through the negated twiddle), the forward core three passes
+    assert info["n_passes"] == (2 if log2n <= 16 or (log2n <= 18 and direction == "INV") else 3), info
     if log2n <= 16:
         with monkeypatch.context() as m:
             m.setenv("INTFFT_NO_TWOPASS", "1")
