@@ -1152,6 +1152,8 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
+    if (two_pass && log2n >= 19) // N = 2^19, 2^20: 1024 rows x 1024 columns, two ten-stage passes (intfft_big2x.hip); natural order out only (planner)
+        return out_bitrev ? hipErrorInvalidValue : launch_big2x(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, in_halves, stream);
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the 32-register first pass (stages L-1..8), then the same second pass
         const size_t nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;

@@ -1,0 +1,370 @@
+// intfft_big2x.hip -- TWO-pass plans for N = 2^19 and 2^20 (BASELINE config 4 is N = 2^20, Taylor twiddles): int_fftNk,
+// DATA_WIDTH = 16 (or 9 .. 15 in int16 containers), TWDL_WIDTH <= 16, scaled-truncate, natural / HALVES order in -> natural order
+// out (src/vhdl/fft/int_fftNk.vhd:184-342; twiddles of STAGE >= 11 from row_twiddle_tay.vhd:123-268 via k_twiddle_stage).
+// Same packed arithmetic as intfft_fast1024.hip.  N = 2^L = 2^(L-10) rows x 1024 columns:
+//
+//   pass A  k_big2x_a<L>  stages L-1..10 down the columns; user array -> plan scratch
+//   pass B  k_big2x_b<L>  stages 9..0 along every 1024-point row + the bit-reversed (natural-order) store; scratch -> user array
+//
+// A ten-stage pass on 128-byte rows needs a 1024 x 32 tile = 128 KiB: one workgroup per CU, nothing to overlap its load / compute /
+// store phases with (measured: 3.8 TB/s on the 1024-row form of k_big2p_a).  Both passes here work on
+// HALF lines instead -- 1024 rows x 16 columns (64-byte row pieces), 512 threads x 32 registers, 68 KiB of LDS: two workgroups
+// per CU -- and the two workgroups that share every line of a tile are blocks b and b + 8: block b runs on XCD b % 8, so the
+// pair sits on ONE XCD at the same time and the line is fetched into (written back from) that L2 once.  tools/xcdbench.hip,
+// part 3: 64-byte pieces cost 3.1-3.7 TB/s when their halves are handled by unrelated workgroups, 3.8-4.6 with this pairing
+// (strided read side) and 5.1-5.2 (strided write side) -- the rates of the 128-byte tiles, at twice the occupancy.
+// The pairing is for speed only: correctness never depends on where a block runs.
+//
+// Scratch layout (per frame; n = row rho * 1024 + column, rho = (k = n(L-1)..n(L-4), rest = n(L-5)..n10), rest = (hi, q = n14..n10),
+// column = (c = n9..n4, l = n3..n0)):   [q][c][hi][k][l]
+//   pass A round 2 holds (thread = (n(L-1)..n15, l), regs = q): every register store of a workgroup is ONE 2 KiB run;
+//   pass B's tile = the 16 rows k of one `rest` x all columns: 64 runs of 1 KiB; its bit-reversed store writes 64-byte pieces
+//   whose other half belongs to the partner block (`rest` with its top bit flipped).
+// Values travel between the passes as in the other multi-pass kernels: multiplier outputs pre-shifted (Y >> 1), so an element's
+// kind after pass A is n10 = q bit 0, which is tile-uniform in pass B.
+#include "intfft_pk16.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+constexpr int ROWX = 17; // pass A: LDS row stride in dwords (16 columns + 1)
+constexpr int ROWY = 33; // pass B: LDS row stride in dwords (32 columns + 1)
+
+// wave-uniform twiddles of pass B's second round (kernel argument -> SGPRs): STAGE 4, 3, 2 (STAGE 1, 0 are multiplier-free)
+struct Round5Consts {
+    u32 wa4[16], wb4[16]; // table index q & 15
+    u32 wa3[8], wb3[8];   // q & 7
+    u32 wa2[4], wb2[4];   // q & 3
+};
+
+__device__ __forceinline__ constexpr int rev5c(int r) { return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4); }
+
+// ---- pass A: stages L-1..10 ---------------------------------------------------------------------------------------------------
+//   tile    2^(L-10) rows (stride 1024 samples = 4 KiB) x 16 consecutive columns; 64 column chunks per frame
+//   round 1 thread = (hx = n(L-6)..n10, l = n3..n0), regs j = n(L-1)..n(L-5): stages L-1..L-5
+//   LDS     row (j << RB | hx), column l                          (RB = L - 15 = 4 or 5 stages in round 2)
+//   round 2 L = 20: thread = (n19..n15, l), regs = n14..n10: stages 14..10
+//           L = 19: thread = (n18..n15, l), regs = (n14, n13..n10): two independent 4-stage rounds 13..10 (n14 rides along)
+// Twiddles as in k_big2p_a: quarter-turn sharing; round 2's set depends on the column only and is parked in LDS, round 1's is
+// per thread and re-read from the L2-resident table in every frame.
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
+                                                                                                        size_t nframes, unsigned groups, const Slice sl, int halves)
+{
+    static_assert(L == 19 || L == 20, "9 or 10 stages");
+    constexpr int RB = L - 15;
+    constexpr int T = 16 << RB;
+    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWX, then the round-2 twiddles: 8 (RB = 4) / 16 slots x 16 columns of {wa, wb}
+    uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWX);
+    const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
+    // blocks b and b + 8 (same XCD, same time) take the two 64-byte halves of the same lines: chunk = (column group g, part)
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
+    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+    const unsigned lfull = chunk * 16 + l;              // n9..n0
+    const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
+    auto ld = [&](unsigned uniform_idx, unsigned thread_off, u32 &wa, u32 &wb) {
+        const uint2 w = (twf + uniform_idx)[thread_off];
+        wa = w.x;
+        wb = w.y;
+    };
+    u32 wa16[8], wb16[8];
+    RoundTwQ t1;
+    if (hx == 0) { // round 2 (stage 10 + b, table index (rr << 10) | lfull): parked per column
+        int s = 0;
+        auto park = [&](unsigned uniform_idx) { tw2[16 * s++ + l] = (twf + uniform_idx)[lfull]; };
+        if constexpr (RB == 5)
+            for (int rr = 0; rr < 8; ++rr) park((1u << 14) - 1u + ((unsigned)rr << 10));
+        for (int rr = 0; rr < 4; ++rr) park((1u << 13) - 1u + ((unsigned)rr << 10));
+        for (int rr = 0; rr < 2; ++rr) park((1u << 12) - 1u + ((unsigned)rr << 10));
+        park((1u << 11) - 1u);
+        park((1u << 10) - 1u);
+    }
+    // round 1: reg bit b <-> stage L-5+b; index of twiddle (stage s, low reg bits jj) = ((jj << RB | hx) << 10) | lfull
+    auto round1_tw = [&](unsigned to) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld((1u << (L - 1)) - 1u + ((unsigned)jj << (RB + 10)), to, wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld((1u << (L - 2)) - 1u + ((unsigned)jj << (RB + 10)), to, t1.wa8[jj], t1.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld((1u << (L - 3)) - 1u + ((unsigned)jj << (RB + 10)), to, t1.wa4[jj], t1.wb4[jj]);
+        ld((1u << (L - 4)) - 1u, to, t1.wa2[0], t1.wb2[0]);
+        ld((1u << (L - 5)) - 1u, to, t1.wa1[0], t1.wb1[0]);
+    };
+    auto round2_tw = [&](u32(&wa2t)[8], u32(&wb2t)[8], RoundTwQ &t2) {
+        int s = 0;
+        auto get = [&](u32 &wa, u32 &wb) {
+            const uint2 w = tw2[16 * s++ + l];
+            wa = w.x;
+            wb = w.y;
+        };
+        if constexpr (RB == 5) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) get(wa2t[rr], wb2t[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) get(t2.wa8[rr], t2.wb8[rr]);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) get(t2.wa4[rr], t2.wb4[rr]);
+        get(t2.wa2[0], t2.wb2[0]);
+        get(t2.wa1[0], t2.wb1[0]);
+    };
+    u32 *const wr_base = lds + ROWX * hx + l;              // transpose, write side: row (j << RB) + hx
+    const u32 *const rd_base = lds + ROWX * (hx << 5) + l; // read side: row (jx << 5) + q, jx = tid >> 4
+    // store side: scratch [q][c][hi][k][l], thread = (jx = n(L-1)..n15, l): k = jx >> (RB - 4), hi = the low RB - 4 bits of jx
+    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & ((1u << (RB - 4)) - 1u)) << 8) | (((unsigned)hx >> (RB - 4)) << 4) | (unsigned)l;
+    const v2s none = {0, 0};
+    const short s2 = (short)(1 - (hx & 1)); // L = 20, round 2: the kind of its inputs is n15 = bit 0 of the new thread index
+    const v2s sh2 = {s2, s2};
+
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = in + (frame << L); // wave-uniform
+        u32 *dst = scr + (frame << L);
+        unsigned toff_l = toff, toff2_l = toff2; // opaque copies: see k_big2p_a (LICM would hoist 40+ VGPRs of addresses)
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        u32 v[32];
+        if (halves) { // HALVES order in: memory index = 2 * (n without n(L-1)) + n(L-1): registers j and j + 16 are one 8-byte load
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *sh = reinterpret_cast<const v2u *>(src);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + 10)) + toff_l);
+                v[j] = w.x;
+                v[j + 16] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 10)) + toff_l); // regs = n(L-1)..n(L-5)
+        }
+        round1_tw(toff_l);
+        // guard-bit vote of the tile (closed under stages L-1..10); the barrier also orders the previous frame's LDS reads
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
+            fast = FAST_OK && bad == 0;
+        }
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+#define INTFFT_2X_ROUND1(FX)                                                                                  \
+    {                                                                                                         \
+        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                     \
+        dif_round_q<FX, 0, 0, false>(v, t1, sl, none);                                                        \
+        dif_round_q<FX, 16, 0xF, false>(v, t1, sl, none);                                                     \
+    }
+        if (fast) INTFFT_2X_ROUND1(FAST_OK)
+        else INTFFT_2X_ROUND1(false)
+#undef INTFFT_2X_ROUND1
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wr_base[ROWX * (j << RB)] = v[j];
+        __syncthreads();
+        u32 wa2t[8], wb2t[8]; // L = 20: top stage of round 2
+        RoundTwQ t2;
+        round2_tw(wa2t, wb2t, t2);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = rd_base[ROWX * q];
+        if constexpr (RB == 4) { // two independent 4-stage rounds 13..10; the kind of their inputs is n14 = q bit 4
+            if (fast) {
+                dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
+                dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
+            } else {
+                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+            }
+        } else { // stages 14..10; the kind of the inputs is n15 = jx bit 0 (a thread bit)
+            if (fast) {
+                dif_top16<FAST_OK, 0, true>(v, wa2t, wb2t, sl, sh2);
+                dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
+                dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
+            } else {
+                dif_top16<false, 0, true>(v, wa2t, wb2t, sl, sh2);
+                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (L - 5)))[toff2_l] = v[q]; // [q][c][hi][k][l]: 2 KiB (L = 19: 1 KiB) per register
+    }
+    (void)T;
+}
+
+// ---- pass B's second round: DIF stages 4..0 on regs = n4..n0, wave-uniform twiddles -------------------------------------------
+// inputs: per-thread kind (shv: 0 where the registers already hold X >> 1)
+template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl, v2s shv)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) { // stage 4: pairs (q, q + 16), twiddle index q
+        const u32 wa[4] = {c.wa4[g], c.wa4[g + 1], c.wa4[g + 2], c.wa4[g + 3]}, wb[4] = {c.wb4[g], c.wb4[g + 1], c.wb4[g + 2], c.wb4[g + 3]};
+        group4<false, FASTX, false, true, true, 0, true>(v[g], v[g + 16], v[g + 1], v[g + 17], v[g + 2], v[g + 18], v[g + 3], v[g + 19], wa, wb, sl, shv);
+    }
+    const u32 wa30[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb30[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa31[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb31[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    // stage 3: pairs (q, q + 8); kind = q & 16
+    group4<false, FASTX, false, true, true, 0>(v[0], v[8], v[1], v[9], v[2], v[10], v[3], v[11], wa30, wb30, sl);
+    group4<false, FASTX, false, true, true, 0>(v[4], v[12], v[5], v[13], v[6], v[14], v[7], v[15], wa31, wb31, sl);
+    group4<false, FASTX, false, true, true, 0xF>(v[16], v[24], v[17], v[25], v[18], v[26], v[19], v[27], wa30, wb30, sl);
+    group4<false, FASTX, false, true, true, 0xF>(v[20], v[28], v[21], v[29], v[22], v[30], v[23], v[31], wa31, wb31, sl);
+#pragma unroll
+    for (int B = 0; B < 32; B += 16) { // stage 2: pairs (q, q + 4); kind = q & 8
+        group4<false, FASTX, false, true, true, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+        group4<false, FASTX, false, true, true, 0xF>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+    }
+#pragma unroll
+    for (int g = 0; g < 32; g += 8) { // stage 1: kind = q & 4
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_mj<false, false>(v[g + 1], v[g + 3]);
+        bfly_triv<false, true>(v[g + 4], v[g + 6]);
+        bfly_mj<false, true>(v[g + 5], v[g + 7]);
+    }
+#pragma unroll
+    for (int g = 0; g < 32; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
+}
+
+// ---- pass B: stages 9..0 on 16 rows x 1024 columns + the bit-reversed store ---------------------------------------------------
+//   tile    (frame, rest): rows rho = (k, rest), k = n(L-1)..n(L-4) = 0..15; scratch [q][c][hi][k][l] -> 64 runs of 1 KiB
+//   round 1 thread = (n4, k, n3..n0), regs j = n9..n5: stages 9..5; twiddles per thread (they depend on n4..n0 only), frame invariant
+//   LDS     row (j << 4 | k), column n4..n0
+//   round 2 thread = (jj = n9..n5, kb = rev4(k)), regs q = n4..n0: stages 4..0, wave-uniform twiddles
+//   store   X index = rev5(q) << (L-5) | rev5(jj) << (L-10) | rev(rest) << 4 | rev4(k): 16 consecutive lanes = one 64-byte piece;
+//           the partner block (`rest` with its top bit flipped -> rev(rest) ^ 1) writes the other half of the line
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_b(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
+                                                                                             const Round5Consts c, size_t nframes, const Slice sl)
+{
+    static_assert(L == 19 || L == 20, "rows of 1024 points");
+    constexpr int RL = L - 14; // bits of `rest`
+    extern __shared__ u32 lds[];
+    const int tid = threadIdx.x;
+    const int m = ((tid >> 8) << 4) | (tid & 15), k = (tid >> 4) & 15;
+    u32 wa16[8], wb16[8];
+    RoundTwQ t1;
+    {
+        auto ld = [&](unsigned idx, u32 &wa, u32 &wb) {
+            const uint2 w = twf[idx + (unsigned)m];
+            wa = w.x;
+            wb = w.y;
+        };
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld(511u + ((unsigned)jj << 5), wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld(255u + ((unsigned)jj << 5), t1.wa8[jj], t1.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld(127u + ((unsigned)jj << 5), t1.wa4[jj], t1.wb4[jj]);
+        ld(63u, t1.wa2[0], t1.wb2[0]);
+        ld(31u, t1.wa1[0], t1.wb1[0]);
+    }
+    const int jj = tid >> 4, kb = tid & 15;
+    const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
+    u32 *const wr_base = lds + ROWY * k + m;                       // row (j << 4) + k
+    const u32 *const rd_base = lds + ROWY * ((jj << 4) | krow);    // row (jj << 4) + k, k = rev4(kb)
+    const unsigned toff = (((unsigned)tid >> 8) << (L - 11)) | ((unsigned)tid & 255u);
+    const unsigned rjj = __brev((unsigned)jj) >> 27;
+    const unsigned toff2 = (rjj << (L - 10)) | (unsigned)kb;
+    const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
+    const v2s sh5 = {s5, s5};
+    const v2s none = {0, 0};
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+
+    for (size_t t = blockIdx.x;; t += gridDim.x) { // gridDim.x is a multiple of 16: slot and part are fixed per block
+        const size_t G = (t >> 4) * 8u + slot;
+        const size_t frame = G >> (RL - 1);
+        if (frame >= nframes) break;
+        const unsigned rest = (part << (RL - 1)) | ((unsigned)G & ((1u << (RL - 1)) - 1u));
+        const unsigned q0 = rest & 31u, hi = rest >> 5;
+        const u32 *src = scr + (frame << L) + ((size_t)q0 << (L - 5)) + (hi << 8); // wave-uniform
+        u32 *dst = out + (frame << L) + ((__brev(rest) >> (32 - RL)) << 4);
+        unsigned toff_l = toff, toff2_l = toff2;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        u32 v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (L - 10)) + toff_l); // c = (j, n4)
+        // kind of this tile's inputs = n10 = q0 bit 0 (pass A left Y >> 1 there); vote on the tile's own inputs
+        const unsigned k10 = q0 & 1u;
+        const short sa = (short)(1 - (int)k10);
+        const v2s sh_a = {sa, sa};
+        bool fast = false;
+        {
+            const u32 addc = k10 ? sl.gbias1 : sl.gbias, maskc = k10 ? sl.gmask1 : sl.gmask;
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + addc;
+            const int bad = __syncthreads_or((acc & maskc) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && bad == 0;
+        }
+        if (fast) {
+            dif_top16<FAST_OK, 0, true>(v, wa16, wb16, sl, sh_a);
+            dif_round_q<FAST_OK, 0, 0, false>(v, t1, sl, none);
+            dif_round_q<FAST_OK, 16, 0xF, false>(v, t1, sl, none);
+        } else {
+            dif_top16<false, 0, true>(v, wa16, wb16, sl, sh_a);
+            dif_round_q<false, 0, 0, false>(v, t1, sl, none);
+            dif_round_q<false, 16, 0xF, false>(v, t1, sl, none);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wr_base[ROWY * (j << 4)] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = rd_base[q];
+        if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
+        else dif_round5_c<false>(v, c, sl, sh5);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) __builtin_nontemporal_store(v[q], dst + ((size_t)rev5c(q) << (L - 5)) + toff2_l);
+    }
+}
+
+// the quarter-turn relation both passes rely on (stages 5 .. L-1), checked on the plan's generated tables (host copy)
+bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd)
+{
+    for (int s = 5; s < log2n; ++s) {
+        const int2 *t = h_tw + ((size_t)1 << s) - 1;
+        const size_t h = (size_t)1 << (s - 1);
+        for (size_t k = 0; k < h; ++k) {
+            const int neg = (int)(((long long)(-t[k].x) << (64 - twd)) >> (64 - twd));
+            if (t[k + h].x != t[k].y || t[k + h].y != neg) return false;
+        }
+    }
+    return true;
+}
+
+bool big2x_supported(int log2n) { return (log2n == 19 || log2n == 20) && !getenv("INTFFT_NO_BIG2X"); }
+
+const char *big2x_kernel_name() { return "k_big2x_a/k_big2x_b"; }
+
+hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes, const Slice &sl,
+                        int halves, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = h_tw[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        wb = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+#define INTFFT_2X_LAUNCH(LL, FX)                                                                                                   \
+    {                                                                                                                              \
+        constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
+        const size_t ldsa = (size_t)(32 << RB) * ROWX * sizeof(u32) + (LL == 20 ? 16 : 8) * 16 * sizeof(uint2);                    \
+        const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
+        allow_max_lds(kptr(k_big2x_a<LL, FX>));                                                                                    \
+        allow_max_lds(kptr(k_big2x_b<LL, FX>));                                                                                    \
+        const size_t per_cu = LL == 20 ? 2 : 4, cap = (size_t)device_cus() * per_cu / 64;                                          \
+        const unsigned groups = (unsigned)(nframes < cap ? nframes : (cap ? cap : 1));                                             \
+        hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
+        const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
+        const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
+        hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl);              \
+    }
+    if (log2n == 20) {
+        if (fx) INTFFT_2X_LAUNCH(20, true) else INTFFT_2X_LAUNCH(20, false)
+    } else {
+        if (fx) INTFFT_2X_LAUNCH(19, true) else INTFFT_2X_LAUNCH(19, false)
+    }
+#undef INTFFT_2X_LAUNCH
+    return hipGetLastError();
+}
+
+} // namespace intfft

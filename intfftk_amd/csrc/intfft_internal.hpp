@@ -221,6 +221,12 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
                           const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16, int rndmode = 0);
 hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int two_pass, const void *in, void *out, void *scratch,
                          const int2 *tw_all, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream, int data_width = 16, int rndmode = 0);
+// two-pass plans for N = 2^19, 2^20 forward: 1024 x 1024 split on half lines, XCD-paired blocks (intfft_big2x.hip)
+bool big2x_supported(int log2n);
+bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd);
+const char *big2x_kernel_name();
+hipError_t launch_big2x(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,
+                        const struct Slice &sl, int halves, hipStream_t stream);
 // two-pass plans for N = 2^17, 2^18 forward: 32-register first pass (intfft_big2p.hip) + k_mid_p2 / k_mid_c
 bool big2p_supported(int log2n);
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd);

@@ -770,6 +770,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
                                 big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+        // N = 2^19, 2^20 forward, truncate mode, natural order out: 1024 rows x 1024 columns in two ten-stage passes (intfft_big2x.hip)
+        const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && p->out_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
+                           !getenv("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+        if (big2x) pl->big_two_pass = true;
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
@@ -795,7 +799,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : big2x ? big2x_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;

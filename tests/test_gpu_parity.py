@@ -119,9 +119,34 @@ def test_three_pass_kernels_n8192_to_n524288(log2n, batch):
     x = uniform_frames(batch, n, 15, 2000 + log2n)
     x[0] = uniform_frames(1, n, 16, 7)[0]  # one full-scale frame: exact extraction in its tiles
     info = check(x, log2n, 16, 16, 0, 0, True)
-    assert info["kernel_name"].startswith("k_big2") and info["n_passes"] == (2 if log2n <= 18 else 3)
+    assert info["kernel_name"].startswith("k_big2") and info["n_passes"] == 2
     if batch <= 9:
         check(x, log2n, 16, 13, 0, 0, False)  # narrower twiddles, XSER "OLD"
+
+
+@pytest.mark.parametrize("log2n,batch", [(19, 1), (19, 5), (19, 34), (20, 1), (20, 3), (20, 17)])
+def test_two_pass_n2pow19_n2pow20(log2n, batch, monkeypatch):
+    """N = 2^19, 2^20 forward (BASELINE config 4 is N = 2^20): 2^(L-10) rows x 1024 columns in two ten-stage passes on half
+    lines (k_big2x_a / k_big2x_b, XCD-paired blocks), natural or HALVES order in; against the oracle and against the three-pass
+    plan it replaces (INTFFT_NO_BIG2X); batches that do not fill the frame groups of the launch, a full-scale frame (exact
+    extraction in its tiles), 13-bit twiddles with XSER "OLD", 12-bit data."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 2100 + log2n + batch)
+    x[0] = uniform_frames(1, n, 16, 7)[0]
+    got, info = run_gpu(x, log2n, 16, 16, 0, 0, True)
+    assert info["kernel_name"] == "k_big2x_a/k_big2x_b" and info["n_passes"] == 2, info
+    assert np.array_equal(got, run_ref(x, log2n, 16, 16, 0, 0, True))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_BIG2X", "1")
+        got3, info3 = run_gpu(x, log2n, 16, 16, 0, 0, True)
+        assert info3["kernel_name"] == "k_big20_p1/p2/p3" and info3["n_passes"] == 3, info3
+    assert np.array_equal(got, got3)
+    if batch <= 5:
+        info = check(x, log2n, 16, 16, 0, 0, True, in_order="HALVES")
+        assert info["n_passes"] == 2
+        check(x[:2], log2n, 16, 13, 0, 0, False)
+        info = check(x[:2] >> 4, log2n, 12, 16, 0, 0, True)
+        assert info["kernel_name"] == "k_big2x_a/k_big2x_b", info
 
 
 @pytest.mark.parametrize("log2n", [17, 18])
@@ -290,7 +315,8 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    two = log2n <= 18  # N = 2^17, 2^18: the 32-register passes take the native orders too
+    # N = 2^17, 2^18: the 32-register passes take the native orders too; N = 2^19, 2^20: HALVES in -> natural order out only
+    two = log2n <= 18 or (direction == "FWD" and out_order == "NATURAL")
     assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 
