@@ -351,8 +351,11 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
         allow_max_lds(kptr(k_big2x_a<LL, FX>));                                                                                    \
         allow_max_lds(kptr(k_big2x_b<LL, FX>));                                                                                    \
-        const size_t per_cu = LL == 20 ? 2 : 4, cap = (size_t)device_cus() * per_cu / 64;                                          \
-        const unsigned groups = (unsigned)(nframes < cap ? nframes : (cap ? cap : 1));                                             \
+        /* frame groups: 64 = every block takes ONE tile of a 64-frame chunk.  The partner blocks b, b + 8 then start together  \
+           (per-XCD dispatch order) instead of drifting apart over a frame walk: FETCH_SIZE 387 MB against 436 MB per 2^26      \
+           samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
+        const size_t cap = 64;                                                                                                     \
+        const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
         hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
         const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \

@@ -46,9 +46,11 @@ def run(name, steps=20, check_frames=8):
     y = torch.empty(core.out_shape(batch), device="cuda", dtype=core.out_dtype)
     st = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
+    calls = steps
     while time.time() - t0 < 0.25:  # clock ramp
         for _ in range(10):
             core.exec_raw(x.data_ptr(), y.data_ptr(), batch, st)
+        calls += 10
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -81,7 +83,7 @@ def run(name, steps=20, check_frames=8):
     gs = batch * n / ms / 1e6
     out = {"config": name, "log2n": log2n, "batch": batch, "dir": direction, "ms": ms, "Gsample/s": gs,
            "GB/s": gs * bps, "roofline_frac": gs * bps / 8000.0, "passes": core.info["n_passes"],
-           "kernel": core.info["kernel_name"], "parity_prefix_ok": ok}
+           "kernel": core.info["kernel_name"], "parity_prefix_ok": ok, "calls": calls}
     core.close()
     del x, y
     torch.cuda.empty_cache()
