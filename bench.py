@@ -81,9 +81,10 @@ def pmc_digest():
 # ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
 def cpu_baseline(x_dev, y_dev, log2n, direction):
     """Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
-    to run) and uses the all-core pass as a parity gate for the GPU output of those frames.  Headline entry: in-place
-    form, all host threads.  Also: single thread, and the stream form (the literal dataflow of math/fn_radix2.m:
-    half-split lanes, per-stage butterflies, fn_rev2rdx commutation) all-core and single-thread."""
+    to run) and uses the all-core passes as parity gates for the GPU output of those frames.  Headline entry (`value`): the
+    FASTER of the two forms on all host threads -- the stream form (the literal dataflow of math/fn_radix2.m: half-split
+    lanes, per-stage butterflies, fn_rev2rdx commutation) or the flat in-place form; `form` says which.  Both forms are
+    also reported on their own, all-core and single-thread."""
     import numpy as np
 
     from oracle import oracle_c as C
@@ -116,10 +117,14 @@ def cpu_baseline(x_dev, y_dev, log2n, direction):
     f_all, v_all, ref = timed(32768 * scale // work, 1, threads)
     parity = bool(np.array_equal(y_dev[:f_all].cpu().numpy(), ref))
     f_one, v_one, _ = timed(1024 * scale // work, 1, 1, reps=2)
-    return {"value": v_sall, "unit": "Gsample/s", "cores": threads, "kind": "port",
-            "sample": "first %d frames of the same workload, oracle STREAM form (the dataflow of math/fn_radix2.m with the RTL's "
-                      "integer butterflies), OpenMP over frames, best of 3 (fixed sample)" % f_sall,
+    best_form = "stream" if v_sall >= v_all else "in_place"
+    return {"value": max(v_sall, v_all), "unit": "Gsample/s", "cores": threads, "kind": "port", "form": best_form,
+            "sample": "first %d frames of the same workload, the faster of the oracle's two forms (here: %s), OpenMP over "
+                      "frames, best of 3 (fixed sample)" % (f_sall, best_form),
             "parity_checked_frames": f_sall, "parity_ok": parity_stream and parity,
+            "stream_form": {"value": v_sall, "cores": threads, "sample": "%d frames, stream form (the dataflow of math/fn_radix2.m "
+                                                                         "with the RTL's integer butterflies)" % f_sall,
+                            "parity_ok": parity_stream},
             "single_thread": {"value": v_sone, "cores": 1, "sample": "%d frames, stream form" % f_sone},
             "in_place_form": {"value": v_all, "cores": threads, "sample": "%d frames, flat in-place form" % f_all,
                               "parity_ok": parity},
@@ -242,6 +247,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's)")
     ap.add_argument("--e2e", action="store_true", help="also time root scatter -> transform -> gather (reported apart)")
+    ap.add_argument("--rank-seeded-data", action="store_true",
+                    help="every rank draws its own input (seed + rank); default: every rank transforms the SAME synthetic batch as "
+                         "rank 0, so that the N = 1 line of a scaling run is the single-GPU bench line exactly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the section-8(d) side figures (profiling runs)")
     ap.add_argument("--prewarm", type=int, default=400,
@@ -249,6 +257,9 @@ def main():
                          "back-to-back launches to reach its steady shader clock; see DESIGN.md)")
     args = ap.parse_args()
 
+    # dmabuf IPC (the host driver has no legacy IPC): needed by RCCL between ranks; set here too, not only in spawn_ranks, so that
+    # the driver's `python -m torch.distributed.run ... bench.py` path has it even if its environment dropped the variable
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # one process per GPU, rendezvous on 127.0.0.1
 
@@ -295,7 +306,7 @@ def main():
     batch = args.batch or cfg_batch
     ctor = int_fft_single_path if direction == "FWD" else int_fft_ifft_pair
     core = ctor(NFFT=log2n, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, device=dev_index)
-    x = make_input(batch, n, seed, rank)
+    x = make_input(batch, n, seed, rank if args.rank_seeded_data else 0)
     y = torch.empty_like(x)
     stream = torch.cuda.current_stream().cuda_stream
     in_ptr, out_ptr = x.data_ptr(), y.data_ptr()
@@ -369,8 +380,34 @@ def main():
         ok = None
         if rank == 0:  # same rows as the resident transform of rank 0's own shard
             ok = bool(torch.equal(res[:batch], core(root_x[:batch])))
+        # scatter and gather timed on their own (max over ranks): the root drives world - 1 peers at once, one xGMI link each
+        link = None
+        if world > 1:
+            res_local = sh.scatter(root_x, total, 0)
+            ts, tg = [], []
+            for it in range(2 + 3):
+                barrier()
+                t0 = time.perf_counter()
+                loc = sh.scatter(root_x, total, 0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t1 = time.perf_counter()
+                sh.gather(res_local, total, 0)
+                torch.cuda.synchronize()
+                dist.barrier()
+                t2 = time.perf_counter()
+                if it >= 2:
+                    ts.append(t1 - t0)
+                    tg.append(t2 - t1)
+            t_s, t_g = max_over_ranks(min(ts), red_dev), max_over_ranks(min(tg), red_dev)
+            peer_bytes = (BYTES_PER_SAMPLE // 2) * batch * n
+            link = {"scatter_ms": t_s * 1e3, "gather_ms": t_g * 1e3, "scatter_link_GBps": peer_bytes / t_s / 1e9,
+                    "gather_link_GBps": peer_bytes / t_g / 1e9, "peers": world - 1,
+                    "what": "bytes to / from ONE peer over the time of the whole grouped scatter / gather (all peers concurrently)"}
+            del loc, res_local
         e2e = {"value": total * n / t_e2e / 1e9, "unit": "Gsample/s", "ms": t_e2e * 1e3, "frames": total,
-               "bytes_moved_per_peer": (BYTES_PER_SAMPLE // 2) * batch * n,
+               "bytes_moved_per_peer": (BYTES_PER_SAMPLE // 2) * batch * n, "link": link,
+               "link_GBps": None if link is None else min(link["scatter_link_GBps"], link["gather_link_GBps"]),
                "mode": "root scatter -> transform -> gather, one batch_isend_irecv group each way "
                        "(%s)" % ("gloo via host staging: diagnostics" if share else "RCCL: ncclGroupStart/ncclSend,Recv/ncclGroupEnd"),
                "p2p_ops_per_group": sh.last_group_sizes[-2:], "matches_resident": ok}
@@ -400,7 +437,8 @@ def main():
                        "batch_per_gpu": batch, "n": n, "parallelism": "batch-shard x%d" % world,
                        "kernel": core.info["kernel_name"], "launches_per_step": core.info["n_passes"],
                        "clock_prewarm_steps": args.prewarm,
-                       "backend": backend, "rccl_ranks": rccl_ranks},
+                       "backend": backend, "rccl_ranks": rccl_ranks,
+                       "data_per_rank": "seed + rank" if args.rank_seeded_data else "identical on every rank (rank 0's batch)"},
             "per_gpu": {"kernel_ms": per_gpu_ms,
                         "Gsample/s": [batch * n / m / 1e6 for m in per_gpu_ms],
                         "roofline_frac": [alg_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS for m in per_gpu_ms]},
@@ -416,7 +454,7 @@ def main():
             out["e2e"] = e2e
         if extras:
             out["cold"] = cold
-            xf = make_input(batch, n, seed, rank, full_scale=True)
+            xf = make_input(batch, n, seed, 0, full_scale=True)
             stepf = lambda: core.exec_raw(xf.data_ptr(), out_ptr, batch, stream)  # noqa: E731
             for _ in range(20):
                 stepf()

@@ -633,7 +633,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (rc == INTFFT_OK) {
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->out_cb;
-            pl->buf2d_frames = std::max<size_t>(1, ((size_t)256 << 20) / frame_bytes);
+            size_t layout_mb = 256; // per layout buffer; INTFFT_SCRATCH_MB bounds these as it bounds the 1-D plans' scratch
+            if (const char *e = getenv("INTFFT_SCRATCH_MB")) layout_mb = atoi(e) > 0 ? (size_t)atoi(e) : layout_mb;
+            pl->buf2d_frames = std::max<size_t>(1, (layout_mb << 20) / frame_bytes);
             if (const char *e = getenv("INTFFT_2D_CHUNK_FRAMES")) // diagnostics: exercise the chunk loop on small batches
                 if (atoi(e) > 0) pl->buf2d_frames = std::min(pl->buf2d_frames, (size_t)atoi(e));
             for (int i = 0; i < 2 && rc == INTFFT_OK; ++i) rc = (int)hipMalloc(&pl->buf2d[i], pl->buf2d_frames * frame_bytes);
@@ -873,7 +875,10 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
         info->compute_word = 0;
         info->fast_path = 0;
+        // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
         info->scratch_bytes = 2 * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+        for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
+            if (sp) info->scratch_bytes += sp->scratch_bytes;
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }

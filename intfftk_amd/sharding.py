@@ -31,13 +31,19 @@ class ShardedTransform:
     stage_via_cpu: move the point-to-point payloads through host memory (gloo cannot send device tensors;
     only the single-GPU diagnostics mode of bench.py needs this -- RCCL sends device memory directly)."""
 
-    def __init__(self, transform: Callable, n: int, in_dtype, out_dtype, device, group=None, stage_via_cpu: bool = False):
+    def __init__(self, transform: Callable, n: int, in_dtype, out_dtype, device, group=None, stage_via_cpu: bool = False,
+                 out_sample_shape: Optional[Tuple[int, ...]] = None):
         import torch.distributed as dist
 
         self.dist = dist
         self.transform = transform
         self.n = n
         self.in_dtype, self.out_dtype = in_dtype, out_dtype
+        # trailing shape of one result frame: [N, 2] containers, or [N, 2, 2] int64 words for results beyond 64 bits
+        # (IntFFTCore.out_shape); taken from the transform when it has one
+        if out_sample_shape is None and hasattr(transform, "out_shape"):
+            out_sample_shape = tuple(transform.out_shape(1))[1:]
+        self.out_sample_shape = tuple(out_sample_shape) if out_sample_shape is not None else (n, 2)
         self.device = device
         self.group = group
         self.rank = dist.get_rank(group)
@@ -79,7 +85,7 @@ class ShardedTransform:
         return local.to(self.device) if self.stage_via_cpu else local
 
     def gather(self, local, batch: int, root: int = 0):
-        """This rank's result shard -> [batch, N, 2] on the root (None elsewhere)."""
+        """This rank's result shard -> [batch, *out_sample_shape] on the root (None elsewhere)."""
         import torch
 
         bounds = shard_bounds(batch, self.world)
@@ -91,12 +97,12 @@ class ShardedTransform:
             else:
                 self._run_group([])
             return None
-        out = torch.empty((batch, self.n, 2), dtype=self.out_dtype, device=self.device)
+        out = torch.empty((batch,) + self.out_sample_shape, dtype=self.out_dtype, device=self.device)
         ops, staged = [], []
         for r, (a, b) in enumerate(bounds):
             if r != root and b > a:
                 if self.stage_via_cpu:
-                    buf = torch.empty((b - a, self.n, 2), dtype=self.out_dtype, device="cpu")
+                    buf = torch.empty((b - a,) + self.out_sample_shape, dtype=self.out_dtype, device="cpu")
                     staged.append((a, b, buf))
                     ops.append(("recv", buf, r))
                 else:
@@ -115,7 +121,7 @@ class ShardedTransform:
     def run_from_root(self, root_batch, batch: int, root: int = 0):
         """End-to-end: scatter from the root, transform, gather back to the root."""
         local = self.scatter(root_batch, batch, root)
-        res = self.transform(local) if local.shape[0] else local.new_empty((0, self.n, 2), dtype=self.out_dtype)
+        res = self.transform(local) if local.shape[0] else local.new_empty((0,) + self.out_sample_shape, dtype=self.out_dtype)
         return self.gather(res, batch, root)
 
 

@@ -53,6 +53,7 @@ def main():
         for mode, (fmt, rnd) in MODES.items():
             core = int_fft_single_path(nfft, 16, 16, fmt, rnd, "NEW")
             y = core(torch.from_numpy(x.astype(np.int16)).cuda()).cpu().numpy()
+            assert core.out_bits <= 32, "the testbench dumps through conv_integer: a VHDL integer holds 32 bits"
             textio.write_di_single(os.path.join(a.out, "%s_expected_%s.dat" % (name, mode)), y)
             manifest["cases"].append({"case": name, "tb": "tb_single_dump", "nfft": nfft, "mode": mode, "format": fmt, "rndmode": rnd,
                                       "frames": int(x.shape[0]), "stimulus": "%s_di_single.dat" % name,
@@ -83,6 +84,7 @@ def main():
     for mode, (fmt, rnd) in [("TRUNCATE", (0, 0)), ("UNSCALED", (1, 0))]:
         core = int_fft_ifft_pair(7, 16, 16, fmt, rnd, "NEW")
         y = core(torch.from_numpy(x.astype(np.int16)).cuda()).cpu().numpy().astype(np.int64)
+        assert core.out_bits <= 32, "the testbench dumps through conv_integer: a VHDL integer holds 32 bits"
         beats = y.reshape(-1, 2, 2)  # [beat, lane, (re, im)]: Q0_RE Q1_RE Q0_IM Q1_IM as the ports SHOULD carry them
         np.savetxt(os.path.join(a.out, "pair_n7_expected_%s.dat" % mode),
                    np.stack([beats[:, 0, 0], beats[:, 1, 0], beats[:, 0, 1], beats[:, 1, 1]], axis=-1), fmt="%d")
