@@ -70,20 +70,18 @@ constexpr int ROW_DW = 20; // LDS row stride in dwords: 16 data + 4 pad (16-B al
 
 // ---- one frame: v[] (lane = n5..0, j = n9..6) -> transformed, stored as frame f -------------------
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (the w-bit wraps of intfft_pk16.hpp)
-template <int L, int ROUND, bool OUT_BITREV, int FASTX>
-__device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
-                                                const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
+// phase 1: stages 9, 8, 7, 6 in registers
+template <int L, int ROUND, int FASTX>
+__device__ __forceinline__ void transform_phase1(u32 (&v)[16], const Twiddles<(ROUND != 0)> &tw, const Slice &sl)
 {
     static_assert(L >= 6 && L <= 10, "wave kernel: 64 <= N <= 1024");
-    static_assert(L >= 7 || !OUT_BITREV, "native orders need N >= 128");
     // P (truncate mode): multiplier outputs are emitted pre-shifted (Y >> 1); after a stage with
     // register offset h the registers with (j & h) != 0 hold Y >> 1, the others hold S.
     constexpr bool P = !ROUND;
     constexpr bool Q = !ROUND;
-    constexpr int M0 = 0, MA = P ? 0xF : 0;                                      // PREMASKs
+    constexpr int M0 = 0;                                                        // PREMASKs
     constexpr int MH = (P && L >= 10) ? 0xC : 0;                                 // stage 8 after stage 9
-    constexpr int MODD7 = (P && L >= 9) ? 0xA : 0, MODD6 = (P && L >= 8) ? 0xA : 0, MODD5 = (P && L >= 7) ? 0xA : 0;
+    constexpr int MODD7 = (P && L >= 9) ? 0xA : 0, MODD6 = (P && L >= 8) ? 0xA : 0;
 
     // ---- phase 1: stages 9, 8, 7, 6 (register offsets 8, 4, 2, 1) ----
     if constexpr (Q) {
@@ -133,6 +131,18 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
         group4<ROUND, FASTX, false, P, false, MODD6>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], wa, wb, sl);
     }
 
+}
+
+// the rest: lane swaps with stages 5 and 4, the LDS transpose, stages 3..0, the store
+template <int L, int ROUND, bool OUT_BITREV, int FASTX>
+__device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
+                                               const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
+                                               const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
+{
+    static_assert(L >= 7 || !OUT_BITREV, "native orders need N >= 128");
+    constexpr bool P = !ROUND;
+    constexpr int M0 = 0, MA = P ? 0xF : 0;
+    constexpr int MODD5 = (P && L >= 7) ? 0xA : 0;
     // ---- lane bit 5 <-> reg bit 3, stage 5: (j, j+8); kind = j & 1 ----
     swap_guard(v);
 #pragma unroll
@@ -252,6 +262,27 @@ __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f
     }
 }
 
+template <int L, int ROUND, bool OUT_BITREV, int FASTX>
+__device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
+                                                const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
+                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
+{
+    transform_phase1<L, ROUND, FASTX>(v, tw, sl);
+    transform_tail<L, ROUND, OUT_BITREV, FASTX>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+}
+
+// Guard-bit test behind phase 1 (frames that failed the input vote): after stage 6 the odd registers hold Y >> 1, the even ones S.
+// If every value now carries a guard bit -- S-type |re|, |im| < 2^14, Y >> 1-type < 2^13 -- the argument of frame_has_guard_bit()
+// restarts here with fewer stages to go, and the remaining six stages take the fast extraction.  Full-scale random input passes
+// this test almost always: four scaled stages average 16 inputs per value.
+__device__ __forceinline__ bool guard_bit_after_phase1(const u32 (&v)[16], const Slice &sl)
+{
+    u32 a0 = 0, a1 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) a0 |= v[j] + sl.gbias, a1 |= v[j + 1] + sl.gbias1;
+    return __builtin_amdgcn_ballot_w64(((a0 & sl.gmask) | (a1 & sl.gmask1)) != 0) == 0;
+}
+
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
 template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
@@ -338,6 +369,21 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
     auto run = [&](u32(&v)[16], size_t f) {
         // partial last chunk: natural order -> per-lane predicate; BITREV order -> "chunk is full" + the frame count
         const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
+        if constexpr (FAST_OK && L >= 8) {
+            // one instance of each phase body: fast or exact phase 1, then -- for a frame that failed the input vote -- a second vote
+            // on the values behind stage 6, then the fast or exact tail
+            if (sl.wd == 16) {
+                bool fast = frame_has_guard_bit(v, sl.gbias, sl.gmask);
+                if (fast) transform_phase1<L, ROUND, 1>(v, tw, sl);
+                else {
+                    transform_phase1<L, ROUND, 2>(v, tw, sl); // the t = 16 exact form (mul2x_t16)
+                    fast = guard_bit_after_phase1(v, sl);
+                }
+                if (fast) transform_tail<L, ROUND, OUT_BITREV, 1>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+                else transform_tail<L, ROUND, OUT_BITREV, 2>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+                return;
+            }
+        }
         if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) {
             transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
             return;

@@ -10,7 +10,8 @@
 // frame: 4096 samples, 16 per thread, 128-byte runs in global memory); pass 2 transforms over c (a workgroup
 // owns the 16 rows r = 16 j + r0, j = 0..15, i.e. the rows whose bit-reversed indices are adjacent, so that
 // each store instruction writes 256-byte runs of the natural-order output brev16(n)).  The scratch layout
-// [r0][j][c] makes the 4096 samples of a pass-2 workgroup contiguous.
+// [r0][c7..4][j][c3..0] makes the 4096 samples of a pass-2 workgroup contiguous AND turns every register store of pass 1 and every
+// register load of pass 2 into one 2 KiB run (round 3; round 2's [r0][j][c] left pass 1 with 128-byte pieces 2 KiB apart).
 //
 // N = 2^13 .. 2^15 (template L; round 2): the same two kernels on VIRTUAL 2^16-point frames of G = 2^(16-L) consecutive real
 // frames.  The top 16 - L bits of r are then frame-number bits g: their stages (STAGE >= L) are skipped, the twiddle index
@@ -209,9 +210,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // plus a compile-time part per register
         const int g = hi4 >> (L - 12);
         if (partial && f * G + (size_t)g >= nframes_user) continue; // uniform per (L-12 .. 3 bits of hi4): the barriers above are passed
-        int2 *dst = scr + f * 65536 + c + 4096 * (g << (L - 12)) + 256 * ((hi4 << (16 - L)) & 15);
+        // within a unit the 4096 samples are laid out [column tile c7..4][t4][c3..0] (round 3; [t4][c] before): the 256 threads of this
+        // workgroup then store 2 KiB runs (L = 16: one run per register) instead of 128-byte pieces 2 KiB apart, and pass 2 reads the
+        // unit as sixteen 2 KiB runs, one per register
+        int2 *dst = scr + f * 65536 + 256 * tile + lo4 + 4096 * (g << (L - 12)) + 16 * ((hi4 << (16 - L)) & 15);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dst[4096 * (q & ((1 << (L - 12)) - 1)) + 256 * (q >> (L - 12))] = make_int2(re[q], im[q]);
+        for (int q = 0; q < 16; ++q) dst[4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12))] = make_int2(re[q], im[q]);
     }
 }
 
@@ -341,10 +345,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
         if (L < 16 && real >= nframes_user) continue;
         i64 re[16], im[16];
-        const int2 *src = scr + f * 65536 + 4096 * r0 + 256 * hi4 + lo4;
+        const int2 *src = scr + f * 65536 + 4096 * r0 + 16 * hi4 + lo4; // unit layout [c7..4 = q][t4 = hi4][c3..0]: 2 KiB per register
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int2 x = src[16 * q];
+            const int2 x = src[256 * q];
             re[q] = x.x;
             im[q] = x.y;
         }

@@ -192,7 +192,7 @@ def test_two_pass_32_register_inverse(log2n, in_order, out_order, monkeypatch):
     assert info3["n_passes"] == 3 and np.array_equal(got2, got3)
 
 
-@pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
+@pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 130), (16, 5), (16, 64)])
 @pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "NATURAL", "NATURAL"), ("FWD", "HALVES", "NATURAL"),
                                                              ("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
                                                              ("INV", "NATURAL", "NATURAL"), ("INV", "HALVES", "NATURAL"),
@@ -559,7 +559,7 @@ W32_CASES = [(12, 16, 0, 0), (12, 16, 0, 1), (14, 18, 0, 0), (18, 18, 0, 0), (24
              (26, 26, 0, 0), (5, 10, 1, 0)]
 
 
-@pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10])
+@pytest.mark.parametrize("log2n", [6, 7, 9, 10])
 @pytest.mark.parametrize("case", W32_CASES)
 def test_general_width_wave_kernel(log2n, case):
     """Any DATA_WIDTH / TWDL_WIDTH / FORMAT / RNDMODE within 32 bits at 64 <= N <= 1024: every multiplier regime
@@ -593,7 +593,7 @@ def test_general_width_block_kernel(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16" if packed_round else "k_fft4096_w32"), info
 
 
-@pytest.mark.parametrize("log2n", [6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("log2n", [6, 8, 10, 11, 12])  # (7 and 9 are template siblings of 6 / 8 / 10: covered by the short-frame tests)
 @pytest.mark.parametrize("case", [(16, 16, 0, 1), (12, 16, 0, 0), (12, 16, 0, 1), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0),
                                   (32, 16, 0, 0), (8, 8, 0, 0), (20, 16, 1, 0), (16, 16, 1, 0), (10, 12, 1, 0), (16, 24, 1, 0),
                                   (26, 26, 0, 0)])
@@ -616,8 +616,7 @@ def test_general_width_inverse_kernels(log2n, case):
 
 
 @pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 11, 12])
-@pytest.mark.parametrize("dw", [9, 12, 15])
-@pytest.mark.parametrize("tw", [16, 12])
+@pytest.mark.parametrize("dw,tw", [(9, 16), (12, 16), (12, 12), (15, 16)])  # (narrower twiddles at one data width: they only move the slice)
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
     """DATA_WIDTH 9 .. 15 (12 / 14-bit converters) in truncate mode run on the packed int16 kernels: guard-safe frames
@@ -670,8 +669,8 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
             assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
 
 
-@pytest.mark.parametrize("log2n", [3, 5, 7, 10, 11, 12, 13, 16, 17])
-@pytest.mark.parametrize("dw", [9, 14, 15])
+@pytest.mark.parametrize("log2n,dw", [(3, 9), (3, 14), (5, 15), (7, 9), (7, 14), (7, 15), (10, 9), (10, 14), (10, 15), (11, 14), (12, 9), (12, 14),
+                                      (12, 15), (13, 14), (13, 15), (16, 9), (16, 14), (17, 14)])  # every kernel family x every width; not the full cross
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_round_mode(log2n, dw, direction):
     """RNDMODE = 1 on narrow data (e.g. a 14-bit converter with rounding): the packed kernels with the w-bit wrap of the rhu2
@@ -1033,7 +1032,7 @@ def _fuzz_cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _fuzz_cases(160, 20260928))
+@pytest.mark.parametrize("case", _fuzz_cases(110, 20260928))
 def test_fuzz_generics_three_way(case, monkeypatch):
     """Random elaboratable generics: whatever kernel the planner picks, the generic LDS pass kernels and the oracle
     agree bit for bit (ragged batch sizes, full-range data)."""
@@ -1059,7 +1058,7 @@ def _fuzz_order_cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _fuzz_order_cases(60, 777))
+@pytest.mark.parametrize("case", _fuzz_order_cases(45, 777))
 def test_fuzz_generics_with_orders(case):
     """Random generics x random I/O orders (HALVES / BITREV / BITREV_LANES / NATURAL on either side)."""
     log2n, dw, tw, fmt, rnd, new, d, in_o, out_o = case
