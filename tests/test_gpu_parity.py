@@ -347,6 +347,35 @@ def test_config2_headline_shape(rnd, out_order):
     check(x, 10, 16, 16, 0, rnd, True, out_order=out_order)
 
 
+@pytest.mark.parametrize("log2n", [8, 9, 10])
+def test_headline_magnitude_votes(log2n):
+    """k_fft1024_i16's fast path is chosen by magnitude votes (|re|, |im| < 23100 on the inputs, or on the values behind stage 6 for
+    a frame that failed the first vote): frames AT the threshold from both sides, with the sample patterns that keep the complex
+    magnitude at its bound through every stage (all four corners (+-A, +-A): constant, alternating with every period, random signs),
+    70 % and 100 % full-scale noise, and mixtures -- all bit-exact to the oracle, whichever extraction a frame takes."""
+    n = 1 << log2n
+    rng = np.random.default_rng(4242 + log2n)
+    A = 23099
+    frames = []
+    for a in (A, A + 1, -A - 1, -A - 2, 32767, -32768):
+        f = np.full((n, 2), a, dtype=np.int64)
+        frames.append(np.clip(f, -32768, 32767))
+        for period in (1, 2, 4, 8, 16, 64, n // 2):  # +-a alternating in blocks: maximal differences at one stage each
+            sgn = np.where((np.arange(n) // period) % 2 == 0, 1, -1)
+            g = np.clip(np.stack([sgn * a, -sgn * a], -1), -32768, 32767)
+            frames.append(g)
+            frames.append(np.clip(np.stack([sgn * a, np.roll(sgn, period // 2 + 1) * a], -1), -32768, 32767))
+    for a in (A, A + 1):
+        for _ in range(6):
+            frames.append(np.stack([rng.choice([-a, a], n), rng.choice([-a, a], n)], -1))
+    x = np.stack(frames).astype(np.int64)
+    x = np.concatenate([x, uniform_frames(24, n, 16, 99), rng.integers(-23100, 23100, size=(24, n, 2)),
+                        rng.integers(-23101, 23101, size=(8, n, 2)), uniform_frames(16, n, 15, 98)])
+    info = check(x, log2n, 16, 16, 0, 0, True)
+    assert info["kernel_name"].startswith("k_fft1024_i16"), info
+    check(x[::3], log2n, 16, 16, 0, 0, True, in_order="HALVES", out_order="BITREV")
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
