@@ -907,7 +907,7 @@ bool big20_supported(int log2n, int data_width, int twdl_width, int format, int 
                      int in_order, int out_order)
 {
     // RNDMODE = 1: every direction; the 32-register two-pass plans of N = 2^17 / 2^18 are truncate-mode only (planner)
-    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false;
+    if (rndmode && diag_env("INTFFT_NO_PACKED_ROUND")) return false;
     if (rndmode && data_width != 16 && direction == 2 && log2n > 16) return false; // narrow round-mode pair beyond N = 65536: generic kernels
     return log2n >= 13 && log2n <= 20 && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            use_fly == 1 &&
@@ -972,7 +972,7 @@ hipError_t launch_bigpair(int log2n, int twd, int two_pass, const void *in, void
     if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode;
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     if (two_pass) { // 2^(L-8) x 256 split: DIF L-1..8, the pair of 7..0 / 0..7 per 256-point group, DIT 8..L-1
@@ -1065,7 +1065,7 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
@@ -1149,7 +1149,7 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     if (data_width != 16) sl.set_width(data_width);
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out), *scr = static_cast<u32 *>(scratch);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     if (two_pass && log2n >= 19) // N = 2^19, 2^20: 1024 rows x 1024 columns, two ten-stage passes (intfft_big2x.hip); natural order out only (planner)

@@ -352,7 +352,7 @@ bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd)
     return true;
 }
 
-bool big2p_supported(int log2n) { return (log2n == 17 || log2n == 18) && !getenv("INTFFT_NO_BIG2P"); }
+bool big2p_supported(int log2n) { return (log2n == 17 || log2n == 18) && !diag_env("INTFFT_NO_BIG2P"); }
 
 hipError_t launch_big2p_a(int log2n, bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl,
                           int halves, hipStream_t stream)

@@ -327,7 +327,7 @@ bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd)
     return true;
 }
 
-bool big2x_supported(int log2n) { return (log2n == 19 || log2n == 20) && !getenv("INTFFT_NO_BIG2X"); }
+bool big2x_supported(int log2n) { return (log2n == 19 || log2n == 20) && !diag_env("INTFFT_NO_BIG2X"); }
 
 const char *big2x_kernel_name() { return "k_big2x_a/k_big2x_b"; }
 

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
 
 bool packed_width_ok(int data_width, int format, int rndmode)
 {
-    const bool narrow = getenv("INTFFT_NO_NARROW16") == nullptr; // read per plan: the tests switch it
+    const bool narrow = diag_env("INTFFT_NO_NARROW16") == nullptr; // read per plan: the tests switch it
     (void)rndmode; // both sum / difference modes
     return data_width == 16 || (narrow && data_width >= 9 && data_width <= 15 && format == 0);
 }
@@ -494,7 +494,7 @@ const char *fast1024_kernel_name() { return "k_fft1024_i16"; }
 
 static int env_int(const char *name, int dflt)
 {
-    const char *e = getenv(name);
+    const char *e = diag_env(name);
     return e ? atoi(e) : dflt;
 }
 

@@ -187,7 +187,7 @@ hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const
         c.wr2[k] = h_tw[3 + k].x;
         c.wi2[k] = h_tw[3 + k].y;
     }
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const u32 *pin = static_cast<const u32 *>(in);
     int2 *pout = static_cast<int2 *>(out);
     switch (log2n) {

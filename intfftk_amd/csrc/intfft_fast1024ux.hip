@@ -348,7 +348,7 @@ hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a,
     UConsts c;
     for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const u32 *pin = static_cast<const u32 *>(in);
     int2 *pout = static_cast<int2 *>(out);
     switch (log2n) {

@@ -253,7 +253,7 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
 {
     if (!(packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
-    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: the same orders as truncate mode
+    if (rndmode && diag_env("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: the same orders as truncate mode
     if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
     // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) in and HALVES (native) out
     return log2n >= 7 && log2n <= 10 &&
@@ -310,7 +310,7 @@ hipError_t launch_fast1024x(int log2n, int direction, int twd, int in_bitrev, in
     if (direction == 1 || !round) to_dit_packing_host(c); // kernels with DP (see k_fft1024x_i16) hold their twiddles in the DIT packing
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     if (data_width != 16) sl.set_width(data_width);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);

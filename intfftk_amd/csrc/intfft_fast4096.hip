@@ -328,7 +328,7 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
 {
     if (!((log2n == 12 || log2n == 11) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
-    if (rndmode && getenv("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: all three directions, the cores' native orders too
+    if (rndmode && diag_env("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: all three directions, the cores' native orders too
     if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
     if (direction == 1) return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2); // + BITREV in, HALVES out
     return in_order == 0 && out_order == 0;
@@ -366,7 +366,7 @@ hipError_t launch_fast4096_mid(int twd, void *scratch, size_t nblocks4k, const i
     if (!rndmode) to_dit_packing_host(c); // MODE_MID runs both cores: DIT packing (see the kernel); round mode: DIF packing
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     if (data_width != 16) sl.set_width(data_width);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     u32 *p = static_cast<u32 *>(scratch);
     if (rndmode) return launch4k<12, MODE_MID, false, false, 1>(p, p, tw_all, c, nblocks4k, sl, stream);
     return (twd == 16 && allow_fast) ? launch4k<12, MODE_MID, true>(p, p, tw_all, c, nblocks4k, sl, stream)
@@ -433,7 +433,7 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int
     if (direction == 1 || (direction == 2 && !round)) to_dit_packing_host(c); // kernels with DP (see k_fft4096_i16) hold the DIT packing
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     if (data_width != 16) sl.set_width(data_width);
-    static const int allow_fast = getenv("INTFFT_FAST_EXTRACT") ? atoi(getenv("INTFFT_FAST_EXTRACT")) : 1;
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fast_ok = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);

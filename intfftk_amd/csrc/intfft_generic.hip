@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
 unsigned pass_threads(const PassArgs &a)
 {
     const size_t elems = (size_t)a.fpb << a.U;
-    static const int mode = getenv("INTFFT_PASS_THREADS") ? atoi(getenv("INTFFT_PASS_THREADS")) : 1;
+    static const int mode = diag_env("INTFFT_PASS_THREADS") ? atoi(diag_env("INTFFT_PASS_THREADS")) : 1;
     if (mode == 1) { // one thread per register round group: 16 points (int32 words) / 8 points (int64 words)
         const size_t t = elems / (a.word == 4 ? 16 : a.word == 8 ? 8 : 4);
         return (unsigned)(t < 256 ? 256 : t > 1024 ? 1024 : t);

@@ -7,6 +7,19 @@
 
 #include "intfft_device.hpp"
 
+#include <cstdlib>
+
+namespace intfft {
+// Diagnostic switches (A/B parity of kernel families in the tests, tuning experiments): the INTFFT_* variables listed in
+// include/intfft.h are honoured ONLY when INTFFT_DIAG=1 is set as well -- a stray INTFFT_* variable in a production environment
+// changes nothing.  Read per call (the tests flip them between plans).
+inline const char *diag_env(const char *name)
+{
+    const char *on = std::getenv("INTFFT_DIAG");
+    return (on && on[0] == '1') ? std::getenv(name) : nullptr;
+}
+} // namespace intfft
+
 namespace intfft {
 
 constexpr int MAX_STAGES_PER_PASS = 40;

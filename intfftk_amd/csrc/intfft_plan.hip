@@ -57,7 +57,7 @@ int device_cus()
 
 size_t resident_blocks(const void *kernel, int threads, int dflt, int max_per_cu, bool env_override)
 {
-    static const int env = getenv("INTFFT_BLOCKS_PER_CU") ? atoi(getenv("INTFFT_BLOCKS_PER_CU")) : 0;
+    static const int env = diag_env("INTFFT_BLOCKS_PER_CU") ? atoi(diag_env("INTFFT_BLOCKS_PER_CU")) : 0;
     const int dev = current_device();
     int per_cu, cus;
     {
@@ -220,7 +220,7 @@ int core_stages(const intfft_params &p, int dw_in, bool inverse, std::vector<Sta
         int clip = 0;
         if (st.s >= 2 && !cmult_shifts(st.mw, p.twdl_width, p.xser, st.sh_a, st.sh_b, &clip))
             return INTFFT_ERR_UNSUPPORTED;
-        st.narrow = clip ? clip : (st.mw + p.twdl_width <= 64 && !getenv("INTFFT_NO_NARROW_MUL")) ? 1 : 0;
+        st.narrow = clip ? clip : (st.mw + p.twdl_width <= 64 && !diag_env("INTFFT_NO_NARROW_MUL")) ? 1 : 0;
         st.tw_off = (1u << st.s) - 1u; // tables of stages 0..s-1 precede: sum 2^i = 2^s - 1
         out.push_back(st);
     }
@@ -393,7 +393,7 @@ int build_passes(intfft_plan &pl)
     int umax = pl.word == 2 ? 14 : pl.word == 4 ? 13 : pl.word == 8 ? 12 : 11; // 64 KiB tiles
     // packed multi-pass plans: 16 KiB tiles (many workgroups per CU) beat 64 KiB ones (measured on C4)
     if (pl.word == 2 && L > umax) umax = 12;
-    if (const char *e = getenv("INTFFT_TILE_LOG2")) umax = atoi(e) >= 8 && atoi(e) <= umax ? atoi(e) : umax; // diagnostics
+    if (const char *e = diag_env("INTFFT_TILE_LOG2")) umax = atoi(e) >= 8 && atoi(e) <= umax ? atoi(e) : umax; // diagnostics
     const int cmin = pl.word == 2 ? 6 : pl.word == 4 ? 5 : pl.word == 8 ? 4 : 3; // >= 256 B contiguous per strided row
 
     std::vector<StageDesc> fwd, inv;
@@ -449,7 +449,7 @@ int build_passes(intfft_plan &pl)
         a.U = sh.len0 + sh.len1;
         // frames per block: enough points that every thread owns work in every round
         int target = pl.word == 2 ? 13 : pl.word == 4 ? 12 : 11; // log2 points per block (int32 words: 11 / 12 / 13 measured 36 / 45 / 47 Gsample/s)
-        if (const char *e = getenv("INTFFT_PASS_TARGET")) target = atoi(e) >= 8 && atoi(e) <= 13 ? atoi(e) : target; // diagnostics
+        if (const char *e = diag_env("INTFFT_PASS_TARGET")) target = atoi(e) >= 8 && atoi(e) <= 13 ? atoi(e) : target; // diagnostics
         a.fpb = (a.U == L && L < target) ? (1 << (target - L)) : 1;
         a.in_mode = i == 0 ? IO_USER : IO_SCRATCH;
         a.out_mode = i + 1 == shapes.size() ? IO_USER : IO_SCRATCH;
@@ -479,7 +479,7 @@ int build_passes(intfft_plan &pl)
     // (C3: the first 8 of 16 stages have widths <= 32).  Those passes run k_pass<int32> and write 8-byte
     // scratch samples; the first 64-bit pass widens them on load.  Scratch is reused in place, so this needs the
     // first 64-bit pass to be the last pass (it reads 8-byte samples and writes the user array).
-    if (pl.word == 8 && pl.passes.size() > 1 && !getenv("INTFFT_NO_MIXED_WORDS")) {
+    if (pl.word == 8 && pl.passes.size() > 1 && !diag_env("INTFFT_NO_MIXED_WORDS")) {
         size_t k = 0;
         for (; k < pl.passes.size(); ++k) {
             const PassArgs &a = pl.passes[k];
@@ -599,11 +599,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     if (!l1 && pass16_supported(p->data_width, p->twdl_width, p->format, p->use_fly)) pl->word = 2;
 
     if ((rc = build_twiddles(*pl, nullptr)) != INTFFT_OK ||
-        (l1 && getenv("INTFFT_2D_GENERIC") && (rc = build_twiddles_2d(*pl)) != INTFFT_OK)) {
+        (l1 && diag_env("INTFFT_2D_GENERIC") && (rc = build_twiddles_2d(*pl)) != INTFFT_OK)) {
         intfft_plan_destroy(pl);
         return rc;
     }
-    if (l1 && !getenv("INTFFT_2D_GENERIC")) {
+    if (l1 && !diag_env("INTFFT_2D_GENERIC")) {
         // composite 2-D plan: the cores are 1-D sub-plans (NATURAL -> NATURAL) on re-laid-out data
         const int l2 = p->log2n - l1, F = p->format;
         auto sub = [&](int log2n, int dw, int direction, intfft_plan **o) {
@@ -634,9 +634,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (rc == INTFFT_OK) {
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->out_cb;
             size_t layout_mb = 256; // per layout buffer; INTFFT_SCRATCH_MB bounds these as it bounds the 1-D plans' scratch
-            if (const char *e = getenv("INTFFT_SCRATCH_MB")) layout_mb = atoi(e) > 0 ? (size_t)atoi(e) : layout_mb;
+            if (const char *e = diag_env("INTFFT_SCRATCH_MB")) layout_mb = atoi(e) > 0 ? (size_t)atoi(e) : layout_mb;
             pl->buf2d_frames = std::max<size_t>(1, (layout_mb << 20) / frame_bytes);
-            if (const char *e = getenv("INTFFT_2D_CHUNK_FRAMES")) // diagnostics: exercise the chunk loop on small batches
+            if (const char *e = diag_env("INTFFT_2D_CHUNK_FRAMES")) // diagnostics: exercise the chunk loop on small batches
                 if (atoi(e) > 0) pl->buf2d_frames = std::min(pl->buf2d_frames, (size_t)atoi(e));
             for (int i = 0; i < 2 && rc == INTFFT_OK; ++i) rc = (int)hipMalloc(&pl->buf2d[i], pl->buf2d_frames * frame_bytes);
         }
@@ -652,7 +652,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     // INTFFT_GENERIC_ONLY=1 (diagnostics / A-B parity): plan with the generic LDS pass kernels only.
     // 2-D scheme plans in their flat form (INTFFT_2D_GENERIC=1: A/B parity of the composite form) also run on the generic
     // kernels: their column stages index the twiddle tables differently.
-    const bool generic_only = getenv("INTFFT_GENERIC_ONLY") != nullptr || l1 != 0;
+    const bool generic_only = diag_env("INTFFT_GENERIC_ONLY") != nullptr || l1 != 0;
     pl->fastsmall = !generic_only && fastsmall_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                                          p->use_fly, p->in_order, p->out_order);
     pl->fast1024 = !generic_only && fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
@@ -663,10 +663,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                                         p->use_fly, p->in_order, p->out_order);
     pl->fast1024u = !generic_only && fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
-                    !getenv("INTFFT_NO_FAST1024U");
+                    !diag_env("INTFFT_NO_FAST1024U");
     pl->fast1024ux = !generic_only && fast1024ux_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                           p->in_order, p->out_order) &&
-                     !getenv("INTFFT_NO_FAST1024U");
+                     !diag_env("INTFFT_NO_FAST1024U");
     if (pl->fast1024ux) { // per-stage multiplier regimes of the inverse core
         std::vector<StageDesc> st;
         const int dw_inv = p->direction == INTFFT_PAIR ? p->data_width + p->log2n : p->data_width;
@@ -681,21 +681,21 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     pl->fastw32 = !generic_only && !pl->fast1024 && !pl->fast1024u && !pl->fast1024ux && !pl->fast1024x &&
                   fastw32_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                     p->out_order) &&
-                  !getenv("INTFFT_NO_FASTW32");
+                  !diag_env("INTFFT_NO_FASTW32");
     pl->fast4096w = !generic_only && !pl->fast4096 &&
                     fast4096w_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                         p->in_order, p->out_order) &&
-                    !getenv("INTFFT_NO_FASTW32");
+                    !diag_env("INTFFT_NO_FASTW32");
     pl->w32inv = !generic_only && !pl->fast1024x && !pl->fast4096 && !pl->fast1024ux &&
                  w32inv_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                   p->out_order) &&
-                 !getenv("INTFFT_NO_FASTW32");
+                 !diag_env("INTFFT_NO_FASTW32");
     pl->bigw = !generic_only &&
                !big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly,
                                 p->in_order, p->out_order) && // the packed three-pass kernels are faster where they apply
                bigw_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                               p->out_order) &&
-               !getenv("INTFFT_NO_FASTW32");
+               !diag_env("INTFFT_NO_FASTW32");
     if (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw) {
         std::vector<StageDesc> st;
         if (core_stages(*p, p->data_width, p->direction == INTFFT_INV, st) != INTFFT_OK || (int)st.size() != p->log2n)
@@ -728,7 +728,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (pl->in_cb > 4 || (pl->out_cb > 4) != (pl->w32args.out64 != 0)) pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
         if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
         if (pl->w32args.out64 == 2) pl->fastw32 = false;        // the 64-bit last round: the block kernel only
-        pl->w32args.two_pass = pl->bigw && !getenv("INTFFT_NO_TWOPASS");
+        pl->w32args.two_pass = pl->bigw && !diag_env("INTFFT_NO_TWOPASS");
     }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
@@ -761,24 +761,24 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
-                    !getenv("INTFFT_NO_BIG20");
-        pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+                    !diag_env("INTFFT_NO_BIG20");
+        pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
         // N = 2^17, 2^18 forward / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
         // quarter turns: verified on this plan's tables)
         // round mode: the inverse's 32-register pass only (the forward one has no registers left for a second set of bodies)
         const bool big2p = pl->big20 && (p->direction == INTFFT_INV || (p->direction == INTFFT_FWD && !p->rndmode)) && big2p_supported(p->log2n) &&
-                           !getenv("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+                           !diag_env("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
-        const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !getenv("INTFFT_NO_TWOPASS") &&
+        const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !diag_env("INTFFT_NO_TWOPASS") &&
                                 big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
-        pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !getenv("INTFFT_NO_TWOPASS");
+        pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
         // N = 2^19, 2^20 forward, truncate mode, natural order out: 1024 rows x 1024 columns in two ten-stage passes (intfft_big2x.hip)
         const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && p->out_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
-                           !getenv("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+                           !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x) pl->big_two_pass = true;
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
-                     pl->passes.size() == 2 && !getenv("INTFFT_NO_WIDE16");
+                     pl->passes.size() == 2 && !diag_env("INTFFT_NO_WIDE16");
         if (pl->wide16) {
             std::vector<StageDesc> st;
             const int LL = p->log2n; // 13 .. 16: STAGE LL-1 .. 8 in pass 1 (int32), 7 .. 0 in pass 2 (64-bit)
@@ -820,7 +820,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             size_t scratch_mb = (pl->big20 || pl->bigw || pl->wide16) ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
-            if (const char *e = getenv("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
+            if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
             const hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
@@ -904,7 +904,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
     int perm[24];
     hipError_t e = hipSuccess;
     int rc = INTFFT_OK;
-    const bool fuse = getenv("INTFFT_2D_NO_FUSE") == nullptr; // diagnostics: the multiplier as its own launch (k_twmul)
+    const bool fuse = diag_env("INTFFT_2D_NO_FUSE") == nullptr; // diagnostics: the multiplier as its own launch (k_twmul)
     for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
         const size_t nf = std::min(pl->buf2d_frames, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;

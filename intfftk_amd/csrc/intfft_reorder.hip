@@ -375,7 +375,7 @@ hipError_t intfft::launch_bitperm_tw(int L, int container_bytes, const int *in_o
 {
     if (batch == 0) return hipSuccess;
     const ReorderArgs a = make_reorder_args(L, in_of_out);
-    static const int no_packed = getenv("INTFFT_2D_NO_PACKED_TW") ? 1 : 0; // A/B: the general multiplier on int16 containers too
+    static const int no_packed = diag_env("INTFFT_2D_NO_PACKED_TW") ? 1 : 0; // A/B: the general multiplier on int16 containers too
     const TwArgs w{l2, mw, sh_a, sh_b, narrow, twd, (container_bytes == 2 && mw == 16 && twd <= 16 && sh_a == 0 && sh_b == twd - 1 && !no_packed) ? 1 : 0};
     switch (container_bytes) {
     case 2: return launch_tw<uint32_t>(a, w, conj, d_in, d_out, batch, stream);

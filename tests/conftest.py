@@ -4,6 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library honours its INTFFT_* diagnostic switches (A/B parity of kernel families) only under this master switch
+os.environ.setdefault("INTFFT_DIAG", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

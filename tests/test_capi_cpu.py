@@ -119,3 +119,21 @@ def test_plan_create_2d_validates_like_elaboration():
     assert rc in (capi.OK, capi.ERR_NO_DEVICE)  # no CPU fallback: without a HIP device nothing is planned
     if rc == capi.OK:
         L.intfft_plan_destroy(plan)
+
+
+def test_diagnostic_switches_need_the_master_switch():
+    """Every INTFFT_* read of the library goes through diag_env() (intfft_internal.hpp): honoured only under INTFFT_DIAG=1, so a
+    stray variable in a production environment cannot change which kernels a plan uses.  The only plain getenv is the master switch."""
+    import glob
+    import re
+
+    src = os.path.join(ROOT, "intfftk_amd", "csrc")
+    hits = []
+    for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp")):
+        for i, line in enumerate(open(f), 1):
+            for m in re.finditer(r"(?<![\w])getenv\(\s*\"([A-Z_0-9]+)\"", line):
+                if "diag_env" not in line[: m.start()][-12:]:
+                    hits.append((os.path.basename(f), i, m.group(1)))
+    assert [h for h in hits if h[2] != "INTFFT_DIAG"] == [], hits
+    hdr = open(os.path.join(ROOT, "include", "intfft.h")).read()
+    assert "INTFFT_DIAG=1" in hdr

@@ -6,6 +6,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("INTFFT_DIAG", "1")  # a diagnostics tool: INTFFT_NO_* A/B switches are honoured (bench.py never sets this)
 import numpy as np
 import torch
 
