@@ -230,7 +230,7 @@ template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32],
 //           the partner block (`rest` with its top bit flipped -> rev(rest) ^ 1) writes the other half of the line
 template <int L, bool FAST_OK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_b(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
-                                                                                             const Round5Consts c, size_t nframes, const Slice sl)
+                                                                                             const Round5Consts c, size_t nframes, const Slice sl, int pre_all)
 {
     static_assert(L == 19 || L == 20, "rows of 1024 points");
     constexpr int RL = L - 14; // bits of `rest`
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (L - 10)) + toff_l); // c = (j, n4)
         // kind of this tile's inputs = n10 = q0 bit 0 (pass A left Y >> 1 there); vote on the tile's own inputs
-        const unsigned k10 = q0 & 1u;
+        const unsigned k10 = pre_all ? 1u : (q0 & 1u); // (pre_all: the 2-D scheme's column pass left Y >> 1 everywhere)
         const short sa = (short)(1 - (int)k10);
         const v2s sh_a = {sa, sa};
         bool fast = false;
@@ -311,6 +311,187 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int q = 0; q < 32; ++q) __builtin_nontemporal_store(v[q], dst + ((size_t)rev5c(q) << (L - 5)) + toff2_l);
     }
+}
+
+// ---- the 2-D scheme at N = 2^20 = 1024 x 1024 in TWO launches: k_big2x_c + k_big2x_b<20> --------------
+// forward, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural / HALVES order in -> natural order out:
+//   k_big2x_c   the column cores (1024-point int_fftNk over n1 for every n2) on pass A's tiles -- 1024 rows x 16 columns, XCD-paired
+//               half lines -- with the 1024-point core's own twiddles (index = row mod 2^s: per thread, frame and column invariant)
+//               and STAGE 4..0 on wave-uniform twiddles; the result of row rho is A[k1 = brev10(rho)][n2], multiplied in place by
+//               W_N^(k1 n2) (int_cmult_dsp48 at 16 x t bits, table [chunk][rho][16 columns] of (wr | wi << 16)), emitted as Y >> 1
+//               (all the row core's first stage reads) into pass B's scratch layout
+//   k_big2x_b   the row cores + the store of X[k1 + 1024 k2]: pass B as it is (its row number rho leaves as brev10(rho) = k1)
+// instead of the five launches of the composite plan (layout change, column sub-plan, layout change + multiplier, row sub-plan,
+// layout change).
+template <bool FAST_OK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_c(const u32 *in, u32 *scr, const uint2 *__restrict__ tw1k, const Round5Consts c,
+                                                                                             const u32 *__restrict__ tw2d, size_t nframes, unsigned groups, const Slice sl,
+                                                                                             int halves)
+{
+    constexpr int L = 20, RB = 5;
+    extern __shared__ u32 lds[]; // 1024 rows x ROWX
+    const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
+    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+    const unsigned lfull = chunk * 16 + l;
+    const unsigned toff = ((unsigned)hx << 10) | lfull;
+    // round 1: regs j = rho9..5, thread hx = rho4..0: stages 9..5 of the 1024-point core, twiddle index (jj << 5 | hx).  The set is
+    // frame invariant, but held over the loop it costs 32 VGPRs next to the 32 inter-core twiddles of round 2 (31 spilled dwords
+    // per lane): it is re-read per tile instead -- 8 KiB of table, L1-resident
+    u32 wa16[8], wb16[8];
+    RoundTwQ t1;
+    auto round1_tw = [&](unsigned h) {
+        auto ld = [&](unsigned idx, u32 &wa, u32 &wb) {
+            const uint2 w = (tw1k + idx)[h];
+            wa = w.x;
+            wb = w.y;
+        };
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld(511u + ((unsigned)jj << 5), wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld(255u + ((unsigned)jj << 5), t1.wa8[jj], t1.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld(127u + ((unsigned)jj << 5), t1.wa4[jj], t1.wb4[jj]);
+        ld(63u, t1.wa2[0], t1.wb2[0]);
+        ld(31u, t1.wa1[0], t1.wb1[0]);
+    };
+    u32 *const wr_base = lds + ROWX * hx + l;              // row (j << 5) + hx
+    const u32 *const rd_base = lds + ROWX * (hx << 5) + l; // row (jx << 5) + q, jx = tid >> 4
+    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l;
+    const u32 *const twp = tw2d + ((size_t)chunk << 14) + ((unsigned)hx << 9) + (unsigned)l; // [chunk][rho = jx << 5 | q][l]
+    const v2s none = {0, 0};
+    const short s5 = (short)(1 - (hx & 1)); // round 2: the kind of its inputs is rho5 = jx bit 0
+    const v2s sh5 = {s5, s5};
+
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = in + (frame << L);
+        u32 *dst = scr + (frame << L);
+        unsigned toff_l = toff, toff2_l = toff2, hx_l = (unsigned)hx;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l), "+v"(hx_l));
+        u32 v[32];
+        if (halves) {
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *sh = reinterpret_cast<const v2u *>(src);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + 10)) + toff_l);
+                v[j] = w.x;
+                v[j + 16] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 10)) + toff_l);
+        }
+        round1_tw(hx_l);
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && bad == 0;
+        }
+        if (fast) {
+            dif_top16<FAST_OK, 0, false>(v, wa16, wb16, sl, none);
+            dif_round_q<FAST_OK, 0, 0, false>(v, t1, sl, none);
+            dif_round_q<FAST_OK, 16, 0xF, false>(v, t1, sl, none);
+        } else {
+            dif_top16<false, 0, false>(v, wa16, wb16, sl, none);
+            dif_round_q<false, 0, 0, false>(v, t1, sl, none);
+            dif_round_q<false, 16, 0xF, false>(v, t1, sl, none);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wr_base[ROWX * (j << RB)] = v[j];
+        __syncthreads();
+        u32 tw[32]; // the inter-core twiddles of this thread's 32 results (L2-resident slice of the table: one dword each)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) tw[q] = twp[16 * q];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = rd_base[ROWX * q];
+        if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
+        else dif_round5_c<false>(v, c, sl, sh5);
+        // B = cmult(A, W_N^(k1 n2)) >> 1: Wa = (wr, -wi), Wb = (wi, wr) from the packed entry; the operand is the plain 16-bit A
+        const v2s pm = {1, -1};
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) {
+            u32 wa[4], wb[4], d[4], y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wa[i] = as_u32(as_v2s(tw[q + i]) * pm);
+                wb[i] = __builtin_amdgcn_alignbit(tw[q + i], tw[q + i], 16);
+                d[i] = v[q + i];
+            }
+            if (fast) mul4f<false>(d, d, wa, wb, sl.sel_hi, y);
+            else {
+                mul2x<15, false>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.off_y1, sl.sel, y[0], y[1], sl.wd);
+                mul2x<15, false>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.off_y1, sl.sel, y[2], y[3], sl.wd);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[q + i] = y[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (L - 5)))[toff2_l] = v[q];
+    }
+}
+
+// the table of k_big2x_c: entry [chunk][rho][l] = W_N^(k1 n2), k1 = brev10(rho), n2 = 16 chunk + l, as (wr | wi << 16)
+__global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int twd)
+{
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; // < 2^20
+    const unsigned chunk = idx >> 14, rho = (idx >> 4) & 1023u, l = idx & 15u;
+    const unsigned k1 = __brev(rho) >> 22, n2 = chunk * 16 + l;
+    int re, im;
+    tw2d_eval(20, twd, (k1 * n2) & ((1u << 20) - 1u), re, im);
+    out[idx] = ((u32)re & 0xFFFFu) | ((u32)im << 16);
+}
+
+bool fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
+{
+    return log2n == 20 && l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 0 &&
+           (in_order == 0 || in_order == 2) && out_order == 0 && !diag_env("INTFFT_2D_NO_FUSED_CORES");
+}
+
+hipError_t build_fused2d_table(u32 *d_table, int twd, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_build_tw2d_tiles, dim3(4096), dim3(256), 0, stream, d_table, twd);
+    return hipGetLastError();
+}
+
+const char *fused2d_kernel_name() { return "2d[k_big2x_c|k_big2x_b]"; }
+
+// tw1k / h_tw1k: the packed / host twiddle tables of the 1024-point sub-plans (both cores are 1024 points long)
+hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
+                          hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = h_tw1k[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        wb = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsa = (size_t)1024 * ROWX * sizeof(u32), ldsb = (size_t)512 * ROWY * sizeof(u32);
+    const unsigned groups = (unsigned)(nframes < 64 ? nframes : 64);
+    const size_t ntiles = nframes << 6, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;
+    const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);
+    if (fx) {
+        allow_max_lds(kptr(k_big2x_c<true>));
+        allow_max_lds(kptr(k_big2x_b<20, true>));
+        hipLaunchKernelGGL((k_big2x_c<true>), dim3(64u * groups), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves);
+        hipLaunchKernelGGL((k_big2x_b<20, true>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw1k, c, nframes, sl, 1);
+    } else {
+        allow_max_lds(kptr(k_big2x_c<false>));
+        allow_max_lds(kptr(k_big2x_b<20, false>));
+        hipLaunchKernelGGL((k_big2x_c<false>), dim3(64u * groups), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves);
+        hipLaunchKernelGGL((k_big2x_b<20, false>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw1k, c, nframes, sl, 1);
+    }
+    return hipGetLastError();
 }
 
 // the quarter-turn relation both passes rely on (stages 5 .. L-1), checked on the plan's generated tables (host copy)
@@ -359,7 +540,7 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
         const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
-        hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl);              \
+        hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);           \
     }
     if (log2n == 20) {
         if (fx) INTFFT_2X_LAUNCH(20, true) else INTFFT_2X_LAUNCH(20, false)

@@ -71,8 +71,37 @@ def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
     check(x, log2n, l1, 16, 16, 0, 0, True, direction=direction)
     if direction == "FWD":
         got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
-        assert info["n_passes"] >= 4 and info["kernel_name"].startswith("2d[")
+        fused = (log2n, l1) == (20, 10)  # 1024 x 1024: both cores and the multiplier in two launches
+        assert info["n_passes"] == (2 if fused else info["n_passes"]) and info["n_passes"] >= (2 if fused else 4) and info["kernel_name"].startswith("2d[")
         assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
+
+
+@pytest.mark.parametrize("frames", [1, 5, 70])
+def test_2d_n2pow20_two_launches(frames, monkeypatch):
+    """N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward: k_big2x_c (column cores on XCD-paired half-line tiles + the
+    inter-core multiplier) + k_big2x_b (row cores + store) against the oracle and against the five-launch composite plan
+    (INTFFT_2D_NO_FUSED_CORES); full-scale frames (exact extraction in their tiles), HALVES order in, 13-bit twiddles, a batch
+    beyond one scratch chunk."""
+    n = 1 << 20
+    x = uniform_frames(frames, n, 15, 777 + frames)
+    x[0] = uniform_frames(1, n, 16, 5)[0]
+    if frames <= 5:
+        info = check(x, 20, 10, 16, 16, 0, 0, True)
+        assert info["kernel_name"] == "2d[k_big2x_c|k_big2x_b]" and info["n_passes"] == 2, info
+        check(x[:2], 20, 10, 16, 16, 0, 0, True, in_order="HALVES")
+        check(x[:1], 20, 10, 16, 13, 0, 0, False)
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
+            got5, info5 = run_gpu(x, 20, 10, 16, 16, 0, 0, True)
+            assert info5["n_passes"] >= 4, info5
+        got2, _ = run_gpu(x, 20, 10, 16, 16, 0, 0, True)
+        assert np.array_equal(got2, got5)
+    else:  # chunk loop (64 frames per 256 MiB layout buffer): frames 0, 63, 64, 69 against the oracle
+        got, info = run_gpu(x, 20, 10, 16, 16, 0, 0, True)
+        assert info["n_passes"] == 2
+        sel = [0, 63, 64, 69]
+        want = C.execute_2d(x[sel], C.make_params(20, 16, 16, 0, 0, True), 10, C.FWD, C.NATURAL, C.NATURAL, form=1)
+        assert np.array_equal(got[sel], want)
 
 
 @pytest.mark.parametrize("case", [(13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (16, 8, 16, 16, 0, 1, True),
