@@ -323,18 +323,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //   k_big2x_b   the row cores + the store of X[k1 + 1024 k2]: pass B as it is (its row number rho leaves as brev10(rho) = k1)
 // instead of the five launches of the composite plan (layout change, column sub-plan, layout change + multiplier, row sub-plan,
 // layout change).
-template <bool FAST_OK>
+// LR = log2 N2 (the row length).  LR = 10: the two-launch plan above (results as Y >> 1 in pass B's layout).  LR = 11 .. 14 (N = 2^21
+// .. 2^24 as 1024 x N2): results as plain Y at [rho][n2] of the scratch, the N2-point row cores run as an ordinary 1-D sub-plan
+// over 1024 frames per transform, and ONE layout change ([rho][k2] -> X[brev10(rho) + 1024 k2], any output order) finishes:
+// three launches (four where the row sub-plan has two passes) instead of five (six).
+template <bool FAST_OK, int LR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_c(const u32 *in, u32 *scr, const uint2 *__restrict__ tw1k, const Round5Consts c,
                                                                                              const u32 *__restrict__ tw2d, size_t nframes, unsigned groups, const Slice sl,
                                                                                              int halves)
 {
-    constexpr int L = 20, RB = 5;
+    static_assert(LR >= 10 && LR <= 14, "1024 rows x 2^LR columns");
+    constexpr int L = 10 + LR, RB = 5;
+    constexpr bool PASSB = LR == 10;
+    constexpr unsigned CG = 1u << (LR - 5); // column groups of 128 bytes per frame
     extern __shared__ u32 lds[]; // 1024 rows x ROWX
     const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
-    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+    const unsigned chunk = (G & (CG - 1u)) * 2u + part, grp = G >> (LR - 5);
     const unsigned lfull = chunk * 16 + l;
-    const unsigned toff = ((unsigned)hx << 10) | lfull;
+    const unsigned toff = ((unsigned)hx << LR) | lfull;
     // round 1: regs j = rho9..5, thread hx = rho4..0: stages 9..5 of the 1024-point core, twiddle index (jj << 5 | hx).  The set is
     // frame invariant, but held over the loop it costs 32 VGPRs next to the 32 inter-core twiddles of round 2 (31 spilled dwords
     // per lane): it is re-read per tile instead -- 8 KiB of table, L1-resident
@@ -357,7 +364,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     u32 *const wr_base = lds + ROWX * hx + l;              // row (j << 5) + hx
     const u32 *const rd_base = lds + ROWX * (hx << 5) + l; // row (jx << 5) + q, jx = tid >> 4
-    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l;
+    // store side, thread = (jx = rho9..5, l), regs q = rho4..0: pass B's layout [q][c][hi][k][l] (LR = 10) or natural [rho][n2]
+    const unsigned toff2 = PASSB ? (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l
+                                 : ((unsigned)hx << (5 + LR)) | lfull;
     const u32 *const twp = tw2d + ((size_t)chunk << 14) + ((unsigned)hx << 9) + (unsigned)l; // [chunk][rho = jx << 5 | q][l]
     const v2s none = {0, 0};
     const short s5 = (short)(1 - (hx & 1)); // round 2: the kind of its inputs is rho5 = jx bit 0
@@ -374,13 +383,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + 10)) + toff_l);
+                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + LR)) + toff_l);
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 10)) + toff_l);
+            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + LR)) + toff_l);
         }
         round1_tw(hx_l);
         bool fast = false;
@@ -410,7 +419,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int q = 0; q < 32; ++q) v[q] = rd_base[ROWX * q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
         else dif_round5_c<false>(v, c, sl, sh5);
-        // B = cmult(A, W_N^(k1 n2)) >> 1: Wa = (wr, -wi), Wb = (wi, wr) from the packed entry; the operand is the plain 16-bit A
+        // B = cmult(A, W_N^(k1 n2)): Wa = (wr, -wi), Wb = (wi, wr) from the packed entry; the operand is the plain 16-bit A.
+        // LR = 10: emitted as Y >> 1 (all the row core's first stage reads; fast extraction where the tile voted for it);
+        // longer rows: the full Y for the row sub-plan (the high halves alone cannot give it: exact extraction)
         const v2s pm = {1, -1};
 #pragma unroll
         for (int q = 0; q < 32; q += 4) {
@@ -421,50 +432,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 wb[i] = __builtin_amdgcn_alignbit(tw[q + i], tw[q + i], 16);
                 d[i] = v[q + i];
             }
-            if (fast) mul4f<false>(d, d, wa, wb, sl.sel_hi, y);
-            else {
-                mul2x<15, false>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.off_y1, sl.sel, y[0], y[1], sl.wd);
-                mul2x<15, false>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.off_y1, sl.sel, y[2], y[3], sl.wd);
+            if constexpr (PASSB) {
+                if (fast) mul4f<false>(d, d, wa, wb, sl.sel_hi, y);
+                else {
+                    mul2x<15, false>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.off_y1, sl.sel, y[0], y[1], sl.wd);
+                    mul2x<15, false>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.off_y1, sl.sel, y[2], y[3], sl.wd);
+                }
+            } else {
+                mul2x<16, false>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.off_y, sl.sel, y[0], y[1], sl.wd);
+                mul2x<16, false>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.off_y, sl.sel, y[2], y[3], sl.wd);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[q + i] = y[i];
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (L - 5)))[toff2_l] = v[q];
+        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (PASSB ? L - 5 : LR)))[toff2_l] = v[q];
     }
 }
 
 // the table of k_big2x_c: entry [chunk][rho][l] = W_N^(k1 n2), k1 = brev10(rho), n2 = 16 chunk + l, as (wr | wi << 16)
-__global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int twd)
+__global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int L, int twd)
 {
-    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; // < 2^20
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; // < 2^L
     const unsigned chunk = idx >> 14, rho = (idx >> 4) & 1023u, l = idx & 15u;
     const unsigned k1 = __brev(rho) >> 22, n2 = chunk * 16 + l;
     int re, im;
-    tw2d_eval(20, twd, (k1 * n2) & ((1u << 20) - 1u), re, im);
+    tw2d_eval(L, twd, (k1 * n2) & ((1u << L) - 1u), re, im);
     out[idx] = ((u32)re & 0xFFFFu) | ((u32)im << 16);
 }
 
-bool fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
+// returns 0 (not this path), 2 (N = 2^20: two launches, natural order out) or 3 (N = 2^21 .. 2^24 with N1 = 1024: column pass, row
+// sub-plan, one layout change; any output order)
+int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
 {
-    return log2n == 20 && l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 0 &&
-           (in_order == 0 || in_order == 2) && out_order == 0 && !diag_env("INTFFT_2D_NO_FUSED_CORES");
+    if (!(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 0 &&
+          (in_order == 0 || in_order == 2)) || diag_env("INTFFT_2D_NO_FUSED_CORES"))
+        return 0;
+    if (log2n == 20) return out_order == 0 ? 2 : 0;
+    return log2n >= 21 && log2n <= 24 ? 3 : 0;
 }
 
-hipError_t build_fused2d_table(u32 *d_table, int twd, hipStream_t stream)
+hipError_t build_fused2d_table(u32 *d_table, int log2n, int twd, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_build_tw2d_tiles, dim3(4096), dim3(256), 0, stream, d_table, twd);
+    hipLaunchKernelGGL(k_build_tw2d_tiles, dim3(1u << (log2n - 8)), dim3(256), 0, stream, d_table, log2n, twd);
     return hipGetLastError();
 }
 
 const char *fused2d_kernel_name() { return "2d[k_big2x_c|k_big2x_b]"; }
 
-// tw1k / h_tw1k: the packed / host twiddle tables of the 1024-point sub-plans (both cores are 1024 points long)
-hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
-                          hipStream_t stream)
+static void fused2d_consts(const int2 *h_tw1k, Round5Consts &c)
 {
-    if (nframes == 0) return hipSuccess;
-    Round5Consts c;
     auto pk = [&](int idx, u32 &wa, u32 &wb) {
         const int2 w = h_tw1k[idx];
         wa = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
@@ -473,22 +490,63 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
     for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
     for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+}
+
+// the column pass alone (any supported row length): user array -> scratch; LR = 10 writes pass B's layout, longer rows [rho][n2]
+hipError_t launch_fused2d_cols(int lr, int twd, const u32 *pin, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
+                               hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    fused2d_consts(h_tw1k, c);
     Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
     static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
-    const size_t ldsa = (size_t)1024 * ROWX * sizeof(u32), ldsb = (size_t)512 * ROWY * sizeof(u32);
-    const unsigned groups = (unsigned)(nframes < 64 ? nframes : 64);
+    const size_t ldsa = (size_t)1024 * ROWX * sizeof(u32);
+    const size_t per_launch = (size_t)64 << (20 - 10) >> lr; // frame groups that make ~4096 blocks, as for N = 2^20
+    const size_t cap = per_launch ? per_launch : 1;
+    const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);
+    const unsigned grid = (unsigned)(((size_t)1 << (lr - 4)) * groups);
+#define INTFFT_2DC(LRR)                                                                                                                   \
+    if (fx) {                                                                                                                             \
+        allow_max_lds(kptr(k_big2x_c<true, LRR>));                                                                                        \
+        hipLaunchKernelGGL((k_big2x_c<true, LRR>), dim3(grid), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves);  \
+    } else {                                                                                                                              \
+        allow_max_lds(kptr(k_big2x_c<false, LRR>));                                                                                       \
+        hipLaunchKernelGGL((k_big2x_c<false, LRR>), dim3(grid), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves); \
+    }
+    switch (lr) {
+    case 10: INTFFT_2DC(10) break;
+    case 11: INTFFT_2DC(11) break;
+    case 12: INTFFT_2DC(12) break;
+    case 13: INTFFT_2DC(13) break;
+    case 14: INTFFT_2DC(14) break;
+    default: return hipErrorInvalidValue;
+    }
+#undef INTFFT_2DC
+    return hipGetLastError();
+}
+
+// N = 2^20: column pass + pass B.  tw1k / h_tw1k: the packed / host twiddle tables of the 1024-point cores
+hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
+                          hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    hipError_t e = launch_fused2d_cols(10, twd, pin, scr, tw1k, h_tw1k, tw2d, nframes, halves, stream);
+    if (e != hipSuccess) return e;
+    Round5Consts c;
+    fused2d_consts(h_tw1k, c);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);
     const size_t ntiles = nframes << 6, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;
     const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);
     if (fx) {
-        allow_max_lds(kptr(k_big2x_c<true>));
         allow_max_lds(kptr(k_big2x_b<20, true>));
-        hipLaunchKernelGGL((k_big2x_c<true>), dim3(64u * groups), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves);
         hipLaunchKernelGGL((k_big2x_b<20, true>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw1k, c, nframes, sl, 1);
     } else {
-        allow_max_lds(kptr(k_big2x_c<false>));
         allow_max_lds(kptr(k_big2x_b<20, false>));
-        hipLaunchKernelGGL((k_big2x_c<false>), dim3(64u * groups), dim3(512), ldsa, stream, pin, scr, tw1k, c, tw2d, nframes, groups, sl, halves);
         hipLaunchKernelGGL((k_big2x_b<20, false>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw1k, c, nframes, sl, 1);
     }
     return hipGetLastError();

@@ -109,7 +109,8 @@ struct intfft_plan {
     struct intfft_plan *sub_col_f = nullptr, *sub_row_f = nullptr, *sub_row_i = nullptr, *sub_col_i = nullptr;
     StageDesc tw_f{}, tw_i{};  // the multiplier between the cores (widths / regime), forward and inverse
     void *buf2d[2] = {nullptr, nullptr};
-    bool fused2d = false;             // N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward: two launches (k_big2x_c + k_big2x_b)
+    int fused2d = 0;                  // 2: N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward in two launches (k_big2x_c + k_big2x_b); 3: N = 2^21 .. 2^24 as
+                                      // 1024 x N2: k_big2x_c, the row sub-plan, one layout change
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
     size_t buf2d_frames = 0;
     int2 *d_tw2d = nullptr;   // 2-D scheme: the inter-pass table W_N^m, N entries
@@ -649,23 +650,25 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const intfft_plan *a = pl->sub_col_f ? pl->sub_col_f : pl->sub_row_i, *b = pl->sub_row_f ? pl->sub_row_f : pl->sub_col_i;
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[%.24s|%.24s]", a->kernel_name, b->kernel_name);
         // 1024 x 1024, packed 16-bit forward: both cores and the multiplier in two launches on the tiles of the N = 2^20 two-pass plan
-        pl->fused2d = fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order) &&
-                      pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->sub_col_f &&
-                      big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width);
+        pl->fused2d = fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
+        if (!(pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->sub_col_f && pl->sub_row_f &&
+              big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width)))
+            pl->fused2d = 0;
         if (pl->fused2d) {
             // the 1024-point cores' twiddles in the packed operand forms (the single-kernel sub-plans pack theirs on the fly)
             const size_t total = ((size_t)1 << 10) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
             if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_col_f->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
-            if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw2d_tiles, ((size_t)1 << 20) * sizeof(uint32_t));
-            if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, p->twdl_width, nullptr);
+            if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw2d_tiles, ((size_t)1 << pl->L) * sizeof(uint32_t));
+            if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, pl->L, p->twdl_width, nullptr);
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) {
                 intfft_plan_destroy(pl);
                 return (int)e;
             }
-            std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
+            if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
+            else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
         }
         *out = pl;
         return INTFFT_OK;
@@ -895,7 +898,8 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
-        if (plan->fused2d) info->n_passes = 2;
+        if (plan->fused2d == 2) info->n_passes = 2;
+        if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
         // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
@@ -928,6 +932,21 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
     hipError_t e = hipSuccess;
     int rc = INTFFT_OK;
     const bool fuse = diag_env("INTFFT_2D_NO_FUSE") == nullptr; // diagnostics: the multiplier as its own launch (k_twmul)
+    if (pl->fused2d == 3) { // column cores + multiplier on tiles, the row sub-plan, ONE layout change [rho][k2] -> X[brev10(rho) + 1024 k2]
+        for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
+            const size_t nf = std::min(pl->buf2d_frames, batch - f);
+            e = launch_fused2d_cols(l2, p.twdl_width, reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame),
+                                    static_cast<uint32_t *>(pl->buf2d[0]), pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
+                                    p.in_order == INTFFT_ORDER_HALVES, stream);
+            if (e != hipSuccess) break;
+            if ((rc = intfft_exec(pl->sub_row_f, pl->buf2d[0], pl->buf2d[1], nf << l1, stream)) != INTFFT_OK) break;
+            // logical k = k1 + N1 k2 sits at [rho = brev(k1)][k2]: k bit j < l1 at in bit l2 + (l1 - 1 - j), else at j - l1
+            for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + (l1 - 1 - j) : j - l1;
+            e = launch_bitperm(L, pl->sub_row_f->out_cb, perm, pl->buf2d[1], static_cast<char *>(d_out) + f * out_frame, nf, stream);
+        }
+        if (rc != INTFFT_OK) return rc;
+        return (int)e;
+    }
     if (pl->fused2d) { // column cores + multiplier, row cores + store: two launches per chunk, one layout buffer as the scratch
         for (size_t f = 0; f < batch && e == hipSuccess; f += pl->buf2d_frames) {
             const size_t nf = std::min(pl->buf2d_frames, batch - f);

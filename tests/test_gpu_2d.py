@@ -61,7 +61,7 @@ def test_2d_io_orders(in_order, out_order, direction):
     check(x, 13, 6, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
 
 
-@pytest.mark.parametrize("log2n,l1,frames", [(20, 10, 3), (20, 8, 2), (21, 10, 2), (21, 11, 1), (22, 11, 1)])
+@pytest.mark.parametrize("log2n,l1,frames", [(20, 10, 3), (20, 8, 2), (21, 10, 2), (21, 11, 1), (22, 11, 1), (22, 10, 2)])
 @pytest.mark.parametrize("direction", ["FWD", "INV"])
 def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
     """N = 2^20 .. 2^22 (the reference's cores stop at 2^19): 16-bit scaled, bit-exact to the oracle; the forward result is
@@ -71,8 +71,10 @@ def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
     check(x, log2n, l1, 16, 16, 0, 0, True, direction=direction)
     if direction == "FWD":
         got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
-        fused = (log2n, l1) == (20, 10)  # 1024 x 1024: both cores and the multiplier in two launches
-        assert info["n_passes"] == (2 if fused else info["n_passes"]) and info["n_passes"] >= (2 if fused else 4) and info["kernel_name"].startswith("2d[")
+        # N1 = 1024: the column cores + multiplier run on tiles (k_big2x_c): two launches at N = 2^20, else column pass + row sub-plan + one
+        # layout change; other splits: the five-launch composite
+        want = 2 if (log2n, l1) == (20, 10) else 3 if l1 == 10 else None
+        assert (info["n_passes"] == want if want else info["n_passes"] >= 4) and info["kernel_name"].startswith("2d["), info
         assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
 
 
@@ -191,3 +193,25 @@ def test_2d_random_configurations():
         check(x, log2n, l1, dw, tw, fmt, rnd, new, direction, str(rng.choice(orders)), str(rng.choice(orders)))
         done += 1
     assert done >= 60
+
+
+@pytest.mark.parametrize("log2n,frames,out_order", [(21, 3, "NATURAL"), (22, 2, "BITREV"), (23, 1, "NATURAL"), (22, 18, "NATURAL")])
+def test_2d_1024_by_n2_three_launches(log2n, frames, out_order, monkeypatch):
+    """N = 2^21 .. 2^23 as 1024 x N2, 16-bit scaled-truncate forward: k_big2x_c (column cores + multiplier on tiles), the N2-point row
+    sub-plan, one layout change -- against the oracle and the five-launch composite (INTFFT_2D_NO_FUSED_CORES); every output order
+    goes through the same last launch; HALVES order in; a batch beyond one scratch chunk (16 frames at N = 2^22)."""
+    n = 1 << log2n
+    x = uniform_frames(frames, n, 15, 888 + log2n)
+    x[0] = uniform_frames(1, n, 16, 6)[0]
+    got, info = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, out_order=out_order)
+    assert info["kernel_name"].startswith("2d[k_big2x_c|") and info["n_passes"] == (3 if log2n <= 22 else 4), info
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
+        got5, info5 = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, out_order=out_order)
+        assert info5["n_passes"] >= 5, info5
+    assert np.array_equal(got, got5)
+    sel = [0, frames - 1] if frames > 1 else [0]
+    want = C.execute_2d(x[sel], C.make_params(log2n, 16, 16, 0, 0, True), 10, C.FWD, C.NATURAL, ORD[out_order], form=1)
+    assert np.array_equal(got[sel], want)
+    if frames <= 3 and log2n <= 22:
+        check(x[:1], log2n, 10, 16, 16, 0, 0, True, in_order="HALVES", out_order=out_order)
