@@ -65,9 +65,24 @@ def make_input(batch: int, n: int, seed: int, rank: int, full_scale: bool = Fals
     return x
 
 
-def pmc_digest():
-    """The newest committed rocprofv3 PMC digest of the dominant kernel (profiles/rNN_k_fft1024_pmc_digest.json,
-    collected by tools/profile.sh on this same command in separate --pmc passes); (path, dict) or (None, None)."""
+def pmc_digest(config="C2"):
+    """The newest committed rocprofv3 PMC digest of this configuration's kernel(s): (path, {"hbm_bytes_per_launch", "SQ_INSTS_VALU",
+    "SQ_WAVES", ...}) or (None, None).  profiles/rNN_<config>_pmc_digest.json (tools/pmc_digest.sh: one --pmc pass per counter set
+    over tools/bench_configs.py <config>, the same plan / batch as this bench) -- per-call HBM bytes = sum over the plan's kernels;
+    older rounds: profiles/rNN_k_fft1024_pmc_digest.json (tools/profile.sh on bench.py itself, C2 only)."""
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_digest.json" % config)))):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            k = max(d["kernels"].values(), key=lambda v: v.get("avg_ns", 0.0))  # the dominant kernel
+            out = dict(k)
+            out["hbm_bytes_per_launch"] = d["hbm_bytes_per_call"]
+            out["traffic_over_algorithmic"] = d.get("traffic_over_algorithmic")
+            return os.path.relpath(path, ROOT), out
+        except Exception:
+            continue
+    if config != "C2":
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k_fft1024_pmc_digest.json")))
     for path in reversed(files):
         try:
@@ -416,8 +431,8 @@ def main():
     if rank == 0:
         samples = float(batch) * n * world * args.steps
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        digest_path, digest = pmc_digest()
-        traffic = float(digest["hbm_bytes_per_launch"]) if (digest and args.config == "C2" and batch == 65536) else None
+        digest_path, digest = pmc_digest(args.config)
+        traffic = float(digest["hbm_bytes_per_launch"]) if (digest and batch == cfg_batch) else None
         metric = ("Gsample/s (complex int16) batched N=1024 scaled FFT" if args.config == "C2"
                   else "Gsample/s (complex int16) batched N=4096 scaled FFT->IFFT pair")
         out = {

@@ -127,6 +127,8 @@ struct intfft_plan {
     bool fast1024u = false;
     bool fast1024ux = false;
     bool fastw32 = false;
+    bool fastw64 = false;  // N = 1024 forward, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
+    StageDesc st64[10] = {};
     bool fast4096w = false;
     bool w32inv = false;
     bool bigw = false;
@@ -754,8 +756,21 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (pl->w32args.out64 == 2) pl->fastw32 = false;        // the 64-bit last round: the block kernel only
         pl->w32args.two_pass = pl->bigw && !diag_env("INTFFT_NO_TWOPASS");
     }
+    pl->fastw64 = !generic_only && !pl->fastw32 && !pl->fast1024 && !pl->fast1024u && !pl->fast1024ux && !pl->fast1024x && !pl->fastsmall &&
+                  pl->word == 8 && pl->in_cb >= 4 && pl->out_cb == 8 &&
+                  fastw64_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
+    if (pl->fastw64) {
+        std::vector<StageDesc> st;
+        if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fastw64 = false;
+        for (size_t i = 0; i < st.size() && pl->fastw64; ++i) {
+            if (st[i].s < 0 || st[i].s > 9 || st[i].wo > 64 || st[i].dtw > 64) pl->fastw64 = false;
+            else pl->st64[st[i].s] = st[i];
+        }
+    }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
+    } else if (pl->fastw64) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64_kernel_name());
     } else if (pl->w32inv) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", w32inv_kernel_name(p->log2n));
     } else if (pl->fast4096w) {
@@ -890,7 +905,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64;
     if (plan->buf2d[0]) {
         intfft_plan_info si;
         int n = 0;
@@ -910,7 +925,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         return INTFFT_OK;
     }
     info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
-    info->compute_word = (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
+    info->compute_word = plan->fastw64 ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -1043,6 +1058,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->fast4096w)
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
+    if (plan->fastw64)
+        return (int)launch_fastw64(plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
+                                   d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                    plan->h_tw.data(), batch, stream);

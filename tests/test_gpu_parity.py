@@ -376,6 +376,33 @@ def test_headline_magnitude_votes(log2n):
     check(x[::3], log2n, 16, 16, 0, 0, True, in_order="HALVES", out_order="BITREV")
 
 
+W64_CASES = [(32, 16, 1, 0, True), (32, 24, 1, 0, True), (32, 24, 1, 0, False), (24, 24, 1, 0, True), (28, 18, 1, 0, True), (40, 16, 0, 0, True),
+             (44, 16, 0, 1, True), (48, 24, 0, 0, True), (36, 16, 1, 0, False), (50, 16, 1, 0, True), (54, 10, 1, 0, True), (33, 26, 0, 1, True),
+             (64, 16, 0, 0, True), (60, 16, 0, 1, False)]
+
+
+@pytest.mark.parametrize("case", W64_CASES)
+def test_wave_kernel_64_bit_results(case, monkeypatch):
+    """N = 1024 forward with results of 33 .. 64 bits (32-bit unscaled data: int_fft_single_path.vhd:15 documents DATA_WIDTH 8-32;
+    wide scaled data; every multiplier regime that fits 64-bit words, both XSER): the 64-bit wave kernel k_fft1024_w64 against the
+    oracle and against the generic pass kernel it replaces (INTFFT_NO_FASTW64); ragged batches, edge frames, int32 and int64
+    input containers."""
+    dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate(C.make_params(10, dw, tw, fmt, rnd, new), C.FWD) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(1024, dw), uniform_frames(37, 1024, dw, 640 + dw), uniform_frames(6, 1024, max(2, dw - 3), 641 + dw)])
+    got, info = run_gpu(x, 10, dw, tw, fmt, rnd, new)
+    if info["out_bits"] <= 32 or info["out_bits"] > 64 or info["kernel_name"] == "k_fft1024_w32":
+        pytest.skip("not a plan of the 64-bit wave kernel (33 / 34-bit unscaled results: k_fft1024_w32 with its 64-bit tail)")
+    assert info["kernel_name"] == "k_fft1024_w64" and info["fast_path"] == 1 and info["compute_word"] == 8, info
+    assert np.array_equal(got, run_ref(x, 10, dw, tw, fmt, rnd, new))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_FASTW64", "1")
+        got_g, info_g = run_gpu(x[:9], 10, dw, tw, fmt, rnd, new)
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    assert np.array_equal(got[:9], got_g)
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
