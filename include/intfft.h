@@ -124,7 +124,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
  * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
  * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
  * (kernel, device) on first use, under a mutex);
- * one plan must not be executed concurrently on two streams (plan-owned scratch). */
+ * one plan must not be executed concurrently on two streams (plan-owned scratch).  Some multi-pass plans (N = 2^19 / 2^20 forward, the
+ * 24-bit unscaled class) run the scratch-sized chunks of a large batch alternately on `hip_stream` and on a plan-owned side stream
+ * (event fork at entry, event join before returning): towards the caller the call is still ordered on `hip_stream` only. */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
 
 /* Host-resident frames (the "streaming block" use): h_in/h_out are HOST pointers with the same layout
@@ -176,7 +178,7 @@ int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *
  *   INTFFT_GENERIC_ONLY, INTFFT_NO_FAST1024U, INTFFT_NO_FASTW32, INTFFT_NO_BIG20, INTFFT_NO_BIG2P, INTFFT_NO_BIG2X, INTFFT_NO_WIDE16,
  *   INTFFT_NO_FASTW64, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_PACKED_TW,
  *   INTFFT_2D_CHUNK_FRAMES (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed
- *   kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS, INTFFT_PASS_TARGET,
+ *   kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS, INTFFT_PASS_TARGET,
  *   INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL (launch geometry / scratch / generic-kernel knobs).  README.md describes each. */
 const char *intfft_strerror(int status);
 const char *intfft_version(void);

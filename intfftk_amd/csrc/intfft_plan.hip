@@ -120,6 +120,14 @@ struct intfft_plan {
     std::vector<int2> h_tw;
     std::vector<PassArgs> passes;
     void *d_scratch = nullptr;
+    // Multi-pass plans of the dedicated kernels process a batch in scratch-sized chunks; consecutive chunks alternate between the
+    // caller's stream and a plan-owned side stream, each with its own scratch half, so that a pass of one chunk runs beside another pass
+    // of the next (fork / join with events: the call stays asynchronous on the caller's stream).  Measured: C4 289 against 269
+    // Gsample/s, C3 142 against 132 (tools/two_stream_probe.py: two 128 MiB halves beat one 256 MiB scratch and three streams);
+    // only the plan families that gain have a second half (create_plan).
+    void *d_scratch2 = nullptr;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t scratch_frames = 0, scratch_bytes = 0;
     bool fast1024 = false;
     bool fast4096 = false;
@@ -858,11 +866,23 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
             const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
-            size_t scratch_mb = (pl->big20 || pl->bigw || pl->wide16) ? 256 : 128; // about the Infinity Cache: inter-pass traffic can stay on die
+            // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
+            // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
+            // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream
+            const bool dual = (big2x || pl->wide16) && !diag_env("INTFFT_ONE_STREAM");
+            size_t scratch_mb = 128; // per scratch buffer; two halves together are about the Infinity Cache
+            if (!dual && (pl->big20 || pl->bigw || pl->wide16)) scratch_mb = 256;
             if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
-            const hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
+            hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
+            if (e == hipSuccess && dual) {
+                e = hipMalloc(&pl->d_scratch2, pl->scratch_bytes);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+                if (e == hipSuccess) pl->scratch_bytes *= 2; // what intfft_plan_get_info reports: both halves
+            }
             if (e != hipSuccess) {
                 intfft_plan_destroy(pl);
                 return (int)e;
@@ -886,6 +906,10 @@ int intfft_plan_destroy(intfft_plan *plan)
         for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
             if (sp) intfft_plan_destroy(sp);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+        if (plan->d_scratch2) (void)hipFree(plan->d_scratch2);
+        if (plan->side_stream) (void)hipStreamDestroy(plan->side_stream);
+        if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+        if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
         if (plan->shard_in) (void)hipFree(plan->shard_in);
         if (plan->shard_out) (void)hipFree(plan->shard_out);
         if (plan->s_shard) (void)hipStreamDestroy(plan->s_shard);
@@ -1087,19 +1111,40 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
     const size_t np = plan->passes.size();
     const size_t chunk = (np > 1 || plan->big20 || plan->bigw) ? plan->scratch_frames : batch;
-    for (size_t f = 0; f < batch; f += chunk) {
+    // more than one chunk: odd chunks run on the plan's side stream with the second scratch half (fork here, join below)
+    hipStream_t const user_stream = stream;
+    const bool dual = plan->d_scratch2 != nullptr && batch > chunk;
+    if (dual) {
+        hipError_t e = hipEventRecord(plan->ev_fork, user_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    struct Join { // joins on every exit path of the loop below
+        intfft_plan *p;
+        hipStream_t s;
+        bool on;
+        ~Join()
+        {
+            if (on && hipEventRecord(p->ev_join, p->side_stream) == hipSuccess) (void)hipStreamWaitEvent(s, p->ev_join, 0);
+        }
+    } join{plan, user_stream, dual};
+    size_t ci = 0;
+    for (size_t f = 0; f < batch; f += chunk, ++ci) {
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
+        const bool odd = dual && (ci & 1);
+        stream = odd ? plan->side_stream : user_stream;
+        void *const scratch = odd ? plan->d_scratch2 : plan->d_scratch;
         // (also for one-frame batches: a lone N = 8192 frame takes 10 us here, 21-53 us as one workgroup of the generic pass)
         if (plan->bigw) {
             const hipError_t e = launch_bigw(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, src, dst,
-                                             plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
+                                             scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
             continue;
         }
         if (plan->wide16) {
-            const hipError_t e = launch_wide16(plan->p.log2n, plan->wargs, src, dst, plan->d_scratch, plan->d_tw, plan->h_tw.data(), nf,
+            const hipError_t e = launch_wide16(plan->p.log2n, plan->wargs, src, dst, scratch, plan->d_tw, plan->h_tw.data(), nf,
                                                stream);
             if (e != hipSuccess) return (int)e;
             continue;
@@ -1107,21 +1152,21 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         if (plan->big20) {
             const hipError_t e = plan->p.direction == INTFFT_INV
                                      ? launch_biginv(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
-                                                     plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
+                                                     plan->p.out_order == INTFFT_ORDER_HALVES, plan->big_two_pass, src, dst, scratch, plan->d_tw,
                                                      plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode)
                                  : plan->p.direction == INTFFT_PAIR
-                                     ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, plan->d_scratch, plan->d_tw,
+                                     ? launch_bigpair(plan->p.log2n, plan->p.twdl_width, plan->big_pair256, src, dst, scratch, plan->d_tw,
                                                       plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode)
                                      : launch_big20(plan->p.log2n, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_HALVES,
-                                                    plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, plan->d_scratch, plan->d_tw,
+                                                    plan->p.out_order == INTFFT_ORDER_BITREV, plan->big_two_pass, src, dst, scratch, plan->d_tw,
                                                     plan->d_tw16f, plan->h_tw.data(), nf, stream, plan->p.data_width, plan->p.rndmode);
             if (e != hipSuccess) return (int)e;
             continue;
         }
         for (size_t i = 0; i < np; ++i) {
             const PassArgs &a = plan->passes[i];
-            const void *pin = a.in_mode == IO_USER ? src : plan->d_scratch;
-            void *pout = a.out_mode == IO_USER ? dst : plan->d_scratch;
+            const void *pin = a.in_mode == IO_USER ? src : scratch;
+            void *pout = a.out_mode == IO_USER ? dst : scratch;
             const hipError_t e = plan->word == 2
                                      ? launch_pass16(a, pin, pout, plan->d_tw16f, plan->d_tw16i, nf, plan->p.twdl_width, stream)
                                      : launch_pass(a, a.word, pin, pout, plan->d_tw, nf, stream, plan->d_tw2d);

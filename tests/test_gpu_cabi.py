@@ -309,3 +309,36 @@ def test_bench_under_the_drivers_launcher():
     assert len(out["per_gpu"]["Gsample/s"]) == 2 and out["value"] > 0
     if torch.cuda.device_count() >= 2:  # ranks on their own GPUs: the aggregate is about the sum of the ranks (on one shared GPU they contend)
         assert abs(out["value"] - sum(out["per_gpu"]["Gsample/s"])) / out["value"] < 0.5
+
+
+def test_chunked_plans_on_two_streams_equal_one_stream(monkeypatch):
+    """The two-pass plans of N = 2^19 / 2^20 and the 24-bit-class plans run the scratch-sized chunks of a large batch alternately on
+    the caller's stream and a plan-owned side stream (fork / join with events).  Same bits as on one stream (INTFFT_ONE_STREAM), for a
+    batch of several chunks, back-to-back calls, a non-default caller stream, and work queued behind the call on that stream."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", "16")  # 4 frames of N = 2^20 (8 of N = 2^16 at 24 bits) per chunk: many chunks in a small batch
+    for log2n, dw, tw, fmt, dt, batch in ((20, 16, 16, 0, torch.int16, 19), (16, 24, 24, 1, torch.int32, 37)):
+        n = 1 << log2n
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5 + log2n)
+        x = torch.randint(-(1 << (dw - 2)), 1 << (dw - 2), (batch, n, 2), device="cuda", dtype=dt, generator=g)
+        core = IntFFTCore(log2n, dw, tw, fmt, 0, "NEW", "FWD", "NATURAL", "NATURAL")
+        s = torch.cuda.Stream()
+        y = torch.empty(core.out_shape(batch), device="cuda", dtype=core.out_dtype)
+        z = torch.empty_like(y)
+        with torch.cuda.stream(s):
+            core.exec_raw(x.data_ptr(), y.data_ptr(), batch, s.cuda_stream)
+            core.exec_raw(x.data_ptr(), z.data_ptr(), batch, s.cuda_stream)  # back to back: the second fork follows the first join
+            total = z.to(torch.int64).sum()  # queued behind the call on the caller's stream: must see every chunk's output
+        s.synchronize()
+        core.close()
+        monkeypatch.setenv("INTFFT_ONE_STREAM", "1")
+        ref = IntFFTCore(log2n, dw, tw, fmt, 0, "NEW", "FWD", "NATURAL", "NATURAL")
+        w = ref(x)
+        torch.cuda.synchronize()
+        ref.close()
+        monkeypatch.delenv("INTFFT_ONE_STREAM")
+        assert torch.equal(y, w) and torch.equal(z, w) and int(total) == int(w.to(torch.int64).sum())

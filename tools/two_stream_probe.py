@@ -15,9 +15,10 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 n = 1 << log2n
 x = torch.randint(-(1 << 14), 1 << 14, (batch, n, 2), device="cuda", dtype=torch.int16)
 y = torch.empty_like(x)
-cores = [IntFFTCore(log2n, 16, 16, 0, 0, "NEW", "FWD", "NATURAL", "NATURAL") for _ in range(2)]
-s = [torch.cuda.Stream(), torch.cuda.Stream()]
-half = batch // 2
+ns = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+cores = [IntFFTCore(log2n, 16, 16, 0, 0, "NEW", "FWD", "NATURAL", "NATURAL") for _ in range(ns)]
+s = [torch.cuda.Stream() for _ in range(ns)]
+half = batch // ns
 
 
 def one():
@@ -26,11 +27,12 @@ def one():
 
 def two(offset_frames=0):
     fb = 2 * n * 2
-    cores[0].exec_raw(x.data_ptr(), y.data_ptr(), half, s[0].cuda_stream)
-    cores[1].exec_raw(x.data_ptr() + half * fb, y.data_ptr() + half * fb, batch - half, s[1].cuda_stream)
+    for i in range(ns):
+        cnt = half if i < ns - 1 else batch - half * (ns - 1)
+        cores[i].exec_raw(x.data_ptr() + i * half * fb, y.data_ptr() + i * half * fb, cnt, s[i].cuda_stream)
 
 
-for name, fn in (("one stream", one), ("two streams", two), ("one stream", one), ("two streams", two)):
+for name, fn in (("one stream", one), ("%d streams" % ns, two), ("one stream", one), ("%d streams" % ns, two)):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
