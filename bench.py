@@ -175,6 +175,8 @@ def diag_lib():
         return None
     L = ctypes.CDLL(path)
     L.diag_copy_wave_nt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    if hasattr(L, "diag_copy_wave_ld"):
+        L.diag_copy_wave_ld.argtypes = L.diag_copy_wave_nt.argtypes
     L.diag_valu_chain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]
     return L
 
@@ -195,14 +197,21 @@ def ceilings(torch, x, y, stream, digest, c2):
         return {"note": "tools/lib/libintfft_diag.so not built"}
     out = {}
     nframes = x.numel() * x.element_size() // 4096
-    copy = lambda: L.diag_copy_wave_nt(x.data_ptr(), y.data_ptr(), nframes, 4, stream)  # noqa: E731
+    fn = L.diag_copy_wave_ld if hasattr(L, "diag_copy_wave_ld") else L.diag_copy_wave_nt
+    copy = lambda: fn(x.data_ptr(), y.data_ptr(), nframes, 4, stream)  # noqa: E731
     for _ in range(50):
         copy()
     ms = event_ms(torch, copy, 50)
     gbs = 2.0 * nframes * 4096 / (ms * 1e-3) / 1e9
     out["copy_ceiling"] = {"GB/s": gbs, "frac_of_peak": gbs / HBM_PEAK_GBS, "ms": ms,
-                           "what": "non-temporal copy of the same buffers with the kernel's access pattern (one wave per "
-                                   "4 KiB frame, 16 dword loads + 16 dword stores per lane), measured in this run"}
+                           "what": "copy of the same buffers with the kernel's access pattern (one wave per 4 KiB frame, 16 plain dword "
+                                   "loads + 16 non-temporal dword stores per lane), measured in this run"}
+    if fn is not L.diag_copy_wave_nt:  # the pattern of rounds 1-2, for comparison
+        copy2 = lambda: L.diag_copy_wave_nt(x.data_ptr(), y.data_ptr(), nframes, 4, stream)  # noqa: E731
+        for _ in range(50):
+            copy2()
+        ms2 = event_ms(torch, copy2, 50)
+        out["copy_ceiling"]["nt_loads_too_GB/s"] = 2.0 * nframes * 4096 / (ms2 * 1e-3) / 1e9
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     scratch = torch.empty(cus * 4 * 256, dtype=torch.int32, device="cuda")
     n = ctypes.c_ulonglong()

@@ -20,6 +20,8 @@
 // Measured (256 MiB of input): N = 2^17 332 Gsample/s (three passes: 252), N = 2^18 298 (247).
 // k_big2p_q below is the inverse counterpart (DIT STAGE 8..L-1 after k_mid_q1 / k_mid_c): 325 (247) and 307 (243); the pair runs
 // k_big2p_a, k_mid_pair, k_big2p_q: 202 (164) and 181 (162).
+// multi-pass kernels: non-temporal loads measure 4-14 % faster here (the single-pass kernels gain 4-30 % from PLAIN loads): intfft_device.hpp
+#define INTFFT_NT_LOADS 1
 #include "intfft_pk16.hpp"
 
 #include <cstdlib>
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             const v2u *s2 = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = __builtin_nontemporal_load(s2 + ((size_t)j << (RB + 8)) + toff_l);
+                const v2u w = INTFFT_LD(s2 + ((size_t)j << (RB + 8)) + toff_l);
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 8)) + toff_l); // regs = n(L-1)..n(L-5)
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + 8)) + toff_l); // regs = n(L-1)..n(L-5)
         }
         round1_tw(toff_l);
         // guard-bit vote of the tile (closed under stages L-1..8); the barrier also orders the previous frame's LDS reads
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = __builtin_nontemporal_load(src + ((size_t)q << 8) + toff_l); // (plain loads: 325 vs 332 Gsample/s)
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)q << 8) + toff_l); // (plain loads: 325 vs 332 Gsample/s)
         bool fast = false;
         {
             u32 acc = 0;

@@ -22,6 +22,8 @@
 //   whose other half belongs to the partner block (`rest` with its top bit flipped).
 // Values travel between the passes as in the other multi-pass kernels: multiplier outputs pre-shifted (Y >> 1), so an element's
 // kind after pass A is n10 = q bit 0, which is tile-uniform in pass B.
+// multi-pass kernels: non-temporal loads measure 4-14 % faster here (the single-pass kernels gain 4-30 % from PLAIN loads): intfft_device.hpp
+#define INTFFT_NT_LOADS 1
 #include "intfft_pk16.hpp"
 
 #include <cstdlib>
@@ -128,13 +130,13 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
             const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + 10)) + toff_l);
+                const v2u w = INTFFT_LD(sh + ((size_t)j << (RB + 10)) + toff_l);
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + 10)) + toff_l); // regs = n(L-1)..n(L-5)
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + 10)) + toff_l); // regs = n(L-1)..n(L-5)
         }
         round1_tw(toff_l);
         // guard-bit vote of the tile (closed under stages L-1..10); the barrier also orders the previous frame's LDS reads
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (L - 10)) + toff_l); // c = (j, n4)
+        for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (L - 10)) + toff_l); // c = (j, n4)
         // kind of this tile's inputs = n10 = q0 bit 0 (pass A left Y >> 1 there); vote on the tile's own inputs
         const unsigned k10 = pre_all ? 1u : (q0 & 1u); // (pre_all: the 2-D scheme's column pass left Y >> 1 everywhere)
         const short sa = (short)(1 - (int)k10);
@@ -383,13 +385,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = __builtin_nontemporal_load(sh + ((size_t)j << (RB + LR)) + toff_l);
+                const v2u w = INTFFT_LD(sh + ((size_t)j << (RB + LR)) + toff_l);
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(src + ((size_t)j << (RB + LR)) + toff_l);
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + LR)) + toff_l);
         }
         round1_tw(hx_l);
         bool fast = false;

@@ -8,6 +8,8 @@
 //   pass 3  STAGE 3..0     tile = 256 values of n(L-1)..n(L-8) x 32 consecutive n, LDS transpose to regs n3..0 with
 //                          thread = (n4, rev8(top 8 bits)): natural-order stores in 1-2 KiB runs
 // (DATA_WIDTH = 16 scaled-truncate with TWDL_WIDTH <= 16 has the packed kernels of intfft_big20.hip.)
+// multi-pass kernels: non-temporal loads measure 4-14 % faster here (the single-pass kernels gain 4-30 % from PLAIN loads): intfft_device.hpp
+#define INTFFT_NT_LOADS 1
 #include "intfft_u32.hpp"
 
 namespace intfft {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512) void k_bigw_p1(const void *in, int2 *scr, cons
             u32 raw[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                raw[j] = (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) ? __builtin_nontemporal_load(src + ((size_t)j << 12)) : 0u;
+                raw[j] = (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) ? INTFFT_LD(src + ((size_t)j << 12)) : 0u;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 re[j] = (int)(raw[j] << a.in_sh) >> a.in_sh, im[j] = (int)(raw[j] << (a.in_sh - 16)) >> a.in_sh;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(512) void k_bigw_p1(const void *in, int2 *scr, cons
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 x[j] = v2i{0, 0};
-                if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) x[j] = __builtin_nontemporal_load(src + ((size_t)j << 12));
+                if (!partial || frame * G + (size_t)(j >> (L - 12)) < nframes_user) x[j] = INTFFT_LD(src + ((size_t)j << 12));
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 raw[j] = (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
-                             ? __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 8))
+                             ? INTFFT_LD(src + ((size_t)(16 * j + hx) << 8))
                              : 0u;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 16; ++j) {
                 x[j] = v2i{0, 0};
                 if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
-                    x[j] = __builtin_nontemporal_load(src + ((size_t)(16 * j + hx) << 8));
+                    x[j] = INTFFT_LD(src + ((size_t)(16 * j + hx) << 8));
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, cons
         const u32 *src = static_cast<const u32 *>(in) + off;
         u32 raw[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+        for (int r = 0; r < 16; ++r) raw[r] = INTFFT_LD(src + ((size_t)rev4g(r) << (L - 4)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
     } else {
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(512) void k_bigw_q3(const void *in, int2 *scr, cons
         const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off);
         v2i x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+        for (int r = 0; r < 16; ++r) x[r] = INTFFT_LD(src + ((size_t)rev4g(r) << (L - 4)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
     }
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, cons
         const u32 *src = static_cast<const u32 *>(in) + off;
         u32 raw[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+        for (int r = 0; r < 16; ++r) raw[r] = INTFFT_LD(src + ((size_t)rev4g(r) << (L - 4)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
     } else {
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, cons
         const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + off);
         v2i x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + ((size_t)rev4g(r) << (L - 4)));
+        for (int r = 0; r < 16; ++r) x[r] = INTFFT_LD(src + ((size_t)rev4g(r) << (L - 4)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
     }

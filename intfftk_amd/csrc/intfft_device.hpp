@@ -13,6 +13,18 @@
 
 #include <type_traits>
 
+// Streaming loads of user / scratch data.  Round 3 measured the four combinations of plain / non-temporal loads and stores on the
+// headline kernel (same box, alternating): nt loads + nt stores 704 Gsample/s (rounds 1-2), nt loads + plain stores 728, plain
+// loads + plain stores 650, PLAIN loads + nt stores 767-830.  Stores stay non-temporal everywhere.  Loads: the single-pass kernels
+// (one read of the user array, one write) gain 3-30 % from plain loads (C2 830 against 739, inverse 803 / 710, N = 4096 forward
+// 696 / 631, the C5 pair 401 / 389, 24-bit unscaled N = 1024 268 / 205); the multi-pass kernels LOSE 4-14 % with them (C4 269
+// against 291, C3 133 / 144, N = 2^16 313 / 357) and define INTFFT_NT_LOADS at the top of their translation units.
+#ifdef INTFFT_NT_LOADS
+#define INTFFT_LD(p) __builtin_nontemporal_load(p)
+#else
+#define INTFFT_LD(p) (*(p))
+#endif
+
 namespace intfft {
 
 // KIND_TWMUL / KIND_TWMULC: the inter-pass twiddle multiply of the N > 512K "2-D scheme" (DESIGN.md section 4.5):

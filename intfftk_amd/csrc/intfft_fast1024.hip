@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
                     constexpr int HB = 1 << (L - 7);
                     const int j0 = ((jj >> (L - 7)) << (L - 6)) | (jj & (HB - 1));
                     v2u w = {0u, 0u};
-                    if (!partial || f * FP + (size_t)(jj >> (L - 7)) < nframes_user) w = __builtin_nontemporal_load(src2 + 64 * jj);
+                    if (!partial || f * FP + (size_t)(jj >> (L - 7)) < nframes_user) w = INTFFT_LD(src2 + 64 * jj);
                     v[j0] = w.x;
                     v[j0 | HB] = w.y;
                 }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
         }
         const u32 *src = in + f * 1024 + lane;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j);
+        for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(src + 64 * j);
     };
 
     const size_t wave0 = (size_t)blockIdx.x * 4 + wv;

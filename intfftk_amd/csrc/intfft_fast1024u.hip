@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
                 raw[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j] : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j);
+            for (int j = 0; j < 16; ++j) raw[j] = INTFFT_LD(src + 64 * j);
         }
         bool fast = false;
         if (FAST_OK) {

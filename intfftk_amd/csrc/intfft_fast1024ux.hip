@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u};
                 if (ok)
-                    x = __builtin_nontemporal_load(
+                    x = INTFFT_LD(
                         reinterpret_cast<const v4u *>(src + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
                 raw[q] = x.x, raw[q + 8] = x.y, raw[q + 4] = x.z, raw[q + 12] = x.w;
             }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
-                raw[r] = __builtin_nontemporal_load(src + 64 * rr + lane);
+                raw[r] = INTFFT_LD(src + 64 * rr + lane);
             }
         } else if (partial) {
 #pragma unroll
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
                 raw[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j + lane] : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) raw[j] = __builtin_nontemporal_load(src + 64 * j + lane);
+            for (int j = 0; j < 16; ++j) raw[j] = INTFFT_LD(src + 64 * j + lane);
         }
         bool fast = false;
         if (FAST_OK) {

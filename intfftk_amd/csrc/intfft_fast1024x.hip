@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u};
                 if (ok)
-                    x = __builtin_nontemporal_load(
+                    x = INTFFT_LD(
                         reinterpret_cast<const v4u *>(src + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
                 v[q] = x.x;
                 v[q + 8] = x.y;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u}; // short frames: the vector's frame = bits a9..aL of (q, lane & 15)
                 if (!partial || f * FP + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) < nframes_user)
-                    x = __builtin_nontemporal_load(s4 + 64 * q);
+                    x = INTFFT_LD(s4 + 64 * q);
                 v[4 * q] = x.x;
                 v[4 * q + 1] = x.y;
                 v[4 * q + 2] = x.z;
@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3);
-                v[r] = __builtin_nontemporal_load(src + 64 * rr + lane);
+                v[r] = INTFFT_LD(src + 64 * rr + lane);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 64 * j + lane);
+            for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(src + 64 * j + lane);
         }
         const bool fast = FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask);
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits (exact path)

@@ -177,14 +177,14 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u};
-                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) x = __builtin_nontemporal_load(s4 + 64 * q);
+                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) x = INTFFT_LD(s4 + 64 * q);
                 v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
             }
         } else if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame (one test around the 16 loads:
             // tested one by one they are issued one by one)
             if (lc_ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = __builtin_nontemporal_load(src + (rev4c(r) << (L - 4)) + lc_off);
+                for (int r = 0; r < 16; ++r) v[r] = INTFFT_LD(src + (rev4c(r) << (L - 4)) + lc_off);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = 0u;
@@ -199,17 +199,17 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                 constexpr int HB = 1 << (L - 9);
                 const int j0 = ((jj >> (L - 9)) << (L - 8)) | (jj & (HB - 1));
                 v2u w = {0u, 0u};
-                if (!partial || f * FP + (size_t)(jj >> (L - 9)) < nframes_user) w = __builtin_nontemporal_load(src2 + 256 * jj);
+                if (!partial || f * FP + (size_t)(jj >> (L - 9)) < nframes_user) w = INTFFT_LD(src2 + 256 * jj);
                 v[j0] = w.x;
                 v[j0 | HB] = w.y;
             }
         } else if (!partial) { // LA: v[j] = x[256 j + tid]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + 256 * j + tid);
+            for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(src + 256 * j + tid);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                v[j] = f * FP + (size_t)((256 * j + tid) >> L) < nframes_user ? __builtin_nontemporal_load(src + 256 * j + tid) : 0u;
+                v[j] = f * FP + (size_t)((256 * j + tid) >> L) < nframes_user ? INTFFT_LD(src + 256 * j + tid) : 0u;
         }
     };
     // Round mode, one core, N = 4096: the workgroup's next frame is loaded into 16 more registers while this one is computed (the

@@ -121,7 +121,7 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
-                const u32 raw = ok ? __builtin_nontemporal_load(src + 256 * j) : 0u;
+                const u32 raw = ok ? INTFFT_LD(src + 256 * j) : 0u;
                 re[j] = (int)(raw << a.in_sh) >> a.in_sh;
                 im[j] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
             }
@@ -132,7 +132,7 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
             for (int j = 0; j < 16; ++j) {
                 const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
                 v2i x = {0, 0};
-                if (ok) x = __builtin_nontemporal_load(src + 256 * j);
+                if (ok) x = INTFFT_LD(src + 256 * j);
                 re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh;
                 im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
             }

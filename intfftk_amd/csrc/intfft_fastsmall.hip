@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_fftsmall_i16(const u32 *in, u32 *out, c
             const int d = 256 * q + 4 * lane; // dword offset within the chunk
             const int fr = d >> L, e = d & (N - 1);
             v4u x = {0u, 0u, 0u, 0u};
-            if (f0 + (size_t)fr < nframes) x = __builtin_nontemporal_load(src + 64 * q);
+            if (f0 + (size_t)fr < nframes) x = INTFFT_LD(src + 64 * q);
             *reinterpret_cast<v4u *>(lds + fr * ROW + e) = x;
         }
         wave_lds_fence(); // wave-private tile: LDS operations of one wave execute in order

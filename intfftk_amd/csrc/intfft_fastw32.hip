@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const bool ok = !partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user;
-                const u32 raw = ok ? __builtin_nontemporal_load(src + 64 * j) : 0u;
+                const u32 raw = ok ? INTFFT_LD(src + 64 * j) : 0u;
                 re[j] = (int)(raw << a.in_sh) >> a.in_sh; // wrap to DATA_WIDTH (conv_std_logic_vector)
                 im[j] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
             }
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
             for (int j = 0; j < 16; ++j) {
                 const bool ok = !partial || f * FP + (size_t)((64 * j + lane) >> L) < nframes_user;
                 v2i x = {0, 0};
-                if (ok) x = __builtin_nontemporal_load(src + 64 * j);
+                if (ok) x = INTFFT_LD(src + 64 * j);
                 re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh;
                 im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
             }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
             const int sh = 32 - a.dw;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2i x = __builtin_nontemporal_load(src + 64 * j);
+                const v2i x = INTFFT_LD(src + 64 * j);
                 re[j] = (int)((u32)x.x << sh) >> sh;
                 im[j] = (int)((u32)x.y << sh) >> sh;
             }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
             const v2l *src = static_cast<const v2l *>(in) + f * 1024 + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2l x = __builtin_nontemporal_load(src + 64 * j);
+                const v2l x = INTFFT_LD(src + 64 * j);
                 re[j] = wrapw<int64_t>((int64_t)x.x, a.dw);
                 im[j] = wrapw<int64_t>((int64_t)x.y, a.dw);
             }

@@ -9,6 +9,8 @@
 // A workgroup moves one tile = the index bits {0..TB-1} of m_out (contiguous stores) united with the m_out bits that feed
 // bits {0..TB-1} of m_in (contiguous loads): 2^U elements, TB <= U <= 2 TB, through LDS -- the classic tiled bit reversal,
 // 256-byte runs on both sides for every pair of orders.  HBM-bound data movement, no arithmetic.
+// multi-pass kernels: non-temporal loads measure 4-14 % faster here (the single-pass kernels gain 4-30 % from PLAIN loads): intfft_device.hpp
+#define INTFFT_NT_LOADS 1
 #include "../../include/intfft.h"
 #include "intfft_pk16.hpp"
 
@@ -64,7 +66,7 @@ template <typename E> __global__ __launch_bounds__(256) void k_reorder(const E *
     E v[16];
 #pragma unroll
     for (unsigned i = 0; i < 16; ++i)
-        if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in | a.i_in[i]));
+        if (i < iters && active) v[i] = INTFFT_LD(src + (t_in | a.i_in[i]));
 #pragma unroll
     for (unsigned i = 0; i < 16; ++i)
         if (i < iters && active) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void k_reorder_tw(const E *in, E *out, const R
         E v[16];
 #pragma unroll
         for (unsigned i = 0; i < 16; ++i)
-            if (i < iters && active) v[i] = __builtin_nontemporal_load(src + (t_in_l | a.i_in[i]));
+            if (i < iters && active) v[i] = INTFFT_LD(src + (t_in_l | a.i_in[i]));
         if constexpr (TW == 2 && PK) {
             if (active) { // T.re = dot(V, Wc), T.im = dot(V, Wd): the swapped feed needs no swap in this packing
 #pragma unroll

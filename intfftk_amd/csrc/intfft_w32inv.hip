@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
                     const size_t off = f * 1024 + lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) +
                                        (q >> 2) * out_weight<L>(2);
                     x[q] = v2u{0u, 0u};
-                    if (ok) x[q] = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + off));
+                    if (ok) x[q] = INTFFT_LD(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + off));
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
                     const size_t off = f * 1024 + lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) +
                                        (q >> 2) * out_weight<L>(2);
                     x[q] = v4i{0, 0, 0, 0};
-                    if (ok) x[q] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + off));
+                    if (ok) x[q] = INTFFT_LD(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + off));
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
                 const u32 *src = static_cast<const u32 *>(in) + f * 1024 + lane;
                 u32 raw[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) raw[r] = __builtin_nontemporal_load(src + 64 * rev4x(r));
+                for (int r = 0; r < 16; ++r) raw[r] = INTFFT_LD(src + 64 * rev4x(r));
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
                 const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + f * 1024 + lane);
                 v2i x[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = __builtin_nontemporal_load(src + 64 * rev4x(r));
+                for (int r = 0; r < 16; ++r) x[r] = INTFFT_LD(src + 64 * rev4x(r));
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     re[r] = (int)((u32)x[r].x << a.in_sh) >> a.in_sh, im[r] = (int)((u32)x[r].y << a.in_sh) >> a.in_sh;
@@ -347,7 +347,7 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
             const u32 *src = static_cast<const u32 *>(in) + f * 4096 + lc_off;
             u32 raw[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) raw[r] = lc_ok ? __builtin_nontemporal_load(src + (rev4x(r) << (L - 4))) : 0u;
+            for (int r = 0; r < 16; ++r) raw[r] = lc_ok ? INTFFT_LD(src + (rev4x(r) << (L - 4))) : 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 re[r] = (int)(raw[r] << a.in_sh) >> a.in_sh, im[r] = (int)(raw[r] << (a.in_sh - 16)) >> a.in_sh;
@@ -358,7 +358,7 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 x[r] = v2i{0, 0};
-                if (lc_ok) x[r] = __builtin_nontemporal_load(src + (rev4x(r) << (L - 4)));
+                if (lc_ok) x[r] = INTFFT_LD(src + (rev4x(r) << (L - 4)));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)

@@ -31,6 +31,8 @@
 // and bits [a+b, a+b+w) of the 64-bit sum are sliced with v_alignbit_b32 (+ v_ashrrev / v_bfe for the sign).
 // 64-bit data d = dH * 2^32 + dL (dL signed): d * w = v_mad_i64_i32(dL, w) + (v_mul_lo_u32(dH, w) << 32),
 // exact because |d| < 2^39 and |w| < 2^23 (width 40 + 24 <= 64).
+// multi-pass kernels: non-temporal loads measure 4-14 % faster here (the single-pass kernels gain 4-30 % from PLAIN loads): intfft_device.hpp
+#define INTFFT_NT_LOADS 1
 #include "intfft_internal.hpp"
 
 #include <cstdlib>
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (!partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2i x = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(src + 4096 * j));
+                const v2i x = INTFFT_LD(reinterpret_cast<const v2i *>(src + 4096 * j));
                 re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
                 im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
             }

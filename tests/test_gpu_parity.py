@@ -219,7 +219,7 @@ def test_two_pass_vs_three_pass_split(log2n, batch, direction, time_order, freq_
 
 
 @pytest.mark.parametrize("log2n", [13, 14, 15])
-@pytest.mark.parametrize("batch", [1, 2, 7, 9])
+@pytest.mark.parametrize("batch", [1, 7])
 def test_multi_pass_kernels_small_batches(log2n, batch):
     """A few frames only (partial virtual 2^16-point frames, grids of a handful of workgroups): the dedicated multi-pass
     kernels serve every batch size -- a lone N = 8192 frame takes 10 us through them, 21-53 us as one workgroup of the
@@ -275,7 +275,7 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
         check(x, log2n, 16, 13, 0, 0, False, direction="INV")
 
 
-@pytest.mark.parametrize("log2n,batch", [(13, 259), (13, 1030), (14, 131), (15, 3), (15, 70), (16, 5), (16, 33)])
+@pytest.mark.parametrize("log2n,batch", [(13, 259), (14, 131), (15, 3), (16, 5), (16, 33)])
 @pytest.mark.parametrize("case", [(16, 16, 1, 0), (16, 16, 0, 1), (12, 16, 0, 0), (18, 24, 0, 0), (10, 18, 1, 0), (32, 16, 0, 0)])
 def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
     """N = 2^13 .. 2^16 with widths within 32 bits (the unscaled 16-bit transform reaches exactly 32 bits at N = 65536):
@@ -295,7 +295,7 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
         m.setenv("INTFFT_NO_TWOPASS", "1")
         info = check(x, log2n, dw, tw, fmt, rnd, True)
         assert info["kernel_name"] == "k_bigw_p1/p2/p3" and info["n_passes"] == 3, info
-    if batch in (259, 131, 3, 5, 1030):  # the inverse through the mirrored passes
+    if batch in (259, 131, 3, 5):  # the inverse through the mirrored passes
         info = check(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
         assert info["kernel_name"] == "k_bigw_qb/qa" and info["n_passes"] == 2, info
         with monkeypatch.context() as m:
@@ -615,7 +615,7 @@ W32_CASES = [(12, 16, 0, 0), (12, 16, 0, 1), (14, 18, 0, 0), (18, 18, 0, 0), (24
              (26, 26, 0, 0), (5, 10, 1, 0)]
 
 
-@pytest.mark.parametrize("log2n", [6, 7, 9, 10])
+@pytest.mark.parametrize("log2n", [6, 8, 10])
 @pytest.mark.parametrize("case", W32_CASES)
 def test_general_width_wave_kernel(log2n, case):
     """Any DATA_WIDTH / TWDL_WIDTH / FORMAT / RNDMODE within 32 bits at 64 <= N <= 1024: every multiplier regime
@@ -649,7 +649,7 @@ def test_general_width_block_kernel(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith("k_fft4096_i16" if packed_round else "k_fft4096_w32"), info
 
 
-@pytest.mark.parametrize("log2n", [6, 8, 10, 11, 12])  # (7 and 9 are template siblings of 6 / 8 / 10: covered by the short-frame tests)
+@pytest.mark.parametrize("log2n", [6, 9, 10, 12])  # (7, 8 and 11 are template siblings: covered by the short-frame / block-kernel tests)
 @pytest.mark.parametrize("case", [(16, 16, 0, 1), (12, 16, 0, 0), (12, 16, 0, 1), (18, 18, 0, 0), (24, 24, 0, 1), (32, 24, 0, 0),
                                   (32, 16, 0, 0), (8, 8, 0, 0), (20, 16, 1, 0), (16, 16, 1, 0), (10, 12, 1, 0), (16, 24, 1, 0),
                                   (26, 26, 0, 0)])
@@ -671,7 +671,7 @@ def test_general_width_inverse_kernels(log2n, case):
         assert info["fast_path"] == 1 and info["kernel_name"].startswith(("k_fft1024x_i16", "k_fft4096_i16") if packed_round else "k_ifft"), info
 
 
-@pytest.mark.parametrize("log2n", [3, 5, 6, 7, 10, 11, 12])
+@pytest.mark.parametrize("log2n", [3, 5, 7, 10, 12])  # (6 and 11 are template siblings of 7 and 12: the short-frame and N = 2048 tests cover them)
 @pytest.mark.parametrize("dw,tw", [(9, 16), (12, 16), (12, 12), (15, 16)])  # (narrower twiddles at one data width: they only move the slice)
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_narrow_data_on_packed_kernels(log2n, dw, tw, direction, monkeypatch):
@@ -1088,7 +1088,7 @@ def _fuzz_cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _fuzz_cases(110, 20260928))
+@pytest.mark.parametrize("case", _fuzz_cases(80, 20260928))
 def test_fuzz_generics_three_way(case, monkeypatch):
     """Random elaboratable generics: whatever kernel the planner picks, the generic LDS pass kernels and the oracle
     agree bit for bit (ragged batch sizes, full-range data)."""

@@ -1,7 +1,8 @@
 // diag_kernels.hip -- on-box ceilings printed next to the bench line (libintfft_diag.so; NOT part of the product library
 // and never on the measured path).  Two probes, both launched by bench.py, which does the timing with HIP events:
-//   diag_copy_wave_nt   a non-temporal copy with the access pattern of k_fft1024_i16 (one wave per 4 KiB frame, 16 dword
-//                       loads then 16 dword stores per lane): the memory-side ceiling of that kernel's own pattern
+//   diag_copy_wave_ld   a copy with the access pattern of k_fft1024_i16 (one wave per 4 KiB frame, 16 plain dword loads then 16
+//                       non-temporal dword stores per lane): the memory-side ceiling of that kernel's own pattern
+//   diag_copy_wave_nt   the same with non-temporal loads as well (the kernel's pattern in rounds 1-2)
 //   diag_valu_chain     N dependent-free packed-int16 adds per lane on 8 register sets: the issue rate of the "slow class"
 //                       VALU instructions (v_pk_*, v_dot2, v_perm, v_bfe) the packed butterflies are made of
 #include <hip/hip_runtime.h>
@@ -9,7 +10,8 @@
 #include <stdint.h>
 typedef unsigned u32;
 
-__global__ __launch_bounds__(256) void k_copy_wave_nt(const u32 *in, u32 *out, size_t nframes)
+// NTLD: loads non-temporal too (the pattern of rounds 1-2); 0: plain loads + non-temporal stores, what the kernel does since round 3
+template <int NTLD> __global__ __launch_bounds__(256) void k_copy_wave_nt(const u32 *in, u32 *out, size_t nframes)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (size_t f = (size_t)blockIdx.x * 4 + wv; f < nframes; f += (size_t)gridDim.x * 4) {
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(256) void k_copy_wave_nt(const u32 *in, u32 *out, s
         u32 *d = out + f * 1024 + lane;
         u32 v[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(s + 64 * j);
+        for (int j = 0; j < 16; ++j) v[j] = NTLD ? __builtin_nontemporal_load(s + 64 * j) : s[64 * j];
 #pragma unroll
         for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], d + 64 * j);
     }
@@ -54,7 +56,17 @@ int diag_copy_wave_nt(const void *d_in, void *d_out, size_t nframes, int blocks_
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    hipLaunchKernelGGL(k_copy_wave_nt, dim3((unsigned)(cus * blocks_per_cu)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_copy_wave_nt<1>, dim3((unsigned)(cus * blocks_per_cu)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32 *)d_in, (u32 *)d_out, nframes);
+    return (int)hipGetLastError();
+}
+// the same with plain loads (non-temporal stores only)
+int diag_copy_wave_ld(const void *d_in, void *d_out, size_t nframes, int blocks_per_cu, void *stream)
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(k_copy_wave_nt<0>, dim3((unsigned)(cus * blocks_per_cu)), dim3(256), 0, (hipStream_t)stream,
                        (const u32 *)d_in, (u32 *)d_out, nframes);
     return (int)hipGetLastError();
 }
