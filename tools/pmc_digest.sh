@@ -23,6 +23,7 @@ for SPEC in "$@"; do
   done
   cd "$REPO"
   python tools/pmc_digest.py "$OUT" "$SPEC" > "$REPO/gpurun_out/pmc_$TAG/${SAFE}_pmc_digest.json"
+  rm -rf "$OUT"  # the raw rocprofv3 output (tens of MiB per configuration): gpurun_out/ is merged back only below 64 MiB
   cat "$REPO/gpurun_out/pmc_$TAG/${SAFE}_pmc_digest.json" | python -c "
 import json,sys
 d=json.load(sys.stdin)

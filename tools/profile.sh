@@ -21,3 +21,6 @@ done
 cd "$REPO"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# keep what profiles/ gets (stats csv, digest, summary); drop the raw traces (gpurun_out/ is merged back only below 64 MiB)
+cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv" 2>/dev/null
+rm -rf "$OUT"/trace "$OUT"/pmc_*

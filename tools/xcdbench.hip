@@ -429,6 +429,63 @@ static void pairs(int cus, u32 nframes)
     hipFree(in), hipFree(out);
 }
 
+// ---------------------------------------------------------------- part 4: load / store cache-policy flavours
+// One wave per 4 KiB frame, 16 dword loads + 16 dword stores per lane (the headline kernel's pattern), 512 MiB in + 512 MiB out.
+// LD: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.   ST: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1
+template <int LD> __device__ __forceinline__ u32 ld_flavour(const u32 *p)
+{
+    u32 v;
+    if (LD == 0) return *p;
+    if (LD == 1) return __builtin_nontemporal_load(p);
+    if (LD == 2) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (LD == 3) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int ST> __device__ __forceinline__ void st_flavour(u32 *p, u32 v)
+{
+    if (ST == 0) *p = v;
+    else if (ST == 1) __builtin_nontemporal_store(v, p);
+    else if (ST == 2) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if (ST == 3) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else if (ST == 4) asm volatile("global_store_dword %0, %1, off nt sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dword %0, %1, off nt sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <int LD, int ST> __global__ __launch_bounds__(256) void k_flavour(const u32 *in, u32 *out, size_t nframes)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t f = (size_t)blockIdx.x * 4 + wv; f < nframes; f += (size_t)gridDim.x * 4) {
+        const u32 *s = in + f * 1024 + lane;
+        u32 *d = out + f * 1024 + lane;
+        u32 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = ld_flavour<LD>(s + 64 * j);
+        if (LD >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 16; ++j) st_flavour<ST>(d + 64 * j, v[j] + 1u);
+    }
+}
+static void flavours(int cus)
+{
+    const size_t nframes = 131072, bytes = nframes * 4096;
+    u32 *in, *out;
+    CK(hipMalloc(&in, bytes));
+    CK(hipMalloc(&out, bytes));
+    CK(hipMemset(in, 1, bytes));
+    CK(hipMemset(out, 0, bytes));
+    printf("# flavours: %zu frames of 4 KiB (%.0f MiB in + same out), grid = 4 blocks/CU; GB/s = read + write\n", nframes, bytes / 1048576.0);
+    const char *ldn[4] = {"plain", "nt", "sc1", "sc0 sc1"}, *stn[6] = {"plain", "nt", "sc1", "sc0 sc1", "nt sc1", "nt sc0 sc1"};
+#define FL(LD, ST)                                                                                                                           \
+    {                                                                                                                                       \
+        float ms = timeit([&] { hipLaunchKernelGGL((k_flavour<LD, ST>), dim3(cus * 4), dim3(256), 0, 0, in, out, nframes); }, 30, 50);        \
+        printf("load %-8s store %-11s %8.3f ms  %7.1f GB/s\n", ldn[LD], stn[ST], ms, 2.0 * bytes / ms / 1e6);                               \
+        fflush(stdout);                                                                                                                     \
+    }
+    FL(0, 0) FL(0, 1) FL(0, 2) FL(0, 3) FL(0, 4) FL(0, 5)
+    FL(1, 0) FL(1, 1) FL(1, 4)
+    FL(2, 1) FL(3, 1)
+    hipFree(in), hipFree(out);
+}
+
 int main(int argc, char **argv)
 {
     int cus;
@@ -441,5 +498,6 @@ int main(int argc, char **argv)
         pipes<1024, 32>(cus, nframes, 1, 128 * 1024);
     }
     if (!strcmp(what, "pairs") || !strcmp(what, "all")) pairs(cus, nframes);
+    if (!strcmp(what, "flavours") || !strcmp(what, "all")) flavours(cus);
     return 0;
 }
