@@ -1072,6 +1072,8 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (two_pass && log2n >= 19) // N = 2^19, 2^20: the mirrors of the forward two-pass plan (intfft_big2x.hip); natural order in only (planner)
+        return in_bitrev ? hipErrorInvalidValue : launch_big2x_inv(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, out_halves, stream);
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the same first pass, then STAGE 8..L-1 with 32 registers per thread
         if (in_bitrev) {
             const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;

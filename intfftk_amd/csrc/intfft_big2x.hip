@@ -315,6 +315,250 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- the inverse: int_ifftNk at N = 2^19, 2^20 in two passes (mirrors of pass B and pass A) ------------------------------------------
+// int_ifftNk (src/vhdl/fft/int_ifftNk.vhd:183-341) is DIT: core position p takes X[brev_L(p)], STAGE s pairs positions that differ
+// in bit s (twiddle index p mod 2^s, re/im-swapped multiplier feed of int_dit2_fly.vhd:290-325), natural order out.
+//   pass QB  k_big2x_qb<L>  the mirror of pass B: tile = the 16 rows k of one `rest` x 1024 columns; loads X with pass B's store
+//            pattern (64-byte pieces, XCD-paired partner = `rest` with its top bit flipped), STAGE 0..4 on wave-uniform twiddles,
+//            LDS transpose, STAGE 5..9 on per-thread twiddles held in registers; user array -> scratch [q][c][hi][k][l]
+//   pass QA  k_big2x_qa<L>  the mirror of pass A: tile = 2^(L-10) rows x 16 columns; scratch (2 KiB runs) -> STAGE 10..14 (L = 19:
+//            two 4-stage rounds 10..13) on per-column twiddles parked in LDS -> LDS transpose -> STAGE L-5..L-1 on per-thread twiddles
+//            re-read per tile -> natural or HALVES order out (64-byte row pieces 4 KiB apart, XCD-paired)
+// DIT butterflies have no pre-shifted kinds (A >> 1 and T >> 1 are formed inside every stage): the scratch holds plain values.
+// Quarter turns negate the twiddle operand (group4_dit<.., QTURN>): the planner checks that no table entry is -2^15.
+
+// five DIT stages 0..4 on regs = n4..n0, wave-uniform twiddles in the DIT packing {Wc, Wd} (host: to_dit_packing_host5)
+template <bool FASTX> __device__ __forceinline__ void dit_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl)
+{
+#pragma unroll
+    for (int g = 0; g < 32; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+#pragma unroll
+    for (int g = 0; g < 32; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_pj_dit<false>(v[g + 1], v[g + 3]);
+    }
+#pragma unroll
+    for (int B = 0; B < 32; B += 8) // STAGE 2: pairs (q, q + 4), twiddle q & 3
+        group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+    const u32 wa30[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb30[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa31[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb31[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+#pragma unroll
+    for (int B = 0; B < 32; B += 16) { // STAGE 3: pairs (q, q + 8), twiddle q & 7
+        group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa30, wb30, sl);
+        group4_dit<FASTX, true, 0, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa31, wb31, sl);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) { // STAGE 4: pairs (q, q + 16), twiddle q
+        const u32 wa[4] = {c.wa4[g], c.wa4[g + 1], c.wa4[g + 2], c.wa4[g + 3]}, wb[4] = {c.wb4[g], c.wb4[g + 1], c.wb4[g + 2], c.wb4[g + 3]};
+        group4_dit<FASTX, true, 0, true>(v[g], v[g + 16], v[g + 1], v[g + 17], v[g + 2], v[g + 18], v[g + 3], v[g + 19], wa, wb, sl);
+    }
+}
+
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qb(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
+                                                                                              const Round5Consts c, size_t nframes, const Slice sl)
+{
+    static_assert(L == 19 || L == 20, "rows of 1024 points");
+    constexpr int RL = L - 14;
+    extern __shared__ u32 lds[];
+    const int tid = threadIdx.x;
+    const int m = ((tid >> 8) << 4) | (tid & 15), k = (tid >> 4) & 15;
+    u32 wa16[8], wb16[8];
+    RoundTwQ t1; // STAGE 5 + b on reg bit b of round 2 (regs n9..n5), twiddle index (jj << 5) | m; DIT packing
+    {
+        auto ld = [&](unsigned idx, u32 &wa, u32 &wb) {
+            const uint2 w = twf[idx + (unsigned)m];
+            wa = w.x, wb = w.y;
+            to_dit_packing(wa, wb);
+        };
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld(511u + ((unsigned)jj << 5), wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld(255u + ((unsigned)jj << 5), t1.wa8[jj], t1.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld(127u + ((unsigned)jj << 5), t1.wa4[jj], t1.wb4[jj]);
+        ld(63u, t1.wa2[0], t1.wb2[0]);
+        ld(31u, t1.wa1[0], t1.wb1[0]);
+    }
+    const int jj = tid >> 4, kb = tid & 15;
+    const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
+    u32 *const wr_base = lds + ROWY * ((jj << 4) | krow);     // round 1 thread (jj, kb): row (jj << 4) + k, column q
+    const u32 *const rd_base = lds + ROWY * k + m;            // round 2 thread (k, m): row (j << 4) + k
+    const unsigned toff = (((unsigned)tid >> 8) << (L - 11)) | ((unsigned)tid & 255u); // scratch side (round 2 thread)
+    const unsigned rjj = __brev((unsigned)jj) >> 27;
+    const unsigned toff2 = (rjj << (L - 10)) | (unsigned)kb;  // user side (round 1 thread)
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+
+    for (size_t t = blockIdx.x;; t += gridDim.x) {
+        const size_t G = (t >> 4) * 8u + slot;
+        const size_t frame = G >> (RL - 1);
+        if (frame >= nframes) break;
+        const unsigned rest = (part << (RL - 1)) | ((unsigned)G & ((1u << (RL - 1)) - 1u));
+        const unsigned q0 = rest & 31u, hi = rest >> 5;
+        const u32 *src = in + (frame << L) + ((__brev(rest) >> (32 - RL)) << 4);
+        u32 *dst = scr + (frame << L) + ((size_t)q0 << (L - 5)) + (hi << 8);
+        unsigned toff_l = toff, toff2_l = toff2;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        u32 v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)rev5c(q) << (L - 5)) + toff2_l); // core position (rho, jj << 5 | q) = X[brev_L]
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && bad == 0;
+        }
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
+        if (fast) dit_round5_c<FAST_OK>(v, c, sl);
+        else dit_round5_c<false>(v, c, sl);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wr_base[q] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = rd_base[ROWY * (j << 4)];
+        if (fast) {
+            dit_round_q<FAST_OK, 0>(v, t1, sl);
+            dit_round_q<FAST_OK, 16>(v, t1, sl);
+            dit_top16<FAST_OK>(v, wa16, wb16, sl);
+        } else {
+            dit_round_q<false, 0>(v, t1, sl);
+            dit_round_q<false, 16>(v, t1, sl);
+            dit_top16<false>(v, wa16, wb16, sl);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) (dst + ((size_t)j << (L - 10)))[toff_l] = v[j];
+    }
+}
+
+template <int L, bool FAST_OK>
+__global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qa(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
+                                                                                                         size_t nframes, unsigned groups, const Slice sl, int halves)
+{
+    static_assert(L == 19 || L == 20, "9 or 10 stages");
+    constexpr int RB = L - 15;
+    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWX, then round 1's twiddles: 8 (RB = 4) / 16 slots x 16 columns, DIT packing
+    uint2 *const tw1 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWX);
+    const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
+    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+    const unsigned lfull = chunk * 16 + l;
+    const unsigned toff = ((unsigned)hx << 10) | lfull; // user side and round-2 twiddles: thread (hx = n(L-6)..n10, l)
+    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & ((1u << (RB - 4)) - 1u)) << 8) | (((unsigned)hx >> (RB - 4)) << 4) | (unsigned)l; // scratch side
+    if (hx == 0) { // round 1 (STAGE 10 + b, table index (rr << 10) | lfull): parked per column, DIT packing
+        int s = 0;
+        auto park = [&](unsigned uniform_idx) {
+            uint2 w = (twf + uniform_idx)[lfull];
+            to_dit_packing(w.x, w.y);
+            tw1[16 * s++ + l] = w;
+        };
+        park((1u << 10) - 1u);
+        park((1u << 11) - 1u);
+        for (int rr = 0; rr < 2; ++rr) park((1u << 12) - 1u + ((unsigned)rr << 10));
+        for (int rr = 0; rr < 4; ++rr) park((1u << 13) - 1u + ((unsigned)rr << 10));
+        if constexpr (RB == 5)
+            for (int rr = 0; rr < 8; ++rr) park((1u << 14) - 1u + ((unsigned)rr << 10));
+    }
+    u32 *const wr_base = lds + ROWX * (hx << 5) + l;  // round 1 thread (jx = tid >> 4, l): row (jx << 5) + q
+    const u32 *const rd_base = lds + ROWX * hx + l;   // round 2 thread (hx, l): row (j << RB) + hx
+
+    for (size_t frame = grp; frame < nframes; frame += groups) {
+        const u32 *src = scr + (frame << L);
+        u32 *dst = out + (frame << L);
+        unsigned toff_l = toff, toff2_l = toff2;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        u32 v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)q << (L - 5)) + toff2_l);
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
+            fast = FAST_OK && bad == 0;
+        }
+        {
+            RoundTwQ t1;
+            u32 wa16[8], wb16[8];
+            int s = 0;
+            auto get = [&](u32 &wa, u32 &wb) {
+                const uint2 w = tw1[16 * s++ + l];
+                wa = w.x, wb = w.y;
+            };
+            get(t1.wa1[0], t1.wb1[0]);
+            get(t1.wa2[0], t1.wb2[0]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) get(t1.wa4[rr], t1.wb4[rr]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) get(t1.wa8[rr], t1.wb8[rr]);
+            if constexpr (RB == 5) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) get(wa16[rr], wb16[rr]);
+            }
+            if (fast) {
+                dit_round_q<FAST_OK, 0>(v, t1, sl);
+                dit_round_q<FAST_OK, 16>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa16, wb16, sl);
+            } else {
+                dit_round_q<false, 0>(v, t1, sl);
+                dit_round_q<false, 16>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<false>(v, wa16, wb16, sl);
+            }
+        }
+        // round 2's per-thread twiddles: STAGE L-5+b, index (jj << (RB + 10)) | toff: re-read per tile, converted to the DIT packing
+        RoundTwQ t2;
+        u32 wa16[8], wb16[8];
+        auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
+            const uint2 w = (twf + uniform_idx)[toff_l];
+            wa = w.x, wb = w.y;
+        };
+        ld((1u << (L - 5)) - 1u, t2.wa1[0], t2.wb1[0]);
+        ld((1u << (L - 4)) - 1u, t2.wa2[0], t2.wb2[0]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld((1u << (L - 3)) - 1u + ((unsigned)jj << (RB + 10)), t2.wa4[jj], t2.wb4[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld((1u << (L - 2)) - 1u + ((unsigned)jj << (RB + 10)), t2.wa8[jj], t2.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld((1u << (L - 1)) - 1u + ((unsigned)jj << (RB + 10)), wa16[jj], wb16[jj]);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wr_base[ROWX * q] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = rd_base[ROWX * (j << RB)];
+        to_dit_packing(t2.wa1[0], t2.wb1[0]);
+        to_dit_packing(t2.wa2[0], t2.wb2[0]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) to_dit_packing(t2.wa4[jj], t2.wb4[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) to_dit_packing(t2.wa8[jj], t2.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) to_dit_packing(wa16[jj], wb16[jj]);
+        if (fast) {
+            dit_round_q<FAST_OK, 0>(v, t2, sl);
+            dit_round_q<FAST_OK, 16>(v, t2, sl);
+            dit_top16<FAST_OK>(v, wa16, wb16, sl);
+        } else {
+            dit_round_q<false, 0>(v, t2, sl);
+            dit_round_q<false, 16>(v, t2, sl);
+            dit_top16<false>(v, wa16, wb16, sl);
+        }
+        if (halves) { // HALVES order out: memory index = 2 * (n without n(L-1)) + n(L-1): registers j and j + 16 are one 8-byte store
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            v2u *d2 = reinterpret_cast<v2u *>(dst);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v2u w = {v[j], v[j + 16]};
+                __builtin_nontemporal_store(w, d2 + ((size_t)j << (RB + 10)) + toff_l);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << (RB + 10)) + toff_l);
+        }
+    }
+}
+
 // ---- the 2-D scheme at N = 2^20 = 1024 x 1024 in TWO launches: k_big2x_c + k_big2x_b<20> --------------
 // forward, DATA_WIDTH = 16, TWDL_WIDTH <= 16, scaled-truncate, natural / HALVES order in -> natural order out:
 //   k_big2x_c   the column cores (1024-point int_fftNk over n1 for every n2) on pass A's tiles -- 1024 rows x 16 columns, XCD-paired
@@ -554,6 +798,41 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
     return hipGetLastError();
 }
 
+hipError_t launch_big2x_inv(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes, const Slice &sl,
+                            int halves, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) { // DIT packing: Wc = (wr, wi), Wd = (-wi, wr)
+        const int2 w = h_tw[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)w.y << 16);
+        wb = ((u32)(-w.y) & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+#define INTFFT_2XQ_LAUNCH(LL, FX)                                                                                                  \
+    {                                                                                                                              \
+        constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
+        const size_t ldsa = (size_t)(32 << RB) * ROWX * sizeof(u32) + (LL == 20 ? 16 : 8) * 16 * sizeof(uint2);                    \
+        const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
+        allow_max_lds(kptr(k_big2x_qa<LL, FX>));                                                                                   \
+        allow_max_lds(kptr(k_big2x_qb<LL, FX>));                                                                                   \
+        const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
+        const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
+        hipLaunchKernelGGL((k_big2x_qb<LL, FX>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl);              \
+        const unsigned groups = (unsigned)(nframes < 64 ? nframes : 64);                                                           \
+        hipLaunchKernelGGL((k_big2x_qa<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, scr, pout, tw16f, nframes, groups, sl, halves); \
+    }
+    if (log2n == 20) {
+        if (fx) INTFFT_2XQ_LAUNCH(20, true) else INTFFT_2XQ_LAUNCH(20, false)
+    } else {
+        if (fx) INTFFT_2XQ_LAUNCH(19, true) else INTFFT_2XQ_LAUNCH(19, false)
+    }
+#undef INTFFT_2XQ_LAUNCH
+    return hipGetLastError();
+}
+
 // the quarter-turn relation both passes rely on (stages 5 .. L-1), checked on the plan's generated tables (host copy)
 bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd)
 {
@@ -563,6 +842,7 @@ bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd)
         for (size_t k = 0; k < h; ++k) {
             const int neg = (int)(((long long)(-t[k].x) << (64 - twd)) >> (64 - twd));
             if (t[k + h].x != t[k].y || t[k + h].y != neg) return false;
+            if (t[k].x == -32768 || t[k].y == -32768) return false; // the inverse negates packed 16-bit twiddle halves
         }
     }
     return true;

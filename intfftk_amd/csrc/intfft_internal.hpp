@@ -253,6 +253,8 @@ hipError_t launch_fused2d(int twd, const uint32_t *pin, uint32_t *pout, uint32_t
                           int halves, hipStream_t stream);
 hipError_t launch_fused2d_cols(int lr, int twd, const uint32_t *pin, uint32_t *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint32_t *tw2d, size_t nframes,
                                int halves, hipStream_t stream);
+hipError_t launch_big2x_inv(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,
+                            const struct Slice &sl, int halves, hipStream_t stream);
 // two-pass plans for N = 2^17, 2^18 forward: 32-register first pass (intfft_big2p.hip) + k_mid_p2 / k_mid_c
 bool big2p_supported(int log2n);
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd);

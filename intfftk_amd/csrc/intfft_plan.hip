@@ -823,6 +823,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && p->out_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
                            !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x) pl->big_two_pass = true;
+        // ... and the inverse from natural order (natural or HALVES order out): k_big2x_qb / k_big2x_qa
+        const bool big2x_inv = pl->big20 && p->direction == INTFFT_INV && !p->rndmode && p->in_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
+                               !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
+        if (big2x_inv) pl->big_two_pass = true;
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !diag_env("INTFFT_NO_WIDE16");
@@ -848,7 +852,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : big2x ? big2x_kernel_name() : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;
@@ -869,7 +873,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream
-            const bool dual = (big2x || pl->wide16) && !diag_env("INTFFT_ONE_STREAM");
+            const bool dual = (big2x || big2x_inv || pl->wide16) && !diag_env("INTFFT_ONE_STREAM");
             size_t scratch_mb = 128; // per scratch buffer; two halves together are about the Infinity Cache
             if (!dual && (pl->big20 || pl->bigw || pl->wide16)) scratch_mb = 256;
             if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
@@ -1113,7 +1117,11 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     const size_t chunk = (np > 1 || plan->big20 || plan->bigw) ? plan->scratch_frames : batch;
     // more than one chunk: odd chunks run on the plan's side stream with the second scratch half (fork here, join below)
     hipStream_t const user_stream = stream;
-    const bool dual = plan->d_scratch2 != nullptr && batch > chunk;
+    bool dual = plan->d_scratch2 != nullptr && batch > chunk;
+    if (dual) { // under stream capture the call stays on the caller's stream (no cross-stream edges in somebody else's graph)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(user_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dual = false;
+    }
     if (dual) {
         hipError_t e = hipEventRecord(plan->ev_fork, user_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0);

@@ -342,3 +342,39 @@ def test_chunked_plans_on_two_streams_equal_one_stream(monkeypatch):
         ref.close()
         monkeypatch.delenv("INTFFT_ONE_STREAM")
         assert torch.equal(y, w) and torch.equal(z, w) and int(total) == int(w.to(torch.int64).sum())
+
+
+def test_exec_under_stream_capture():
+    """intfft_exec inside a hipGraph capture: every launch stays on the capturing stream (the chunked plans do not fork onto their side
+    stream there), and the replayed graph reproduces the eager result -- a multi-chunk two-pass plan and the headline kernel."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    for log2n, batch, mb in ((20, 9, "16"), (10, 4096, None)):
+        if mb:
+            os.environ["INTFFT_SCRATCH_MB"] = mb
+        try:
+            core = IntFFTCore(log2n, 16, 16, 0, 0, "NEW", "FWD", "NATURAL", "NATURAL")
+        finally:
+            os.environ.pop("INTFFT_SCRATCH_MB", None)
+        n = 1 << log2n
+        g = torch.Generator(device="cuda")
+        g.manual_seed(11 + log2n)
+        x = torch.randint(-(1 << 14), 1 << 14, (batch, n, 2), device="cuda", dtype=torch.int16, generator=g)
+        want = core(x)
+        y = torch.zeros_like(want)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(graph, stream=s):
+            rc = core.exec_raw(x.data_ptr(), y.data_ptr(), batch, torch.cuda.current_stream().cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        core.close()

@@ -270,9 +270,33 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
     x = uniform_frames(batch, n, 15, 4000 + log2n)
     x[0] = uniform_frames(1, n, 16, 9)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction="INV")
-    assert ("k_big2" in info["kernel_name"]) and info["n_passes"] == (2 if log2n <= 18 else 3)
+    assert ("k_big2" in info["kernel_name"]) and info["n_passes"] == 2
     if batch <= 9 and log2n < 20:
         check(x, log2n, 16, 13, 0, 0, False, direction="INV")
+
+
+@pytest.mark.parametrize("log2n,batch", [(19, 1), (19, 5), (19, 70), (20, 1), (20, 3), (20, 35)])
+def test_two_pass_inverse_n2pow19_n2pow20(log2n, batch, monkeypatch):
+    """int_ifftNk at N = 2^19, 2^20 from natural order: k_big2x_qb (bit-reversed gather as 64-byte pieces, STAGE 0..9 along the rows)
+    + k_big2x_qa (STAGE 10..L-1 down the columns, natural or HALVES order out) against the oracle and the three-pass plan they replace
+    (INTFFT_NO_BIG2X); several scratch chunks (two streams), a full-scale frame, 13-bit twiddles / XSER OLD, 12-bit data."""
+    n = 1 << log2n
+    x = uniform_frames(batch, n, 15, 4100 + log2n + batch)
+    x[0] = uniform_frames(1, n, 16, 9)[0]
+    got, info = run_gpu(x, log2n, 16, 16, 0, 0, True, direction="INV")
+    assert info["kernel_name"] == "k_big2x_qb/k_big2x_qa" and info["n_passes"] == 2, info
+    sel = list(range(batch)) if batch <= 5 else [0, 1, batch // 2, batch - 1]
+    assert np.array_equal(got[sel], run_ref(x[sel], log2n, 16, 16, 0, 0, True, direction="INV"))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_BIG2X", "1")
+        got3, info3 = run_gpu(x, log2n, 16, 16, 0, 0, True, direction="INV")
+        assert info3["kernel_name"] == "k_big20_q3/q2/q1" and info3["n_passes"] == 3, info3
+    assert np.array_equal(got, got3)
+    if batch <= 5:
+        info = check(x, log2n, 16, 16, 0, 0, True, direction="INV", out_order="HALVES")
+        assert info["n_passes"] == 2
+        check(x[:2], log2n, 16, 13, 0, 0, False, direction="INV")
+        check(x[:2] >> 4, log2n, 12, 16, 0, 0, True, direction="INV")
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 259), (14, 131), (15, 3), (16, 5), (16, 33)])
@@ -316,7 +340,7 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
     # N = 2^17, 2^18: the 32-register passes take the native orders too; N = 2^19, 2^20: HALVES in -> natural order out only
-    two = log2n <= 18 or (direction == "FWD" and out_order == "NATURAL")
+    two = log2n <= 18 or (direction == "FWD" and out_order == "NATURAL") or (direction == "INV" and in_order == "NATURAL")
     assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
 
 
