@@ -873,7 +873,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream
-            const bool dual = (big2x || big2x_inv || pl->wide16) && !diag_env("INTFFT_ONE_STREAM");
+            const bool dual = (big2x || big2x_inv || pl->wide16 || (diag_env("INTFFT_TWO_STREAMS") && (pl->big20 || pl->bigw))) && !diag_env("INTFFT_ONE_STREAM");
             size_t scratch_mb = 128; // per scratch buffer; two halves together are about the Infinity Cache
             if (!dual && (pl->big20 || pl->bigw || pl->wide16)) scratch_mb = 256;
             if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;

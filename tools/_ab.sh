@@ -1,2 +1,6 @@
-for b in 3 4 5 6 8; do echo "blocks/CU=$b $(INTFFT_DIAG=1 INTFFT_BLOCKS_PER_CU=$b python bench.py --no-cpu-baseline --no-extras --steps 200 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['roofline']['kernel_ms']*1000,2),'us', round(d['roofline']['frac'],4))")"; done
-for b in 4 5 6 8; do echo "PIPE=0 blocks/CU=$b $(INTFFT_DIAG=1 INTFFT_FAST_PIPE=0 INTFFT_BLOCKS_PER_CU=$b python bench.py --no-cpu-baseline --no-extras --steps 200 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['roofline']['kernel_ms']*1000,2),'us', round(d['roofline']['frac'],4))")"; done
+export BENCH_INPUT_MB=2048
+for spec in 16:16:16:0 14:16:16:0 18:16:16:0 16:16:16:0:0:INV 20:16:16:0:0:INV 16:16:16:0:0:PAIR 20:16:16:0:0:PAIR 16:16:16:1 16:16:16:0:1 20:16:16:0:1; do
+a=$(python tools/bench_configs.py $spec 2>&1 | grep -o '"Gsample/s": [0-9.]*' | sed 's/"Gsample\/s": //')
+b=$(INTFFT_TWO_STREAMS=1 python tools/bench_configs.py $spec 2>&1 | grep -o '"Gsample/s": [0-9.]*\|"parity_prefix_ok": [a-z]*' | paste - - | sed 's/"Gsample\/s": //; s/"parity_prefix_ok": //')
+echo "$spec (2 GiB in) default: $a | two streams forced: $b"
+done

@@ -102,7 +102,7 @@ def adhoc(spec):
     in_cb = 2 if dw <= 16 else 4 if dw <= 32 else 8
     ob = dw + (fmt * log2n) * (2 if direction == "PAIR" else 1)
     out_cb = 2 if ob <= 16 else 4 if ob <= 32 else 8 if ob <= 64 else 16
-    batch = max(1, (256 << 20) // ((2 * in_cb) << log2n))
+    batch = max(1, (int(os.environ.get("BENCH_INPUT_MB", "256")) << 20) // ((2 * in_cb) << log2n))
     CONFIGS[spec] = (log2n, dw, tw, fmt, rnd, direction, batch, min(dw, 31) - 1, 2 * (in_cb + out_cb))
 
 
