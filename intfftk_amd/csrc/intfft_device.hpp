@@ -45,7 +45,8 @@ struct StageDesc {
     int rnd;     // RoundKind
     int sh_a;    // multiplier: per-product pre-shift  (0 in the single-DSP regimes)
     int sh_b;    // multiplier: post-sum shift
-    int narrow;  // 1: 64-bit words with mw + TWDL_WIDTH <= 64, every product of the multiplier fits one int64;
+    int narrow;  // (-3: set by a kernel at compile time, never by the planner: the three-dword product form of cmult<int64_t>)
+                 // 1: 64-bit words with mw + TWDL_WIDTH <= 64, every product of the multiplier fits one int64;
                  // 59 / 61: trpl18 regime with mw beyond the multiplier's A port: the data operand is cut to that many bits first
                  // (SXT(M_AA, AWD), int_cmult_trpl18_dsp48.vhd:161-162); 0: neither
     unsigned tw_off; // offset of this stage's table in the twiddle buffer (int2 entries)
@@ -165,6 +166,46 @@ __device__ __forceinline__ void cmult(int64_t dre, int64_t dim, int32_t wr, int3
             ore = wrapw<int64_t>((int64_t)xr >> sh, mw);
             oim = wrapw<int64_t>((int64_t)xi >> sh, mw);
         }
+        return;
+    }
+    if (narrow == -3 || (mw <= 63 && a + b <= 31)) { // (-3: the caller has checked the condition for every stage of its plan)
+        // three-dword products: d = dH 2^32 + dL (dL signed; |dH| < 2^31 for mw <= 63), P = (dH w + ((dL w) >> 32)) 2^32 + lo32(dL w): two
+        // v_mad_i64_i32 per product; the truncation points as a mask on the low dword, the sums with carry chains, the mw result bits
+        // from bit a + b <= 31 of the 96-bit sum with two v_alignbit_b32
+        struct P3 { uint32_t w0, w1, w2; };
+        auto mul = [](int64_t d, int32_t w) -> P3 {
+            const int32_t dl = (int32_t)d, dh = (int32_t)(d >> 32) - (dl >> 31);
+            const int64_t plo = (int64_t)dl * w;
+            const int64_t u = (int64_t)dh * w + (plo >> 32);
+            return P3{(uint32_t)plo, (uint32_t)u, (uint32_t)((uint64_t)u >> 32)};
+        };
+        P3 m2r = mul(dre, wr), m1r = mul(dim, wi), m2i = mul(dre, wi), m1i = mul(dim, wr);
+        if (a) {
+            const uint32_t k = ~((1u << a) - 1u);
+            m2r.w0 &= k, m1r.w0 &= k, m2i.w0 &= k, m1i.w0 &= k;
+        }
+        auto sub = [](P3 x, P3 y) -> P3 {
+            unsigned c0, c1, c2;
+            P3 r;
+            r.w0 = __builtin_subc(x.w0, y.w0, 0u, &c0);
+            r.w1 = __builtin_subc(x.w1, y.w1, c0, &c1);
+            r.w2 = __builtin_subc(x.w2, y.w2, c1, &c2);
+            return r;
+        };
+        auto add = [](P3 x, P3 y) -> P3 {
+            unsigned c0, c1, c2;
+            P3 r;
+            r.w0 = __builtin_addc(x.w0, y.w0, 0u, &c0);
+            r.w1 = __builtin_addc(x.w1, y.w1, c0, &c1);
+            r.w2 = __builtin_addc(x.w2, y.w2, c1, &c2);
+            return r;
+        };
+        const P3 xr = sub(m2r, m1r), xi = add(m2i, m1i);
+        const uint32_t sh = (uint32_t)(a + b);
+        const uint32_t lr = __builtin_amdgcn_alignbit(xr.w1, xr.w0, sh), hr = __builtin_amdgcn_alignbit(xr.w2, xr.w1, sh);
+        const uint32_t li = __builtin_amdgcn_alignbit(xi.w1, xi.w0, sh), hi = __builtin_amdgcn_alignbit(xi.w2, xi.w1, sh);
+        ore = wrapw<int64_t>((int64_t)(((uint64_t)hr << 32) | lr), mw);
+        oim = wrapw<int64_t>((int64_t)(((uint64_t)hi << 32) | li), mw);
         return;
     }
     const Prod96 m2r = mul96(dre, wr), m1r = mul96(dim, wi);

@@ -38,7 +38,9 @@ template <typename T> __device__ __forceinline__ void store_user(void *base, int
 // 2^R-point sub-transform in registers: element r of the group lives at lds[pad(e + (r << lb_lo))] and
 // carries index bits s_lo .. s_lo+R-1 = r.  Stage s_lo+i pairs r-bit i and uses twiddle
 // kb + ((r mod 2^i) << s_lo) of its table; stage descriptors a.st[si ..] are in processing order.
-template <typename T, int KIND, int R, int RND>
+// NARROW (64-bit words): every multiplier stage of the pass has StageDesc::narrow == 1, so the regime test of cmult() folds at
+// compile time and the 96-bit product path leaves the instruction stream (as in intfft_fastw64.hip)
+template <typename T, int KIND, int R, int RND, bool NARROW>
 __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo, int s_lo, unsigned kb,
                                               const PassArgs &a, int si, const int2 *__restrict__ tw)
 {
@@ -49,9 +51,8 @@ __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo,
 #pragma unroll
     for (int ii = 0; ii < R; ++ii) {
         const int i = KIND == KIND_DIF ? R - 1 - ii : ii;
-        const StageDesc st = a.st[si + ii];
-        constexpr int dummy = 0;
-        (void)dummy;
+        StageDesc st = a.st[si + ii];
+        if (NARROW) st.narrow = 1;
         const int h = 1 << i;
         // the kind of the stage (multiplier / STAGE 1 / STAGE 0) is uniform: one branch per stage, straight-line butterflies inside
         if (st.ts >= 2) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void round_generic(Cx<T> *lds, unsigned e, int lb_lo,
 
 // RND: the rounding kind of the plan's butterflies (one per plan: FORMAT / RNDMODE) as a template parameter -- a third of the
 // sum / difference code per instantiation, no run-time mode branches in the register rounds
-template <typename T, int RND>
+template <typename T, int RND, bool NARROW = false>
 __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in, void *out,
                                                        const int2 *__restrict__ tw, size_t nframes,
                                                        const int2 *__restrict__ tw2d)
@@ -206,17 +207,17 @@ __global__ __launch_bounds__(1024) void k_pass(const PassArgs a, const void *in,
             const unsigned e = (f << U) + u0;
             if (st.kind == KIND_DIF) {
                 switch (R) {
-                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIF, 4, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 3: round_generic<T, KIND_DIF, 3, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 2: round_generic<T, KIND_DIF, 2, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                default: round_generic<T, KIND_DIF, 1, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIF, 4, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIF, 3, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIF, 2, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIF, 1, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
                 }
             } else {
                 switch (R) {
-                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIT, 4, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 3: round_generic<T, KIND_DIT, 3, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                case 2: round_generic<T, KIND_DIT, 2, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
-                default: round_generic<T, KIND_DIT, 1, RND>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 4: if constexpr (RMAX >= 4) round_generic<T, KIND_DIT, 4, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 3: round_generic<T, KIND_DIT, 3, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                case 2: round_generic<T, KIND_DIT, 2, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
+                default: round_generic<T, KIND_DIT, 1, RND, NARROW>(lds, e, lb_lo, s_lo, kb, a, si, tw); break;
                 }
             }
         }
@@ -282,12 +283,16 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = pass_lds_bytes(a, word_bytes);
     int rnd = RND_UNSCALED; // the butterflies of a plan share one kind (the 2-D scheme's multiplier stages carry none)
+    bool narrow64 = word_bytes == 8 && !diag_env("INTFFT_NO_NARROW_PASS");
     for (int i = 0; i < a.nstages; ++i)
-        if (a.st[i].kind == KIND_DIF || a.st[i].kind == KIND_DIT) rnd = a.st[i].rnd;
-#define INTFFT_LAUNCH_PASS(T, R)                                                                                          \
+        if (a.st[i].kind == KIND_DIF || a.st[i].kind == KIND_DIT) {
+            rnd = a.st[i].rnd;
+            if (a.st[i].ts >= 2 && a.st[i].narrow != 1) narrow64 = false;
+        }
+#define INTFFT_LAUNCH_PASS(T, R, ...)                                                                                     \
     {                                                                                                                     \
-        allow_max_lds(kptr(&k_pass<T, R>));                                                                               \
-        hipLaunchKernelGGL((k_pass<T, R>), dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in, out, tw, nframes, tw2d); \
+        allow_max_lds(kptr(&k_pass<T, R, ##__VA_ARGS__>));                                                                \
+        hipLaunchKernelGGL((k_pass<T, R, ##__VA_ARGS__>), dim3((unsigned)blocks), dim3(pass_threads(a)), lds, stream, a, in, out, tw, nframes, tw2d); \
     }
 #define INTFFT_LAUNCH_PASS_T(T)                                                                                           \
     {                                                                                                                     \
@@ -297,7 +302,11 @@ hipError_t launch_pass(const PassArgs &a, int word_bytes, const void *in, void *
     }
     if (word_bytes == 4) INTFFT_LAUNCH_PASS_T(int32_t)
     else if (word_bytes == 16) INTFFT_LAUNCH_PASS(i128, RND_UNSCALED) // results beyond 64 bits exist with bit growth only
-    else INTFFT_LAUNCH_PASS_T(int64_t)
+    else if (narrow64) {
+        if (rnd == RND_TRUNC) INTFFT_LAUNCH_PASS(int64_t, RND_TRUNC, true)
+        else if (rnd == RND_ROUND) INTFFT_LAUNCH_PASS(int64_t, RND_ROUND, true)
+        else INTFFT_LAUNCH_PASS(int64_t, RND_UNSCALED, true)
+    } else INTFFT_LAUNCH_PASS_T(int64_t)
 #undef INTFFT_LAUNCH_PASS_T
 #undef INTFFT_LAUNCH_PASS
     return hipGetLastError();

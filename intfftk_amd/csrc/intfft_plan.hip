@@ -135,7 +135,12 @@ struct intfft_plan {
     bool fast1024u = false;
     bool fast1024ux = false;
     bool fastw32 = false;
-    bool fastw64 = false;  // N = 1024 forward, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
+    // PAIR plans on 64-bit words whose two halves both have dedicated kernels: int_fftNk sub-plan -> middle buffer -> int_ifftNk sub-plan
+    // (int_fft_ifft_pair.vhd:209-280: the cores are chained; natural order in the middle is the same chain with both reorders applied)
+    intfft_plan *pair_f = nullptr, *pair_i = nullptr;
+    void *pair_buf = nullptr;
+    size_t pair_frames = 0;
+    bool fastw64 = false;  // N = 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
     StageDesc st64[10] = {};
     bool fast4096w = false;
     bool w32inv = false;
@@ -769,7 +774,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                   fastw64_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
     if (pl->fastw64) {
         std::vector<StageDesc> st;
-        if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fastw64 = false;
+        if (core_stages(*p, p->data_width, p->direction == INTFFT_INV, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fastw64 = false;
         for (size_t i = 0; i < st.size() && pl->fastw64; ++i) {
             if (st[i].s < 0 || st[i].s > 9 || st[i].wo > 64 || st[i].dtw > 64) pl->fastw64 = false;
             else pl->st64[st[i].s] = st[i];
@@ -778,7 +783,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
     } else if (pl->fastw64) {
-        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64_kernel_name());
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64_kernel_name(p->direction));
     } else if (pl->w32inv) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", w32inv_kernel_name(p->log2n));
     } else if (pl->fast4096w) {
@@ -809,6 +814,32 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !diag_env("INTFFT_NO_BIG20");
+        if (!generic_only && !l1 && p->direction == INTFFT_PAIR && pl->word == 8 && !pl->big20 && !pl->bigw && p->use_fly == 1 &&
+            !diag_env("INTFFT_NO_PAIR_COMPOSITE")) {
+            intfft_params qf = *p, qi = *p;
+            qf.direction = INTFFT_FWD, qf.out_order = INTFFT_ORDER_NATURAL;
+            qi.direction = INTFFT_INV, qi.in_order = INTFFT_ORDER_NATURAL, qi.data_width = p->data_width + (p->format ? p->log2n : 0);
+            auto dedicated = [](const intfft_plan *q) { return q && (q->passes.empty() || q->big20 || q->bigw || q->wide16); };
+            int rs = qi.data_width <= 64 ? create_plan(&pl->pair_f, &qf, 0, hip_device) : INTFFT_ERR_INVALID;
+            if (rs == INTFFT_OK && dedicated(pl->pair_f)) rs = create_plan(&pl->pair_i, &qi, 0, hip_device);
+            if (rs == INTFFT_OK && dedicated(pl->pair_f) && dedicated(pl->pair_i) && pl->pair_f->out_cb == pl->pair_i->in_cb) {
+                const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->pair_i->in_cb;
+                size_t mb = 256;
+                if (const char *e = diag_env("INTFFT_SCRATCH_MB")) mb = atoi(e) > 0 ? (size_t)atoi(e) : mb;
+                pl->pair_frames = std::max<size_t>(1, (mb << 20) / frame_bytes);
+                if (hipMalloc(&pl->pair_buf, pl->pair_frames * frame_bytes) != hipSuccess) {
+                    intfft_plan_destroy(pl);
+                    return INTFFT_ERR_ALLOC;
+                }
+                pl->scratch_bytes = pl->pair_frames * frame_bytes + pl->pair_f->scratch_bytes + pl->pair_i->scratch_bytes;
+                std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "pair[%.24s|%.24s]", pl->pair_f->kernel_name, pl->pair_i->kernel_name);
+                *out = pl;
+                return INTFFT_OK;
+            }
+            if (pl->pair_f) intfft_plan_destroy(pl->pair_f);
+            if (pl->pair_i) intfft_plan_destroy(pl->pair_i);
+            pl->pair_f = pl->pair_i = nullptr;
+        }
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
         // N = 2^17, 2^18 forward / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
         // quarter turns: verified on this plan's tables)
@@ -907,8 +938,9 @@ int intfft_plan_destroy(intfft_plan *plan)
         if (plan->d_tw2d_tiles) (void)hipFree(plan->d_tw2d_tiles);
         for (void *b : plan->buf2d)
             if (b) (void)hipFree(b);
-        for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
+        for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i, plan->pair_f, plan->pair_i})
             if (sp) intfft_plan_destroy(sp);
+        if (plan->pair_buf) (void)hipFree(plan->pair_buf);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
         if (plan->d_scratch2) (void)hipFree(plan->d_scratch2);
         if (plan->side_stream) (void)hipStreamDestroy(plan->side_stream);
@@ -934,6 +966,16 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64;
+    if (plan->pair_buf) {
+        intfft_plan_info sf, si;
+        if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK || intfft_plan_get_info(plan->pair_i, &si) != INTFFT_OK) return INTFFT_ERR_INVALID;
+        info->n_passes = sf.n_passes + si.n_passes;
+        info->compute_word = std::max(sf.compute_word, si.compute_word);
+        info->fast_path = sf.fast_path && si.fast_path;
+        info->scratch_bytes = plan->scratch_bytes;
+        std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
+        return INTFFT_OK;
+    }
     if (plan->buf2d[0]) {
         intfft_plan_info si;
         int n = 0;
@@ -1077,6 +1119,16 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (plan->buf2d[0]) return exec_2d(plan, d_in, d_out, batch, stream);
+    if (plan->pair_buf) { // composite pair: forward sub-plan -> middle buffer -> inverse sub-plan, chunk by chunk
+        const size_t in_frame = ((size_t)2 << plan->L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+        for (size_t f = 0; f < batch; f += plan->pair_frames) {
+            const size_t nf = std::min(plan->pair_frames, batch - f);
+            int rc = intfft_exec(plan->pair_f, static_cast<const char *>(d_in) + f * in_frame, plan->pair_buf, nf, stream);
+            if (rc == INTFFT_OK) rc = intfft_exec(plan->pair_i, plan->pair_buf, static_cast<char *>(d_out) + f * out_frame, nf, stream);
+            if (rc != INTFFT_OK) return rc;
+        }
+        return INTFFT_OK;
+    }
     if (plan->fastsmall)
         return (int)launch_fastsmall(plan->p.log2n, plan->p.direction, plan->p.rndmode, plan->p.twdl_width, d_in, d_out,
                                      plan->h_tw.data(), batch, stream, plan->p.data_width);
@@ -1087,7 +1139,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
     if (plan->fastw64)
-        return (int)launch_fastw64(plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
+        return (int)launch_fastw64(plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
                                    d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,

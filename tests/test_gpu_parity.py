@@ -427,6 +427,55 @@ def test_wave_kernel_64_bit_results(case, monkeypatch):
     assert np.array_equal(got[:9], got_g)
 
 
+W64_INV_CASES = [(26, 16, 1, 0, True), (34, 24, 1, 0, True), (34, 24, 1, 0, False), (30, 18, 1, 0, True), (40, 16, 0, 0, True), (44, 16, 0, 1, True),
+                 (48, 24, 0, 0, True), (42, 16, 1, 0, False), (50, 10, 1, 0, True), (33, 26, 0, 1, True), (64, 16, 0, 0, True)]
+
+
+@pytest.mark.parametrize("case", W64_INV_CASES)
+def test_wave_kernel_64_bit_results_inverse(case, monkeypatch):
+    """N = 1024 int_ifftNk with results of 33 .. 64 bits (the inverse half of an unscaled pair: its DATA_WIDTH is the forward core's
+    output width, int_fft_ifft_pair.vhd:100-103): k_ifft1024_w64 against the oracle and against the generic pass kernel."""
+    dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate(C.make_params(10, dw, tw, fmt, rnd, new), C.INV) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(1024, dw), uniform_frames(37, 1024, dw, 740 + dw), uniform_frames(6, 1024, max(2, dw - 3), 741 + dw)])
+    got, info = run_gpu(x, 10, dw, tw, fmt, rnd, new, direction="INV")
+    if info["out_bits"] <= 32 or info["out_bits"] > 64:
+        pytest.skip("not a plan of the 64-bit wave kernel")
+    assert info["kernel_name"] == "k_ifft1024_w64" and info["fast_path"] == 1 and info["compute_word"] == 8, info
+    assert np.array_equal(got, run_ref(x, 10, dw, tw, fmt, rnd, new, direction="INV"))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_FASTW64", "1")
+        got_g, info_g = run_gpu(x[:9], 10, dw, tw, fmt, rnd, new, direction="INV")
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    assert np.array_equal(got[:9], got_g)
+
+
+@pytest.mark.parametrize("case", [(10, 16, 16, 1, 0, True), (10, 24, 24, 1, 0, True), (10, 22, 16, 1, 0, False), (10, 40, 16, 0, 0, True), (10, 36, 18, 0, 1, True)])
+def test_pair_of_dedicated_kernels_on_64_bit_words(case, monkeypatch):
+    """FFT -> IFFT pairs whose results need 33 .. 64 bits (16-bit unscaled: 36 bits; 24-bit unscaled: 44): a forward sub-plan, a
+    middle buffer and an inverse sub-plan, each on its dedicated kernel, against the oracle's pair and the generic pair kernel;
+    the chunk loop of the middle buffer on a small INTFFT_SCRATCH_MB."""
+    log2n, dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.PAIR) != 0:
+        pytest.skip("not elaboratable")
+    n = 1 << log2n
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(70, n, dw, 840 + dw)])
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+    assert info["kernel_name"].startswith("pair[") and info["n_passes"] == 2, info
+    assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, new, direction="PAIR"))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_PAIR_COMPOSITE", "1")
+        got_g, info_g = run_gpu(x[:9], log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    assert np.array_equal(got[:9], got_g)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_SCRATCH_MB", "1")  # 1 MiB middle buffer: 64 / 128 frames per chunk
+        got_c, info_c = run_gpu(np.concatenate([x] * 4), log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+        assert info_c["kernel_name"].startswith("pair["), info_c
+    assert np.array_equal(got_c, np.concatenate([got] * 4))
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
