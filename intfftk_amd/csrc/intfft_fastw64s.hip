@@ -1,0 +1,34 @@
+// intfft_fastw64s.hip -- the 64-bit wave kernels (intfft_w64.hpp) at N = 64 .. 512: 2^(10 - NFFT) consecutive frames share a wave.
+// 32-bit unscaled data at the reference testbenches' N = 128 (fft_signle_test.vhd:70-92: NFFT = 7; int_fft_single_path.vhd:15:
+// DATA_WIDTH 8-32) has 39-bit results.  Narrow multiplier form only (fastw64_plan_ok); its own translation unit for build time.
+#include "intfft_w64.hpp"
+
+namespace intfft {
+
+hipError_t launch_fastw64_short(int log2n, int direction, int rnd_kind, const UConsts &c, const W64Args &a, const void *in, void *out,
+                                const int2 *tw_all, size_t nframes, hipStream_t stream)
+{
+#define INTFFT_W64S(LL, R)                                                                                                               \
+    {                                                                                                                                   \
+        if (direction == 1) launch_w64_kernel(k_ifft1024_w64<LL, R, 1>, LL, c, a, in, out, tw_all, nframes, stream);                     \
+        else launch_w64_kernel(k_fft1024_w64<LL, R, 1>, LL, c, a, in, out, tw_all, nframes, stream);                                     \
+    }
+#define INTFFT_W64SL(R)                                                                                                                  \
+    {                                                                                                                                   \
+        switch (log2n) {                                                                                                                \
+        case 6: INTFFT_W64S(6, R) break;                                                                                                 \
+        case 7: INTFFT_W64S(7, R) break;                                                                                                 \
+        case 8: INTFFT_W64S(8, R) break;                                                                                                 \
+        case 9: INTFFT_W64S(9, R) break;                                                                                                 \
+        default: return hipErrorInvalidValue;                                                                                           \
+        }                                                                                                                               \
+    }
+    if (rnd_kind == RND_TRUNC) INTFFT_W64SL(RND_TRUNC)
+    else if (rnd_kind == RND_ROUND) INTFFT_W64SL(RND_ROUND)
+    else INTFFT_W64SL(RND_UNSCALED)
+#undef INTFFT_W64SL
+#undef INTFFT_W64S
+    return hipGetLastError();
+}
+
+} // namespace intfft

@@ -240,10 +240,11 @@ bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd);
 const char *big2x_kernel_name();
 hipError_t launch_big2x(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,
                         const struct Slice &sl, int halves, hipStream_t stream);
-// 64-bit wave kernels: N = 1024 forward / inverse with results of 33 .. 64 bits (intfft_fastw64.hip)
+// 64-bit wave kernels: N = 64 .. 1024 forward / inverse with results of 33 .. 64 bits (intfft_fastw64.hip)
 bool fastw64_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
 const char *fastw64_kernel_name(int direction);
-hipError_t launch_fastw64(int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
+bool fastw64_plan_ok(int log2n, const StageDesc *st10, int rnd_kind); // short frames: the narrow multiplier form only
+hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                           size_t nframes, hipStream_t stream);
 // the 2-D scheme at N = 2^20 = 1024 x 1024 in two launches (intfft_big2x.hip): column cores + multiplier, row cores + store
 int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order);

@@ -140,7 +140,7 @@ struct intfft_plan {
     intfft_plan *pair_f = nullptr, *pair_i = nullptr;
     void *pair_buf = nullptr;
     size_t pair_frames = 0;
-    bool fastw64 = false;  // N = 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
+    bool fastw64 = false;  // N = 64 .. 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
     StageDesc st64[10] = {};
     bool fast4096w = false;
     bool w32inv = false;
@@ -779,6 +779,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (st[i].s < 0 || st[i].s > 9 || st[i].wo > 64 || st[i].dtw > 64) pl->fastw64 = false;
             else pl->st64[st[i].s] = st[i];
         }
+        if (pl->fastw64 && !fastw64_plan_ok(p->log2n, pl->st64, p->format ? RND_UNSCALED : p->rndmode ? RND_ROUND : RND_TRUNC)) pl->fastw64 = false;
     }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
@@ -1139,7 +1140,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
     if (plan->fastw64)
-        return (int)launch_fastw64(plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
+        return (int)launch_fastw64(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
                                    d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,

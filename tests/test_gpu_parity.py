@@ -451,7 +451,26 @@ def test_wave_kernel_64_bit_results_inverse(case, monkeypatch):
     assert np.array_equal(got[:9], got_g)
 
 
-@pytest.mark.parametrize("case", [(10, 16, 16, 1, 0, True), (10, 24, 24, 1, 0, True), (10, 22, 16, 1, 0, False), (10, 40, 16, 0, 0, True), (10, 36, 18, 0, 1, True)])
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("case", [(6, 32, 16, 1, 0), (7, 32, 16, 1, 0), (7, 40, 24, 1, 0), (8, 32, 24, 1, 0), (9, 30, 18, 1, 0), (7, 44, 16, 0, 1), (8, 48, 24, 0, 0),
+                                  (9, 40, 16, 0, 0), (6, 50, 16, 1, 0)])
+def test_wave_kernel_64_bit_short_frames(case, direction):
+    """N = 64 .. 512 on the 64-bit wave kernels (2^(10 - NFFT) frames per wave): 32-bit unscaled data at the reference testbenches'
+    N = 128 (fft_signle_test.vhd:70-92), ragged batches (the last wave's absent frames), int32 and int64 containers."""
+    log2n, dw, tw, fmt, rnd = case
+    n = 1 << log2n
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, True), DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(77, n, dw, 940 + dw + log2n)])
+    for nb in (len(x), 1, 5):
+        got, info = run_gpu(x[:nb], log2n, dw, tw, fmt, rnd, True, direction=direction)
+        # (short frames are instantiated for the one-int64-per-product multiplier form: beyond mw + TWDL_WIDTH = 64 the generic kernel)
+        narrow = dw + ((log2n - 2 if direction == "FWD" else log2n - 1) if fmt else 0) + tw <= 64
+        assert info["kernel_name"] == (("k_ifft1024_w64" if direction == "INV" else "k_fft1024_w64") if narrow else "k_pass<long>"), info
+        assert np.array_equal(got, run_ref(x[:nb], log2n, dw, tw, fmt, rnd, True, direction=direction)), nb
+
+
+@pytest.mark.parametrize("case", [(7, 32, 16, 1, 0, True), (10, 16, 16, 1, 0, True), (10, 24, 24, 1, 0, True), (10, 22, 16, 1, 0, False), (10, 40, 16, 0, 0, True), (10, 36, 18, 0, 1, True)])
 def test_pair_of_dedicated_kernels_on_64_bit_words(case, monkeypatch):
     """FFT -> IFFT pairs whose results need 33 .. 64 bits (16-bit unscaled: 36 bits; 24-bit unscaled: 44): a forward sub-plan, a
     middle buffer and an inverse sub-plan, each on its dedicated kernel, against the oracle's pair and the generic pair kernel;
