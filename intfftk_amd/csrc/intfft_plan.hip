@@ -682,6 +682,15 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 intfft_plan_destroy(pl);
                 return (int)e;
             }
+            if (e == hipSuccess && !diag_env("INTFFT_ONE_STREAM")) {
+                e = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    intfft_plan_destroy(pl);
+                    return (int)e;
+                }
+            }
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
         }
@@ -1018,28 +1027,56 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
     hipError_t e = hipSuccess;
     int rc = INTFFT_OK;
     const bool fuse = diag_env("INTFFT_2D_NO_FUSE") == nullptr; // diagnostics: the multiplier as its own launch (k_twmul)
-    if (pl->fused2d == 3) { // column cores + multiplier on tiles, the row sub-plan, ONE layout change [rho][k2] -> X[brev10(rho) + 1024 k2]
-        for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
-            const size_t nf = std::min(pl->buf2d_frames, batch - f);
-            e = launch_fused2d_cols(l2, p.twdl_width, reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame),
-                                    static_cast<uint32_t *>(pl->buf2d[0]), pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
-                                    p.in_order == INTFFT_ORDER_HALVES, stream);
+    if (pl->fused2d) {
+        // Two launches (N2 = 1024: column cores + multiplier, row cores + store, one layout buffer as the scratch) or three (N2 > 1024: the
+        // column cores + multiplier on tiles, the row sub-plan, ONE layout change [rho][k2] -> X[brev10(rho) + 1024 k2]) per chunk.  The
+        // chunks of a batch alternate between the caller's stream and the plan's side stream, each on its own half of the layout
+        // buffers (section 4.2d: the strided column pass of one chunk beside the streaming launches of the other); under stream capture, and
+        // when the row sub-plan owns a scratch of its own, everything stays on the caller's stream.
+        const size_t half = pl->buf2d_frames / 2;
+        bool dual = pl->side_stream && half >= 1 && batch > half && (pl->fused2d == 2 || pl->sub_row_f->scratch_bytes == 0);
+        if (dual) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dual = false;
+        }
+        const size_t chunk = dual ? half : pl->buf2d_frames;
+        if (dual) {
+            e = hipEventRecord(pl->ev_fork, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0);
+            if (e != hipSuccess) return (int)e;
+        }
+        struct Join { // joins on every exit path
+            intfft_plan *p;
+            hipStream_t s;
+            bool on;
+            ~Join()
+            {
+                if (on && hipEventRecord(p->ev_join, p->side_stream) == hipSuccess) (void)hipStreamWaitEvent(s, p->ev_join, 0);
+            }
+        } join{pl, stream, dual};
+        size_t ci = 0;
+        for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += chunk, ++ci) {
+            const size_t nf = std::min(chunk, batch - f);
+            const bool odd = dual && (ci & 1);
+            hipStream_t st = odd ? pl->side_stream : stream;
+            const size_t off = odd ? half * out_frame : 0; // (layout buffers are sized in frames of the output container)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame);
+            char *dst = static_cast<char *>(d_out) + f * out_frame;
+            uint32_t *b0 = reinterpret_cast<uint32_t *>(static_cast<char *>(pl->buf2d[0]) + off);
+            if (pl->fused2d == 2) {
+                e = launch_fused2d(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
+                                   p.in_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            char *b1 = static_cast<char *>(pl->buf2d[1]) + off;
+            e = launch_fused2d_cols(l2, p.twdl_width, src, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
             if (e != hipSuccess) break;
-            if ((rc = intfft_exec(pl->sub_row_f, pl->buf2d[0], pl->buf2d[1], nf << l1, stream)) != INTFFT_OK) break;
+            if ((rc = intfft_exec(pl->sub_row_f, b0, b1, nf << l1, st)) != INTFFT_OK) break;
             // logical k = k1 + N1 k2 sits at [rho = brev(k1)][k2]: k bit j < l1 at in bit l2 + (l1 - 1 - j), else at j - l1
             for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + (l1 - 1 - j) : j - l1;
-            e = launch_bitperm(L, pl->sub_row_f->out_cb, perm, pl->buf2d[1], static_cast<char *>(d_out) + f * out_frame, nf, stream);
+            e = launch_bitperm(L, pl->sub_row_f->out_cb, perm, b1, dst, nf, st);
         }
         if (rc != INTFFT_OK) return rc;
-        return (int)e;
-    }
-    if (pl->fused2d) { // column cores + multiplier, row cores + store: two launches per chunk, one layout buffer as the scratch
-        for (size_t f = 0; f < batch && e == hipSuccess; f += pl->buf2d_frames) {
-            const size_t nf = std::min(pl->buf2d_frames, batch - f);
-            e = launch_fused2d(p.twdl_width, reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame),
-                               reinterpret_cast<uint32_t *>(static_cast<char *>(d_out) + f * out_frame), static_cast<uint32_t *>(pl->buf2d[0]),
-                               pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, stream);
-        }
         return (int)e;
     }
     for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {

@@ -83,7 +83,7 @@ def test_2d_n2pow20_two_launches(frames, monkeypatch):
     """N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward: k_big2x_c (column cores on XCD-paired half-line tiles + the
     inter-core multiplier) + k_big2x_b (row cores + store) against the oracle and against the five-launch composite plan
     (INTFFT_2D_NO_FUSED_CORES); full-scale frames (exact extraction in their tiles), HALVES order in, 13-bit twiddles, a batch
-    beyond one scratch chunk."""
+    beyond one scratch chunk (two streams against one)."""
     n = 1 << 20
     x = uniform_frames(frames, n, 15, 777 + frames)
     x[0] = uniform_frames(1, n, 16, 5)[0]
@@ -101,9 +101,13 @@ def test_2d_n2pow20_two_launches(frames, monkeypatch):
     else:  # chunk loop (64 frames per 256 MiB layout buffer): frames 0, 63, 64, 69 against the oracle
         got, info = run_gpu(x, 20, 10, 16, 16, 0, 0, True)
         assert info["n_passes"] == 2
-        sel = [0, 63, 64, 69]
+        sel = [0, 31, 32, 63, 64, 69]
         want = C.execute_2d(x[sel], C.make_params(20, 16, 16, 0, 0, True), 10, C.FWD, C.NATURAL, C.NATURAL, form=1)
         assert np.array_equal(got[sel], want)
+        with monkeypatch.context() as m:  # the chunks alternate between two streams (32-frame halves); one stream: 64-frame chunks
+            m.setenv("INTFFT_ONE_STREAM", "1")
+            got1, _ = run_gpu(x, 20, 10, 16, 16, 0, 0, True)
+        assert np.array_equal(got, got1)
 
 
 @pytest.mark.parametrize("case", [(13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (16, 8, 16, 16, 0, 1, True),
