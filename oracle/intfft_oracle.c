@@ -613,6 +613,25 @@ static int exec_frame(const orc_params *p, const tw_set *tw, int direction, int 
     return 0;
 }
 
+/* threads <= 0: sized to the work (about 2^21 stage-samples per thread, never more threads than frames) -- a team of every host
+ * thread for a handful of short frames costs ~0.15 s per call on a 256-thread box (spin-up / spin-down beside torch's own pool),
+ * which was 85 % of the GPU parity suite's run time.  An explicit count (bench.py's cpu_baseline) is taken as given. */
+static int pick_threads(int threads, size_t batch, size_t n, int log2n)
+{
+#ifdef _OPENMP
+    const int mx = omp_get_max_threads();
+    if (threads <= 0) {
+        const size_t want = (batch * n * (size_t)log2n) >> 21;
+        threads = want < 1 ? 1 : want > (size_t)mx ? mx : (int)want;
+    }
+    if ((size_t)threads > batch) threads = (int)(batch ? batch : 1);
+    return threads;
+#else
+    (void)batch; (void)n; (void)log2n;
+    return threads > 0 ? threads : 1;
+#endif
+}
+
 int orc_exec(const orc_params *p, int direction, int in_order, int out_order, const int64_t *in,
              int64_t *out, size_t batch, int form, int threads)
 {
@@ -622,7 +641,7 @@ int orc_exec(const orc_params *p, int direction, int in_order, int out_order, co
     if (tw_build(&tw, p->log2n, p->twdl_width, p->xser)) { tw_free(&tw); return -2; }
     int err = 0;
 #ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
+    threads = pick_threads(threads, batch, n, p->log2n);
 #pragma omp parallel num_threads(threads)
 #endif
     {
@@ -654,7 +673,7 @@ int orc_exec_i16(const orc_params *p, int direction, int in_order, int out_order
     if (tw_build(&tw, p->log2n, p->twdl_width, p->xser)) { tw_free(&tw); return -2; }
     int err = 0;
 #ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
+    threads = pick_threads(threads, batch, n, p->log2n);
 #pragma omp parallel num_threads(threads)
 #endif
     {
@@ -1002,8 +1021,7 @@ int orc_exec_2d(const orc_params *p, int log2_n1, int direction, int in_order, i
     if (tw2d_build(&t, p, log2_n1)) { tw2d_free(&t); return -2; }
     int err = 0;
 #ifdef _OPENMP
-    if (threads <= 0) threads = omp_get_max_threads();
-    if ((size_t)threads > batch) threads = (int)(batch ? batch : 1);
+    threads = pick_threads(threads, batch, n, p->log2n);
 #pragma omp parallel num_threads(threads)
 #endif
     {
