@@ -27,6 +27,33 @@ int fastw64_multiplier_form(int log2n, const StageDesc *st10, int rnd_kind)
 // to 64 - TWDL_WIDTH bits); the planner sends the other short-frame plans to the generic kernel
 bool fastw64_plan_ok(int log2n, const StageDesc *st10, int rnd_kind) { return log2n == 10 || fastw64_multiplier_form(log2n, st10, rnd_kind) == 1; }
 
+// N = 2048 / 4096: the block kernels (intfft_fastw64b.hip / intfft_fastw64bi.hip)
+bool fastw64b_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
+{
+    const int out_bits = data_width + format * log2n;
+    return (log2n == 11 || log2n == 12) && out_bits > 32 && out_bits <= 64 && data_width >= 2 && data_width <= 64 && (direction == 0 || direction == 1) &&
+           use_fly == 1 && in_order == 0 && out_order == 0 && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64");
+}
+bool fastw64b_plan_ok(int log2n, const StageDesc *st12, int rnd_kind)
+{
+    const int cm = fastw64_multiplier_form(log2n, st12, rnd_kind);
+    return cm == 1 || cm == 3; // (form 3 is never chosen in round mode)
+}
+const char *fastw64b_kernel_name(int direction) { return direction == 1 ? "k_ifft4096_w64" : "k_fft4096_w64"; }
+
+hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDesc *st12, int in_cb, int dw, const void *in, void *out, const int2 *tw_all,
+                           const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    UConsts c;
+    for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
+    for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
+    W64BArgs a;
+    for (int s = 0; s < 12; ++s) a.st[s] = st12[s];
+    a.in_cb = in_cb, a.dw = dw;
+    return launch_fastw64_block(log2n, direction, rnd_kind, fastw64_multiplier_form(log2n, st12, rnd_kind), c, a, in, out, tw_all, nframes, stream);
+}
+
 const char *fastw64_kernel_name(int direction) { return direction == 1 ? "k_ifft1024_w64" : "k_fft1024_w64"; }
 
 hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,

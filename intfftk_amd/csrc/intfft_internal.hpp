@@ -244,6 +244,12 @@ hipError_t launch_big2x(int log2n, bool fx, const uint32_t *pin, uint32_t *pout,
 bool fastw64_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
 const char *fastw64_kernel_name(int direction);
 bool fastw64_plan_ok(int log2n, const StageDesc *st10, int rnd_kind); // short frames: the narrow multiplier form only
+// ... and N = 2048 / 4096 on the block kernels (intfft_fastw64b.hip, intfft_fastw64bi.hip)
+bool fastw64b_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
+bool fastw64b_plan_ok(int log2n, const StageDesc *st12, int rnd_kind);
+const char *fastw64b_kernel_name(int direction);
+hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDesc *st12, int in_cb, int dw, const void *in, void *out, const int2 *tw_all,
+                           const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                           size_t nframes, hipStream_t stream);
 // the 2-D scheme at N = 2^20 = 1024 x 1024 in two launches (intfft_big2x.hip): column cores + multiplier, row cores + store

@@ -141,7 +141,8 @@ struct intfft_plan {
     void *pair_buf = nullptr;
     size_t pair_frames = 0;
     bool fastw64 = false;  // N = 64 .. 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
-    StageDesc st64[10] = {};
+    StageDesc st64[12] = {};
+    bool fastw64b = false; // N = 2048 / 4096 forward / inverse, results of 33 .. 64 bits beyond k_fft4096_w32's 64-bit last round
     bool fast4096w = false;
     bool w32inv = false;
     bool bigw = false;
@@ -790,8 +791,21 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (pl->fastw64 && !fastw64_plan_ok(p->log2n, pl->st64, p->format ? RND_UNSCALED : p->rndmode ? RND_ROUND : RND_TRUNC)) pl->fastw64 = false;
     }
+    pl->fastw64b = !generic_only && !pl->fast4096w && !pl->w32inv && !pl->fast4096 && pl->word == 8 && pl->in_cb >= 4 && pl->out_cb == 8 &&
+                   fastw64b_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
+    if (pl->fastw64b) {
+        std::vector<StageDesc> st;
+        if (core_stages(*p, p->data_width, p->direction == INTFFT_INV, st) != INTFFT_OK || (int)st.size() != p->log2n) pl->fastw64b = false;
+        for (size_t i = 0; i < st.size() && pl->fastw64b; ++i) {
+            if (st[i].s < 0 || st[i].s > 11 || st[i].wo > 64 || st[i].dtw > 64) pl->fastw64b = false;
+            else pl->st64[st[i].s] = st[i];
+        }
+        if (pl->fastw64b && !fastw64b_plan_ok(p->log2n, pl->st64, p->format ? RND_UNSCALED : p->rndmode ? RND_ROUND : RND_TRUNC)) pl->fastw64b = false;
+    }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
+    } else if (pl->fastw64b) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64b_kernel_name(p->direction));
     } else if (pl->fastw64) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64_kernel_name(p->direction));
     } else if (pl->w32inv) {
@@ -975,7 +989,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
     if (plan->pair_buf) {
         intfft_plan_info sf, si;
         if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK || intfft_plan_get_info(plan->pair_i, &si) != INTFFT_OK) return INTFFT_ERR_INVALID;
@@ -1005,7 +1019,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         return INTFFT_OK;
     }
     info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
-    info->compute_word = plan->fastw64 ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
+    info->compute_word = (plan->fastw64 || plan->fastw64b) ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->scratch_bytes;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
@@ -1176,6 +1190,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     if (plan->fast4096w)
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);
+    if (plan->fastw64b)
+        return (int)launch_fastw64b(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb,
+                                    plan->p.data_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw64)
         return (int)launch_fastw64(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
                                    d_out, plan->d_tw, plan->h_tw.data(), batch, stream);

@@ -467,6 +467,335 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
     }
 }
 
+// ---- block kernels, N = 2048 / 4096 (intfft_fastw64b.hip) ------------------------------------------------------------------------
+// Workgroup mapping of intfft_fast4096w.hip / intfft_w32inv.hip: 256 threads own 4096 consecutive samples (one frame, or two 2048-point
+// frames whose frame-number stage is skipped), 16 samples per thread as 64-bit register pairs, three register rounds of four stages
+//   LA  reg = n11..8, thread = n7..0            STAGE 11..8
+//   LB  reg = n7..4,  thread = (n11..8, n3..0)  STAGE 7..4
+//   LC  reg = n3..0,  thread = lc64_bit<L>()    STAGE 3..0, the bit reversal folded into the mapping
+// with block-wide LDS transposes: one component (re, then im) at a time through two dword planes (lo, hi) of one 40 KiB region --
+// four planes at once would be 80 KiB per workgroup, all of a CU's LDS for the two workgroups the 256-VGPR budget allows.
+// The 30 thread-dependent twiddle pairs are frame invariant and live in VGPRs.
+struct W64BArgs {
+    StageDesc st[12]; // indexed by the STAGE generic
+    int in_cb;        // input container bytes per component: 4 or 8
+    int dw;           // DATA_WIDTH
+};
+
+constexpr int ROW64B = 20;
+constexpr int PLANE64B = 256 * ROW64B;
+template <int L> __host__ __device__ constexpr int lc64_bit(int k) { return k < L ? (L - 1) - k : (L - 4) + (k - L); }
+template <int L> __host__ __device__ constexpr int lc64_row_of_reg(int j)
+{
+    return (((j >> 0) & 1) << lc64_bit<L>(4)) | (((j >> 1) & 1) << lc64_bit<L>(5)) | (((j >> 2) & 1) << lc64_bit<L>(6)) |
+           (((j >> 3) & 1) << lc64_bit<L>(7));
+}
+__device__ __forceinline__ constexpr int rev4b(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// one register round of the forward core: stages S0 + 3 .. S0 on register offsets 8, 4, 2, 1 (only those below L)
+template <int RNDC, int CM, int L, int S0>
+__device__ __forceinline__ void round64_dif(i64 (&re)[16], i64 (&im)[16], const int (&w8r)[8], const int (&w8i)[8], const int (&w4r)[4],
+                                            const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2], int w1r, int w1i, const W64BArgs &a)
+{
+    if constexpr (S0 + 3 < L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fly64<RNDC, 2, CM>(a.st[S0 + 3], 0, re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j]);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fly64<RNDC, 2, CM>(a.st[S0 + 2], 0, re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fly64<RNDC, 2, CM>(a.st[S0 + 1], 0, re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) fly64<RNDC, 2, CM>(a.st[S0], 0, re[g], im[g], re[g + 1], im[g + 1], w1r, w1i);
+}
+// ... and of the inverse core: stages S0 .. S0 + 3 on register offsets 1, 2, 4, 8
+template <int RNDC, int CM, int L, int S0>
+__device__ __forceinline__ void round64_dit(i64 (&re)[16], i64 (&im)[16], const int (&w8r)[8], const int (&w8i)[8], const int (&w4r)[4],
+                                            const int (&w4i)[4], const int (&w2r)[2], const int (&w2i)[2], int w1r, int w1i, const W64BArgs &a)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) fly64<RNDC, 2, CM, true>(a.st[S0], 0, re[g], im[g], re[g + 1], im[g + 1], w1r, w1i);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fly64<RNDC, 2, CM, true>(a.st[S0 + 1], 0, re[g + j], im[g + j], re[g + j + 2], im[g + j + 2], w2r[j], w2i[j]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fly64<RNDC, 2, CM, true>(a.st[S0 + 2], 0, re[g + j], im[g + j], re[g + j + 4], im[g + j + 4], w4r[j], w4i[j]);
+    if constexpr (S0 + 3 < L) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fly64<RNDC, 2, CM, true>(a.st[S0 + 3], 0, re[j], im[j], re[j + 8], im[j + 8], w8r[j], w8i[j]);
+    }
+}
+
+// the thread-dependent twiddles of rounds LA (thread = n7..0: STAGE 11 index 256 jj + tid .. STAGE 8 index tid) and LB (thread low
+// nibble = n3..0: STAGE 7 index 16 jj + lo4 .. STAGE 4 index lo4)
+struct Tw64B {
+    int a8r[8], a8i[8], a4r[4], a4i[4], a2r[2], a2i[2], a1r, a1i;
+    int b8r[8], b8i[8], b4r[4], b4i[4], b2r[2], b2i[2], b1r, b1i;
+};
+template <int L> __device__ __forceinline__ void load_tw64_la(Tw64B &t, const int2 *__restrict__ twt, int tid)
+{
+    int2 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.a8r[j] = t.a8i[j] = 0;
+    if constexpr (L >= 12) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w = twt[2047 + 256 * j + tid], t.a8r[j] = w.x, t.a8i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w = twt[1023 + 256 * j + tid], t.a4r[j] = w.x, t.a4i[j] = w.y;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w = twt[511 + 256 * j + tid], t.a2r[j] = w.x, t.a2i[j] = w.y;
+    w = twt[255 + tid], t.a1r = w.x, t.a1i = w.y;
+}
+__device__ __forceinline__ void load_tw64_lb(Tw64B &t, const int2 *__restrict__ twt, int lo4)
+{
+    int2 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w = twt[127 + 16 * j + lo4], t.b8r[j] = w.x, t.b8i[j] = w.y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w = twt[63 + 16 * j + lo4], t.b4r[j] = w.x, t.b4i[j] = w.y;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w = twt[31 + 16 * j + lo4], t.b2r[j] = w.x, t.b2i[j] = w.y;
+    w = twt[15 + lo4], t.b1r = w.x, t.b1i = w.y;
+}
+// round LA's 15 pairs stay in registers over the frame loop where the butterflies leave room (narrow products, truncate / unscaled);
+// the three-dword and round-mode bodies re-read them per frame from the L2-resident table instead (they spill 50-320 dwords otherwise)
+template <int RNDC, int CM> constexpr bool keep_la64() { return CM == 1 && RNDC != RND_ROUND; }
+template <int RNDC, int CM> constexpr bool keep_lb64() { return CM == 1; } // (three-dword products: round LB's 15 pairs too)
+
+// block-wide transpose of one 64-bit component: register j of every thread goes to wbase[woff(j)] (lo plane; hi plane PLANE64B above),
+// thread t then reads row t (16 consecutive values)
+template <typename OFF>
+__device__ __forceinline__ void xpose64(i64 (&v)[16], u32 *lds, u32 *wbase, OFF woff, int tid)
+{
+    __syncthreads(); // the previous reads of the region are done
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        wbase[woff(j)] = (u32)v[j];
+        wbase[PLANE64B + woff(j)] = (u32)((unsigned long long)v[j] >> 32);
+    }
+    __syncthreads();
+    const uint4 *rd = reinterpret_cast<const uint4 *>(lds + ROW64B * tid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 x = rd[q], h = rd[q + PLANE64B / 4];
+        const u32 xl[4] = {x.x, x.y, x.z, x.w}, xh[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * q + i] = (i64)(((unsigned long long)xh[i] << 32) | xl[i]);
+    }
+}
+
+template <int L, int RNDC, int CM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft4096_w64(const void *in, i64 *out, const int2 *__restrict__ twt,
+                                                                                                 const UConsts c, const W64BArgs a, size_t nframes_user)
+{
+    static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
+    constexpr int FP = 1 << (12 - L);
+    const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 4096 samples
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANE64B];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    Tw64B t;
+    if constexpr (keep_lb64<RNDC, CM>()) load_tw64_lb(t, twt, lo4);
+    if constexpr (keep_la64<RNDC, CM>()) load_tw64_la<L>(t, twt, tid);
+    // LA -> LB: element (thread x, reg y) -> row 16 y + x3..0, column x7..4
+    u32 *const w_ab = lds + ROW64B * lo4 + hi4;
+    // LB -> LC: thread (hi4 = n11..8, lo4 = n3..0), reg j' = n7..4 -> row = LC thread (lc64_bit<L>), column n3..0
+    const int row_hi = ((hi4 & 1) << lc64_bit<L>(8)) | (((hi4 >> 1) & 1) << lc64_bit<L>(9)) | (((hi4 >> 2) & 1) << lc64_bit<L>(10)) |
+                       (((hi4 >> 3) & 1) << lc64_bit<L>(11));
+    u32 *const w_bc = lds + ROW64B * row_hi + lo4;
+    int lc_off = 0, lc_frame = 0; // LC <-> natural-order X: index = rev4(r) * 2^(L-4) + lc_off
+#pragma unroll
+    for (int k = 4; k < 12; ++k) {
+        const int bit = (tid >> lc64_bit<L>(k)) & 1;
+        lc_off += bit * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
+        if (k >= L) lc_frame += bit << (k - L);
+    }
+    auto off_ab = [](int j) { return ROW64B * 16 * j; };
+    auto off_bc = [](int j) { return ROW64B * lc64_row_of_reg<L>(j); };
+
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
+        i64 re[16], im[16];
+        if (a.in_cb == 4) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = static_cast<const v2i *>(in) + f * 4096 + tid;
+            const int sh = 32 - a.dw;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v2i x = {0, 0};
+                if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user) x = INTFFT_LD(src + 256 * j);
+                re[j] = (int)((u32)x.x << sh) >> sh;
+                im[j] = (int)((u32)x.y << sh) >> sh;
+            }
+        } else {
+            typedef i64 v2l __attribute__((ext_vector_type(2)));
+            const v2l *src = static_cast<const v2l *>(in) + f * 4096 + tid;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v2l x = {0, 0};
+                if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user) x = INTFFT_LD(src + 256 * j);
+                re[j] = wrapw<int64_t>((int64_t)x.x, a.dw);
+                im[j] = wrapw<int64_t>((int64_t)x.y, a.dw);
+            }
+        }
+        if constexpr (!keep_la64<RNDC, CM>()) {
+            const int2 *tp = twt;
+            asm volatile("" : "+s"(tp)); // (opaque: the loads stay inside the frame loop)
+            load_tw64_la<L>(t, tp, tid);
+        }
+        round64_dif<RNDC, CM, L, 8>(re, im, t.a8r, t.a8i, t.a4r, t.a4i, t.a2r, t.a2i, t.a1r, t.a1i, a);
+        xpose64(re, lds, w_ab, off_ab, tid);
+        xpose64(im, lds, w_ab, off_ab, tid);
+        if constexpr (!keep_lb64<RNDC, CM>()) {
+            const int2 *tp = twt;
+            asm volatile("" : "+s"(tp));
+            load_tw64_lb(t, tp, lo4);
+        }
+        round64_dif<RNDC, CM, 12, 4>(re, im, t.b8r, t.b8i, t.b4r, t.b4i, t.b2r, t.b2i, t.b1r, t.b1i, a);
+        xpose64(re, lds, w_bc, off_bc, tid);
+        xpose64(im, lds, w_bc, off_bc, tid);
+        // LC: stages 3, 2 (wave-uniform twiddles), 1, 0 (multiplier-free)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) fly64<RNDC, 2, CM>(a.st[3], 0, re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fly64<RNDC, 2, CM>(a.st[2], 0, re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r]);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            fly64<RNDC, 1, CM>(a.st[1], 0, re[g], im[g], re[g + 2], im[g + 2], 0, 0);
+            fly64<RNDC, 1, CM>(a.st[1], 1, re[g + 1], im[g + 1], re[g + 3], im[g + 3], 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) fly64<RNDC, 1, CM>(a.st[0], 0, re[g], im[g], re[g + 1], im[g + 1], 0, 0);
+        if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+            typedef i64 v2l __attribute__((ext_vector_type(2)));
+            v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const v2l y = {re[r], im[r]};
+                __builtin_nontemporal_store(y, dst + (rev4b(r) << (L - 4)));
+            }
+        }
+    }
+}
+
+template <int L, int RNDC, int CM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ifft4096_w64(const void *in, i64 *out, const int2 *__restrict__ twt,
+                                                                                                  const UConsts c, const W64BArgs a, size_t nframes_user)
+{
+    static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
+    constexpr int FP = 1 << (12 - L);
+    const size_t nframes = (nframes_user + FP - 1) / FP;
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANE64B];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    Tw64B t;
+    if constexpr (keep_lb64<RNDC, CM>()) load_tw64_lb(t, twt, lo4);
+    if constexpr (keep_la64<RNDC, CM>()) load_tw64_la<L>(t, twt, tid);
+    // LC thread carries n_k on bit lc64_bit<L>(k); LC -> LB: row = LB thread 16 (n11..8) + r, column = n7..4
+    auto nb = [&](int k) { return (tid >> lc64_bit<L>(k)) & 1; };
+    const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
+    u32 *const w_cb = lds + ROW64B * 16 * lb_hi + lb_reg;
+    // LB -> LA: element (thread (n11..8 = hi4, n3..0 = lo4), reg n7..4) -> row n7..0 = 16 j' + lo4, column n11..8 = hi4
+    u32 *const w_ba = lds + ROW64B * lo4 + hi4;
+    int lc_off = 0, lc_frame = 0;
+#pragma unroll
+    for (int k = 4; k < 12; ++k) {
+        lc_off += nb(k) * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
+        if (k >= L) lc_frame += nb(k) << (k - L);
+    }
+    auto off_cb = [](int r) { return ROW64B * r; };
+    auto off_ba = [](int j) { return ROW64B * 16 * j; };
+
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const bool partial = L < 12 && (f + 1) * FP > nframes_user;
+        const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
+        i64 re[16], im[16];
+        // LC: X[brev_L(n)] of the thread's frame
+        if (a.in_cb == 4) {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = static_cast<const v2i *>(in) + f * 4096 + lc_off;
+            const int sh = 32 - a.dw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v2i x = {0, 0};
+                if (lc_ok) x = INTFFT_LD(src + (rev4b(r) << (L - 4)));
+                re[r] = (int)((u32)x.x << sh) >> sh;
+                im[r] = (int)((u32)x.y << sh) >> sh;
+            }
+        } else {
+            typedef i64 v2l __attribute__((ext_vector_type(2)));
+            const v2l *src = static_cast<const v2l *>(in) + f * 4096 + lc_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v2l x = {0, 0};
+                if (lc_ok) x = INTFFT_LD(src + (rev4b(r) << (L - 4)));
+                re[r] = wrapw<int64_t>((int64_t)x.x, a.dw);
+                im[r] = wrapw<int64_t>((int64_t)x.y, a.dw);
+            }
+        }
+        // DIT 0, 1 (multiplier-free), 2, 3 (wave-uniform twiddles) on register offsets 1, 2, 4, 8
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) fly64<RNDC, 1, CM, true>(a.st[0], 0, re[g], im[g], re[g + 1], im[g + 1], 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            fly64<RNDC, 1, CM, true>(a.st[1], 0, re[g], im[g], re[g + 2], im[g + 2], 0, 0);
+            fly64<RNDC, 1, CM, true>(a.st[1], 1, re[g + 1], im[g + 1], re[g + 3], im[g + 3], 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 8)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fly64<RNDC, 2, CM, true>(a.st[2], 0, re[g + r], im[g + r], re[g + r + 4], im[g + r + 4], c.wr2[r], c.wi2[r]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) fly64<RNDC, 2, CM, true>(a.st[3], 0, re[r], im[r], re[r + 8], im[r + 8], c.wr3[r], c.wi3[r]);
+        xpose64(re, lds, w_cb, off_cb, tid); // LB: regs = n7..4
+        xpose64(im, lds, w_cb, off_cb, tid);
+        if constexpr (!keep_lb64<RNDC, CM>()) {
+            const int2 *tp = twt;
+            asm volatile("" : "+s"(tp));
+            load_tw64_lb(t, tp, lo4);
+        }
+        round64_dit<RNDC, CM, 12, 4>(re, im, t.b8r, t.b8i, t.b4r, t.b4i, t.b2r, t.b2i, t.b1r, t.b1i, a);
+        xpose64(re, lds, w_ba, off_ba, tid); // LA: regs = n11..8, thread = n7..0
+        xpose64(im, lds, w_ba, off_ba, tid);
+        if constexpr (!keep_la64<RNDC, CM>()) {
+            const int2 *tp = twt;
+            asm volatile("" : "+s"(tp));
+            load_tw64_la<L>(t, tp, tid);
+        }
+        round64_dit<RNDC, CM, L, 8>(re, im, t.a8r, t.a8i, t.a4r, t.a4i, t.a2r, t.a2i, t.a1r, t.a1i, a);
+        typedef i64 v2l __attribute__((ext_vector_type(2)));
+        v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + tid;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user) {
+                const v2l y = {re[j], im[j]};
+                __builtin_nontemporal_store(y, dst + 256 * j);
+            }
+    }
+}
+
+template <typename K>
+inline void launch_w64b_kernel(K kernel, int log2n, const UConsts &c, const W64BArgs &a, const void *in, void *out, const int2 *tw_all, size_t nframes,
+                               hipStream_t stream)
+{
+    const size_t chunks = (nframes + ((size_t)1 << (12 - log2n)) - 1) >> (12 - log2n); // one workgroup per 4096 samples
+    const size_t cap = resident_blocks(kptr(kernel), 256, 2, 2, false);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, static_cast<i64 *>(out), tw_all, c, a, nframes);
+}
+
+hipError_t launch_fastw64_block(int log2n, int direction, int rnd_kind, int cm, const UConsts &c, const W64BArgs &a, const void *in, void *out,
+                                const int2 *tw_all, size_t nframes, hipStream_t stream);
+hipError_t launch_fastw64_block_inv(int log2n, int rnd_kind, int cm, const UConsts &c, const W64BArgs &a, const void *in, void *out,
+                                    const int2 *tw_all, size_t nframes, hipStream_t stream);
+
 template <typename K>
 inline void launch_w64_kernel(K kernel, int log2n, const UConsts &c, const W64Args &a, const void *in, void *out, const int2 *tw_all, size_t nframes,
                               hipStream_t stream)

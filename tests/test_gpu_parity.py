@@ -470,7 +470,43 @@ def test_wave_kernel_64_bit_short_frames(case, direction):
         assert np.array_equal(got, run_ref(x[:nb], log2n, dw, tw, fmt, rnd, True, direction=direction)), nb
 
 
-@pytest.mark.parametrize("case", [(7, 32, 16, 1, 0, True), (10, 16, 16, 1, 0, True), (10, 24, 24, 1, 0, True), (10, 22, 16, 1, 0, False), (10, 40, 16, 0, 0, True), (10, 36, 18, 0, 1, True)])
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("case", [(11, 32, 16, 1, 0, True), (12, 32, 16, 1, 0, True), (12, 32, 24, 1, 0, False), (11, 30, 18, 1, 0, True), (12, 40, 16, 0, 0, True),
+                                  (11, 44, 16, 0, 1, True), (12, 48, 24, 0, 0, True), (12, 36, 24, 1, 0, True), (11, 50, 10, 1, 0, True), (12, 33, 26, 0, 1, True),
+                                  (12, 64, 16, 0, 0, True), (12, 28, 16, 1, 0, True), (11, 26, 24, 1, 0, False)])
+def test_block_kernel_64_bit_results(case, direction, monkeypatch):
+    """N = 2048 / 4096 with results of 33 .. 64 bits on the 64-bit block kernels k_fft4096_w64 / k_ifft4096_w64 (32-bit unscaled data:
+    43 / 44-bit results; the inverse half of unscaled pairs; wide scaled data; narrow and three-dword products): against the oracle and
+    the generic pass kernel, ragged batches (N = 2048: two frames per workgroup), int32 and int64 containers.  Plans the partly-32-bit
+    block kernel k_fft4096_w32 serves (24-bit unscaled forward) keep it; round mode beyond mw + t = 64 stays generic."""
+    log2n, dw, tw, fmt, rnd, new = case
+    n = 1 << log2n
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(21, n, dw, 1040 + dw + log2n), uniform_frames(4, n, max(2, dw - 3), 1041 + dw)])
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=direction)
+    if info["out_bits"] <= 32 or info["out_bits"] > 64:
+        pytest.skip("not a 64-bit-word plan")
+    mw_max = dw + ((log2n - 2 if direction == "FWD" else log2n - 1) if fmt else 0)
+    if info["kernel_name"] == "k_fft4096_w32":
+        assert direction == "FWD" and fmt == 1 and dw + log2n <= 40, info
+    elif (rnd == 1 or mw_max > 63) and mw_max + tw > 64:  # neither the narrow nor the three-dword multiplier form
+        assert info["kernel_name"] == "k_pass<long>", info
+    else:
+        assert info["kernel_name"] == ("k_ifft4096_w64" if direction == "INV" else "k_fft4096_w64") and info["fast_path"] == 1 and info["compute_word"] == 8, info
+    assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, new, direction=direction))
+    for nb in (1, 2, 3):
+        g, _ = run_gpu(x[:nb], log2n, dw, tw, fmt, rnd, new, direction=direction)
+        assert np.array_equal(g, got[:nb]), nb
+    if info["kernel_name"].endswith("4096_w64"):
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_FASTW64", "1")
+            got_g, info_g = run_gpu(x[:5], log2n, dw, tw, fmt, rnd, new, direction=direction)
+            assert info_g["kernel_name"].startswith("k_pass"), info_g
+        assert np.array_equal(got[:5], got_g)
+
+
+@pytest.mark.parametrize("case", [(7, 32, 16, 1, 0, True), (12, 16, 16, 1, 0, True), (11, 24, 16, 1, 0, True), (10, 16, 16, 1, 0, True), (10, 24, 24, 1, 0, True), (10, 22, 16, 1, 0, False), (10, 40, 16, 0, 0, True), (10, 36, 18, 0, 1, True)])
 def test_pair_of_dedicated_kernels_on_64_bit_words(case, monkeypatch):
     """FFT -> IFFT pairs whose results need 33 .. 64 bits (16-bit unscaled: 36 bits; 24-bit unscaled: 44): a forward sub-plan, a
     middle buffer and an inverse sub-plan, each on its dedicated kernel, against the oracle's pair and the generic pair kernel;
