@@ -936,7 +936,7 @@ def test_unscaled_results_of_35_and_36_bits(case, monkeypatch):
     """24-bit unscaled data at N = 2048 / 4096 (the lengths below BASELINE config 3's): STAGE 4 still fits 32 bits, the whole
     last register round of k_fft4096_w32 (STAGE 3, 2 with their multipliers, then 1, 0) runs in 64 bits (gfly64); every
     multiplier regime the widths reach, both XSER, odd batches incl. the two-frames-per-block form at N = 2048; and equal to
-    the generic kernel it replaces."""
+    the all-64-bit block kernel (INTFFT_NO_FASTW32) and the generic kernel (+ INTFFT_NO_FASTW64) on the same plan."""
     log2n, dw, tw = case
     n = 1 << log2n
     for new in (True, False):
@@ -948,9 +948,12 @@ def test_unscaled_results_of_35_and_36_bits(case, monkeypatch):
         assert info["out_bits"] == dw + log2n and 35 <= info["out_bits"] <= 36
     x = uniform_frames(5, n, dw, 99)
     a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
-    monkeypatch.setenv("INTFFT_NO_FASTW32", "1")
+    monkeypatch.setenv("INTFFT_NO_FASTW32", "1")  # ... then the all-64-bit block kernel serves the plan,
     b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
-    assert ib["kernel_name"] == "k_pass<long>" and np.array_equal(a, b)
+    assert ib["kernel_name"] == "k_fft4096_w64" and np.array_equal(a, b), ib
+    monkeypatch.setenv("INTFFT_NO_FASTW64", "1")  # ... then the generic one
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    assert ib["kernel_name"] == "k_pass<long>" and np.array_equal(a, b), ib
 
 
 @pytest.mark.parametrize("log2n,dw,tw,batch", [(13, 24, 24, 9), (13, 24, 16, 8), (14, 24, 24, 5), (14, 24, 18, 4), (15, 24, 24, 3), (15, 24, 16, 1),
