@@ -1,5 +1,6 @@
-// intfft_w64.hpp -- the 64-bit wave kernels as templates (intfft_fastw64.hip: N = 1024 and the launcher; intfft_fastw64s.hip: N = 64 .. 512)
-// 64-bit wave kernels: int_fftNk / int_ifftNk with NFFT = 6 .. 10 (N = 64 .. 1024), natural order in and out, for every DATA_WIDTH /
+// intfft_w64.hpp -- the 64-bit kernels as templates: wave kernels (intfft_fastw64.hip: N = 1024 and the launchers; intfft_fastw64s.hip:
+// N = 64 .. 512) and, further down, block kernels (intfft_fastw64b.hip / intfft_fastw64bi.hip: N = 2048 / 4096).
+// Wave kernels: int_fftNk / int_ifftNk with NFFT = 6 .. 10 (N = 64 .. 1024), natural order in and out, for every DATA_WIDTH /
 // TWDL_WIDTH / FORMAT / RNDMODE whose results need more than 32 and at most 64 bits -- 32-bit unscaled data (42-bit results,
 // int_fft_single_path.vhd:15 documents DATA_WIDTH 8-32), 24-bit unscaled data with 16- or 24-bit twiddles, wide scaled data, the
 // row cores of unscaled 2-D scheme plans.  These plans ran on the generic LDS pass kernel k_pass<int64> (37-55 Gsample/s).
@@ -13,7 +14,6 @@
 // int_dif2_fly.vhd:144-241), with the rounding kind as a template parameter.
 #pragma once
 #include "intfft_u32.hpp"
-
 
 namespace intfft {
 
