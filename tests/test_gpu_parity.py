@@ -1220,7 +1220,7 @@ def _fuzz_cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _fuzz_cases(160, 20260928))
+@pytest.mark.parametrize("case", _fuzz_cases(240, 20260928))
 def test_fuzz_generics_three_way(case, monkeypatch):
     """Random elaboratable generics: whatever kernel the planner picks, the generic LDS pass kernels and the oracle
     agree bit for bit (ragged batch sizes, full-range data)."""
@@ -1237,6 +1237,44 @@ def test_fuzz_generics_three_way(case, monkeypatch):
         assert np.array_equal(gen, want), (case, "generic")
 
 
+def _fuzz_cases_64(count, seed):
+    """Random elaboratable generics whose results need 33 .. 64 bits at N = 64 .. 4096 (the 64-bit wave / block kernels' domain and
+    the sub-plan pairs), every direction."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        log2n = int(rng.integers(6, 13))
+        fmt = int(rng.integers(0, 2))
+        rnd = 0 if fmt else int(rng.integers(0, 2))
+        dw = int(rng.integers(12, 65))
+        tw = int(rng.integers(8, 27))
+        new = bool(rng.integers(0, 2))
+        d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
+        ob = dw + (fmt * log2n) * (2 if d == "PAIR" else 1)
+        if ob <= 32 or ob > 64 or C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), DIR[d]) != 0:
+            continue
+        out.append((log2n, dw, tw, fmt, rnd, new, d))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases_64(120, 20260929))
+def test_fuzz_64_bit_word_plans(case, monkeypatch):
+    """Seeded fuzz over the plans on 64-bit words at N = 64 .. 4096: whichever kernel serves them (k_fft1024_w64 / k_ifft1024_w64,
+    the block kernels, k_fft1024_w32 / k_fft4096_w32 with their 64-bit tails, forward + inverse sub-plans for a pair, k_pass<long>),
+    the oracle and the generic kernels agree bit for bit; ragged batches, full-range data, edge frames."""
+    log2n, dw, tw, fmt, rnd, new, d = case
+    n = 1 << log2n
+    batch = int(2 + (log2n * 5 + dw) % 9)
+    x = np.concatenate([uniform_frames(batch, n, dw, 15000 + log2n * 100 + dw), edge_frames(n, dw)[[1, 4]]])
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+    want = run_ref(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+    assert np.array_equal(got, want), (case, info["kernel_name"])
+    if not info["kernel_name"].startswith("k_pass"):
+        monkeypatch.setenv("INTFFT_GENERIC_ONLY", "1")
+        gen, ig = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=d)
+        assert ig["kernel_name"].startswith("k_pass") and np.array_equal(gen, want), (case, "generic")
+
+
 def _fuzz_order_cases(count, seed):
     rng = np.random.default_rng(seed)
     names = list(ORD)
@@ -1246,7 +1284,7 @@ def _fuzz_order_cases(count, seed):
     return out
 
 
-@pytest.mark.parametrize("case", _fuzz_order_cases(60, 777))
+@pytest.mark.parametrize("case", _fuzz_order_cases(100, 777))
 def test_fuzz_generics_with_orders(case):
     """Random generics x random I/O orders (HALVES / BITREV / BITREV_LANES / NATURAL on either side)."""
     log2n, dw, tw, fmt, rnd, new, d, in_o, out_o = case
