@@ -1073,7 +1073,7 @@ hipError_t launch_biginv(int log2n, int twd, int in_bitrev, int out_halves, int 
     const size_t nb3 = nframes << (log2n - 13), nb = nframes << (log2n - 12);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
     if (two_pass && log2n >= 19) // N = 2^19, 2^20: the mirrors of the forward two-pass plan (intfft_big2x.hip); natural order in only (planner)
-        return in_bitrev ? hipErrorInvalidValue : launch_big2x_inv(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, out_halves, stream);
+        return launch_big2x_inv(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, out_halves, stream, in_bitrev);
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the same first pass, then STAGE 8..L-1 with 32 registers per thread
         if (in_bitrev) {
             const size_t nch = nframes << (log2n - 10), ccap = (size_t)device_cus() * 8;
@@ -1156,8 +1156,8 @@ hipError_t launch_big20(int log2n, int twd, int in_halves, int out_bitrev, int t
     static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast && !rndmode; // round mode: the exact-path instantiations, sl.round set
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
-    if (two_pass && log2n >= 19) // N = 2^19, 2^20: 1024 rows x 1024 columns, two ten-stage passes (intfft_big2x.hip); natural order out only (planner)
-        return out_bitrev ? hipErrorInvalidValue : launch_big2x(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, in_halves, stream);
+    if (two_pass && log2n >= 19) // N = 2^19, 2^20: 1024 rows x 1024 columns, two ten-stage passes (intfft_big2x.hip); natural or BITREV order out
+        return launch_big2x(log2n, fx, pin, pout, scr, tw16f, h_tw, nframes, sl, in_halves, stream, out_bitrev);
     if (two_pass && log2n > 16) { // N = 2^17, 2^18: the 32-register first pass (stages L-1..8), then the same second pass
         const size_t nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;

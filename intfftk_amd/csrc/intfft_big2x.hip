@@ -230,7 +230,9 @@ template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32],
 //   round 2 thread = (jj = n9..n5, kb = rev4(k)), regs q = n4..n0: stages 4..0, wave-uniform twiddles
 //   store   X index = rev5(q) << (L-5) | rev5(jj) << (L-10) | rev(rest) << 4 | rev4(k): 16 consecutive lanes = one 64-byte piece;
 //           the partner block (`rest` with its top bit flipped -> rev(rest) ^ 1) writes the other half of the line
-template <int L, bool FAST_OK>
+//   OUT_BR  BITREV order out (the core's own order: memory index = core position, int_fftNk.vhd:184-342 without the reorder buffer):
+//           the thread's 32 results are 32 consecutive positions of its row -- eight 16-byte stores, every row of the tile one 4 KiB run
+template <int L, bool FAST_OK, bool OUT_BR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_b(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
                                                                                              const Round5Consts c, size_t nframes, const Slice sl, int pre_all)
 {
@@ -310,8 +312,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int q = 0; q < 32; ++q) v[q] = rd_base[q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
         else dif_round5_c<false>(v, c, sl, sh5);
+        if constexpr (OUT_BR) { // position = ((k << RL | rest) << 10) | (jj << 5) | q
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            v4u *dbr = reinterpret_cast<v4u *>(out + (frame << L) + ((((size_t)krow << RL) | rest) << 10) + ((size_t)jj << 5));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) __builtin_nontemporal_store(v[q], dst + ((size_t)rev5c(q) << (L - 5)) + toff2_l);
+            for (int q = 0; q < 32; q += 4) {
+                const v4u y = {v[q], v[q + 1], v[q + 2], v[q + 3]};
+                dbr[q >> 2] = y; // (plain: the eight pieces of a line meet in L2; non-temporal they leave as eight partial writes)
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) __builtin_nontemporal_store(v[q], dst + ((size_t)rev5c(q) << (L - 5)) + toff2_l);
+        }
     }
 }
 
@@ -354,7 +366,9 @@ template <bool FASTX> __device__ __forceinline__ void dit_round5_c(u32 (&v)[32],
     }
 }
 
-template <int L, bool FAST_OK>
+// IN_BR: BITREV order in (int_ifftNk's own order: memory index = core position): the thread's 32 inputs are 32 consecutive positions of
+// its row (eight 16-byte loads)
+template <int L, bool FAST_OK, bool IN_BR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qb(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
                                                                                               const Round5Consts c, size_t nframes, const Slice sl)
 {
@@ -400,8 +414,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unsigned toff_l = toff, toff2_l = toff2;
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
+        if constexpr (IN_BR) { // position = ((k << RL | rest) << 10) | (jj << 5) | q
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            const v4u *sbr = reinterpret_cast<const v4u *>(in + (frame << L) + ((((size_t)krow << RL) | rest) << 10) + ((size_t)jj << 5));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)rev5c(q) << (L - 5)) + toff2_l); // core position (rho, jj << 5 | q) = X[brev_L]
+            for (int q = 0; q < 32; q += 4) {
+                const v4u x = sbr[q >> 2]; // (plain: the eight pieces of a line are asked for by eight instructions -- the line has to stay in cache)
+                v[q] = x.x, v[q + 1] = x.y, v[q + 2] = x.z, v[q + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)rev5c(q) << (L - 5)) + toff2_l); // core position (rho, jj << 5 | q) = X[brev_L]
+        }
         bool fast = false;
         {
             u32 acc = 0;
@@ -799,7 +823,7 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
 }
 
 hipError_t launch_big2x_inv(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes, const Slice &sl,
-                            int halves, hipStream_t stream)
+                            int halves, hipStream_t stream, bool in_bitrev)
 {
     if (nframes == 0) return hipSuccess;
     Round5Consts c;
@@ -818,9 +842,11 @@ hipError_t launch_big2x_inv(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *
         const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
         allow_max_lds(kptr(k_big2x_qa<LL, FX>));                                                                                   \
         allow_max_lds(kptr(k_big2x_qb<LL, FX>));                                                                                   \
+        allow_max_lds(kptr(k_big2x_qb<LL, FX, true>));                                                                             \
         const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
-        hipLaunchKernelGGL((k_big2x_qb<LL, FX>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl);              \
+        if (in_bitrev) hipLaunchKernelGGL((k_big2x_qb<LL, FX, true>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl); \
+        else hipLaunchKernelGGL((k_big2x_qb<LL, FX>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl);         \
         const unsigned groups = (unsigned)(nframes < 64 ? nframes : 64);                                                           \
         hipLaunchKernelGGL((k_big2x_qa<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, scr, pout, tw16f, nframes, groups, sl, halves); \
     }
@@ -853,7 +879,7 @@ bool big2x_supported(int log2n) { return (log2n == 19 || log2n == 20) && !diag_e
 const char *big2x_kernel_name() { return "k_big2x_a/k_big2x_b"; }
 
 hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes, const Slice &sl,
-                        int halves, hipStream_t stream)
+                        int halves, hipStream_t stream, bool out_bitrev)
 {
     if (nframes == 0) return hipSuccess;
     Round5Consts c;
@@ -872,6 +898,7 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
         allow_max_lds(kptr(k_big2x_a<LL, FX>));                                                                                    \
         allow_max_lds(kptr(k_big2x_b<LL, FX>));                                                                                    \
+        allow_max_lds(kptr(k_big2x_b<LL, FX, true>));                                                                              \
         /* frame groups: 64 = every block takes ONE tile of a 64-frame chunk.  The partner blocks b, b + 8 then start together  \
            (per-XCD dispatch order) instead of drifting apart over a frame walk: FETCH_SIZE 387 MB against 436 MB per 2^26      \
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
@@ -880,7 +907,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
         const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
-        hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);           \
+        if (out_bitrev) hipLaunchKernelGGL((k_big2x_b<LL, FX, true>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0); \
+        else hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);      \
     }
     if (log2n == 20) {
         if (fx) INTFFT_2X_LAUNCH(20, true) else INTFFT_2X_LAUNCH(20, false)

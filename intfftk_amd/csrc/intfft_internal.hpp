@@ -239,7 +239,7 @@ bool big2x_supported(int log2n);
 bool big2x_tables_ok(int log2n, const int2 *h_tw, int twd);
 const char *big2x_kernel_name();
 hipError_t launch_big2x(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,
-                        const struct Slice &sl, int halves, hipStream_t stream);
+                        const struct Slice &sl, int halves, hipStream_t stream, bool out_bitrev = false);
 // 64-bit wave kernels: N = 64 .. 1024 forward / inverse with results of 33 .. 64 bits (intfft_fastw64.hip)
 bool fastw64_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
 const char *fastw64_kernel_name(int direction);
@@ -261,7 +261,7 @@ hipError_t launch_fused2d(int twd, const uint32_t *pin, uint32_t *pout, uint32_t
 hipError_t launch_fused2d_cols(int lr, int twd, const uint32_t *pin, uint32_t *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint32_t *tw2d, size_t nframes,
                                int halves, hipStream_t stream);
 hipError_t launch_big2x_inv(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,
-                            const struct Slice &sl, int halves, hipStream_t stream);
+                            const struct Slice &sl, int halves, hipStream_t stream, bool in_bitrev = false);
 // two-pass plans for N = 2^17, 2^18 forward: 32-register first pass (intfft_big2p.hip) + k_mid_p2 / k_mid_c
 bool big2p_supported(int log2n);
 bool big2p_tables_ok(int log2n, const int2 *h_tw, int twd);

@@ -874,12 +874,14 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !diag_env("INTFFT_NO_TWOPASS") &&
                                 big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
-        // N = 2^19, 2^20 forward, truncate mode, natural order out: 1024 rows x 1024 columns in two ten-stage passes (intfft_big2x.hip)
-        const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && p->out_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
+        // N = 2^19, 2^20 forward, truncate mode, natural or BITREV order out: 1024 rows x 1024 columns in two ten-stage passes (intfft_big2x.hip)
+        const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && (p->out_order == INTFFT_ORDER_NATURAL || p->out_order == INTFFT_ORDER_BITREV) &&
+                           big2x_supported(p->log2n) &&
                            !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x) pl->big_two_pass = true;
-        // ... and the inverse from natural order (natural or HALVES order out): k_big2x_qb / k_big2x_qa
-        const bool big2x_inv = pl->big20 && p->direction == INTFFT_INV && !p->rndmode && p->in_order == INTFFT_ORDER_NATURAL && big2x_supported(p->log2n) &&
+        // ... and the inverse from natural or BITREV order (natural or HALVES order out): k_big2x_qb / k_big2x_qa
+        const bool big2x_inv = pl->big20 && p->direction == INTFFT_INV && !p->rndmode && (p->in_order == INTFFT_ORDER_NATURAL || p->in_order == INTFFT_ORDER_BITREV) &&
+                               big2x_supported(p->log2n) &&
                                !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x_inv) pl->big_two_pass = true;
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,

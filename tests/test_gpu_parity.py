@@ -339,9 +339,9 @@ def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)
-    # N = 2^17, 2^18: the 32-register passes take the native orders too; N = 2^19, 2^20: HALVES in -> natural order out only
-    two = log2n <= 18 or (direction == "FWD" and out_order == "NATURAL") or (direction == "INV" and in_order == "NATURAL")
-    assert "k_big2" in info["kernel_name"] and info["n_passes"] == (2 if two else 3)
+    # every length in two passes: N = 2^17, 2^18 on the 32-register passes, N = 2^19, 2^20 on the half-line tiles (BITREV side: the
+    # thread's 32 consecutive core positions as eight 16-byte accesses)
+    assert "k_big2" in info["kernel_name"] and info["n_passes"] == 2, info
 
 
 def test_config4_n_2pow20_taylor_extension():

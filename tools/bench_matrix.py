@@ -79,6 +79,8 @@ ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit r
 NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (native int_fftNk beats)"),
           ("12:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
           ("16:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
+          ("20:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
+          ("20:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
           ("7:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out (native int_ifftNk beats)"),
           ("12:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
           ("16:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out")]
