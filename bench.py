@@ -12,7 +12,8 @@ Launch forms:
   python bench.py                          1 GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N    (the driver's form)
   python bench.py --gpus N                 no WORLD_SIZE in the environment: spawns its own N ranks (127.0.0.1)
-Options: --config C2|C5 (C5 = N=4096 FFT->IFFT pair, 16384 frames per GPU), --e2e (adds the end-to-end
+Options: --config C2|C3|C4|C5 (the other BASELINE configurations in the same line format: C3 = N=65536 24-bit unscaled, 4096 frames;
+C4 = N=2^20 16-bit scaled, 1024 frames; C5 = N=4096 FFT->IFFT pair, 16384 frames per GPU), --e2e (adds the end-to-end
 scatter -> transform -> gather rate as a separate field; never `value`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`, plus the
@@ -43,14 +44,25 @@ CONFIGS = {
     # name: (log2n, direction, frames per GPU, seed, workload text)
     "C2": (10, "FWD", 65536, 0xC0FFEE02,
            "configs[1]: N=1024, 16-bit data / 16-bit twiddle, scaled-truncate DIF FFT, natural->natural"),
+    "C3": (16, "FWD", 4096, 0xC0FFEE03,
+           "configs[2]: N=65536, 24-bit data / 24-bit twiddle, unscaled (full bit growth: 40-bit results) DIF FFT, natural->natural"),
+    "C4": (20, "FWD", 1024, 0xC0FFEE04,
+           "configs[3]: N=2^20, 16-bit data / 16-bit twiddle, scaled-truncate DIF FFT, Taylor twiddles (row_twiddle_tay), natural->natural"),
     "C5": (12, "PAIR", 16384, 0xC0FFEE05,
            "configs[4]: N=4096, 16-bit scaled FFT->IFFT pair (int_fft_ifft_pair), natural->natural, batch split over the GPUs"),
 }
+# generics and accounting per config: (DATA_WIDTH, TWDL_WIDTH, FORMAT, algorithmic bytes per sample, dtype of the line, metric)
+GENERICS = {
+    "C2": (16, 16, 0, 8, "int16", "Gsample/s (complex int16) batched N=1024 scaled FFT"),
+    "C3": (24, 24, 1, 24, "int64", "Gsample/s (complex, 24-bit in int32 -> 40-bit in int64) batched N=65536 unscaled FFT"),
+    "C4": (16, 16, 0, 8, "int16", "Gsample/s (complex int16) batched N=2^20 scaled FFT (Taylor twiddles)"),
+    "C5": (16, 16, 0, 8, "int16", "Gsample/s (complex int16) batched N=4096 scaled FFT->IFFT pair"),
+}
 
 
-def make_input(batch: int, n: int, seed: int, rank: int, full_scale: bool = False):
-    """Synthetic input: frames 0..7 = edge set, the rest i.i.d. uniform in [-2^14, 2^14)
-    (full_scale: the whole int16 range -- every frame then fails the guard-bit vote and takes the exact extraction)."""
+def make_input(batch: int, n: int, seed: int, rank: int, full_scale: bool = False, dw: int = 16):
+    """Synthetic input: frames 0..7 = edge set, the rest i.i.d. uniform in [-2^(w-2), 2^(w-2))
+    (full_scale: the whole w-bit range -- every frame then fails the guard-bit vote and takes the exact extraction)."""
     import numpy as np
     import torch
 
@@ -58,10 +70,11 @@ def make_input(batch: int, n: int, seed: int, rank: int, full_scale: bool = Fals
 
     g = torch.Generator(device="cuda")
     g.manual_seed(seed + rank)
-    lim = 1 << (15 if full_scale else 14)
-    x = torch.randint(-lim, lim, (batch, n, 2), device="cuda", dtype=torch.int16, generator=g)
+    lim = 1 << (dw - 1 if full_scale else dw - 2)
+    dt, npdt = (torch.int16, np.int16) if dw <= 16 else (torch.int32, np.int32)
+    x = torch.randint(-lim, lim, (batch, n, 2), device="cuda", dtype=dt, generator=g)
     if batch >= 8 and not full_scale:
-        x[:8] = torch.from_numpy(edge_frames(n, 16).astype(np.int16)).cuda()
+        x[:8] = torch.from_numpy(edge_frames(n, dw).astype(npdt)).cuda()
     return x
 
 
@@ -94,7 +107,7 @@ def pmc_digest(config="C2"):
 
 
 # ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
-def cpu_baseline(x_dev, y_dev, log2n, direction):
+def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0):
     """Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
     to run) and uses the all-core passes as parity gates for the GPU output of those frames.  Headline entry (`value`): the
     FASTER of the two forms on all host threads -- the stream form (the literal dataflow of math/fn_radix2.m: half-split
@@ -105,21 +118,22 @@ def cpu_baseline(x_dev, y_dev, log2n, direction):
     from oracle import oracle_c as C
 
     n = 1 << log2n
-    p = C.make_params(log2n, 16, 16, 0, 0, True)
+    p = C.make_params(log2n, dw, tw, fmt, 0, True)
     d = {"FWD": C.FWD, "PAIR": C.PAIR}[direction]
+    i16 = dw <= 16 and fmt == 0  # int16 containers both ways: the oracle's int16 entry point; else its int64 one
     threads = C.num_threads()
     scale = 1024 // n if n <= 1024 else 1
     work = (2 if direction == "PAIR" else 1) * max(1, n // 1024)
 
     def timed(frames, form, nthreads, reps=3):
         frames = max(8, min(int(frames), x_dev.shape[0]))
-        xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy())
+        xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy() if i16 else x_dev[:frames].cpu().numpy().astype(np.int64))
         ref = np.zeros_like(xs)  # pre-touched: page faults are not part of the baseline
+        fn = C.lib().orc_exec_i16 if i16 else C.lib().orc_exec
         best = None
         for _ in range(reps + 1):  # first pass warms the OpenMP team and the caches
             t0 = time.perf_counter()
-            rc = C.lib().orc_exec_i16(ctypes.byref(p), d, C.NATURAL, C.NATURAL, xs.ctypes.data, ref.ctypes.data,
-                                      frames, form, nthreads)
+            rc = fn(ctypes.byref(p), d, C.NATURAL, C.NATURAL, xs.ctypes.data, ref.ctypes.data, frames, form, nthreads)
             dt = time.perf_counter() - t0
             assert rc == 0
             best = dt if best is None else min(best, dt)
@@ -328,14 +342,15 @@ def main():
     log2n, direction, cfg_batch, seed, workload = CONFIGS[args.config]
     n = 1 << log2n
     batch = args.batch or cfg_batch
+    dw, tw, fmt, bytes_per_sample, line_dtype, metric = GENERICS[args.config]
     ctor = int_fft_single_path if direction == "FWD" else int_fft_ifft_pair
-    core = ctor(NFFT=log2n, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMODE=0, device=dev_index)
-    x = make_input(batch, n, seed, rank if args.rank_seeded_data else 0)
-    y = torch.empty_like(x)
+    core = ctor(NFFT=log2n, DATA_WIDTH=dw, TWDL_WIDTH=tw, FORMAT=fmt, RNDMODE=0, device=dev_index)
+    x = make_input(batch, n, seed, rank if args.rank_seeded_data else 0, dw=dw)
+    y = torch.empty(core.out_shape(batch), device=x.device, dtype=core.out_dtype)
     stream = torch.cuda.current_stream().cuda_stream
     in_ptr, out_ptr = x.data_ptr(), y.data_ptr()
     step = lambda: core.exec_raw(in_ptr, out_ptr, batch, stream)  # noqa: E731
-    alg_bytes = BYTES_PER_SAMPLE * batch * n
+    alg_bytes = bytes_per_sample * batch * n
 
     def barrier():
         torch.cuda.synchronize()
@@ -386,7 +401,7 @@ def main():
 
     # end-to-end: the whole batch on rank 0 -> one grouped scatter -> transform -> one grouped gather -> rank 0
     e2e = None
-    if args.e2e:
+    if args.e2e and args.config in ("C2", "C5"):  # (int16 both ways: the per-peer byte accounting below)
         total = batch * world
         sh = ShardedTransform(core, n, core.in_dtype, core.out_dtype, device, stage_via_cpu=share)
         root_x = make_input(total, n, seed, 0) if rank == 0 else None
@@ -442,8 +457,6 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         digest_path, digest = pmc_digest(args.config)
         traffic = float(digest["hbm_bytes_per_launch"]) if (digest and batch == cfg_batch) else None
-        metric = ("Gsample/s (complex int16) batched N=1024 scaled FFT" if args.config == "C2"
-                  else "Gsample/s (complex int16) batched N=4096 scaled FFT->IFFT pair")
         out = {
             "metric": metric,
             "value": samples / t_all / 1e9,
@@ -455,7 +468,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int16",
+            "dtype": line_dtype,
             "data": "synthetic",
             "config": {"workload": "%s, batch=%d per GPU" % (workload, batch),
                        "batch_per_gpu": batch, "n": n, "parallelism": "batch-shard x%d" % world,
@@ -478,24 +491,25 @@ def main():
             out["e2e"] = e2e
         if extras:
             out["cold"] = cold
-            xf = make_input(batch, n, seed, 0, full_scale=True)
+            xf = make_input(batch, n, seed, 0, full_scale=True, dw=dw)
             stepf = lambda: core.exec_raw(xf.data_ptr(), out_ptr, batch, stream)  # noqa: E731
             for _ in range(20):
                 stepf()
             ms = event_ms(torch, stepf, args.steps)
             out["full_scale_input"] = {"kernel_ms": ms, "value": batch * n / ms / 1e6,
                                        "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "what": "input uniform over the whole int16 range: no frame has a guard bit, every frame takes "
+                                       "what": "input uniform over the whole DATA_WIDTH range: no frame has a guard bit, every frame takes "
                                                "the exact result extraction (the headline input is uniform in [-2^14, 2^14) as SURVEY 8d names)"}
             del xf
             step()  # y := transform(x) again for the parity gate below
             torch.cuda.synchronize()
-            out.update(ceilings(torch, x, torch.empty_like(x), stream, digest, args.config == "C2" and batch == 65536))
+            if args.config in ("C2", "C5"):  # the copy ceiling is the single-pass kernels' access pattern (one wave per 4 KiB)
+                out.update(ceilings(torch, x, torch.empty_like(x), stream, digest, args.config == "C2" and batch == 65536))
             out["octave"] = octave_probe()
         if world == 1 and not args.no_cpu_baseline:
             step()
             torch.cuda.synchronize()
-            out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction)
+            out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction, dw, tw, fmt)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -286,6 +286,11 @@ def test_bench_single_gpu_line_has_the_8d_fields():
     assert out["e2e"]["matches_resident"] is True
     c5 = _bench(["--config", "C5", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "512", "--no-extras"])
     assert c5["config"]["n"] == 4096 and c5["cpu_baseline"]["parity_ok"] is True
+    # the other BASELINE configurations in the same line format (reduced batches: their CPU samples are a few frames)
+    c3 = _bench(["--config", "C3", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "16", "--no-extras"])
+    assert c3["config"]["n"] == 65536 and c3["dtype"] == "int64" and c3["config"]["launches_per_step"] == 2 and c3["cpu_baseline"]["parity_ok"] is True
+    c4 = _bench(["--config", "C4", "--steps", "3", "--warmup", "1", "--prewarm", "5", "--batch", "8", "--no-extras"])
+    assert c4["config"]["n"] == 1 << 20 and c4["config"]["kernel"] == "k_big2x_a/k_big2x_b" and c4["cpu_baseline"]["parity_ok"] is True
 
 
 def test_bench_under_the_drivers_launcher():
