@@ -126,7 +126,7 @@ def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0):
     work = (2 if direction == "PAIR" else 1) * max(1, n // 1024)
 
     def timed(frames, form, nthreads, reps=3):
-        frames = max(8, min(int(frames), x_dev.shape[0]))
+        frames = max(8, min(max(int(frames), nthreads), x_dev.shape[0]))  # (at least one frame per thread: long frames)
         xs = np.ascontiguousarray(x_dev[:frames].cpu().numpy() if i16 else x_dev[:frames].cpu().numpy().astype(np.int64))
         ref = np.zeros_like(xs)  # pre-touched: page faults are not part of the baseline
         fn = C.lib().orc_exec_i16 if i16 else C.lib().orc_exec
