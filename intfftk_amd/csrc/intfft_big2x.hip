@@ -231,7 +231,9 @@ template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32],
 //   store   X index = rev5(q) << (L-5) | rev5(jj) << (L-10) | rev(rest) << 4 | rev4(k): 16 consecutive lanes = one 64-byte piece;
 //           the partner block (`rest` with its top bit flipped -> rev(rest) ^ 1) writes the other half of the line
 //   OUT_BR  BITREV order out (the core's own order: memory index = core position, int_fftNk.vhd:184-342 without the reorder buffer):
-//           the thread's 32 results are 32 consecutive positions of its row -- eight 16-byte stores, every row of the tile one 4 KiB run
+//           the thread's 32 results are 32 consecutive positions of its row, every row of the tile one 4 KiB run -- staged through LDS
+//           once more so that a wave writes 1 KiB runs non-temporally (stored straight from the registers the eight 16-byte pieces
+//           of a line come from eight instructions: 257-270 Gsample/s with plain stores, 92 non-temporally; staged: 283-297)
 template <int L, bool FAST_OK, bool OUT_BR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_b(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
                                                                                              const Round5Consts c, size_t nframes, const Slice sl, int pre_all)
@@ -312,13 +314,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int q = 0; q < 32; ++q) v[q] = rd_base[q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
         else dif_round5_c<false>(v, c, sl, sh5);
-        if constexpr (OUT_BR) { // position = ((k << RL | rest) << 10) | (jj << 5) | q
-            typedef u32 v4u __attribute__((ext_vector_type(4)));
-            v4u *dbr = reinterpret_cast<v4u *>(out + (frame << L) + ((((size_t)krow << RL) | rest) << 10) + ((size_t)jj << 5));
+        if constexpr (OUT_BR) { // position = ((k << RL | rest) << 10) | (jj << 5) | q: the tile is 16 rows of 4 KiB
+            // through LDS once more (every thread rewrites the row it has just read), so that a wave writes 1 KiB runs non-temporally
+            u32 *const own = lds + ROWY * ((jj << 4) | krow);
 #pragma unroll
-            for (int q = 0; q < 32; q += 4) {
-                const v4u y = {v[q], v[q + 1], v[q + 2], v[q + 3]};
-                dbr[q >> 2] = y; // (plain: the eight pieces of a line meet in L2; non-temporal they leave as eight partial writes)
+            for (int q = 0; q < 32; ++q) own[q] = v[q];
+            __syncthreads();
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned e = ((unsigned)i * 512u + (unsigned)tid) * 4u; // flat [k][column] index of the tile
+                const unsigned kk = e >> 10, col = e & 1023u;
+                const u32 *sp = lds + ROWY * (((col >> 5) << 4) | kk) + (col & 31u);
+                const v4u y = {sp[0], sp[1], sp[2], sp[3]};
+                __builtin_nontemporal_store(y, reinterpret_cast<v4u *>(out + (frame << L) + ((((size_t)kk << RL) | rest) << 10) + col));
             }
         } else {
 #pragma unroll
@@ -367,7 +376,7 @@ template <bool FASTX> __device__ __forceinline__ void dit_round5_c(u32 (&v)[32],
 }
 
 // IN_BR: BITREV order in (int_ifftNk's own order: memory index = core position): the thread's 32 inputs are 32 consecutive positions of
-// its row (eight 16-byte loads)
+// its row (eight plain 16-byte loads: 274 Gsample/s at N = 2^20; loaded as 1 KiB runs per wave and handed over through LDS: 240-260)
 template <int L, bool FAST_OK, bool IN_BR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qb(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
                                                                                               const Round5Consts c, size_t nframes, const Slice sl)
