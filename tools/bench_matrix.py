@@ -86,6 +86,9 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("16:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out")]
 
 if __name__ == "__main__":
+    print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
+          "lengths that is ONE scratch chunk per call, so the two-stream chunk alternation of N = 2^19 / 2^20, the 24-bit class and the tiled "
+          "2-D plans does not show here: BASELINE's batches are `python bench.py --config C3 | C4 | C5` (C4: 291-295, C3: 143).\n")
     print("| N | mode | kernel | passes | Gsample/s | B/sample | GB/s | frac of 8 TB/s | parity prefix |")
     print("|---|---|---|---|---|---|---|---|---|")
     for spec, label in ROWS:
