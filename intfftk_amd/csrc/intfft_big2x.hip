@@ -1,10 +1,11 @@
 // intfft_big2x.hip -- TWO-pass plans for N = 2^19 and 2^20 (BASELINE config 4 is N = 2^20, Taylor twiddles): int_fftNk,
-// DATA_WIDTH = 16 (or 9 .. 15 in int16 containers), TWDL_WIDTH <= 16, scaled-truncate, natural / HALVES order in -> natural order
-// out (src/vhdl/fft/int_fftNk.vhd:184-342; twiddles of STAGE >= 11 from row_twiddle_tay.vhd:123-268 via k_twiddle_stage).
+// DATA_WIDTH = 16 (or 9 .. 15 in int16 containers), TWDL_WIDTH <= 16, scaled-truncate, natural / HALVES order in -> natural / BITREV
+// order out, and the inverse mirrors (src/vhdl/fft/int_fftNk.vhd:184-342; twiddles of STAGE >= 11 from row_twiddle_tay.vhd:123-268 via k_twiddle_stage).
 // Same packed arithmetic as intfft_fast1024.hip.  N = 2^L = 2^(L-10) rows x 1024 columns:
 //
 //   pass A  k_big2x_a<L>  stages L-1..10 down the columns; user array -> plan scratch
-//   pass B  k_big2x_b<L>  stages 9..0 along every 1024-point row + the bit-reversed (natural-order) store; scratch -> user array
+//   pass B  k_big2x_b<L>  stages 9..0 along every 1024-point row + the bit-reversed (natural-order) store, or the core-order (BITREV) one;
+//                         scratch -> user array
 //
 // A ten-stage pass on 128-byte rows needs a 1024 x 32 tile = 128 KiB: one workgroup per CU, nothing to overlap its load / compute /
 // store phases with (measured: 3.8 TB/s on the 1024-row form of k_big2p_a).  Both passes here work on
