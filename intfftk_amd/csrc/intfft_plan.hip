@@ -670,12 +670,25 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (!(pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->sub_col_f && pl->sub_row_f &&
               big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width)))
             pl->fused2d = 0;
+        // ... and the inverse (4): the row cores as pass QB, the conj multiplier + the column cores on pass QA's tiles (k_big2x_ci)
+        if (!pl->fused2d && fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order) &&
+            pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 && pl->tw_i.sh_b == p->twdl_width - 1 && pl->sub_row_i && pl->sub_col_i &&
+            big2x_tables_ok(10, pl->sub_row_i->h_tw.data(), p->twdl_width))
+            pl->fused2d = 4;
+        // ... and the pair (5): the forward two launches into the second layout buffer, the inverse two launches from there
+        if (!pl->fused2d && p->direction == INTFFT_PAIR && !diag_env("INTFFT_2D_NO_FUSED_CORES") && pl->sub_col_f && pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
+            fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 2 &&
+            fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_INV, INTFFT_ORDER_NATURAL, p->out_order) &&
+            pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 &&
+            pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width))
+            pl->fused2d = 5;
+        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
             // the 1024-point cores' twiddles in the packed operand forms (the single-kernel sub-plans pack theirs on the fly)
             const size_t total = ((size_t)1 << 10) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
-            if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_col_f->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
+            if (e == hipSuccess) e = launch_pack_twiddles16(core1k->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw2d_tiles, ((size_t)1 << pl->L) * sizeof(uint32_t));
             if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, pl->L, p->twdl_width, nullptr);
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
@@ -693,6 +706,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 }
             }
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
+            else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
+            else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
             else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
         }
         *out = pl;
@@ -1009,7 +1024,8 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
-        if (plan->fused2d == 2) info->n_passes = 2;
+        if (plan->fused2d == 2 || plan->fused2d == 4) info->n_passes = 2;
+        if (plan->fused2d == 5) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
@@ -1050,7 +1066,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
         // buffers (section 4.2d: the strided column pass of one chunk beside the streaming launches of the other); under stream capture, and
         // when the row sub-plan owns a scratch of its own, everything stays on the caller's stream.
         const size_t half = pl->buf2d_frames / 2;
-        bool dual = pl->side_stream && half >= 1 && batch > half && (pl->fused2d == 2 || pl->sub_row_f->scratch_bytes == 0);
+        bool dual = pl->side_stream && half >= 1 && batch > half && (pl->fused2d != 3 || pl->sub_row_f->scratch_bytes == 0);
         if (dual) {
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dual = false;
@@ -1079,6 +1095,19 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
             const uint32_t *src = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame);
             char *dst = static_cast<char *>(d_out) + f * out_frame;
             uint32_t *b0 = reinterpret_cast<uint32_t *>(static_cast<char *>(pl->buf2d[0]) + off);
+            if (pl->fused2d == 5) { // the pair: X in natural order in the second layout buffer between the two directions
+                uint32_t *b1 = reinterpret_cast<uint32_t *>(static_cast<char *>(pl->buf2d[1]) + off);
+                e = launch_fused2d(p.twdl_width, src, b1, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
+                if (e == hipSuccess)
+                    e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
+                                           p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 4) {
+                e = launch_fused2d_inv(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_row_i->h_tw.data(), pl->d_tw2d_tiles, nf,
+                                       p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
             if (pl->fused2d == 2) {
                 e = launch_fused2d(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                    p.in_order == INTFFT_ORDER_HALVES, st);

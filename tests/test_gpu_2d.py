@@ -110,6 +110,54 @@ def test_2d_n2pow20_two_launches(frames, monkeypatch):
         assert np.array_equal(got, got1)
 
 
+def test_2d_n2pow20_pair_four_launches(monkeypatch):
+    """N = 2^20 = 1024 x 1024 FFT -> IFFT pair, 16-bit scaled-truncate: the forward two launches into the second layout buffer (X in
+    natural order), the inverse two launches from there -- against the oracle's pair and the eight-launch composite; HALVES orders."""
+    n = 1 << 20
+    x = uniform_frames(3, n, 15, 2777)
+    x[0] = uniform_frames(1, n, 16, 16)[0]
+    info = check(x, 20, 10, 16, 16, 0, 0, True, "PAIR")
+    assert info["kernel_name"] == "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]" and info["n_passes"] == 4, info
+    check(x[:1], 20, 10, 16, 16, 0, 0, True, "PAIR", "HALVES", "HALVES")
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
+        got8, info8 = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "PAIR")
+        assert info8["n_passes"] >= 7, info8
+    got4, _ = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "PAIR")
+    assert np.array_equal(got4, got8)
+
+
+@pytest.mark.parametrize("frames", [3, 70])
+def test_2d_n2pow20_inverse_two_launches(frames, monkeypatch):
+    """N = 2^20 = 1024 x 1024, 16-bit scaled-truncate INVERSE: k_big2x_qb (row cores: pass QB of the 1-D two-pass inverse as it is) +
+    k_big2x_ci (conj multiplier + column cores on pass QA's tiles) against the oracle and the five-launch composite plan; full-scale
+    frames, HALVES order out, 13-bit twiddles / XSER OLD, a batch beyond one scratch chunk (two streams against one)."""
+    n = 1 << 20
+    x = uniform_frames(frames, n, 15, 1777 + frames)
+    x[0] = uniform_frames(1, n, 16, 15)[0]
+    if frames <= 5:
+        info = check(x, 20, 10, 16, 16, 0, 0, True, "INV")
+        assert info["kernel_name"] == "2d[k_big2x_qb|k_big2x_ci]" and info["n_passes"] == 2, info
+        check(x[:2], 20, 10, 16, 16, 0, 0, True, "INV", "NATURAL", "HALVES")
+        check(x[:1], 20, 10, 16, 13, 0, 0, False, "INV")
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
+            got5, info5 = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "INV")
+            assert info5["n_passes"] >= 4, info5
+        got2, _ = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "INV")
+        assert np.array_equal(got2, got5)
+    else:
+        got, info = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "INV")
+        assert info["n_passes"] == 2
+        sel = [0, 31, 32, 63, 64, 69]
+        want = C.execute_2d(x[sel], C.make_params(20, 16, 16, 0, 0, True), 10, C.INV, C.NATURAL, C.NATURAL, form=1)
+        assert np.array_equal(got[sel], want)
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_ONE_STREAM", "1")
+            got1, _ = run_gpu(x, 20, 10, 16, 16, 0, 0, True, "INV")
+        assert np.array_equal(got, got1)
+
+
 @pytest.mark.parametrize("case", [(13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (16, 8, 16, 16, 0, 1, True),
                                   (15, 3, 24, 24, 1, 0, False), (17, 4, 16, 16, 0, 0, True), (17, 13, 16, 16, 0, 0, True)])
 @pytest.mark.parametrize("direction", list(DIR))
