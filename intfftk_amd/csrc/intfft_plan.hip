@@ -110,7 +110,8 @@ struct intfft_plan {
     StageDesc tw_f{}, tw_i{};  // the multiplier between the cores (widths / regime), forward and inverse
     void *buf2d[2] = {nullptr, nullptr};
     int fused2d = 0;                  // 2: N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward in two launches (k_big2x_c + k_big2x_b); 3: N = 2^21 .. 2^24 as
-                                      // 1024 x N2: k_big2x_c, the row sub-plan, one layout change
+                                      // 1024 x N2: k_big2x_c, the row sub-plan, one layout change; 4: N = 2^20 inverse in two launches (k_big2x_qb + k_big2x_ci);
+                                      // 5: N = 2^20 pair = the forward two launches, then the inverse two
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
     size_t buf2d_frames = 0;
     int2 *d_tw2d = nullptr;   // 2-D scheme: the inter-pass table W_N^m, N entries
