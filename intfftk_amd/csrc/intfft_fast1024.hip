@@ -244,12 +244,33 @@ __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f,
 #pragma unroll
             for (int r = 0; r < 4; ++r) swap16(v[g + r], v[g + r + 4]);
         typedef u32 v4u __attribute__((ext_vector_type(4)));
-        u32 *dst = out + f * 1024 + lane_off;
-        if (st_ok) {
+        if constexpr (L == 6) {
+            // N = 64: a lane's four vectors lie in four quarters of its 256-byte frame and a store instruction would write sixteen 64-byte
+            // runs.  The chunk goes through the wave's (now idle) LDS tile in memory order instead and leaves as 1 KiB per instruction.
+            u32 *const tile = const_cast<u32 *>(reinterpret_cast<const u32 *>(rd_base)) - ROW_DW * lane; // the wave's 64 x ROW_DW dwords
+            wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const v4u x = {v[q], v[q + 8], v[q + 4], v[q + 12]};
-                __builtin_nontemporal_store(x, reinterpret_cast<v4u *>(dst + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
+                *reinterpret_cast<v4u *>(tile + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)) = x;
+            }
+            wave_lds_fence();
+            v4u *dst4 = reinterpret_cast<v4u *>(out + f * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 64 * i + lane; // 16-byte piece of the chunk: frame (4 e) >> 6 within it
+                if (f * (size_t)(1 << (10 - L)) + (size_t)(e >> (L - 2)) >= nframes_user) continue;
+                __builtin_nontemporal_store(*reinterpret_cast<const v4u *>(tile + 4 * e), dst4 + e);
+            }
+            wave_lds_fence(); // the next frame's transposition writes this tile again
+        } else {
+            u32 *dst = out + f * 1024 + lane_off;
+            if (st_ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4u x = {v[q], v[q + 8], v[q + 4], v[q + 12]};
+                    __builtin_nontemporal_store(x, reinterpret_cast<v4u *>(dst + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
+                }
             }
         }
     } else {

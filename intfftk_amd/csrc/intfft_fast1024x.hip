@@ -116,16 +116,41 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         if (L < 10 && MODE == X_INV && !in_bitrev) {
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
+            if constexpr (L == 6) {
+                // N = 64: a lane's four vectors lie in four quarters of its 256-byte frame (a load instruction would read sixteen 64-byte
+                // runs): the chunk comes in as 1 KiB per instruction and is handed over through the wave's LDS tile in memory order
+                v4u y[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4u x = {0u, 0u, 0u, 0u};
-                if (ok)
-                    x = INTFFT_LD(
-                        reinterpret_cast<const v4u *>(src + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
-                v[q] = x.x;
-                v[q + 8] = x.y;
-                v[q + 4] = x.z;
-                v[q + 12] = x.w;
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 64 * i + lane; // 16-byte piece of the chunk: frame e >> 4 within it
+                    y[i] = v4u{0u, 0u, 0u, 0u};
+                    if (!partial || f * FP + (size_t)(e >> (L - 2)) < nframes_user) y[i] = INTFFT_LD(reinterpret_cast<const v4u *>(src) + e);
+                }
+                wave_lds_fence(); // the previous frame's transposition reads
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<v4u *>(lds + 4 * (64 * i + lane)) = y[i];
+                wave_lds_fence();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4u x = *reinterpret_cast<const v4u *>(lds + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1));
+                    v[q] = x.x;
+                    v[q + 8] = x.y;
+                    v[q + 4] = x.z;
+                    v[q + 12] = x.w;
+                }
+                wave_lds_fence();
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4u x = {0u, 0u, 0u, 0u};
+                    if (ok)
+                        x = INTFFT_LD(
+                            reinterpret_cast<const v4u *>(src + lane_off + (q & 1) * out_weight<L>(0) + (q >> 1) * out_weight<L>(1)));
+                    v[q] = x.x;
+                    v[q + 8] = x.y;
+                    v[q + 4] = x.z;
+                    v[q + 12] = x.w;
+                }
             }
 #pragma unroll
             for (int g = 0; g < 16; g += 8)
