@@ -124,7 +124,25 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
             }
             typedef int v4i __attribute__((ext_vector_type(4)));
             int2 *dst = out + f * 1024 + lane_off;
-            if (f * FP + (size_t)lane_frame < nframes_user) {
+            if constexpr (L == 6) {
+                // N = 64: two lanes share a run, a store instruction would write thirty-two 32-byte runs -- the finished chunk (8 KiB) goes
+                // through the wave's idle LDS tile in memory order and leaves as 1 KiB per instruction (intfft_fast1024.hip does the same)
+                wave_lds_fence();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4i y = {re[q], im[q], re[q + 8], im[q + 8]};
+                    *reinterpret_cast<v4i *>(lds + 2 * (lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) + (q >> 2) * out_weight<L>(2))) = y;
+                }
+                wave_lds_fence();
+                v4i *dst4 = reinterpret_cast<v4i *>(out + f * 1024);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 64 * i + lane; // 16-byte piece = two samples: frame (2 e) >> 6 within the chunk
+                    if (f * FP + (size_t)(e >> (L - 1)) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 4 * e), dst4 + e);
+                }
+                wave_lds_fence();
+            } else if (f * FP + (size_t)lane_frame < nframes_user) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const v4i y = {re[q], im[q], re[q + 8], im[q + 8]};

@@ -193,7 +193,30 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
                 uswap32(re[r], re[r + 8]);
                 uswap32(im[r], im[r + 8]);
             }
-            if (f * FP + (size_t)lane_frame < nframes_user) {
+            if constexpr (L == 6) {
+                // N = 64: the finished chunk goes through the wave's idle LDS tile in memory order and leaves as 1 KiB per instruction
+                // (a lane's pairs lie 32 samples apart: thirty-two short runs per store instruction otherwise; intfft_fast1024u.hip)
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                wave_lds_fence();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int off = lane_off + (q & 1) * out_weight<L>(0) + ((q >> 1) & 1) * out_weight<L>(1) + (q >> 2) * out_weight<L>(2);
+                    if (a.out16) *reinterpret_cast<v2u *>(lds + off) = v2u{((u32)re[q] & 0xFFFFu) | ((u32)im[q] << 16), ((u32)re[q + 8] & 0xFFFFu) | ((u32)im[q + 8] << 16)};
+                    else *reinterpret_cast<v4i *>(lds + 2 * off) = v4i{re[q], im[q], re[q + 8], im[q + 8]};
+                }
+                wave_lds_fence();
+                const int pieces = a.out16 ? 4 : 8, shift = a.out16 ? L - 2 : L - 1; // 16-byte pieces of the chunk per lane; piece -> frame
+                v4i *dst4 = static_cast<v4i *>(out) + f * (a.out16 ? 256 : 512);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (i >= pieces) break;
+                    const int e = 64 * i + lane;
+                    if (f * FP + (size_t)(e >> shift) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 4 * e), dst4 + e);
+                }
+                wave_lds_fence();
+            } else if (f * FP + (size_t)lane_frame < nframes_user) {
                 if (a.out16) {
                     typedef u32 v2u __attribute__((ext_vector_type(2)));
                     u32 *dst = static_cast<u32 *>(out) + f * 1024 + lane_off;
