@@ -149,6 +149,30 @@ def test_two_pass_n2pow19_n2pow20(log2n, batch, monkeypatch):
         assert info["kernel_name"] == "k_big2x_a/k_big2x_b", info
 
 
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+def test_two_pass_cores_own_orders_chunked_n2pow20(direction, monkeypatch):
+    """N = 2^20 in the cores' own orders (int_fftNk: HALVES in / BITREV out; int_ifftNk: BITREV in / HALVES out) on the two-pass tiles,
+    with a batch beyond one scratch half: the chunks alternate between two streams (32-frame halves) -- frames around the chunk borders
+    against the oracle, the whole batch against the one-stream run and against the three-pass plan; a full-scale frame included."""
+    n = 1 << 20
+    x = uniform_frames(70, n, 15, 4100)
+    x[33] = uniform_frames(1, n, 16, 17)[0]
+    kw = dict(in_order="HALVES", out_order="BITREV") if direction == "FWD" else dict(direction="INV", in_order="BITREV", out_order="HALVES")
+    got, info = run_gpu(x, 20, 16, 16, 0, 0, True, **kw)
+    assert info["n_passes"] == 2 and "k_big2x" in info["kernel_name"], info
+    sel = [0, 31, 32, 33, 63, 64, 69]
+    assert np.array_equal(got[sel], run_ref(x[sel], 20, 16, 16, 0, 0, True, **kw))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_ONE_STREAM", "1")
+        got1, _ = run_gpu(x, 20, 16, 16, 0, 0, True, **kw)
+    assert np.array_equal(got, got1)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_TWOPASS", "1")
+        got3, info3 = run_gpu(x[:40], 20, 16, 16, 0, 0, True, **kw)
+        assert info3["n_passes"] == 3, info3
+    assert np.array_equal(got[:40], got3)
+
+
 @pytest.mark.parametrize("log2n", [17, 18])
 @pytest.mark.parametrize("out_order", ["NATURAL", "BITREV"])
 def test_two_pass_32_register_first_pass(log2n, out_order, monkeypatch):
