@@ -37,6 +37,10 @@ static inline int64_t wrap128(i128 v, int w)
 
 /* round-half-up of v/2: int_dif2_fly.vhd:196-217, row_twiddle_tay.vhd:176-196 */
 static inline int64_t rhu2(int64_t v) { return (v >> 1) + (v & 1); }
+/* ... of the exact (w + 1)-bit sum / difference of two w-bit values, w up to 64 (the sum of two 64-bit operands does not fit int64: found by
+ * tools/fuzz_soak.py against the Python twin and the GPU, DATA_WIDTH = 64 with RNDMODE = 1); the low 64 bits are what orc_wrap keeps */
+static inline int64_t rhu2_sum(int64_t a, int64_t b) { return (int64_t)(((__int128)a + (__int128)b + 1) >> 1); }
+static inline int64_t rhu2_diff(int64_t a, int64_t b) { return (int64_t)(((__int128)a - (__int128)b + 1) >> 1); }
 
 static inline size_t bitrev(size_t v, int bits)
 {
@@ -269,10 +273,10 @@ void orc_dif_fly(const orc_params *p, int stage, int dtw, int odd, orc_cplx a, o
         d.re = (a.re >> 1) - (b.re >> 1);
         d.im = (a.im >> 1) - (b.im >> 1);
     } else if (scale) { /* xROUND :167-219 */
-        s.re = orc_wrap(rhu2(a.re + b.re), wo);
-        s.im = orc_wrap(rhu2(a.im + b.im), wo);
-        d.re = orc_wrap(rhu2(a.re - b.re), wo);
-        d.im = orc_wrap(rhu2(a.im - b.im), wo);
+        s.re = orc_wrap(rhu2_sum(a.re, b.re), wo);
+        s.im = orc_wrap(rhu2_sum(a.im, b.im), wo);
+        d.re = orc_wrap(rhu2_diff(a.re, b.re), wo);
+        d.im = orc_wrap(rhu2_diff(a.im, b.im), wo);
     } else { /* xUNSCALED :221-241 */
         s.re = a.re + b.re;
         s.im = a.im + b.im;
@@ -322,10 +326,10 @@ void orc_dit_fly(const orc_params *p, int stage, int dtw, int odd, orc_cplx a, o
         y->re = (a.re >> 1) - (t.re >> 1);
         y->im = (a.im >> 1) - (t.im >> 1);
     } else if (scale) { /* xROUND :164-217 */
-        x->re = orc_wrap(rhu2(a.re + t.re), wo);
-        x->im = orc_wrap(rhu2(a.im + t.im), wo);
-        y->re = orc_wrap(rhu2(a.re - t.re), wo);
-        y->im = orc_wrap(rhu2(a.im - t.im), wo);
+        x->re = orc_wrap(rhu2_sum(a.re, t.re), wo);
+        x->im = orc_wrap(rhu2_sum(a.im, t.im), wo);
+        y->re = orc_wrap(rhu2_diff(a.re, t.re), wo);
+        y->im = orc_wrap(rhu2_diff(a.im, t.im), wo);
     } else {
         x->re = a.re + t.re;
         x->im = a.im + t.im;

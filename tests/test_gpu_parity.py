@@ -426,7 +426,7 @@ def test_headline_magnitude_votes(log2n):
 
 W64_CASES = [(32, 16, 1, 0, True), (32, 24, 1, 0, True), (32, 24, 1, 0, False), (24, 24, 1, 0, True), (28, 18, 1, 0, True), (40, 16, 0, 0, True),
              (44, 16, 0, 1, True), (48, 24, 0, 0, True), (36, 16, 1, 0, False), (50, 16, 1, 0, True), (54, 10, 1, 0, True), (33, 26, 0, 1, True),
-             (64, 16, 0, 0, True), (60, 16, 0, 1, False)]
+             (64, 16, 0, 0, True), (60, 16, 0, 1, False), (64, 16, 0, 1, True)]
 
 
 @pytest.mark.parametrize("case", W64_CASES)
@@ -452,7 +452,7 @@ def test_wave_kernel_64_bit_results(case, monkeypatch):
 
 
 W64_INV_CASES = [(26, 16, 1, 0, True), (34, 24, 1, 0, True), (34, 24, 1, 0, False), (30, 18, 1, 0, True), (40, 16, 0, 0, True), (44, 16, 0, 1, True),
-                 (48, 24, 0, 0, True), (42, 16, 1, 0, False), (50, 10, 1, 0, True), (33, 26, 0, 1, True), (64, 16, 0, 0, True)]
+                 (48, 24, 0, 0, True), (42, 16, 1, 0, False), (50, 10, 1, 0, True), (33, 26, 0, 1, True), (64, 16, 0, 0, True), (64, 16, 0, 1, True)]
 
 
 @pytest.mark.parametrize("case", W64_INV_CASES)

@@ -27,6 +27,8 @@ CONFIGS = [
     (5, 44, 16, 1, 0, True),    # trpl18
     (4, 42, 16, 1, 0, False),   # OLD: trpl18 from w = 43
     (5, 8, 8, 0, 0, True),
+    (5, 64, 16, 0, 1, True),    # 64-bit data, round mode: the exact 65-bit sums (the C oracle's int64 rhu2 overflowed here until round 3)
+    (4, 64, 16, 0, 0, True),
 ]
 
 

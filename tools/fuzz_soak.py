@@ -1,0 +1,78 @@
+"""tools/fuzz_soak.py [seconds] [seed] -- open-ended parity fuzz on the GPU box (diagnostics; the seeded, bounded fuzz sets live in tests/).
+Random elaboratable generics (NFFT 3..20, DATA_WIDTH 4..64, TWDL_WIDTH 8..26, every mode / direction / XSERIES / order pair, ragged
+batches; now and then the 2-D scheme with a random split): whatever kernel the planner picks must equal the C oracle bit for bit.
+Prints one line per mismatch (none expected) and a summary of the kernels that were exercised."""
+import collections
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from intfftk_amd import IntFFTCore
+from oracle import oracle_c as C
+from tests.helpers import edge_frames, uniform_frames
+
+DIR = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}
+ORD = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
+NP = {2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    seen = collections.Counter()
+    bad = done = 0
+    t0 = time.time()
+    while time.time() - t0 < budget:
+        log2n = int(rng.choice([3, 4, 5, 6, 6, 7, 7, 8, 9, 10, 10, 11, 12, 12, 13, 14, 15, 16, 17, 18, 19, 20]))
+        fmt = int(rng.integers(0, 2))
+        rnd = 0 if fmt else int(rng.integers(0, 2))
+        dw = int(rng.choice([16, 16, 16, 12, 14, 24, 32, int(rng.integers(4, 65))]))
+        tw = int(rng.choice([16, 16, 24, int(rng.integers(8, 27))]))
+        new = bool(rng.integers(0, 2))
+        d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
+        in_o, out_o = (list(ORD)[int(rng.integers(0, 4))], list(ORD)[int(rng.integers(0, 4))]) if rng.random() < 0.4 else ("NATURAL", "NATURAL")
+        l1 = 0
+        if log2n >= 6 and rng.random() < 0.15:
+            l1 = int(rng.integers(3, log2n - 2)) if rng.random() < 0.6 or log2n < 13 else 10 if log2n >= 20 else l1
+        p = C.make_params(log2n, dw, tw, fmt, rnd, new)
+        if l1:
+            if in_o == "BITREV_LANES" or out_o == "BITREV_LANES" or C.lib().orc_validate_2d(p, l1, DIR[d]) != 0:
+                continue
+        elif C.lib().orc_validate(p, DIR[d]) != 0:
+            continue
+        n = 1 << log2n
+        batch = int(rng.integers(1, 4)) if log2n >= 17 else int(rng.integers(1, 40)) if log2n >= 12 else int(rng.integers(1, 300))
+        bits = dw if rng.random() < 0.5 else max(2, dw - 1)
+        x = uniform_frames(batch, n, bits, int(rng.integers(1, 1 << 30)))
+        if rng.random() < 0.3:
+            x = np.concatenate([x, edge_frames(n, dw)[: 1 + int(rng.integers(0, 6))]])
+        try:
+            core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW" if new else "OLD", d, in_o, out_o, NFFT1=l1)
+        except Exception as exc:  # the planner refuses what the oracle accepts: report it
+            print("PLAN-REFUSED", (log2n, dw, tw, fmt, rnd, new, d, in_o, out_o, l1), repr(exc)[:120], flush=True)
+            bad += 1
+            continue
+        y = core(torch.from_numpy(np.ascontiguousarray(x.astype(NP[core.in_container]))).cuda())
+        torch.cuda.synchronize()
+        got = y.cpu().numpy().astype(np.int64)
+        name = core.info["kernel_name"]
+        core.close()
+        want = (C.execute_2d(x, p, l1, DIR[d], ORD[in_o], ORD[out_o], form=1) if l1
+                else C.execute(x, p, DIR[d], ORD[in_o], ORD[out_o], form=1))
+        seen[name] += 1
+        done += 1
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad += 1
+            print("MISMATCH", (log2n, dw, tw, fmt, rnd, new, d, in_o, out_o, l1, batch, bits), name, flush=True)
+    print("fuzz_soak: %d configurations in %.0f s, %d mismatches" % (done, time.time() - t0, bad))
+    for k, v in seen.most_common():
+        print("  %5d  %s" % (v, k))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
