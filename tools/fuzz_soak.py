@@ -27,16 +27,19 @@ def main():
     bad = done = 0
     t0 = time.time()
     while time.time() - t0 < budget:
-        log2n = int(rng.choice([3, 4, 5, 6, 6, 7, 7, 8, 9, 10, 10, 11, 12, 12, 13, 14, 15, 16, 17, 18, 19, 20]))
+        big = os.environ.get("FUZZ_BIG") == "1"  # the multi-pass families: long frames, mostly 16-bit data, the tiled 2-D plans
+        log2n = int(rng.choice([13, 14, 15, 16, 17, 18, 19, 19, 20, 20] if big else [3, 4, 5, 6, 6, 7, 7, 8, 9, 10, 10, 11, 12, 12, 13, 14, 15, 16, 17, 18, 19, 20]))
         fmt = int(rng.integers(0, 2))
         rnd = 0 if fmt else int(rng.integers(0, 2))
-        dw = int(rng.choice([16, 16, 16, 12, 14, 24, 32, int(rng.integers(4, 65))]))
+        dw = int(rng.choice([16, 16, 16, 16, 16, 12, 14, 24] if big else [16, 16, 16, 12, 14, 24, 32, int(rng.integers(4, 65))]))
         tw = int(rng.choice([16, 16, 24, int(rng.integers(8, 27))]))
         new = bool(rng.integers(0, 2))
         d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
         in_o, out_o = (list(ORD)[int(rng.integers(0, 4))], list(ORD)[int(rng.integers(0, 4))]) if rng.random() < 0.4 else ("NATURAL", "NATURAL")
         l1 = 0
-        if log2n >= 6 and rng.random() < 0.15:
+        if big and log2n == 20 and rng.random() < 0.3:
+            l1, log2n = 10, int(rng.choice([20, 20, 21, 22]))
+        elif log2n >= 6 and rng.random() < 0.15:
             l1 = int(rng.integers(3, log2n - 2)) if rng.random() < 0.6 or log2n < 13 else 10 if log2n >= 20 else l1
         p = C.make_params(log2n, dw, tw, fmt, rnd, new)
         if l1:
@@ -45,7 +48,7 @@ def main():
         elif C.lib().orc_validate(p, DIR[d]) != 0:
             continue
         n = 1 << log2n
-        batch = int(rng.integers(1, 4)) if log2n >= 17 else int(rng.integers(1, 40)) if log2n >= 12 else int(rng.integers(1, 300))
+        batch = int(rng.integers(1, 3)) if log2n >= 21 else int(rng.integers(1, 4)) if log2n >= 17 else int(rng.integers(1, 40)) if log2n >= 12 else int(rng.integers(1, 300))
         bits = dw if rng.random() < 0.5 else max(2, dw - 1)
         x = uniform_frames(batch, n, bits, int(rng.integers(1, 1 << 30)))
         if rng.random() < 0.3:
