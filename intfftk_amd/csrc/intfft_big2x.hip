@@ -27,6 +27,20 @@
 #define INTFFT_NT_LOADS 1
 #include "intfft_pk16.hpp"
 
+// memory policy of the two hot passes (round-4 A/B variants: tools/build_variant.sh <name> intfft_big2x.hip -DINTFFT_2XA_PLAIN ...; the
+// counters per variant are in DESIGN.md section 4.2d).  Shipped: non-temporal loads of the user array in pass A, non-temporal stores of
+// the user array in pass B.
+#ifdef INTFFT_2XA_PLAIN
+#define INTFFT_2XA_LD(p) (*(p))
+#else
+#define INTFFT_2XA_LD(p) INTFFT_LD(p)
+#endif
+#ifdef INTFFT_2XB_PLAIN
+#define INTFFT_2XB_ST(x, p) (*(p) = (x))
+#else
+#define INTFFT_2XB_ST(x, p) __builtin_nontemporal_store(x, p)
+#endif
+
 #include <cstdlib>
 
 namespace intfft {
@@ -67,7 +81,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     const unsigned lfull = chunk * 16 + l;              // n9..n0
     const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
     auto ld = [&](unsigned uniform_idx, unsigned thread_off, u32 &wa, u32 &wb) {
-        const uint2 w = (twf + uniform_idx)[thread_off];
+        const uint2 w = ld2_at32(twf + uniform_idx, thread_off);
         wa = w.x;
         wb = w.y;
     };
@@ -131,13 +145,13 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
             const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = INTFFT_LD(sh + ((size_t)j << (RB + 10)) + toff_l);
+                const v2u w = INTFFT_2XA_LD(at32(sh + ((size_t)j << (RB + 10)), toff_l));
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + 10)) + toff_l); // regs = n(L-1)..n(L-5)
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_2XA_LD(at32(src + ((size_t)j << (RB + 10)), toff_l)); // regs = n(L-1)..n(L-5)
         }
         round1_tw(toff_l);
         // guard-bit vote of the tile (closed under stages L-1..10); the barrier also orders the previous frame's LDS reads
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
             }
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (L - 5)))[toff2_l] = v[q]; // [q][c][hi][k][l]: 2 KiB (L = 19: 1 KiB) per register
+        for (int q = 0; q < 32; ++q) *at32(dst + ((size_t)q << (L - 5)), toff2_l) = v[q]; // [q][c][hi][k][l]: 2 KiB (L = 19: 1 KiB) per register
     }
     (void)T;
 }
@@ -271,12 +285,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
     const v2s sh5 = {s5, s5};
     const v2s none = {0, 0};
-    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
-
-    for (size_t t = blockIdx.x;; t += gridDim.x) { // gridDim.x is a multiple of 16: slot and part are fixed per block
-        const size_t G = (t >> 4) * 8u + slot;
+    // ONE block finishes both `rest` partners (the two 64-byte halves of every output line), one after the other: round 3 gave them to blocks
+    // b and b + 8 (same XCD, same time), whose non-temporal half-line stores then left the L2 as 1.20 x the bytes (TCC_EA0_WRREQ, also in the
+    // store-only skeleton tools/reqbench.hip: 1.29 x); from one block in sequence 1.02 x at the same or a slightly better rate
+    for (size_t t = blockIdx.x;; t += gridDim.x) {
+        const size_t G = t;
         const size_t frame = G >> (RL - 1);
         if (frame >= nframes) break;
+        for (unsigned part = 0; part < 2; ++part) {
         const unsigned rest = (part << (RL - 1)) | ((unsigned)G & ((1u << (RL - 1)) - 1u));
         const unsigned q0 = rest & 31u, hi = rest >> 5;
         const u32 *src = scr + (frame << L) + ((size_t)q0 << (L - 5)) + (hi << 8); // wave-uniform
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (L - 10)) + toff_l); // c = (j, n4)
+        for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 10)), toff_l)); // c = (j, n4)
         // kind of this tile's inputs = n10 = q0 bit 0 (pass A left Y >> 1 there); vote on the tile's own inputs
         const unsigned k10 = pre_all ? 1u : (q0 & 1u); // (pre_all: the 2-D scheme's column pass left Y >> 1 everywhere)
         const short sa = (short)(1 - (int)k10);
@@ -332,7 +348,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 32; ++q) __builtin_nontemporal_store(v[q], dst + ((size_t)rev5c(q) << (L - 5)) + toff2_l);
+            for (int q = 0; q < 32; ++q) INTFFT_2XB_ST(v[q], at32(dst + ((size_t)rev5c(q) << (L - 5)), toff2_l));
+        }
         }
     }
 }
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)rev5c(q) << (L - 5)) + toff2_l); // core position (rho, jj << 5 | q) = X[brev_L]
+            for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)rev5c(q) << (L - 5)), toff2_l)); // core position (rho, jj << 5 | q) = X[brev_L]
         }
         bool fast = false;
         {
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             dit_top16<false>(v, wa16, wb16, sl);
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) (dst + ((size_t)j << (L - 10)))[toff_l] = v[j];
+        for (int j = 0; j < 32; ++j) *at32(dst + ((size_t)j << (L - 10)), toff_l) = v[j];
     }
 }
 
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)q << (L - 5)) + toff2_l);
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
         bool fast = false;
         {
             u32 acc = 0;
@@ -545,7 +562,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         RoundTwQ t2;
         u32 wa16[8], wb16[8];
         auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
-            const uint2 w = (twf + uniform_idx)[toff_l];
+            const uint2 w = ld2_at32(twf + uniform_idx, toff_l);
             wa = w.x, wb = w.y;
         };
         ld((1u << (L - 5)) - 1u, t2.wa1[0], t2.wb1[0]);
@@ -584,11 +601,11 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const v2u w = {v[j], v[j + 16]};
-                __builtin_nontemporal_store(w, d2 + ((size_t)j << (RB + 10)) + toff_l);
+                __builtin_nontemporal_store(w, at32(d2 + ((size_t)j << (RB + 10)), toff_l));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << (RB + 10)) + toff_l);
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (RB + 10)), toff_l));
         }
     }
 }
@@ -647,7 +664,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // store side, thread = (jx = rho9..5, l), regs q = rho4..0: pass B's layout [q][c][hi][k][l] (LR = 10) or natural [rho][n2]
     const unsigned toff2 = PASSB ? (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l
                                  : ((unsigned)hx << (5 + LR)) | lfull;
-    const u32 *const twp = tw2d + ((size_t)chunk << 14) + ((unsigned)hx << 9) + (unsigned)l; // [chunk][rho = jx << 5 | q][l]
+    const u32 *const twu = tw2d + ((size_t)chunk << 14); // [chunk][rho = jx << 5 | q][l]
+    const unsigned twoff = ((unsigned)hx << 9) + (unsigned)l;
     const v2s none = {0, 0};
     const short s5 = (short)(1 - (hx & 1)); // round 2: the kind of its inputs is rho5 = jx bit 0
     const v2s sh5 = {s5, s5};
@@ -663,13 +681,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = INTFFT_LD(sh + ((size_t)j << (RB + LR)) + toff_l);
+                const v2u w = INTFFT_LD(at32(sh + ((size_t)j << (RB + LR)), toff_l));
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + LR)) + toff_l);
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (RB + LR)), toff_l));
         }
         round1_tw(hx_l);
         bool fast = false;
@@ -694,7 +712,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
         u32 tw[32]; // the inter-core twiddles of this thread's 32 results (L2-resident slice of the table: one dword each)
 #pragma unroll
-        for (int q = 0; q < 32; ++q) tw[q] = twp[16 * q];
+        for (int q = 0; q < 32; ++q) tw[q] = *at32(twu + 16 * q, twoff);
 #pragma unroll
         for (int q = 0; q < 32; ++q) v[q] = rd_base[ROWX * q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
@@ -726,7 +744,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int i = 0; i < 4; ++i) v[q + i] = y[i];
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << (PASSB ? L - 5 : LR)))[toff2_l] = v[q];
+        for (int q = 0; q < 32; ++q) *at32(dst + ((size_t)q << (PASSB ? L - 5 : LR)), toff2_l) = v[q];
     }
 }
 
@@ -826,7 +844,7 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
     static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
     const bool fx = twd == 16 && allow_fast;
     const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);
-    const size_t ntiles = nframes << 6, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;
+    const size_t ntiles = nframes << 5, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16; // (a block of pass B takes both partner tiles)
     const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);
     if (fx) {
         allow_max_lds(kptr(k_big2x_b<20, true>));
@@ -861,7 +879,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned lfull = chunk * 16 + l;
     const unsigned toff = ((unsigned)hx << 10) | lfull; // user side: thread (hx = r4..r0 after the transpose, l)
     const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l; // scratch side: r = hx << 5 | q
-    const u32 *const twp = tw2d + ((size_t)chunk << 14) + ((unsigned)hx << 9) + (unsigned)l; // [chunk][r = hx << 5 | q][l]
+    const u32 *const twu = tw2d + ((size_t)chunk << 14); // [chunk][r = hx << 5 | q][l]
+    const unsigned twoff = ((unsigned)hx << 9) + (unsigned)l;
     // round 2 (regs = r9..r5, thread = r4..r0 = hx): STAGE 5 + b on reg bit b, twiddle index (jj << 5) | hx; DIT packing; frame invariant
     u32 wa16[8], wb16[8];
     RoundTwQ t2;
@@ -890,9 +909,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32], tw[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)q << (L - 5)) + toff2_l);
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) tw[q] = twp[16 * q];
+        for (int q = 0; q < 32; ++q) tw[q] = *at32(twu + 16 * q, twoff);
         // T = V conj(W): T.re = V.re wr + V.im wi, T.im = V.im wr - V.re wi = the DIT butterfly's multiplier with Wc = (wr, wi) -- the table
         // entry itself -- and Wd = (-wi, wr); plain 16-bit results (exact extraction: DIT stages form A >> 1 and T >> 1 themselves)
         const v2s mp = {-1, 1};
@@ -934,11 +953,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const v2u w = {v[j], v[j + 16]};
-                __builtin_nontemporal_store(w, d2 + ((size_t)j << (RB + 10)) + toff_l);
+                __builtin_nontemporal_store(w, at32(d2 + ((size_t)j << (RB + 10)), toff_l));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << (RB + 10)) + toff_l);
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (RB + 10)), toff_l));
         }
     }
 }
@@ -1047,6 +1066,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
     for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
     for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+#define INTFFT_2XB_SHIFT 1 /* a block of pass B takes both partner tiles */
+#define INTFFT_2XA_LAUNCH(LL, FX) hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves);
 #define INTFFT_2X_LAUNCH(LL, FX)                                                                                                   \
     {                                                                                                                              \
         constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
@@ -1060,8 +1081,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
         const size_t cap = 64;                                                                                                     \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
-        hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
-        const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
+        INTFFT_2XA_LAUNCH(LL, FX)                                                                                                  \
+        const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
         if (out_bitrev) hipLaunchKernelGGL((k_big2x_b<LL, FX, true>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0); \
         else hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);      \

@@ -27,6 +27,28 @@
 
 namespace intfft {
 
+// (wave-uniform pointer)[per-thread 32-bit element offset] formed as SGPR base + zero-extended 32-bit VGPR BYTE offset: the saddr form of
+// global_load / global_store.  Written as p[off] the compiler re-associates (base + thread offset) + constant, keeps the sum in a VGPR
+// pair and spends a v_add_co / v_addc pair on every access (k_big2x_a: 186 of its 1300 VALU operations per thread and tile).  The base
+// goes through an opaque SGPR pair (as a global-address-space pointer: through a generic one the accesses would become flat_*).
+template <typename T> using gptr_t = T __attribute__((address_space(1))) *;
+template <typename T> __device__ __forceinline__ gptr_t<T> at32(T *uniform_base, unsigned elem_off)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    gptr_t<B> g = (gptr_t<B>)uniform_base;
+    asm("" : "+s"(g));
+    return (gptr_t<T>)(g + (size_t)(elem_off * (unsigned)sizeof(T)));
+}
+
+// a uint2 table entry through at32 (HIP's vector structs do not copy out of an address-space-qualified reference)
+__device__ __forceinline__ uint2 ld2_at32(const uint2 *uniform_base, unsigned elem_off)
+{
+    typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+    const v2u_t x = *at32(reinterpret_cast<const v2u_t *>(uniform_base), elem_off);
+    return make_uint2(x.x, x.y);
+}
+
+
 // KIND_TWMUL / KIND_TWMULC: the inter-pass twiddle multiply of the N > 512K "2-D scheme" (DESIGN.md section 4.5):
 // a pointwise Y = cmult(V, W_N^(k1*n2)) (forward) / T = V * conj(W) through the re/im-swapped feed (inverse)
 enum StageKind : int { KIND_DIF = 0, KIND_DIT = 1, KIND_TWMUL = 2, KIND_TWMULC = 3 };

@@ -1,0 +1,364 @@
+// intfft_fast16k.hip -- ONE-pass block kernels for N = 8192 and N = 16384: int_fftNk / int_ifftNk with NFFT = 13, 14, DATA_WIDTH = 16
+// (or 9 .. 15 in int16 containers), TWDL_WIDTH <= 16, scaled-truncate, natural order in and out
+// (src/vhdl/fft/int_fftNk.vhd:75,184-207: NFFT is a free generic; a 32 / 64 KiB frame fits one workgroup's LDS, so these lengths need not
+// take the two HBM passes of the N >= 2^15 plans).  Same packed arithmetic as intfft_fast1024.hip / intfft_fast4096.hip (intfft_pk16.hpp).
+//
+// One workgroup of 2^(L-5) threads owns one frame, 32 packed (re | im << 16) samples per thread, persistent loop over frames.
+// L stages = three in-register rounds (5 + 5 + 4 stages at L = 14; 5 + 4 + 4 at L = 13) with two block-wide LDS transposes:
+//
+//   layout A  reg j = n(L-1)..n(L-5), thread = n(L-6)..n0              DIF L-1..L-5      / DIT L-5..L-1      per-thread twiddles, re-read per frame
+//   layout B  reg q = n8..n4,         thread = (jx = n(L-1)..n9, l = n3..n0)   DIF 8..4 (L = 13: 7..4, n8 rides along) / DIT 4..8   twiddles per l, parked in LDS
+//   layout C  reg r = n4..n0,         thread t3 = rev(n(L-1)..n5)      DIF 3..0 / DIT 0..3 on the two 16-register halves (n4 rides along), wave-uniform twiddles
+//
+// The forward core stores from layout C with the bit reversal (int_bitrev_order / outbuf_half_path) folded into the thread mapping:
+// X[brev_L(n)] = out[rev5(r) << (L-5) | t3], every store instruction 256 contiguous bytes per wave; the inverse core loads the same way.
+// Layout A <-> B goes through LDS rows (row = n(L-1)..n4, 17 dwords apart), B <-> C through rows of 32 + 1 dwords indexed by
+// R = (the five low bits of t3) | (the other bits of n8..n5 in natural order) << 5: the 32 lanes of a b32 access then hit 32 banks on
+// the C side and at most two lanes share one on the B side.  Both transposes share one region (4 barriers per frame).
+// Twiddles: quarter-turn sharing as in intfft_big2x.hip (W[k + 2^(s-1)] = (W[k].im, -W[k].re), rom_twiddle_int.vhd:177-183, checked by the
+// planner on the plan's own tables -- STAGE 11, 12, 13 are Taylor stages, row_twiddle_tay.vhd:123-268).
+#include "intfft_pk16.hpp"
+
+#include <cstdlib>
+
+namespace intfft {
+
+constexpr int ROWP = 17; // transpose A <-> B: LDS row stride in dwords (16 columns + 1)
+constexpr int ROWQ = 33; // transpose B <-> C: 32 columns + 1
+
+// DIF stages 3, 2, 1, 0 on v[B .. B+15] (reg = n3..n0), wave-uniform twiddles; P0: PREMASK of the inputs (0xF: they hold X >> 1)
+template <bool FASTX, int B, int P0> __device__ __forceinline__ void dif_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
+{
+    const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    group4<false, FASTX, false, true, true, P0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
+    group4<false, FASTX, false, true, true, P0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
+    group4<false, FASTX, false, true, true, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+    group4<false, FASTX, false, true, true, 0xF>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+#pragma unroll
+    for (int g = B; g < B + 16; g += 8) { // stage 1: kind = r & 4
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_mj<false, false>(v[g + 1], v[g + 3]);
+        bfly_triv<false, true>(v[g + 4], v[g + 6]);
+        bfly_mj<false, true>(v[g + 5], v[g + 7]);
+    }
+#pragma unroll
+    for (int g = B; g < B + 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
+}
+
+// DIT stages 0, 1, 2, 3 on v[B .. B+15], wave-uniform twiddles in the DIT packing
+template <bool FASTX, int B> __device__ __forceinline__ void dit_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
+{
+#pragma unroll
+    for (int g = B; g < B + 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+#pragma unroll
+    for (int g = B; g < B + 16; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
+        bfly_triv<false, false>(v[g], v[g + 2]);
+        bfly_pj_dit<false>(v[g + 1], v[g + 3]);
+    }
+    group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, 0, true>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+    const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+    const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
+    group4_dit<FASTX, true, 0, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
+}
+
+__device__ __forceinline__ constexpr int rev5k(int r) { return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4); }
+
+enum { M16_FWD = 0, M16_INV = 1 };
+
+template <int L, int MODE, bool FAST_OK>
+__global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft16k_i16(const u32 *in, u32 *out, const uint2 *__restrict__ twf,
+                                                                                                          const RoundCConsts c, size_t nframes, const Slice sl)
+{
+    static_assert(L == 13 || L == 14, "one workgroup per frame of 8192 / 16384 points");
+    constexpr int RB = L - 9; // thread bits above l in layouts A and B
+    constexpr bool DIT = MODE == M16_INV;
+    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWP (covers the 2^(L-5) rows x ROWQ of the second transpose), then layout B's twiddles
+    uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWP);
+    const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
+
+    // layout B's twiddles (STAGE 4 + b on reg bit b of q, table index (rr << 4) | l): frame invariant, one set per column l, parked once.
+    // slots: [STAGE 8: 8 (L = 14 only)] [STAGE 7: 4] [STAGE 6: 2] [STAGE 5: 1] [STAGE 4: 1]
+    if (hx == 0) {
+        int s = 0;
+        auto park = [&](unsigned idx) {
+            uint2 w = twf[idx + (unsigned)l];
+            if (DIT) to_dit_packing(w.x, w.y);
+            tw2[16 * s++ + l] = w;
+        };
+        if constexpr (RB == 5)
+            for (int rr = 0; rr < 8; ++rr) park(255u + ((unsigned)rr << 4));
+        for (int rr = 0; rr < 4; ++rr) park(127u + ((unsigned)rr << 4));
+        for (int rr = 0; rr < 2; ++rr) park(63u + ((unsigned)rr << 4));
+        park(31u);
+        park(15u);
+    }
+    auto tw_b = [&](u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) {
+        int s = 0;
+        auto get = [&](u32 &wa, u32 &wb) {
+            const uint2 w = tw2[16 * s++ + l];
+            wa = w.x, wb = w.y;
+        };
+        if constexpr (RB == 5) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) get(wat[rr], wbt[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) get(t.wa8[rr], t.wb8[rr]);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) get(t.wa4[rr], t.wb4[rr]);
+        get(t.wa2[0], t.wb2[0]);
+        get(t.wa1[0], t.wb1[0]);
+    };
+    // layout A's twiddles (STAGE L-5 + b on reg bit b of j, table index (jj << (L-5)) | tid): per thread, re-read from the L2-resident table
+    // in every frame (held over the loop they cost 32 VGPRs: spills, as in k_big2p_a)
+    auto tw_a = [&](unsigned to, u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) {
+        auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
+            const uint2 w = ld2_at32(twf + uniform_idx, to);
+            wa = w.x, wb = w.y;
+        };
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ld((1u << (L - 1)) - 1u + ((unsigned)jj << (L - 5)), wat[jj], wbt[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ld((1u << (L - 2)) - 1u + ((unsigned)jj << (L - 5)), t.wa8[jj], t.wb8[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ld((1u << (L - 3)) - 1u + ((unsigned)jj << (L - 5)), t.wa4[jj], t.wb4[jj]);
+        ld((1u << (L - 4)) - 1u, t.wa2[0], t.wb2[0]);
+        ld((1u << (L - 5)) - 1u, t.wa1[0], t.wb1[0]);
+    };
+
+    // transpose addressing.  A <-> B: element (row = n(L-1)..n4, column l)
+    u32 *const a_base = lds + ROWP * hx + l;        // layout A thread (hx = n(L-6)..n4, l): row (j << RB) | hx
+    u32 *const b_base = lds + ROWP * (hx << 5) + l; // layout B thread (jx = hx, l):         row (jx << 5) | q
+    // B <-> C: row R of ROWQ dwords, column n4..n0.  Layout C thread t3 = rev(n(L-1)..n5): bit i = n(L-1-i).
+    //   L = 14: R = rev5(jx) | (n8..n5 = q >> 1) << 5;           t3 = rev5(jx) | rev4(q >> 1) << 5
+    //   L = 13: R = rev4(jx) | (n8 = q >> 4) << 4 | (n7..n5 = (q >> 1) & 7) << 5;   t3 = rev4(jx) | n8 << 4 | rev3(n7..n5) << 5
+    const unsigned rjx = __brev((unsigned)hx) >> (32 - RB);
+    u32 *const bq_base = lds + ROWQ * rjx + l; // + ROWQ * rowq_of(q) + ((q & 1) << 4)
+    const unsigned t3 = (unsigned)tid;
+    const unsigned rc = RB == 5 ? ((t3 & 31u) | ((__brev(t3 >> 5) >> 28) << 5)) : ((t3 & 31u) | ((__brev(t3 >> 5) >> 29) << 5));
+    u32 *const c_base = lds + ROWQ * rc;
+    const short s2 = (short)(1 - (hx & 1)); // L = 14, layout B: the kind of its inputs is n9 = jx bit 0
+    const v2s sh2 = {s2, s2};
+    const v2s none = {0, 0};
+    (void)sh2;
+
+    for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
+        const u32 *src = in + (f << L); // wave-uniform
+        u32 *dst = out + (f << L);
+        unsigned tid_l = (unsigned)tid; // opaque copy: keeps the per-access addresses out of loop-invariant VGPR pairs (see k_big2p_a)
+        asm volatile("" : "+v"(tid_l));
+        u32 v[32];
+        if constexpr (!DIT) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 5)), tid_l)); // layout A
+        } else {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) v[r] = INTFFT_LD(at32(src + ((size_t)rev5k(r) << (L - 5)), tid_l)); // layout C: position (t3, r) = X[brev_L]
+        }
+        u32 wat[8], wbt[8];
+        RoundTwQ ta;
+        if constexpr (!DIT) tw_a(tid_l, wat, wbt, ta);
+        // guard-bit vote of the frame (closed under all L stages); the barrier also orders the previous frame's LDS reads
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
+            fast = FAST_OK && bad == 0;
+        }
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
+
+        if constexpr (!DIT) {
+            // ---- layout A: DIF L-1 .. L-5 ----
+            if (fast) {
+                dif_top16<FAST_OK, 0, false>(v, wat, wbt, sl, none);
+                dif_round_q<FAST_OK, 0, 0, false>(v, ta, sl, none);
+                dif_round_q<FAST_OK, 16, 0xF, false>(v, ta, sl, none);
+            } else {
+                dif_top16<false, 0, false>(v, wat, wbt, sl, none);
+                dif_round_q<false, 0, 0, false>(v, ta, sl, none);
+                dif_round_q<false, 16, 0xF, false>(v, ta, sl, none);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a_base[ROWP * (j << RB)] = v[j];
+            __syncthreads();
+            u32 wa2t[8], wb2t[8];
+            RoundTwQ tb;
+            tw_b(wa2t, wb2t, tb);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = b_base[ROWP * q];
+            // ---- layout B: DIF 8 .. 4 (L = 13: 7 .. 4 on the two halves; the kind of their inputs is n8 = q bit 4) ----
+            if constexpr (RB == 4) {
+                if (fast) {
+                    dif_round_q<FAST_OK, 0, 0, false>(v, tb, sl, none);
+                    dif_round_q<FAST_OK, 16, 0xF, false>(v, tb, sl, none);
+                } else {
+                    dif_round_q<false, 0, 0, false>(v, tb, sl, none);
+                    dif_round_q<false, 16, 0xF, false>(v, tb, sl, none);
+                }
+            } else {
+                if (fast) {
+                    dif_top16<FAST_OK, 0, true>(v, wa2t, wb2t, sl, sh2);
+                    dif_round_q<FAST_OK, 0, 0, false>(v, tb, sl, none);
+                    dif_round_q<FAST_OK, 16, 0xF, false>(v, tb, sl, none);
+                } else {
+                    dif_top16<false, 0, true>(v, wa2t, wb2t, sl, sh2);
+                    dif_round_q<false, 0, 0, false>(v, tb, sl, none);
+                    dif_round_q<false, 16, 0xF, false>(v, tb, sl, none);
+                }
+            }
+            __syncthreads(); // every thread has read its A -> B rows: the region may take the B -> C rows
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int rq = RB == 5 ? ((q >> 1) << 5) : (((q >> 4) << 4) | (((q >> 1) & 7) << 5));
+                bq_base[ROWQ * rq + ((q & 1) << 4)] = v[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) v[r] = c_base[r];
+            // ---- layout C: DIF 3 .. 0 on the halves n4 = 0 / 1 (the upper half holds Y >> 1 of STAGE 4) ----
+            if (fast) {
+                dif_round4_c<FAST_OK, 0, 0>(v, c, sl);
+                dif_round4_c<FAST_OK, 16, 0xF>(v, c, sl);
+            } else {
+                dif_round4_c<false, 0, 0>(v, c, sl);
+                dif_round4_c<false, 16, 0xF>(v, c, sl);
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev5k(r) << (L - 5)), tid_l));
+        } else {
+            // ---- layout C: DIT 0 .. 3 ----
+            if (fast) {
+                dit_round4_c<FAST_OK, 0>(v, c, sl);
+                dit_round4_c<FAST_OK, 16>(v, c, sl);
+            } else {
+                dit_round4_c<false, 0>(v, c, sl);
+                dit_round4_c<false, 16>(v, c, sl);
+            }
+#pragma unroll
+            for (int r = 0; r < 32; ++r) c_base[r] = v[r];
+            __syncthreads();
+            u32 wa2t[8], wb2t[8];
+            RoundTwQ tb;
+            tw_b(wa2t, wb2t, tb);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int rq = RB == 5 ? ((q >> 1) << 5) : (((q >> 4) << 4) | (((q >> 1) & 7) << 5));
+                v[q] = bq_base[ROWQ * rq + ((q & 1) << 4)];
+            }
+            // ---- layout B: DIT 4 .. 8 (L = 13: 4 .. 7) ----
+            if (fast) {
+                dit_round_q<FAST_OK, 0>(v, tb, sl);
+                dit_round_q<FAST_OK, 16>(v, tb, sl);
+                if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa2t, wb2t, sl);
+            } else {
+                dit_round_q<false, 0>(v, tb, sl);
+                dit_round_q<false, 16>(v, tb, sl);
+                if constexpr (RB == 5) dit_top16<false>(v, wa2t, wb2t, sl);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 32; ++q) b_base[ROWP * q] = v[q];
+            tw_a(tid_l, wat, wbt, ta); // in flight across the barrier (the data registers are free here)
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v[j] = a_base[ROWP * (j << RB)];
+            to_dit_packing(ta.wa1[0], ta.wb1[0]);
+            to_dit_packing(ta.wa2[0], ta.wb2[0]);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) to_dit_packing(ta.wa4[jj], ta.wb4[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) to_dit_packing(ta.wa8[jj], ta.wb8[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) to_dit_packing(wat[jj], wbt[jj]);
+            // ---- layout A: DIT L-5 .. L-1 ----
+            if (fast) {
+                dit_round_q<FAST_OK, 0>(v, ta, sl);
+                dit_round_q<FAST_OK, 16>(v, ta, sl);
+                dit_top16<FAST_OK>(v, wat, wbt, sl);
+            } else {
+                dit_round_q<false, 0>(v, ta, sl);
+                dit_round_q<false, 16>(v, ta, sl);
+                dit_top16<false>(v, wat, wbt, sl);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (L - 5)), tid_l));
+        }
+    }
+}
+
+bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order)
+{
+    return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
+           use_fly == 1 && (direction == 0 || direction == 1) && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
+}
+
+// the quarter-turn relation of the shared-twiddle rounds (stages 5 .. L-1), checked on the plan's generated tables (host copy); the inverse
+// negates packed 16-bit twiddle halves, so no entry may be -2^15
+bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd)
+{
+    for (int s = 5; s < log2n; ++s) {
+        const int2 *t = h_tw + ((size_t)1 << s) - 1;
+        const size_t h = (size_t)1 << (s - 1);
+        for (size_t k = 0; k < h; ++k) {
+            const int neg = (int)(((long long)(-t[k].x) << (64 - twd)) >> (64 - twd));
+            if (t[k + h].x != t[k].y || t[k + h].y != neg) return false;
+            if (t[k].x == -32768 || t[k].y == -32768) return false;
+        }
+    }
+    return true;
+}
+
+const char *fast16k_kernel_name() { return "k_fft16k_i16"; }
+
+template <int L, int MODE, bool FX>
+static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream)
+{
+    constexpr int RB = L - 9, T = 16 << RB;
+    const size_t ldsb = (size_t)(32 << RB) * ROWP * sizeof(u32) + (size_t)(RB == 5 ? 16 : 8) * 16 * sizeof(uint2);
+    allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX>));
+    const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
+    const unsigned blocks = (unsigned)(nframes < cap ? nframes : cap);
+    hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,
+                          int data_width)
+{
+    if (nframes == 0) return hipSuccess;
+    RoundCConsts c;
+    for (int k = 0; k < 8; ++k) {
+        const int2 w = h_tw[7 + k];
+        c.wa3[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb3[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int2 w = h_tw[3 + k];
+        c.wa2[k] = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        c.wb2[k] = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    }
+    if (direction == 1) to_dit_packing_host(c);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    if (data_width != 16) sl.set_width(data_width);
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const u32 *pin = static_cast<const u32 *>(in);
+    u32 *pout = static_cast<u32 *>(out);
+#define INTFFT_16K(LL)                                                                                                              \
+    if (direction == 0) return fx ? launch16k<LL, M16_FWD, true>(pin, pout, tw16f, c, nframes, sl, stream)                        \
+                                  : launch16k<LL, M16_FWD, false>(pin, pout, tw16f, c, nframes, sl, stream);                       \
+    return fx ? launch16k<LL, M16_INV, true>(pin, pout, tw16f, c, nframes, sl, stream)                                             \
+              : launch16k<LL, M16_INV, false>(pin, pout, tw16f, c, nframes, sl, stream);
+    if (log2n == 13) {
+        INTFFT_16K(13)
+    }
+    INTFFT_16K(14)
+#undef INTFFT_16K
+}
+
+} // namespace intfft

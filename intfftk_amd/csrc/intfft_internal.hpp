@@ -285,6 +285,12 @@ int order_mem_bit(int order, int L, int j); // memory-index bit that carries log
 hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj,
                         int twd, size_t nframes, hipStream_t stream);
 
+// packed int16 block kernels for N = 8192 / 16384 in one pass, FWD / INV (intfft_fast16k.hip)
+bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order);
+bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd);
+hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,
+                          int data_width);
+const char *fast16k_kernel_name();
 // packed int16 block kernel for N = 4096, FWD / INV / PAIR (intfft_fast4096.hip)
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,
                         int in_order, int out_order);

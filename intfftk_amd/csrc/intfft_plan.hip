@@ -132,6 +132,7 @@ struct intfft_plan {
     size_t scratch_frames = 0, scratch_bytes = 0;
     bool fast1024 = false;
     bool fast4096 = false;
+    bool fast16k = false;  // N = 8192 / 16384, 16-bit scaled-truncate FWD / INV in ONE pass (intfft_fast16k.hip)
     bool fast1024x = false;
     bool fast1024u = false;
     bool fast1024ux = false;
@@ -724,6 +725,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                                                        p->direction, p->use_fly, p->in_order, p->out_order);
     pl->fast4096 = !generic_only && !pl->fast1024 && fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode,
                                                        p->direction, p->use_fly, p->in_order, p->out_order);
+    pl->fast16k = !generic_only && fast16k_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order,
+                                                    p->out_order) &&
+                  fast16k_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
     pl->fast1024x = !generic_only && fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                         p->use_fly, p->in_order, p->out_order);
     pl->fast1024u = !generic_only && fast1024u_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
@@ -820,6 +824,17 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     }
     if (pl->fastsmall) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastsmall_kernel_name());
+    } else if (pl->fast16k) {
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast16k_kernel_name());
+        const size_t total = ((size_t)1 << pl->L) - 1; // the packed dot-product operand forms of the whole table
+        hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
+        if (e == hipSuccess) e = launch_pack_twiddles16(pl->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            intfft_plan_destroy(pl);
+            return (int)e;
+        }
     } else if (pl->fastw64b) {
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fastw64b_kernel_name(p->direction));
     } else if (pl->fastw64) {
@@ -1007,7 +1022,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->out_bits = plan->out_bits;
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
-    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
+    const bool fast = plan->fast1024 || plan->fast4096 || plan->fast16k || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
     if (plan->pair_buf) {
         intfft_plan_info sf, si;
         if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK || intfft_plan_get_info(plan->pair_i, &si) != INTFFT_OK) return INTFFT_ERR_INVALID;
@@ -1242,6 +1257,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream, plan->p.rndmode, plan->p.data_width);
+    if (plan->fast16k)
+        return (int)launch_fast16k(plan->p.log2n, plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw16f, plan->h_tw.data(), batch, stream,
+                                   plan->p.data_width);
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
                                     plan->p.direction == INTFFT_FWD ? plan->p.out_order == INTFFT_ORDER_BITREV

@@ -166,13 +166,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const size_t fstep = gridDim.x >> 4;
     for (size_t f = blockIdx.x >> 4; f < nframes; f += fstep) {
         int re[16], im[16];
-        const int2 *src = in + f * 65536 + c + 256 * hi4;
+        const int2 *src = in + f * 65536; // wave-uniform; the thread's part is toff (at32: SGPR base + 32-bit VGPR offset, no 64-bit VALU address arithmetic)
+        unsigned toff = (unsigned)(c + 256 * hi4);
+        asm volatile("" : "+v"(toff)); // opaque per iteration: hoisted out of the frame loop the zero-extended offset becomes a VGPR pair again
         const bool partial = L < 16 && (f + 1) * G > nframes_user; // last group: rows of absent frames read as 0, are not stored
         typedef int v2i __attribute__((ext_vector_type(2)));
         if (!partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2i x = INTFFT_LD(reinterpret_cast<const v2i *>(src + 4096 * j));
+                const v2i x = INTFFT_LD(at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff));
                 re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
                 im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
             }
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 16; ++j) { // r = 16 j + hi4: real frame g = r >> (L - 8) = j >> (L - 12)
                 v2i x = {0, 0};
-                if (f * G + (size_t)(j >> (L - 12)) < nframes_user) x = *reinterpret_cast<const v2i *>(src + 4096 * j);
+                if (f * G + (size_t)(j >> (L - 12)) < nframes_user) x = *at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff);
                 re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw);
                 im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
             }
@@ -215,9 +217,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // within a unit the 4096 samples are laid out [column tile c7..4][t4][c3..0] (round 3; [t4][c] before): the 256 threads of this
         // workgroup then store 2 KiB runs (L = 16: one run per register) instead of 128-byte pieces 2 KiB apart, and pass 2 reads the
         // unit as sixteen 2 KiB runs, one per register
-        int2 *dst = scr + f * 65536 + 256 * tile + lo4 + 4096 * (g << (L - 12)) + 16 * ((hi4 << (16 - L)) & 15);
+        int2 *dst = scr + f * 65536;
+        unsigned toff2 = (unsigned)(256 * tile + lo4 + 4096 * (g << (L - 12)) + 16 * ((hi4 << (16 - L)) & 15));
+        asm volatile("" : "+v"(toff2));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dst[4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12))] = make_int2(re[q], im[q]);
+        for (int q = 0; q < 16; ++q) {
+            const v2i y = {re[q], im[q]};
+            *at32(reinterpret_cast<v2i *>(dst + 4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12))), toff2) = y;
+        }
     }
 }
 
@@ -347,10 +354,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
         if (L < 16 && real >= nframes_user) continue;
         i64 re[16], im[16];
-        const int2 *src = scr + f * 65536 + 4096 * r0 + 16 * hi4 + lo4; // unit layout [c7..4 = q][t4 = hi4][c3..0]: 2 KiB per register
+        const int2 *src = scr + f * 65536 + 4096 * r0; // unit layout [c7..4 = q][t4 = hi4][c3..0]: 2 KiB per register; thread part = tid
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        unsigned tid_l = (unsigned)tid;
+        asm volatile("" : "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int2 x = src[256 * q];
+            const v2i x = *at32(reinterpret_cast<const v2i *>(src + 256 * q), tid_l);
             re[q] = x.x;
             im[q] = x.y;
         }
@@ -404,11 +414,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         //   = 2^(L-4) rev4(c3..0) + 2^(L-8) rev4(c7..4) + 16 brev_(L-12)(low) + rev4(t4)      (L = 16: low = r0, t4 = j)
         typedef i64 v2l __attribute__((ext_vector_type(2)));
         const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
-        v2l *dst = reinterpret_cast<v2l *>(out) + (real << L) + (rev4w(hi4) << (L - 8)) + 16 * rlow + rev4w(lo4);
+        v2l *dst = reinterpret_cast<v2l *>(out) + (real << L) + 16 * rlow; // wave-uniform
+        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4));
+        asm volatile("" : "+v"(toff));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const v2l y = {re[q], im[q]};
-            __builtin_nontemporal_store(y, dst + ((size_t)rev4w(q) << (L - 4)));
+            __builtin_nontemporal_store(y, at32(dst + ((size_t)rev4w(q) << (L - 4)), toff));
         }
     }
 }

@@ -119,7 +119,10 @@ def test_three_pass_kernels_n8192_to_n524288(log2n, batch):
     x = uniform_frames(batch, n, 15, 2000 + log2n)
     x[0] = uniform_frames(1, n, 16, 7)[0]  # one full-scale frame: exact extraction in its tiles
     info = check(x, log2n, 16, 16, 0, 0, True)
-    assert info["kernel_name"].startswith("k_big2") and info["n_passes"] == 2
+    if log2n <= 14:  # one pass since round 4
+        assert info["kernel_name"] == "k_fft16k_i16" and info["n_passes"] == 1, info
+    else:
+        assert info["kernel_name"].startswith("k_big2") and info["n_passes"] == 2
     if batch <= 9:
         check(x, log2n, 16, 13, 0, 0, False)  # narrower twiddles, XSER "OLD"
 
@@ -216,6 +219,40 @@ def test_two_pass_32_register_inverse(log2n, in_order, out_order, monkeypatch):
     assert info3["n_passes"] == 3 and np.array_equal(got2, got3)
 
 
+@pytest.mark.parametrize("log2n", [13, 14])
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+def test_single_pass_n8192_n16384(log2n, direction, monkeypatch):
+    """N = 8192 / 16384, 16-bit scaled-truncate, natural order: ONE pass (k_fft16k_i16: a workgroup per frame, three register rounds
+    around two LDS transposes, int_fftNk.vhd:75,184-207 / int_ifftNk.vhd:183-341) against the oracle and against the two-pass plan it
+    replaces (INTFFT_NO_FAST16K); batches of one frame, fewer frames than workgroups, more frames than the resident grid; a
+    full-scale frame (exact extraction), edge frames, XSER "OLD" with narrower twiddles, narrow data (DATA_WIDTH 12 and 9)."""
+    n = 1 << log2n
+    for batch in (1, 3, 1500 if log2n == 13 else 700):
+        x = uniform_frames(batch, n, 15, 4100 + log2n + batch)
+        x[0] = uniform_frames(1, n, 16, 13)[0]
+        if batch > 2:
+            x[1] = -(1 << 15)
+            x[2] = 0
+            x[2, 1] = (1 << 14, -(1 << 14))
+        a, ia = run_gpu(x, log2n, 16, 16, 0, 0, True, direction=direction)
+        assert ia["kernel_name"] == "k_fft16k_i16" and ia["n_passes"] == 1 and ia["fast_path"] == 1, ia
+        sel = [0, 1, 2, batch - 1] if batch > 2 else list(range(batch))
+        assert np.array_equal(a[sel], run_ref(x[sel], log2n, 16, 16, 0, 0, True, direction=direction))
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_FAST16K", "1")
+            b, ib = run_gpu(x, log2n, 16, 16, 0, 0, True, direction=direction)
+            assert ib["n_passes"] == 2, ib
+        assert np.array_equal(a, b)
+    x = uniform_frames(5, n, 15, 4200 + log2n)
+    check(x, log2n, 16, 13, 0, 0, False, direction=direction)  # exact extraction (t != 16), XSER "OLD"
+    check(x, log2n, 16, 9, 0, 0, True, direction=direction)
+    for dw in (12, 9):
+        xs = uniform_frames(4, n, dw - 1, 4300 + dw)
+        xs[3] = uniform_frames(1, n, 16, 5)[0]  # containers beyond DATA_WIDTH: wrapped on load like conv_std_logic_vector
+        info = check(xs, log2n, dw, 16, 0, 0, True, direction=direction)
+        assert info["kernel_name"] == "k_fft16k_i16", info
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
 @pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "NATURAL", "NATURAL"), ("FWD", "HALVES", "NATURAL"),
                                                              ("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
@@ -231,6 +268,10 @@ def test_two_pass_vs_three_pass_split(log2n, batch, direction, time_order, freq_
     x[batch // 2] = uniform_frames(1, n, 16, 9)[0]
     kw = (dict(direction=direction, in_order=time_order, out_order=freq_order) if direction == "FWD"
           else dict(direction=direction, in_order=freq_order, out_order=time_order))
+    # natural <-> natural at N = 8192 / 16384 is ONE pass since round 4 (k_fft16k_i16, test_single_pass_n8192_n16384): the two-pass
+    # split is then the A/B form behind INTFFT_NO_FAST16K
+    if log2n <= 14 and time_order == "NATURAL" and freq_order == "NATURAL":
+        monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     a, ia = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
     two = {("FWD", "NATURAL"): "k_big20_p1/k_mid_p2", ("FWD", "BITREV"): "k_big20_p1/k_mid_c",
            ("INV", "NATURAL"): "k_mid_q1/k_big20_q1", ("INV", "BITREV"): "k_mid_c/k_big20_q1"}[(direction, freq_order)]
@@ -253,9 +294,10 @@ def test_multi_pass_kernels_small_batches(log2n, batch):
     x[0] = uniform_frames(1, n, 16, 11)[0]
     for direction in ("FWD", "INV", "PAIR"):
         info = check(x, log2n, 16, 16, 0, 0, True, direction=direction)
-        assert "k_big20" in info["kernel_name"], info
+        assert ("k_big20" if log2n > 14 or direction == "PAIR" else "k_fft16k_i16") in info["kernel_name"], info
     for kw in (dict(in_order="HALVES", out_order="BITREV"), dict(direction="INV", in_order="BITREV", out_order="HALVES")):
-        check(x, log2n, 16, 16, 0, 0, True, **kw)
+        info = check(x, log2n, 16, 16, 0, 0, True, **kw)
+        assert "k_big20" in info["kernel_name"] or "k_mid" in info["kernel_name"], info
     for direction in ("FWD", "INV"):  # general widths: unscaled 16-bit, 12-bit scaled-round
         info = check(x, log2n, 16, 16, 1, 0, True, direction=direction)
         assert info["kernel_name"].startswith("k_bigw"), info
@@ -294,7 +336,10 @@ def test_three_pass_inverse_n8192_to_n2pow20(log2n, batch):
     x = uniform_frames(batch, n, 15, 4000 + log2n)
     x[0] = uniform_frames(1, n, 16, 9)[0]
     info = check(x, log2n, 16, 16, 0, 0, True, direction="INV")
-    assert ("k_big2" in info["kernel_name"]) and info["n_passes"] == 2
+    if log2n <= 14:  # one pass since round 4 (test_single_pass_n8192_n16384)
+        assert info["kernel_name"] == "k_fft16k_i16" and info["n_passes"] == 1, info
+    else:
+        assert ("k_big2" in info["kernel_name"]) and info["n_passes"] == 2
     if batch <= 9 and log2n < 20:
         check(x, log2n, 16, 13, 0, 0, False, direction="INV")
 
@@ -936,7 +981,7 @@ def test_narrow_data_multi_pass(log2n, batch, dw, tw, direction):
     x = np.concatenate([uniform_frames(batch, n, dw - 1, 400 + dw), uniform_frames(2, n, dw, 401 + dw), uniform_frames(1, n, 16, 402 + dw),
                         uniform_frames(1, n, dw - 1, 403 + dw)])
     info = check(x, log2n, dw, tw, 0, 0, True, direction=direction)
-    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big", "k_mid")), info
+    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big", "k_mid", "k_fft16k")), info  # (N = 8192 / 16384 FWD / INV: one pass)
     if log2n in (13, 16):
         for in_order, out_order in ([("HALVES", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES")] if direction == "INV" else []):
             check(x[:batch + 2], log2n, dw, tw, 0, 0, True, direction=direction, in_order=in_order, out_order=out_order)

@@ -35,7 +35,8 @@ NFFT1 = {}  # spec -> log2 N1 of a 2-D scheme plan (spec "L:DW:TW:FMT:RND:DIR:L1
 CONFIGS["C2native"] = (10, 16, 16, 0, 0, "FWD", 65536, 15, 8)
 
 
-def run(name, steps=20, check_frames=8):
+def run(name, steps=None, check_frames=8):
+    steps = steps or int(os.environ.get("BENCH_STEPS", "20"))  # (PMC passes serialise every launch: BENCH_STEPS / BENCH_RAMP_S shorten them)
     log2n, dw, tw, fmt, rnd, direction, batch, bits, bps = CONFIGS[name]
     n = 1 << log2n
     in_o, out_o = ORDERS.get(name, ("NATURAL", "NATURAL"))
@@ -48,7 +49,7 @@ def run(name, steps=20, check_frames=8):
     st = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
     calls = steps
-    while time.time() - t0 < 0.25:  # clock ramp
+    while time.time() - t0 < float(os.environ.get("BENCH_RAMP_S", "0.25")):  # clock ramp
         for _ in range(10):
             core.exec_raw(x.data_ptr(), y.data_ptr(), batch, st)
         calls += 10
