@@ -91,6 +91,10 @@ def pmc_digest(config="C2"):
             out = dict(k)
             out["hbm_bytes_per_launch"] = d["hbm_bytes_per_call"]
             out["traffic_over_algorithmic"] = d.get("traffic_over_algorithmic")
+            # VALU wave-instructions of ONE intfft_exec call: every kernel of the plan x its launches per call
+            out["valu_insts_per_call"] = sum(float(v.get("SQ_INSTS_VALU", 0.0)) * float(v.get("launches_per_call", 1.0))
+                                             for v in d["kernels"].values())
+            out["digest_batch"] = d.get("batch")
             return os.path.relpath(path, ROOT), out
         except Exception:
             continue
@@ -205,11 +209,13 @@ def event_ms(torch, fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def ceilings(torch, x, y, stream, digest, c2):
+def ceilings(torch, x, y, stream, digest, c2, samples_per_call=None, copy=True):
     L = diag_lib()
     if L is None:
         return {"note": "tools/lib/libintfft_diag.so not built"}
     out = {}
+    if not copy:
+        return valu_rates(torch, L, stream, digest, c2, samples_per_call, out)
     nframes = x.numel() * x.element_size() // 4096
     fn = L.diag_copy_wave_ld if hasattr(L, "diag_copy_wave_ld") else L.diag_copy_wave_nt
     copy = lambda: fn(x.data_ptr(), y.data_ptr(), nframes, 4, stream)  # noqa: E731
@@ -226,6 +232,13 @@ def ceilings(torch, x, y, stream, digest, c2):
             copy2()
         ms2 = event_ms(torch, copy2, 50)
         out["copy_ceiling"]["nt_loads_too_GB/s"] = 2.0 * nframes * 4096 / (ms2 * 1e-3) / 1e9
+    return valu_rates(torch, L, stream, digest, c2, samples_per_call, out)
+
+
+def valu_rates(torch, L, stream, digest, c2, samples_per_call, out):
+    """The VALU-issue bound of this configuration: the slow-class issue rate measured in this run (v_pk_*, v_dot2_i32_i16, v_perm_b32,
+    v_bfe_i32, v_mad_i64_i32 ... all issue at ~4.4 clk per wave-instruction on gfx950) over the plan's SQ_INSTS_VALU per call from
+    the committed PMC digest of the same command."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     scratch = torch.empty(cus * 4 * 256, dtype=torch.int32, device="cuda")
     n = ctypes.c_ulonglong()
@@ -249,6 +262,12 @@ def ceilings(torch, x, y, stream, digest, c2):
         vb["value"] = rates[1] / insts * 1024 / 1e9
         vb["unit"] = "Gsample/s"
         vb["note"] = "bound if every VALU instruction of the kernel (SQ_INSTS_VALU of the committed PMC digest) issued at the slow-class rate"
+    elif (not c2) and digest and digest.get("valu_insts_per_call") and samples_per_call:
+        vb["valu_insts_per_call"] = digest["valu_insts_per_call"]
+        vb["value"] = rates[1] / float(digest["valu_insts_per_call"]) * samples_per_call / 1e9
+        vb["unit"] = "Gsample/s"
+        vb["note"] = ("bound if every VALU instruction of the plan's kernels (sum of SQ_INSTS_VALU x launches per call, committed PMC "
+                      "digest) issued at the slow-class rate")
     out["valu_bound"] = vb
     return out
 
@@ -489,6 +508,9 @@ def main():
         }
         if e2e:
             out["e2e"] = e2e
+        elif args.e2e:
+            out["e2e"] = None
+            out["e2e_note"] = "--e2e covers the int16 -> int16 configurations (C2, C5); not measured for %s" % args.config
         if extras:
             out["cold"] = cold
             xf = make_input(batch, n, seed, 0, full_scale=True, dw=dw)
@@ -503,8 +525,21 @@ def main():
             del xf
             step()  # y := transform(x) again for the parity gate below
             torch.cuda.synchronize()
-            if args.config in ("C2", "C5"):  # the copy ceiling is the single-pass kernels' access pattern (one wave per 4 KiB)
-                out.update(ceilings(torch, x, torch.empty_like(x), stream, digest, args.config == "C2" and batch == 65536))
+            # the copy ceiling is the single-pass kernels' access pattern (one wave per 4 KiB): C2 / C5; the VALU-issue bound: every config
+            same_batch = bool(digest) and digest.get("digest_batch") in (None, batch)
+            out.update(ceilings(torch, x, torch.empty_like(x) if args.config in ("C2", "C5") else None, stream, digest if same_batch else None,
+                                args.config == "C2" and batch == 65536, samples_per_call=float(batch) * n, copy=args.config in ("C2", "C5")))
+            vb = out.get("valu_bound", {})
+            if vb.get("value"):  # name the roofline that binds this configuration: whichever of HBM bytes / VALU issue allows less
+                hbm_bound = HBM_PEAK_GBS / bytes_per_sample  # Gsample/s at 100 % of the HBM roofline
+                here = batch * n / kern_ms / 1e6
+                r = out["roofline"]
+                r["frac_hbm"] = r["frac"]
+                r["frac_valu"] = here / vb["value"]
+                r["bound"] = "valu" if vb["value"] < hbm_bound else "hbm"
+                r["bounds_Gsample_per_s"] = {"hbm": hbm_bound, "valu": vb["value"]}
+                r["note"] = ("`frac`, `achieved`, `peak` are the HBM figures (algorithmic bytes / kernel time over 8 TB/s) for every configuration; "
+                             "`bound` names the lower of the two ceilings, `frac_valu` = measured rate over the VALU-issue bound")
             out["octave"] = octave_probe()
         if world == 1 and not args.no_cpu_baseline:
             step()

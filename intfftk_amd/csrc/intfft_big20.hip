@@ -96,6 +96,9 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
     const short s2 = (short)(1 - (hx & 1)); // round 2: kind of the inputs = n(LOWB+4) = (tid >> 5) & 1
     const v2s sh2 = {s2, s2};
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = in + frame * ((size_t)1 << LV) + lfull;
         u32 *dst = scr + frame * ((size_t)1 << LV) + lfull;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
         }
         // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
         // the barrier also orders the previous frame's LDS reads before this frame's writes
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+        const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0);
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
         for (int j = 0; j < 2; ++j) ld_tw(twf, (1u << (LOWB + 1)) - 1u + lfull + (unsigned)j * ROW, t2.wa2[j], t2.wb2[j]);
         ld_tw(twf, ROW - 1u + lfull, t2.wa1[0], t2.wb1[0]);
     }
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = scr + frame * ((size_t)1 << LV) + lfull;
         u32 *dst = out + frame * ((size_t)1 << LV) + lfull;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
             for (int r = 0; r < 16; ++r) // thread hx = n19..16, regs = n15..12; (two-pass split: non-temporal loads +3 %, three-pass: -2 %)
                 v[r] = LOWB == 8 ? INTFFT_LD(src + ((size_t)(16 * hx + r) << LOWB)) : src[(size_t)(16 * hx + r) << LOWB];
         }
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0; // also orders the previous LDS reads
+        const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0); // also orders the previous LDS reads
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
@@ -405,6 +411,9 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
     const short sb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
     const v2s sh_b = {sb, sb};
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
         u32 *p = scr + b * 4096;
         // kind of this block's inputs = n12 = block index bit 0 (pass 1 left Y >> 1 where n12 = 1)
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(256) void k_big20_p2(u32 *scr, const int2 *__restri
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
-            fast = __syncthreads_or((acc & maskc) != 0) == 0;
+            fast = !block_any(vote_flags, vote_phase, (acc & maskc) != 0);
         }
         if (fast) dif_round<FAST_OK, true>(v, ta, sl, sh_a);
         else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, ta, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
@@ -483,7 +492,10 @@ __global__ __launch_bounds__(512) void k_big20_p3(const u32 *scr, u32 *out, cons
         u32 acc = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc |= v[r] + addc;
-        fast = __syncthreads_or((acc & maskc) != 0) == 0;
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+        fast = !block_any(vote_flags, vote_phase, (acc & maskc) != 0);
     }
     if (fast) dif_round_c<FAST_OK>(v, c, sl, sh3);
     else if (!FAST_OK && sl.round == 1) dif_round_c<false, 1>(v, c, sl, sh3); // RNDMODE = 1: plain values in every pass, exact extraction
@@ -527,7 +539,10 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
         u32 acc = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc |= v[j] + addc;
-        fast = __syncthreads_or((acc & maskc) != 0) == 0;
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+        fast = !block_any(vote_flags, vote_phase, (acc & maskc) != 0);
     }
     if (fast) dif_round<FAST_OK, true>(v, tb, sl, sh_a);
     else if (!FAST_OK && sl.round == 1) dif_round<false, true, 4, 1>(v, tb, sl, sh_a); // RNDMODE = 1: plain values in every pass, exact extraction
@@ -573,7 +588,10 @@ __global__ __launch_bounds__(512) void k_mid_q1(const u32 *in, u32 *scr, const i
     u32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = INTFFT_LD(src + ((size_t)rev4b(r) << (L - 4)));
-    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0; // the tile is closed under STAGE 0..7
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0); // the tile is closed under STAGE 0..7
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
     else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
@@ -619,7 +637,10 @@ __global__ __launch_bounds__(512) void k_big20_q3(const u32 *in, u32 *scr, const
     u32 v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = INTFFT_LD(src + ((size_t)rev4b(r) << (L - 4)));
-    const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0);
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
     if (fast) dit_round_c<FAST_OK>(v, c, sl);
     else if (!FAST_OK && sl.round == 1) dit_round_c<false, 1>(v, c, sl); // RNDMODE = 1: plain values in every pass, exact extraction
@@ -651,12 +672,15 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
     load_round_tw<8>(twt, tid, ta);   // STAGE 11..8, low = n7..0
     load_round_tw<4>(twt, lo4, tb);   // STAGE 7..4, low = n3..0
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t b = blockIdx.x; b < nblocks4k; b += gridDim.x) {
         u32 *p = scr + b * 4096;
         u32 v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
-        const bool fast = FAST_OK && __syncthreads_or(guard_acc(v, sl.gbias, sl.gmask) != 0) == 0;
+        const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0);
     if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads(); // orders the previous block's reg1 reads before this block's writes

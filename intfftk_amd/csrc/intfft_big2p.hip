@@ -107,6 +107,9 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
     const short s2 = (short)(1 - (hx & 1));
     const v2s sh2 = {s2, s2};
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = in + (frame << L); // wave-uniform
         u32 *dst = scr + (frame << L);
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0);
+            fast = FAST_OK && !bad;
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 #define INTFFT_2P_ROUND1(FX)                                                                                  \
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
     }
     u32 *const wr_base = lds + ROW2P * (hx << 5) + l;  // write side: row (hx << 5) + q
     const u32 *const rd_base = lds + ROW2P * hx + l;   // read side: row (j << RB) + p
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = scr + (frame << L);
         u32 *dst = out + (frame << L);
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             u32 acc = 0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
+            fast = FAST_OK && !bad;
         }
         const int rnd = FAST_OK ? 0 : sl.round; // RNDMODE = 1 on the exact-path instantiation (2: narrow data)
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // (first pass after k_mid_q1: already w-bit values; harmless)

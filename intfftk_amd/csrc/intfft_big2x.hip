@@ -80,8 +80,8 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
     const unsigned lfull = chunk * 16 + l;              // n9..n0
     const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
-    auto ld = [&](unsigned uniform_idx, unsigned thread_off, u32 &wa, u32 &wb) {
-        const uint2 w = ld2_at32(twf + uniform_idx, thread_off);
+    auto ld = [&](unsigned uniform_idx, unsigned thread_boff, u32 &wa, u32 &wb) { // thread_boff: BYTE offset of the thread's entry
+        const uint2 w = ld2_at32b(twf + uniform_idx, thread_boff);
         wa = w.x;
         wb = w.y;
     };
@@ -133,6 +133,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     const v2s none = {0, 0};
     const short s2 = (short)(1 - (hx & 1)); // L = 20, round 2: the kind of its inputs is n15 = bit 0 of the new thread index
     const v2s sh2 = {s2, s2};
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
 
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = in + (frame << L); // wave-uniform
@@ -153,15 +156,17 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int j = 0; j < 32; ++j) v[j] = INTFFT_2XA_LD(at32(src + ((size_t)j << (RB + 10)), toff_l)); // regs = n(L-1)..n(L-5)
         }
-        round1_tw(toff_l);
+        unsigned twb = toff_l * 8u;
+        asm volatile("" : "+v"(twb));
+        round1_tw(twb);
         // guard-bit vote of the tile (closed under stages L-1..10); the barrier also orders the previous frame's LDS reads
         bool fast = false;
         {
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0);
+            fast = FAST_OK && !bad;
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 #define INTFFT_2X_ROUND1(FX)                                                                                  \
@@ -285,6 +290,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
     const v2s sh5 = {s5, s5};
     const v2s none = {0, 0};
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     // ONE block finishes both `rest` partners (the two 64-byte halves of every output line), one after the other: round 3 gave them to blocks
     // b and b + 8 (same XCD, same time), whose non-temporal half-line stores then left the L2 as 1.20 x the bytes (TCC_EA0_WRREQ, also in the
     // store-only skeleton tools/reqbench.hip: 1.29 x); from one block in sequence 1.02 x at the same or a slightly better rate
@@ -312,8 +320,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc |= v[j] + addc;
-            const int bad = __syncthreads_or((acc & maskc) != 0); // also orders the previous tile's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & maskc) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
         }
         if (fast) {
             dif_top16<FAST_OK, 0, true>(v, wa16, wb16, sl, sh_a);
@@ -430,6 +438,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned toff2 = (rjj << (L - 10)) | (unsigned)kb;  // user side (round 1 thread)
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t t = blockIdx.x;; t += gridDim.x) {
         const size_t G = (t >> 4) * 8u + slot;
         const size_t frame = G >> (RL - 1);
@@ -458,8 +469,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             u32 acc = 0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
         if (fast) dit_round5_c<FAST_OK>(v, c, sl);
@@ -514,6 +525,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     u32 *const wr_base = lds + ROWX * (hx << 5) + l;  // round 1 thread (jx = tid >> 4, l): row (jx << 5) + q
     const u32 *const rd_base = lds + ROWX * hx + l;   // round 2 thread (hx, l): row (j << RB) + hx
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = scr + (frame << L);
         u32 *dst = out + (frame << L);
@@ -527,8 +541,8 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
             u32 acc = 0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous frame's LDS reads
+            fast = FAST_OK && !bad;
         }
         {
             RoundTwQ t1;
@@ -561,8 +575,10 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         // round 2's per-thread twiddles: STAGE L-5+b, index (jj << (RB + 10)) | toff: re-read per tile, converted to the DIT packing
         RoundTwQ t2;
         u32 wa16[8], wb16[8];
+        unsigned twb = toff_l * 8u; // the thread's byte offset into a stage table, opaque (see k_big2x_a)
+        asm volatile("" : "+v"(twb));
         auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
-            const uint2 w = ld2_at32(twf + uniform_idx, toff_l);
+            const uint2 w = ld2_at32b(twf + uniform_idx, twb);
             wa = w.x, wb = w.y;
         };
         ld((1u << (L - 5)) - 1u, t2.wa1[0], t2.wb1[0]);
@@ -670,11 +686,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const short s5 = (short)(1 - (hx & 1)); // round 2: the kind of its inputs is rho5 = jx bit 0
     const v2s sh5 = {s5, s5};
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = in + (frame << L);
         u32 *dst = scr + (frame << L);
-        unsigned toff_l = toff, toff2_l = toff2, hx_l = (unsigned)hx;
-        asm volatile("" : "+v"(toff_l), "+v"(toff2_l), "+v"(hx_l));
+        unsigned toff_l = toff, toff2_l = toff2, hx_l = (unsigned)hx, twoff_l = twoff;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l), "+v"(hx_l), "+v"(twoff_l));
         u32 v[32];
         if (halves) {
             typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -695,8 +714,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
         }
         if (fast) {
             dif_top16<FAST_OK, 0, false>(v, wa16, wb16, sl, none);
@@ -711,8 +730,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int j = 0; j < 32; ++j) wr_base[ROWX * (j << RB)] = v[j];
         __syncthreads();
         u32 tw[32]; // the inter-core twiddles of this thread's 32 results (L2-resident slice of the table: one dword each)
+        const gptr_t<const u32> twq = at32(twu, twoff_l);
 #pragma unroll
-        for (int q = 0; q < 32; ++q) tw[q] = *at32(twu + 16 * q, twoff);
+        for (int q = 0; q < 32; ++q) tw[q] = twq[16 * q]; // one SGPR base + thread offset, 64-byte steps in the immediate
 #pragma unroll
         for (int q = 0; q < 32; ++q) v[q] = rd_base[ROWX * q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
@@ -902,16 +922,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     u32 *const wr_base = lds + ROWX * (hx << 5) + l;  // round 1 thread (hx = r9..r5, l): row (hx << 5) + q
     const u32 *const rd_base = lds + ROWX * hx + l;   // round 2 thread (hx = r4..r0, l): row (j << 5) + hx
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = scr + (frame << L);
         u32 *dst = out + (frame << L);
-        unsigned toff_l = toff, toff2_l = toff2;
-        asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
+        unsigned toff_l = toff, toff2_l = toff2, twoff_l = twoff;
+        asm volatile("" : "+v"(toff_l), "+v"(toff2_l), "+v"(twoff_l));
         u32 v[32], tw[32];
+        const gptr_t<const u32> twq = at32(twu, twoff_l);
 #pragma unroll
         for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) tw[q] = *at32(twu + 16 * q, twoff);
+        for (int q = 0; q < 32; ++q) tw[q] = twq[16 * q]; // one SGPR base + thread offset, 64-byte steps in the immediate
         // T = V conj(W): T.re = V.re wr + V.im wi, T.im = V.im wr - V.re wi = the DIT butterfly's multiplier with Wc = (wr, wi) -- the table
         // entry itself -- and Wd = (-wi, wr); plain 16-bit results (exact extraction: DIT stages form A >> 1 and T >> 1 themselves)
         const v2s mp = {-1, 1};
@@ -928,8 +952,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             u32 acc = 0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0); // on the products (a rotation can use the guard bit up); also orders the previous frame's LDS reads
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // on the products (a rotation can use the guard bit up); also orders the previous frame's LDS reads
+            fast = FAST_OK && !bad;
         }
         if (fast) dit_round5_c<FAST_OK>(v, c, sl);
         else dit_round5_c<false>(v, c, sl);

@@ -40,6 +40,21 @@ template <typename T> __device__ __forceinline__ gptr_t<T> at32(T *uniform_base,
     return (gptr_t<T>)(g + (size_t)(elem_off * (unsigned)sizeof(T)));
 }
 
+// the same with the thread's BYTE offset given (one opaque 32-bit value shared by every access of a loop iteration)
+template <typename T> __device__ __forceinline__ gptr_t<T> at32b(T *uniform_base, unsigned byte_off)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    gptr_t<B> g = (gptr_t<B>)uniform_base;
+    asm("" : "+s"(g));
+    return (gptr_t<T>)(g + (size_t)byte_off);
+}
+__device__ __forceinline__ uint2 ld2_at32b(const uint2 *uniform_base, unsigned byte_off)
+{
+    typedef uint32_t v2u_t __attribute__((ext_vector_type(2)));
+    const v2u_t x = *at32b(reinterpret_cast<const v2u_t *>(uniform_base), byte_off);
+    return make_uint2(x.x, x.y);
+}
+
 // a uint2 table entry through at32 (HIP's vector structs do not copy out of an address-space-qualified reference)
 __device__ __forceinline__ uint2 ld2_at32(const uint2 *uniform_base, unsigned elem_off)
 {

@@ -114,9 +114,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
     };
     // layout A's twiddles (STAGE L-5 + b on reg bit b of j, table index (jj << (L-5)) | tid): per thread, re-read from the L2-resident table
     // in every frame (held over the loop they cost 32 VGPRs: spills, as in k_big2p_a)
-    auto tw_a = [&](unsigned to, u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) {
+    auto tw_a = [&](unsigned to, u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) { // to: the thread's BYTE offset into a stage table (8 tid)
         auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
-            const uint2 w = ld2_at32(twf + uniform_idx, to);
+            const uint2 w = ld2_at32b(twf + uniform_idx, to);
             wa = w.x, wb = w.y;
         };
 #pragma unroll
@@ -145,11 +145,14 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
     const v2s none = {0, 0};
     (void)sh2;
 
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64]; // (256 bytes: the dynamic LDS behind it keeps the alignment it had behind __syncthreads_or's own buffer)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
         const u32 *src = in + (f << L); // wave-uniform
         u32 *dst = out + (f << L);
-        unsigned tid_l = (unsigned)tid; // opaque copy: keeps the per-access addresses out of loop-invariant VGPR pairs (see k_big2p_a)
-        asm volatile("" : "+v"(tid_l));
+        unsigned tid_l = (unsigned)tid, twb = (unsigned)tid * 8u; // opaque copies: keep the per-access addresses out of loop-invariant VGPR pairs (see k_big2p_a)
+        asm volatile("" : "+v"(tid_l), "+v"(twb));
         u32 v[32];
         if constexpr (!DIT) {
 #pragma unroll
@@ -160,15 +163,15 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         }
         u32 wat[8], wbt[8];
         RoundTwQ ta;
-        if constexpr (!DIT) tw_a(tid_l, wat, wbt, ta);
+        if constexpr (!DIT) tw_a(twb, wat, wbt, ta);
         // guard-bit vote of the frame (closed under all L stages); the barrier also orders the previous frame's LDS reads
         bool fast = false;
         {
             u32 acc = 0;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
-            const int bad = __syncthreads_or((acc & sl.gmask) != 0);
-            fast = FAST_OK && bad == 0;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0);
+            fast = FAST_OK && !bad;
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 32; ++q) b_base[ROWP * q] = v[q];
-            tw_a(tid_l, wat, wbt, ta); // in flight across the barrier (the data registers are free here)
+            tw_a(twb, wat, wbt, ta); // in flight across the barrier (the data registers are free here)
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 32; ++j) v[j] = a_base[ROWP * (j << RB)];

@@ -233,6 +233,9 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
     }
     u32 y[4];
     if (QTURN) {
+        // W' = (W.im, -W.re): Y.re = dot(D, Wb), Y.im = dot(-D, Wa).  (Round 4 tried the negated TWIDDLE operand instead -- one packed
+        // subtract per distinct twiddle, shared by the compiler between the butterflies of a round: 49 fewer operations per thread and tile
+        // in k_big2x_a, but the longer live ranges spill 4-8 VGPRs there: C4 270 against 308 Gsample/s, N = 16384 449 against 541.)
         const v2s z = {0, 0};
         const u32 n[4] = {as_u32(z - as_v2s(d[0])), as_u32(z - as_v2s(d[1])), as_u32(z - as_v2s(d[2])),
                           as_u32(z - as_v2s(d[3]))};
@@ -357,6 +360,33 @@ __device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16], u32 gbia
 {
     return __builtin_amdgcn_ballot_w64(guard_acc(v, gbias, gmask) != 0) == 0;
 }
+// Block-wide "does any thread object?" with ONE barrier per call (HIP's __syncthreads_or is three: reset, or, read).  Three flag words
+// rotate: call k uses flag k mod 3; behind its barrier thread 0 clears flag (k + 2) mod 3 -- last read behind barrier k - 1, which
+// every thread has left, and first set behind barrier k + 1, which thread 0 has yet to reach -- so no reset can race a set or a read.
+// flags: three dwords of LDS, zeroed (+ one __syncthreads) before the first call; `phase` is the caller's wave-uniform call counter
+// mod 3 (block_any advances it).  Like __syncthreads_or the barrier also orders the caller's earlier LDS reads against its later writes.
+__device__ __forceinline__ bool block_any(u32 (&flags)[64], unsigned &phase, bool mine) // (a reference to the __shared__ array: through a volatile generic pointer the accesses become flat_* with vmcnt waits)
+{
+#ifdef INTFFT_VOTE_OCKL // A/B: HIP's own three-barrier reduction
+    (void)flags, (void)phase;
+    return __syncthreads_or(mine) != 0;
+#endif
+    if (mine) flags[phase] = 1u;
+    // LDS-only barrier: __syncthreads() is a full workgroup fence and would also wait for the global loads the callers keep in flight
+    // across the vote (the per-tile twiddle re-reads issued right behind the data loads): measured C4 288 against 305 Gsample/s
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool any = flags[phase] != 0u;
+    const unsigned clr = phase == 0 ? 2u : phase - 1u; // (phase + 2) mod 3
+    if (threadIdx.x == 0) flags[clr] = 0u;
+    phase = phase == 2 ? 0u : phase + 1u;
+    return any;
+}
+__device__ __forceinline__ void block_any_init(u32 (&flags)[64])
+{
+    if (threadIdx.x < 3) flags[threadIdx.x] = 0u;
+    __syncthreads();
+}
+
 // input wrap to DATA_WIDTH (conv_std_logic_vector) of int16 containers that hold more than w bits: exact path of narrow plans
 template <int NV> __device__ __forceinline__ void wrap_inputs(u32 (&v)[NV], int w)
 {
