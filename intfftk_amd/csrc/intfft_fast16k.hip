@@ -1,4 +1,4 @@
-// intfft_fast16k.hip -- ONE-pass block kernels for N = 8192 and N = 16384: int_fftNk / int_ifftNk with NFFT = 13, 14, DATA_WIDTH = 16
+// intfft_fast16k.hip -- ONE-pass block kernels for N = 8192 and N = 16384: int_fftNk / int_ifftNk / int_fft_ifft_pair with NFFT = 13, 14, DATA_WIDTH = 16
 // (or 9 .. 15 in int16 containers), TWDL_WIDTH <= 16, scaled-truncate, natural order in and out
 // (src/vhdl/fft/int_fftNk.vhd:75,184-207: NFFT is a free generic; a 32 / 64 KiB frame fits one workgroup's LDS, so these lengths need not
 // take the two HBM passes of the N >= 2^15 plans).  Same packed arithmetic as intfft_fast1024.hip / intfft_fast4096.hip (intfft_pk16.hpp).
@@ -46,8 +46,9 @@ template <bool FASTX, int B, int P0> __device__ __forceinline__ void dif_round4_
     for (int g = B; g < B + 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]);
 }
 
-// DIT stages 0, 1, 2, 3 on v[B .. B+15], wave-uniform twiddles in the DIT packing
-template <bool FASTX, int B> __device__ __forceinline__ void dit_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
+// DIT stages 0, 1, 2, 3 on v[B .. B+15], wave-uniform twiddles in the DIT packing (DITPACK) or -- the pair, which shares one set of
+// constants between its cores -- in the DIF packing through the re/im-swapped multiplier feed of int_dit2_fly.vhd:304-322
+template <bool FASTX, int B, bool DITPACK = true> __device__ __forceinline__ void dit_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
 {
 #pragma unroll
     for (int g = B; g < B + 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
@@ -56,17 +57,17 @@ template <bool FASTX, int B> __device__ __forceinline__ void dit_round4_c(u32 (&
         bfly_triv<false, false>(v[g], v[g + 2]);
         bfly_pj_dit<false>(v[g + 1], v[g + 3]);
     }
-    group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
-    group4_dit<FASTX, true, 0, true>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, 0, DITPACK>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, 0, DITPACK>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
-    group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
-    group4_dit<FASTX, true, 0, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
+    group4_dit<FASTX, true, 0, DITPACK>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
+    group4_dit<FASTX, true, 0, DITPACK>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
 }
 
 __device__ __forceinline__ constexpr int rev5k(int r) { return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4); }
 
-enum { M16_FWD = 0, M16_INV = 1 };
+enum { M16_FWD = 0, M16_INV = 1, M16_PAIR = 2 }; // PAIR: int_fft_ifft_pair (int_fft_ifft_pair.vhd:209-280): the forward core into the inverse core without leaving layout C
 
 template <int L, int MODE, bool FAST_OK>
 __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft16k_i16(const u32 *in, u32 *out, const uint2 *__restrict__ twf,
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
 {
     static_assert(L == 13 || L == 14, "one workgroup per frame of 8192 / 16384 points");
     constexpr int RB = L - 9; // thread bits above l in layouts A and B
-    constexpr bool DIT = MODE == M16_INV;
-    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWP (covers the 2^(L-5) rows x ROWQ of the second transpose), then layout B's twiddles
+    constexpr bool FWD_PART = MODE != M16_INV, INV_PART = MODE != M16_FWD;
+    constexpr int NSLOT = RB == 5 ? 16 : 8; // layout B's twiddle slots per packing
+    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWP (covers the 2^(L-5) rows x ROWQ of the second transpose), then layout B's twiddles (the pair: both packings)
     uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWP);
     const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
 
@@ -85,8 +87,10 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         int s = 0;
         auto park = [&](unsigned idx) {
             uint2 w = twf[idx + (unsigned)l];
-            if (DIT) to_dit_packing(w.x, w.y);
-            tw2[16 * s++ + l] = w;
+            if (FWD_PART) tw2[16 * s + l] = w; // DIF packing {Wa, Wb}
+            to_dit_packing(w.x, w.y);
+            if (INV_PART) tw2[16 * (s + (FWD_PART ? NSLOT : 0)) + l] = w; // DIT packing {Wc, Wd} (the pair: behind the forward set)
+            ++s;
         };
         if constexpr (RB == 5)
             for (int rr = 0; rr < 8; ++rr) park(255u + ((unsigned)rr << 4));
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         park(31u);
         park(15u);
     }
-    auto tw_b = [&](u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) {
-        int s = 0;
+    auto tw_b = [&](int s, u32(&wat)[8], u32(&wbt)[8], RoundTwQ &t) { // s: first slot of the packing wanted
+
         auto get = [&](u32 &wa, u32 &wb) {
             const uint2 w = tw2[16 * s++ + l];
             wa = w.x, wb = w.y;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         unsigned tid_l = (unsigned)tid, twb = (unsigned)tid * 8u; // opaque copies: keep the per-access addresses out of loop-invariant VGPR pairs (see k_big2p_a)
         asm volatile("" : "+v"(tid_l), "+v"(twb));
         u32 v[32];
-        if constexpr (!DIT) {
+        if constexpr (FWD_PART) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 5)), tid_l)); // layout A
         } else {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         }
         u32 wat[8], wbt[8];
         RoundTwQ ta;
-        if constexpr (!DIT) tw_a(twb, wat, wbt, ta);
+        if constexpr (FWD_PART) tw_a(twb, wat, wbt, ta);
         // guard-bit vote of the frame (closed under all L stages); the barrier also orders the previous frame's LDS reads
         bool fast = false;
         {
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 
-        if constexpr (!DIT) {
+        if constexpr (FWD_PART) {
             // ---- layout A: DIF L-1 .. L-5 ----
             if (fast) {
                 dif_top16<FAST_OK, 0, false>(v, wat, wbt, sl, none);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
             __syncthreads();
             u32 wa2t[8], wb2t[8];
             RoundTwQ tb;
-            tw_b(wa2t, wb2t, tb);
+            tw_b(0, wa2t, wb2t, tb);
 #pragma unroll
             for (int q = 0; q < 32; ++q) v[q] = b_base[ROWP * q];
             // ---- layout B: DIF 8 .. 4 (L = 13: 7 .. 4 on the two halves; the kind of their inputs is n8 = q bit 4) ----
@@ -231,23 +235,27 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dif_round4_c<false, 0, 0>(v, c, sl);
                 dif_round4_c<false, 16, 0xF>(v, c, sl);
             }
+            if constexpr (MODE == M16_FWD) {
 #pragma unroll
-            for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev5k(r) << (L - 5)), tid_l));
-        } else {
-            // ---- layout C: DIT 0 .. 3 ----
+                for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev5k(r) << (L - 5)), tid_l));
+            }
+        }
+        if constexpr (INV_PART) {
+            // ---- layout C: DIT 0 .. 3 (the pair: position n holds X[brev n], what int_ifftNk takes there; the constants stay in the DIF packing) ----
+            constexpr bool CP = MODE == M16_INV;
             if (fast) {
-                dit_round4_c<FAST_OK, 0>(v, c, sl);
-                dit_round4_c<FAST_OK, 16>(v, c, sl);
+                dit_round4_c<FAST_OK, 0, CP>(v, c, sl);
+                dit_round4_c<FAST_OK, 16, CP>(v, c, sl);
             } else {
-                dit_round4_c<false, 0>(v, c, sl);
-                dit_round4_c<false, 16>(v, c, sl);
+                dit_round4_c<false, 0, CP>(v, c, sl);
+                dit_round4_c<false, 16, CP>(v, c, sl);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) c_base[r] = v[r];
             __syncthreads();
             u32 wa2t[8], wb2t[8];
             RoundTwQ tb;
-            tw_b(wa2t, wb2t, tb);
+            tw_b(FWD_PART ? NSLOT : 0, wa2t, wb2t, tb);
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const int rq = RB == 5 ? ((q >> 1) << 5) : (((q >> 4) << 4) | (((q >> 1) & 7) << 5));
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
 bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order)
 {
     return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           use_fly == 1 && (direction == 0 || direction == 1) && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
+           use_fly == 1 && direction >= 0 && direction <= 2 && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
 }
 
 // the quarter-turn relation of the shared-twiddle rounds (stages 5 .. L-1), checked on the plan's generated tables (host copy); the inverse
@@ -322,7 +330,7 @@ template <int L, int MODE, bool FX>
 static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream)
 {
     constexpr int RB = L - 9, T = 16 << RB;
-    const size_t ldsb = (size_t)(32 << RB) * ROWP * sizeof(u32) + (size_t)(RB == 5 ? 16 : 8) * 16 * sizeof(uint2);
+    const size_t ldsb = (size_t)(32 << RB) * ROWP * sizeof(u32) + (size_t)(RB == 5 ? 16 : 8) * (MODE == M16_PAIR ? 2 : 1) * 16 * sizeof(uint2);
     allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX>));
     const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
     const unsigned blocks = (unsigned)(nframes < cap ? nframes : cap);
@@ -355,6 +363,8 @@ hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, voi
 #define INTFFT_16K(LL)                                                                                                              \
     if (direction == 0) return fx ? launch16k<LL, M16_FWD, true>(pin, pout, tw16f, c, nframes, sl, stream)                        \
                                   : launch16k<LL, M16_FWD, false>(pin, pout, tw16f, c, nframes, sl, stream);                       \
+    if (direction == 2) return fx ? launch16k<LL, M16_PAIR, true>(pin, pout, tw16f, c, nframes, sl, stream)                       \
+                                  : launch16k<LL, M16_PAIR, false>(pin, pout, tw16f, c, nframes, sl, stream);                      \
     return fx ? launch16k<LL, M16_INV, true>(pin, pout, tw16f, c, nframes, sl, stream)                                             \
               : launch16k<LL, M16_INV, false>(pin, pout, tw16f, c, nframes, sl, stream);
     if (log2n == 13) {

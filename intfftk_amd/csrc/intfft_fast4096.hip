@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
     u32 *const reg0 = lds, *const reg1 = lds + REGION4K;
-    volatile u32 *const s_unsafe = lds + (REGION4K - 1); // the last pad cell of region 0 (columns 16..19 are never transposed; beyond the 16 x 316 dwords of the LC -> LB transpose too)
+    u32 *const vote_flags = lds + (REGION4K - 4); // three pad cells of region 0's last row (columns 16..19 are never transposed; beyond the 16 x 316 dwords of the LC -> LB transpose too)
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
     const int tid = threadIdx.x;
     const int lo4 = tid & 15, hi4 = tid >> 4;
 
@@ -244,9 +246,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         bool fast = false;
         const short sm = (short)(1 - (int)(f & 1)); // MODE_MID: shift amount of the first stage's inputs
         const v2s sh_m = {sm, sm};
-        if (FAST_OK) {
-            if (tid == 0) *s_unsafe = 0;
-            __syncthreads();
+        if (FAST_OK) { // one barrier (block_any; round 3: two + the one at the end of the frame): it also orders the previous frame's LDS reads
             bool bad = guard_acc(v, sl.gbias, sl.gmask) != 0;
             if (MODE == MODE_MID && (f & 1)) { // Y >> 1 inputs: |v| < 2^13
                 u32 acc = 0;
@@ -254,9 +254,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                 for (int j = 0; j < 16; ++j) acc |= v[j] + sl.gbias1;
                 bad = (acc & sl.gmask1) != 0;
             }
-            if (bad) *s_unsafe = 1;
-            __syncthreads();
-            fast = *s_unsafe == 0;
+            fast = !block_any(vote_flags, vote_phase, bad);
         }
         if (MODE != MODE_MID && !fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16: containers wrapped to w bits
 
@@ -319,7 +317,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         if (FAST_OK && fast) INTFFT_BODY(FAST_OK, ROUND)
         else INTFFT_BODY(false, ROUND)
 #undef INTFFT_BODY
-        __syncthreads(); // region reuse by the next frame (and s_unsafe)
+        if (!FAST_OK) __syncthreads(); // region reuse by the next frame (the vote's barrier does it where there is a vote)
     }
 }
 

@@ -365,7 +365,7 @@ __device__ __forceinline__ bool frame_has_guard_bit(const u32 (&v)[16], u32 gbia
 // every thread has left, and first set behind barrier k + 1, which thread 0 has yet to reach -- so no reset can race a set or a read.
 // flags: three dwords of LDS, zeroed (+ one __syncthreads) before the first call; `phase` is the caller's wave-uniform call counter
 // mod 3 (block_any advances it).  Like __syncthreads_or the barrier also orders the caller's earlier LDS reads against its later writes.
-__device__ __forceinline__ bool block_any(u32 (&flags)[64], unsigned &phase, bool mine) // (a reference to the __shared__ array: through a volatile generic pointer the accesses become flat_* with vmcnt waits)
+__device__ __forceinline__ bool block_any(u32 *flags, unsigned &phase, bool mine) // (flags: derived from a __shared__ array, NOT volatile: through a volatile generic pointer the accesses become flat_* with vmcnt waits)
 {
 #ifdef INTFFT_VOTE_OCKL // A/B: HIP's own three-barrier reduction
     (void)flags, (void)phase;
@@ -381,7 +381,7 @@ __device__ __forceinline__ bool block_any(u32 (&flags)[64], unsigned &phase, boo
     phase = phase == 2 ? 0u : phase + 1u;
     return any;
 }
-__device__ __forceinline__ void block_any_init(u32 (&flags)[64])
+__device__ __forceinline__ void block_any_init(u32 *flags)
 {
     if (threadIdx.x < 3) flags[threadIdx.x] = 0u;
     __syncthreads();

@@ -220,7 +220,7 @@ def test_two_pass_32_register_inverse(log2n, in_order, out_order, monkeypatch):
 
 
 @pytest.mark.parametrize("log2n", [13, 14])
-@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_single_pass_n8192_n16384(log2n, direction, monkeypatch):
     """N = 8192 / 16384, 16-bit scaled-truncate, natural order: ONE pass (k_fft16k_i16: a workgroup per frame, three register rounds
     around two LDS transposes, int_fftNk.vhd:75,184-207 / int_ifftNk.vhd:183-341) against the oracle and against the two-pass plan it
@@ -241,7 +241,7 @@ def test_single_pass_n8192_n16384(log2n, direction, monkeypatch):
         with monkeypatch.context() as m:
             m.setenv("INTFFT_NO_FAST16K", "1")
             b, ib = run_gpu(x, log2n, 16, 16, 0, 0, True, direction=direction)
-            assert ib["n_passes"] == 2, ib
+            assert ib["n_passes"] == (3 if direction == "PAIR" else 2), ib
         assert np.array_equal(a, b)
     x = uniform_frames(5, n, 15, 4200 + log2n)
     check(x, log2n, 16, 13, 0, 0, False, direction=direction)  # exact extraction (t != 16), XSER "OLD"
@@ -294,7 +294,7 @@ def test_multi_pass_kernels_small_batches(log2n, batch):
     x[0] = uniform_frames(1, n, 16, 11)[0]
     for direction in ("FWD", "INV", "PAIR"):
         info = check(x, log2n, 16, 16, 0, 0, True, direction=direction)
-        assert ("k_big20" if log2n > 14 or direction == "PAIR" else "k_fft16k_i16") in info["kernel_name"], info
+        assert ("k_big20" if log2n > 14 else "k_fft16k_i16") in info["kernel_name"], info
     for kw in (dict(in_order="HALVES", out_order="BITREV"), dict(direction="INV", in_order="BITREV", out_order="HALVES")):
         info = check(x, log2n, 16, 16, 0, 0, True, **kw)
         assert "k_big20" in info["kernel_name"] or "k_mid" in info["kernel_name"], info
@@ -314,6 +314,10 @@ def test_three_pass_pair_n8192_to_n2pow20(log2n, batch, monkeypatch):
     n = 1 << log2n
     x = uniform_frames(batch, n, 15, 3000 + log2n)
     x[0] = uniform_frames(1, n, 16, 8)[0]
+    if log2n <= 14:  # one launch since round 4 (k_fft16k_i16<PAIR>); the three-pass plans are its A/B forms
+        info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
+        assert info["kernel_name"] == "k_fft16k_i16" and info["n_passes"] == 1, info
+        monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     info = check(x, log2n, 16, 16, 0, 0, True, direction="PAIR")
     assert info["kernel_name"] == ("k_big20_p1/k_mid_pair/q1" if log2n <= 16 else "k_big2p_a/k_mid_pair/k_big2p_q" if log2n <= 18
                                    else "k_big20_p1/k_fft4096_i16<MID>/q1")
