@@ -30,11 +30,12 @@ namespace intfft {
 
 constexpr int ROW2P = 33; // LDS row stride in dwords (32 columns + 1): conflict-free rows and columns
 
-template <int L, bool FAST_OK>
+template <int L, bool FAST_OK, int ROUND = 0> // ROUND: RNDMODE = 1 (2: on narrow data), its own instantiation (round 4: quarter turns through the negated twiddle)
 __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2p_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes,
                                                             unsigned groups, const Slice sl, int halves)
 {
     static_assert(L == 17 || L == 18, "9 or 10 stages");
+    static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int RB = L - 13;        // stages of round 2; thread bits hx
     constexpr int T = 32 << RB;
     extern __shared__ u32 lds[];      // (32 << RB) rows x ROW2P, then the round-2 twiddles: 8 (RB = 4) / 16 slots x 32 columns of {wa, wb}
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 #define INTFFT_2P_ROUND1(FX)                                                                                  \
     {                                                                                                         \
-        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                     \
-        dif_round_q<FX, 0, 0, false>(v, t1, sl, none);                                                        \
-        dif_round_q<FX, 16, 0xF, false>(v, t1, sl, none);                                                     \
+        dif_top16<FX, 0, false, ROUND>(v, wa16, wb16, sl, none);                                              \
+        dif_round_q<FX, 0, 0, false, 4, ROUND>(v, t1, sl, none);                                              \
+        dif_round_q<FX, 16, 0xF, false, 4, ROUND>(v, t1, sl, none);                                           \
     }
         if (fast) INTFFT_2P_ROUND1(FAST_OK)
         else INTFFT_2P_ROUND1(false)
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
                 dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
                 dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
             } else {
-                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
-                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+                dif_round_q<false, 0, 0, false, 4, ROUND>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, t2, sl, none);
             }
         } else { // stages 12..8; the kind of the inputs is n13 = jx bit 0 (a thread bit)
             if (fast) {
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
                 dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
                 dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
             } else {
-                dif_top16<false, 0, true>(v, wa2t, wb2t, sl, sh2);
-                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
-                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+                dif_top16<false, 0, true, ROUND>(v, wa2t, wb2t, sl, sh2);
+                dif_round_q<false, 0, 0, false, 4, ROUND>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, t2, sl, none);
             }
         }
 #pragma unroll
@@ -365,19 +366,21 @@ bool big2p_supported(int log2n) { return (log2n == 17 || log2n == 18) && !diag_e
 hipError_t launch_big2p_a(int log2n, bool fx, const u32 *pin, u32 *scr, const uint2 *tw16f, size_t nframes, const Slice &sl,
                           int halves, hipStream_t stream)
 {
-#define INTFFT_2P_LAUNCH(LL, FX)                                                                                          \
+#define INTFFT_2P_LAUNCH(LL, FX, RD)                                                                                      \
     {                                                                                                                     \
         constexpr int TT = 32 << (LL - 13);                                                                               \
         const size_t ldsb = ((size_t)TT * ROW2P + 1) * sizeof(u32) + (LL == 18 ? 16 : 8) * 32 * sizeof(uint2);             \
-        allow_max_lds(kptr(k_big2p_a<LL, FX>));                                                                           \
+        allow_max_lds(kptr(k_big2p_a<LL, FX, RD>));                                                                           \
         const size_t per_cu = LL == 17 ? 2 : 1, cap = (size_t)device_cus() * per_cu / 8;                                  \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : (cap ? cap : 1));                                    \
-        hipLaunchKernelGGL((k_big2p_a<LL, FX>), dim3(8u * groups), dim3(TT), ldsb, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
+        hipLaunchKernelGGL((k_big2p_a<LL, FX, RD>), dim3(8u * groups), dim3(TT), ldsb, stream, pin, scr, tw16f, nframes, groups, sl, halves); \
     }
     if (log2n == 17) {
-        if (fx) INTFFT_2P_LAUNCH(17, true) else INTFFT_2P_LAUNCH(17, false)
+        if (sl.round == 1) INTFFT_2P_LAUNCH(17, false, 1) else if (sl.round == 2) INTFFT_2P_LAUNCH(17, false, 2)
+        else if (fx) INTFFT_2P_LAUNCH(17, true, 0) else INTFFT_2P_LAUNCH(17, false, 0)
     } else {
-        if (fx) INTFFT_2P_LAUNCH(18, true) else INTFFT_2P_LAUNCH(18, false)
+        if (sl.round == 1) INTFFT_2P_LAUNCH(18, false, 1) else if (sl.round == 2) INTFFT_2P_LAUNCH(18, false, 2)
+        else if (fx) INTFFT_2P_LAUNCH(18, true, 0) else INTFFT_2P_LAUNCH(18, false, 0)
     }
 #undef INTFFT_2P_LAUNCH
     return hipGetLastError();

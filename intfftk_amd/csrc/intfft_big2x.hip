@@ -65,11 +65,12 @@ __device__ __forceinline__ constexpr int rev5c(int r) { return ((r & 1) << 4) | 
 //           L = 19: thread = (n18..n15, l), regs = (n14, n13..n10): two independent 4-stage rounds 13..10 (n14 rides along)
 // Twiddles as in k_big2p_a: quarter-turn sharing; round 2's set depends on the column only and is parked in LDS, round 1's is
 // per thread and re-read from the L2-resident table in every frame.
-template <int L, bool FAST_OK>
+template <int L, bool FAST_OK, int ROUND = 0> // ROUND: RNDMODE = 1 (2: on narrow data) -- its own instantiation, exact extraction only
 __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
                                                                                                         size_t nframes, unsigned groups, const Slice sl, int halves)
 {
     static_assert(L == 19 || L == 20, "9 or 10 stages");
+    static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int RB = L - 15;
     constexpr int T = 16 << RB;
     extern __shared__ u32 lds[]; // (32 << RB) rows x ROWX, then the round-2 twiddles: 8 (RB = 4) / 16 slots x 16 columns of {wa, wb}
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
 #define INTFFT_2X_ROUND1(FX)                                                                                  \
     {                                                                                                         \
-        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                     \
-        dif_round_q<FX, 0, 0, false>(v, t1, sl, none);                                                        \
-        dif_round_q<FX, 16, 0xF, false>(v, t1, sl, none);                                                     \
+        dif_top16<FX, 0, false, ROUND>(v, wa16, wb16, sl, none);                                              \
+        dif_round_q<FX, 0, 0, false, 4, ROUND>(v, t1, sl, none);                                              \
+        dif_round_q<FX, 16, 0xF, false, 4, ROUND>(v, t1, sl, none);                                           \
     }
         if (fast) INTFFT_2X_ROUND1(FAST_OK)
         else INTFFT_2X_ROUND1(false)
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
                 dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
                 dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
             } else {
-                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
-                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+                dif_round_q<false, 0, 0, false, 4, ROUND>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, t2, sl, none);
             }
         } else { // stages 14..10; the kind of the inputs is n15 = jx bit 0 (a thread bit)
             if (fast) {
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
                 dif_round_q<FAST_OK, 0, 0, false>(v, t2, sl, none);
                 dif_round_q<FAST_OK, 16, 0xF, false>(v, t2, sl, none);
             } else {
-                dif_top16<false, 0, true>(v, wa2t, wb2t, sl, sh2);
-                dif_round_q<false, 0, 0, false>(v, t2, sl, none);
-                dif_round_q<false, 16, 0xF, false>(v, t2, sl, none);
+                dif_top16<false, 0, true, ROUND>(v, wa2t, wb2t, sl, sh2);
+                dif_round_q<false, 0, 0, false, 4, ROUND>(v, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, t2, sl, none);
             }
         }
 #pragma unroll
@@ -213,8 +214,29 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
 
 // ---- pass B's second round: DIF stages 4..0 on regs = n4..n0, wave-uniform twiddles -------------------------------------------
 // inputs: per-thread kind (shv: 0 where the registers already hold X >> 1)
-template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl, v2s shv)
+template <bool FASTX, int ROUND = 0> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl, v2s shv)
 {
+    if constexpr (ROUND != 0) { // RNDMODE = 1 (int_dif2_fly.vhd:167-219): plain values, rhu2 sums, exact extraction; STAGE 1 / 0 in round_stages10
+        static_assert(!FASTX, "round mode uses the exact extraction");
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            const u32 wa[4] = {c.wa4[g], c.wa4[g + 1], c.wa4[g + 2], c.wa4[g + 3]}, wb[4] = {c.wb4[g], c.wb4[g + 1], c.wb4[g + 2], c.wb4[g + 3]};
+            group4<ROUND, 0, false, false, true, 0>(v[g], v[g + 16], v[g + 1], v[g + 17], v[g + 2], v[g + 18], v[g + 3], v[g + 19], wa, wb, sl);
+        }
+        const u32 wa30[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb30[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
+        const u32 wa31[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb31[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+#pragma unroll
+        for (int B = 0; B < 32; B += 16) {
+            group4<ROUND, 0, false, false, true, 0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa30, wb30, sl);
+            group4<ROUND, 0, false, false, true, 0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa31, wb31, sl);
+        }
+#pragma unroll
+        for (int B = 0; B < 32; B += 8)
+            group4<ROUND, 0, false, false, true, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+        round_stages10<32, ROUND == 2>(v, sl);
+        (void)shv;
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 16; g += 4) { // stage 4: pairs (q, q + 16), twiddle index q
         const u32 wa[4] = {c.wa4[g], c.wa4[g + 1], c.wa4[g + 2], c.wa4[g + 3]}, wb[4] = {c.wb4[g], c.wb4[g + 1], c.wb4[g + 2], c.wb4[g + 3]};
@@ -254,11 +276,12 @@ template <bool FASTX> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32],
 //           the thread's 32 results are 32 consecutive positions of its row, every row of the tile one 4 KiB run -- staged through LDS
 //           once more so that a wave writes 1 KiB runs non-temporally (stored straight from the registers the eight 16-byte pieces
 //           of a line come from eight instructions: 257-270 Gsample/s with plain stores, 92 non-temporally; staged: 283-297)
-template <int L, bool FAST_OK, bool OUT_BR = false>
+template <int L, bool FAST_OK, bool OUT_BR = false, int ROUND = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_b(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
                                                                                              const Round5Consts c, size_t nframes, const Slice sl, int pre_all)
 {
     static_assert(L == 19 || L == 20, "rows of 1024 points");
+    static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int RL = L - 14; // bits of `rest`
     extern __shared__ u32 lds[];
     const int tid = threadIdx.x;
@@ -328,9 +351,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             dif_round_q<FAST_OK, 0, 0, false>(v, t1, sl, none);
             dif_round_q<FAST_OK, 16, 0xF, false>(v, t1, sl, none);
         } else {
-            dif_top16<false, 0, true>(v, wa16, wb16, sl, sh_a);
-            dif_round_q<false, 0, 0, false>(v, t1, sl, none);
-            dif_round_q<false, 16, 0xF, false>(v, t1, sl, none);
+            dif_top16<false, 0, true, ROUND>(v, wa16, wb16, sl, sh_a);
+            dif_round_q<false, 0, 0, false, 4, ROUND>(v, t1, sl, none);
+            dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, t1, sl, none);
         }
 #pragma unroll
         for (int j = 0; j < 32; ++j) wr_base[ROWY * (j << 4)] = v[j];
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int q = 0; q < 32; ++q) v[q] = rd_base[q];
         if (fast) dif_round5_c<FAST_OK>(v, c, sl, sh5);
-        else dif_round5_c<false>(v, c, sl, sh5);
+        else dif_round5_c<false, ROUND>(v, c, sl, sh5);
         if constexpr (OUT_BR) { // position = ((k << RL | rest) << 10) | (jj << 5) | q: the tile is 16 rows of 4 KiB
             // through LDS once more (every thread rewrites the row it has just read), so that a wave writes 1 KiB runs non-temporally
             u32 *const own = lds + ROWY * ((jj << 4) | krow);
@@ -375,35 +398,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // Quarter turns negate the twiddle operand (group4_dit<.., QTURN>): the planner checks that no table entry is -2^15.
 
 // five DIT stages 0..4 on regs = n4..n0, wave-uniform twiddles in the DIT packing {Wc, Wd} (host: to_dit_packing_host5)
-template <bool FASTX> __device__ __forceinline__ void dit_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl)
+template <bool FASTX, int ROUND = 0> __device__ __forceinline__ void dit_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl)
 {
+    constexpr bool RD = ROUND != 0; // RNDMODE = 1 (int_dit2_fly.vhd:164-217): rhu2 sums on full-width values; ROUND == 2: + the w-bit wrap of narrow data
 #pragma unroll
-    for (int g = 0; g < 32; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    for (int g = 0; g < 32; g += 2) bfly_triv<RD, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    if constexpr (ROUND == 2) {
+#pragma unroll
+        for (int g = 1; g < 32; g += 2) v[g] = wrap_w(v[g], sl.wd);
+    }
 #pragma unroll
     for (int g = 0; g < 32; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
-        bfly_triv<false, false>(v[g], v[g + 2]);
-        bfly_pj_dit<false>(v[g + 1], v[g + 3]);
+        bfly_triv<RD, false>(v[g], v[g + 2]);
+        bfly_pj_dit<RD>(v[g + 1], v[g + 3]);
+    }
+    if constexpr (ROUND == 2) {
+#pragma unroll
+        for (int g = 0; g < 32; g += 4) v[g + 2] = wrap_w(v[g + 2], sl.wd), v[g + 3] = wrap_w(v[g + 3], sl.wd);
     }
 #pragma unroll
     for (int B = 0; B < 32; B += 8) // STAGE 2: pairs (q, q + 4), twiddle q & 3
-        group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+        group4_dit<FASTX, true, ROUND, true>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
     const u32 wa30[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb30[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa31[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb31[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
 #pragma unroll
     for (int B = 0; B < 32; B += 16) { // STAGE 3: pairs (q, q + 8), twiddle q & 7
-        group4_dit<FASTX, true, 0, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa30, wb30, sl);
-        group4_dit<FASTX, true, 0, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa31, wb31, sl);
+        group4_dit<FASTX, true, ROUND, true>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa30, wb30, sl);
+        group4_dit<FASTX, true, ROUND, true>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa31, wb31, sl);
     }
 #pragma unroll
     for (int g = 0; g < 16; g += 4) { // STAGE 4: pairs (q, q + 16), twiddle q
         const u32 wa[4] = {c.wa4[g], c.wa4[g + 1], c.wa4[g + 2], c.wa4[g + 3]}, wb[4] = {c.wb4[g], c.wb4[g + 1], c.wb4[g + 2], c.wb4[g + 3]};
-        group4_dit<FASTX, true, 0, true>(v[g], v[g + 16], v[g + 1], v[g + 17], v[g + 2], v[g + 18], v[g + 3], v[g + 19], wa, wb, sl);
+        group4_dit<FASTX, true, ROUND, true>(v[g], v[g + 16], v[g + 1], v[g + 17], v[g + 2], v[g + 18], v[g + 3], v[g + 19], wa, wb, sl);
     }
 }
 
 // IN_BR: BITREV order in (int_ifftNk's own order: memory index = core position): the thread's 32 inputs are 32 consecutive positions of
 // its row (eight plain 16-byte loads: 274 Gsample/s at N = 2^20; loaded as 1 KiB runs per wave and handed over through LDS: 240-260)
-template <int L, bool FAST_OK, bool IN_BR = false>
+template <int L, bool FAST_OK, bool IN_BR = false, int ROUND = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qb(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
                                                                                               const Round5Consts c, size_t nframes, const Slice sl)
 {
@@ -474,7 +506,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
         if (fast) dit_round5_c<FAST_OK>(v, c, sl);
-        else dit_round5_c<false>(v, c, sl);
+        else dit_round5_c<false, ROUND>(v, c, sl);
 #pragma unroll
         for (int q = 0; q < 32; ++q) wr_base[q] = v[q];
         __syncthreads();
@@ -485,16 +517,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             dit_round_q<FAST_OK, 16>(v, t1, sl);
             dit_top16<FAST_OK>(v, wa16, wb16, sl);
         } else {
-            dit_round_q<false, 0>(v, t1, sl);
-            dit_round_q<false, 16>(v, t1, sl);
-            dit_top16<false>(v, wa16, wb16, sl);
+            dit_round_q<false, 0, ROUND>(v, t1, sl);
+            dit_round_q<false, 16, ROUND>(v, t1, sl);
+            dit_top16<false, ROUND>(v, wa16, wb16, sl);
         }
 #pragma unroll
         for (int j = 0; j < 32; ++j) *at32(dst + ((size_t)j << (L - 10)), toff_l) = v[j];
     }
 }
 
-template <int L, bool FAST_OK>
+template <int L, bool FAST_OK, int ROUND = 0>
 __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_qa(const u32 *scr, u32 *out, const uint2 *__restrict__ twf,
                                                                                                          size_t nframes, unsigned groups, const Slice sl, int halves)
 {
@@ -567,9 +599,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
                 dit_round_q<FAST_OK, 16>(v, t1, sl);
                 if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa16, wb16, sl);
             } else {
-                dit_round_q<false, 0>(v, t1, sl);
-                dit_round_q<false, 16>(v, t1, sl);
-                if constexpr (RB == 5) dit_top16<false>(v, wa16, wb16, sl);
+                dit_round_q<false, 0, ROUND>(v, t1, sl);
+                dit_round_q<false, 16, ROUND>(v, t1, sl);
+                if constexpr (RB == 5) dit_top16<false, ROUND>(v, wa16, wb16, sl);
             }
         }
         // round 2's per-thread twiddles: STAGE L-5+b, index (jj << (RB + 10)) | toff: re-read per tile, converted to the DIT packing
@@ -607,9 +639,9 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
             dit_round_q<FAST_OK, 16>(v, t2, sl);
             dit_top16<FAST_OK>(v, wa16, wb16, sl);
         } else {
-            dit_round_q<false, 0>(v, t2, sl);
-            dit_round_q<false, 16>(v, t2, sl);
-            dit_top16<false>(v, wa16, wb16, sl);
+            dit_round_q<false, 0, ROUND>(v, t2, sl);
+            dit_round_q<false, 16, ROUND>(v, t2, sl);
+            dit_top16<false, ROUND>(v, wa16, wb16, sl);
         }
         if (halves) { // HALVES order out: memory index = 2 * (n without n(L-1)) + n(L-1): registers j and j + 16 are one 8-byte store
             typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -1034,25 +1066,28 @@ hipError_t launch_big2x_inv(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *
     for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
     for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
-#define INTFFT_2XQ_LAUNCH(LL, FX)                                                                                                  \
+#define INTFFT_2XQ_LAUNCH(LL, FX, RD)                                                                                              \
     {                                                                                                                              \
         constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
         const size_t ldsa = (size_t)(32 << RB) * ROWX * sizeof(u32) + (LL == 20 ? 16 : 8) * 16 * sizeof(uint2);                    \
         const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
-        allow_max_lds(kptr(k_big2x_qa<LL, FX>));                                                                                   \
-        allow_max_lds(kptr(k_big2x_qb<LL, FX>));                                                                                   \
-        allow_max_lds(kptr(k_big2x_qb<LL, FX, true>));                                                                             \
+        allow_max_lds(kptr(k_big2x_qa<LL, FX, RD>));                                                                                   \
+        allow_max_lds(kptr(k_big2x_qb<LL, FX, false, RD>));                                                                                   \
+        allow_max_lds(kptr(k_big2x_qb<LL, FX, true, RD>));                                                                             \
         const size_t ntiles = nframes << (LL - 14), capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;                              \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
-        if (in_bitrev) hipLaunchKernelGGL((k_big2x_qb<LL, FX, true>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl); \
-        else hipLaunchKernelGGL((k_big2x_qb<LL, FX>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl);         \
+        if (in_bitrev) hipLaunchKernelGGL((k_big2x_qb<LL, FX, true, RD>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl); \
+        else hipLaunchKernelGGL((k_big2x_qb<LL, FX, false, RD>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw16f, c, nframes, sl);         \
         const unsigned groups = (unsigned)(nframes < 64 ? nframes : 64);                                                           \
-        hipLaunchKernelGGL((k_big2x_qa<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, scr, pout, tw16f, nframes, groups, sl, halves); \
+        hipLaunchKernelGGL((k_big2x_qa<LL, FX, RD>), dim3(64u * groups), dim3(TT), ldsa, stream, scr, pout, tw16f, nframes, groups, sl, halves); \
     }
+    // RNDMODE = 1 (sl.round; 2 = on narrow data): the exact-path kernels in their ROUND instantiations
     if (log2n == 20) {
-        if (fx) INTFFT_2XQ_LAUNCH(20, true) else INTFFT_2XQ_LAUNCH(20, false)
+        if (sl.round == 1) INTFFT_2XQ_LAUNCH(20, false, 1) else if (sl.round == 2) INTFFT_2XQ_LAUNCH(20, false, 2)
+        else if (fx) INTFFT_2XQ_LAUNCH(20, true, 0) else INTFFT_2XQ_LAUNCH(20, false, 0)
     } else {
-        if (fx) INTFFT_2XQ_LAUNCH(19, true) else INTFFT_2XQ_LAUNCH(19, false)
+        if (sl.round == 1) INTFFT_2XQ_LAUNCH(19, false, 1) else if (sl.round == 2) INTFFT_2XQ_LAUNCH(19, false, 2)
+        else if (fx) INTFFT_2XQ_LAUNCH(19, true, 0) else INTFFT_2XQ_LAUNCH(19, false, 0)
     }
 #undef INTFFT_2XQ_LAUNCH
     return hipGetLastError();
@@ -1091,30 +1126,32 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
     for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
 #define INTFFT_2XB_SHIFT 1 /* a block of pass B takes both partner tiles */
-#define INTFFT_2XA_LAUNCH(LL, FX) hipLaunchKernelGGL((k_big2x_a<LL, FX>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves);
-#define INTFFT_2X_LAUNCH(LL, FX)                                                                                                   \
+#define INTFFT_2XA_LAUNCH(LL, FX, RD) hipLaunchKernelGGL((k_big2x_a<LL, FX, RD>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves);
+#define INTFFT_2X_LAUNCH(LL, FX, RD)                                                                                               \
     {                                                                                                                              \
         constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
         const size_t ldsa = (size_t)(32 << RB) * ROWX * sizeof(u32) + (LL == 20 ? 16 : 8) * 16 * sizeof(uint2);                    \
         const size_t ldsb = (size_t)512 * ROWY * sizeof(u32);                                                                      \
-        allow_max_lds(kptr(k_big2x_a<LL, FX>));                                                                                    \
-        allow_max_lds(kptr(k_big2x_b<LL, FX>));                                                                                    \
-        allow_max_lds(kptr(k_big2x_b<LL, FX, true>));                                                                              \
+        allow_max_lds(kptr(k_big2x_a<LL, FX, RD>));                                                                                    \
+        allow_max_lds(kptr(k_big2x_b<LL, FX, false, RD>));                                                                                    \
+        allow_max_lds(kptr(k_big2x_b<LL, FX, true, RD>));                                                                              \
         /* frame groups: 64 = every block takes ONE tile of a 64-frame chunk.  The partner blocks b, b + 8 then start together  \
            (per-XCD dispatch order) instead of drifting apart over a frame walk: FETCH_SIZE 387 MB against 436 MB per 2^26      \
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
         const size_t cap = 64;                                                                                                     \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
-        INTFFT_2XA_LAUNCH(LL, FX)                                                                                                  \
+        INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                \
         const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
-        if (out_bitrev) hipLaunchKernelGGL((k_big2x_b<LL, FX, true>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0); \
-        else hipLaunchKernelGGL((k_big2x_b<LL, FX>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);      \
+        if (out_bitrev) hipLaunchKernelGGL((k_big2x_b<LL, FX, true, RD>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0); \
+        else hipLaunchKernelGGL((k_big2x_b<LL, FX, false, RD>), dim3(gb), dim3(512), ldsb, stream, scr, pout, tw16f, c, nframes, sl, 0);      \
     }
     if (log2n == 20) {
-        if (fx) INTFFT_2X_LAUNCH(20, true) else INTFFT_2X_LAUNCH(20, false)
+        if (sl.round == 1) INTFFT_2X_LAUNCH(20, false, 1) else if (sl.round == 2) INTFFT_2X_LAUNCH(20, false, 2)
+        else if (fx) INTFFT_2X_LAUNCH(20, true, 0) else INTFFT_2X_LAUNCH(20, false, 0)
     } else {
-        if (fx) INTFFT_2X_LAUNCH(19, true) else INTFFT_2X_LAUNCH(19, false)
+        if (sl.round == 1) INTFFT_2X_LAUNCH(19, false, 1) else if (sl.round == 2) INTFFT_2X_LAUNCH(19, false, 2)
+        else if (fx) INTFFT_2X_LAUNCH(19, true, 0) else INTFFT_2X_LAUNCH(19, false, 0)
     }
 #undef INTFFT_2X_LAUNCH
     return hipGetLastError();

@@ -210,7 +210,7 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
                                        const u32 (&wa_in)[4], const u32 (&wb_in)[4], const Slice &sl, v2s shv = v2s{0, 0})
 {
     static_assert(FASTX == 0 || (!ROUND && OUT_PRE), "fast extraction yields Y >> 1 only");
-    static_assert(!QTURN || !ROUND, "quarter-turn sharing needs an exact -D");
+    static_assert(!QTURN || !SG || !ROUND, "a round-mode quarter turn negates its twiddle operand: a VGPR");
     const u32 (&wa)[4] = DPK ? wb_in : wa_in;
     const u32 (&wb)[4] = DPK ? wa_in : wb_in;
     u32 d[4];
@@ -232,7 +232,14 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
         }
     }
     u32 y[4];
-    if (QTURN) {
+    if constexpr (QTURN && ROUND != 0) {
+        // RNDMODE = 1: D = rhu2(A - B) can be -2^15, so -D is not exact; the negated TWIDDLE operand is (no table entry is -2^15: the
+        // planners' *_tables_ok check it): Y.re = dot(D, Wb), Y.im = dot(D, -Wa), full-width results, exact extraction
+        const v2s z = {0, 0};
+        const u32 nwa[4] = {as_u32(z - as_v2s(wa[0])), as_u32(z - as_v2s(wa[1])), as_u32(z - as_v2s(wa[2])), as_u32(z - as_v2s(wa[3]))};
+        mul2x<16, SG>(d[0], d[0], wb[0], nwa[0], d[1], d[1], wb[1], nwa[1], sl.off_y, sl.sel, y[0], y[1], sl.wd);
+        mul2x<16, SG>(d[2], d[2], wb[2], nwa[2], d[3], d[3], wb[3], nwa[3], sl.off_y, sl.sel, y[2], y[3], sl.wd);
+    } else if (QTURN) {
         // W' = (W.im, -W.re): Y.re = dot(D, Wb), Y.im = dot(-D, Wa).  (Round 4 tried the negated TWIDDLE operand instead -- one packed
         // subtract per distinct twiddle, shared by the compiler between the butterflies of a round: 49 fewer operations per thread and tile
         // in k_big2x_a, but the longer live ranges spill 4-8 VGPRs there: C4 270 against 308 Gsample/s, N = 16384 449 against 541.)
@@ -572,11 +579,19 @@ struct RoundTwQ {
 
 // offset 16: pairs (j, j + 16), twiddle index j (0..15): base for j < 8, quarter turn of base[j - 8] for j >= 8.
 // P0: PREMASK of the inputs (0 unshifted, 0xF already X >> 1), or VARSH with a per-thread shift amount.
-template <bool FASTX, int P0, bool VARSH>
+template <bool FASTX, int P0, bool VARSH, int ROUND = 0>
 __device__ __forceinline__ void dif_top16(u32 (&v)[32], const u32 (&wa)[8], const u32 (&wb)[8], const Slice &sl, v2s shv)
 {
     const u32 wa0[4] = {wa[0], wa[1], wa[2], wa[3]}, wb0[4] = {wb[0], wb[1], wb[2], wb[3]};
     const u32 wa1[4] = {wa[4], wa[5], wa[6], wa[7]}, wb1[4] = {wb[4], wb[5], wb[6], wb[7]};
+    if constexpr (ROUND != 0) { // RNDMODE = 1: plain values everywhere (no kinds, no pre-shifted outputs), exact extraction
+        static_assert(!FASTX, "round mode uses the exact extraction");
+        group4<ROUND, 0, false, false, false, 0>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl);
+        group4<ROUND, 0, false, false, false, 0>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl);
+        group4<ROUND, 0, true, false, false, 0>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl);
+        group4<ROUND, 0, true, false, false, 0>(v[12], v[28], v[13], v[29], v[14], v[30], v[15], v[31], wa1, wb1, sl);
+        return;
+    }
     group4<false, FASTX, false, true, false, P0, VARSH>(v[0], v[16], v[1], v[17], v[2], v[18], v[3], v[19], wa0, wb0, sl, shv);
     group4<false, FASTX, false, true, false, P0, VARSH>(v[4], v[20], v[5], v[21], v[6], v[22], v[7], v[23], wa1, wb1, sl, shv);
     group4<false, FASTX, true, true, false, P0, VARSH>(v[8], v[24], v[9], v[25], v[10], v[26], v[11], v[27], wa0, wb0, sl, shv);
@@ -586,10 +601,34 @@ __device__ __forceinline__ void dif_top16(u32 (&v)[32], const u32 (&wa)[8], cons
 // four DIF stages on registers v[B .. B+15], offsets 8, 4, 2, 1 (stage numbers s0+3 .. s0).  NS < 4 runs only the last NS.
 // The inputs of the FIRST executed stage: PREMASK P0 (0 / 0xF) or VARSH0 (per-thread shift); later stages follow the
 // rule "the upper output of a butterfly is Y >> 1".
-template <bool FASTX, int B, int P0, bool VARSH0, int NS = 4>
+template <bool FASTX, int B, int P0, bool VARSH0, int NS = 4, int ROUND = 0>
 __device__ __forceinline__ void dif_round_q(u32 (&v)[32], const RoundTwQ &t, const Slice &sl, v2s shv)
 {
     const v2s none = {0, 0};
+    if constexpr (ROUND != 0) { // RNDMODE = 1: the same pairings and twiddle sharing on plain values
+        static_assert(!FASTX, "round mode uses the exact extraction");
+        if constexpr (NS >= 4) {
+            group4<ROUND, 0, false, false, false, 0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl);
+            group4<ROUND, 0, true, false, false, 0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl);
+        }
+        if constexpr (NS >= 3) {
+            const u32 wa[4] = {t.wa4[0], t.wa4[1], t.wa4[0], t.wa4[1]}, wb[4] = {t.wb4[0], t.wb4[1], t.wb4[0], t.wb4[1]};
+            group4<ROUND, 0, false, false, false, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 8], v[B + 12], v[B + 9], v[B + 13], wa, wb, sl);
+            group4<ROUND, 0, true, false, false, 0>(v[B + 2], v[B + 6], v[B + 3], v[B + 7], v[B + 10], v[B + 14], v[B + 11], v[B + 15], wa, wb, sl);
+        }
+        if constexpr (NS >= 2) {
+            const u32 wa[4] = {t.wa2[0], t.wa2[0], t.wa2[0], t.wa2[0]}, wb[4] = {t.wb2[0], t.wb2[0], t.wb2[0], t.wb2[0]};
+            group4<ROUND, 0, false, false, false, 0>(v[B + 0], v[B + 2], v[B + 4], v[B + 6], v[B + 8], v[B + 10], v[B + 12], v[B + 14], wa, wb, sl);
+            group4<ROUND, 0, true, false, false, 0>(v[B + 1], v[B + 3], v[B + 5], v[B + 7], v[B + 9], v[B + 11], v[B + 13], v[B + 15], wa, wb, sl);
+        }
+        if constexpr (NS >= 1) {
+            const u32 wa[4] = {t.wa1[0], t.wa1[0], t.wa1[0], t.wa1[0]}, wb[4] = {t.wb1[0], t.wb1[0], t.wb1[0], t.wb1[0]};
+            group4<ROUND, 0, false, false, false, 0>(v[B + 0], v[B + 1], v[B + 4], v[B + 5], v[B + 8], v[B + 9], v[B + 12], v[B + 13], wa, wb, sl);
+            group4<ROUND, 0, false, false, false, 0>(v[B + 2], v[B + 3], v[B + 6], v[B + 7], v[B + 10], v[B + 11], v[B + 14], v[B + 15], wa, wb, sl);
+        }
+        (void)shv;
+        return;
+    }
     if constexpr (NS >= 4) { // offset 8: twiddle j & 7: base j < 4, quarter turn j >= 4
         group4<false, FASTX, false, true, false, P0, VARSH0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], t.wa8, t.wb8, sl, shv);
         group4<false, FASTX, true, true, false, P0, VARSH0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], t.wa8, t.wb8, sl, shv);

@@ -898,20 +898,21 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->big_two_pass = pl->big20 && p->log2n <= 16 && p->direction != INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
         // N = 2^17, 2^18 forward / inverse: the 32-register pass of stages 8..L-1 (it shares twiddles by
         // quarter turns: verified on this plan's tables)
-        // round mode: the inverse's 32-register pass only (the forward one has no registers left for a second set of bodies)
-        const bool big2p = pl->big20 && (p->direction == INTFFT_INV || (p->direction == INTFFT_FWD && !p->rndmode)) && big2p_supported(p->log2n) &&
+        // (round mode: the forward pass on its own instantiations since round 4 -- quarter turns through the negated twiddle, group4)
+        const bool big2p = pl->big20 && (p->direction == INTFFT_INV || p->direction == INTFFT_FWD) && big2p_supported(p->log2n) &&
                            !diag_env("INTFFT_NO_TWOPASS") && big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2p) pl->big_two_pass = true;
         const bool big2p_pair = pl->big20 && !p->rndmode && p->direction == INTFFT_PAIR && big2p_supported(p->log2n) && !diag_env("INTFFT_NO_TWOPASS") &&
                                 big2p_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         pl->big_pair256 = pl->big20 && (p->log2n <= 16 || big2p_pair) && p->direction == INTFFT_PAIR && !diag_env("INTFFT_NO_TWOPASS");
-        // N = 2^19, 2^20 forward, truncate mode, natural or BITREV order out: 1024 rows x 1024 columns in two ten-stage passes (intfft_big2x.hip)
-        const bool big2x = pl->big20 && p->direction == INTFFT_FWD && !p->rndmode && (p->out_order == INTFFT_ORDER_NATURAL || p->out_order == INTFFT_ORDER_BITREV) &&
+        // N = 2^19, 2^20 forward (truncate mode, and since round 4 RNDMODE = 1 on its own instantiations), natural or BITREV order out: 1024 rows x
+        // 1024 columns in two ten-stage passes (intfft_big2x.hip)
+        const bool big2x = pl->big20 && p->direction == INTFFT_FWD && (p->out_order == INTFFT_ORDER_NATURAL || p->out_order == INTFFT_ORDER_BITREV) &&
                            big2x_supported(p->log2n) &&
                            !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x) pl->big_two_pass = true;
         // ... and the inverse from natural or BITREV order (natural or HALVES order out): k_big2x_qb / k_big2x_qa
-        const bool big2x_inv = pl->big20 && p->direction == INTFFT_INV && !p->rndmode && (p->in_order == INTFFT_ORDER_NATURAL || p->in_order == INTFFT_ORDER_BITREV) &&
+        const bool big2x_inv = pl->big20 && p->direction == INTFFT_INV && (p->in_order == INTFFT_ORDER_NATURAL || p->in_order == INTFFT_ORDER_BITREV) &&
                                big2x_supported(p->log2n) &&
                                !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x_inv) pl->big_two_pass = true;

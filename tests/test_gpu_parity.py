@@ -912,9 +912,17 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
     n = 1 << log2n
     x = np.concatenate([uniform_frames(batch, n, 16, 500 + log2n), edge_frames(n, 16)[3:6], uniform_frames(2, n, 15, 501 + log2n)])
     info = check(x, log2n, 16, tw, 0, 1, True, direction=direction)
-    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big20", "k_mid")), info
-    # N = 2^17, 2^18: the inverse takes the 32-register pass (quarter turns through the negated twiddle), the forward core three passes
-    assert info["n_passes"] == (2 if log2n <= 16 or (log2n <= 18 and direction == "INV") else 3), info
+    assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big2", "k_mid")), info
+    # every length in two passes since round 4: the 32-register passes of N = 2^17, 2^18 and the half-line tiles of N = 2^19, 2^20 in their
+    # ROUND instantiations (quarter turns through the negated twiddle: D = rhu2(A - B) can be -2^15, -D is not exact)
+    assert info["n_passes"] == 2, info
+    if log2n >= 17:  # ... against the three-pass plans they replace
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_BIG2P" if log2n <= 18 else "INTFFT_NO_BIG2X", "1")
+            got3, info3 = run_gpu(x, log2n, 16, tw, 0, 1, True, direction=direction)
+            assert info3["n_passes"] == 3, info3
+        got2, _ = run_gpu(x, log2n, 16, tw, 0, 1, True, direction=direction)
+        assert np.array_equal(got2, got3)
     if log2n <= 16:
         with monkeypatch.context() as m:
             m.setenv("INTFFT_NO_TWOPASS", "1")
@@ -924,7 +932,7 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
         t_o, f_o = ("in_order", "out_order") if direction == "FWD" else ("out_order", "in_order")
         for time_order, freq_order in (("HALVES", "BITREV"), ("NATURAL", "BITREV"), ("HALVES", "NATURAL")):
             info = check(x[:batch + 3], log2n, 16, tw, 0, 1, True, direction=direction, **{t_o: time_order, f_o: freq_order})
-            assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
+            assert info["kernel_name"].startswith(("k_big2", "k_mid")), info
 
 
 @pytest.mark.parametrize("log2n", [3, 5, 7, 10, 11, 12, 13, 16, 17])
@@ -952,7 +960,7 @@ def test_narrow_data_round_mode(log2n, dw, direction):
         if log2n <= 12:
             assert "_i16" in info["kernel_name"], info
         elif log2n >= 13 and not (direction == "PAIR" and log2n > 16):  # the multi-pass kernels in their ROUND = 2 forms
-            assert info["kernel_name"].startswith(("k_big20", "k_mid")), info
+            assert info["kernel_name"].startswith(("k_big2", "k_mid")), info
 
 
 @pytest.mark.parametrize("log2n,batch", [(13, 37), (13, 259), (14, 9), (15, 5), (16, 5), (16, 19), (17, 3), (18, 2), (19, 1), (20, 1)])
