@@ -919,7 +919,26 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
                                       p->in_order, p->out_order) &&
                      pl->passes.size() == 2 && !diag_env("INTFFT_NO_WIDE16");
-        if (pl->wide16) {
+        if (pl->wide16 && p->direction == INTFFT_INV) { // the inverse: STAGE 0 .. 7 in pass 1 (int32), 8 .. LL-1 in pass 2 (64-bit); st[s] = STAGE s
+            std::vector<StageDesc> st;
+            const int LL = p->log2n;
+            if (core_stages(*p, p->data_width, true, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
+            pl->wargs.dw = p->data_width;
+            for (int s = 0; s < LL && pl->wide16; ++s) {
+                const StageDesc &d = st[s];
+                WideStage &w = pl->wargs.st[s];
+                w.sh = d.sh_a + d.sh_b;
+                w.keep = ~((1u << d.sh_a) - 1u);
+                w.az = d.sh_a == 0;
+                w.s2 = w.sh + d.mw - 32; // the slice is the multiplier's own width mw = DATA_WIDTH + s
+                w.s3 = 32 - d.mw;
+                w.w32 = d.mw - 32;
+                if (d.s != s || d.mw != p->data_width + s || d.mw + p->twdl_width > 64) pl->wide16 = false;
+                if (s >= 2 && s < 8 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
+                if (s >= 8 && w.w32 >= 1 && w.sh + w.w32 > 32) pl->wide16 = false;
+                if (s >= 8 && (d.mw > 40 || w.sh + d.mw > 64)) pl->wide16 = false;
+            }
+        } else if (pl->wide16) {
             std::vector<StageDesc> st;
             const int LL = p->log2n; // 13 .. 16: STAGE LL-1 .. 8 in pass 1 (int32), 7 .. 0 in pass 2 (64-bit)
             if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
@@ -941,7 +960,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name() : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name(p->direction) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;
@@ -1311,7 +1330,7 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         }
         if (plan->wide16) {
             const hipError_t e = launch_wide16(plan->p.log2n, plan->wargs, src, dst, scratch, plan->d_tw, plan->h_tw.data(), nf,
-                                               stream);
+                                               stream, plan->p.direction);
             if (e != hipSuccess) return (int)e;
             continue;
         }

@@ -425,24 +425,354 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ---- the inverse: int_ifftNk on the same class (round 4) --------------------------------------------------------------------------------
+// int_ifftNk (src/vhdl/fft/int_ifftNk.vhd:183-341), DATA_WIDTH 17 .. 24 in int32 containers, FORMAT = 1, natural order in and out: DIT
+// STAGE s pairs the positions that differ in bit s (position p takes X[brev_L(p)]), multiplies the INPUT B at its own width 24 + s
+// (int_dit2_fly.vhd:290-325: the re/im-swapped multiplier feed, T.im = the multiplier's re output, T.re = its im output) and grows one
+// bit in X = A + T, Y = A - T.  The widths cross 32 bits behind STAGE 7, so the passes mirror the forward ones with the word sizes exchanged:
+//   pass 1  k_wide16_q1   STAGE 0..7 over c = p7..p0 on int32 registers: the geometry of k_wide16_p2 (a workgroup = one unit of 16 rows whose
+//                         bit-reversed indices are adjacent; the bit-reversed gather of the natural-order input in 128-byte runs), user array ->
+//                         plan scratch (the forward layout [unit][c7..4][t4][c3..0], 2 KiB per register)
+//   pass 2  k_wide16_q2   STAGE 8..L-1 over r = p15..p8 on 64-bit registers: the geometry of k_wide16_p1 (16 adjacent columns of a virtual frame),
+//                         three-plane LDS transpose of the <= 36-bit values, natural-order store in 256-byte runs
+// WideArgs::st[s] is STAGE s here (processing order = stage number); the slice width of a stage is its multiplier width mw = 24 + s.
+template <bool UNIFORM_W>
+__device__ __forceinline__ void wdit32(int &are, int &aim, int &bre, int &bim, int wr, int wi, const WideStage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    else asm volatile("" : "+v"(wr), "+v"(wi)); // (see wfly32)
+    const u64 m2r = (u64)((i64)bim * wr), m1r = (u64)((i64)bre * wi); // the multiplier's re output on (DI_RE, DI_IM) = (B.im, B.re): T.im
+    const u64 m2i = (u64)((i64)bim * wi), m1i = (u64)((i64)bre * wr); // its im output: T.re
+    const u64 k = 0xFFFFFFFF00000000ull | s.keep;
+    const u64 xi = (m2r & k) - (m1r & k), xr = (m2i & k) + (m1i & k);
+    const int tre = (int)__builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.s2) >> s.s3;
+    const int tim = (int)__builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.s2) >> s.s3;
+    bre = are - tre, bim = aim - tim; // unscaled: exact, one bit of growth (int_dit2_fly.vhd:142-162)
+    are += tre, aim += tim;
+}
+template <int H, bool UNIFORM_W = false>
+__device__ __forceinline__ void wdstage32(int (&re)[16], int (&im)[16], const int (&wr)[H], const int (&wi)[H], const WideStage &s)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2 * H)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            wdit32<UNIFORM_W>(re[g + j], im[g + j], re[g + j + H], im[g + j + H], wr[j], wi[j], s);
+            if (SCHED_GROUP && ((g / 2 + j) % SCHED_GROUP) == SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+template <bool UNIFORM_W>
+__device__ __forceinline__ void wdit64(i64 &are, i64 &aim, i64 &bre, i64 &bim, int wr, int wi, const WideStage &s)
+{
+    if (UNIFORM_W) asm volatile("" : "+s"(wr), "+s"(wi));
+    else asm volatile("" : "+v"(wr), "+v"(wi));
+    const int rl = (int)bre, rh = (int)(bre >> 32) - (rl >> 31);
+    const int il = (int)bim, ih = (int)(bim >> 32) - (il >> 31);
+    u64 m2r = mul64x32(il, ih, wr), m1r = mul64x32(rl, rh, wi);
+    u64 m2i = mul64x32(il, ih, wi), m1i = mul64x32(rl, rh, wr);
+    const u64 k = 0xFFFFFFFF00000000ull | s.keep;
+    m2r &= k, m1r &= k, m2i &= k, m1i &= k;
+    const u64 xi = m2r - m1r, xr = m2i + m1i;
+    i64 tre, tim;
+    if (s.w32 < 1) { // a 32-bit multiplier (STAGE 8 of 24-bit data): the general form of the slice
+        const int wo = 32 + s.w32;
+        tre = (i64)(xr << (64 - s.sh - wo)) >> (64 - wo);
+        tim = (i64)(xi << (64 - s.sh - wo)) >> (64 - wo);
+    } else {
+        const u32 lr = __builtin_amdgcn_alignbit((u32)(xr >> 32), (u32)xr, (u32)s.sh);
+        const u32 li = __builtin_amdgcn_alignbit((u32)(xi >> 32), (u32)xi, (u32)s.sh);
+        const int hr = __builtin_amdgcn_sbfe((int)(xr >> 32), s.sh, s.w32);
+        const int hi = __builtin_amdgcn_sbfe((int)(xi >> 32), s.sh, s.w32);
+        tre = (i64)(((u64)(u32)hr << 32) | lr);
+        tim = (i64)(((u64)(u32)hi << 32) | li);
+    }
+    bre = are - tre, bim = aim - tim;
+    are += tre, aim += tim;
+}
+template <int H>
+__device__ __forceinline__ void wdstage64(i64 (&re)[16], i64 (&im)[16], const int (&wr)[H], const int (&wi)[H], const WideStage &s)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2 * H)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            wdit64<false>(re[g + j], im[g + j], re[g + j + H], im[g + j + H], wr[j], wi[j], s);
+            if (SCHED_GROUP && ((g / 2 + j) % SCHED_GROUP) == SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_q1(const int2 *in, int2 *scr, const int2 *__restrict__ twt, const WideArgs a,
+                                                                                             const W2Consts k, size_t nframes_user)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    // round 2: thread = (j = hi4, c3..0 = lo4), registers c7..4: STAGE 4 index lo4, STAGE 5 index 16 jj + lo4, ... (frame invariant)
+    int w7r[8], w7i[8], w6r[4], w6i[4], w5r[2], w5i[2], w4r[1], w4i[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int2 w = twt[127 + 16 * j + lo4];
+        w7r[j] = w.x, w7i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int2 w = twt[63 + 16 * j + lo4];
+        w6r[j] = w.x, w6i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int2 w = twt[31 + 16 * j + lo4];
+        w5r[j] = w.x, w5i[j] = w.y;
+    }
+    {
+        const int2 w = twt[15 + lo4];
+        w4r[0] = w.x, w4i[0] = w.y;
+    }
+    // transpose: round-1 thread t = (c7..4 = hi4, j = lo4) holds registers c3..0 -> row t; round-2 thread (j = hi4, c3..0 = lo4), register
+    // q = c7..4, reads (row 16 q + j, column c3..0) -- k_wide16_p2's transpose run backwards
+    uint4 *const wr0 = reinterpret_cast<uint4 *>(lds + ROWW * tid);
+    uint4 *const wr1 = reinterpret_cast<uint4 *>(lds + PLANEW + ROWW * tid);
+    const u32 *const rd0 = lds + ROWW * hi4 + lo4;
+    const u32 *const rd1 = rd0 + PLANEW;
+
+    const size_t units = nframes * 16; // work unit u = 16 f + (g, low)
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const size_t f = u >> 4;
+        const int r0 = (int)(u & 15);
+        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
+        if (L < 16 && real >= nframes_user) continue;
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        // position (r' = 2^(L-12) t4 + low, c) takes X[brev_L] = in[2^(L-4) rev4(c3..0) + 2^(L-8) rev4(c7..4) + 16 brev_(L-12)(low) + rev4(t4)]
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
+        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << L) + 16 * rlow; // wave-uniform
+        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
+        asm volatile("" : "+v"(toff), "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
+        int re[16], im[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff); // (plain: the sixteen 8-byte pieces of a 128-byte line come from sixteen lanes of one instruction)
+            re[q] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
+            im[q] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+        }
+        // STAGE 0: T = B (int_dit2_fly.vhd:221-230); STAGE 1: T = B on even positions, +j B with the negation quirk on odd ones (:234-286)
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+            const int xr = re[g] + re[g + 1], xi = im[g] + im[g + 1];
+            re[g + 1] = re[g] - re[g + 1], im[g + 1] = im[g] - im[g + 1];
+            re[g] = xr, im[g] = xi;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            { // even position
+                const int xr = re[g] + re[g + 2], xi = im[g] + im[g + 2];
+                re[g + 2] = re[g] - re[g + 2], im[g + 2] = im[g] - im[g + 2];
+                re[g] = xr, im[g] = xi;
+            }
+            { // odd position: T.im = B.re, T.re = B.im >= 0 ? -B.im : ~B.im
+                const int tre = (im[g + 3] >> 31) - im[g + 3], tim = re[g + 3];
+                re[g + 3] = re[g + 1] - tre, im[g + 3] = im[g + 1] - tim;
+                re[g + 1] += tre, im[g + 1] += tim;
+            }
+        }
+        wdstage32<4, true>(re, im, k.wr2, k.wi2, a.st[2]);
+        wdstage32<8, true>(re, im, k.wr3, k.wi3, a.st[3]);
+        __syncthreads(); // the previous unit's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wr0[q] = make_uint4((u32)re[4 * q], (u32)re[4 * q + 1], (u32)re[4 * q + 2], (u32)re[4 * q + 3]);
+            wr1[q] = make_uint4((u32)im[4 * q], (u32)im[4 * q + 1], (u32)im[4 * q + 2], (u32)im[4 * q + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            re[q] = (int)rd0[ROWW * 16 * q];
+            im[q] = (int)rd1[ROWW * 16 * q];
+        }
+        wdstage32<1>(re, im, w4r, w4i, a.st[4]);
+        wdstage32<2>(re, im, w5r, w5i, a.st[5]);
+        wdstage32<4>(re, im, w6r, w6i, a.st[6]);
+        wdstage32<8>(re, im, w7r, w7i, a.st[7]);
+        // scratch, the forward layout: unit r0 = [c7..4 = q][t4 = hi4][c3..0 = lo4]: 2 KiB per register
+        v2i *dst = reinterpret_cast<v2i *>(scr) + f * 65536 + 4096 * r0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2i y = {re[q], im[q]};
+            *at32(dst + 256 * q, tid_l) = y;
+        }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_q2(const int2 *scr, i64 *out, const int2 *__restrict__ twt, const WideArgs a,
+                                                                                             size_t nframes_user)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    const int tile = blockIdx.x & 15;
+    const int c = 16 * tile + lo4;
+    // round 1: thread = (r7..4 = hi4, c3..0 = lo4), registers r3..0: STAGE 8 + b on register bit b, index (rr << 8) | c: per column
+    int w11r[8], w11i[8], w10r[4], w10i[4], w9r[2], w9i[2], w8r[1], w8i[1];
+    // round 2: thread = (r3..0 = hi4, c3..0), registers r7..4: STAGE 12 + b, index n mod 2^s with n = c + 256 hi4 + 4096 jj (stages >= L: frame-number bits, skipped)
+    int w15r[8], w15i[8], w14r[4], w14i[4], w13r[2], w13i[2], w12r[1], w12i[1];
+    {
+        int2 w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w = twt[2047 + c + 256 * j];
+            w11r[j] = w.x, w11i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w = twt[1023 + c + 256 * j];
+            w10r[j] = w.x, w10i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w = twt[511 + c + 256 * j];
+            w9r[j] = w.x, w9i[j] = w.y;
+        }
+        w = twt[255 + c];
+        w8r[0] = w.x, w8i[0] = w.y;
+        const int base = c + 256 * hi4;
+        w = twt[4095 + base];
+        w12r[0] = w.x, w12i[0] = w.y;
+        if constexpr (L > 13) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                w = twt[8191 + ((base + 4096 * j) & 8191)];
+                w13r[j] = w.x, w13i[j] = w.y;
+            }
+        }
+        if constexpr (L > 14) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w = twt[16383 + ((base + 4096 * j) & 16383)];
+                w14r[j] = w.x, w14i[j] = w.y;
+            }
+        }
+        if constexpr (L > 15) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w = twt[32767 + base + 4096 * j];
+                w15r[j] = w.x, w15i[j] = w.y;
+            }
+        }
+    }
+    // transpose: round-1 thread t = (r7..4, c3..0) holds registers r3..0 -> row t; round-2 thread (r3..0 = hi4, c3..0 = lo4), register j = r7..4,
+    // reads (row 16 j + lo4, column hi4) -- k_wide16_p1's transpose run backwards; <= 36-bit values through three dword planes
+    uint4 *const wr0 = reinterpret_cast<uint4 *>(lds + ROWW * tid);
+    uint4 *const wr1 = reinterpret_cast<uint4 *>(lds + PLANEW + ROWW * tid);
+    const u32 *const rd0 = lds + ROWW * lo4 + hi4;
+    const u32 *const rd1 = rd0 + PLANEW;
+
+    const size_t fstep = gridDim.x >> 4;
+    for (size_t f = blockIdx.x >> 4; f < nframes; f += fstep) {
+        const bool partial = L < 16 && (f + 1) * G > nframes_user; // last group: rows of absent frames read as 0, are not stored
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const int g = hi4 >> (L - 12); // the real frame (within the group) of this thread's round-1 rows
+        const bool present = !partial || f * G + (size_t)g < nframes_user;
+        const v2i *src = reinterpret_cast<const v2i *>(scr) + f * 65536; // wave-uniform
+        unsigned toff2 = (unsigned)(256 * tile + lo4 + 4096 * (g << (L - 12)) + 16 * ((hi4 << (16 - L)) & 15));
+        unsigned toff = (unsigned)(c + 256 * hi4);
+        asm volatile("" : "+v"(toff), "+v"(toff2));
+        i64 re[16], im[16];
+        if (present) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2i x = INTFFT_LD(at32(src + 4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12)), toff2));
+                re[q] = x.x, im[q] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) re[q] = 0, im[q] = 0;
+        }
+        wdstage64<1>(re, im, w8r, w8i, a.st[8]);
+        wdstage64<2>(re, im, w9r, w9i, a.st[9]);
+        wdstage64<4>(re, im, w10r, w10i, a.st[10]);
+        wdstage64<8>(re, im, w11r, w11i, a.st[11]);
+        u32 hp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hp[q] = ((u32)((u64)re[q] >> 32) & 0xFFFFu) | ((u32)((u64)im[q] >> 32) << 16);
+        u32 rlo[16], ilo[16];
+        __syncthreads(); // the previous frame's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wr0[q] = make_uint4((u32)re[4 * q], (u32)re[4 * q + 1], (u32)re[4 * q + 2], (u32)re[4 * q + 3]);
+            wr1[q] = make_uint4((u32)im[4 * q], (u32)im[4 * q + 1], (u32)im[4 * q + 2], (u32)im[4 * q + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            rlo[j] = rd0[ROWW * 16 * j];
+            ilo[j] = rd1[ROWW * 16 * j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr0[q] = make_uint4(hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hp[j] = rd0[ROWW * 16 * j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            re[j] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[j], 0, 16) << 32) | rlo[j]);
+            im[j] = (i64)(((u64)(u32)((int)hp[j] >> 16) << 32) | ilo[j]);
+        }
+        wdstage64<1>(re, im, w12r, w12i, a.st[12]);
+        if constexpr (L > 13) wdstage64<2>(re, im, w13r, w13i, a.st[13]);
+        if constexpr (L > 14) wdstage64<4>(re, im, w14r, w14i, a.st[14]);
+        if constexpr (L > 15) wdstage64<8>(re, im, w15r, w15i, a.st[15]);
+        // natural order: x[(16 j + hi4) 256 + c] of the virtual frame; register j's real frame is j >> (L - 12)
+        typedef i64 v2l __attribute__((ext_vector_type(2)));
+        v2l *dst = reinterpret_cast<v2l *>(out) + f * 65536;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const v2l y = {re[j], im[j]};
+            if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) __builtin_nontemporal_store(y, at32(dst + 4096 * j, toff));
+        }
+    }
+}
+
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order)
 {
     // int32 containers in (DATA_WIDTH 17..32), pass 1 within 32 bits (DATA_WIDTH + NFFT - 8 <= 32), results in int64 containers
     // of at most 40 bits (the 64-bit products and the three-plane transpose of pass 2)
+    // the inverse (round 4): STAGE 0..7 on int32 (DATA_WIDTH + 8 <= 32), STAGE 8..L-1 on 64-bit words, the same result widths
+    if (direction == 1)
+        return log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width + 8 <= 32 && data_width + log2n > 32 && data_width + log2n <= 40 &&
+               twdl_width >= 16 && twdl_width <= 24 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0;
     return log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width + log2n - 8 <= 32 && data_width + log2n > 32 &&
            data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 && use_fly == 1 &&
            in_order == 0 && out_order == 0;
 }
 
-const char *wide16_kernel_name() { return "k_wide16_p1+p2"; }
+const char *wide16_kernel_name(int direction) { return direction == 1 ? "k_wide16_q1+q2" : "k_wide16_p1+p2"; }
 
 template <int L>
 static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void *in, void *out, void *scratch, const int2 *tw_all,
-                                size_t nframes, hipStream_t stream)
+                                size_t nframes, hipStream_t stream, int direction)
 {
     const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L); // virtual 2^16-point frames
     const size_t units = nvf * 16;
+    if (direction == 1) {
+        size_t g1 = resident_blocks(kptr(k_wide16_q1<L>), 256, 2);
+        if (g1 > units) g1 = units;
+        size_t g2 = resident_blocks(kptr(k_wide16_q2<L>), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
+        if (g2 < 16) g2 = 16;
+        if (g2 > units) g2 = units;
+        hipLaunchKernelGGL(k_wide16_q1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<int2 *>(scratch), tw_all, a, k,
+                           nframes);
+        hipLaunchKernelGGL(k_wide16_q2<L>, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a,
+                           nframes);
+        return hipGetLastError();
+    }
     size_t g1 = resident_blocks(kptr(k_wide16_p1<L>), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
     if (g1 < 16) g1 = 16;
     if (g1 > units) g1 = units;
@@ -456,17 +786,17 @@ static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void
 }
 
 hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,
-                         const int2 *h_tw, size_t nframes, hipStream_t stream)
+                         const int2 *h_tw, size_t nframes, hipStream_t stream, int direction)
 {
     if (nframes == 0) return hipSuccess;
     W2Consts k;
     for (int i = 0; i < 8; ++i) k.wr3[i] = h_tw[7 + i].x, k.wi3[i] = h_tw[7 + i].y;
     for (int i = 0; i < 4; ++i) k.wr2[i] = h_tw[3 + i].x, k.wi2[i] = h_tw[3 + i].y;
     switch (log2n) {
-    case 13: return launch_wide_l<13>(a, k, in, out, scratch, tw_all, nframes, stream);
-    case 14: return launch_wide_l<14>(a, k, in, out, scratch, tw_all, nframes, stream);
-    case 15: return launch_wide_l<15>(a, k, in, out, scratch, tw_all, nframes, stream);
-    default: return launch_wide_l<16>(a, k, in, out, scratch, tw_all, nframes, stream);
+    case 13: return launch_wide_l<13>(a, k, in, out, scratch, tw_all, nframes, stream, direction);
+    case 14: return launch_wide_l<14>(a, k, in, out, scratch, tw_all, nframes, stream, direction);
+    case 15: return launch_wide_l<15>(a, k, in, out, scratch, tw_all, nframes, stream, direction);
+    default: return launch_wide_l<16>(a, k, in, out, scratch, tw_all, nframes, stream, direction);
     }
 }
 

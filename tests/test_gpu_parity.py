@@ -1058,6 +1058,26 @@ def test_wide_two_pass_kernels_n8192_to_n65536(log2n, dw, tw, batch, monkeypatch
     assert ib["kernel_name"] != "k_wide16_p1+p2" and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(13, 24, 24, 9), (13, 24, 16, 8), (14, 24, 24, 5), (14, 22, 18, 4), (15, 24, 24, 3), (15, 24, 16, 1),
+                                               (16, 24, 24, 2), (16, 24, 16, 1), (14, 20, 16, 6), (15, 18, 24, 2), (16, 17, 16, 1), (13, 21, 24, 17)])
+def test_wide_two_pass_inverse_n8192_to_n65536(log2n, dw, tw, batch, monkeypatch):
+    """int_ifftNk on the class of BASELINE config 3 (round 4): k_wide16_q1 (bit-reversed gather, DIT STAGE 0..7 on int32) + k_wide16_q2
+    (STAGE 8..L-1 on 64-bit words), N = 2^13 .. 2^16, DATA_WIDTH 17 .. 24 (int_ifftNk.vhd:183-341; the multiplier of STAGE s works
+    at 24 + s bits, int_dit2_fly.vhd:290-325): bit-exact to the oracle incl. edge frames and partial last groups, both XSER, and equal to
+    the generic kernels it replaces (INTFFT_NO_WIDE16)."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 350 + log2n + dw), edge_frames(n, dw)[[0, 1, 4]]])[:max(batch, 1) + (2 if log2n < 15 else 0)]
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), C.INV) != 0:
+            continue
+        info = check(x, log2n, dw, tw, 1, 0, new, direction="INV")
+        assert info["kernel_name"] == "k_wide16_q1+q2" and info["n_passes"] == 2 and info["out_container"] == 8, info
+    a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+    monkeypatch.setenv("INTFFT_NO_WIDE16", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+    assert ib["kernel_name"] != "k_wide16_q1+q2" and np.array_equal(a, b)
+
+
 def test_wide_family_random_configurations():
     """Seeded fuzz over the unscaled plans with int64 results (N = 2^10 .. 2^16, DATA_WIDTH 17 .. 30, TWDL_WIDTH 10 .. 25, both
     XSER): whichever kernel the planner picks (k_fft1024_w32 / k_fft4096_w32 with 64-bit tails, k_wide16_p1+p2<L>, k_pass<long>),
