@@ -156,6 +156,19 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
  * (intfftk_amd/sharding.py: grouped ncclSend/ncclRecv scatter and gather). */
 int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t max_batch);
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch);
+/* How intfft_exec_sharded moves the shards between the root and the other devices ("grouped
+ * ncclSend / ncclRecv root <-> peers so that all links of the root are driven concurrently"):
+ *   INTFFT_TRANSPORT_PEER  hipMemcpyPeerAsync per shard on the shard's stream (the default)
+ *   INTFFT_TRANSPORT_RCCL  RCCL over xGMI: ONE ncclGroupStart .. ncclGroupEnd of ncclSend (root) / ncclRecv (peer) pairs for the scatter,
+ *                          one for the gather.  librccl.so is loaded with dlopen on the first request (no link-time dependency); the
+ *                          communicators (ncclCommInitAll over the plans' devices, rank i = plans[i]) belong to the plan set and are
+ *                          released by intfft_plan_destroy of plans[0].  Needs every plan on its own device.
+ * Returns INTFFT_OK; INTFFT_ERR_UNSUPPORTED when RCCL cannot be loaded or the communicators cannot be created (two plans on one
+ * device, no librccl.so): the plan set then stays on peer copies, so a caller may simply try RCCL first.  The two transports give the
+ * same bytes.  Like intfft_shard_prepare this call modifies the plans: not concurrently with any other call on them. */
+#define INTFFT_TRANSPORT_PEER 0
+#define INTFFT_TRANSPORT_RCCL 1
+int intfft_shard_set_transport(intfft_plan *const *plans, int nplans, int root, int transport);
 
 /* Standalone re-orderer: the stream buffers of src/vhdl/buffers/ as an operator of their own (no plan, no arithmetic).
  * d_out[f][m_out] = d_in[f][m_in] for every frame f, where m_in (memory index in `from_order`) and m_out (memory index

@@ -10,13 +10,14 @@ LIB_PATH = os.environ.get("INTFFT_LIB") or os.path.join(_HERE, "lib", "libintfft
 OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_NULL, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3, -4, -5
 FWD, INV, PAIR = 0, 1, 2
+TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1
 ORDER_NATURAL, ORDER_BITREV, ORDER_HALVES, ORDER_BITREV_LANES = 0, 1, 2, 3
 ORDERS = {"NATURAL": 0, "BITREV": 1, "HALVES": 2, "BITREV_LANES": 3}
 DIRECTIONS = {"FWD": 0, "INV": 1, "PAIR": 2}
 
 # every symbol include/intfft.h declares
 SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy", "intfft_plan_get_info",
-           "intfft_exec", "intfft_exec_host", "intfft_shard_prepare", "intfft_exec_sharded", "intfft_reorder",
+           "intfft_exec", "intfft_exec_host", "intfft_shard_prepare", "intfft_exec_sharded", "intfft_shard_set_transport", "intfft_reorder",
            "intfft_twiddles", "intfft_strerror", "intfft_version")
 
 
@@ -72,6 +73,7 @@ def lib():
         L.intfft_exec_sharded.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_size_t]
         L.intfft_shard_prepare.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+        L.intfft_shard_set_transport.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.intfft_reorder.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         L.intfft_twiddles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -81,7 +83,7 @@ def lib():
         L.intfft_version.restype = ctypes.c_char_p
         for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy",
                    "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded",
-                   "intfft_shard_prepare", "intfft_reorder", "intfft_twiddles"):
+                   "intfft_shard_prepare", "intfft_shard_set_transport", "intfft_reorder", "intfft_twiddles"):
             getattr(L, fn).restype = ctypes.c_int
         _lib = L
     return _lib

@@ -11,6 +11,8 @@
 #include "../../include/intfft.h"
 #include "intfft_internal.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -166,6 +168,11 @@ struct intfft_plan {
     size_t shard_in_bytes = 0, shard_out_bytes = 0;
     hipStream_t s_shard = nullptr;
     int shard_peer = -1; // root device this plan's device has peer access to (-1: not set up yet)
+    // RCCL transport of intfft_exec_sharded (intfft_shard_set_transport): this plan's communicator of the plan set (rank = its index in the
+    // set), the set's size; plans[0] of the set owns all of them (rccl_owned)
+    void *rccl_comm = nullptr;
+    int rccl_rank = -1, rccl_nranks = 0;
+    std::vector<void *> rccl_owned;
     size_t slot_frames = 0;
     char kernel_name[64] = {0};
 };
@@ -561,6 +568,52 @@ int build_twiddles(intfft_plan &pl, hipStream_t stream)
 }
 
 } // namespace
+
+// ---- RCCL, loaded at run time (no link-time dependency; the peer-copy transport needs none of it) --------------------------------------
+namespace {
+struct Rccl {
+    typedef int (*comm_init_all_t)(void **, int, const int *);
+    typedef int (*comm_destroy_t)(void *);
+    typedef int (*group_t)(void);
+    typedef int (*sendrecv_t)(const void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*recv_t)(void *, size_t, int, int, void *, hipStream_t);
+    void *handle = nullptr;
+    comm_init_all_t comm_init_all = nullptr;
+    comm_destroy_t comm_destroy = nullptr;
+    group_t group_start = nullptr, group_end = nullptr;
+    sendrecv_t send = nullptr;
+    recv_t recv = nullptr;
+    bool ok = false;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if ((r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        }
+        if (!r.handle) return;
+        r.comm_init_all = reinterpret_cast<Rccl::comm_init_all_t>(dlsym(r.handle, "ncclCommInitAll"));
+        r.comm_destroy = reinterpret_cast<Rccl::comm_destroy_t>(dlsym(r.handle, "ncclCommDestroy"));
+        r.group_start = reinterpret_cast<Rccl::group_t>(dlsym(r.handle, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<Rccl::group_t>(dlsym(r.handle, "ncclGroupEnd"));
+        r.send = reinterpret_cast<Rccl::sendrecv_t>(dlsym(r.handle, "ncclSend"));
+        r.recv = reinterpret_cast<Rccl::recv_t>(dlsym(r.handle, "ncclRecv"));
+        r.ok = r.comm_init_all && r.comm_destroy && r.group_start && r.group_end && r.send && r.recv;
+    });
+    return r;
+}
+constexpr int NCCL_INT8 = 0; // ncclInt8 / ncclChar (rccl.h)
+} // namespace
+
+static void rccl_release(intfft_plan *owner)
+{
+    Rccl &r = rccl();
+    for (void *c : owner->rccl_owned)
+        if (c && r.ok) (void)r.comm_destroy(c);
+    owner->rccl_owned.clear();
+}
 
 extern "C" {
 
@@ -1025,6 +1078,7 @@ int intfft_plan_destroy(intfft_plan *plan)
         if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
         if (plan->shard_in) (void)hipFree(plan->shard_in);
         if (plan->shard_out) (void)hipFree(plan->shard_out);
+        if (!plan->rccl_owned.empty()) rccl_release(plan);
         if (plan->s_shard) (void)hipStreamDestroy(plan->s_shard);
         free_stream_state(plan);
         if (plan->d_tw16f) (void)hipFree(plan->d_tw16f);
@@ -1521,12 +1575,113 @@ int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t
     return INTFFT_OK;
 }
 
+int intfft_shard_set_transport(intfft_plan *const *plans, int nplans, int root, int transport)
+{
+    const int rc = shard_check(plans, nplans, root);
+    if (rc != INTFFT_OK) return rc;
+    if (transport != INTFFT_TRANSPORT_PEER && transport != INTFFT_TRANSPORT_RCCL) return INTFFT_ERR_INVALID;
+    // drop what the set had (the owner is whichever plan created the communicators)
+    for (int i = 0; i < nplans; ++i) {
+        if (!plans[i]->rccl_owned.empty()) rccl_release(plans[i]);
+        plans[i]->rccl_comm = nullptr, plans[i]->rccl_rank = -1, plans[i]->rccl_nranks = 0;
+    }
+    if (transport == INTFFT_TRANSPORT_PEER) return INTFFT_OK;
+    Rccl &r = rccl();
+    if (!r.ok) return INTFFT_ERR_UNSUPPORTED;
+    std::vector<int> devs(nplans);
+    for (int i = 0; i < nplans; ++i) {
+        devs[i] = plans[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i]) return INTFFT_ERR_UNSUPPORTED; // RCCL: one rank per device
+    }
+    std::vector<void *> comms(nplans, nullptr);
+    if (r.comm_init_all(comms.data(), nplans, devs.data()) != 0) return INTFFT_ERR_UNSUPPORTED;
+    for (int i = 0; i < nplans; ++i) plans[i]->rccl_comm = comms[i], plans[i]->rccl_rank = i, plans[i]->rccl_nranks = nplans;
+    plans[0]->rccl_owned = comms;
+    return INTFFT_OK;
+}
+
+// the RCCL transport of intfft_exec_sharded: scatter group, transforms, gather group (every shard's operations on its own stream)
+static int exec_sharded_rccl(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
+{
+    Rccl &r = rccl();
+    intfft_plan *rp = plans[root];
+    const size_t N = (size_t)1 << rp->L;
+    const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
+    hipError_t e = hipSuccess;
+    int rc = INTFFT_OK, nc = 0;
+    std::vector<size_t> first(nplans, 0), cnt(nplans, 0);
+    for (int i = 0, start = 0; i < nplans; ++i) {
+        cnt[i] = shard_frames(batch, nplans, i);
+        first[i] = (size_t)start;
+        start += (int)cnt[i];
+    }
+    for (int i = 0; i < nplans && e == hipSuccess; ++i) { // staging + streams (no-op after intfft_shard_prepare)
+        DeviceGuard g(plans[i]->device);
+        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+        e = shard_state(plans[i], rp->device, i == root ? 0 : cnt[i] * in_frame, i == root ? 0 : cnt[i] * out_frame);
+    }
+    if (e != hipSuccess) return (int)e;
+    // scatter: ONE group; the root's sends go out on all its links at once
+    nc |= r.group_start();
+    for (int i = 0; i < nplans; ++i) {
+        if (i == root || cnt[i] == 0) continue;
+        {
+            DeviceGuard g(rp->device);
+            nc |= r.send(static_cast<const char *>(d_in) + first[i] * in_frame, cnt[i] * in_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard);
+        }
+        DeviceGuard g(plans[i]->device);
+        nc |= r.recv(plans[i]->shard_in, cnt[i] * in_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard);
+    }
+    nc |= r.group_end();
+    for (int i = 0; i < nplans && nc == 0 && rc == INTFFT_OK; ++i) { // every device transforms its shard (stream order behind its receive)
+        if (cnt[i] == 0) continue;
+        DeviceGuard g(plans[i]->device);
+        rc = i == root ? intfft_exec(plans[i], static_cast<const char *>(d_in) + first[i] * in_frame, static_cast<char *>(d_out) + first[i] * out_frame,
+                                     cnt[i], plans[i]->s_shard)
+                       : intfft_exec(plans[i], plans[i]->shard_in, plans[i]->shard_out, cnt[i], plans[i]->s_shard);
+    }
+    if (nc == 0 && rc == INTFFT_OK) { // gather: one group
+        nc |= r.group_start();
+        for (int i = 0; i < nplans; ++i) {
+            if (i == root || cnt[i] == 0) continue;
+            {
+                DeviceGuard g(plans[i]->device);
+                nc |= r.send(plans[i]->shard_out, cnt[i] * out_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard);
+            }
+            DeviceGuard g(rp->device);
+            nc |= r.recv(static_cast<char *>(d_out) + first[i] * out_frame, cnt[i] * out_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard);
+        }
+        nc |= r.group_end();
+    }
+    for (int i = 0; i < nplans; ++i) { // drain every stream that was used, also after an error
+        if (!plans[i]->s_shard) continue;
+        DeviceGuard g(plans[i]->device);
+        const hipError_t es = hipStreamSynchronize(plans[i]->s_shard);
+        if (e == hipSuccess) e = es;
+    }
+    if (rc != INTFFT_OK) return rc;
+    if (nc != 0) return (int)hipErrorUnknown; // an RCCL call failed (positive status = device-side error class, intfft_strerror)
+    return e == hipSuccess ? INTFFT_OK : (int)e;
+}
+
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
 {
     int rc = shard_check(plans, nplans, root);
     if (rc != INTFFT_OK) return rc;
     if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
     if (batch == 0) return INTFFT_OK;
+    bool use_rccl = true; // the whole set carries communicators of this very set
+    for (int i = 0; i < nplans; ++i) use_rccl = use_rccl && plans[i]->rccl_comm && plans[i]->rccl_rank == i && plans[i]->rccl_nranks == nplans;
+    if (use_rccl) {
+        {   // same entry contract as the peer-copy transport
+            DeviceGuard g(plans[root]->device);
+            if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+            const hipError_t es = hipDeviceSynchronize();
+            if (es != hipSuccess) return (int)es;
+        }
+        return exec_sharded_rccl(plans, nplans, root, d_in, d_out, batch);
+    }
     intfft_plan *rp = plans[root];
     const size_t N = (size_t)1 << rp->L;
     const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;

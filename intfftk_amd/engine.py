@@ -212,10 +212,12 @@ def int_fft_2d(NFFT=20, NFFT1=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMOD
                       NFFT1=NFFT1)
 
 
-def exec_sharded(cores, x, root: int = 0):
+def exec_sharded(cores, x, root: int = 0, transport: str = None):
     """Single-process multi-GPU transform through intfft_exec_sharded: `cores` are IntFFTCore objects with identical
     generics (normally one per HIP device), `x` a [batch, N, 2] tensor on the device of cores[root].  Contiguous
-    shards, remainder to the last cores, peer copies over xGMI, no collective.  Blocking."""
+    shards, remainder to the last cores, no collective.  transport: None (leave the plan set as it is: peer copies unless
+    changed earlier), "peer" (hipMemcpyPeerAsync) or "rccl" (grouped ncclSend / ncclRecv over xGMI, one group each way;
+    raises if RCCL cannot serve the set, e.g. two cores on one device).  Blocking."""
     import torch
 
     if not cores or not 0 <= root < len(cores):
@@ -229,6 +231,11 @@ def exec_sharded(cores, x, root: int = 0):
         raise ValueError("input must be a contiguous [batch, %d, 2] %s tensor" % (c0.n, c0.in_dtype))
     y = torch.empty(c0.out_shape(x.shape[0]), dtype=c0.out_dtype, device=x.device)
     arr = (ctypes.c_void_p * len(cores))(*[c._plan for c in cores])
+    if transport is not None:
+        if transport not in ("peer", "rccl"):
+            raise ValueError("transport must be 'peer' or 'rccl'")
+        capi.check(capi.lib().intfft_shard_set_transport(arr, len(cores), root, capi.TRANSPORT_RCCL if transport == "rccl" else capi.TRANSPORT_PEER),
+                   "intfft_shard_set_transport")
     torch.cuda.synchronize(x.device)
     capi.check(capi.lib().intfft_exec_sharded(arr, len(cores), root, x.data_ptr(), y.data_ptr(), x.shape[0]),
                "intfft_exec_sharded")

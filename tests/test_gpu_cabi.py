@@ -58,6 +58,25 @@ def test_c_driver_matches_oracle(c_driver, tmp_path, nfft, mode, batch):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+def test_c_driver_sharded(c_driver, tmp_path, transport):
+    """driver --sharded: one plan per visible device, intfft_shard_prepare + intfft_shard_set_transport + intfft_exec_sharded from plain C
+    (RCCL through the library's dlopen -- the driver itself links neither RCCL nor torch); the result is the oracle's."""
+    nfft, batch = 10, 77
+    n = 1 << nfft
+    x = uniform_frames(batch, n, 16, 5151)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    x.astype(np.int16).tofile(fin)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "intfftk_amd", "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([c_driver, "--sharded", transport, fin, fout, str(batch), str(nfft), "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert ("transport rccl" if transport == "rccl" else "transport peer copies") in r.stdout, r.stdout
+    got = np.fromfile(fout, dtype=np.int16).reshape(batch, n, 2).astype(np.int64)
+    assert np.array_equal(got, C.execute(x, C.make_params(nfft, 16, 16, 0, 0, True), C.FWD))
+
+
 # ---- intfft_reorder: the buffers/ blocks as an operator ------------------------------------------------------------
 def _order_index(order, log2n):
     L = C.lib()
@@ -181,6 +200,42 @@ def test_shard_prepare_then_exec_sharded():
         exec_sharded(cores, xd.cpu(), 1)
     with pytest.raises(ValueError):
         exec_sharded([cores[0], cores[0]], xd, 0)
+    for c in cores:
+        c.close()
+
+
+def test_exec_sharded_rccl_transport_equals_peer_copies():
+    """intfft_shard_set_transport(INTFFT_TRANSPORT_RCCL): the scatter and the gather of intfft_exec_sharded as ONE group of ncclSend / ncclRecv
+    each (librccl.so through dlopen, communicators owned by the plan set), one plan per visible device (world = device_count: 1 on the
+    single-GPU box -- the root transforms in place and both groups are empty --, 8 on a full node), bit for bit the result of the peer-copy
+    transport and of the oracle; two plans on one device are refused by RCCL and the set stays on peer copies; odd batches (remainder to the
+    last plans), a batch smaller than the set."""
+    import torch
+
+    from intfftk_amd import IntFFTCore, exec_sharded
+    from intfftk_amd import _capi as capi
+
+    ndev = torch.cuda.device_count()
+    cores = [IntFFTCore(10, 16, 16, 0, 0, "NEW", "FWD", device=i) for i in range(ndev)]
+    p = C.make_params(10, 16, 16, 0, 0, True)
+    for batch in (max(1, ndev - 1), 5 * ndev + 3, 4096 + 1):
+        x = uniform_frames(batch, 1024, 15, 90 + batch)
+        xd = torch.from_numpy(x.astype(np.int16)).to("cuda:0")
+        y_rccl = exec_sharded(cores, xd, 0, transport="rccl")
+        y_peer = exec_sharded(cores, xd, 0, transport="peer")
+        assert torch.equal(y_rccl, y_peer)
+        sel = sorted({0, batch // 2, batch - 1})
+        assert np.array_equal(y_rccl[sel].cpu().numpy().astype(np.int64), C.execute(x[sel], p, C.FWD))
+    if ndev > 1:  # another root
+        xd1 = xd.to("cuda:1")
+        assert torch.equal(exec_sharded(cores, xd1, 1, transport="rccl").cpu(), y_peer.cpu())
+    # one rank per device: a set with two plans on device 0 cannot have communicators; it keeps working on peer copies
+    twin = IntFFTCore(10, 16, 16, 0, 0, "NEW", "FWD", device=0)
+    arr = (ctypes.c_void_p * 2)(cores[0]._plan, twin._plan)
+    assert capi.lib().intfft_shard_set_transport(arr, 2, 0, capi.TRANSPORT_RCCL) == capi.ERR_UNSUPPORTED
+    assert capi.lib().intfft_shard_set_transport(arr, 2, 0, 7) == capi.ERR_INVALID
+    assert torch.equal(exec_sharded([cores[0], twin], xd, 0), y_peer)
+    twin.close()
     for c in cores:
         c.close()
 
