@@ -102,6 +102,11 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = in + frame * ((size_t)1 << LV) + lfull;
         u32 *dst = scr + frame * ((size_t)1 << LV) + lfull;
+        // the full-group path: wave-uniform base + 32-bit thread offset (at32: SGPR base, no 64-bit VALU address arithmetic per access)
+        const u32 *srcu = in + frame * ((size_t)1 << LV);
+        u32 *dstu = scr + frame * ((size_t)1 << LV);
+        unsigned toff_a = ((unsigned)hx << LOWB) + lfull, toff_b = ((unsigned)hx << (LOWB + 4)) + lfull;
+        asm volatile("" : "+v"(toff_a), "+v"(toff_b));
         u32 v[16];
         const bool partial = L < LV && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
         if (halves) { // HALVES beats (x[i], x[i + N/2]): beat 65536 jj + 4096 hx + n11..0 of the group -> regs (j0, j0 | 2^(L-17))
@@ -122,12 +127,11 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
                 v[j] = frame * G + (size_t)((16 * j + hx) >> (L - LOWB)) < nframes_user ? src[(size_t)(16 * j + hx) << LOWB] : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(src + ((size_t)(16 * j + hx) << LOWB)); // regs = n19..16
+            for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(at32(srcu + ((size_t)j << (LOWB + 4)), toff_a)); // regs = n19..16
         }
         // guard-bit vote of the tile (it is closed under stages 19..12, so its own inputs bound every sum);
         // the barrier also orders the previous frame's LDS reads before this frame's writes
         const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0);
-    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dif_round<FAST_OK, false, NS1>(v, t1, sl, none);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(512) void k_big20_p1(const u32 *in, u32 *scr, const
                 if (frame * G + (size_t)((16 * hx + r) >> (L - LOWB)) < nframes_user) dst[(size_t)(16 * hx + r) << LOWB] = v[r];
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dst[(size_t)(16 * hx + r) << LOWB] = v[r];
+            for (int r = 0; r < 16; ++r) *at32(dstu + ((size_t)r << LOWB), toff_b) = v[r];
         }
     }
 }
@@ -329,6 +333,10 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const u32 *src = scr + frame * ((size_t)1 << LV) + lfull;
         u32 *dst = out + frame * ((size_t)1 << LV) + lfull;
+        const u32 *srcu = scr + frame * ((size_t)1 << LV); // (the full-group path: at32, see k_big20_p1)
+        u32 *dstu = out + frame * ((size_t)1 << LV);
+        unsigned toff_a = ((unsigned)hx << LOWB) + lfull, toff_b = ((unsigned)hx << (LOWB + 4)) + lfull;
+        asm volatile("" : "+v"(toff_a), "+v"(toff_b));
         const bool partial = L < LV && (frame + 1) * G > nframes_user;
         u32 v[16];
         if (partial) {
@@ -338,10 +346,9 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) // thread hx = n19..16, regs = n15..12; (two-pass split: non-temporal loads +3 %, three-pass: -2 %)
-                v[r] = LOWB == 8 ? INTFFT_LD(src + ((size_t)(16 * hx + r) << LOWB)) : src[(size_t)(16 * hx + r) << LOWB];
+                v[r] = LOWB == 8 ? INTFFT_LD(at32(srcu + ((size_t)r << LOWB), toff_b)) : *at32(srcu + ((size_t)r << LOWB), toff_b);
         }
         const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0); // also orders the previous LDS reads
-    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads();
         if (fast) dit_round<FAST_OK>(v, t2, sl);
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(512) void k_big20_q1(const u32 *scr, u32 *out, cons
                 if (frame * G + (size_t)((16 * j + hx) >> (L - LOWB)) < nframes_user) dst[(size_t)(16 * j + hx) << LOWB] = v[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)(16 * j + hx) << LOWB));
+            for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], at32(dstu + ((size_t)j << (LOWB + 4)), toff_a));
         }
     }
 }
@@ -566,9 +573,10 @@ __global__ __launch_bounds__(512) void k_mid_p2(const u32 *scr, u32 *out, const 
     else if (!FAST_OK && sl.round == 2) dif_round_c<false, 2>(v, c, sl, sh3); // ... on narrow data: with the w-bit wraps (intfft_pk16.hpp)
     else dif_round_c<false>(v, c, sl, sh3);
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
-    u32 *dst = out + (frame << L) + ((size_t)rev4b(hi4) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
+    u32 *dst = out + (frame << L) + ((size_t)rmid << 5); // wave-uniform; thread part through at32 (SGPR base + 32-bit offset)
+    const unsigned toff = ((unsigned)rev4b(hi4) << (L - 8)) + (unsigned)(tid & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], dst + ((size_t)rev4b(r) << (L - 4)));
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev4b(r) << (L - 4)), toff));
 }
 
 // ---- inverse two-pass split (mirror of k_mid_p2): bit-reversed load of the natural-order input + DIT STAGE 0..7 -------
@@ -681,7 +689,6 @@ __global__ __launch_bounds__(256) void k_big20_q2(u32 *scr, const int2 *__restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = p[256 * j + tid]; // LA: regs = n11..8, thread = n7..0
         const bool fast = FAST_OK && !block_any(vote_flags, vote_phase, guard_acc(v, sl.gbias, sl.gmask) != 0);
-    if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd); // DATA_WIDTH < 16, exact path: containers wrapped to w bits
         if (!FAST_OK) __syncthreads(); // orders the previous block's reg1 reads before this block's writes
         // LA -> LB: row = 16 j + n3..0, column = n7..4

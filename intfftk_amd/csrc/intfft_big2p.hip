@@ -49,7 +49,7 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
     // and ONE offset VGPR (global_load ... v_off, s[base]) instead of materialising a 64-bit address pair per access -- with
     // 32 loads, 32 stores and 16 twiddle loads per frame that was 160 VGPRs of addresses and 60 spilled dwords per lane
     auto ld = [&](unsigned uniform_idx, unsigned thread_off, u32 &wa, u32 &wb) {
-        const uint2 w = (twf + uniform_idx)[thread_off];
+        const uint2 w = ld2_at32b(twf + uniform_idx, thread_off); // thread_off: the thread's BYTE offset (opaque per frame)
         wa = w.x;
         wb = w.y;
     };
@@ -124,15 +124,17 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             const v2u *s2 = reinterpret_cast<const v2u *>(src);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const v2u w = INTFFT_LD(s2 + ((size_t)j << (RB + 8)) + toff_l);
+                const v2u w = INTFFT_LD(at32(s2 + ((size_t)j << (RB + 8)), toff_l));
                 v[j] = w.x;
                 v[j + 16] = w.y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(src + ((size_t)j << (RB + 8)) + toff_l); // regs = n(L-1)..n(L-5)
+            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (RB + 8)), toff_l)); // regs = n(L-1)..n(L-5)
         }
-        round1_tw(toff_l);
+        unsigned twb = toff_l * 8u;
+        asm volatile("" : "+v"(twb));
+        round1_tw(twb);
         // guard-bit vote of the tile (closed under stages L-1..8); the barrier also orders the previous frame's LDS reads
         bool fast = false;
         {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
             }
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) (dst + ((size_t)q << 8))[toff2_l] = v[q]; // row (jx << 5 | q): uniform q part + thread part
+        for (int q = 0; q < 32; ++q) *at32(dst + ((size_t)q << 8), toff2_l) = v[q]; // row (jx << 5 | q): uniform q part + thread part
     }
     (void)T;
 }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(src + ((size_t)q << 8) + toff_l); // (plain loads: 325 vs 332 Gsample/s)
+        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)q << 8), toff_l)); // (plain loads: 325 vs 332 Gsample/s)
         bool fast = false;
         {
             u32 acc = 0;
@@ -287,8 +289,10 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
         // round 2's per-thread twiddles: stage L-5+b, index (jj << (L-5)) | (p << 8) | lfull
         RoundTwQ t2;
         u32 wa16[8], wb16[8];
+        unsigned twb = toff2_l * 8u;
+        asm volatile("" : "+v"(twb));
         auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
-            const uint2 w = (twf + uniform_idx)[toff2_l];
+            const uint2 w = ld2_at32b(twf + uniform_idx, twb);
             wa = w.x;
             wb = w.y;
         };
@@ -336,11 +340,11 @@ __global__ __launch_bounds__(32 << (L - 13)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const v2u w = {v[j], v[j + 16]};
-                __builtin_nontemporal_store(w, d2 + ((size_t)j << (L - 5)) + toff2_l);
+                __builtin_nontemporal_store(w, at32(d2 + ((size_t)j << (L - 5)), toff2_l));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], dst + ((size_t)j << (L - 5)) + toff2_l);
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (L - 5)), toff2_l));
         }
     }
     (void)T;
