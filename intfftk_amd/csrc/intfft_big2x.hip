@@ -144,6 +144,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         unsigned toff_l = toff, toff2_l = toff2; // opaque copies: see k_big2p_a (LICM would hoist 40+ VGPRs of addresses)
         asm volatile("" : "+v"(toff_l), "+v"(toff2_l));
         u32 v[32];
+        __builtin_amdgcn_s_setprio(3); // the tile's 32 + 16 loads go out ahead of the other workgroup's arithmetic (C4 300-302 -> 305 Gsample/s)
         if (halves) { // HALVES order in: memory index = 2 * (n without n(L-1)) + n(L-1): registers j and j + 16 are one 8-byte load
             typedef u32 v2u __attribute__((ext_vector_type(2)));
             const v2u *sh = reinterpret_cast<const v2u *>(src);
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
         unsigned twb = toff_l * 8u;
         asm volatile("" : "+v"(twb));
         round1_tw(twb);
+        __builtin_amdgcn_s_setprio(0);
         // guard-bit vote of the tile (closed under stages L-1..10); the barrier also orders the previous frame's LDS reads
         bool fast = false;
         {
@@ -1138,7 +1140,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         /* frame groups: 64 = every block takes ONE tile of a 64-frame chunk.  The partner blocks b, b + 8 then start together  \
            (per-XCD dispatch order) instead of drifting apart over a frame walk: FETCH_SIZE 387 MB against 436 MB per 2^26      \
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
-        const size_t cap = 64;                                                                                                     \
+        static const size_t cap_env = diag_env("INTFFT_2XA_GROUPS") ? (size_t)atoi(diag_env("INTFFT_2XA_GROUPS")) : 0;             \
+        const size_t cap = cap_env ? cap_env : 64;                                                                                 \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
         INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                \
         const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \

@@ -58,6 +58,18 @@ ROWS.append(("14:16:16:1:0:INV", "16-bit unscaled INV"))
 ROWS.append(("16:16:16:1:0:INV", "16-bit unscaled INV"))
 ROWS.append(("16:32:24:0", "32-bit scaled FWD"))
 ROWS.append(("19:16:16:0", "16-bit scaled-trunc FWD"))
+# round 4
+ROWS.append(("15:16:16:0", "16-bit scaled-trunc FWD"))
+for L in (13, 15):
+    ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
+    ROWS.append(("%d:16:16:0:0:PAIR" % L, "16-bit scaled-trunc PAIR"))
+for L in (17, 18, 19):
+    ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
+ROWS.append(("18:16:16:0:1:INV", "16-bit scaled-round INV"))
+ROWS.append(("23:16:16:0:0:FWD:10", "16-bit scaled-trunc FWD, 2-D scheme 2^10 x 2^13"))
+for L in (13, 14, 16):
+    ROWS.append(("%d:24:24:1:0:INV" % L, "24-bit unscaled INV (40-bit results)"))
+ROWS.append(("16:24:16:1:0:INV", "24-bit data / 16-bit twiddle unscaled INV"))
 ROWS.append(("19:16:16:0:0:INV", "16-bit scaled-trunc INV"))
 ROWS.append(("10:32:16:1", "32-bit unscaled FWD (42-bit results)"))
 ROWS.append(("7:32:16:1", "32-bit unscaled FWD (39-bit results)"))
@@ -88,10 +100,14 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
           "lengths that is ONE scratch chunk per call, so the two-stream chunk alternation of N = 2^19 / 2^20, the 24-bit class and the tiled "
-          "2-D plans does not show here: BASELINE's batches are `python bench.py --config C3 | C4 | C5` (C4: 291-295, C3: 143).\n")
+          "2-D plans does not show here: BASELINE's batches are `python bench.py --config C3 | C4 | C5` (profiles/rNN_other_configs_bench.jsonl).\n")
     print("| N | mode | kernel | passes | Gsample/s | B/sample | GB/s | frac of 8 TB/s | parity prefix |")
     print("|---|---|---|---|---|---|---|---|---|")
+    seen = set()
     for spec, label in ROWS:
+        if spec in seen:
+            continue
+        seen.add(spec)
         B.adhoc(spec)
         r = B.run(spec, steps=10)
         bps = r["GB/s"] / r["Gsample/s"]
