@@ -1140,8 +1140,7 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         /* frame groups: 64 = every block takes ONE tile of a 64-frame chunk.  The partner blocks b, b + 8 then start together  \
            (per-XCD dispatch order) instead of drifting apart over a frame walk: FETCH_SIZE 387 MB against 436 MB per 2^26      \
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
-        static const size_t cap_env = diag_env("INTFFT_2XA_GROUPS") ? (size_t)atoi(diag_env("INTFFT_2XA_GROUPS")) : 0;             \
-        const size_t cap = cap_env ? cap_env : 64;                                                                                 \
+        const size_t cap = 64;                                                                                                     \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
         INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                \
         const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \
