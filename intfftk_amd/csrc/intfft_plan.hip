@@ -739,6 +739,19 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             pl->fused2d = 5;
         const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
+            // the fused launches run none of the 1-D sub-plans except form 3's rows, and forms 2 / 4 need one layout buffer only:
+            // keep the core whose twiddle tables the tile kernels read (core1k), release the rest
+            auto drop = [&](intfft_plan **sp) {
+                if (*sp && *sp != core1k && !(pl->fused2d == 3 && *sp == pl->sub_row_f)) {
+                    intfft_plan_destroy(*sp);
+                    *sp = nullptr;
+                }
+            };
+            drop(&pl->sub_col_f), drop(&pl->sub_row_f), drop(&pl->sub_row_i), drop(&pl->sub_col_i);
+            if (pl->fused2d == 2 || pl->fused2d == 4) {
+                (void)hipFree(pl->buf2d[1]);
+                pl->buf2d[1] = nullptr;
+            }
             // the 1024-point cores' twiddles in the packed operand forms (the single-kernel sub-plans pack theirs on the fly)
             const size_t total = ((size_t)1 << 10) - 1;
             hipError_t e = hipMalloc((void **)&pl->d_tw16f, (total + 1) * sizeof(uint2));
@@ -940,6 +953,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                     return INTFFT_ERR_ALLOC;
                 }
                 pl->scratch_bytes = pl->pair_frames * frame_bytes + pl->pair_f->scratch_bytes + pl->pair_i->scratch_bytes;
+                // the two sub-plans carry their own tables and passes: the parent's were only needed to decide eligibility
+                (void)hipFree(pl->d_tw);
+                pl->d_tw = nullptr;
+                pl->passes.clear();
+                pl->passes.shrink_to_fit();
                 std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "pair[%.24s|%.24s]", pl->pair_f->kernel_name, pl->pair_i->kernel_name);
                 *out = pl;
                 return INTFFT_OK;
@@ -1120,7 +1138,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
         // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
-        info->scratch_bytes = 2 * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+        info->scratch_bytes = (plan->buf2d[1] ? 2 : 1) * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
         for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
             if (sp) info->scratch_bytes += sp->scratch_bytes;
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);

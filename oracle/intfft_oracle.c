@@ -619,7 +619,9 @@ static int exec_frame(const orc_params *p, const tw_set *tw, int direction, int 
 
 /* threads <= 0: sized to the work (about 2^21 stage-samples per thread, never more threads than frames) -- a team of every host
  * thread for a handful of short frames costs ~0.15 s per call on a 256-thread box (spin-up / spin-down beside torch's own pool),
- * which was 85 % of the GPU parity suite's run time.  An explicit count (bench.py's cpu_baseline) is taken as given. */
+ * which was 85 % of the GPU parity suite's run time.  An explicit count (bench.py's cpu_baseline passes one) is used as given except
+ * that it, too, is capped at the number of frames: frames are the only unit of parallelism here, extra threads would idle.
+ * Callers that relied on the earlier "threads <= 0 means every core" now get the work-sized team; pass omp_get_max_threads() for that. */
 static int pick_threads(int threads, size_t batch, size_t n, int log2n)
 {
 #ifdef _OPENMP

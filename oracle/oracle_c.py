@@ -96,7 +96,9 @@ def out_width(p: Params, direction: int) -> int:
 
 def execute(x: np.ndarray, p: Params, direction=FWD, in_order=NATURAL, out_order=NATURAL,
             form=1, threads=0) -> np.ndarray:
-    """x: integer array [batch, N, 2] (any int dtype) -> int64 array [batch, N, 2]."""
+    """x: integer array [batch, N, 2] (any int dtype) -> int64 array [batch, N, 2].
+    threads = 0: a team sized to the work (about 2^21 stage-samples per thread, at most one per frame; see pick_threads in
+    intfft_oracle.c) -- not "every core" as before round 3; an explicit count is capped at the number of frames."""
     n = 1 << p.log2n
     a = np.ascontiguousarray(x, dtype=np.int64).reshape(-1, n, 2)
     out = np.empty_like(a)

@@ -176,6 +176,28 @@ def test_two_pass_cores_own_orders_chunked_n2pow20(direction, monkeypatch):
     assert np.array_equal(got[:40], got3)
 
 
+@pytest.mark.parametrize("case", [(18, 16, 16, 0, 0, "PAIR", 300), (18, 16, 16, 0, 0, "INV", 300), (16, 18, 24, 0, 0, "FWD", 1100)])
+def test_two_stream_switch_other_multi_pass_families(case, monkeypatch):
+    """INTFFT_TWO_STREAMS=1 (include/intfft.h): the chunk alternation between the caller's stream and the plan's side stream for the
+    multi-pass families that keep one stream by default (k_big20_* / k_big2p_* / k_bigw_*).  A batch beyond one scratch half (128 MiB),
+    so both streams carry chunks: same bits as the default plan, frames around the chunk border against the oracle."""
+    log2n, dw, tw, fmt, rnd, direction, batch = case
+    if dw != 16:
+        monkeypatch.setenv("INTFFT_NO_WIDE16", "1")
+    n = 1 << log2n
+    x = uniform_frames(batch, n, dw, 5200 + log2n)
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=direction)
+    assert info["n_passes"] >= 2, info
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_TWO_STREAMS", "1")
+        got2, info2 = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=direction)
+    assert info2["kernel_name"] == info["kernel_name"] and info2["scratch_bytes"] >= info["scratch_bytes"], (info, info2)
+    assert np.array_equal(got, got2)
+    half = (128 << 20) // (n * 2 * (2 if dw == 16 else 4))
+    sel = [0, half - 1, half, min(2 * half, batch - 1), batch - 1]
+    assert np.array_equal(got2[sel], run_ref(x[sel], log2n, dw, tw, fmt, rnd, True, direction=direction))
+
+
 @pytest.mark.parametrize("log2n", [17, 18])
 @pytest.mark.parametrize("out_order", ["NATURAL", "BITREV"])
 def test_two_pass_32_register_first_pass(log2n, out_order, monkeypatch):

@@ -3,6 +3,8 @@
 //   diag_copy_wave_ld   a copy with the access pattern of k_fft1024_i16 (one wave per 4 KiB frame, 16 plain dword loads then 16
 //                       non-temporal dword stores per lane): the memory-side ceiling of that kernel's own pattern
 //   diag_copy_wave_nt   the same with non-temporal loads as well (the kernel's pattern in rounds 1-2)
+//   diag_xcc_map        the XCD (HW_REG_XCC_ID) every workgroup of a launch ran on: the half-line tiles of intfft_big2x.hip pair blocks b and
+//                       b + 8 and rely on the dispatcher's round robin putting them on one XCD (tests/test_gpu_xcd.py fails loudly if not)
 //   diag_valu_chain     N dependent-free packed-int16 adds per lane on 8 register sets: the issue rate of the "slow class"
 //                       VALU instructions (v_pk_*, v_dot2, v_perm, v_bfe) the packed butterflies are made of
 #include <hip/hip_runtime.h>
@@ -23,6 +25,21 @@ template <int NTLD> __global__ __launch_bounds__(256) void k_copy_wave_nt(const 
 #pragma unroll
         for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(v[j], d + 64 * j);
     }
+}
+
+// out[b] = XCC id of block b; the shape of k_big2x_a (512 threads, 68 KiB of LDS: two workgroups per CU), a short spin so that the
+// launch outlives its own dispatch (blocks of a trivially short kernel would all fit the first CUs that come free)
+__global__ __launch_bounds__(512) void k_xcc_map(u32 *out, int spin)
+{
+    extern __shared__ u32 lds_dummy[];
+    u32 acc = threadIdx.x;
+    for (int i = 0; i < spin; ++i) {
+        lds_dummy[threadIdx.x] = acc;
+        __syncthreads();
+        acc += lds_dummy[(threadIdx.x + 1) & 511];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u) | (acc == 0xffffffffu ? 16u : 0u);
 }
 
 #define DIAG_UNROLL 8
@@ -82,6 +99,15 @@ int diag_valu_chain(int slow, int iters, void *d_out, unsigned long long *n_wave
     if (slow) hipLaunchKernelGGL(k_valu_chain<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32 *)d_out, 12345u, iters);
     else hipLaunchKernelGGL(k_valu_chain<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (u32 *)d_out, 12345u, iters);
     if (n_wave_insts) *n_wave_insts = (unsigned long long)grid * 4ull * 8ull * DIAG_UNROLL * (unsigned long long)iters;
+    return (int)hipGetLastError();
+}
+
+// d_out: nblocks dwords.  returns a hipError_t
+int diag_xcc_map(void *d_out, unsigned nblocks, int spin, void *stream)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_xcc_map, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_xcc_map, dim3(nblocks), dim3(512), 68 * 1024, (hipStream_t)stream, (u32 *)d_out, spin);
     return (int)hipGetLastError();
 }
 

@@ -55,6 +55,11 @@ for n, c in kern.items():
     if "TCC_EA0_RDREQ_sum" in d:
         d["crosscheck_rdreq_x128B"] = d["TCC_EA0_RDREQ_sum"] * 128
         d["crosscheck_wrreq_x64B"] = d.get("TCC_EA0_WRREQ_sum", 0) * 64
+    if "TCC_EA0_RDREQ_128B_sum" in d:  # round 4: bytes by request size (tools/reqbench.hip: every read miss is a 128-byte request,
+        # also for 64- / 32-byte pieces; writes leave as 64-byte requests, 32-byte ones for 32-byte pieces)
+        d["rdreq_bytes_by_size"] = d["TCC_EA0_RDREQ_128B_sum"] * 128 + d.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + d.get("TCC_EA0_RDREQ_32B_sum", 0) * 32
+        if "TCC_EA0_WRREQ_sum" in d and "TCC_EA0_WRREQ_64B_sum" in d:
+            d["wrreq_bytes_by_size"] = d["TCC_EA0_WRREQ_64B_sum"] * 64 + (d["TCC_EA0_WRREQ_sum"] - d["TCC_EA0_WRREQ_64B_sum"]) * 32
     out["kernels"][n] = d
 # launches per intfft_exec call from the trace run (bench_configs.py prints its number of calls)
 calls = None

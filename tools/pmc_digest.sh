@@ -2,7 +2,8 @@
 # tools/pmc_digest.sh <tag> <bench_configs spec> [more specs]  -- per-kernel PMC digest of one configuration (run on the GPU box via gpurun).
 # One `rocprofv3 --pmc` pass per counter set (never combined with trace domains), plus one --kernel-trace pass for durations;
 # writes gpurun_out/pmc_<tag>/<spec>_pmc_digest.json: per kernel {mean counters per launch, launches, avg ns, HBM bytes derived as in
-# MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950; cross-check TCC_EA0_RDREQ x 128 B / WRREQ x 64 B)} and the config's algorithmic bytes.
+# MI355X_MICROARCH.md (FETCH_SIZE x 2 on gfx950; cross-check TCC_EA0_RDREQ x 128 B / WRREQ x 64 B; round 4: the request-size split
+# TCC_EA0_RDREQ_128B / _64B / _32B and WRREQ_64B, calibrated with tools/reqbench.hip)} and the config's algorithmic bytes.
 set -u
 TAG=$1; shift
 REPO=$(pwd)
@@ -15,6 +16,7 @@ for SPEC in "$@"; do
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- python $REPO/tools/bench_configs.py $SPEC > "$OUT/trace.log" 2>&1
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" \
+             "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum" \
              "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
              "GRBM_GUI_ACTIVE"; do
