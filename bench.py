@@ -536,10 +536,16 @@ def main():
                 r = out["roofline"]
                 r["frac_hbm"] = r["frac"]
                 r["frac_valu"] = here / vb["value"]
-                r["bound"] = "valu" if vb["value"] < hbm_bound else "hbm"
-                r["bounds_Gsample_per_s"] = {"hbm": hbm_bound, "valu": vb["value"]}
+                bounds = {"hbm": hbm_bound, "valu": vb["value"]}
+                if r.get("traffic"):  # multi-pass plans: the bytes their passes really move (PMC digest) against the same 8 TB/s
+                    bounds["hbm_pass_traffic"] = HBM_PEAK_GBS / (r["traffic"] / (float(batch) * n))
+                    r["frac_hbm_pass_traffic"] = here / bounds["hbm_pass_traffic"]
+                r["bound"] = "valu" if vb["value"] < min(v for k, v in bounds.items() if k != "valu") else "hbm"
+                r["bounds_Gsample_per_s"] = bounds
                 r["note"] = ("`frac`, `achieved`, `peak` are the HBM figures (algorithmic bytes / kernel time over 8 TB/s) for every configuration; "
-                             "`bound` names the lower of the two ceilings, `frac_valu` = measured rate over the VALU-issue bound")
+                             "`bound` names the lowest ceiling: `hbm` (algorithmic bytes, or `hbm_pass_traffic` = the measured bytes of all passes, "
+                             "at 8 TB/s) or `valu` (the plan's VALU wave-instructions at the slow-class issue rate measured in this run); "
+                             "`frac_valu` / `frac_hbm_pass_traffic` = measured rate over those bounds")
             out["octave"] = octave_probe()
         if world == 1 and not args.no_cpu_baseline:
             step()

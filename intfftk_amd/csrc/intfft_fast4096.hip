@@ -4,7 +4,7 @@
 //
 // One 256-thread workgroup owns one frame: 16 packed (re | im << 16) samples per thread, persistent loop
 // over frames.  Twelve radix-2 stages = three in-register rounds of four stages, with a block-wide LDS
-// transpose between rounds (two alternating 20 KiB regions -> one barrier per transpose):
+// transpose between rounds (two alternating 20 KiB regions -> one barrier per transpose; rows of 18 dwords):
 //
 //   layout LA  reg = n11..8, thread = n7..0                       DIF 11,10,9,8   / DIT 8,9,10,11
 //   layout LB  reg = n7..4,  thread = (n11..8, n3..0)             DIF 7,6,5,4     / DIT 4,5,6,7
@@ -28,22 +28,55 @@
 
 namespace intfft {
 
-constexpr int ROW4K = 20;             // LDS row stride in dwords (16 data + 4 pad)
-constexpr int REGION4K = 256 * ROW4K; // dwords per transpose region
+// LDS row stride in dwords.  18 (round 4): b64 row reads; every ds_write_b32 (two groups of 32 lanes, bank = dword address mod 32) and every
+// ds_read_b64 (two groups of 32 lanes, 64 banks) of the four transposes is conflict-free -- SQ_LDS_BANK_CONFLICT of the forward kernel 4.2e6 -> 0
+// per 2^26 samples, of the pair 1.57e7 -> 4.2e6 -- which is worth 0-2 % (the kernels are VALU-bound: DESIGN 4.1).  -DINTFFT_4K_ROW=20 restores
+// the b128 form of rounds 1-3 (2-way on every write) for A/B runs.
+#ifndef INTFFT_4K_ROW
+#define INTFFT_4K_ROW 18
+#endif
+constexpr int ROW4K = INTFFT_4K_ROW;
+constexpr int ROW_CB = 20;            // the LC -> LB transpose keeps 16-byte aligned rows inside its blocks (BLK_CB)
+constexpr int REGION4K = 256 * 20;    // dwords per transpose region (16 x BLK_CB = 5056 for LC -> LB)
+
+// Diagnostics only (tools/build_variant_multi.sh <name> "-DINTFFT_4K_ABL=<bits>" intfft_fast4096.hip; never set in the product build; the
+// results of an ablated kernel are WRONG, its time and counters are the measurement -- DESIGN 4.1, "where the pair's time goes"):
+//   1: no block-wide barrier in the transposes    2: every transpose through conflict-free addresses (lane-linear writes, linear b128 reads)
+//   4: no global loads                             8: no global stores
+//   16 << k: the writes of transpose k skipped (0: LA -> LB, 1: LB -> LC, 2: LC -> LB, 3: LB -> LA) -- bank-conflict attribution by counter difference
+#ifndef INTFFT_4K_ABL
+#define INTFFT_4K_ABL 0
+#endif
+#define INTFFT_X_BARRIER() { if (!(INTFFT_4K_ABL & 1)) __syncthreads(); }
+// one transposed write of register j: K = transpose number, off = the kernel's dword offset
+#define INTFFT_X_WRITE(K, region, off, j, val)                                                         \
+    {                                                                                                  \
+        if (!((INTFFT_4K_ABL >> (4 + (K))) & 1)) (region)[(INTFFT_4K_ABL & 2) ? tid + 256 * (j) : (off)] = (val); \
+    }
 
 // ---- block-wide transposes: write 16 scattered dwords, barrier, read one padded row ------------------
 // OFF(j): compile-time row offset (in rows) of register j; wr: this thread's base (dword index)
 #define INTFFT_X_READ(region)                                                                          \
     {                                                                                                  \
-        __syncthreads();                                                                               \
-        const uint4 *rp = reinterpret_cast<const uint4 *>((region) + ROW4K * tid);                     \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
-        {                                                                                              \
-            const uint4 x = rp[q];                                                                     \
-            v[4 * q + 0] = x.x;                                                                        \
-            v[4 * q + 1] = x.y;                                                                        \
-            v[4 * q + 2] = x.z;                                                                        \
-            v[4 * q + 3] = x.w;                                                                        \
+        INTFFT_X_BARRIER()                                                                             \
+        if constexpr (ROW4K % 4 == 0) {                                                                \
+            const uint4 *rp = reinterpret_cast<const uint4 *>((region) + ((INTFFT_4K_ABL & 2) ? 16 * tid : ROW4K * tid)); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+            {                                                                                          \
+                const uint4 x = rp[q];                                                                 \
+                v[4 * q + 0] = x.x;                                                                    \
+                v[4 * q + 1] = x.y;                                                                    \
+                v[4 * q + 2] = x.z;                                                                    \
+                v[4 * q + 3] = x.w;                                                                    \
+            }                                                                                          \
+        } else {                                                                                       \
+            const uint2 *rp = reinterpret_cast<const uint2 *>((region) + ROW4K * tid);                 \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q)                                              \
+            {                                                                                          \
+                const uint2 x = rp[q];                                                                 \
+                v[2 * q + 0] = x.x;                                                                    \
+                v[2 * q + 1] = x.y;                                                                    \
+            }                                                                                          \
         }                                                                                              \
     }
 
@@ -54,18 +87,32 @@ constexpr int REGION4K = 256 * ROW4K; // dwords per transpose region
 // n6 + 2 n7 + 4 n4 + 8 n5: 316 = -4 mod 64, so the wave's 64 writes land on banks (n6 + 2 n7) - 4 (n11..8) + const -- all
 // distinct (N = 2048, where the wave holds n10..8 and n7..5: 2-way).  Rows stay 16-byte aligned for the b128 reads, whose
 // registers come back in the permuted order; 16 * 316 dwords fit the region.
-constexpr int BLK_CB = 316;
+constexpr int BLK_CB = ROW4K % 4 == 0 ? 316 : 318;
+// With b64 row reads (ROW4K = 18) this transpose takes blocks 318 dwords apart and column n7..4 at position n7 + 2 n6 + 4 n5 + 8 n4: a
+// ds_write_b32 is served in two groups of 32 lanes on banks (a / 4) mod 32 -- the group holds n11..8 and n7, and 318 = -2 mod 32 puts its 32
+// writes on 32 banks -- and a ds_read_b64 in two groups of 32 lanes on banks mod 64: rows 20 apart in two blocks 318 apart cover all 64
+// (the 316-dword form was laid out for 64 banks per write: it is 2-way on every write, measured 32 conflict cycles per wave and transpose).
 #define INTFFT_X_READ_CB(region)                                                                       \
     {                                                                                                  \
-        __syncthreads();                                                                               \
-        const uint4 *rp = reinterpret_cast<const uint4 *>((region) + BLK_CB * (tid >> 4) + ROW4K * (tid & 15)); \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
-        {                                                                                              \
-            const uint4 x = rp[q];                                                                     \
-            v[q] = x.x;                                                                                \
-            v[q + 4] = x.y;                                                                            \
-            v[q + 8] = x.z;                                                                            \
-            v[q + 12] = x.w;                                                                           \
+        INTFFT_X_BARRIER()                                                                             \
+        if constexpr (ROW4K % 4 == 0) {                                                                \
+            const uint4 *rp = reinterpret_cast<const uint4 *>((region) + ((INTFFT_4K_ABL & 2) ? 16 * tid : BLK_CB * (tid >> 4) + ROW_CB * (tid & 15))); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+            {                                                                                          \
+                const uint4 x = rp[q];                                                                 \
+                v[q] = x.x;                                                                            \
+                v[q + 4] = x.y;                                                                        \
+                v[q + 8] = x.z;                                                                        \
+                v[q + 12] = x.w;                                                                       \
+            }                                                                                          \
+        } else {                                                                                       \
+            const uint2 *rp = reinterpret_cast<const uint2 *>((region) + BLK_CB * (tid >> 4) + ROW_CB * (tid & 15)); \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q)                                              \
+            {                                                                                          \
+                const uint2 x = rp[q];                                                                 \
+                v[rev4c(2 * q)] = x.x;                                                                 \
+                v[rev4c(2 * q + 1)] = x.y;                                                             \
+            }                                                                                          \
         }                                                                                              \
     }
 
@@ -103,6 +150,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     constexpr int FP = 1 << (12 - L), NS = L - 8;        // frames per 4096-sample chunk; executed stages of round A
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds[2 * REGION4K];
+    static_assert((ROW4K == 20 || 256 * ROW4K <= REGION4K - 4) && 16 * BLK_CB <= REGION4K - 4, "vote cells: pad columns of the last row / behind the layouts of region 0");
     u32 *const reg0 = lds, *const reg1 = lds + REGION4K;
     u32 *const vote_flags = lds + (REGION4K - 4); // three pad cells of region 0's last row (columns 16..19 are never transposed; beyond the 16 x 316 dwords of the LC -> LB transpose too)
     unsigned vote_phase = 0;
@@ -154,7 +202,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
     // LC -> LB: thread t'' , reg r = n3..0 -> row = LB thread 16 * (n11..8) + r, column = LB register n7..4
     auto nb = [&](int k) { return (tid >> lc_bit<L, OB>(k)) & 1; };
     const int lb_hi = nb(8) | (nb(9) << 1) | (nb(10) << 2) | (nb(11) << 3), lb_reg = nb(4) | (nb(5) << 1) | (nb(6) << 2) | (nb(7) << 3);
-    const int w_cb = BLK_CB * lb_hi + (lb_reg >> 2) + 4 * (lb_reg & 3); // see INTFFT_X_READ_CB
+    const int w_cb = BLK_CB * lb_hi + (ROW4K % 4 == 0 ? (lb_reg >> 2) + 4 * (lb_reg & 3) : rev4c(lb_reg)); // see INTFFT_X_READ_CB
     // per-thread shift amounts where the value kind depends on a thread bit after a transpose
     const short shb = (short)(1 - (hi4 & 1)); // LB: kind = n8 = t'4
     const short shc = (short)(1 - nb(4));     // LC: kind = n4
@@ -207,7 +255,7 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             }
         } else if (!partial) { // LA: v[j] = x[256 j + tid]
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = INTFFT_LD(src + 256 * j + tid);
+            for (int j = 0; j < 16; ++j) v[j] = (INTFFT_4K_ABL & 4) ? (u32)(tid * 0x00030005u + j * 0x00110007u + (u32)f) & 0x1fff1fffu : INTFFT_LD(src + 256 * j + tid);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -263,10 +311,10 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
         if (MODE != MODE_INV) {                                                                         \
             if (MODE == MODE_MID) dif_round<FX, true, NS, RD, DP>(v, ta, sl, sh_m); /* round mode: plain inputs */ \
             else dif_round<FX, false, NS, RD, DP>(v, ta, sl, sh_b);                                      \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg0[w_ab + ROW4K * 16 * j] = v[j];          \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) INTFFT_X_WRITE(0, reg0, w_ab + ROW4K * 16 * j, j, v[j]) \
             INTFFT_X_READ(reg0)                                                                         \
             dif_round<FX, true, 4, RD, DP>(v, tb, sl, sh_b);                                             \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_bc + ROW4K * lc_row_of_reg<L, OB>(j)] = v[j]; \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) INTFFT_X_WRITE(1, reg1, (w_bc + ROW4K * lc_row_of_reg<L, OB>(j)), j, v[j]) \
             INTFFT_X_READ(reg1)                                                                         \
             dif_round_c<FX, RD, DP>(v, c, sl, sh_c);                                                     \
         }                                                                                               \
@@ -290,10 +338,10 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             }                                                                                           \
         } else {                                                                                        \
             dit_round_c<FX, RD, DP>(v, c, sl);                                                       \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) reg0[w_cb + ROW4K * r] = v[r];               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) INTFFT_X_WRITE(2, reg0, w_cb + ROW_CB * r, r, v[r]) \
             INTFFT_X_READ_CB(reg0)                                                                      \
             dit_round<FX, 4, RD, DP>(v, tb, sl);                                                     \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) reg1[w_ab + ROW4K * 16 * j] = v[j];          \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) INTFFT_X_WRITE(3, reg1, w_ab + ROW4K * 16 * j, j, v[j]) \
             INTFFT_X_READ(reg1)                                                                         \
             dit_round<FX, NS, RD, DP>(v, ta, sl);                                                    \
             if (MODE == MODE_INV && halves) { /* HALVES beats, mirror of the forward load */            \
@@ -308,6 +356,11 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
                         __builtin_nontemporal_store(w, d2 + 256 * jj);                                  \
                 }                                                                                       \
             } else {                                                                                    \
+            if (INTFFT_4K_ABL & 8) {                                                                    \
+                u32 acc = 0;                                                                            \
+                _Pragma("unroll") for (int j = 0; j < 16; ++j) acc ^= v[j];                             \
+                if (acc == 0x12345u) dst[tid] = acc;                                                    \
+            } else                                                                                      \
             _Pragma("unroll") for (int j = 0; j < 16; ++j)                                              \
                 if (!partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user)                 \
                     __builtin_nontemporal_store(v[j], dst + 256 * j + tid);                             \
