@@ -124,7 +124,9 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
  * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
  * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
  * (kernel, device) on first use, under a mutex);
- * one plan must not be executed concurrently on two streams (plan-owned scratch).  Some multi-pass plans (N = 2^19 / 2^20 forward and inverse, the
+ * a plan WITHOUT plan-owned scratch (intfft_plan_info.scratch_bytes == 0: every single-launch plan) holds no mutable state and may be executed on any
+ * number of streams at once; a plan that owns scratch (the multi-pass plans) must not be executed concurrently on two streams -- create one plan per
+ * stream for those.  Some multi-pass plans (N = 2^19 / 2^20 forward and inverse, the
  * 24-bit unscaled class, the tiled 2-D plans) run the scratch-sized chunks of a large batch alternately on `hip_stream` and on a plan-owned side stream
  * (event fork at entry, event join before returning): towards the caller the call is still ordered on `hip_stream` only. */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);

@@ -404,6 +404,36 @@ def test_chunked_plans_on_two_streams_equal_one_stream(monkeypatch):
         assert torch.equal(y, w) and torch.equal(z, w) and int(total) == int(w.to(torch.int64).sum())
 
 
+@pytest.mark.parametrize("cfg", [(10, 16, 16, 0, "FWD", 20000), (12, 16, 16, 0, "PAIR", 6000), (14, 16, 16, 0, "INV", 1500), (10, 24, 24, 1, "FWD", 8000)])
+def test_single_launch_plans_are_reentrant_across_streams(cfg):
+    """"exec is re-entrant across streams".  A plan without plan-owned scratch (info.scratch_bytes == 0: every single-launch plan,
+    N <= 16384 on the packed kernels and N <= 4096 elsewhere) holds no mutable state, so ONE plan may be executed on several streams at once
+    (include/intfft.h); multi-pass plans own their scratch and must not.  Four streams, interleaved calls on different batches, no host sync in between."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    log2n, dw, tw, fmt, direction, batch = cfg
+    core = IntFFTCore(log2n, dw, tw, fmt, 0, "NEW", direction, "NATURAL", "NATURAL")
+    assert core.info["scratch_bytes"] == 0 and core.info["n_passes"] == 1, core.info
+    n = 1 << log2n
+    dt = torch.int16 if dw <= 16 else torch.int32
+    g = torch.Generator(device="cuda")
+    g.manual_seed(500 + log2n)
+    xs = [torch.randint(-(1 << (dw - 2)), 1 << (dw - 2), (batch, n, 2), device="cuda", dtype=dt, generator=g) for _ in range(4)]
+    want = [core(x) for x in xs]
+    ys = [torch.zeros_like(w) for w in want]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            core.exec_raw(xs[i].data_ptr(), ys[i].data_ptr(), batch, st.cuda_stream)  # raises on a non-zero status
+    torch.cuda.synchronize()
+    for y, w in zip(ys, want):
+        assert torch.equal(y, w)
+    core.close()
+
+
 def test_exec_under_stream_capture():
     """intfft_exec inside a hipGraph capture: every launch stays on the capturing stream (the chunked plans do not fork onto their side
     stream there), and the replayed graph reproduces the eager result -- a multi-chunk two-pass plan and the headline kernel."""
