@@ -935,7 +935,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->big20 = !generic_only && big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction,
                                     p->use_fly, p->in_order, p->out_order) &&
                     !diag_env("INTFFT_NO_BIG20");
-        if (!generic_only && !l1 && p->direction == INTFFT_PAIR && pl->word == 8 && !pl->big20 && !pl->bigw && p->use_fly == 1 &&
+        // pairs without a pair kernel of their own whose two halves both have dedicated kernels: forward sub-plan, middle buffer in natural order,
+        // inverse sub-plan (64-bit words since round 3; 32-bit words -- general widths within 32 bits -- since round 4)
+        if (!generic_only && !l1 && p->direction == INTFFT_PAIR && (pl->word == 8 || pl->word == 4) && !pl->big20 && !pl->bigw && p->use_fly == 1 &&
             !diag_env("INTFFT_NO_PAIR_COMPOSITE")) {
             intfft_params qf = *p, qi = *p;
             qf.direction = INTFFT_FWD, qf.out_order = INTFFT_ORDER_NATURAL;

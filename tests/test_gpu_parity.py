@@ -626,6 +626,34 @@ def test_pair_of_dedicated_kernels_on_64_bit_words(case, monkeypatch):
     assert np.array_equal(got_c, np.concatenate([got] * 4))
 
 
+@pytest.mark.parametrize("case", [(10, 18, 16, 0, 0, True), (10, 24, 24, 0, 1, True), (12, 24, 18, 0, 0, False), (11, 20, 24, 0, 1, True), (8, 12, 18, 1, 0, True),
+                                  (7, 9, 12, 1, 0, False), (14, 18, 16, 0, 0, True), (13, 24, 24, 0, 1, True), (16, 32, 16, 0, 0, True), (9, 32, 26, 0, 0, True)])
+def test_pair_of_dedicated_kernels_on_32_bit_words(case, monkeypatch):
+    """FFT -> IFFT pairs of general widths within 32 bits (18 / 24 / 32-bit scaled data in both rounding modes, small unscaled pairs): since
+    round 4 a forward sub-plan (k_fft1024_w32 / k_fft4096_w32 / k_bigw_a/b), a middle buffer and an inverse sub-plan (k_ifft*_w32 / k_bigw_qb/qa)
+    instead of the generic pair kernel -- against the oracle's pair, the generic kernel, and through the chunk loop of the middle buffer."""
+    log2n, dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.PAIR) != 0:
+        pytest.skip("not elaboratable")
+    monkeypatch.setenv("INTFFT_NO_NARROW16", "1")
+    n = 1 << log2n
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(max(3, (1 << 16) // n), n, dw, 860 + dw + log2n)])
+    got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+    assert info["kernel_name"].startswith("pair[") and "k_pass" not in info["kernel_name"], info
+    assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, new, direction="PAIR"))
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_PAIR_COMPOSITE", "1")
+        got_g, info_g = run_gpu(x[:9], log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    assert np.array_equal(got[:9], got_g)
+    if log2n <= 12:
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_SCRATCH_MB", "1")  # 1 MiB middle buffer: the chunk loop
+            got_c, info_c = run_gpu(np.concatenate([x] * 3), log2n, dw, tw, fmt, rnd, new, direction="PAIR")
+            assert info_c["kernel_name"].startswith("pair["), info_c
+        assert np.array_equal(got_c, np.concatenate([got] * 3))
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)

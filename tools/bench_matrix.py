@@ -85,6 +85,9 @@ ROWS.append(("11:32:16:1", "32-bit unscaled FWD (43-bit results)"))
 ROWS.append(("12:28:16:1:0:INV", "28-bit unscaled INV (the second half of a 16-bit unscaled pair)"))
 ROWS.append(("12:16:16:1:0:PAIR", "16-bit unscaled PAIR (40-bit results)"))
 ROWS.append(("16:24:24:1:0:INV", "24-bit unscaled INV (40-bit results)"))
+ROWS.append(("10:18:16:0:0:PAIR", "18-bit scaled PAIR (32-bit words: forward + inverse sub-plans, round 4)"))
+ROWS.append(("12:24:24:0:1:PAIR", "24-bit scaled-round PAIR (32-bit words)"))
+ROWS.append(("14:18:16:0:0:PAIR", "18-bit scaled PAIR (32-bit words, two passes each way)"))
 ROWS.append(("10:56:16:1", "56-bit unscaled FWD (66-bit results, 16-byte containers)"))
 ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit results)"))
 
