@@ -120,7 +120,9 @@ int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 
 /* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
- * (see intfft_io_widths).  Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
+ * (see intfft_io_widths), aligned to one complex sample (2 containers); nothing beyond the two arrays is read or written
+ * (tests/test_gpu_cabi.py::test_no_writes_outside_the_output_buffer: guard bands, ragged batches, buffers one sample off a 64 KiB boundary).
+ * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
  * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
  * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
  * (kernel, device) on first use, under a mutex);

@@ -434,6 +434,62 @@ def test_single_launch_plans_are_reentrant_across_streams(cfg):
     core.close()
 
 
+GUARD_CASES = [
+    # (log2n, dw, tw, fmt, rnd, direction, in_order, out_order, batch): every dedicated kernel family at a batch that does not fill its
+    # last chunk / group / tile, so the predicated stores of the partial paths are what runs
+    (3, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 67), (5, 16, 16, 0, 1, "PAIR", "NATURAL", "NATURAL", 131),
+    (6, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 17), (7, 16, 16, 0, 0, "INV", "BITREV", "HALVES", 9), (9, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 5),
+    (10, 16, 16, 0, 0, "FWD", "HALVES", "BITREV", 7), (10, 12, 16, 0, 1, "FWD", "NATURAL", "NATURAL", 3), (7, 16, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 11),
+    (8, 16, 16, 1, 0, "PAIR", "NATURAL", "NATURAL", 7), (9, 24, 18, 1, 0, "FWD", "NATURAL", "NATURAL", 3), (10, 18, 16, 0, 0, "INV", "NATURAL", "NATURAL", 5),
+    (11, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3), (11, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 5), (12, 16, 16, 0, 1, "INV", "NATURAL", "NATURAL", 3),
+    (11, 24, 24, 1, 0, "FWD", "NATURAL", "NATURAL", 3), (12, 16, 16, 1, 0, "INV", "NATURAL", "NATURAL", 3), (7, 32, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 13),
+    (11, 32, 16, 1, 0, "INV", "NATURAL", "NATURAL", 3), (13, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 5), (14, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 3),
+    (13, 16, 16, 0, 1, "FWD", "HALVES", "BITREV", 5), (15, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 3), (16, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 3),
+    (13, 24, 24, 1, 0, "FWD", "NATURAL", "NATURAL", 3), (14, 24, 24, 1, 0, "INV", "NATURAL", "NATURAL", 5), (13, 16, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 3),
+    (17, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3), (18, 16, 16, 0, 1, "INV", "NATURAL", "NATURAL", 1), (19, 16, 16, 0, 0, "FWD", "NATURAL", "BITREV", 3),
+    (20, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1), (10, 18, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 3), (10, 40, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3),
+    (9, 16, 16, 0, 0, "FWD", "NATURAL", "BITREV_LANES", 3),
+]
+
+
+@pytest.mark.parametrize("shift_samples", [0, 1])
+@pytest.mark.parametrize("case", GUARD_CASES)
+def test_no_writes_outside_the_output_buffer(case, shift_samples):
+    """Buffer-overrun check of every kernel family on ragged batches: the output lives between two poisoned guard bands of one allocation (and
+    the input between two others, so a read beyond it would at least read poison, not a neighbour's data); after intfft_exec the bands still
+    hold the poison and the result equals the oracle's.  shift_samples = 1: both buffers start ONE complex sample behind a 64 KiB boundary (the ABI asks
+    for container alignment only: the 16-byte vector accesses of the kernels must not assume more)."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    log2n, dw, tw, fmt, rnd, direction, in_o, out_o, batch = case
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, True), {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]) != 0:
+        pytest.skip("not elaboratable")
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o)
+    n = 1 << log2n
+    x = uniform_frames(batch, n, dw, 7700 + log2n + dw)
+    xin = torch.from_numpy(np.ascontiguousarray(x.astype({2: np.int16, 4: np.int32, 8: np.int64}[core.in_container])))
+    guard = 1 << 16  # bytes on each side
+    gi, go = guard + shift_samples * 2 * core.in_container, guard + shift_samples * 2 * core.out_container
+    in_bytes, out_bytes = batch * n * 2 * core.in_container, batch * n * 2 * core.out_container
+    ibuf = torch.full((gi + in_bytes + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    obuf = torch.full((go + out_bytes + guard,), 0xA5, dtype=torch.uint8, device="cuda")
+    ibuf[gi:gi + in_bytes] = xin.cuda().view(torch.uint8).reshape(-1)
+    torch.cuda.synchronize()
+    core.exec_raw(ibuf.data_ptr() + gi, obuf.data_ptr() + go, batch, 0)
+    torch.cuda.synchronize()
+    info = core.info
+    assert bool((obuf[:go] == 0xA5).all()) and bool((obuf[go + out_bytes:] == 0xA5).all()), ("write outside the output buffer", info)
+    assert bool((ibuf[:gi] == 0x5A).all()) and bool((ibuf[gi + in_bytes:] == 0x5A).all()), ("write into the input's guard bands", info)
+    got = obuf[go:go + out_bytes].clone().view(core.out_dtype).reshape(core.out_shape(batch)).cpu().numpy().astype(np.int64)
+    p = C.make_params(log2n, dw, tw, fmt, rnd, True)
+    om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
+    want = C.execute(x, p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction], om[in_o], om[out_o], form=1)
+    assert np.array_equal(got, want), info
+    core.close()
+
+
 def test_exec_under_stream_capture():
     """intfft_exec inside a hipGraph capture: every launch stays on the capturing stream (the chunked plans do not fork onto their side
     stream there), and the replayed graph reproduces the eager result -- a multi-chunk two-pass plan and the headline kernel."""
