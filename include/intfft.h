@@ -120,7 +120,7 @@ int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 
 /* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
- * (see intfft_io_widths), aligned to one complex sample (2 containers); nothing beyond the two arrays is read or written
+ * (see intfft_io_widths), aligned to one complex sample (2 containers); nothing outside the output array is written and the loads of absent frames of a partial last group are predicated
  * (tests/test_gpu_cabi.py::test_no_writes_outside_the_output_buffer: guard bands, ragged batches, buffers one sample off a 64 KiB boundary).
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
  * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
