@@ -27,10 +27,18 @@ constexpr int ROWP = 17; // transpose A <-> B: LDS row stride in dwords (16 colu
 constexpr int ROWQ = 33; // transpose B <-> C: 32 columns + 1
 
 // DIF stages 3, 2, 1, 0 on v[B .. B+15] (reg = n3..n0), wave-uniform twiddles; P0: PREMASK of the inputs (0xF: they hold X >> 1)
-template <bool FASTX, int B, int P0> __device__ __forceinline__ void dif_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
+template <bool FASTX, int B, int P0, int ROUND = 0> __device__ __forceinline__ void dif_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
 {
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
+    if constexpr (ROUND != 0) { // RNDMODE = 1 (int_dif2_fly.vhd:167-219): plain values, rhu2 sums, exact extraction; STAGE 1 / 0 of all 32 registers follow in the caller
+        static_assert(!FASTX, "round mode uses the exact extraction");
+        group4<ROUND, 0, false, false, true, 0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
+        group4<ROUND, 0, false, false, true, 0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
+        group4<ROUND, 0, false, false, true, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+        group4<ROUND, 0, false, false, true, 0>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+        return;
+    }
     group4<false, FASTX, false, true, true, P0>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
     group4<false, FASTX, false, true, true, P0>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
     group4<false, FASTX, false, true, true, 0>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
@@ -48,32 +56,44 @@ template <bool FASTX, int B, int P0> __device__ __forceinline__ void dif_round4_
 
 // DIT stages 0, 1, 2, 3 on v[B .. B+15], wave-uniform twiddles in the DIT packing (DITPACK) or -- the pair, which shares one set of
 // constants between its cores -- in the DIF packing through the re/im-swapped multiplier feed of int_dit2_fly.vhd:304-322
-template <bool FASTX, int B, bool DITPACK = true> __device__ __forceinline__ void dit_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
+template <bool FASTX, int B, bool DITPACK = true, int ROUND = 0> __device__ __forceinline__ void dit_round4_c(u32 (&v)[32], const RoundCConsts &c, const Slice &sl)
 {
+    constexpr bool RD = ROUND != 0; // RNDMODE = 1 (int_dit2_fly.vhd:164-217): rhu2 sums on full-width values; ROUND == 2: + the w-bit wrap of narrow data
 #pragma unroll
-    for (int g = B; g < B + 16; g += 2) bfly_triv<false, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    for (int g = B; g < B + 16; g += 2) bfly_triv<RD, false>(v[g], v[g + 1]); // STAGE 0: T = B
+    if constexpr (ROUND == 2) {
+#pragma unroll
+        for (int g = B + 1; g < B + 16; g += 2) v[g] = wrap_w(v[g], sl.wd);
+    }
 #pragma unroll
     for (int g = B; g < B + 16; g += 4) { // STAGE 1: even positions T = B, odd positions T = +j B (quirk)
-        bfly_triv<false, false>(v[g], v[g + 2]);
-        bfly_pj_dit<false>(v[g + 1], v[g + 3]);
+        bfly_triv<RD, false>(v[g], v[g + 2]);
+        bfly_pj_dit<RD>(v[g + 1], v[g + 3]);
     }
-    group4_dit<FASTX, true, 0, DITPACK>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
-    group4_dit<FASTX, true, 0, DITPACK>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
+    if constexpr (ROUND == 2) {
+#pragma unroll
+        for (int g = B; g < B + 16; g += 4) v[g + 2] = wrap_w(v[g + 2], sl.wd), v[g + 3] = wrap_w(v[g + 3], sl.wd);
+    }
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[B + 0], v[B + 4], v[B + 1], v[B + 5], v[B + 2], v[B + 6], v[B + 3], v[B + 7], c.wa2, c.wb2, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[B + 8], v[B + 12], v[B + 9], v[B + 13], v[B + 10], v[B + 14], v[B + 11], v[B + 15], c.wa2, c.wb2, sl);
     const u32 wa0[4] = {c.wa3[0], c.wa3[1], c.wa3[2], c.wa3[3]}, wb0[4] = {c.wb3[0], c.wb3[1], c.wb3[2], c.wb3[3]};
     const u32 wa1[4] = {c.wa3[4], c.wa3[5], c.wa3[6], c.wa3[7]}, wb1[4] = {c.wb3[4], c.wb3[5], c.wb3[6], c.wb3[7]};
-    group4_dit<FASTX, true, 0, DITPACK>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
-    group4_dit<FASTX, true, 0, DITPACK>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[B + 0], v[B + 8], v[B + 1], v[B + 9], v[B + 2], v[B + 10], v[B + 3], v[B + 11], wa0, wb0, sl);
+    group4_dit<FASTX, true, ROUND, DITPACK>(v[B + 4], v[B + 12], v[B + 5], v[B + 13], v[B + 6], v[B + 14], v[B + 7], v[B + 15], wa1, wb1, sl);
 }
 
 __device__ __forceinline__ constexpr int rev5k(int r) { return ((r & 1) << 4) | ((r & 2) << 2) | (r & 4) | ((r & 8) >> 2) | ((r & 16) >> 4); }
 
 enum { M16_FWD = 0, M16_INV = 1, M16_PAIR = 2 }; // PAIR: int_fft_ifft_pair (int_fft_ifft_pair.vhd:209-280): the forward core into the inverse core without leaving layout C
 
-template <int L, int MODE, bool FAST_OK>
+// ROUND: RNDMODE = 1 (the testbench's "ROUNDING" UUT) on its own instantiations (round 4): the ROUND forms of every register round -- rhu2 sums on
+// full-width values, exact extraction, no pre-shifted kinds, quarter turns through the negated twiddle -- 1: 16-bit data, 2: DATA_WIDTH 9 .. 15
+template <int L, int MODE, bool FAST_OK, int ROUND = 0>
 __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft16k_i16(const u32 *in, u32 *out, const uint2 *__restrict__ twf,
                                                                                                           const RoundCConsts c, size_t nframes, const Slice sl)
 {
     static_assert(L == 13 || L == 14, "one workgroup per frame of 8192 / 16384 points");
+    static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int RB = L - 9; // thread bits above l in layouts A and B
     constexpr bool FWD_PART = MODE != M16_INV, INV_PART = MODE != M16_FWD;
     constexpr int NSLOT = RB == 5 ? 16 : 8; // layout B's twiddle slots per packing
@@ -186,9 +206,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dif_round_q<FAST_OK, 0, 0, false>(v, ta, sl, none);
                 dif_round_q<FAST_OK, 16, 0xF, false>(v, ta, sl, none);
             } else {
-                dif_top16<false, 0, false>(v, wat, wbt, sl, none);
-                dif_round_q<false, 0, 0, false>(v, ta, sl, none);
-                dif_round_q<false, 16, 0xF, false>(v, ta, sl, none);
+                dif_top16<false, 0, false, ROUND>(v, wat, wbt, sl, none);
+                dif_round_q<false, 0, 0, false, 4, ROUND>(v, ta, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, ta, sl, none);
             }
 #pragma unroll
             for (int j = 0; j < 32; ++j) a_base[ROWP * (j << RB)] = v[j];
@@ -204,8 +224,8 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                     dif_round_q<FAST_OK, 0, 0, false>(v, tb, sl, none);
                     dif_round_q<FAST_OK, 16, 0xF, false>(v, tb, sl, none);
                 } else {
-                    dif_round_q<false, 0, 0, false>(v, tb, sl, none);
-                    dif_round_q<false, 16, 0xF, false>(v, tb, sl, none);
+                    dif_round_q<false, 0, 0, false, 4, ROUND>(v, tb, sl, none);
+                    dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, tb, sl, none);
                 }
             } else {
                 if (fast) {
@@ -213,9 +233,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                     dif_round_q<FAST_OK, 0, 0, false>(v, tb, sl, none);
                     dif_round_q<FAST_OK, 16, 0xF, false>(v, tb, sl, none);
                 } else {
-                    dif_top16<false, 0, true>(v, wa2t, wb2t, sl, sh2);
-                    dif_round_q<false, 0, 0, false>(v, tb, sl, none);
-                    dif_round_q<false, 16, 0xF, false>(v, tb, sl, none);
+                    dif_top16<false, 0, true, ROUND>(v, wa2t, wb2t, sl, sh2);
+                    dif_round_q<false, 0, 0, false, 4, ROUND>(v, tb, sl, none);
+                    dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, tb, sl, none);
                 }
             }
             __syncthreads(); // every thread has read its A -> B rows: the region may take the B -> C rows
@@ -232,8 +252,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dif_round4_c<FAST_OK, 0, 0>(v, c, sl);
                 dif_round4_c<FAST_OK, 16, 0xF>(v, c, sl);
             } else {
-                dif_round4_c<false, 0, 0>(v, c, sl);
-                dif_round4_c<false, 16, 0xF>(v, c, sl);
+                dif_round4_c<false, 0, 0, ROUND>(v, c, sl);
+                dif_round4_c<false, 16, 0xF, ROUND>(v, c, sl);
+                if constexpr (ROUND != 0) round_stages10<32, ROUND == 2>(v, sl); // STAGE 1, 0 in their round forms on both halves
             }
             if constexpr (MODE == M16_FWD) {
 #pragma unroll
@@ -247,8 +268,8 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dit_round4_c<FAST_OK, 0, CP>(v, c, sl);
                 dit_round4_c<FAST_OK, 16, CP>(v, c, sl);
             } else {
-                dit_round4_c<false, 0, CP>(v, c, sl);
-                dit_round4_c<false, 16, CP>(v, c, sl);
+                dit_round4_c<false, 0, CP, ROUND>(v, c, sl);
+                dit_round4_c<false, 16, CP, ROUND>(v, c, sl);
             }
 #pragma unroll
             for (int r = 0; r < 32; ++r) c_base[r] = v[r];
@@ -267,9 +288,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dit_round_q<FAST_OK, 16>(v, tb, sl);
                 if constexpr (RB == 5) dit_top16<FAST_OK>(v, wa2t, wb2t, sl);
             } else {
-                dit_round_q<false, 0>(v, tb, sl);
-                dit_round_q<false, 16>(v, tb, sl);
-                if constexpr (RB == 5) dit_top16<false>(v, wa2t, wb2t, sl);
+                dit_round_q<false, 0, ROUND>(v, tb, sl);
+                dit_round_q<false, 16, ROUND>(v, tb, sl);
+                if constexpr (RB == 5) dit_top16<false, ROUND>(v, wa2t, wb2t, sl);
             }
             __syncthreads();
 #pragma unroll
@@ -292,9 +313,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dit_round_q<FAST_OK, 16>(v, ta, sl);
                 dit_top16<FAST_OK>(v, wat, wbt, sl);
             } else {
-                dit_round_q<false, 0>(v, ta, sl);
-                dit_round_q<false, 16>(v, ta, sl);
-                dit_top16<false>(v, wat, wbt, sl);
+                dit_round_q<false, 0, ROUND>(v, ta, sl);
+                dit_round_q<false, 16, ROUND>(v, ta, sl);
+                dit_top16<false, ROUND>(v, wat, wbt, sl);
             }
 #pragma unroll
             for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (L - 5)), tid_l));
@@ -304,8 +325,8 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
 
 bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order)
 {
-    return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 &&
-           use_fly == 1 && direction >= 0 && direction <= 2 && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
+    return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
+           (!rndmode || !diag_env("INTFFT_NO_PACKED_ROUND")) && use_fly == 1 && direction >= 0 && direction <= 2 && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
 }
 
 // the quarter-turn relation of the shared-twiddle rounds (stages 5 .. L-1), checked on the plan's generated tables (host copy); the inverse
@@ -326,20 +347,20 @@ bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd)
 
 const char *fast16k_kernel_name() { return "k_fft16k_i16"; }
 
-template <int L, int MODE, bool FX>
+template <int L, int MODE, bool FX, int RD = 0>
 static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream)
 {
     constexpr int RB = L - 9, T = 16 << RB;
     const size_t ldsb = (size_t)(32 << RB) * ROWP * sizeof(u32) + (size_t)(RB == 5 ? 16 : 8) * (MODE == M16_PAIR ? 2 : 1) * 16 * sizeof(uint2);
-    allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX>));
-    const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
+    allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX, RD>));
+    const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX, RD>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
     const unsigned blocks = (unsigned)(nframes < cap ? nframes : cap);
-    hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl);
+    hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX, RD>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl);
     return hipGetLastError();
 }
 
 hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,
-                          int data_width)
+                          int data_width, int rndmode)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -360,6 +381,22 @@ hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, voi
     const bool fx = twd == 16 && allow_fast;
     const u32 *pin = static_cast<const u32 *>(in);
     u32 *pout = static_cast<u32 *>(out);
+    sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
+#define INTFFT_16K_RD(LL, RD)                                                                                                       \
+    {                                                                                                                              \
+        if (direction == 0) return launch16k<LL, M16_FWD, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                    \
+        if (direction == 2) return launch16k<LL, M16_PAIR, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                   \
+        return launch16k<LL, M16_INV, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                                        \
+    }
+    if (sl.round == 1) {
+        if (log2n == 13) INTFFT_16K_RD(13, 1)
+        INTFFT_16K_RD(14, 1)
+    }
+    if (sl.round == 2) {
+        if (log2n == 13) INTFFT_16K_RD(13, 2)
+        INTFFT_16K_RD(14, 2)
+    }
+#undef INTFFT_16K_RD
 #define INTFFT_16K(LL)                                                                                                              \
     if (direction == 0) return fx ? launch16k<LL, M16_FWD, true>(pin, pout, tw16f, c, nframes, sl, stream)                        \
                                   : launch16k<LL, M16_FWD, false>(pin, pout, tw16f, c, nframes, sl, stream);                       \

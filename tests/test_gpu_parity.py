@@ -275,6 +275,42 @@ def test_single_pass_n8192_n16384(log2n, direction, monkeypatch):
         assert info["kernel_name"] == "k_fft16k_i16", info
 
 
+@pytest.mark.parametrize("log2n", [13, 14])
+@pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
+def test_single_pass_n8192_n16384_round_mode(log2n, direction, monkeypatch):
+    """RNDMODE = 1 (the testbench's "ROUNDING" UUT, int_dif2_fly.vhd:167-219 / int_dit2_fly.vhd:164-217) on the one-pass kernel's ROUND instantiations
+    (round 4): full-scale frames (the rhu2 wrap at the maximum), edge frames, ragged batches, both XSER / a narrower twiddle width, narrow data (the
+    w-bit wraps), against the oracle and against the two-pass round-mode plan (INTFFT_NO_FAST16K)."""
+    n = 1 << log2n
+    for batch in (1, 3, 700 if log2n == 13 else 330):
+        x = uniform_frames(batch, n, 16, 4400 + log2n + batch)
+        if batch > 2:
+            x[1] = -(1 << 15)
+            x[2] = (1 << 15) - 1
+            x[2, ::2] = -(1 << 15)
+        a, ia = run_gpu(x, log2n, 16, 16, 0, 1, True, direction=direction)
+        assert ia["kernel_name"] == "k_fft16k_i16" and ia["n_passes"] == 1, ia
+        sel = [0, 1, 2, batch - 1] if batch > 2 else list(range(batch))
+        assert np.array_equal(a[sel], run_ref(x[sel], log2n, 16, 16, 0, 1, True, direction=direction))
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_FAST16K", "1")
+            b, ib = run_gpu(x, log2n, 16, 16, 0, 1, True, direction=direction)
+            assert ib["n_passes"] == (3 if direction == "PAIR" else 2), ib
+        assert np.array_equal(a, b)
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(3, n, 16, 4500 + log2n)])
+    check(x, log2n, 16, 13, 0, 1, False, direction=direction)
+    check(x, log2n, 16, 10, 0, 1, True, direction=direction)
+    for dw in (14, 9):
+        xs = np.concatenate([edge_frames(n, dw), uniform_frames(3, n, dw, 4600 + dw)])
+        xs[-1] = uniform_frames(1, n, 16, 7)[0]  # containers beyond DATA_WIDTH
+        info = check(xs, log2n, dw, 16, 0, 1, True, direction=direction)
+        assert info["kernel_name"] == "k_fft16k_i16", info
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_PACKED_ROUND", "1")
+        _, ig = run_gpu(x[:2], log2n, 16, 16, 0, 1, True, direction=direction)
+        assert ig["kernel_name"] != "k_fft16k_i16", ig
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (13, 1027), (14, 259), (15, 130), (16, 5), (16, 64)])
 @pytest.mark.parametrize("direction,time_order,freq_order", [("FWD", "NATURAL", "NATURAL"), ("FWD", "HALVES", "NATURAL"),
                                                              ("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
@@ -961,6 +997,8 @@ def test_round_mode_multi_pass(log2n, batch, direction, tw, monkeypatch):
         pytest.skip("long frames: one twiddle width is enough")
     n = 1 << log2n
     x = np.concatenate([uniform_frames(batch, n, 16, 500 + log2n), edge_frames(n, 16)[3:6], uniform_frames(2, n, 15, 501 + log2n)])
+    if log2n <= 14:  # N = 8192 / 16384 run ONE pass since round 4 (test_single_pass_n8192_n16384_round_mode): this test keeps the multi-pass plans covered
+        monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     info = check(x, log2n, 16, tw, 0, 1, True, direction=direction)
     assert info["compute_word"] == 2 and info["kernel_name"].startswith(("k_big2", "k_mid")), info
     # every length in two passes since round 4: the 32-register passes of N = 2^17, 2^18 and the half-line tiles of N = 2^19, 2^20 in their
@@ -1009,7 +1047,9 @@ def test_narrow_data_round_mode(log2n, dw, direction):
         info = check(x, log2n, dw, tw, 0, 1, True, direction=direction)
         if log2n <= 12:
             assert "_i16" in info["kernel_name"], info
-        elif log2n >= 13 and not (direction == "PAIR" and log2n > 16):  # the multi-pass kernels in their ROUND = 2 forms
+        elif log2n <= 14:  # one pass since round 4: k_fft16k_i16<., ., ., ROUND = 2>
+            assert info["kernel_name"] == "k_fft16k_i16", info
+        elif not (direction == "PAIR" and log2n > 16):  # the multi-pass kernels in their ROUND = 2 forms
             assert info["kernel_name"].startswith(("k_big2", "k_mid")), info
 
 
@@ -1022,6 +1062,8 @@ def test_round_mode_pair_multi_pass(log2n, batch, tw, monkeypatch):
     x = np.concatenate([uniform_frames(batch, n, 16, 700 + log2n), edge_frames(n, 16)[3:6], uniform_frames(2, n, 15, 701 + log2n)])
     if tw != 16 and log2n > 16:
         pytest.skip("long frames: one twiddle width is enough")
+    if log2n <= 14:  # one pass since round 4 (test_single_pass_n8192_n16384_round_mode): keep the three-pass pair of these lengths covered
+        monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     info = check(x, log2n, 16, tw, 0, 1, True, direction="PAIR")
     assert info["kernel_name"] == ("k_big20_p1/k_mid_pair/q1" if log2n <= 16 else "k_big20_p1/k_fft4096_i16<MID>/q1"), info
     if log2n in (13, 16):  # the same plan through the 4096-point middle pass
