@@ -88,10 +88,19 @@ enum { M16_FWD = 0, M16_INV = 1, M16_PAIR = 2 }; // PAIR: int_fft_ifft_pair (int
 
 // ROUND: RNDMODE = 1 (the testbench's "ROUNDING" UUT) on its own instantiations (round 4): the ROUND forms of every register round -- rhu2 sums on
 // full-width values, exact extraction, no pre-shifted kinds, quarter turns through the negated twiddle -- 1: 16-bit data, 2: DATA_WIDTH 9 .. 15
-template <int L, int MODE, bool FAST_OK, int ROUND = 0>
+// The cores' own beat orders (round 4, template OB + launch argument native_orders).  Time side: a HALVES beat (x[i], x[i + N/2]) is the register pair (j, j + 16) of
+// layout A, one 8-byte access per lane.  Frequency side: BITREV order is the core position n itself, so a layout-C thread owns 32
+// CONSECUTIVE samples (128 bytes) -- moved straight between registers and memory every wave instruction would touch 64 lines; the chunk goes through the
+// idle transpose region once more instead (thread-major rows of 33 dwords, read back position-major) and is loaded / stored 256 bytes per wave instruction.
+template <int L, int MODE, bool FAST_OK, int ROUND = 0, bool OB = false>
 __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft16k_i16(const u32 *in, u32 *out, const uint2 *__restrict__ twf,
-                                                                                                          const RoundCConsts c, size_t nframes, const Slice sl)
+                                                                                                          const RoundCConsts c, size_t nframes, const Slice sl, int native_orders)
 {
+    static_assert(!OB || MODE != M16_PAIR, "native orders: forward or inverse core alone");
+    // OB instantiations serve every non-natural combination (bit 0: HALVES on the time side, bit 1: BITREV on the frequency side, wave-uniform tests);
+    // the natural-order instantiations carry none of that code (a run-time `halves` test alone cost the inverse kernel two spilled registers)
+    const bool halves = OB && (native_orders & 1), bitrev = OB && (native_orders & 2);
+    typedef u32 v2u __attribute__((ext_vector_type(2)));
     static_assert(L == 13 || L == 14, "one workgroup per frame of 8192 / 16384 points");
     static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
     constexpr int RB = L - 9; // thread bits above l in layouts A and B
@@ -164,6 +173,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
     const unsigned t3 = (unsigned)tid;
     const unsigned rc = RB == 5 ? ((t3 & 31u) | ((__brev(t3 >> 5) >> 28) << 5)) : ((t3 & 31u) | ((__brev(t3 >> 5) >> 29) << 5));
     u32 *const c_base = lds + ROWQ * rc;
+    // OB staging: thread t3's 32 positions in row t3; position p = 32 * brev(row) + column, read back as p = k * T + tid
+    u32 *const stg_own = lds + ROWQ * (int)t3;
+    u32 *const stg_lin = lds + ROWQ * (int)((__brev(t3 >> 5) >> (32 - (L - 10))) << 5) + (int)(t3 & 31u); // + ROWQ * rev5(k)
     const short s2 = (short)(1 - (hx & 1)); // L = 14, layout B: the kind of its inputs is n9 = jx bit 0
     const v2s sh2 = {s2, s2};
     const v2s none = {0, 0};
@@ -179,8 +191,26 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
         asm volatile("" : "+v"(tid_l), "+v"(twb));
         u32 v[32];
         if constexpr (FWD_PART) {
+            if (OB && halves) { // HALVES beats: 8-byte loads of the register pairs (j, j + 16)
+                const v2u *sh = reinterpret_cast<const v2u *>(src);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 5)), tid_l)); // layout A
+                for (int j = 0; j < 16; ++j) {
+                    const v2u w = INTFFT_LD(at32(sh + ((size_t)j << (L - 5)), tid_l));
+                    v[j] = w.x, v[j + 16] = w.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 5)), tid_l)); // layout A
+            }
+        } else if (OB && bitrev) { // BITREV order in: memory index = core position; linear loads, handed over to layout C through the staging rows
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = INTFFT_LD(at32(src + ((size_t)k << (L - 5)), tid_l));
+            __syncthreads(); // the previous frame's last transpose reads
+#pragma unroll
+            for (int k = 0; k < 32; ++k) stg_lin[ROWQ * rev5k(k)] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) v[r] = stg_own[r];
         } else {
 #pragma unroll
             for (int r = 0; r < 32; ++r) v[r] = INTFFT_LD(at32(src + ((size_t)rev5k(r) << (L - 5)), tid_l)); // layout C: position (t3, r) = X[brev_L]
@@ -256,7 +286,16 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dif_round4_c<false, 16, 0xF, ROUND>(v, c, sl);
                 if constexpr (ROUND != 0) round_stages10<32, ROUND == 2>(v, sl); // STAGE 1, 0 in their round forms on both halves
             }
-            if constexpr (MODE == M16_FWD) {
+            if (MODE == M16_FWD && OB && bitrev) { // BITREV order out: through the staging rows, then 256 bytes per wave instruction
+                __syncthreads(); // every thread has read its layout-C row
+#pragma unroll
+                for (int r = 0; r < 32; ++r) stg_own[r] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 32; ++k) v[k] = stg_lin[ROWQ * rev5k(k)];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) __builtin_nontemporal_store(v[k], at32(dst + ((size_t)k << (L - 5)), tid_l));
+            } else if constexpr (MODE == M16_FWD) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev5k(r) << (L - 5)), tid_l));
             }
@@ -317,8 +356,17 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dit_round_q<false, 16, ROUND>(v, ta, sl);
                 dit_top16<false, ROUND>(v, wat, wbt, sl);
             }
+            if (OB && halves) { // HALVES beats out: 8-byte stores of the register pairs (j, j + 16)
+                v2u *dh = reinterpret_cast<v2u *>(dst);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (L - 5)), tid_l));
+                for (int j = 0; j < 16; ++j) {
+                    const v2u w = {v[j], v[j + 16]};
+                    __builtin_nontemporal_store(w, at32(dh + ((size_t)j << (L - 5)), tid_l));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (L - 5)), tid_l));
+            }
         }
     }
 }
@@ -326,7 +374,11 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
 bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order)
 {
     return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
-           (!rndmode || !diag_env("INTFFT_NO_PACKED_ROUND")) && use_fly == 1 && direction >= 0 && direction <= 2 && in_order == 0 && out_order == 0 && !diag_env("INTFFT_NO_FAST16K");
+           (!rndmode || !diag_env("INTFFT_NO_PACKED_ROUND")) && use_fly == 1 && !diag_env("INTFFT_NO_FAST16K") &&
+           // + the cores' own beat orders: int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out (and the mixed forms)
+           (direction == 0   ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)
+            : direction == 1 ? (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)
+                             : direction == 2 && in_order == 0 && out_order == 0);
 }
 
 // the quarter-turn relation of the shared-twiddle rounds (stages 5 .. L-1), checked on the plan's generated tables (host copy); the inverse
@@ -347,20 +399,29 @@ bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd)
 
 const char *fast16k_kernel_name() { return "k_fft16k_i16"; }
 
-template <int L, int MODE, bool FX, int RD = 0>
-static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream)
+template <int L, int MODE, bool FX, int RD = 0, bool OB = false>
+static hipError_t launch16k_ob(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream, int native_orders)
 {
     constexpr int RB = L - 9, T = 16 << RB;
     const size_t ldsb = (size_t)(32 << RB) * ROWP * sizeof(u32) + (size_t)(RB == 5 ? 16 : 8) * (MODE == M16_PAIR ? 2 : 1) * 16 * sizeof(uint2);
-    allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX, RD>));
-    const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX, RD>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
+    allow_max_lds(kptr(k_fft16k_i16<L, MODE, FX, RD, OB>));
+    const size_t cap = resident_blocks(kptr(k_fft16k_i16<L, MODE, FX, RD, OB>), T, RB == 5 ? 2 : 4, RB == 5 ? 2 : 4);
     const unsigned blocks = (unsigned)(nframes < cap ? nframes : cap);
-    hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX, RD>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl);
+    hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX, RD, OB>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl, native_orders);
     return hipGetLastError();
+}
+// native_orders: bit 0 = HALVES on the time side, bit 1 = BITREV on the frequency side (single cores only): any of them -> the OB instantiation
+template <int L, int MODE, bool FX, int RD = 0>
+static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream, int native_orders)
+{
+    if constexpr (MODE != M16_PAIR) {
+        if (native_orders) return launch16k_ob<L, MODE, FX, RD, true>(in, out, tw16f, c, nframes, sl, stream, native_orders);
+    }
+    return launch16k_ob<L, MODE, FX, RD, false>(in, out, tw16f, c, nframes, sl, stream, 0);
 }
 
 hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,
-                          int data_width, int rndmode)
+                          int data_width, int rndmode, int native_orders)
 {
     if (nframes == 0) return hipSuccess;
     RoundCConsts c;
@@ -384,9 +445,9 @@ hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, voi
     sl.round = rndmode ? (data_width != 16 ? 2 : 1) : 0;
 #define INTFFT_16K_RD(LL, RD)                                                                                                       \
     {                                                                                                                              \
-        if (direction == 0) return launch16k<LL, M16_FWD, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                    \
-        if (direction == 2) return launch16k<LL, M16_PAIR, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                   \
-        return launch16k<LL, M16_INV, false, RD>(pin, pout, tw16f, c, nframes, sl, stream);                                        \
+        if (direction == 0) return launch16k<LL, M16_FWD, false, RD>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);                    \
+        if (direction == 2) return launch16k<LL, M16_PAIR, false, RD>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);                   \
+        return launch16k<LL, M16_INV, false, RD>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);                                        \
     }
     if (sl.round == 1) {
         if (log2n == 13) INTFFT_16K_RD(13, 1)
@@ -398,12 +459,12 @@ hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, voi
     }
 #undef INTFFT_16K_RD
 #define INTFFT_16K(LL)                                                                                                              \
-    if (direction == 0) return fx ? launch16k<LL, M16_FWD, true>(pin, pout, tw16f, c, nframes, sl, stream)                        \
-                                  : launch16k<LL, M16_FWD, false>(pin, pout, tw16f, c, nframes, sl, stream);                       \
-    if (direction == 2) return fx ? launch16k<LL, M16_PAIR, true>(pin, pout, tw16f, c, nframes, sl, stream)                       \
-                                  : launch16k<LL, M16_PAIR, false>(pin, pout, tw16f, c, nframes, sl, stream);                      \
-    return fx ? launch16k<LL, M16_INV, true>(pin, pout, tw16f, c, nframes, sl, stream)                                             \
-              : launch16k<LL, M16_INV, false>(pin, pout, tw16f, c, nframes, sl, stream);
+    if (direction == 0) return fx ? launch16k<LL, M16_FWD, true>(pin, pout, tw16f, c, nframes, sl, stream, native_orders)                        \
+                                  : launch16k<LL, M16_FWD, false>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);                       \
+    if (direction == 2) return fx ? launch16k<LL, M16_PAIR, true>(pin, pout, tw16f, c, nframes, sl, stream, native_orders)                       \
+                                  : launch16k<LL, M16_PAIR, false>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);                      \
+    return fx ? launch16k<LL, M16_INV, true>(pin, pout, tw16f, c, nframes, sl, stream, native_orders)                                             \
+              : launch16k<LL, M16_INV, false>(pin, pout, tw16f, c, nframes, sl, stream, native_orders);
     if (log2n == 13) {
         INTFFT_16K(13)
     }

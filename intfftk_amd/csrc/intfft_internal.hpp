@@ -289,7 +289,7 @@ hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, 
 bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly, int in_order, int out_order);
 bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd);
 hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,
-                          int data_width, int rndmode = 0);
+                          int data_width, int rndmode = 0, int native_orders = 0); // native_orders: bit 0 HALVES on the time side, bit 1 BITREV on the frequency side
 const char *fast16k_kernel_name();
 // packed int16 block kernel for N = 4096, FWD / INV / PAIR (intfft_fast4096.hip)
 bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,

@@ -1353,7 +1353,9 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                      plan->h_tw.data(), batch, stream, plan->p.rndmode, plan->p.data_width);
     if (plan->fast16k)
         return (int)launch_fast16k(plan->p.log2n, plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw16f, plan->h_tw.data(), batch, stream,
-                                   plan->p.data_width, plan->p.rndmode);
+                                   plan->p.data_width, plan->p.rndmode,
+                                   ((plan->p.direction == INTFFT_FWD ? plan->p.in_order : plan->p.out_order) == INTFFT_ORDER_HALVES ? 1 : 0) |
+                                       ((plan->p.direction == INTFFT_FWD ? plan->p.out_order : plan->p.in_order) == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
                                     plan->p.direction == INTFFT_FWD ? plan->p.out_order == INTFFT_ORDER_BITREV

@@ -276,6 +276,33 @@ def test_single_pass_n8192_n16384(log2n, direction, monkeypatch):
 
 
 @pytest.mark.parametrize("log2n", [13, 14])
+@pytest.mark.parametrize("rnd", [0, 1])
+@pytest.mark.parametrize("direction,in_order,out_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"), ("FWD", "HALVES", "NATURAL"),
+                                                          ("INV", "BITREV", "HALVES"), ("INV", "NATURAL", "HALVES"), ("INV", "BITREV", "NATURAL")])
+def test_single_pass_n8192_n16384_native_orders(log2n, rnd, direction, in_order, out_order, monkeypatch):
+    """The cores' own beat orders on the one-pass kernel (round 4): int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out and the
+    mixed forms -- HALVES beats as 8-byte accesses of layout-A register pairs, BITREV order through the staging rows of the transpose region -- in
+    both rounding modes, ragged batches, a full-scale frame; against the oracle and against the two-pass plan in the same orders."""
+    n = 1 << log2n
+    kw = dict(direction=direction, in_order=in_order, out_order=out_order)
+    for batch in (1, 5, 600 if log2n == 13 else 300):
+        x = uniform_frames(batch, n, 15, 4700 + log2n + batch)
+        x[0] = uniform_frames(1, n, 16, 17)[0]
+        a, ia = run_gpu(x, log2n, 16, 16, 0, rnd, True, **kw)
+        assert ia["kernel_name"] == "k_fft16k_i16" and ia["n_passes"] == 1, ia
+        sel = sorted({0, 1 % batch, batch // 2, batch - 1})
+        assert np.array_equal(a[sel], run_ref(x[sel], log2n, 16, 16, 0, rnd, True, **kw))
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_FAST16K", "1")
+            b, ib = run_gpu(x, log2n, 16, 16, 0, rnd, True, **kw)
+            assert ib["n_passes"] == 2, ib
+        assert np.array_equal(a, b)
+    xs = np.concatenate([edge_frames(n, 12), uniform_frames(3, n, 11, 4800 + log2n)])
+    info = check(xs, log2n, 12, 14, 0, rnd, True, **kw)  # narrow data, narrower twiddles (exact extraction)
+    assert info["kernel_name"] == "k_fft16k_i16", info
+
+
+@pytest.mark.parametrize("log2n", [13, 14])
 @pytest.mark.parametrize("direction", ["FWD", "INV", "PAIR"])
 def test_single_pass_n8192_n16384_round_mode(log2n, direction, monkeypatch):
     """RNDMODE = 1 (the testbench's "ROUNDING" UUT, int_dif2_fly.vhd:167-219 / int_dit2_fly.vhd:164-217) on the one-pass kernel's ROUND instantiations
@@ -326,9 +353,9 @@ def test_two_pass_vs_three_pass_split(log2n, batch, direction, time_order, freq_
     x[batch // 2] = uniform_frames(1, n, 16, 9)[0]
     kw = (dict(direction=direction, in_order=time_order, out_order=freq_order) if direction == "FWD"
           else dict(direction=direction, in_order=freq_order, out_order=time_order))
-    # natural <-> natural at N = 8192 / 16384 is ONE pass since round 4 (k_fft16k_i16, test_single_pass_n8192_n16384): the two-pass
+    # N = 8192 / 16384 is ONE pass since round 4 (k_fft16k_i16, test_single_pass_n8192_n16384 and ..._native_orders): the two-pass
     # split is then the A/B form behind INTFFT_NO_FAST16K
-    if log2n <= 14 and time_order == "NATURAL" and freq_order == "NATURAL":
+    if log2n <= 14:
         monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     a, ia = run_gpu(x, log2n, 16, 16, 0, 0, True, **kw)
     two = {("FWD", "NATURAL"): "k_big20_p1/k_mid_p2", ("FWD", "BITREV"): "k_big20_p1/k_mid_c",
@@ -355,7 +382,7 @@ def test_multi_pass_kernels_small_batches(log2n, batch):
         assert ("k_big20" if log2n > 14 else "k_fft16k_i16") in info["kernel_name"], info
     for kw in (dict(in_order="HALVES", out_order="BITREV"), dict(direction="INV", in_order="BITREV", out_order="HALVES")):
         info = check(x, log2n, 16, 16, 0, 0, True, **kw)
-        assert "k_big20" in info["kernel_name"] or "k_mid" in info["kernel_name"], info
+        assert ("k_big20" in info["kernel_name"] or "k_mid" in info["kernel_name"]) if log2n > 14 else info["kernel_name"] == "k_fft16k_i16", info
     for direction in ("FWD", "INV"):  # general widths: unscaled 16-bit, 12-bit scaled-round
         info = check(x, log2n, 16, 16, 1, 0, True, direction=direction)
         assert info["kernel_name"].startswith("k_bigw"), info
@@ -463,9 +490,11 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
 @pytest.mark.parametrize("direction,in_order,out_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
                                                           ("FWD", "HALVES", "NATURAL"), ("INV", "BITREV", "HALVES"),
                                                           ("INV", "NATURAL", "HALVES"), ("INV", "BITREV", "NATURAL")])
-def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order):
+def test_three_pass_native_orders(log2n, batch, direction, in_order, out_order, monkeypatch):
     """The cores' own beat orders for N >= 8192: HALVES beats as 8-byte loads / stores of register pairs in pass 1,
     BITREV order = the core index, so the last (first) four stages run on 16 consecutive samples (k_big_c)."""
+    if log2n <= 14:  # one pass since round 4 (test_single_pass_n8192_n16384_native_orders): this test keeps the multi-pass plans covered
+        monkeypatch.setenv("INTFFT_NO_FAST16K", "1")
     n = 1 << log2n
     x = uniform_frames(batch, n, 15, 7000 + log2n)
     x[0] = uniform_frames(1, n, 16, 10)[0]

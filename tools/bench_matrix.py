@@ -45,6 +45,10 @@ for L in (14, 16, 20):
 ROWS.append(("16:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("20:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("14:16:16:0:1:PAIR", "16-bit scaled-round PAIR"))
+ROWS.append(("13:16:16:0:1", "16-bit scaled-round FWD"))
+ROWS.append(("13:16:16:0:1:INV", "16-bit scaled-round INV"))
+ROWS.append(("14:16:16:0:1:INV", "16-bit scaled-round INV"))
+ROWS.append(("13:16:16:0:1:PAIR", "16-bit scaled-round PAIR"))
 ROWS.append(("10:18:18:0:0:INV", "18-bit scaled INV"))
 ROWS.append(("12:14:16:0:1", "14-bit scaled-round FWD"))
 ROWS.append(("12:14:16:0:1:PAIR", "14-bit scaled-round PAIR"))
@@ -98,7 +102,12 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("20:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
           ("7:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out (native int_ifftNk beats)"),
           ("12:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
-          ("16:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out")]
+          ("16:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out"),
+          ("13:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (one pass, round 4)"),
+          ("14:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (one pass, round 4)"),
+          ("13:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out (one pass, round 4)"),
+          ("14:16:16:0:0:INV", ("BITREV", "HALVES"), "16-bit scaled-trunc INV, BITREV in / HALVES out (one pass, round 4)"),
+          ("14:16:16:0:1", ("HALVES", "BITREV"), "16-bit scaled-round FWD, HALVES in / BITREV out (one pass, round 4)")]
 
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
