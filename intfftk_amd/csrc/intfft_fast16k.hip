@@ -163,16 +163,30 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
     };
 
     // transpose addressing.  A <-> B: element (row = n(L-1)..n4, column l)
-    u32 *const a_base = lds + ROWP * hx + l;        // layout A thread (hx = n(L-6)..n4, l): row (j << RB) | hx
-    u32 *const b_base = lds + ROWP * (hx << 5) + l; // layout B thread (jx = hx, l):         row (jx << 5) | q
+    // (every base below is recomputed from an opaque copy of the thread index at its transpose -- `REMAT` -- instead of being held over the register
+    // rounds: four resident address registers were what pushed the pair and the native-order kernels over 128 VGPRs)
+#ifdef INTFFT_16K_NO_REMAT
+#define INTFFT_16K_OPQ(t)
+#else
+#define INTFFT_16K_OPQ(t) asm volatile("" : "+v"(t))
+#endif
+    auto a_base_f = [&]() { unsigned t = (unsigned)tid; INTFFT_16K_OPQ(t); return lds + ROWP * (int)(t >> 4) + (int)(t & 15u); };        // layout A thread (hx = n(L-6)..n4, l): row (j << RB) | hx
+    auto b_base_f = [&]() { unsigned t = (unsigned)tid; INTFFT_16K_OPQ(t); return lds + ROWP * (int)((t >> 4) << 5) + (int)(t & 15u); }; // layout B thread (jx = hx, l):         row (jx << 5) | q
     // B <-> C: row R of ROWQ dwords, column n4..n0.  Layout C thread t3 = rev(n(L-1)..n5): bit i = n(L-1-i).
     //   L = 14: R = rev5(jx) | (n8..n5 = q >> 1) << 5;           t3 = rev5(jx) | rev4(q >> 1) << 5
     //   L = 13: R = rev4(jx) | (n8 = q >> 4) << 4 | (n7..n5 = (q >> 1) & 7) << 5;   t3 = rev4(jx) | n8 << 4 | rev3(n7..n5) << 5
-    const unsigned rjx = __brev((unsigned)hx) >> (32 - RB);
-    u32 *const bq_base = lds + ROWQ * rjx + l; // + ROWQ * rowq_of(q) + ((q & 1) << 4)
+    auto bq_base_f = [&]() { // + ROWQ * rowq_of(q) + ((q & 1) << 4)
+        unsigned t = (unsigned)tid;
+        INTFFT_16K_OPQ(t);
+        return lds + ROWQ * (int)(__brev(t >> 4) >> (32 - RB)) + (int)(t & 15u);
+    };
     const unsigned t3 = (unsigned)tid;
-    const unsigned rc = RB == 5 ? ((t3 & 31u) | ((__brev(t3 >> 5) >> 28) << 5)) : ((t3 & 31u) | ((__brev(t3 >> 5) >> 29) << 5));
-    u32 *const c_base = lds + ROWQ * rc;
+    auto c_base_f = [&]() {
+        unsigned t = (unsigned)tid;
+        INTFFT_16K_OPQ(t);
+        const unsigned rc = RB == 5 ? ((t & 31u) | ((__brev(t >> 5) >> 28) << 5)) : ((t & 31u) | ((__brev(t >> 5) >> 29) << 5));
+        return lds + ROWQ * (int)rc;
+    };
     // OB staging: thread t3's 32 positions in row t3; position p = 32 * brev(row) + column, read back as p = k * T + tid
     u32 *const stg_own = lds + ROWQ * (int)t3;
     u32 *const stg_lin = lds + ROWQ * (int)((__brev(t3 >> 5) >> (32 - (L - 10))) << 5) + (int)(t3 & 31u); // + ROWQ * rev5(k)
@@ -240,14 +254,20 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dif_round_q<false, 0, 0, false, 4, ROUND>(v, ta, sl, none);
                 dif_round_q<false, 16, 0xF, false, 4, ROUND>(v, ta, sl, none);
             }
+            {
+                u32 *const a_base = a_base_f();
 #pragma unroll
-            for (int j = 0; j < 32; ++j) a_base[ROWP * (j << RB)] = v[j];
+                for (int j = 0; j < 32; ++j) a_base[ROWP * (j << RB)] = v[j];
+            }
             __syncthreads();
             u32 wa2t[8], wb2t[8];
             RoundTwQ tb;
             tw_b(0, wa2t, wb2t, tb);
+            {
+                u32 *const b_base = b_base_f();
 #pragma unroll
-            for (int q = 0; q < 32; ++q) v[q] = b_base[ROWP * q];
+                for (int q = 0; q < 32; ++q) v[q] = b_base[ROWP * q];
+            }
             // ---- layout B: DIF 8 .. 4 (L = 13: 7 .. 4 on the two halves; the kind of their inputs is n8 = q bit 4) ----
             if constexpr (RB == 4) {
                 if (fast) {
@@ -269,14 +289,18 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 }
             }
             __syncthreads(); // every thread has read its A -> B rows: the region may take the B -> C rows
+            u32 *const bq_base = bq_base_f();
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const int rq = RB == 5 ? ((q >> 1) << 5) : (((q >> 4) << 4) | (((q >> 1) & 7) << 5));
                 bq_base[ROWQ * rq + ((q & 1) << 4)] = v[q];
             }
             __syncthreads();
+            {
+                u32 *const c_base = c_base_f();
 #pragma unroll
-            for (int r = 0; r < 32; ++r) v[r] = c_base[r];
+                for (int r = 0; r < 32; ++r) v[r] = c_base[r];
+            }
             // ---- layout C: DIF 3 .. 0 on the halves n4 = 0 / 1 (the upper half holds Y >> 1 of STAGE 4) ----
             if (fast) {
                 dif_round4_c<FAST_OK, 0, 0>(v, c, sl);
@@ -310,16 +334,20 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 dit_round4_c<false, 0, CP, ROUND>(v, c, sl);
                 dit_round4_c<false, 16, CP, ROUND>(v, c, sl);
             }
+            {
+                u32 *const c_base = c_base_f();
 #pragma unroll
-            for (int r = 0; r < 32; ++r) c_base[r] = v[r];
+                for (int r = 0; r < 32; ++r) c_base[r] = v[r];
+            }
             __syncthreads();
             u32 wa2t[8], wb2t[8];
             RoundTwQ tb;
             tw_b(FWD_PART ? NSLOT : 0, wa2t, wb2t, tb);
+            u32 *const bq_base_i = bq_base_f();
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 const int rq = RB == 5 ? ((q >> 1) << 5) : (((q >> 4) << 4) | (((q >> 1) & 7) << 5));
-                v[q] = bq_base[ROWQ * rq + ((q & 1) << 4)];
+                v[q] = bq_base_i[ROWQ * rq + ((q & 1) << 4)];
             }
             // ---- layout B: DIT 4 .. 8 (L = 13: 4 .. 7) ----
             if (fast) {
@@ -332,12 +360,18 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 if constexpr (RB == 5) dit_top16<false, ROUND>(v, wa2t, wb2t, sl);
             }
             __syncthreads();
+            {
+                u32 *const b_base = b_base_f();
 #pragma unroll
-            for (int q = 0; q < 32; ++q) b_base[ROWP * q] = v[q];
+                for (int q = 0; q < 32; ++q) b_base[ROWP * q] = v[q];
+            }
             tw_a(twb, wat, wbt, ta); // in flight across the barrier (the data registers are free here)
             __syncthreads();
+            {
+                u32 *const a_base = a_base_f();
 #pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = a_base[ROWP * (j << RB)];
+                for (int j = 0; j < 32; ++j) v[j] = a_base[ROWP * (j << RB)];
+            }
             to_dit_packing(ta.wa1[0], ta.wb1[0]);
             to_dit_packing(ta.wa2[0], ta.wb2[0]);
 #pragma unroll
