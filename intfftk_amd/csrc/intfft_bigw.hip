@@ -247,28 +247,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (size_t frame = grp; frame < nframes; frame += groups) {
         const bool partial = L < 16 && (frame + 1) * G > nframes_user; // last group: absent frames read as 0, not stored
         unsigned lf = lfull, t1 = tb1; // opaque per tile: keeps the (loop-invariant) twiddle loads inside the loop
-        asm volatile("" : "+v"(lf), "+v"(t1));
+        // every global access below is (wave-uniform pointer)[32-bit thread offset] (at32, intfft_device.hpp): 64-bit per-access address pairs cost this
+        // kernel 10-18 spilled VGPRs (round 4)
+        unsigned toff = (unsigned)hx * 256u + (unsigned)l; // row hx of the register's 16-row block, column l of the chunk
+        asm volatile("" : "+v"(lf), "+v"(t1), "+v"(toff));
         int re[16], im[16];
         if (a.in16) {
-            const u32 *src = static_cast<const u32 *>(in) + frame * 65536 + lfull;
+            const u32 *src = static_cast<const u32 *>(in) + frame * 65536 + chunk * 32; // wave-uniform
             u32 raw[16];
+            if (!partial) { // (one test around the 16 loads: tested one by one they are issued one by one)
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                raw[j] = (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
-                             ? INTFFT_LD(src + ((size_t)(16 * j + hx) << 8))
-                             : 0u;
+                for (int j = 0; j < 16; ++j) raw[j] = INTFFT_LD(at32(src + ((size_t)j << 12), toff));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    raw[j] = frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user ? INTFFT_LD(at32(src + ((size_t)j << 12), toff)) : 0u;
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 re[j] = (int)(raw[j] << a.in_sh) >> a.in_sh, im[j] = (int)(raw[j] << (a.in_sh - 16)) >> a.in_sh;
         } else {
             typedef int v2i __attribute__((ext_vector_type(2)));
-            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + frame * 65536 + lfull);
+            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + frame * 65536 + chunk * 32);
             v2i x[16];
+            if (!partial) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                x[j] = v2i{0, 0};
-                if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user)
-                    x[j] = INTFFT_LD(src + ((size_t)(16 * j + hx) << 8));
+                for (int j = 0; j < 16; ++j) x[j] = INTFFT_LD(at32(src + ((size_t)j << 12), toff));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    x[j] = v2i{0, 0};
+                    if (frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) x[j] = INTFFT_LD(at32(src + ((size_t)j << 12), toff));
+                }
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -321,10 +331,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __syncthreads(); // the next tile's writes stay behind these reads
         }
         gstages<MODE, MASKED, 4, 8>(re, im, b8r, b8i, b4r, b4i, b2r, b2i, b1r, b1i, a);
-        int2 *dst = scr + frame * 65536 + lfull;
+        {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(scr + frame * 65536 + chunk * 32); // wave-uniform
+            const unsigned soff = (unsigned)hx * 4096u + (toff & 31u);            // row 16 hx + r: r goes into the uniform part
+            if (!partial) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (!partial || frame * G + (size_t)((16 * hx + r) >> (L - 8)) < nframes_user) dst[(size_t)(16 * hx + r) << 8] = make_int2(re[r], im[r]);
+                for (int r = 0; r < 16; ++r) *at32(dst + ((size_t)r << 8), soff) = v2i{re[r], im[r]};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (frame * G + (size_t)((16 * hx + r) >> (L - 8)) < nframes_user) *at32(dst + ((size_t)r << 8), soff) = v2i{re[r], im[r]};
+            }
+        }
     }
 }
 
