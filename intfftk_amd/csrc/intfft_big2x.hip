@@ -371,13 +371,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int q = 0; q < 32; ++q) own[q] = v[q];
             __syncthreads();
             typedef u32 v4u __attribute__((ext_vector_type(4)));
+            // flat [k][column] index of the tile: e = (512 i + tid) * 4 -> k = 2 i + (tid >> 8), column = 4 (tid & 255): the i part is wave-uniform
+            // (at32: a uniform pointer + a 32-bit thread offset; as 64-bit per-access addresses these eight stores cost the kernel ten spilled VGPRs)
+            unsigned tl = (unsigned)tid;
+            asm volatile("" : "+v"(tl));
+            const unsigned col = (tl & 255u) * 4u, k0 = tl >> 8;
+            const u32 *sp0 = lds + ROWY * (((col >> 5) << 4) | k0) + (col & 31u);
+            v4u *const d4 = reinterpret_cast<v4u *>(out + (frame << L) + ((size_t)rest << 10)); // wave-uniform
+            const unsigned doff = (k0 << (RL + 8)) | (tl & 255u);                                // in 16-byte units
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const unsigned e = ((unsigned)i * 512u + (unsigned)tid) * 4u; // flat [k][column] index of the tile
-                const unsigned kk = e >> 10, col = e & 1023u;
-                const u32 *sp = lds + ROWY * (((col >> 5) << 4) | kk) + (col & 31u);
+                const u32 *sp = sp0 + ROWY * 2 * i;
                 const v4u y = {sp[0], sp[1], sp[2], sp[3]};
-                __builtin_nontemporal_store(y, reinterpret_cast<v4u *>(out + (frame << L) + ((((size_t)kk << RL) | rest) << 10) + col));
+                __builtin_nontemporal_store(y, at32(d4 + ((size_t)(2 * i) << (RL + 8)), doff));
             }
         } else {
 #pragma unroll
