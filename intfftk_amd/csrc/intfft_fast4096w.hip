@@ -116,25 +116,43 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
     for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
         const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
         int re[16], im[16];
+        // (wave-uniform pointer)[32-bit thread offset] for every global access (at32, intfft_device.hpp), the partial-chunk test around the loops:
+        // per-access 64-bit addresses and a test inside the unrolled loads cost these kernels 4-24 spilled VGPRs and serialised loads (round 4)
+        unsigned tl = (unsigned)tid, lco = (unsigned)lc_off;
+        asm volatile("" : "+v"(tl), "+v"(lco));
         if (a.in16) {
-            const u32 *src = static_cast<const u32 *>(in) + f * 4096 + tid;
+            const u32 *src = static_cast<const u32 *>(in) + f * 4096; // wave-uniform
+            u32 raw[16];
+            if (!partial) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) raw[j] = INTFFT_LD(at32(src + 256 * j, tl));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) raw[j] = f * FP + (size_t)((256 * j + tid) >> L) < nframes_user ? INTFFT_LD(at32(src + 256 * j, tl)) : 0u;
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
-                const u32 raw = ok ? INTFFT_LD(src + 256 * j) : 0u;
-                re[j] = (int)(raw << a.in_sh) >> a.in_sh;
-                im[j] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
+                re[j] = (int)(raw[j] << a.in_sh) >> a.in_sh;
+                im[j] = (int)(raw[j] << (a.in_sh - 16)) >> a.in_sh;
             }
         } else {
             typedef int v2i __attribute__((ext_vector_type(2)));
-            const v2i *src = static_cast<const v2i *>(in) + f * 4096 + tid;
+            const v2i *src = static_cast<const v2i *>(in) + f * 4096;
+            v2i x[16];
+            if (!partial) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) x[j] = INTFFT_LD(at32(src + 256 * j, tl));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    x[j] = v2i{0, 0};
+                    if (f * FP + (size_t)((256 * j + tid) >> L) < nframes_user) x[j] = INTFFT_LD(at32(src + 256 * j, tl));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const bool ok = !partial || f * FP + (size_t)((256 * j + tid) >> L) < nframes_user;
-                v2i x = {0, 0};
-                if (ok) x = INTFFT_LD(src + 256 * j);
-                re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh;
-                im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+                re[j] = (int)((u32)x[j].x << a.in_sh) >> a.in_sh;
+                im[j] = (int)((u32)x[j].y << a.in_sh) >> a.in_sh;
             }
         }
         ground<MODE, MASKED, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
@@ -164,11 +182,11 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
             tail64_stages10(xr, xi);
             if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
                 typedef long long v2l __attribute__((ext_vector_type(2)));
-                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
+                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096; // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const v2l y = {xr[r], xi[r]};
-                    __builtin_nontemporal_store(y, dst + (rev4q(r) << (L - 4)));
+                    __builtin_nontemporal_store(y, at32(dst + (rev4q(r) << (L - 4)), lco));
                 }
             }
             continue;
@@ -185,11 +203,11 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
             tail64_unscaled(re, im, xr, xi);
             if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
                 typedef long long v2l __attribute__((ext_vector_type(2)));
-                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
+                v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096; // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const v2l y = {xr[r], xi[r]};
-                    __builtin_nontemporal_store(y, dst + (rev4q(r) << (L - 4)));
+                    __builtin_nontemporal_store(y, at32(dst + (rev4q(r) << (L - 4)), lco));
                 }
             }
             continue;
@@ -204,17 +222,17 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
 
         if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
             if (a.out16) {
-                u32 *dst = static_cast<u32 *>(out) + f * 4096 + lc_off;
+                u32 *dst = static_cast<u32 *>(out) + f * 4096; // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), dst + (rev4q(r) << (L - 4)));
+                    __builtin_nontemporal_store(((u32)re[r] & 0xFFFFu) | ((u32)im[r] << 16), at32(dst + (rev4q(r) << (L - 4)), lco));
             } else {
                 typedef int v2i __attribute__((ext_vector_type(2)));
-                int2 *dst = static_cast<int2 *>(out) + f * 4096 + lc_off;
+                v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + f * 4096); // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const v2i y = {re[r], im[r]};
-                    __builtin_nontemporal_store(y, reinterpret_cast<v2i *>(dst + (rev4q(r) << (L - 4))));
+                    __builtin_nontemporal_store(y, at32(dst + (rev4q(r) << (L - 4)), lco));
                 }
             }
         }
