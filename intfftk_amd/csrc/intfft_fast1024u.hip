@@ -23,10 +23,17 @@
 
 namespace intfft {
 
-template <int L, bool FAST_OK>
+// NAT (round 4): the instantiation for int_fftNk's own beat orders, selected by `native` (bit 0: HALVES in, bit 1: BITREV out; N >= 128) --
+//   HALVES  a beat (x[i], x[i + N/2]) is the register pair (j0, j0 | 2^(L-7)) of one lane: eight 8-byte loads, 512 contiguous bytes per wave instruction
+//   BITREV  memory index = core position: after the last stage a lane holds 16 CONSECUTIVE positions (reg = a3..a0); the chunk goes through the wave's
+//           idle LDS tile (rows of 16 samples, 36 dwords apart) and leaves in memory order, 1 KiB per wave instruction
+// The natural-order instantiation (NAT = false) carries none of it.
+template <int L, bool FAST_OK, bool NAT = false>
 __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt, const UConsts c,
-                                                     size_t nframes_user, int sh)
+                                                     size_t nframes_user, int sh, int native)
 {
+    static_assert(!NAT || L >= 7, "native beat orders: N >= 128");
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     constexpr int FP = 1 << (10 - L);                    // frames per 1024-sample chunk (intfft_fast1024.hip)
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
@@ -92,7 +99,22 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
     for (size_t f = wave0; f < nframes; f += nwaves) {
         const u32 *src = in + f * 1024 + lane;
         u32 raw[16];
-        if (L < 10 && (f + 1) * FP > nframes_user) { // partial last chunk: absent frames read as 0
+        if (NAT && halves) {
+            // pair index of (register pair jj, lane): logical position P = 64 j0 + lane with bit L-1 clear -> frame P >> L, beat P mod N/2
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
+            const v2u *src2 = reinterpret_cast<const v2u *>(in + f * 1024) + lane;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L >= 7 ? L - 7 : 0);                 // register bit that carries a(L-1)
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 64 * j0;                                       // register part of P
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                v2u w = {0u, 0u};
+                if (!(L < 10) || f * FP + (size_t)(p0 >> L) < nframes_user) w = INTFFT_LD(src2 + pair);
+                raw[j0] = w.x;
+                raw[j0 | HB] = w.y;
+            }
+        } else if (L < 10 && (f + 1) * FP > nframes_user) { // partial last chunk: absent frames read as 0
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 raw[j] = f * FP + (size_t)((64 * j + lane) >> L) < nframes_user ? src[64 * j] : 0u;
@@ -115,7 +137,29 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
         }
         if (FAST_OK && fast) utransform<L, false>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
         else utransform<L, true>(re, im, w9r, w9i, w8r, w8i, w7r, w7i, w6r, w6i, w5r, w5i, w4r, w4i, c, sh, wr_base, rd_base);
-        if constexpr (L < 10) {
+        if (NAT && bitrev) {
+            // position of (lane, reg r) = A(lane) | r with A = the index bits a9..a4 the lane carries (lane_bit_u<L>): 16 consecutive samples per lane
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            int A = 0;
+#pragma unroll
+            for (int k = 4; k < 10; ++k) A |= ((lane >> lane_bit_u<L>(k)) & 1) << k;
+            wave_lds_fence();
+            u32 *row = lds + 36 * (A >> 4); // 16 samples = 32 dwords per row, 4 dwords of pad
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v4i y = {re[2 * q], im[2 * q], re[2 * q + 1], im[2 * q + 1]};
+                *reinterpret_cast<v4i *>(row + 4 * q) = y;
+            }
+            wave_lds_fence();
+            v4i *dst4 = reinterpret_cast<v4i *>(out + f * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 64 * i + lane; // 16-byte piece = samples 2 e, 2 e + 1 of the chunk
+                if (L < 10 && f * FP + (size_t)((2 * e) >> L) >= nframes_user) continue;
+                __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 36 * (e >> 3) + 4 * (e & 7)), dst4 + e);
+            }
+            wave_lds_fence();
+        } else if constexpr (L < 10) {
             // one lane swap per plane: reg bit 3 = a(L-1); registers {q, q+8} are two consecutive outputs
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -167,33 +211,39 @@ __global__ __launch_bounds__(256) void k_fft1024_u32(const u32 *in, int2 *out, c
 bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                          int in_order, int out_order)
 {
-    return log2n >= 6 && log2n <= 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && direction == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!(log2n >= 6 && log2n <= 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && direction == 0 && use_fly == 1))
+        return false;
+    if (in_order == 0 && out_order == 0) return true;
+    // int_fftNk's own beat orders (HALVES in, BITREV out) and the mixed forms, N >= 128
+    return log2n >= 7 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
 }
 
 const char *fast1024u_kernel_name() { return "k_fft1024_u32"; }
 
-template <int L, bool FAST_OK>
+template <int L, bool FAST_OK, bool NAT>
 static hipError_t launchu(const u32 *in, int2 *out, const int2 *tw, const UConsts &c, size_t nframes, int sh,
-                          hipStream_t stream)
+                          hipStream_t stream, int native)
 {
-    const size_t cap = resident_blocks(kptr(k_fft1024_u32<L, FAST_OK>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft1024_u32<L, FAST_OK, NAT>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4;
-    hipLaunchKernelGGL((k_fft1024_u32<L, FAST_OK>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
-                       c, nframes, sh);
+    hipLaunchKernelGGL((k_fft1024_u32<L, FAST_OK, NAT>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+                       c, nframes, sh, native);
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launchu_l(bool fast, const u32 *in, int2 *out, const int2 *tw, const UConsts &c, size_t nframes, int sh,
-                            hipStream_t stream)
+                            hipStream_t stream, int native)
 {
-    return fast ? launchu<L, true>(in, out, tw, c, nframes, sh, stream) : launchu<L, false>(in, out, tw, c, nframes, sh, stream);
+    if constexpr (L >= 7) {
+        if (native) return fast ? launchu<L, true, true>(in, out, tw, c, nframes, sh, stream, native) : launchu<L, false, true>(in, out, tw, c, nframes, sh, stream, native);
+    }
+    return fast ? launchu<L, true, false>(in, out, tw, c, nframes, sh, stream, 0) : launchu<L, false, false>(in, out, tw, c, nframes, sh, stream, 0);
 }
 
 hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
-                            hipStream_t stream)
+                            hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
@@ -209,11 +259,11 @@ hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const
     const u32 *pin = static_cast<const u32 *>(in);
     int2 *pout = static_cast<int2 *>(out);
     switch (log2n) {
-    case 6: return launchu_l<6>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
-    case 7: return launchu_l<7>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
-    case 8: return launchu_l<8>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
-    case 9: return launchu_l<9>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
-    default: return launchu_l<10>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream);
+    case 6: return launchu_l<6>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream, native);
+    case 7: return launchu_l<7>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream, native);
+    case 8: return launchu_l<8>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream, native);
+    case 9: return launchu_l<9>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream, native);
+    default: return launchu_l<10>(allow_fast, pin, pout, tw_all, c, nframes, twd - 1, stream, native);
     }
 }
 

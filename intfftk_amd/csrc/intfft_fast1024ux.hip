@@ -157,10 +157,16 @@ __device__ __forceinline__ void uinverse(int (&re)[16], int (&im)[16], const int
 
 // four waves per SIMD (the 40 KiB of LDS admit four workgroups): without the hint the N = 256 pair takes 172 VGPRs
 // (116 with it, no spills: 289 -> 310 Gsample/s); the other instantiations are unchanged within noise
-template <int L, int MODE, bool FAST_OK>
+// NAT (round 4): the inverse core's instantiation for int_ifftNk's own beat orders, selected by `native` (bit 0: HALVES out, bit 1: BITREV in; N >= 128) --
+//   BITREV  memory index = core position: an LC lane needs 16 CONSECUTIVE samples (reg = a3..a0); the chunk is loaded in memory order (1 KiB per wave
+//           instruction), passed through the wave's idle LDS tile (rows of 16 samples, 20 dwords apart) and read back one row per lane
+//   HALVES  a beat (x[i], x[i + N/2]) is the L1 register pair (j0, j0 | 2^(L-7)) of one lane: eight 16-byte stores, 1 KiB per wave instruction
+template <int L, int MODE, bool FAST_OK, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4 : 2))) void k_fft1024ux_u32(const u32 *in, int2 *out, const int2 *__restrict__ twt,
-                                                       const UConsts c, const UxArgs a, size_t nframes_user, int sh)
+                                                       const UConsts c, const UxArgs a, size_t nframes_user, int sh, int native)
 {
+    static_assert(!NAT || (MODE == UX_INV && L >= 7), "native beat orders: the inverse core alone, N >= 128");
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     constexpr int FP = 1 << (10 - L);
     constexpr int MAP = MODE == UX_PAIR ? 1 : 2;
     constexpr bool MASKED = MODE == UX_PAIR;
@@ -228,7 +234,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
         const u32 *src = in + f * 1024;
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0, not stored
         u32 raw[16];
-        if (MODE == UX_INV && L < 10) {
+        if (NAT && bitrev) {
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            const v4u *src4 = reinterpret_cast<const v4u *>(src);
+            v4u x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { // piece e = 64 i + lane: positions 4 e .. 4 e + 3
+                const int e = 64 * i + lane;
+                x[i] = v4u{0u, 0u, 0u, 0u};
+                if (!partial || f * FP + (size_t)((4 * e) >> L) < nframes_user) x[i] = INTFFT_LD(src4 + e);
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 64 * i + lane;
+                *reinterpret_cast<v4u *>(lds + ROWU * (e >> 2) + 4 * (e & 3)) = x[i];
+            }
+            wave_lds_fence();
+            int A = 0; // the index bits a9..a4 this lane carries in LC
+#pragma unroll
+            for (int k = 4; k < 10; ++k) A |= ab(k) << k;
+            const v4u *row = reinterpret_cast<const v4u *>(lds + ROWU * (A >> 4));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4u y = row[q];
+                raw[4 * q] = y.x, raw[4 * q + 1] = y.y, raw[4 * q + 2] = y.z, raw[4 * q + 3] = y.w;
+            }
+            wave_lds_fence();
+        } else if (MODE == UX_INV && L < 10) {
             typedef u32 v4u __attribute__((ext_vector_type(4)));
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
 #pragma unroll
@@ -289,7 +322,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
         }
         int2 *dst = out + f * 1024 + lane;
         typedef int v2i __attribute__((ext_vector_type(2)));
-        if (partial) {
+        if (NAT && halves) {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            v4i *dst4 = reinterpret_cast<v4i *>(out + f * 1024) + lane;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                constexpr int HB = 1 << (L >= 7 ? L - 7 : 0); // register bit that carries a(L-1)
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 64 * j0;
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                const v4i y = {re[j0], im[j0], re[j0 | HB], im[j0 | HB]};
+                if (!partial || f * FP + (size_t)(p0 >> L) < nframes_user) __builtin_nontemporal_store(y, dst4 + pair);
+            }
+        } else if (partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if (f * FP + (size_t)((64 * j + lane) >> L) < nframes_user) dst[64 * j] = make_int2(re[j], im[j]);
@@ -306,9 +351,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FAST_OK ? 4
 bool fast1024ux_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                           int in_order, int out_order)
 {
-    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && use_fly == 1 && in_order == 0 &&
-          out_order == 0))
-        return false;
+    if (!(data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 1 && use_fly == 1)) return false;
+    if (direction == 1 && (in_order != 0 || out_order != 0)) // int_ifftNk's own beat orders (BITREV in, HALVES out) and the mixed forms, N >= 128
+        return log2n >= 7 && log2n <= 10 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2);
+    if (in_order != 0 || out_order != 0) return false;
     if (direction == 1) return log2n >= 6 && log2n <= 10;
     if (direction == 2) return log2n >= 6 && log2n <= 8; // 16 + 2 L <= 32 bits
     return false;
@@ -316,22 +362,27 @@ bool fast1024ux_supported(int log2n, int data_width, int twdl_width, int format,
 
 const char *fast1024ux_kernel_name() { return "k_fft1024ux_u32"; }
 
-template <int L, int MODE, bool FAST_OK>
+template <int L, int MODE, bool FAST_OK, bool NAT = false>
 static hipError_t launchux(const u32 *in, int2 *out, const int2 *tw, const UConsts &c, const UxArgs &a, size_t nframes,
-                           int sh, hipStream_t stream)
+                           int sh, hipStream_t stream, int native = 0)
 {
-    const size_t cap = resident_blocks(kptr(k_fft1024ux_u32<L, MODE, FAST_OK>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft1024ux_u32<L, MODE, FAST_OK, NAT>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4;
-    hipLaunchKernelGGL((k_fft1024ux_u32<L, MODE, FAST_OK>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream,
-                       in, out, tw, c, a, nframes, sh);
+    hipLaunchKernelGGL((k_fft1024ux_u32<L, MODE, FAST_OK, NAT>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream,
+                       in, out, tw, c, a, nframes, sh, native);
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launchux_l(int direction, bool fast, const u32 *in, int2 *out, const int2 *tw, const UConsts &c,
-                             const UxArgs &a, size_t nframes, int sh, hipStream_t stream)
+                             const UxArgs &a, size_t nframes, int sh, hipStream_t stream, int native)
 {
+    if constexpr (L >= 7) {
+        if (direction == 1 && native)
+            return fast ? launchux<L, UX_INV, true, true>(in, out, tw, c, a, nframes, sh, stream, native)
+                        : launchux<L, UX_INV, false, true>(in, out, tw, c, a, nframes, sh, stream, native);
+    }
     if (direction == 1)
         return fast ? launchux<L, UX_INV, true>(in, out, tw, c, a, nframes, sh, stream)
                     : launchux<L, UX_INV, false>(in, out, tw, c, a, nframes, sh, stream);
@@ -342,7 +393,7 @@ static hipError_t launchux_l(int direction, bool fast, const u32 *in, int2 *out,
 }
 
 hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a, const void *in, void *out,
-                             const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream)
+                             const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
@@ -352,11 +403,11 @@ hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a,
     const u32 *pin = static_cast<const u32 *>(in);
     int2 *pout = static_cast<int2 *>(out);
     switch (log2n) {
-    case 6: return launchux_l<6>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream);
-    case 7: return launchux_l<7>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream);
-    case 8: return launchux_l<8>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream);
-    case 9: return launchux_l<9>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream);
-    default: return launchux_l<10>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream);
+    case 6: return launchux_l<6>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream, native);
+    case 7: return launchux_l<7>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream, native);
+    case 8: return launchux_l<8>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream, native);
+    case 9: return launchux_l<9>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream, native);
+    default: return launchux_l<10>(direction, allow_fast, pin, pout, tw_all, c, a, nframes, twd - 1, stream, native);
     }
 }
 

@@ -147,7 +147,7 @@ const char *fast1024x_kernel_name();
 bool fast1024u_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                          int in_order, int out_order);
 hipError_t launch_fast1024u(int log2n, int twd, const void *in, void *out, const int2 *tw_all, const int2 *h_tw, size_t nframes,
-                            hipStream_t stream);
+                            hipStream_t stream, int native = 0); // native: bit 0 HALVES in, bit 1 BITREV out
 const char *fast1024u_kernel_name();
 
 // unscaled int32 wave kernel, inverse core and pair (intfft_fast1024ux.hip)
@@ -162,7 +162,7 @@ struct UxArgs {
 bool fast1024ux_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly,
                           int in_order, int out_order);
 hipError_t launch_fast1024ux(int log2n, int direction, int twd, const UxArgs &a, const void *in, void *out,
-                             const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream);
+                             const int2 *tw_all, const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native (inverse core): bit 0 HALVES out, bit 1 BITREV in
 const char *fast1024ux_kernel_name();
 
 // general-width int32 wave kernel, N = 64..1024 (intfft_fastw32.hip)

@@ -1342,9 +1342,11 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                    plan->h_tw.data(), batch, stream);
     if (plan->fast1024ux)
         return (int)launch_fast1024ux(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->uxargs, d_in, d_out,
-                                      plan->d_tw, plan->h_tw.data(), batch, stream);
+                                      plan->d_tw, plan->h_tw.data(), batch, stream,
+                                      (plan->p.out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.in_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast1024u)
-        return (int)launch_fast1024u(plan->p.log2n, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+        return (int)launch_fast1024u(plan->p.log2n, plan->p.twdl_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream,
+                                     (plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024x)

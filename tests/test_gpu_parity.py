@@ -719,6 +719,56 @@ def test_pair_of_dedicated_kernels_on_32_bit_words(case, monkeypatch):
         assert np.array_equal(got_c, np.concatenate([got] * 3))
 
 
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10])
+@pytest.mark.parametrize("in_order,out_order", [("HALVES", "BITREV"), ("NATURAL", "BITREV"), ("HALVES", "NATURAL")])
+def test_unscaled_wave_kernel_native_orders(log2n, in_order, out_order, monkeypatch):
+    """int_fftNk with FORMAT = 1 in its own beat orders (HALVES in / BITREV out, and the mixed forms) on k_fft1024_u32's native-order instantiation
+    (round 4): HALVES beats as 8-byte loads of register pairs, BITREV order through the wave's LDS tile in memory order.  Ragged batches (partial
+    last chunk of 2^(10-L) frames), full-scale frames (exact path), both XSER / a narrower twiddle width; against the oracle and the generic kernel."""
+    n = 1 << log2n
+    fp = 1 << (10 - log2n)
+    kw = dict(in_order=in_order, out_order=out_order)
+    for batch in (1, fp + 1, 5 * fp + 3, 300):
+        x = uniform_frames(batch, n, 15, 5100 + log2n + batch)
+        x[0] = uniform_frames(1, n, 16, 19)[0]
+        got, info = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+        assert info["kernel_name"] == "k_fft1024_u32" and info["n_passes"] == 1, info
+        assert np.array_equal(got, run_ref(x, log2n, 16, 16, 1, 0, True, **kw))
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(fp + 1, n, 16, 5200 + log2n)])
+    check(x, log2n, 16, 12, 1, 0, False, **kw)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_FAST1024U", "1")
+        got_g, info_g = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+        assert info_g["kernel_name"] != "k_fft1024_u32", info_g
+    got, _ = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+    assert np.array_equal(got, got_g)
+
+
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10])
+@pytest.mark.parametrize("in_order,out_order", [("BITREV", "HALVES"), ("NATURAL", "HALVES"), ("BITREV", "NATURAL")])
+def test_unscaled_inverse_wave_kernel_native_orders(log2n, in_order, out_order, monkeypatch):
+    """int_ifftNk with FORMAT = 1 in its own beat orders (BITREV in / HALVES out, and the mixed forms) on k_fft1024ux_u32's native-order
+    instantiation (round 4): the chunk loaded in memory order and handed to the LC lanes through the wave's LDS tile, HALVES beats as 16-byte
+    stores of L1 register pairs.  Ragged batches, full-scale frames, XSER "OLD" with narrower twiddles; against the oracle and the generic kernel."""
+    n = 1 << log2n
+    fp = 1 << (10 - log2n)
+    kw = dict(direction="INV", in_order=in_order, out_order=out_order)
+    for batch in (1, fp + 1, 5 * fp + 3, 300):
+        x = uniform_frames(batch, n, 15, 5300 + log2n + batch)
+        x[0] = uniform_frames(1, n, 16, 23)[0]
+        got, info = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+        assert info["kernel_name"] == "k_fft1024ux_u32" and info["n_passes"] == 1, info
+        assert np.array_equal(got, run_ref(x, log2n, 16, 16, 1, 0, True, **kw))
+    x = np.concatenate([edge_frames(n, 16), uniform_frames(fp + 1, n, 16, 5400 + log2n)])
+    check(x, log2n, 16, 12, 1, 0, False, **kw)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_GENERIC_ONLY", "1")
+        got_g, info_g = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    got, _ = run_gpu(x, log2n, 16, 16, 1, 0, True, **kw)
+    assert np.array_equal(got, got_g)
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
