@@ -18,10 +18,15 @@ namespace intfft {
 
 // OUT64 (L = 10, unscaled): 33 / 34-bit results, stages 1, 0 in 64 bits -- a template parameter, so that the 32-bit unscaled
 // kernel does not carry the 64-bit tail's registers (192 VGPRs with the runtime branch, two waves per SIMD)
-template <int L, int MODE, bool MASKED, bool OUT64 = false>
+// NAT (round 4): the instantiation for int_fftNk's own beat orders (`native` bit 0: HALVES in, bit 1: BITREV out; N >= 128, results within 32 bits),
+// as in intfft_fast1024u.hip: HALVES beats = one 8- / 16-byte load of the register pair (j0, j0 | 2^(L-7)); BITREV order = the core position, 16
+// consecutive ones per LC lane, through the wave's LDS tile in memory order (padded rows of 16 samples), 1 KiB per wave instruction
+template <int L, int MODE, bool MASKED, bool OUT64 = false, bool NAT = false>
 __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
-                                                     const W32Args a, size_t nframes_user)
+                                                     const W32Args a, size_t nframes_user, int native)
 {
+    static_assert(!NAT || (L >= 7 && !OUT64), "native beat orders: N >= 128, int16 / int32 results");
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     constexpr int FP = 1 << (10 - L);
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 1024 samples
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
@@ -81,7 +86,29 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
     for (size_t f = wave0; f < nframes; f += nwaves) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0
         int re[16], im[16];
-        if (a.in16) {
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L >= 7 ? L - 7 : 0); // register bit that carries a(L-1)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 64 * j0; // logical position P = p0 + lane (bit L-1 clear): frame P >> L, beat P mod N/2
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                const bool ok = !partial || f * FP + (size_t)(p0 >> L) < nframes_user;
+                if (a.in16) {
+                    typedef u32 v2u __attribute__((ext_vector_type(2)));
+                    v2u w = {0u, 0u};
+                    if (ok) w = INTFFT_LD(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + f * 1024) + lane + pair);
+                    re[j0] = (int)(w.x << a.in_sh) >> a.in_sh, im[j0] = (int)(w.x << (a.in_sh - 16)) >> a.in_sh;
+                    re[j0 | HB] = (int)(w.y << a.in_sh) >> a.in_sh, im[j0 | HB] = (int)(w.y << (a.in_sh - 16)) >> a.in_sh;
+                } else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    v4i w = {0, 0, 0, 0};
+                    if (ok) w = INTFFT_LD(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + f * 1024) + lane + pair);
+                    re[j0] = (int)((u32)w.x << a.in_sh) >> a.in_sh, im[j0] = (int)((u32)w.y << a.in_sh) >> a.in_sh;
+                    re[j0 | HB] = (int)((u32)w.z << a.in_sh) >> a.in_sh, im[j0 | HB] = (int)((u32)w.w << a.in_sh) >> a.in_sh;
+                }
+            }
+        } else if (a.in16) {
             const u32 *src = static_cast<const u32 *>(in) + f * 1024 + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -187,7 +214,46 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
         for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
 
         // ---- store ----
-        if constexpr (L < 10) {
+        if (NAT && bitrev) {
+            // position of (lane, reg r) = A(lane) | r: 16 consecutive samples per lane -> one padded row of the wave's LDS tile
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            int A = 0;
+#pragma unroll
+            for (int k = 4; k < 10; ++k) A |= ((lane >> lane_bit_u<L>(k)) & 1) << k;
+            wave_lds_fence();
+            if (a.out16) {
+                typedef u32 v4u __attribute__((ext_vector_type(4)));
+                u32 *row = lds + 20 * (A >> 4); // 16 samples = 16 dwords per row, 4 dwords of pad
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4u y;
+                    y.x = ((u32)re[4 * q] & 0xFFFFu) | ((u32)im[4 * q] << 16), y.y = ((u32)re[4 * q + 1] & 0xFFFFu) | ((u32)im[4 * q + 1] << 16);
+                    y.z = ((u32)re[4 * q + 2] & 0xFFFFu) | ((u32)im[4 * q + 2] << 16), y.w = ((u32)re[4 * q + 3] & 0xFFFFu) | ((u32)im[4 * q + 3] << 16);
+                    *reinterpret_cast<v4u *>(row + 4 * q) = y;
+                }
+                wave_lds_fence();
+                v4i *dst4 = static_cast<v4i *>(out) + f * 256;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 64 * i + lane; // 16-byte piece = samples 4 e .. 4 e + 3
+                    if (L < 10 && f * FP + (size_t)((4 * e) >> L) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 20 * (e >> 2) + 4 * (e & 3)), dst4 + e);
+                }
+            } else {
+                u32 *row = lds + 36 * (A >> 4); // 16 samples = 32 dwords per row, 4 dwords of pad
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *reinterpret_cast<v4i *>(row + 4 * q) = v4i{re[2 * q], im[2 * q], re[2 * q + 1], im[2 * q + 1]};
+                wave_lds_fence();
+                v4i *dst4 = static_cast<v4i *>(out) + f * 512;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 64 * i + lane; // 16-byte piece = samples 2 e, 2 e + 1
+                    if (L < 10 && f * FP + (size_t)((2 * e) >> L) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 36 * (e >> 3) + 4 * (e & 7)), dst4 + e);
+                }
+            }
+            wave_lds_fence();
+        } else if constexpr (L < 10) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 uswap32(re[r], re[r + 8]);
@@ -265,61 +331,72 @@ bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, in
     // N = 1024 unscaled: also 33 / 34-bit results (e.g. DATA_WIDTH = 24): only the two multiplier-free stages exceed 32 bits
     const int out_bits = data_width + format * log2n;
     const bool fits = out_bits <= 32 || (log2n == 10 && format == 1 && out_bits <= 34);
-    return log2n >= 6 && log2n <= 10 && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!(log2n >= 6 && log2n <= 10 && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 && use_fly == 1)) return false;
+    if (in_order == 0 && out_order == 0) return true;
+    // int_fftNk's own beat orders (HALVES in, BITREV out) and the mixed forms: N >= 128, results within 32 bits
+    return log2n >= 7 && out_bits <= 32 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
 }
 
 const char *fastw32_kernel_name() { return "k_fft1024_w32"; }
 
-template <int L, int MODE, bool MASKED, bool OUT64 = false>
-static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
-                          hipStream_t stream)
+template <int L, int MODE, bool MASKED, bool OUT64, bool NAT>
+static hipError_t launchw_n(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
+                            hipStream_t stream, int native)
 {
-    const size_t cap = resident_blocks(kptr(k_fft1024_w32<L, MODE, MASKED, OUT64>), 256, 2);
+    const size_t cap = resident_blocks(kptr(k_fft1024_w32<L, MODE, MASKED, OUT64, NAT>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
     const size_t need = (chunks + 3) / 4;
-    hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED, OUT64>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
-                       c, a, nframes);
+    hipLaunchKernelGGL((k_fft1024_w32<L, MODE, MASKED, OUT64, NAT>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in, out, tw,
+                       c, a, nframes, native);
     return hipGetLastError();
+}
+template <int L, int MODE, bool MASKED, bool OUT64 = false>
+static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
+                          hipStream_t stream, int native)
+{
+    if constexpr (L >= 7 && !OUT64) {
+        if (native) return launchw_n<L, MODE, MASKED, OUT64, true>(in, out, tw, c, a, nframes, stream, native);
+    }
+    return launchw_n<L, MODE, MASKED, OUT64, false>(in, out, tw, c, a, nframes, stream, 0);
 }
 
 template <int L>
 static hipError_t launchw_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
-                            size_t nframes, hipStream_t stream)
+                            size_t nframes, hipStream_t stream, int native)
 {
     if (a.masked) {
         switch (mode) {
-        case W_TRUNC: return launchw<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
-        case W_ROUND: return launchw<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
+        case W_TRUNC: return launchw<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream, native);
+        case W_ROUND: return launchw<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream, native);
         default:
             if constexpr (L == 10)
-                if (a.out64) return launchw<L, W_UNSCALED, true, true>(in, out, tw, c, a, nframes, stream);
-            return launchw<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+                if (a.out64) return launchw<L, W_UNSCALED, true, true>(in, out, tw, c, a, nframes, stream, native);
+            return launchw<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream, native);
         }
     }
     switch (mode) {
-    case W_TRUNC: return launchw<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
-    case W_ROUND: return launchw<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
+    case W_TRUNC: return launchw<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream, native);
+    case W_ROUND: return launchw<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream, native);
     default:
         if constexpr (L == 10)
-            if (a.out64) return launchw<L, W_UNSCALED, false, true>(in, out, tw, c, a, nframes, stream);
-        return launchw<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
+            if (a.out64) return launchw<L, W_UNSCALED, false, true>(in, out, tw, c, a, nframes, stream, native);
+        return launchw<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream, native);
     }
 }
 
 hipError_t launch_fastw32(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                          const int2 *h_tw, size_t nframes, hipStream_t stream)
+                          const int2 *h_tw, size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
     for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
     switch (log2n) {
-    case 6: return launchw_l<6>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 7: return launchw_l<7>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 8: return launchw_l<8>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 9: return launchw_l<9>(mode, in, out, tw_all, c, a, nframes, stream);
-    default: return launchw_l<10>(mode, in, out, tw_all, c, a, nframes, stream);
+    case 6: return launchw_l<6>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 7: return launchw_l<7>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 8: return launchw_l<8>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 9: return launchw_l<9>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    default: return launchw_l<10>(mode, in, out, tw_all, c, a, nframes, stream, native);
     }
 }
 

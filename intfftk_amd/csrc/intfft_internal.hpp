@@ -185,7 +185,7 @@ struct W32Args {
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                        int out_order);
 hipError_t launch_fastw32(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                          const int2 *h_tw, size_t nframes, hipStream_t stream);
+                          const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native: bit 0 HALVES in, bit 1 BITREV out
 const char *fastw32_kernel_name();
 // general-width int32 block kernel, N = 2048 / 4096 (intfft_fast4096w.hip)
 bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,

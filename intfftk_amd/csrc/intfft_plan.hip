@@ -1339,7 +1339,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                    d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
-                                   plan->h_tw.data(), batch, stream);
+                                   plan->h_tw.data(), batch, stream,
+                                   (plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast1024ux)
         return (int)launch_fast1024ux(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->uxargs, d_in, d_out,
                                       plan->d_tw, plan->h_tw.data(), batch, stream,
