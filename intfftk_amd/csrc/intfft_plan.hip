@@ -1327,7 +1327,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                      plan->h_tw.data(), batch, stream, plan->p.data_width);
     if (plan->w32inv)
         return (int)launch_w32inv(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
-                                  plan->h_tw.data(), batch, stream);
+                                  plan->h_tw.data(), batch, stream,
+                                  (plan->p.out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.in_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast4096w)
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream);

@@ -37,10 +37,16 @@ __device__ __forceinline__ void ground_c_dit(int (&re)[16], int (&im)[16], const
 }
 
 // ---- wave kernel, 64 <= N <= 1024 ---------------------------------------------------------------------------------------
-template <int L, int MODE, bool MASKED>
+// NAT (round 4): the instantiation for int_ifftNk's own beat orders (`native` bit 0: HALVES out, bit 1: BITREV in; N >= 128), as in
+// intfft_fast1024ux.hip: BITREV order = the core position, 16 consecutive ones per LC lane -- the chunk is loaded in memory order (1 KiB per wave
+// instruction), passed through the wave's idle LDS tile (padded rows of 16 samples) and read back one row per lane; HALVES beats = one 8- / 16-byte
+// store of the L1 register pair (j0, j0 | 2^(L-7))
+template <int L, int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
-                                                      const W32Args a, size_t nframes_user)
+                                                      const W32Args a, size_t nframes_user, int native)
 {
+    static_assert(!NAT || L >= 7, "native beat orders: N >= 128");
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     constexpr int FP = 1 << (10 - L);
     const size_t nframes = (nframes_user + FP - 1) / FP;
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 2 * 64 * ROWU];
@@ -104,7 +110,62 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
         const bool partial = L < 10 && (f + 1) * FP > nframes_user;
         int re[16], im[16];
         // ---- load X[brev_L(n)] into LC ----
-        if constexpr (L < 10) {
+        if (NAT && bitrev) {
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            int A = 0; // the index bits a9..a4 this lane carries in LC
+#pragma unroll
+            for (int k = 4; k < 10; ++k) A |= ab(k) << k;
+            if (a.in16) { // 4 B per sample: pieces of 4 samples, rows of 16 dwords 20 apart
+                const v4u *src4 = reinterpret_cast<const v4u *>(static_cast<const u32 *>(in) + f * 1024);
+                v4u x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 64 * i + lane;
+                    x[i] = v4u{0u, 0u, 0u, 0u};
+                    if (!partial || f * FP + (size_t)((4 * e) >> L) < nframes_user) x[i] = INTFFT_LD(src4 + e);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 64 * i + lane;
+                    *reinterpret_cast<v4u *>(lds + 20 * (e >> 2) + 4 * (e & 3)) = x[i];
+                }
+                wave_lds_fence();
+                const v4u *row = reinterpret_cast<const v4u *>(lds + 20 * (A >> 4));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4u y = row[q];
+                    const u32 raw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        re[4 * q + t] = (int)(raw[t] << a.in_sh) >> a.in_sh, im[4 * q + t] = (int)(raw[t] << (a.in_sh - 16)) >> a.in_sh;
+                }
+            } else { // 8 B per sample: pieces of 2 samples, rows of 32 dwords 36 apart
+                const v4u *src4 = reinterpret_cast<const v4u *>(static_cast<const int2 *>(in) + f * 1024);
+                v4u x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 64 * i + lane;
+                    x[i] = v4u{0u, 0u, 0u, 0u};
+                    if (!partial || f * FP + (size_t)((2 * e) >> L) < nframes_user) x[i] = INTFFT_LD(src4 + e);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 64 * i + lane;
+                    *reinterpret_cast<v4u *>(lds + 36 * (e >> 3) + 4 * (e & 7)) = x[i];
+                }
+                wave_lds_fence();
+                const v4u *row = reinterpret_cast<const v4u *>(lds + 36 * (A >> 4));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4u y = row[q];
+                    re[2 * q] = (int)(y.x << a.in_sh) >> a.in_sh, im[2 * q] = (int)(y.y << a.in_sh) >> a.in_sh;
+                    re[2 * q + 1] = (int)(y.z << a.in_sh) >> a.in_sh, im[2 * q + 1] = (int)(y.w << a.in_sh) >> a.in_sh;
+                }
+            }
+            wave_lds_fence();
+        } else if constexpr (L < 10) {
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
             // (the container test stays outside the unrolled loops: one batch of loads in flight, not 16 round trips)
             if (a.in16) {
@@ -223,7 +284,25 @@ __global__ __launch_bounds__(256) void k_ifft1024_w32(const void *in, void *out,
             for (int j = 0; j < 8; ++j) gfly_dit<MODE, false, MASKED>(re[j], im[j], re[j + 8], im[j + 8], w9r[j], w9i[j], a.st[9]);
         }
         // ---- store (L1 layout: natural order, coalesced) ----
-        if (a.out16) {
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L >= 7 ? L - 7 : 0); // register bit that carries a(L-1)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 64 * j0;
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                if (partial && !(f * FP + (size_t)(p0 >> L) < nframes_user)) continue;
+                if (a.out16) {
+                    typedef u32 v2u __attribute__((ext_vector_type(2)));
+                    const v2u y = {((u32)re[j0] & 0xFFFFu) | ((u32)im[j0] << 16), ((u32)re[j0 | HB] & 0xFFFFu) | ((u32)im[j0 | HB] << 16)};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2u *>(static_cast<u32 *>(out) + f * 1024) + lane + pair);
+                } else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const v4i y = {re[j0], im[j0], re[j0 | HB], im[j0 | HB]};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v4i *>(static_cast<int2 *>(out) + f * 1024) + lane + pair);
+                }
+            }
+        } else if (a.out16) {
             u32 *dst = static_cast<u32 *>(out) + f * 1024 + lane;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -401,16 +480,30 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
 bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order)
 {
-    return log2n >= 6 && log2n <= 12 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
-           twdl_width <= 26 && direction == 1 && use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!(log2n >= 6 && log2n <= 12 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 && twdl_width <= 26 && direction == 1 &&
+          use_fly == 1))
+        return false;
+    if (in_order == 0 && out_order == 0) return true;
+    // int_ifftNk's own beat orders (BITREV in, HALVES out) and the mixed forms on the wave kernel, N = 128 .. 1024
+    return log2n >= 7 && log2n <= 10 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2);
 }
 
 const char *w32inv_kernel_name(int log2n) { return log2n > 10 ? "k_ifft4096_w32" : "k_ifft1024_w32"; }
 
 template <int L, int MODE, bool MASKED>
 static hipError_t launchxi(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
-                           hipStream_t stream)
+                           hipStream_t stream, int native)
 {
+    if constexpr (L >= 7 && L <= 10) {
+        if (native) {
+            const size_t capn = resident_blocks(kptr(k_ifft1024_w32<L, MODE, MASKED, true>), 256, 2);
+            const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
+            const size_t need = (chunks + 3) / 4;
+            hipLaunchKernelGGL((k_ifft1024_w32<L, MODE, MASKED, true>), dim3((unsigned)(need < capn ? need : capn)), dim3(256), 0, stream, in, out, tw, c, a,
+                               nframes, native);
+            return hipGetLastError();
+        }
+    }
     constexpr bool BLOCK = L > 10;
     const void *kernel;
     if constexpr (BLOCK) kernel = kptr(k_ifft4096_w32<L, MODE, MASKED>);
@@ -424,44 +517,44 @@ static hipError_t launchxi(const void *in, void *out, const int2 *tw, const UCon
         const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
         const size_t need = (chunks + 3) / 4;
         hipLaunchKernelGGL((k_ifft1024_w32<L, MODE, MASKED>), dim3((unsigned)(need < cap ? need : cap)), dim3(256), 0, stream, in,
-                           out, tw, c, a, nframes);
+                           out, tw, c, a, nframes, 0);
     }
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launchxi_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
-                             size_t nframes, hipStream_t stream)
+                             size_t nframes, hipStream_t stream, int native)
 {
     if (a.masked) {
         switch (mode) {
-        case W_TRUNC: return launchxi<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
-        case W_ROUND: return launchxi<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
-        default: return launchxi<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+        case W_TRUNC: return launchxi<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream, native);
+        case W_ROUND: return launchxi<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream, native);
+        default: return launchxi<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream, native);
         }
     }
     switch (mode) {
-    case W_TRUNC: return launchxi<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
-    case W_ROUND: return launchxi<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
-    default: return launchxi<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
+    case W_TRUNC: return launchxi<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream, native);
+    case W_ROUND: return launchxi<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream, native);
+    default: return launchxi<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream, native);
     }
 }
 
 hipError_t launch_w32inv(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                         const int2 *h_tw, size_t nframes, hipStream_t stream)
+                         const int2 *h_tw, size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
     for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
     switch (log2n) {
-    case 6: return launchxi_l<6>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 7: return launchxi_l<7>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 8: return launchxi_l<8>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 9: return launchxi_l<9>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 10: return launchxi_l<10>(mode, in, out, tw_all, c, a, nframes, stream);
-    case 11: return launchxi_l<11>(mode, in, out, tw_all, c, a, nframes, stream);
-    default: return launchxi_l<12>(mode, in, out, tw_all, c, a, nframes, stream);
+    case 6: return launchxi_l<6>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 7: return launchxi_l<7>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 8: return launchxi_l<8>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 9: return launchxi_l<9>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 10: return launchxi_l<10>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    case 11: return launchxi_l<11>(mode, in, out, tw_all, c, a, nframes, stream, native);
+    default: return launchxi_l<12>(mode, in, out, tw_all, c, a, nframes, stream, native);
     }
 }
 

@@ -795,6 +795,31 @@ def test_general_width_wave_kernel_native_orders(case, in_order, out_order, monk
     assert np.array_equal(got, got_g)
 
 
+@pytest.mark.parametrize("case", [(10, 18, 16, 0, 0), (8, 24, 18, 0, 1), (7, 24, 24, 1, 0), (9, 12, 16, 0, 0), (10, 32, 24, 0, 0), (7, 14, 16, 0, 1), (9, 20, 16, 1, 0)])
+@pytest.mark.parametrize("in_order,out_order", [("BITREV", "HALVES"), ("NATURAL", "HALVES"), ("BITREV", "NATURAL")])
+def test_general_width_inverse_wave_kernel_native_orders(case, in_order, out_order, monkeypatch):
+    """int_ifftNk in its own beat orders for general widths within 32 bits (k_ifft1024_w32's native-order instantiation, round 4): int16 and
+    int32 containers on either side, the three sum / difference modes; ragged batches, edge frames; against the oracle and the generic kernel."""
+    log2n, dw, tw, fmt, rnd = case
+    monkeypatch.setenv("INTFFT_NO_NARROW16", "1")
+    n = 1 << log2n
+    fp = 1 << (10 - log2n)
+    kw = dict(direction="INV", in_order=in_order, out_order=out_order)
+    for batch in (1, 5 * fp + 3, 200):
+        x = uniform_frames(batch, n, dw, 5700 + log2n + batch + dw)
+        got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+        assert info["kernel_name"] == "k_ifft1024_w32" and info["n_passes"] == 1, info
+        assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, True, **kw))
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(fp + 1, n, dw, 5800 + log2n)])
+    check(x, log2n, dw, tw, fmt, rnd, False, **kw)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_GENERIC_ONLY", "1")
+        got_g, info_g = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    got, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+    assert np.array_equal(got, got_g)
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
