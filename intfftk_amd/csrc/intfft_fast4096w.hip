@@ -51,11 +51,16 @@ __device__ __forceinline__ void ground(int (&re)[16], int (&im)[16], const int (
 // whole last round in 64 bits).  A template parameter, not a runtime branch: the 64-bit rounds hold 64 more live dwords, and
 // compiled into the 32-bit kernel they cost it 120 spilled dwords per lane under the 128-VGPR cap of four waves per SIMD
 // (16-bit unscaled N = 4096: 139 Gsample/s).  The 64-bit variants run three waves per SIMD instead.
-template <int L, int MODE, bool MASKED, int OUT64>
+// NAT (round 4): the instantiation for int_fftNk's own beat orders (`native` bit 0: HALVES in, bit 1: BITREV out; results within 32 bits): HALVES
+// beats = one 8- / 16-byte load of the LA register pair (j0, j0 | 2^(L-9)); BITREV order = the core position, 16 consecutive ones per LC thread,
+// through the (then idle) transpose region in memory order -- padded rows of 16 samples -- 1 KiB per wave instruction
+template <int L, int MODE, bool MASKED, int OUT64, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OUT64 ? 3 : 4, OUT64 ? 3 : 4)))
 void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
-                   size_t nframes_user)
+                   size_t nframes_user, int native)
 {
+    static_assert(!NAT || OUT64 == 0, "native beat orders: int16 / int32 results");
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
     constexpr int FP = 1 << (12 - L);
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 4096 samples
@@ -120,7 +125,29 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
         // per-access 64-bit addresses and a test inside the unrolled loads cost these kernels 4-24 spilled VGPRs and serialised loads (round 4)
         unsigned tl = (unsigned)tid, lco = (unsigned)lc_off;
         asm volatile("" : "+v"(tl), "+v"(lco));
-        if (a.in16) {
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L - 9); // LA register bit that carries n(L-1)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 256 * j0; // logical position P = p0 + tid (bit L-1 clear): frame P >> L, beat P mod N/2
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                const bool ok = !partial || f * FP + (size_t)(p0 >> L) < nframes_user;
+                if (a.in16) {
+                    typedef u32 v2u __attribute__((ext_vector_type(2)));
+                    v2u w = {0u, 0u};
+                    if (ok) w = INTFFT_LD(at32(reinterpret_cast<const v2u *>(static_cast<const u32 *>(in) + f * 4096) + pair, tl));
+                    re[j0] = (int)(w.x << a.in_sh) >> a.in_sh, im[j0] = (int)(w.x << (a.in_sh - 16)) >> a.in_sh;
+                    re[j0 | HB] = (int)(w.y << a.in_sh) >> a.in_sh, im[j0 | HB] = (int)(w.y << (a.in_sh - 16)) >> a.in_sh;
+                } else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    v4i w = {0, 0, 0, 0};
+                    if (ok) w = INTFFT_LD(at32(reinterpret_cast<const v4i *>(static_cast<const int2 *>(in) + f * 4096) + pair, tl));
+                    re[j0] = (int)((u32)w.x << a.in_sh) >> a.in_sh, im[j0] = (int)((u32)w.y << a.in_sh) >> a.in_sh;
+                    re[j0 | HB] = (int)((u32)w.z << a.in_sh) >> a.in_sh, im[j0 | HB] = (int)((u32)w.w << a.in_sh) >> a.in_sh;
+                }
+            }
+        } else if (a.in16) {
             const u32 *src = static_cast<const u32 *>(in) + f * 4096; // wave-uniform
             u32 raw[16];
             if (!partial) {
@@ -220,7 +247,46 @@ void k_fft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, cons
 #pragma unroll
         for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
 
-        if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+        if (NAT && bitrev) {
+            // position of (thread, reg r) = A(tid) | r: 16 consecutive samples per thread -> one padded row of the transpose region (free here:
+            // the last transpose_read ends with a barrier)
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            int A = 0;
+#pragma unroll
+            for (int k = 4; k < 12; ++k) A |= ((tid >> lcw_bit<L>(k)) & 1) << k;
+            if (a.out16) {
+                typedef u32 v4u __attribute__((ext_vector_type(4)));
+                u32 *row = lds + 20 * (A >> 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4u y;
+                    y.x = ((u32)re[4 * q] & 0xFFFFu) | ((u32)im[4 * q] << 16), y.y = ((u32)re[4 * q + 1] & 0xFFFFu) | ((u32)im[4 * q + 1] << 16);
+                    y.z = ((u32)re[4 * q + 2] & 0xFFFFu) | ((u32)im[4 * q + 2] << 16), y.w = ((u32)re[4 * q + 3] & 0xFFFFu) | ((u32)im[4 * q + 3] << 16);
+                    *reinterpret_cast<v4u *>(row + 4 * q) = y;
+                }
+                __syncthreads();
+                v4i *dst4 = static_cast<v4i *>(out) + f * 1024; // wave-uniform (4096 samples x 4 B)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 256 * i + tid; // 16-byte piece = samples 4 e .. 4 e + 3
+                    if (partial && f * FP + (size_t)((4 * e) >> L) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 20 * (e >> 2) + 4 * (e & 3)), at32(dst4 + 256 * i, tl));
+                }
+            } else {
+                u32 *row = lds + 36 * (A >> 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *reinterpret_cast<v4i *>(row + 4 * q) = v4i{re[2 * q], im[2 * q], re[2 * q + 1], im[2 * q + 1]};
+                __syncthreads();
+                v4i *dst4 = static_cast<v4i *>(out) + f * 2048; // wave-uniform (4096 samples x 8 B)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 256 * i + tid; // 16-byte piece = samples 2 e, 2 e + 1
+                    if (partial && f * FP + (size_t)((2 * e) >> L) >= nframes_user) continue;
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4i *>(lds + 36 * (e >> 3) + 4 * (e & 7)), at32(dst4 + 256 * i, tl));
+                }
+            }
+            __syncthreads(); // the region is rewritten by the next frame's transposes
+        } else if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
             if (a.out16) {
                 u32 *dst = static_cast<u32 *>(out) + f * 4096; // wave-uniform
 #pragma unroll
@@ -245,56 +311,66 @@ bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, 
     const int out_bits = data_width + format * log2n; // unscaled: 33 / 34-bit results through the 64-bit tail stages,
     // up to 40 bits with the whole last round in 64 bits as long as STAGE 4 still fits 32 (e.g. 24-bit data: 35 / 36-bit results)
     const bool fits = out_bits <= 32 || (format == 1 && out_bits <= 34) || (format == 1 && data_width + log2n - 4 <= 32 && out_bits <= 40);
-    return (log2n == 11 || log2n == 12) && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!((log2n == 11 || log2n == 12) && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 && use_fly == 1)) return false;
+    if (in_order == 0 && out_order == 0) return true;
+    // int_fftNk's own beat orders (HALVES in, BITREV out) and the mixed forms: results within 32 bits
+    return out_bits <= 32 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
 }
 
 const char *fast4096w_kernel_name() { return "k_fft4096_w32"; }
 
 template <int L, int MODE, bool MASKED, int OUT64 = 0>
 static hipError_t launch4w(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
-                           hipStream_t stream)
+                           hipStream_t stream, int native)
 {
-    const size_t cap = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED, OUT64>), 256, 2);
     const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
+    if constexpr (OUT64 == 0) {
+        if (native) {
+            const size_t capn = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED, OUT64, true>), 256, 2);
+            hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED, OUT64, true>), dim3((unsigned)(chunks < capn ? chunks : capn)), dim3(256), 0, stream, in, out,
+                               tw, c, a, nframes, native);
+            return hipGetLastError();
+        }
+    }
+    const size_t cap = resident_blocks(kptr(k_fft4096_w32<L, MODE, MASKED, OUT64>), 256, 2);
     hipLaunchKernelGGL((k_fft4096_w32<L, MODE, MASKED, OUT64>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream, in, out,
-                       tw, c, a, nframes);
+                       tw, c, a, nframes, 0);
     return hipGetLastError();
 }
 
 template <int L>
 static hipError_t launch4w_l(int mode, const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a,
-                             size_t nframes, hipStream_t stream)
+                             size_t nframes, hipStream_t stream, int native)
 {
     if (a.masked) {
         switch (mode) {
-        case W_TRUNC: return launch4w<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream);
-        case W_ROUND: return launch4w<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream);
+        case W_TRUNC: return launch4w<L, W_TRUNC, true>(in, out, tw, c, a, nframes, stream, native);
+        case W_ROUND: return launch4w<L, W_ROUND, true>(in, out, tw, c, a, nframes, stream, native);
         default:
-            return a.out64 == 2   ? launch4w<L, W_UNSCALED, true, 2>(in, out, tw, c, a, nframes, stream)
-                   : a.out64 == 1 ? launch4w<L, W_UNSCALED, true, 1>(in, out, tw, c, a, nframes, stream)
-                                  : launch4w<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream);
+            return a.out64 == 2   ? launch4w<L, W_UNSCALED, true, 2>(in, out, tw, c, a, nframes, stream, native)
+                   : a.out64 == 1 ? launch4w<L, W_UNSCALED, true, 1>(in, out, tw, c, a, nframes, stream, native)
+                                  : launch4w<L, W_UNSCALED, true>(in, out, tw, c, a, nframes, stream, native);
         }
     }
     switch (mode) {
-    case W_TRUNC: return launch4w<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream);
-    case W_ROUND: return launch4w<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream);
+    case W_TRUNC: return launch4w<L, W_TRUNC, false>(in, out, tw, c, a, nframes, stream, native);
+    case W_ROUND: return launch4w<L, W_ROUND, false>(in, out, tw, c, a, nframes, stream, native);
     default:
-        return a.out64 == 2   ? launch4w<L, W_UNSCALED, false, 2>(in, out, tw, c, a, nframes, stream)
-               : a.out64 == 1 ? launch4w<L, W_UNSCALED, false, 1>(in, out, tw, c, a, nframes, stream)
-                              : launch4w<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream);
+        return a.out64 == 2   ? launch4w<L, W_UNSCALED, false, 2>(in, out, tw, c, a, nframes, stream, native)
+               : a.out64 == 1 ? launch4w<L, W_UNSCALED, false, 1>(in, out, tw, c, a, nframes, stream, native)
+                              : launch4w<L, W_UNSCALED, false>(in, out, tw, c, a, nframes, stream, native);
     }
 }
 
 hipError_t launch_fast4096w(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                            const int2 *h_tw, size_t nframes, hipStream_t stream)
+                            const int2 *h_tw, size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
     for (int k = 0; k < 8; ++k) c.wr3[k] = h_tw[7 + k].x, c.wi3[k] = h_tw[7 + k].y;
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
-    return log2n == 11 ? launch4w_l<11>(mode, in, out, tw_all, c, a, nframes, stream)
-                       : launch4w_l<12>(mode, in, out, tw_all, c, a, nframes, stream);
+    return log2n == 11 ? launch4w_l<11>(mode, in, out, tw_all, c, a, nframes, stream, native)
+                       : launch4w_l<12>(mode, in, out, tw_all, c, a, nframes, stream, native);
 }
 
 } // namespace intfft

@@ -191,7 +191,7 @@ const char *fastw32_kernel_name();
 bool fast4096w_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                          int out_order);
 hipError_t launch_fast4096w(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                            const int2 *h_tw, size_t nframes, hipStream_t stream);
+                            const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native: bit 0 HALVES in, bit 1 BITREV out
 const char *fast4096w_kernel_name();
 // general-width inverse kernels, N = 64..4096 (intfft_w32inv.hip)
 bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,

@@ -1331,7 +1331,8 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
                                   (plan->p.out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.in_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fast4096w)
         return (int)launch_fast4096w(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
-                                     plan->h_tw.data(), batch, stream);
+                                     plan->h_tw.data(), batch, stream,
+                                     (plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fastw64b)
         return (int)launch_fastw64b(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb,
                                     plan->p.data_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
