@@ -197,7 +197,7 @@ const char *fast4096w_kernel_name();
 bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order);
 hipError_t launch_w32inv(int log2n, int mode, const W32Args &a, const void *in, void *out, const int2 *tw_all,
-                         const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native: bit 0 HALVES out, bit 1 BITREV in (wave kernel)
+                         const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native: bit 0 HALVES out, bit 1 BITREV in
 const char *w32inv_kernel_name(int log2n);
 // general-width three-pass kernels, N = 2^13 .. 2^16 (intfft_bigw.hip)
 bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,

@@ -345,11 +345,14 @@ __device__ __forceinline__ void ground_dit(int (&re)[16], int (&im)[16], const i
     }
 }
 
-template <int L, int MODE, bool MASKED>
+// NAT (round 4): int_ifftNk's own beat orders (`native` bit 0: HALVES out, bit 1: BITREV in): the chunk loaded in memory order and handed to the LC
+// threads (16 consecutive core positions each) through padded rows of the transpose region; HALVES beats as 8- / 16-byte stores of LA register pairs
+template <int L, int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c, const W32Args a,
-                    size_t nframes_user)
+                    size_t nframes_user, int native)
 {
+    const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
     constexpr int FP = 1 << (12 - L);
     const size_t nframes = (nframes_user + FP - 1) / FP;
@@ -422,7 +425,60 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
         const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
         int re[16], im[16];
         // LC: X[brev_L(n)] of the thread's frame (container test outside the unrolled loops)
-        if (a.in16) {
+        if (NAT && bitrev) {
+            typedef u32 v4u __attribute__((ext_vector_type(4)));
+            int A = 0; // the index bits n11..n4 this thread carries in LC
+#pragma unroll
+            for (int k = 4; k < 12; ++k) A |= nb(k) << k;
+            if (a.in16) {
+                const v4u *src4 = reinterpret_cast<const v4u *>(static_cast<const u32 *>(in) + f * 4096);
+                v4u x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 256 * i + tid; // samples 4 e .. 4 e + 3
+                    x[i] = v4u{0u, 0u, 0u, 0u};
+                    if (!partial || f * FP + (size_t)((4 * e) >> L) < nframes_user) x[i] = INTFFT_LD(src4 + e);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = 256 * i + tid;
+                    *reinterpret_cast<v4u *>(lds + 20 * (e >> 2) + 4 * (e & 3)) = x[i];
+                }
+                __syncthreads();
+                const v4u *row = reinterpret_cast<const v4u *>(lds + 20 * (A >> 4));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4u y = row[q];
+                    const u32 raw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        re[4 * q + t] = (int)(raw[t] << a.in_sh) >> a.in_sh, im[4 * q + t] = (int)(raw[t] << (a.in_sh - 16)) >> a.in_sh;
+                }
+            } else {
+                const v4u *src4 = reinterpret_cast<const v4u *>(static_cast<const int2 *>(in) + f * 4096);
+                v4u x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 256 * i + tid; // samples 2 e, 2 e + 1
+                    x[i] = v4u{0u, 0u, 0u, 0u};
+                    if (!partial || f * FP + (size_t)((2 * e) >> L) < nframes_user) x[i] = INTFFT_LD(src4 + e);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 256 * i + tid;
+                    *reinterpret_cast<v4u *>(lds + 36 * (e >> 3) + 4 * (e & 7)) = x[i];
+                }
+                __syncthreads();
+                const v4u *row = reinterpret_cast<const v4u *>(lds + 36 * (A >> 4));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v4u y = row[q];
+                    re[2 * q] = (int)(y.x << a.in_sh) >> a.in_sh, im[2 * q] = (int)(y.y << a.in_sh) >> a.in_sh;
+                    re[2 * q + 1] = (int)(y.z << a.in_sh) >> a.in_sh, im[2 * q + 1] = (int)(y.w << a.in_sh) >> a.in_sh;
+                }
+            }
+            __syncthreads(); // the region takes the LC -> LB rows next
+        } else if (a.in16) {
             const u32 *src = static_cast<const u32 *>(in) + f * 4096 + lc_off;
             u32 raw[16];
 #pragma unroll
@@ -458,7 +514,25 @@ void k_ifft4096_w32(const void *in, void *out, const int2 *__restrict__ twt, con
         }
         transpose_read(re, im); // LA: regs = n11..8, thread = n7..0
         ground_dit<MODE, MASKED, L, 8>(re, im, a8r, a8i, a4r, a4i, a2r, a2i, a1r, a1i, a);
-        if (a.out16) {
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L - 9); // LA register bit that carries n(L-1)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB);
+                const int p0 = 256 * j0;
+                const int pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                if (partial && !(f * FP + (size_t)(p0 >> L) < nframes_user)) continue;
+                if (a.out16) {
+                    typedef u32 v2u __attribute__((ext_vector_type(2)));
+                    const v2u y = {((u32)re[j0] & 0xFFFFu) | ((u32)im[j0] << 16), ((u32)re[j0 | HB] & 0xFFFFu) | ((u32)im[j0 | HB] << 16)};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v2u *>(static_cast<u32 *>(out) + f * 4096) + tid + pair);
+                } else {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const v4i y = {re[j0], im[j0], re[j0 | HB], im[j0 | HB]};
+                    __builtin_nontemporal_store(y, reinterpret_cast<v4i *>(static_cast<int2 *>(out) + f * 4096) + tid + pair);
+                }
+            }
+        } else if (a.out16) {
             u32 *dst = static_cast<u32 *>(out) + f * 4096 + tid;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -484,8 +558,8 @@ bool w32inv_supported(int log2n, int data_width, int twdl_width, int format, int
           use_fly == 1))
         return false;
     if (in_order == 0 && out_order == 0) return true;
-    // int_ifftNk's own beat orders (BITREV in, HALVES out) and the mixed forms on the wave kernel, N = 128 .. 1024
-    return log2n >= 7 && log2n <= 10 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2);
+    // int_ifftNk's own beat orders (BITREV in, HALVES out) and the mixed forms, N = 128 .. 4096
+    return log2n >= 7 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2);
 }
 
 const char *w32inv_kernel_name(int log2n) { return log2n > 10 ? "k_ifft4096_w32" : "k_ifft1024_w32"; }
@@ -494,6 +568,15 @@ template <int L, int MODE, bool MASKED>
 static hipError_t launchxi(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                            hipStream_t stream, int native)
 {
+    if constexpr (L > 10) {
+        if (native) {
+            const size_t capn = resident_blocks(kptr(k_ifft4096_w32<L, MODE, MASKED, true>), 256, 2);
+            const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
+            hipLaunchKernelGGL((k_ifft4096_w32<L, MODE, MASKED, true>), dim3((unsigned)(chunks < capn ? chunks : capn)), dim3(256), 0, stream, in, out, tw, c,
+                               a, nframes, native);
+            return hipGetLastError();
+        }
+    }
     if constexpr (L >= 7 && L <= 10) {
         if (native) {
             const size_t capn = resident_blocks(kptr(k_ifft1024_w32<L, MODE, MASKED, true>), 256, 2);
@@ -512,7 +595,7 @@ static hipError_t launchxi(const void *in, void *out, const int2 *tw, const UCon
     if constexpr (BLOCK) {
         const size_t chunks = (nframes + ((size_t)1 << (12 - L)) - 1) >> (12 - L);
         hipLaunchKernelGGL((k_ifft4096_w32<L, MODE, MASKED>), dim3((unsigned)(chunks < cap ? chunks : cap)), dim3(256), 0, stream,
-                           in, out, tw, c, a, nframes);
+                           in, out, tw, c, a, nframes, 0);
     } else {
         const size_t chunks = (nframes + ((size_t)1 << (10 - L)) - 1) >> (10 - L);
         const size_t need = (chunks + 3) / 4;

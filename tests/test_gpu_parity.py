@@ -845,6 +845,30 @@ def test_general_width_block_kernel_native_orders(case, in_order, out_order, mon
     assert np.array_equal(got, got_g)
 
 
+@pytest.mark.parametrize("case", [(12, 16, 16, 1, 0), (11, 16, 16, 1, 0), (12, 18, 16, 0, 0), (11, 24, 24, 0, 1), (12, 12, 16, 0, 0), (12, 20, 18, 1, 0), (11, 32, 16, 0, 0)])
+@pytest.mark.parametrize("in_order,out_order", [("BITREV", "HALVES"), ("NATURAL", "HALVES"), ("BITREV", "NATURAL")])
+def test_general_width_inverse_block_kernel_native_orders(case, in_order, out_order, monkeypatch):
+    """int_ifftNk in its own beat orders at N = 2048 / 4096 for general widths within 32 bits (k_ifft4096_w32's native-order instantiation, round 4);
+    ragged batches, edge frames; against the oracle and the generic kernel."""
+    log2n, dw, tw, fmt, rnd = case
+    monkeypatch.setenv("INTFFT_NO_NARROW16", "1")
+    n = 1 << log2n
+    kw = dict(direction="INV", in_order=in_order, out_order=out_order)
+    for batch in (1, 3, 70):
+        x = uniform_frames(batch, n, dw, 6100 + log2n + batch + dw)
+        got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+        assert info["kernel_name"] == "k_ifft4096_w32" and info["n_passes"] == 1, info
+        assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, True, **kw))
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(3, n, dw, 6200 + log2n)])
+    check(x, log2n, dw, tw, fmt, rnd, False, **kw)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_GENERIC_ONLY", "1")
+        got_g, info_g = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+        assert info_g["kernel_name"].startswith("k_pass"), info_g
+    got, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, True, **kw)
+    assert np.array_equal(got, got_g)
+
+
 def test_config1_chirp_frame():
     x = (chirp_frame(1024) * 64)[None]
     check(x, 10, 16, 16, 0, 0, True)
