@@ -25,7 +25,7 @@ template <int L, int MODE, bool MASKED, bool OUT64 = false, bool NAT = false>
 __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, const int2 *__restrict__ twt, const UConsts c,
                                                      const W32Args a, size_t nframes_user, int native)
 {
-    static_assert(!NAT || (L >= 7 && !OUT64), "native beat orders: N >= 128, int16 / int32 results");
+    static_assert(!NAT || L >= 7, "native beat orders: N >= 128");
     const bool halves = NAT && (native & 1), bitrev = NAT && (native & 2);
     constexpr int FP = 1 << (10 - L);
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 1024 samples
@@ -196,6 +196,31 @@ __global__ __launch_bounds__(256) void k_fft1024_w32(const void *in, void *out, 
             long long xr[16], xi[16];
             tail64_unscaled(re, im, xr, xi);
             typedef long long v2l __attribute__((ext_vector_type(2)));
+            if (NAT && bitrev) {
+                // 16 B per sample: the 16 KiB chunk goes through the 10 KiB tile in two halves (a9 = 0, then a9 = 1: a lane's 16 consecutive positions
+                // share a9); rows of 16 samples = 64 dwords, 68 apart
+                int A = 0;
+#pragma unroll
+                for (int k = 4; k < 10; ++k) A |= ((lane >> lane_bit_u<L>(k)) & 1) << k;
+                v2l *dst2 = reinterpret_cast<v2l *>(out) + f * 1024;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    wave_lds_fence();
+                    if ((A >> 9) == h) {
+                        v2l *row = reinterpret_cast<v2l *>(lds + 68 * ((A >> 4) & 31));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) row[r] = v2l{xr[r], xi[r]};
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int e = 64 * i + lane; // sample e of this half
+                        __builtin_nontemporal_store(*reinterpret_cast<const v2l *>(lds + 68 * (e >> 4) + 4 * (e & 15)), dst2 + 512 * h + e);
+                    }
+                }
+                wave_lds_fence();
+                continue;
+            }
             v2l *dst = reinterpret_cast<v2l *>(out) + f * 1024 + lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -333,8 +358,8 @@ bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, in
     const bool fits = out_bits <= 32 || (log2n == 10 && format == 1 && out_bits <= 34);
     if (!(log2n >= 6 && log2n <= 10 && data_width >= 2 && fits && twdl_width >= 4 && twdl_width <= 26 && direction == 0 && use_fly == 1)) return false;
     if (in_order == 0 && out_order == 0) return true;
-    // int_fftNk's own beat orders (HALVES in, BITREV out) and the mixed forms: N >= 128, results within 32 bits
-    return log2n >= 7 && out_bits <= 32 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
+    // int_fftNk's own beat orders (HALVES in, BITREV out) and the mixed forms: N >= 128
+    return log2n >= 7 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
 }
 
 const char *fastw32_kernel_name() { return "k_fft1024_w32"; }
@@ -354,7 +379,7 @@ template <int L, int MODE, bool MASKED, bool OUT64 = false>
 static hipError_t launchw(const void *in, void *out, const int2 *tw, const UConsts &c, const W32Args &a, size_t nframes,
                           hipStream_t stream, int native)
 {
-    if constexpr (L >= 7 && !OUT64) {
+    if constexpr (L >= 7) {
         if (native) return launchw_n<L, MODE, MASKED, OUT64, true>(in, out, tw, c, a, nframes, stream, native);
     }
     return launchw_n<L, MODE, MASKED, OUT64, false>(in, out, tw, c, a, nframes, stream, 0);

@@ -769,7 +769,8 @@ def test_unscaled_inverse_wave_kernel_native_orders(log2n, in_order, out_order, 
     assert np.array_equal(got, got_g)
 
 
-@pytest.mark.parametrize("case", [(10, 18, 16, 0, 0), (8, 24, 18, 0, 1), (7, 24, 24, 1, 0), (9, 12, 16, 0, 0), (10, 32, 24, 0, 0), (7, 14, 16, 0, 1), (9, 20, 16, 1, 0)])
+@pytest.mark.parametrize("case", [(10, 18, 16, 0, 0), (8, 24, 18, 0, 1), (7, 24, 24, 1, 0), (9, 12, 16, 0, 0), (10, 32, 24, 0, 0), (7, 14, 16, 0, 1), (9, 20, 16, 1, 0),
+                                  (10, 24, 24, 1, 0), (10, 23, 16, 1, 0)])  # the last two: 34- / 33-bit results in int64 containers (the 64-bit tail stages)
 @pytest.mark.parametrize("in_order,out_order", [("HALVES", "BITREV"), ("NATURAL", "BITREV"), ("HALVES", "NATURAL")])
 def test_general_width_wave_kernel_native_orders(case, in_order, out_order, monkeypatch):
     """int_fftNk in its own beat orders for general widths within 32 bits (k_fft1024_w32's native-order instantiation, round 4): int16 and int32
