@@ -111,8 +111,10 @@ def pmc_digest(config="C2"):
 
 
 # ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
-def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0):
-    """Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
+def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0, quick=False):
+    """(quick: one form -- the stream form -- on all host threads over a smaller fixed sample, one timed pass after the warm one; the
+    compact baseline / parity gate of the `other_configs` sub-records.)
+    Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
     to run) and uses the all-core passes as parity gates for the GPU output of those frames.  Headline entry (`value`): the
     FASTER of the two forms on all host threads -- the stream form (the literal dataflow of math/fn_radix2.m: half-split
     lanes, per-stage butterflies, fn_rev2rdx commutation) or the flat in-place form; `form` says which.  Both forms are
@@ -143,6 +145,11 @@ def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0):
             best = dt if best is None else min(best, dt)
         return frames, frames * n / best / 1e9, ref
 
+    if quick:
+        f_q, v_q, ref_q = timed(8192 * scale // work, 0, threads, reps=1)
+        return {"value": v_q, "unit": "Gsample/s", "cores": threads, "kind": "port", "form": "stream",
+                "sample": "first %d frames of the same workload, stream form, OpenMP over frames, one timed pass after a warm one" % f_q,
+                "parity_checked_frames": f_q, "parity_ok": bool(np.array_equal(y_dev[:f_q].cpu().numpy(), ref_q))}
     # fixed sample sizes: ~10-20 s of CPU thread-time in total on a 128-thread host
     f_sall, v_sall, ref_s = timed(32768 * scale // work, 0, threads)
     parity_stream = bool(np.array_equal(y_dev[:f_sall].cpu().numpy(), ref_s))
@@ -272,6 +279,75 @@ def valu_rates(torch, L, stream, digest, c2, samples_per_call, out):
     return out
 
 
+# ---- BASELINE's other configurations on the driver's clock (default single-GPU run) --------------------------------
+def other_config(torch, name, steps, warmup, dev_index, slow_rate, cpu=True):
+    """One sub-record of `other_configs`: `steps` calls of the C3 / C4 / C5 plan in THIS process, timed like the headline (wall clock
+    between synchronisations = `ms_per_step`, HIP events on the launch stream = `kernel_ms`), the roofline fields of `--config <name>`
+    (bounds from the committed PMC digest of the same plan and the slow-class VALU issue rate measured in this run), and the oracle
+    on a bounded prefix of the same input as CPU baseline and parity gate.  Buffers are freed before returning (C4: 8 GiB)."""
+    from intfftk_amd import int_fft_ifft_pair, int_fft_single_path
+
+    log2n, direction, batch, seed, workload = CONFIGS[name]
+    dw, tw, fmt, bps, line_dtype, metric = GENERICS[name]
+    n = 1 << log2n
+    ctor = int_fft_single_path if direction == "FWD" else int_fft_ifft_pair
+    core = ctor(NFFT=log2n, DATA_WIDTH=dw, TWDL_WIDTH=tw, FORMAT=fmt, RNDMODE=0, device=dev_index)
+    x = make_input(batch, n, seed, 0, dw=dw)
+    y = torch.empty(core.out_shape(batch), device=x.device, dtype=core.out_dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+    in_ptr, out_ptr = x.data_ptr(), y.data_ptr()
+    step = lambda: core.exec_raw(in_ptr, out_ptr, batch, stream)  # noqa: E731
+    step()
+    torch.cuda.synchronize()
+    ramp = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.4:  # untimed clock ramp (the CPU legs before this leave the GPU idle), then W warm-up steps
+        for _ in range(5):
+            step()
+        ramp += 5
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / steps
+    alg_bytes = float(bps) * batch * n
+    here = batch * n / kern_ms / 1e6
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    digest_path, digest = pmc_digest(name)
+    same = bool(digest) and digest.get("digest_batch") in (None, batch)
+    traffic = float(digest["hbm_bytes_per_launch"]) if same else None
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "frac_hbm": achieved / HBM_PEAK_GBS, "traffic": traffic,
+         "traffic_source": ("%s (static)" % digest_path) if traffic else None, "algorithmic_bytes_per_step": alg_bytes}
+    bounds = {"hbm": HBM_PEAK_GBS / bps}
+    if traffic:
+        bounds["hbm_pass_traffic"] = HBM_PEAK_GBS / (traffic / (float(batch) * n))
+        r["frac_hbm_pass_traffic"] = here / bounds["hbm_pass_traffic"]
+        r["traffic_over_algorithmic"] = traffic / alg_bytes
+    if same and slow_rate and digest.get("valu_insts_per_call"):
+        bounds["valu"] = slow_rate / float(digest["valu_insts_per_call"]) * float(batch) * n / 1e9
+        r["frac_valu"] = here / bounds["valu"]
+        r["bound"] = "valu" if bounds["valu"] < min(v for k, v in bounds.items() if k != "valu") else "hbm"
+    r["bounds_Gsample_per_s"] = bounds
+    out = {"workload": "%s, batch=%d" % (workload, batch), "metric": metric, "dtype": line_dtype, "value": batch * n * steps / wall / 1e9,
+           "unit": "Gsample/s", "steps": steps, "warmup": warmup, "clock_ramp_steps": ramp, "ms_per_step": wall / steps * 1e3,
+           "kernel_ms": kern_ms, "kernel": core.info["kernel_name"], "launches_per_step": core.info["n_passes"], "roofline": r}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction, dw, tw, fmt, quick=True)
+    core.close()
+    del x, y, core
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---- self-spawn: `python bench.py --gpus N` without a launcher -----------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -309,6 +385,8 @@ def main():
                          "rank 0, so that the N = 1 line of a scaling run is the single-GPU bench line exactly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the section-8(d) side figures (profiling runs)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the C3 / C4 / C5 sub-records the default single-GPU C2 run appends as `other_configs`")
     ap.add_argument("--prewarm", type=int, default=400,
                     help="untimed clock-ramp launches before the W warmup steps (the GPU needs ~300 "
                          "back-to-back launches to reach its steady shader clock; see DESIGN.md)")
@@ -551,6 +629,20 @@ def main():
             step()
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction, dw, tw, fmt)
+        if world == 1 and args.config == "C2" and not args.batch and not args.no_other_configs and not args.no_extras:
+            # BASELINE's other configurations, timed in this process after everything that belongs to the headline (the headline fields
+            # above are complete and unchanged); LAST key of the line, so that a tail of it shows the three sub-records
+            slow = out.get("valu_bound", {}).get("slow_class_wave_insts_per_s")
+            del x, y
+            torch.cuda.empty_cache()
+            oc = {}
+            for name in ("C3", "C4", "C5"):
+                try:
+                    oc[name] = other_config(torch, name, args.steps, args.warmup, dev_index, slow, cpu=not args.no_cpu_baseline)
+                except Exception as exc:  # a sub-record must never cost the headline line
+                    oc[name] = {"error": repr(exc)}
+                    torch.cuda.empty_cache()
+            out["other_configs"] = oc
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

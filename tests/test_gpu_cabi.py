@@ -348,6 +348,26 @@ def test_bench_single_gpu_line_has_the_8d_fields():
     assert c4["config"]["n"] == 1 << 20 and c4["config"]["kernel"] == "k_big2x_a/k_big2x_b" and c4["cpu_baseline"]["parity_ok"] is True
 
 
+def test_bench_default_line_carries_other_configs():
+    """The driver's single-GPU command (BASELINE's batches, no --batch): the headline fields as before, and as the LAST key the
+    `other_configs` sub-records -- C3, C4, C5 timed in the same process, each with value / ms_per_step / kernel_ms / roofline
+    {bound, frac_hbm, frac_valu, frac_hbm_pass_traffic, traffic} and the oracle on a prefix as parity gate."""
+    out = _bench(["--steps", "5", "--warmup", "2", "--prewarm", "50"])
+    assert out["n_gpus"] == 1 and out["config"]["batch_per_gpu"] == 65536 and out["cpu_baseline"]["parity_ok"] is True
+    assert list(out)[-1] == "other_configs" and sorted(out["other_configs"]) == ["C3", "C4", "C5"]
+    want_n = {"C3": 65536, "C4": 1 << 20, "C5": 4096}
+    for name, rec in out["other_configs"].items():
+        assert "error" not in rec, (name, rec)
+        assert ("N=%d" % want_n[name] in rec["workload"]) or ("N=2^20" in rec["workload"])
+        assert rec["steps"] == 5 and rec["value"] > 0 and rec["kernel_ms"] > 0 and rec["ms_per_step"] >= 0.9 * rec["kernel_ms"]
+        r = rec["roofline"]
+        for key in ("bound", "frac", "frac_hbm", "frac_valu", "frac_hbm_pass_traffic", "traffic"):
+            assert key in r, (name, key)
+        assert r["bound"] in ("hbm", "valu") and 0 < r["frac"] < 1 and r["traffic"] >= r["algorithmic_bytes_per_step"]
+        assert rec["cpu_baseline"]["parity_ok"] is True and rec["cpu_baseline"]["parity_checked_frames"] >= 8
+    assert out["other_configs"]["C4"]["kernel"] == "k_big2x_a/k_big2x_b" and out["other_configs"]["C3"]["launches_per_step"] == 2
+
+
 def test_bench_under_the_drivers_launcher():
     """The driver's form for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE from the environment, ONE JSON line from rank 0."""
