@@ -32,6 +32,8 @@ extern "C" {
 #define INTFFT_ERR_NULL        (-3) /* NULL argument                                                  */
 #define INTFFT_ERR_NO_DEVICE   (-4) /* no HIP device / wrong device index -- there is NO CPU fallback */
 #define INTFFT_ERR_ALLOC       (-5) /* host allocation failed                                         */
+#define INTFFT_ERR_TRANSPORT   (-6) /* intfft_shard_set_transport / intfft_exec_sharded: RCCL cannot be loaded, two
+                                       plans of the set share a device, or an RCCL call failed          */
 
 /* direction: which core(s) a frame goes through */
 #define INTFFT_FWD  0 /* int_fftNk  : radix-2 DIF forward  (int_fftNk.vhd:72)                     */
@@ -83,7 +85,7 @@ typedef struct intfft_plan_info {
     int32_t compute_word;                /* bytes of the on-chip word (2 = packed int16 kernels)   */
     int32_t fast_path;                   /* 1 if a single dedicated kernel serves this plan        */
     int32_t reserved;
-    uint64_t scratch_bytes;              /* plan-owned device scratch                              */
+    uint64_t scratch_bytes;              /* plan-owned device scratch (0 after intfft_plan_release_scratch) */
     char kernel_name[64];                /* dominant kernel symbol (for rocprof matching)          */
 } intfft_plan_info;
 
@@ -120,18 +122,42 @@ int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 
 /* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
- * (see intfft_io_widths), aligned to one complex sample (2 containers); nothing outside the output array is written and the loads of absent frames of a partial last group are predicated
+ * (see intfft_io_widths), aligned to one complex sample (2 containers: 4 bytes for int16 pairs) -- the dedicated kernels then issue 8- and
+ * 16-byte vector accesses on addresses that are only sample-aligned, which is legal in the unaligned-access mode HIP runs gfx950 in
+ * (SH_MEM_CONFIG.alignment_mode = unaligned, the ROCm default; tests/test_gpu_cabi.py shifts every kernel family's buffers by one sample);
+ * buffers from hipMalloc are 256-byte aligned and need no thought; nothing outside the output array is written and the loads of absent frames of a partial last group are predicated
  * (tests/test_gpu_cabi.py::test_no_writes_outside_the_output_buffer: guard bands, ragged batches, buffers one sample off a 64 KiB boundary).
  * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
  * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
  * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
  * (kernel, device) on first use, under a mutex);
  * a plan WITHOUT plan-owned scratch (intfft_plan_info.scratch_bytes == 0: every single-launch plan) holds no mutable state and may be executed on any
- * number of streams at once; a plan that owns scratch (the multi-pass plans) must not be executed concurrently on two streams -- create one plan per
- * stream for those.  Some multi-pass plans (N = 2^19 / 2^20 forward and inverse, the
- * 24-bit unscaled class, the tiled 2-D plans) run the scratch-sized chunks of a large batch alternately on `hip_stream` and on a plan-owned side stream
- * (event fork at entry, event join before returning): towards the caller the call is still ordered on `hip_stream` only. */
+ * number of streams at once; a plan that owns scratch (the multi-pass plans) must not be executed concurrently on two streams THROUGH THIS ENTRY POINT --
+ * use intfft_exec_ws below with one workspace per stream (or one plan per stream).  Some multi-pass plans (N = 2^19 / 2^20 forward and inverse, the
+ * 24-bit unscaled class, the tiled 2-D plans) run the scratch-sized chunks of a large batch alternately on `hip_stream` and on a side stream taken from
+ * a pool inside the plan for the duration of the call (event fork at entry, event join before returning): towards the caller the call is still ordered
+ * on `hip_stream` only. */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
+
+/* The same transform on a CALLER-SUPPLIED workspace: every plan is re-entrant through this entry point.  The RTL core is stateless between
+ * instances (int_fftNk.vhd:23-37: frames may follow each other back to back, nothing is kept between them) and SURVEY.md section 8(b) asks for
+ * an exec that is re-entrant across streams: with the inter-pass scratch, the layout buffers of the 2-D plans and the middle buffer of composite
+ * pairs all carved out of `d_workspace`, a call reads the plan and writes nothing in it (the side stream of the two-stream plans comes from a
+ * mutex-protected pool and goes back when the call returns), so ONE plan may run on any number of streams / host threads at once as long as every
+ * concurrent call has its own workspace.
+ *   intfft_plan_workspace_bytes(plan, batch, &bytes): the workspace with which a call of `batch` frames runs exactly like intfft_exec on the plan's
+ *     own scratch (0 for single-launch plans: d_workspace may then be NULL).  Monotone in `batch` and bounded: at most 2 x 128 MiB halves / 256 MiB
+ *     (+ the sub-plans' share for composite plans) however large the batch.
+ *   intfft_exec_ws(..., d_workspace, ws_bytes, stream): d_workspace is a device pointer on the plan's device, 256-byte aligned, not overlapping
+ *     d_in / d_out.  A workspace smaller than intfft_plan_workspace_bytes(plan, batch) is accepted as long as it serves one frame
+ *     (>= intfft_plan_workspace_bytes(plan, 1)): the batch is then cut into the largest sub-batches the workspace serves, one after the other on
+ *     `hip_stream` (slower: no two-stream overlap inside a sub-batch that fits one scratch half); smaller than that -> INTFFT_ERR_INVALID.
+ *   intfft_plan_release_scratch(plan): frees the plan-owned scratch (and that of its sub-plans) after waiting for the device; from then on
+ *     intfft_exec / intfft_exec_host / intfft_exec_sharded on this plan return INTFFT_ERR_INVALID and only intfft_exec_ws runs it -- for callers
+ *     that bring their own workspaces and do not want N x up to 256 MiB held by plans. */
+int intfft_plan_workspace_bytes(const intfft_plan *plan, size_t batch, size_t *bytes);
+int intfft_exec_ws(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *d_workspace, size_t ws_bytes, void *hip_stream);
+int intfft_plan_release_scratch(intfft_plan *plan);
 
 /* Host-resident frames (the "streaming block" use): h_in/h_out are HOST pointers with the same layout
  * as above.  The batch is cut into chunks of `chunk_frames` frames (0 = library default) that are
@@ -149,6 +175,8 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
  * of plans[root].  The batch is cut into contiguous shards (remainder to the LAST plans); shard i is copied
  * root -> device i (hipMemcpyPeerAsync over xGMI, peer access enabled where the devices allow it), transformed there,
  * and copied back; the root transforms its own shard in place of the copy.  Blocking.
+ * Every peer's shard moves in up to 4 pieces (>= 2 MiB each) so that the copy back of piece k runs beside the copy in of piece k + 1 (xGMI links are
+ * full duplex; end to end this path is link-bound) and beside the transform of the root's own shard.
  * Synchronisation contract: on entry the call waits for EVERY stream of the root device (hipDeviceSynchronize), so
  * d_in may have been produced on any stream of that device; on return d_out is complete.  On an error every stream the
  * call used is still drained before it returns.
@@ -160,16 +188,28 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
  * (intfftk_amd/sharding.py: grouped ncclSend/ncclRecv scatter and gather). */
 int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t max_batch);
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch);
+/* The same call without host synchronisation -- a "streaming block" over several GPUs that can be enqueued behind other work: everything is ordered
+ * behind what `hip_stream` (a stream of plans[root]'s device, NULL = its default stream) holds at the time of the call (d_in must be complete in
+ * THAT stream's order -- no hipDeviceSynchronize here), and when the call returns `hip_stream` has been made to wait for every copy and transform
+ * of the call, so work enqueued on it afterwards sees d_out complete.  Back-to-back calls on the same plans are ordered among themselves (each plan's
+ * streams first wait for the previous call's completion event).  Staging that has to grow is (re)allocated inside the call, which synchronises the
+ * device: call intfft_shard_prepare first.  Same state and threading rules as intfft_exec_sharded. */
+int intfft_exec_sharded_async(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch, void *hip_stream);
 /* How intfft_exec_sharded moves the shards between the root and the other devices ("grouped
  * ncclSend / ncclRecv root <-> peers so that all links of the root are driven concurrently"):
  *   INTFFT_TRANSPORT_PEER  hipMemcpyPeerAsync per shard on the shard's stream (the default)
- *   INTFFT_TRANSPORT_RCCL  RCCL over xGMI: ONE ncclGroupStart .. ncclGroupEnd of ncclSend (root) / ncclRecv (peer) pairs for the scatter,
- *                          one for the gather.  librccl.so is loaded with dlopen on the first request (no link-time dependency); the
+ *   INTFFT_TRANSPORT_RCCL  EXPERIMENTAL -- no run on two or more devices has been recorded for it yet (every box this library was
+ *                          measured on had ONE GPU: with one rank the groups are empty, so only dlopen, ncclCommInitAll and the empty-group
+ *                          path are proven; tests/test_gpu_cabi.py compares it with the peer transport whenever >= 2 devices are visible).
+ *                          RCCL over xGMI: per piece of the shards ONE ncclGroupStart .. ncclGroupEnd holding the ncclSend (root) / ncclRecv
+ *                          (peer) pairs of the scatter of piece t AND the reverse pairs of the gather of piece t - 1, so that every link of
+ *                          the root runs in both directions at once.  librccl.so is loaded with dlopen on the first request (no link-time dependency); the
  *                          communicators (ncclCommInitAll over the plans' devices, rank i = plans[i]) belong to the plan set and are
  *                          released by intfft_plan_destroy of plans[0].  Needs every plan on its own device.
- * Returns INTFFT_OK; INTFFT_ERR_UNSUPPORTED when RCCL cannot be loaded or the communicators cannot be created (two plans on one
+ * Returns INTFFT_OK; INTFFT_ERR_TRANSPORT when RCCL cannot be loaded or the communicators cannot be created (two plans on one
  * device, no librccl.so): the plan set then stays on peer copies, so a caller may simply try RCCL first.  The two transports give the
- * same bytes.  Like intfft_shard_prepare this call modifies the plans: not concurrently with any other call on them. */
+ * same bytes.  A set is identified by the call that created it: plans whose communicators come from different calls (or whose owner,
+ * plans[0] of that call, was destroyed or re-assigned since) fall back to peer copies rather than touching a stale communicator.  Like intfft_shard_prepare this call modifies the plans: not concurrently with any other call on them. */
 #define INTFFT_TRANSPORT_PEER 0
 #define INTFFT_TRANSPORT_RCCL 1
 int intfft_shard_set_transport(intfft_plan *const *plans, int nplans, int root, int transport);
@@ -196,7 +236,8 @@ int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *
  *   INTFFT_NO_FASTW64, INTFFT_NO_PAIR_COMPOSITE, INTFFT_NO_NARROW_PASS, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_PACKED_TW,
  *   INTFFT_2D_CHUNK_FRAMES (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed
  *   kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS, INTFFT_PASS_TARGET,
- *   INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL (launch geometry / scratch / generic-kernel knobs).  README.md describes each. */
+ *   INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL, INTFFT_SHARD_PIECES (launch geometry / scratch / generic-kernel / shard-pipeline knobs),
+ *   INTFFT_VERBOSE (the failing RCCL call and its ncclResult_t on stderr).  README.md describes each. */
 const char *intfft_strerror(int status);
 const char *intfft_version(void);
 

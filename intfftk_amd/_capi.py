@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("INTFFT_LIB") or os.path.join(_HERE, "lib", "libintfft.so")
 
 OK = 0
-ERR_INVALID, ERR_UNSUPPORTED, ERR_NULL, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3, -4, -5
+ERR_INVALID, ERR_UNSUPPORTED, ERR_NULL, ERR_NO_DEVICE, ERR_ALLOC, ERR_TRANSPORT = -1, -2, -3, -4, -5, -6
 FWD, INV, PAIR = 0, 1, 2
 TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1
 ORDER_NATURAL, ORDER_BITREV, ORDER_HALVES, ORDER_BITREV_LANES = 0, 1, 2, 3
@@ -17,7 +17,8 @@ DIRECTIONS = {"FWD": 0, "INV": 1, "PAIR": 2}
 
 # every symbol include/intfft.h declares
 SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy", "intfft_plan_get_info",
-           "intfft_exec", "intfft_exec_host", "intfft_shard_prepare", "intfft_exec_sharded", "intfft_shard_set_transport", "intfft_reorder",
+           "intfft_exec", "intfft_plan_workspace_bytes", "intfft_exec_ws", "intfft_plan_release_scratch", "intfft_exec_host",
+           "intfft_shard_prepare", "intfft_exec_sharded", "intfft_exec_sharded_async", "intfft_shard_set_transport", "intfft_reorder",
            "intfft_twiddles", "intfft_strerror", "intfft_version")
 
 
@@ -68,6 +69,12 @@ def lib():
         L.intfft_plan_get_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(PlanInfo)]
         L.intfft_exec.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                   ctypes.c_void_p]
+        L.intfft_plan_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.intfft_exec_ws.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                     ctypes.c_void_p]
+        L.intfft_plan_release_scratch.argtypes = [ctypes.c_void_p]
+        L.intfft_exec_sharded_async.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L.intfft_exec_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_size_t]
         L.intfft_exec_sharded.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
@@ -82,7 +89,8 @@ def lib():
         L.intfft_strerror.argtypes = [ctypes.c_int]
         L.intfft_version.restype = ctypes.c_char_p
         for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy",
-                   "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded",
+                   "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded", "intfft_exec_sharded_async",
+                   "intfft_plan_workspace_bytes", "intfft_exec_ws", "intfft_plan_release_scratch",
                    "intfft_shard_prepare", "intfft_shard_set_transport", "intfft_reorder", "intfft_twiddles"):
             getattr(L, fn).restype = ctypes.c_int
         _lib = L

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -99,6 +100,13 @@ void allow_max_lds(const void *kernel)
 
 using namespace intfft;
 
+constexpr int SHARD_EVENTS = 3 + 8; // entry, done, first-stream done, one per piece of a shard
+
+struct ExecCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
 struct intfft_plan {
     intfft_params p;
     int device = 0;
@@ -129,9 +137,19 @@ struct intfft_plan {
     // Gsample/s, C3 142 against 132 (tools/two_stream_probe.py: two 128 MiB halves beat one 256 MiB scratch and three streams);
     // only the plan families that gain have a second half (create_plan).
     void *d_scratch2 = nullptr;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The side stream and its fork / join events are an "execution context" taken from a per-plan pool for the duration of one call
+    // (host side) and put back when the call returns: concurrent calls on one plan (intfft_exec_ws on distinct workspaces) each get their
+    // own, so nothing in the plan is written by an exec.  Re-recording a pooled event later is harmless: a hipStreamWaitEvent already
+    // enqueued keeps waiting for the record that preceded it.
+    bool wants_side = false;     // this plan's chunk loop alternates between the caller's stream and a side stream
+    std::mutex ctx_mu;
+    std::vector<ExecCtx> ctx_pool;
     size_t scratch_frames = 0, scratch_bytes = 0;
+    size_t scratch_frame_bytes = 0; // bytes of one frame of inter-pass words
+    bool dual_scratch = false;      // two scratch halves (one per stream)
+    bool is2d = false, is_pair = false;
+    int n2d_bufs = 0;               // layout buffers a 2-D plan uses (1: the two-launch fused forms)
+    bool owns_scratch = true;       // false after intfft_plan_release_scratch: only intfft_exec_ws runs the plan then
     bool fast1024 = false;
     bool fast4096 = false;
     bool fast16k = false;  // N = 8192 / 16384, 16-bit scaled-truncate FWD / INV in ONE pass (intfft_fast16k.hip)
@@ -166,18 +184,94 @@ struct intfft_plan {
     // intfft_exec_sharded: this plan's staging buffers (grow only) and stream
     void *shard_in = nullptr, *shard_out = nullptr;
     size_t shard_in_bytes = 0, shard_out_bytes = 0;
-    hipStream_t s_shard = nullptr;
+    hipStream_t s_shard = nullptr;  // scatter side + transforms of this plan's shard
+    hipStream_t s_shard2 = nullptr; // gather side (peer copies) / the root's own transform
+    hipStream_t s_call = nullptr;   // the blocking intfft_exec_sharded's "caller stream" (root plan)
+    hipEvent_t shard_ev[SHARD_EVENTS] = {};
+    bool shard_used = false;        // shard_ev[1] has been recorded by an earlier call
     int shard_peer = -1; // root device this plan's device has peer access to (-1: not set up yet)
     // RCCL transport of intfft_exec_sharded (intfft_shard_set_transport): this plan's communicator of the plan set (rank = its index in the
     // set), the set's size; plans[0] of the set owns all of them (rccl_owned)
     void *rccl_comm = nullptr;
     int rccl_rank = -1, rccl_nranks = 0;
+    uint64_t rccl_set = 0;               // which ncclCommInitAll this communicator came from (0: none)
+    intfft_plan *rccl_owner = nullptr;   // the plan that owns the set's communicators (plans[0] of the set)
     std::vector<void *> rccl_owned;
+    std::vector<intfft_plan *> rccl_members; // owner only: every plan that holds one of rccl_owned (back-pointers for release)
     size_t slot_frames = 0;
     char kernel_name[64] = {0};
 };
 
 static void free_stream_state(intfft_plan *pl);
+
+static void ctx_destroy(ExecCtx &c)
+{
+    if (c.side) (void)hipStreamDestroy(c.side);
+    if (c.fork) (void)hipEventDestroy(c.fork);
+    if (c.join) (void)hipEventDestroy(c.join);
+    c = ExecCtx{};
+}
+
+// One execution context for the duration of a call (the caller holds the plan's device current).
+static bool ctx_acquire(intfft_plan *pl, ExecCtx &c)
+{
+    {
+        std::lock_guard<std::mutex> lk(pl->ctx_mu);
+        if (!pl->ctx_pool.empty()) {
+            c = pl->ctx_pool.back();
+            pl->ctx_pool.pop_back();
+            return true;
+        }
+    }
+    c = ExecCtx{};
+    hipError_t e = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        ctx_destroy(c);
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
+static void ctx_release(intfft_plan *pl, const ExecCtx &c)
+{
+    std::lock_guard<std::mutex> lk(pl->ctx_mu);
+    pl->ctx_pool.push_back(c);
+}
+
+// Fork / join of a chunk loop that alternates between the caller's stream and a pooled side stream; joins (and returns the context) on
+// every exit path.
+struct SideStream {
+    intfft_plan *pl;
+    hipStream_t user;
+    ExecCtx c;
+    bool on = false;
+    SideStream(intfft_plan *p, hipStream_t s) : pl(p), user(s) {}
+    hipError_t fork() // under stream capture the call stays on the caller's stream (no cross-stream edges in somebody else's graph)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(user, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return hipSuccess;
+        if (!ctx_acquire(pl, c)) return hipSuccess; // no context: one stream, still correct
+        hipError_t e = hipEventRecord(c.fork, user);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c.side, c.fork, 0);
+        if (e != hipSuccess) {
+            ctx_release(pl, c);
+            return e;
+        }
+        on = true;
+        return hipSuccess;
+    }
+    ~SideStream()
+    {
+        if (!on) return;
+        if (hipEventRecord(c.join, c.side) == hipSuccess) (void)hipStreamWaitEvent(user, c.join, 0);
+        ctx_release(pl, c);
+    }
+};
+
+static size_t ws_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 namespace {
 
@@ -607,12 +701,31 @@ Rccl &rccl()
 constexpr int NCCL_INT8 = 0; // ncclInt8 / ncclChar (rccl.h)
 } // namespace
 
+// The owner of a set releases it: every member (whichever sets it is passed in later) forgets its communicator first.
 static void rccl_release(intfft_plan *owner)
 {
     Rccl &r = rccl();
+    for (intfft_plan *m : owner->rccl_members)
+        if (m && m->rccl_owner == owner) m->rccl_comm = nullptr, m->rccl_rank = -1, m->rccl_nranks = 0, m->rccl_set = 0, m->rccl_owner = nullptr;
+    owner->rccl_members.clear();
     for (void *c : owner->rccl_owned)
         if (c && r.ok) (void)r.comm_destroy(c);
     owner->rccl_owned.clear();
+}
+
+// A member leaves its set (destroyed, or moved to another set): the owner keeps the communicator object until it releases the set,
+// but no longer points at this plan.
+static void rccl_leave(intfft_plan *pl)
+{
+    if (pl->rccl_owner && pl->rccl_owner != pl)
+        for (intfft_plan *&m : pl->rccl_owner->rccl_members)
+            if (m == pl) m = nullptr;
+    if (pl->rccl_owner != pl) pl->rccl_comm = nullptr, pl->rccl_rank = -1, pl->rccl_nranks = 0, pl->rccl_set = 0, pl->rccl_owner = nullptr;
+}
+
+static void rccl_report(const char *what, int status)
+{
+    if (diag_env("INTFFT_VERBOSE")) std::fprintf(stderr, "intfft: %s failed with ncclResult_t %d\n", what, status);
 }
 
 extern "C" {
@@ -713,6 +826,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (const char *e = diag_env("INTFFT_2D_CHUNK_FRAMES")) // diagnostics: exercise the chunk loop on small batches
                 if (atoi(e) > 0) pl->buf2d_frames = std::min(pl->buf2d_frames, (size_t)atoi(e));
             for (int i = 0; i < 2 && rc == INTFFT_OK; ++i) rc = (int)hipMalloc(&pl->buf2d[i], pl->buf2d_frames * frame_bytes);
+            pl->is2d = true;
+            pl->n2d_bufs = 2;
         }
         if (rc != INTFFT_OK) {
             intfft_plan_destroy(pl);
@@ -751,6 +866,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (pl->fused2d == 2 || pl->fused2d == 4) {
                 (void)hipFree(pl->buf2d[1]);
                 pl->buf2d[1] = nullptr;
+                pl->n2d_bufs = 1;
             }
             // the 1024-point cores' twiddles in the packed operand forms (the single-kernel sub-plans pack theirs on the fly)
             const size_t total = ((size_t)1 << 10) - 1;
@@ -765,13 +881,13 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 return (int)e;
             }
             if (e == hipSuccess && !diag_env("INTFFT_ONE_STREAM")) {
-                e = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
-                if (e != hipSuccess) {
+                pl->wants_side = true;
+                ExecCtx c; // the first context of the pool up front: no stream is created inside the first exec
+                if (!ctx_acquire(pl, c)) {
                     intfft_plan_destroy(pl);
-                    return (int)e;
+                    return (int)hipErrorOutOfMemory;
                 }
+                ctx_release(pl, c);
             }
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
@@ -954,6 +1070,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                     intfft_plan_destroy(pl);
                     return INTFFT_ERR_ALLOC;
                 }
+                pl->is_pair = true;
+                pl->scratch_frame_bytes = frame_bytes;
                 pl->scratch_bytes = pl->pair_frames * frame_bytes + pl->pair_f->scratch_bytes + pl->pair_i->scratch_bytes;
                 // the two sub-plans carry their own tables and passes: the parent's were only needed to decide eligibility
                 (void)hipFree(pl->d_tw);
@@ -1059,13 +1177,15 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (!dual && (pl->big20 || pl->bigw || pl->wide16)) scratch_mb = 256;
             if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
+            pl->scratch_frame_bytes = frame_bytes;
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
             hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
             if (e == hipSuccess && dual) {
                 e = hipMalloc(&pl->d_scratch2, pl->scratch_bytes);
-                if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+                pl->dual_scratch = pl->wants_side = true;
+                ExecCtx c;
+                if (e == hipSuccess && !ctx_acquire(pl, c)) e = hipErrorOutOfMemory;
+                if (e == hipSuccess) ctx_release(pl, c);
                 if (e == hipSuccess) pl->scratch_bytes *= 2; // what intfft_plan_get_info reports: both halves
             }
             if (e != hipSuccess) {
@@ -1093,13 +1213,15 @@ int intfft_plan_destroy(intfft_plan *plan)
         if (plan->pair_buf) (void)hipFree(plan->pair_buf);
         if (plan->d_scratch) (void)hipFree(plan->d_scratch);
         if (plan->d_scratch2) (void)hipFree(plan->d_scratch2);
-        if (plan->side_stream) (void)hipStreamDestroy(plan->side_stream);
-        if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
-        if (plan->ev_join) (void)hipEventDestroy(plan->ev_join);
+        for (ExecCtx &c : plan->ctx_pool) ctx_destroy(c);
         if (plan->shard_in) (void)hipFree(plan->shard_in);
         if (plan->shard_out) (void)hipFree(plan->shard_out);
-        if (!plan->rccl_owned.empty()) rccl_release(plan);
-        if (plan->s_shard) (void)hipStreamDestroy(plan->s_shard);
+        if (plan->rccl_owner == plan) rccl_release(plan);
+        else rccl_leave(plan);
+        for (hipStream_t st : {plan->s_shard, plan->s_shard2, plan->s_call})
+            if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : plan->shard_ev)
+            if (ev) (void)hipEventDestroy(ev);
         free_stream_state(plan);
         if (plan->d_tw16f) (void)hipFree(plan->d_tw16f);
         if (plan->d_tw16i) (void)hipFree(plan->d_tw16i);
@@ -1117,17 +1239,17 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast16k || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
-    if (plan->pair_buf) {
+    if (plan->is_pair) {
         intfft_plan_info sf, si;
         if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK || intfft_plan_get_info(plan->pair_i, &si) != INTFFT_OK) return INTFFT_ERR_INVALID;
         info->n_passes = sf.n_passes + si.n_passes;
         info->compute_word = std::max(sf.compute_word, si.compute_word);
         info->fast_path = sf.fast_path && si.fast_path;
-        info->scratch_bytes = plan->scratch_bytes;
+        info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }
-    if (plan->buf2d[0]) {
+    if (plan->is2d) {
         intfft_plan_info si;
         int n = 0;
         for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
@@ -1140,16 +1262,17 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
         // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
-        info->scratch_bytes = (plan->buf2d[1] ? 2 : 1) * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+        info->scratch_bytes = (size_t)plan->n2d_bufs * plan->buf2d_frames * ((size_t)2 << plan->L) * (size_t)plan->out_cb;
         for (const intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i})
             if (sp) info->scratch_bytes += sp->scratch_bytes;
+        if (!plan->owns_scratch) info->scratch_bytes = 0;
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }
     info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
     info->compute_word = (plan->fastw64 || plan->fastw64b) ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
-    info->scratch_bytes = plan->scratch_bytes;
+    info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
     std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
     return INTFFT_OK;
 }
@@ -1160,9 +1283,55 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
 //            | [k1][k2] -> user (out_order, X[k1 + N1 k2])
 //   inverse  user (in_order, X) -> [k1][k2] | N2-point int_ifftNk | x conj W | [k1][n2] -> [n2][k1] | N1-point int_ifftNk
 //            | [n2][n1] -> user (out_order)          pair: forward up to [k1][k2], then the inverse from there
-static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch, hipStream_t stream)
+static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, hipStream_t stream, char *ws);
+
+// Frames per layout buffer of a 2-D plan for a call of `batch` frames on a caller-supplied workspace (plan-owned buffers hold
+// buf2d_frames): the chunking below is the same in both cases.
+static bool dual_2d(const intfft_plan *pl)
+{
+    return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || pl->sub_row_f->scratch_bytes == 0);
+}
+static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
+{
+    if (dual_2d(pl)) return batch <= pl->buf2d_frames / 2 ? batch : pl->buf2d_frames;
+    return std::min(batch, pl->buf2d_frames);
+}
+
+// Workspace a call of `batch` frames needs when the caller supplies it (0: the plan is a single launch).  Monotone in `batch`.
+static size_t ws_need(const intfft_plan *pl, size_t batch)
+{
+    if (batch == 0) return 0;
+    if (pl->is2d) {
+        const size_t bf = ws_frames_2d(pl, batch);
+        size_t sub = 0;
+        const int l1 = pl->l1, l2 = pl->L - pl->l1;
+        if (pl->fused2d == 3) sub = ws_need(pl->sub_row_f, bf << l1);
+        else if (!pl->fused2d) {
+            if (pl->sub_col_f) sub = std::max(sub, ws_need(pl->sub_col_f, bf << l2));
+            if (pl->sub_row_f) sub = std::max(sub, ws_need(pl->sub_row_f, bf << l1));
+            if (pl->sub_row_i) sub = std::max(sub, ws_need(pl->sub_row_i, bf << l1));
+            if (pl->sub_col_i) sub = std::max(sub, ws_need(pl->sub_col_i, bf << l2));
+        }
+        return (size_t)pl->n2d_bufs * ws_align(bf * ((size_t)2 << pl->L) * (size_t)pl->out_cb) + sub;
+    }
+    if (pl->is_pair) {
+        const size_t pf = std::min(pl->pair_frames, batch);
+        return ws_align(pf * pl->scratch_frame_bytes) + std::max(ws_need(pl->pair_f, pf), ws_need(pl->pair_i, pf));
+    }
+    if (pl->scratch_frames == 0) return 0;
+    if (batch <= pl->scratch_frames) return ws_align(batch * pl->scratch_frame_bytes);
+    return (pl->dual_scratch ? 2 : 1) * ws_align(pl->scratch_frames * pl->scratch_frame_bytes);
+}
+
+static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch, hipStream_t stream, char *ws)
 {
     const int L = pl->L, l1 = pl->l1, l2 = L - l1;
+    // the layout buffers and what the sub-plans may use: the plan's own, or carved from the caller's workspace
+    const size_t bufs_frames = ws ? ws_frames_2d(pl, batch) : pl->buf2d_frames;
+    const size_t buf_bytes = ws_align(bufs_frames * ((size_t)2 << L) * (size_t)pl->out_cb);
+    void *const buf0 = ws ? ws : pl->buf2d[0];
+    void *const buf1 = ws ? (pl->n2d_bufs == 2 ? ws + buf_bytes : nullptr) : pl->buf2d[1];
+    char *const subws = ws ? ws + (size_t)pl->n2d_bufs * buf_bytes : nullptr;
     const intfft_params &p = pl->p;
     const size_t in_frame = ((size_t)2 << L) * (size_t)pl->in_cb, out_frame = ((size_t)2 << L) * (size_t)pl->out_cb;
     int perm[24];
@@ -1176,37 +1345,21 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
         // buffers (section 4.2d: the strided column pass of one chunk beside the streaming launches of the other); under stream capture, and
         // when the row sub-plan owns a scratch of its own, everything stays on the caller's stream.
         const size_t half = pl->buf2d_frames / 2;
-        bool dual = pl->side_stream && half >= 1 && batch > half && (pl->fused2d != 3 || pl->sub_row_f->scratch_bytes == 0);
-        if (dual) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dual = false;
-        }
-        const size_t chunk = dual ? half : pl->buf2d_frames;
-        if (dual) {
-            e = hipEventRecord(pl->ev_fork, stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0);
-            if (e != hipSuccess) return (int)e;
-        }
-        struct Join { // joins on every exit path
-            intfft_plan *p;
-            hipStream_t s;
-            bool on;
-            ~Join()
-            {
-                if (on && hipEventRecord(p->ev_join, p->side_stream) == hipSuccess) (void)hipStreamWaitEvent(s, p->ev_join, 0);
-            }
-        } join{pl, stream, dual};
+        SideStream side(pl, stream);
+        if (dual_2d(pl) && batch > half && (e = side.fork()) != hipSuccess) return (int)e;
+        const bool dual = side.on;
+        const size_t chunk = dual ? half : bufs_frames;
         size_t ci = 0;
         for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += chunk, ++ci) {
             const size_t nf = std::min(chunk, batch - f);
             const bool odd = dual && (ci & 1);
-            hipStream_t st = odd ? pl->side_stream : stream;
+            hipStream_t st = odd ? side.c.side : stream;
             const size_t off = odd ? half * out_frame : 0; // (layout buffers are sized in frames of the output container)
             const uint32_t *src = reinterpret_cast<const uint32_t *>(static_cast<const char *>(d_in) + f * in_frame);
             char *dst = static_cast<char *>(d_out) + f * out_frame;
-            uint32_t *b0 = reinterpret_cast<uint32_t *>(static_cast<char *>(pl->buf2d[0]) + off);
+            uint32_t *b0 = reinterpret_cast<uint32_t *>(static_cast<char *>(buf0) + off);
             if (pl->fused2d == 5) { // the pair: X in natural order in the second layout buffer between the two directions
-                uint32_t *b1 = reinterpret_cast<uint32_t *>(static_cast<char *>(pl->buf2d[1]) + off);
+                uint32_t *b1 = reinterpret_cast<uint32_t *>(static_cast<char *>(buf1) + off);
                 e = launch_fused2d(p.twdl_width, src, b1, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
@@ -1223,10 +1376,10 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                                    p.in_order == INTFFT_ORDER_HALVES, st);
                 continue;
             }
-            char *b1 = static_cast<char *>(pl->buf2d[1]) + off;
+            char *b1 = static_cast<char *>(buf1) + off;
             e = launch_fused2d_cols(l2, p.twdl_width, src, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
             if (e != hipSuccess) break;
-            if ((rc = intfft_exec(pl->sub_row_f, b0, b1, nf << l1, st)) != INTFFT_OK) break;
+            if ((rc = exec_core(pl->sub_row_f, b0, b1, nf << l1, st, subws)) != INTFFT_OK) break;
             // logical k = k1 + N1 k2 sits at [rho = brev(k1)][k2]: k bit j < l1 at in bit l2 + (l1 - 1 - j), else at j - l1
             for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + (l1 - 1 - j) : j - l1;
             e = launch_bitperm(L, pl->sub_row_f->out_cb, perm, b1, dst, nf, st);
@@ -1234,18 +1387,18 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
         if (rc != INTFFT_OK) return rc;
         return (int)e;
     }
-    for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += pl->buf2d_frames) {
-        const size_t nf = std::min(pl->buf2d_frames, batch - f);
+    for (size_t f = 0; f < batch && e == hipSuccess && rc == INTFFT_OK; f += bufs_frames) {
+        const size_t nf = std::min(bufs_frames, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
-        void *cur = pl->buf2d[0], *oth = pl->buf2d[1];
+        void *cur = buf0, *oth = buf1;
         int cb = pl->in_cb;
         if (p.direction != INTFFT_INV) {
             // user (time side, logical n = n1 N2 + n2) -> [n2][n1]: n2 bit j -> bit l1 + j, n1 bit j -> bit j
             for (int j = 0; j < L; ++j) perm[j < l2 ? l1 + j : j - l2] = order_mem_bit(p.in_order, L, j);
             e = launch_bitperm(L, cb, perm, src, cur, nf, stream);
             if (e != hipSuccess) break;
-            if ((rc = intfft_exec(pl->sub_col_f, cur, oth, nf << l2, stream)) != INTFFT_OK) break;
+            if ((rc = exec_core(pl->sub_col_f, cur, oth, nf << l2, stream, subws)) != INTFFT_OK) break;
             std::swap(cur, oth);
             cb = pl->sub_col_f->out_cb;
             // [n2][k1] -> [k1][n2]: out bit b < l2 (n2) <- in bit l1 + b; out bit b >= l2 (k1) <- in bit b - l2
@@ -1259,7 +1412,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 std::swap(cur, oth);
                 if ((e = launch_twmul(cur, cb, L, l2, t.mw, t.sh_a, t.sh_b, t.narrow, 0, p.twdl_width, nf, stream)) != hipSuccess) break;
             }
-            if ((rc = intfft_exec(pl->sub_row_f, cur, oth, nf << l1, stream)) != INTFFT_OK) break;
+            if ((rc = exec_core(pl->sub_row_f, cur, oth, nf << l1, stream, subws)) != INTFFT_OK) break;
             std::swap(cur, oth);
             cb = pl->sub_row_f->out_cb;
             if (p.direction == INTFFT_FWD) {
@@ -1273,7 +1426,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
             for (int j = 0; j < L; ++j) perm[j < l1 ? l2 + j : j - l1] = order_mem_bit(p.in_order, L, j);
             if ((e = launch_bitperm(L, cb, perm, src, cur, nf, stream)) != hipSuccess) break;
         }
-        if ((rc = intfft_exec(pl->sub_row_i, cur, oth, nf << l1, stream)) != INTFFT_OK) break;
+        if ((rc = exec_core(pl->sub_row_i, cur, oth, nf << l1, stream, subws)) != INTFFT_OK) break;
         std::swap(cur, oth);
         cb = pl->sub_row_i->out_cb;
         const StageDesc &t = pl->tw_i;
@@ -1286,7 +1439,7 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
             if ((e = launch_bitperm(L, cb, perm, cur, oth, nf, stream)) != hipSuccess) break;
         }
         std::swap(cur, oth);
-        if ((rc = intfft_exec(pl->sub_col_i, cur, oth, nf << l2, stream)) != INTFFT_OK) break;
+        if ((rc = exec_core(pl->sub_col_i, cur, oth, nf << l2, stream, subws)) != INTFFT_OK) break;
         std::swap(cur, oth);
         cb = pl->sub_col_i->out_cb;
         // [n2][n1] -> user (time side, logical n = n1 N2 + n2): n bit j < l2 sits at in bit l1 + j, else at j - l2
@@ -1297,10 +1450,9 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
     return (int)e;
 }
 
-int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream)
+static int exec_check(const intfft_plan *plan, const void *d_in, const void *d_out, size_t batch)
 {
     if (!plan || (batch && (!d_in || !d_out))) return INTFFT_ERR_NULL;
-    if (batch == 0) return INTFFT_OK;
     {   // in place only as d_in == d_out with equal containers; any other overlap of the two byte ranges would let a
         // block overwrite frames another block has not read yet
         const size_t n2 = (size_t)2 << plan->L;
@@ -1308,16 +1460,90 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
         const uintptr_t b0 = reinterpret_cast<uintptr_t>(d_out), b1 = b0 + batch * n2 * (size_t)plan->out_cb;
         if (a0 < b1 && b0 < a1 && (a0 != b0 || plan->in_cb != plan->out_cb)) return INTFFT_ERR_INVALID;
     }
+    return INTFFT_OK;
+}
+
+int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream)
+{
+    const int rc = exec_check(plan, d_in, d_out, batch);
+    if (rc != INTFFT_OK || batch == 0) return rc;
+    if (!plan->owns_scratch) return INTFFT_ERR_INVALID; // intfft_plan_release_scratch: intfft_exec_ws only
+    DeviceGuard guard(plan->device);
+    if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
+    return exec_core(plan, d_in, d_out, batch, reinterpret_cast<hipStream_t>(hip_stream), nullptr);
+}
+
+int intfft_plan_workspace_bytes(const intfft_plan *plan, size_t batch, size_t *bytes)
+{
+    if (!plan || !bytes) return INTFFT_ERR_NULL;
+    *bytes = ws_need(plan, batch);
+    return INTFFT_OK;
+}
+
+int intfft_exec_ws(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *d_workspace, size_t ws_bytes, void *hip_stream)
+{
+    int rc = exec_check(plan, d_in, d_out, batch);
+    if (rc != INTFFT_OK || batch == 0) return rc;
+    const size_t need = ws_need(plan, batch);
+    if (need && !d_workspace) return INTFFT_ERR_NULL;
+    if (need && (reinterpret_cast<uintptr_t>(d_workspace) & 255)) return INTFFT_ERR_INVALID;
+    {   // the workspace must not overlap the user arrays
+        const size_t n2 = (size_t)2 << plan->L;
+        const uintptr_t w0 = reinterpret_cast<uintptr_t>(d_workspace), w1 = w0 + ws_bytes;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_in), a1 = a0 + batch * n2 * (size_t)plan->in_cb;
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(d_out), b1 = b0 + batch * n2 * (size_t)plan->out_cb;
+        if (need && ((w0 < a1 && a0 < w1) || (w0 < b1 && b0 < w1))) return INTFFT_ERR_INVALID;
+    }
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
-    if (plan->buf2d[0]) return exec_2d(plan, d_in, d_out, batch, stream);
-    if (plan->pair_buf) { // composite pair: forward sub-plan -> middle buffer -> inverse sub-plan, chunk by chunk
+    char *ws = static_cast<char *>(d_workspace);
+    if (need <= ws_bytes) return exec_core(plan, d_in, d_out, batch, stream, need ? ws : nullptr);
+    // a smaller workspace: the largest sub-batch it serves (ws_need is monotone), sub-batch after sub-batch on the caller's stream
+    if (ws_need(plan, 1) > ws_bytes) return INTFFT_ERR_INVALID;
+    size_t lo = 1, hi = batch; // ws_need(lo) <= ws_bytes < ws_need(hi)
+    while (hi - lo > 1) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (ws_need(plan, mid) <= ws_bytes) lo = mid;
+        else hi = mid;
+    }
+    const size_t in_frame = ((size_t)2 << plan->L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << plan->L) * (size_t)plan->out_cb;
+    for (size_t f = 0; f < batch && rc == INTFFT_OK; f += lo)
+        rc = exec_core(plan, static_cast<const char *>(d_in) + f * in_frame, static_cast<char *>(d_out) + f * out_frame, std::min(lo, batch - f), stream, ws);
+    return rc;
+}
+
+int intfft_plan_release_scratch(intfft_plan *plan)
+{
+    if (!plan) return INTFFT_ERR_NULL;
+    DeviceGuard guard(plan->device);
+    if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
+    const hipError_t e = hipDeviceSynchronize(); // nothing of an earlier intfft_exec may still be using the buffers
+    for (void **b : {&plan->d_scratch, &plan->d_scratch2, &plan->buf2d[0], &plan->buf2d[1], &plan->pair_buf})
+        if (*b) {
+            (void)hipFree(*b);
+            *b = nullptr;
+        }
+    plan->owns_scratch = false;
+    for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i, plan->pair_f, plan->pair_i})
+        if (sp) (void)intfft_plan_release_scratch(sp);
+    return (int)e;
+}
+
+// One call on the plan's own scratch (ws == nullptr) or on a caller-supplied workspace of ws_need(plan, batch) bytes.  Reads the plan
+// only (execution contexts come from its pool), so calls with distinct workspaces may run concurrently.
+static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, hipStream_t stream, char *ws)
+{
+    if (plan->is2d) return exec_2d(plan, d_in, d_out, batch, stream, ws);
+    if (plan->is_pair) { // composite pair: forward sub-plan -> middle buffer -> inverse sub-plan, chunk by chunk
         const size_t in_frame = ((size_t)2 << plan->L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << plan->L) * (size_t)plan->out_cb;
-        for (size_t f = 0; f < batch; f += plan->pair_frames) {
-            const size_t nf = std::min(plan->pair_frames, batch - f);
-            int rc = intfft_exec(plan->pair_f, static_cast<const char *>(d_in) + f * in_frame, plan->pair_buf, nf, stream);
-            if (rc == INTFFT_OK) rc = intfft_exec(plan->pair_i, plan->pair_buf, static_cast<char *>(d_out) + f * out_frame, nf, stream);
+        const size_t pf = ws ? std::min(plan->pair_frames, batch) : plan->pair_frames;
+        void *const mid = ws ? ws : plan->pair_buf;
+        char *const subws = ws ? ws + ws_align(pf * plan->scratch_frame_bytes) : nullptr;
+        for (size_t f = 0; f < batch; f += pf) {
+            const size_t nf = std::min(pf, batch - f);
+            int rc = exec_core(plan->pair_f, static_cast<const char *>(d_in) + f * in_frame, mid, nf, stream, subws);
+            if (rc == INTFFT_OK) rc = exec_core(plan->pair_i, mid, static_cast<char *>(d_out) + f * out_frame, nf, stream, subws);
             if (rc != INTFFT_OK) return rc;
         }
         return INTFFT_OK;
@@ -1373,35 +1599,24 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
     const size_t np = plan->passes.size();
     const size_t chunk = (np > 1 || plan->big20 || plan->bigw) ? plan->scratch_frames : batch;
-    // more than one chunk: odd chunks run on the plan's side stream with the second scratch half (fork here, join below)
+    // more than one chunk: odd chunks run on a pooled side stream with the second scratch half (fork here, join on every exit path)
     hipStream_t const user_stream = stream;
-    bool dual = plan->d_scratch2 != nullptr && batch > chunk;
-    if (dual) { // under stream capture the call stays on the caller's stream (no cross-stream edges in somebody else's graph)
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(user_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) dual = false;
-    }
-    if (dual) {
-        hipError_t e = hipEventRecord(plan->ev_fork, user_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(plan->side_stream, plan->ev_fork, 0);
+    void *const scratch0 = ws ? ws : plan->d_scratch;
+    void *const scratch1 = ws ? (plan->dual_scratch ? ws + ws_align(plan->scratch_frames * plan->scratch_frame_bytes) : nullptr) : plan->d_scratch2;
+    SideStream side(plan, user_stream);
+    if (plan->dual_scratch && scratch1 && batch > chunk) {
+        const hipError_t e = side.fork();
         if (e != hipSuccess) return (int)e;
     }
-    struct Join { // joins on every exit path of the loop below
-        intfft_plan *p;
-        hipStream_t s;
-        bool on;
-        ~Join()
-        {
-            if (on && hipEventRecord(p->ev_join, p->side_stream) == hipSuccess) (void)hipStreamWaitEvent(s, p->ev_join, 0);
-        }
-    } join{plan, user_stream, dual};
+    const bool dual = side.on;
     size_t ci = 0;
     for (size_t f = 0; f < batch; f += chunk, ++ci) {
         const size_t nf = std::min(chunk, batch - f);
         const void *src = static_cast<const char *>(d_in) + f * in_frame;
         void *dst = static_cast<char *>(d_out) + f * out_frame;
         const bool odd = dual && (ci & 1);
-        stream = odd ? plan->side_stream : user_stream;
-        void *const scratch = odd ? plan->d_scratch2 : plan->d_scratch;
+        stream = odd ? side.c.side : user_stream;
+        void *const scratch = odd ? scratch1 : scratch0;
         // (also for one-frame batches: a lone N = 8192 frame takes 10 us here, 21-53 us as one workgroup of the generic pass)
         if (plan->bigw) {
             const hipError_t e = launch_bigw(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, src, dst,
@@ -1534,6 +1749,10 @@ static hipError_t shard_state(intfft_plan *pl, int root_device, size_t in_bytes,
 {
     hipError_t e = hipSuccess;
     if (!pl->s_shard) e = hipStreamCreateWithFlags(&pl->s_shard, hipStreamNonBlocking);
+    if (e == hipSuccess && !pl->s_shard2) e = hipStreamCreateWithFlags(&pl->s_shard2, hipStreamNonBlocking);
+    if (e == hipSuccess && !pl->s_call) e = hipStreamCreateWithFlags(&pl->s_call, hipStreamNonBlocking);
+    for (int k = 0; k < SHARD_EVENTS && e == hipSuccess; ++k)
+        if (!pl->shard_ev[k]) e = hipEventCreateWithFlags(&pl->shard_ev[k], hipEventDisableTiming);
     if (e != hipSuccess) return e;
     if (pl->device != root_device && pl->shard_peer != root_device) {
         int can = 0;
@@ -1545,6 +1764,8 @@ static hipError_t shard_state(intfft_plan *pl, int root_device, size_t in_bytes,
         }
         pl->shard_peer = root_device;
     }
+    // (growing a staging buffer frees the old one: hipFree waits for the device, so an earlier asynchronous call that still uses it has
+    // finished by then)
     if (pl->shard_in_bytes < in_bytes) {
         if (pl->shard_in) (void)hipFree(pl->shard_in);
         pl->shard_in = nullptr, pl->shard_in_bytes = 0;
@@ -1607,29 +1828,59 @@ int intfft_shard_set_transport(intfft_plan *const *plans, int nplans, int root, 
     const int rc = shard_check(plans, nplans, root);
     if (rc != INTFFT_OK) return rc;
     if (transport != INTFFT_TRANSPORT_PEER && transport != INTFFT_TRANSPORT_RCCL) return INTFFT_ERR_INVALID;
-    // drop what the set had (the owner is whichever plan created the communicators)
+    // drop what these plans had: a plan that owns a set releases all of it (every member of that set, in this call's set or not, goes
+    // back to peer copies); a member of somebody else's set leaves that set
     for (int i = 0; i < nplans; ++i) {
-        if (!plans[i]->rccl_owned.empty()) rccl_release(plans[i]);
-        plans[i]->rccl_comm = nullptr, plans[i]->rccl_rank = -1, plans[i]->rccl_nranks = 0;
+        if (plans[i]->rccl_owner == plans[i]) rccl_release(plans[i]);
+        else rccl_leave(plans[i]);
     }
     if (transport == INTFFT_TRANSPORT_PEER) return INTFFT_OK;
     Rccl &r = rccl();
-    if (!r.ok) return INTFFT_ERR_UNSUPPORTED;
+    if (!r.ok) return INTFFT_ERR_TRANSPORT;
     std::vector<int> devs(nplans);
     for (int i = 0; i < nplans; ++i) {
         devs[i] = plans[i]->device;
         for (int j = 0; j < i; ++j)
-            if (devs[j] == devs[i]) return INTFFT_ERR_UNSUPPORTED; // RCCL: one rank per device
+            if (devs[j] == devs[i]) return INTFFT_ERR_TRANSPORT; // RCCL: one rank per device
     }
     std::vector<void *> comms(nplans, nullptr);
-    if (r.comm_init_all(comms.data(), nplans, devs.data()) != 0) return INTFFT_ERR_UNSUPPORTED;
-    for (int i = 0; i < nplans; ++i) plans[i]->rccl_comm = comms[i], plans[i]->rccl_rank = i, plans[i]->rccl_nranks = nplans;
+    const int st = r.comm_init_all(comms.data(), nplans, devs.data());
+    if (st != 0) {
+        rccl_report("ncclCommInitAll", st);
+        return INTFFT_ERR_TRANSPORT;
+    }
+    static std::atomic<uint64_t> next_set{1};
+    const uint64_t id = next_set.fetch_add(1);
+    for (int i = 0; i < nplans; ++i) {
+        plans[i]->rccl_comm = comms[i], plans[i]->rccl_rank = i, plans[i]->rccl_nranks = nplans;
+        plans[i]->rccl_set = id, plans[i]->rccl_owner = plans[0];
+    }
     plans[0]->rccl_owned = comms;
+    plans[0]->rccl_members.assign(plans, plans + nplans);
     return INTFFT_OK;
 }
 
-// the RCCL transport of intfft_exec_sharded: scatter group, transforms, gather group (every shard's operations on its own stream)
-static int exec_sharded_rccl(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
+// How many pieces a shard is cut into so that the gather of piece k overlaps the scatter of piece k + 1 on the full-duplex links
+// (end to end is link-bound; serial scatter -> transform -> gather pays both directions one after the other).
+// Pieces stay >= 2 MiB of input so that a piece still fills the chip and a link transfer is not latency-bound.
+static int shard_pieces(size_t frames, size_t in_frame)
+{
+    int want = 4;
+    if (const char *e = diag_env("INTFFT_SHARD_PIECES")) want = std::max(1, std::min(SHARD_EVENTS - 3, atoi(e)));
+    else want = (int)std::max<size_t>(1, std::min<size_t>(4, frames * in_frame / ((size_t)2 << 20)));
+    return (int)std::min<size_t>((size_t)want, std::max<size_t>(1, frames));
+}
+static void piece_range(size_t frames, int pieces, int k, size_t &first, size_t &cnt)
+{
+    const size_t base = frames / (size_t)pieces, rem = frames % (size_t)pieces;
+    first = (size_t)k * base + std::min<size_t>((size_t)k, rem);
+    cnt = base + ((size_t)k < rem ? 1 : 0);
+}
+
+// The asynchronous core of intfft_exec_sharded: everything is enqueued behind an event recorded on `user` (a stream of the root
+// device) and `user` waits for every stream that was used; no host synchronisation.  shard_ev: [0] entry (root plan), [1] done (per
+// plan: what the next call's first operation on this plan's streams waits for), [2] its first stream done, [3 + k] transform of piece k done.
+static int exec_sharded_enqueue(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch, hipStream_t user, bool use_rccl)
 {
     Rccl &r = rccl();
     intfft_plan *rp = plans[root];
@@ -1637,59 +1888,149 @@ static int exec_sharded_rccl(intfft_plan *const *plans, int nplans, int root, co
     const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
     hipError_t e = hipSuccess;
     int rc = INTFFT_OK, nc = 0;
+    const char *nc_what = "";
+    auto ck = [&](int st, const char *what) { // the first failing RCCL call is the one reported
+        if (st != 0 && nc == 0) nc = st, nc_what = what;
+    };
     std::vector<size_t> first(nplans, 0), cnt(nplans, 0);
+    size_t widest = 0;
     for (int i = 0, start = 0; i < nplans; ++i) {
         cnt[i] = shard_frames(batch, nplans, i);
         first[i] = (size_t)start;
         start += (int)cnt[i];
+        if (i != root) widest = std::max(widest, cnt[i]);
     }
-    for (int i = 0; i < nplans && e == hipSuccess; ++i) { // staging + streams (no-op after intfft_shard_prepare)
+    const int pieces = widest ? shard_pieces(widest, in_frame) : 1; // one schedule for all peers (shard sizes differ by one frame at most)
+    for (int i = 0; i < nplans && e == hipSuccess; ++i) { // staging + streams + events (no-op after intfft_shard_prepare)
         DeviceGuard g(plans[i]->device);
         if (!g.ok) return INTFFT_ERR_NO_DEVICE;
         e = shard_state(plans[i], rp->device, i == root ? 0 : cnt[i] * in_frame, i == root ? 0 : cnt[i] * out_frame);
     }
     if (e != hipSuccess) return (int)e;
-    // scatter: ONE group; the root's sends go out on all its links at once
-    nc |= r.group_start();
-    for (int i = 0; i < nplans; ++i) {
-        if (i == root || cnt[i] == 0) continue;
-        {
-            DeviceGuard g(rp->device);
-            nc |= r.send(static_cast<const char *>(d_in) + first[i] * in_frame, cnt[i] * in_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard);
+    {   // entry: every stream of the call starts behind the caller's stream and behind the previous call on these plans
+        DeviceGuard g(rp->device);
+        if (!g.ok) return INTFFT_ERR_NO_DEVICE;
+        if ((e = hipEventRecord(rp->shard_ev[0], user)) != hipSuccess) return (int)e;
+    }
+    for (int i = 0; i < nplans && e == hipSuccess; ++i) {
+        intfft_plan *pl = plans[i];
+        DeviceGuard g(pl->device);
+        for (hipStream_t st : {pl->s_shard, pl->s_shard2}) {
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, rp->shard_ev[0], 0);
+            if (e == hipSuccess && pl->shard_used) e = hipStreamWaitEvent(st, pl->shard_ev[1], 0);
         }
-        DeviceGuard g(plans[i]->device);
-        nc |= r.recv(plans[i]->shard_in, cnt[i] * in_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard);
     }
-    nc |= r.group_end();
-    for (int i = 0; i < nplans && nc == 0 && rc == INTFFT_OK; ++i) { // every device transforms its shard (stream order behind its receive)
-        if (cnt[i] == 0) continue;
-        DeviceGuard g(plans[i]->device);
-        rc = i == root ? intfft_exec(plans[i], static_cast<const char *>(d_in) + first[i] * in_frame, static_cast<char *>(d_out) + first[i] * out_frame,
-                                     cnt[i], plans[i]->s_shard)
-                       : intfft_exec(plans[i], plans[i]->shard_in, plans[i]->shard_out, cnt[i], plans[i]->s_shard);
+    if (e != hipSuccess) return (int)e;
+    // the root's own shard: one call on its second stream, beside its sends / the peers' copies
+    if (cnt[root]) {
+        DeviceGuard g(rp->device);
+        rc = intfft_exec(rp, static_cast<const char *>(d_in) + first[root] * in_frame, static_cast<char *>(d_out) + first[root] * out_frame, cnt[root], rp->s_shard2);
     }
-    if (nc == 0 && rc == INTFFT_OK) { // gather: one group
-        nc |= r.group_start();
-        for (int i = 0; i < nplans; ++i) {
-            if (i == root || cnt[i] == 0) continue;
-            {
-                DeviceGuard g(plans[i]->device);
-                nc |= r.send(plans[i]->shard_out, cnt[i] * out_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard);
+    if (!use_rccl) {
+        // peer copies: per peer, piece k goes in and is transformed on its first stream, and comes back on its second one -- the
+        // copy back of piece k beside the copy in of piece k + 1 (the links are full duplex)
+        for (int k = 0; k < pieces && e == hipSuccess && rc == INTFFT_OK; ++k)
+            for (int i = 0; i < nplans && e == hipSuccess && rc == INTFFT_OK; ++i) {
+                intfft_plan *pl = plans[i];
+                size_t pf, pn;
+                piece_range(cnt[i], pieces, k, pf, pn);
+                if (i == root || pn == 0) continue;
+                DeviceGuard g(pl->device);
+                if (!g.ok) {
+                    rc = INTFFT_ERR_NO_DEVICE;
+                    break;
+                }
+                const char *src = static_cast<const char *>(d_in) + (first[i] + pf) * in_frame;
+                char *dst = static_cast<char *>(d_out) + (first[i] + pf) * out_frame;
+                char *sin = static_cast<char *>(pl->shard_in) + pf * in_frame, *sout = static_cast<char *>(pl->shard_out) + pf * out_frame;
+                e = hipMemcpyPeerAsync(sin, pl->device, src, rp->device, pn * in_frame, pl->s_shard);
+                if (e != hipSuccess) break;
+                rc = intfft_exec(pl, sin, sout, pn, pl->s_shard);
+                if (rc != INTFFT_OK) break;
+                e = hipEventRecord(pl->shard_ev[3 + k], pl->s_shard);
+                if (e == hipSuccess) e = hipStreamWaitEvent(pl->s_shard2, pl->shard_ev[3 + k], 0);
+                if (e == hipSuccess) e = hipMemcpyPeerAsync(dst, rp->device, sout, pl->device, pn * out_frame, pl->s_shard2);
             }
-            DeviceGuard g(rp->device);
-            nc |= r.recv(static_cast<char *>(d_out) + first[i] * out_frame, cnt[i] * out_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard);
+    } else {
+        // RCCL: step t = ONE group of { scatter of piece t, gather of piece t - 1 } -- the root sends to and receives from every peer in
+        // the same group, so all its links run in both directions at once --, then the peers transform piece t.  (Operations of one
+        // communicator execute in issue order whatever their streams, so the overlap has to be inside a group.)
+        for (int t = 0; t <= pieces && nc == 0 && rc == INTFFT_OK; ++t) {
+            ck(r.group_start(), "ncclGroupStart");
+            for (int i = 0; i < nplans; ++i) {
+                if (i == root) continue;
+                size_t pf, pn;
+                if (t < pieces) {
+                    piece_range(cnt[i], pieces, t, pf, pn);
+                    if (pn) {
+                        {
+                            DeviceGuard g(rp->device);
+                            ck(r.send(static_cast<const char *>(d_in) + (first[i] + pf) * in_frame, pn * in_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard), "ncclSend (scatter)");
+                        }
+                        DeviceGuard g(plans[i]->device);
+                        ck(r.recv(static_cast<char *>(plans[i]->shard_in) + pf * in_frame, pn * in_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard), "ncclRecv (scatter)");
+                    }
+                }
+                if (t >= 1) {
+                    piece_range(cnt[i], pieces, t - 1, pf, pn);
+                    if (pn) {
+                        {
+                            DeviceGuard g(plans[i]->device);
+                            ck(r.send(static_cast<const char *>(plans[i]->shard_out) + pf * out_frame, pn * out_frame, NCCL_INT8, root, plans[i]->rccl_comm, plans[i]->s_shard), "ncclSend (gather)");
+                        }
+                        DeviceGuard g(rp->device);
+                        ck(r.recv(static_cast<char *>(d_out) + (first[i] + pf) * out_frame, pn * out_frame, NCCL_INT8, i, rp->rccl_comm, rp->s_shard), "ncclRecv (gather)");
+                    }
+                }
+            }
+            ck(r.group_end(), "ncclGroupEnd");
+            for (int i = 0; i < nplans && t < pieces && nc == 0 && rc == INTFFT_OK; ++i) { // stream order: behind the receive of piece t
+                size_t pf, pn;
+                piece_range(cnt[i], pieces, t, pf, pn);
+                if (i == root || pn == 0) continue;
+                DeviceGuard g(plans[i]->device);
+                rc = intfft_exec(plans[i], static_cast<char *>(plans[i]->shard_in) + pf * in_frame, static_cast<char *>(plans[i]->shard_out) + pf * out_frame, pn, plans[i]->s_shard);
+            }
         }
-        nc |= r.group_end();
     }
-    for (int i = 0; i < nplans; ++i) { // drain every stream that was used, also after an error
-        if (!plans[i]->s_shard) continue;
-        DeviceGuard g(plans[i]->device);
-        const hipError_t es = hipStreamSynchronize(plans[i]->s_shard);
-        if (e == hipSuccess) e = es;
+    // exit: the caller's stream waits for every stream of the call, also after an error (what was enqueued still runs)
+    for (int i = 0; i < nplans; ++i) {
+        intfft_plan *pl = plans[i];
+        DeviceGuard g(pl->device);
+        hipError_t ee = hipEventRecord(pl->shard_ev[2], pl->s_shard);
+        if (ee == hipSuccess) ee = hipStreamWaitEvent(pl->s_shard2, pl->shard_ev[2], 0);
+        if (ee == hipSuccess) ee = hipEventRecord(pl->shard_ev[1], pl->s_shard2); // done = both streams of this plan
+        if (ee == hipSuccess) {
+            DeviceGuard gr(rp->device);
+            ee = hipStreamWaitEvent(user, pl->shard_ev[1], 0);
+        }
+        pl->shard_used = true;
+        if (e == hipSuccess) e = ee;
     }
     if (rc != INTFFT_OK) return rc;
-    if (nc != 0) return (int)hipErrorUnknown; // an RCCL call failed (positive status = device-side error class, intfft_strerror)
+    if (nc != 0) {
+        rccl_report(nc_what, nc);
+        return INTFFT_ERR_TRANSPORT;
+    }
     return e == hipSuccess ? INTFFT_OK : (int)e;
+}
+
+static bool shard_uses_rccl(intfft_plan *const *plans, int nplans)
+{
+    bool use = true; // the whole set carries live communicators of this very set (one ncclCommInitAll: same set id, same owner)
+    for (int i = 0; i < nplans; ++i)
+        use = use && plans[i]->rccl_comm && plans[i]->rccl_rank == i && plans[i]->rccl_nranks == nplans && plans[i]->rccl_set != 0 &&
+              plans[i]->rccl_set == plans[0]->rccl_set && plans[i]->rccl_owner == plans[0]->rccl_owner;
+    return use;
+}
+
+int intfft_exec_sharded_async(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch, void *hip_stream)
+{
+    const int rc = shard_check(plans, nplans, root);
+    if (rc != INTFFT_OK) return rc;
+    if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
+    if (batch == 0) return INTFFT_OK;
+    return exec_sharded_enqueue(plans, nplans, root, d_in, d_out, batch, reinterpret_cast<hipStream_t>(hip_stream), shard_uses_rccl(plans, nplans));
 }
 
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch)
@@ -1698,58 +2039,26 @@ int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const v
     if (rc != INTFFT_OK) return rc;
     if (batch && (!d_in || !d_out)) return INTFFT_ERR_NULL;
     if (batch == 0) return INTFFT_OK;
-    bool use_rccl = true; // the whole set carries communicators of this very set
-    for (int i = 0; i < nplans; ++i) use_rccl = use_rccl && plans[i]->rccl_comm && plans[i]->rccl_rank == i && plans[i]->rccl_nranks == nplans;
-    if (use_rccl) {
-        {   // same entry contract as the peer-copy transport
-            DeviceGuard g(plans[root]->device);
-            if (!g.ok) return INTFFT_ERR_NO_DEVICE;
-            const hipError_t es = hipDeviceSynchronize();
-            if (es != hipSuccess) return (int)es;
-        }
-        return exec_sharded_rccl(plans, nplans, root, d_in, d_out, batch);
-    }
     intfft_plan *rp = plans[root];
-    const size_t N = (size_t)1 << rp->L;
-    const size_t in_frame = N * 2 * (size_t)rp->in_cb, out_frame = N * 2 * (size_t)rp->out_cb;
     hipError_t e = hipSuccess;
     {   // contract (intfft.h): d_in is complete once every stream of the root device is idle
         DeviceGuard g(rp->device);
         if (!g.ok) return INTFFT_ERR_NO_DEVICE;
         e = hipDeviceSynchronize();
+        if (e == hipSuccess && !rp->s_call) e = hipStreamCreateWithFlags(&rp->s_call, hipStreamNonBlocking);
+        if (e != hipSuccess) return (int)e;
     }
-    size_t start = 0;
-    for (int i = 0; i < nplans && e == hipSuccess && rc == INTFFT_OK; ++i) {
-        intfft_plan *pl = plans[i];
-        const size_t nf = shard_frames(batch, nplans, i);
-        const char *src = static_cast<const char *>(d_in) + start * in_frame;
-        char *dst = static_cast<char *>(d_out) + start * out_frame;
-        start += nf;
-        if (nf == 0) continue;
-        DeviceGuard g(pl->device);
-        if (!g.ok) {
-            rc = INTFFT_ERR_NO_DEVICE; // fall through to the drain loop: earlier shards are still in flight
-            break;
+    rc = exec_sharded_enqueue(plans, nplans, root, d_in, d_out, batch, rp->s_call, shard_uses_rccl(plans, nplans));
+    {
+        DeviceGuard g(rp->device);
+        e = hipStreamSynchronize(rp->s_call);
+    }
+    if (rc != INTFFT_OK || e != hipSuccess)
+        for (int i = 0; i < nplans; ++i) { // after an error: drain every stream that was used
+            DeviceGuard g(plans[i]->device);
+            for (hipStream_t st : {plans[i]->s_shard, plans[i]->s_shard2})
+                if (st) (void)hipStreamSynchronize(st);
         }
-        // no-op after intfft_shard_prepare with max_batch >= batch
-        e = shard_state(pl, rp->device, i == root ? 0 : nf * in_frame, i == root ? 0 : nf * out_frame);
-        if (e != hipSuccess) break;
-        if (i == root) {
-            rc = intfft_exec(pl, src, dst, nf, pl->s_shard);
-            continue;
-        }
-        e = hipMemcpyPeerAsync(pl->shard_in, pl->device, src, rp->device, nf * in_frame, pl->s_shard);
-        if (e != hipSuccess) break;
-        rc = intfft_exec(pl, pl->shard_in, pl->shard_out, nf, pl->s_shard);
-        if (rc != INTFFT_OK) break;
-        e = hipMemcpyPeerAsync(dst, rp->device, pl->shard_out, pl->device, nf * out_frame, pl->s_shard);
-    }
-    for (int i = 0; i < nplans; ++i) { // drain every stream that was used, also after an error
-        if (!plans[i]->s_shard) continue;
-        DeviceGuard g(plans[i]->device);
-        const hipError_t es = hipStreamSynchronize(plans[i]->s_shard);
-        if (e == hipSuccess) e = es;
-    }
     if (rc != INTFFT_OK) return rc;
     return e == hipSuccess ? INTFFT_OK : (int)e;
 }
@@ -1777,7 +2086,8 @@ const char *intfft_strerror(int status)
     switch (status) {
     case INTFFT_OK: return "ok";
     case INTFFT_ERR_INVALID: return "invalid parameter";
-    case INTFFT_ERR_UNSUPPORTED: return "generic combination does not elaborate in the reference RTL";
+    case INTFFT_ERR_UNSUPPORTED: return "unsupported configuration (the generic combination does not elaborate in the reference RTL, or the 2-D scheme does not cover it)";
+    case INTFFT_ERR_TRANSPORT: return "shard transport unavailable or failed (RCCL not loadable, two plans on one device, or an RCCL call failed)";
     case INTFFT_ERR_NULL: return "null argument";
     case INTFFT_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
     case INTFFT_ERR_ALLOC: return "host allocation failed";

@@ -149,6 +149,38 @@ class IntFFTCore:
         """Straight intfft_exec on raw device pointers (bench loop: no tensor bookkeeping)."""
         capi.check(capi.lib().intfft_exec(self._plan, in_ptr, out_ptr, batch, stream), "intfft_exec")
 
+    def workspace_bytes(self, batch: int) -> int:
+        """intfft_plan_workspace_bytes: the caller-supplied workspace with which exec_ws(batch frames) runs like the plan-owned scratch
+        (0 for single-launch plans)."""
+        n = ctypes.c_size_t()
+        capi.check(capi.lib().intfft_plan_workspace_bytes(self._plan, batch, ctypes.byref(n)), "intfft_plan_workspace_bytes")
+        return n.value
+
+    def exec_ws(self, x, workspace=None, out=None):
+        """The transform on a caller-supplied workspace (intfft_exec_ws): re-entrant for every plan -- one core may run on several
+        streams at once, each call with its own workspace (a uint8 / any-dtype device tensor of >= workspace_bytes(1) bytes, 256-byte
+        aligned as torch allocations are; None for single-launch plans)."""
+        torch = _torch()
+        if not (x.is_cuda and x.device.index == self.device) or x.dtype != self.in_dtype or x.dim() != 3 or x.shape[1] != self.n or x.shape[2] != 2:
+            raise ValueError("input must be a [batch, %d, 2] %s tensor on cuda:%d" % (self.n, self.in_dtype, self.device))
+        x = x.contiguous()
+        batch = x.shape[0]
+        if out is None:
+            out = torch.empty(self.out_shape(batch), dtype=self.out_dtype, device=x.device)
+        elif out.dtype != self.out_dtype or tuple(out.shape) != self.out_shape(batch) or not out.is_contiguous():
+            raise ValueError("bad `out` tensor")
+        ws_ptr, ws_bytes = (0, 0) if workspace is None else (workspace.data_ptr(), workspace.numel() * workspace.element_size())
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        capi.check(capi.lib().intfft_exec_ws(self._plan, x.data_ptr(), out.data_ptr(), batch, ws_ptr, ws_bytes, stream), "intfft_exec_ws")
+        return out
+
+    def release_scratch(self):
+        """intfft_plan_release_scratch: frees the plan-owned scratch; afterwards only exec_ws runs this core."""
+        capi.check(capi.lib().intfft_plan_release_scratch(self._plan), "intfft_plan_release_scratch")
+        info = capi.PlanInfo()
+        capi.check(capi.lib().intfft_plan_get_info(self._plan, ctypes.byref(info)), "intfft_plan_get_info")
+        self.info["scratch_bytes"] = info.scratch_bytes
+
     def exec_host(self, x: np.ndarray, chunk_frames: int = 0) -> np.ndarray:
         """Host-resident frames through intfft_exec_host: chunked, double-buffered H2D / transform / D2H
         on three streams (every frame is still transformed on the GPU)."""
@@ -212,12 +244,14 @@ def int_fft_2d(NFFT=20, NFFT1=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=0, RNDMOD
                       NFFT1=NFFT1)
 
 
-def exec_sharded(cores, x, root: int = 0, transport: str = None):
+def exec_sharded(cores, x, root: int = 0, transport: str = None, asynchronous: bool = False):
     """Single-process multi-GPU transform through intfft_exec_sharded: `cores` are IntFFTCore objects with identical
     generics (normally one per HIP device), `x` a [batch, N, 2] tensor on the device of cores[root].  Contiguous
     shards, remainder to the last cores, no collective.  transport: None (leave the plan set as it is: peer copies unless
     changed earlier), "peer" (hipMemcpyPeerAsync) or "rccl" (grouped ncclSend / ncclRecv over xGMI, one group each way;
-    raises if RCCL cannot serve the set, e.g. two cores on one device).  Blocking."""
+    raises if RCCL cannot serve the set, e.g. two cores on one device).  Blocking -- or, with asynchronous=True,
+    intfft_exec_sharded_async on torch's current stream of the root device: no host synchronisation, the result is ordered on that
+    stream like any other kernel's."""
     import torch
 
     if not cores or not 0 <= root < len(cores):
@@ -236,6 +270,11 @@ def exec_sharded(cores, x, root: int = 0, transport: str = None):
             raise ValueError("transport must be 'peer' or 'rccl'")
         capi.check(capi.lib().intfft_shard_set_transport(arr, len(cores), root, capi.TRANSPORT_RCCL if transport == "rccl" else capi.TRANSPORT_PEER),
                    "intfft_shard_set_transport")
+    if asynchronous:
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        capi.check(capi.lib().intfft_exec_sharded_async(arr, len(cores), root, x.data_ptr(), y.data_ptr(), x.shape[0], stream),
+                   "intfft_exec_sharded_async")
+        return y
     torch.cuda.synchronize(x.device)
     capi.check(capi.lib().intfft_exec_sharded(arr, len(cores), root, x.data_ptr(), y.data_ptr(), x.shape[0]),
                "intfft_exec_sharded")

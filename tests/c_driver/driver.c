@@ -43,7 +43,7 @@ static int run_single_path(const int16_t *h_frames, void *h_out, size_t batch, i
 /* ---- driver --sharded: the batch over every visible HIP device ------------------------------------------
  * One plan per device, the frames on device 0; intfft_exec_sharded cuts contiguous shards and moves them with the transport asked for:
  * transport = 1: RCCL (one group of ncclSend / ncclRecv each way, intfft_shard_set_transport), 0: peer copies.  Returns the library's
- * status (INTFFT_ERR_UNSUPPORTED from the transport call is reported and the run continues on peer copies). */
+ * status (INTFFT_ERR_TRANSPORT from the transport call is reported and the run continues on peer copies). */
 static int run_sharded(const int16_t *h_frames, void *h_out, size_t batch, int nfft, int mode, int transport, int *used_rccl)
 {
     intfft_params p = {.log2n = nfft, .data_width = 16, .twdl_width = 16, .format = mode / 2, .rndmode = mode % 2,
@@ -67,7 +67,7 @@ static int run_sharded(const int16_t *h_frames, void *h_out, size_t batch, int n
     if (!rc && transport == INTFFT_TRANSPORT_RCCL) {
         const int rt = intfft_shard_set_transport(plans, ndev, 0, INTFFT_TRANSPORT_RCCL);
         if (rt == INTFFT_OK) *used_rccl = 1;
-        else if (rt != INTFFT_ERR_UNSUPPORTED) rc = rt;
+        else if (rt != INTFFT_ERR_TRANSPORT) rc = rt;
     }
     if (!rc) rc = intfft_exec_sharded(plans, ndev, 0, d_in, d_out, batch); /* blocking */
     if (!rc && hipMemcpy(h_out, d_out, batch * n * 2 * out_c, hipMemcpyDeviceToHost) != hipSuccess) rc = 1002;

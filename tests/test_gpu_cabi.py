@@ -232,7 +232,8 @@ def test_exec_sharded_rccl_transport_equals_peer_copies():
     # one rank per device: a set with two plans on device 0 cannot have communicators; it keeps working on peer copies
     twin = IntFFTCore(10, 16, 16, 0, 0, "NEW", "FWD", device=0)
     arr = (ctypes.c_void_p * 2)(cores[0]._plan, twin._plan)
-    assert capi.lib().intfft_shard_set_transport(arr, 2, 0, capi.TRANSPORT_RCCL) == capi.ERR_UNSUPPORTED
+    assert capi.lib().intfft_shard_set_transport(arr, 2, 0, capi.TRANSPORT_RCCL) == capi.ERR_TRANSPORT
+    assert "transport" in capi.strerror(capi.ERR_TRANSPORT)
     assert capi.lib().intfft_shard_set_transport(arr, 2, 0, 7) == capi.ERR_INVALID
     assert torch.equal(exec_sharded([cores[0], twin], xd, 0), y_peer)
     twin.close()
@@ -452,6 +453,188 @@ def test_single_launch_plans_are_reentrant_across_streams(cfg):
     for y, w in zip(ys, want):
         assert torch.equal(y, w)
     core.close()
+
+
+WS_CASES = [
+    # (log2n, dw, tw, fmt, rnd, direction, l1, batch, INTFFT_SCRATCH_MB): every kind of plan that owns scratch
+    (16, 16, 16, 0, 0, "FWD", 0, 24, 1),    # two passes, one scratch on the caller's stream: 4 frames per chunk
+    (20, 16, 16, 0, 0, "FWD", 0, 9, 8),     # two passes, two scratch halves on two streams: 2 frames per chunk
+    (16, 24, 24, 1, 0, "FWD", 0, 21, 4),    # the 24-bit class (int32 -> int64), two streams
+    (20, 16, 16, 0, 0, "FWD", 10, 7, 8),    # the tiled 2-D plan: two launches, two streams
+    (21, 16, 16, 0, 0, "FWD", 10, 3, 16),   # 2-D, three launches with a row sub-plan
+    (14, 18, 16, 0, 0, "FWD", 6, 9, 1),     # composite 2-D plan on sub-plans
+    (14, 18, 16, 0, 0, "PAIR", 0, 20, 1),   # composite pair: middle buffer + two sub-plans with scratch of their own
+    (13, 32, 16, 1, 0, "INV", 0, 11, 1),    # the generic 64-bit passes
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_every_plan_is_reentrant_on_caller_workspaces(case, monkeypatch):
+    """intfft_exec_ws: ONE plan, two streams at once, each call with its own workspace -- bit-exact against the oracle and against
+    intfft_exec on the plan's own scratch.  Then: an under-sized workspace (sub-batches), a workspace that cannot serve one frame (refused),
+    overlap with the data (refused), and the plan with its own scratch released (intfft_exec refuses, intfft_exec_ws still runs)."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+    from intfftk_amd import _capi as capi
+
+    log2n, dw, tw, fmt, rnd, direction, l1, batch, mb = case
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", str(mb))  # small chunks: the chunk loops (and the two-stream alternation) run on small batches
+    n = 1 << log2n
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, "NATURAL", "NATURAL", NFFT1=l1)
+    assert core.info["scratch_bytes"] > 0, core.info
+    need = core.workspace_bytes(batch)
+    assert 0 < core.workspace_bytes(1) <= need <= core.workspace_bytes(10 * batch) and need % 256 == 0
+    npdt = {2: np.int16, 4: np.int32, 8: np.int64}[core.in_container]
+    xs = [uniform_frames(batch, n, dw - 1, 700 + 13 * i + log2n) for i in range(2)]
+    xd = [torch.from_numpy(x.astype(npdt)).cuda() for x in xs]
+    p = C.make_params(log2n, dw, tw, fmt, rnd, True)
+    d = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
+    want = [C.execute_2d(x, p, l1, d) if l1 else C.execute(x, p, d) for x in xs]
+    own = [core(x) for x in xd]
+    for o, w in zip(own, want):
+        assert np.array_equal(o.cpu().numpy().astype(np.int64), w)
+    wss = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    ys = [torch.zeros_like(o) for o in own]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep_ in range(3):  # interleaved calls, no host synchronisation in between
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                core.exec_ws(xd[i], wss[i], out=ys[i])
+    torch.cuda.synchronize()
+    for y, o in zip(ys, own):
+        assert torch.equal(y, o)
+    # an under-sized workspace: the largest sub-batches it serves; one byte short of a frame: refused
+    small = core.workspace_bytes(max(1, batch // 3))
+    if small < need:
+        y = core.exec_ws(xd[0], torch.empty(small, dtype=torch.uint8, device="cuda"))
+        assert torch.equal(y, own[0])
+    one = core.workspace_bytes(1)
+    with pytest.raises(capi.IntFFTError) as ei:
+        core.exec_ws(xd[0], torch.empty(one - 256, dtype=torch.uint8, device="cuda"))
+    assert ei.value.status == capi.ERR_INVALID
+    with pytest.raises(capi.IntFFTError):
+        core.exec_ws(xd[0], None)
+    st = capi.lib().intfft_exec_ws(core._plan, xd[0].data_ptr(), ys[0].data_ptr(), batch, xd[0].data_ptr(), need, None)
+    assert st == capi.ERR_INVALID  # workspace overlaps the input
+    st = capi.lib().intfft_exec_ws(core._plan, xd[0].data_ptr(), ys[0].data_ptr(), batch, wss[0].data_ptr() + 4, need - 4, None)
+    assert st == capi.ERR_INVALID  # not 256-byte aligned
+    # the plan without its own scratch
+    core.release_scratch()
+    assert core.info["scratch_bytes"] == 0
+    with pytest.raises(capi.IntFFTError) as ei:
+        core(xd[0])
+    assert ei.value.status == capi.ERR_INVALID
+    ys[1].zero_()
+    core.exec_ws(xd[1], wss[1], out=ys[1])
+    assert torch.equal(ys[1], own[1])
+    core.close()
+
+
+def test_exec_ws_on_single_launch_plans_needs_no_workspace():
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    core = IntFFTCore(10, 16, 16, 0, 0, "NEW", "FWD", "NATURAL", "NATURAL")
+    assert core.workspace_bytes(4096) == 0
+    x = torch.from_numpy(uniform_frames(33, 1024, 15, 4).astype(np.int16)).cuda()
+    assert torch.equal(core.exec_ws(x), core(x))
+    core.release_scratch()  # nothing to free, but the switch is the same for every plan: only exec_ws runs it from here on
+    assert torch.equal(core.exec_ws(x, None), core.exec_ws(x))
+    core.close()
+
+
+def test_exec_ws_from_two_host_threads():
+    """Two host threads, one plan (two-stream N = 2^20 plan: the side stream comes from the plan's pool), each thread with its own stream and
+    workspace, 6 calls each: same bits as the plan's own scratch."""
+    import threading
+
+    import torch
+
+    from intfftk_amd import IntFFTCore
+
+    os.environ["INTFFT_SCRATCH_MB"] = "8"
+    try:
+        core = IntFFTCore(20, 16, 16, 0, 0, "NEW", "FWD", "NATURAL", "NATURAL")
+    finally:
+        del os.environ["INTFFT_SCRATCH_MB"]
+    batch = 7
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    xs = [torch.randint(-(1 << 14), 1 << 14, (batch, 1 << 20, 2), device="cuda", dtype=torch.int16, generator=g) for _ in range(2)]
+    want = [core(x) for x in xs]
+    need = core.workspace_bytes(batch)
+    ys = [torch.zeros_like(w) for w in want]
+    wss = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(6):
+                    core.exec_ws(xs[i], wss[i], out=ys[i])
+            st.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for y, w in zip(ys, want):
+        assert torch.equal(y, w)
+    core.close()
+
+
+@pytest.mark.parametrize("pieces", [None, 1, 3, 8])
+def test_exec_sharded_async_equals_blocking(pieces, monkeypatch):
+    """intfft_exec_sharded_async: no host synchronisation -- the input is produced on the caller's stream right before the call and the
+    result consumed on it right after; shards move in pieces (INTFFT_SHARD_PIECES; default: up to 4 of >= 2 MiB) with the copy back of piece
+    k beside the copy in of piece k + 1.  Bit-equal to the blocking call and the oracle; three plans per visible device (on a single-GPU box
+    all of them share it: the peer copies become local copies, the schedule is the same), ragged batch, back-to-back calls, another root."""
+    import torch
+
+    from intfftk_amd import IntFFTCore, exec_sharded
+    from intfftk_amd import _capi as capi
+
+    if pieces is not None:
+        monkeypatch.setenv("INTFFT_SHARD_PIECES", str(pieces))
+    ndev = torch.cuda.device_count()
+    nplans = max(3, ndev)
+    cores = [IntFFTCore(12, 16, 16, 0, 0, "NEW", "PAIR", device=i % ndev) for i in range(nplans)]
+    arr = (ctypes.c_void_p * nplans)(*[c._plan for c in cores])
+    batch = 1031  # 1031 = 343 + 344 + 344 frames of 16 KiB: 5.4 MiB per shard
+    assert capi.lib().intfft_shard_prepare(arr, nplans, 0, batch) == 0
+    x = uniform_frames(batch, 4096, 15, 21)
+    want = C.execute(x, C.make_params(12, 16, 16, 0, 0, True), C.PAIR)
+    xh = torch.from_numpy(x.astype(np.int16)).pin_memory()
+    y_block = exec_sharded(cores, xh.to("cuda:0"), 0)
+    assert np.array_equal(y_block.cpu().numpy().astype(np.int64), want)
+    s = torch.cuda.Stream(device=0)
+    with torch.cuda.stream(s):
+        outs = []
+        for rep_ in range(3):  # produced on s, transformed behind it, consumed on s: no synchronisation anywhere
+            xd = xh.to("cuda:0", non_blocking=True)
+            xd2 = xd + 0  # a kernel on s the call has to wait for
+            y = exec_sharded(cores, xd2, 0, asynchronous=True)
+            outs.append(y.clone())  # a kernel on s that has to wait for the call
+    s.synchronize()
+    for y in outs:
+        assert torch.equal(y, y_block)
+    root = 1
+    xd = xh.to("cuda:%d" % (root % ndev))
+    torch.cuda.synchronize()
+    y1 = exec_sharded(cores, xd, root, asynchronous=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.cpu(), y_block.cpu())
+    for c in cores:
+        c.close()
 
 
 GUARD_CASES = [
