@@ -513,6 +513,22 @@ def main():
             if it >= 3:
                 times.append(time.perf_counter() - t0)
         t_e2e = max_over_ranks(sum(times) / len(times), red_dev)
+        groups_serial = sh.last_group_sizes[-2:]
+        # the same end to end as a pipeline: shards in 4 pieces, the gather of piece k in ONE group with the scatter of piece k + 1
+        # (full-duplex links), the root's own shard beside the first group
+        times_p = []
+        for it in range(2 + 5):
+            barrier()
+            t0 = time.perf_counter()
+            res_p = sh.run_from_root_pipelined(root_x, total, 0, pieces=4)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            if it >= 2:
+                times_p.append(time.perf_counter() - t0)
+        t_pipe = max_over_ranks(sum(times_p) / len(times_p), red_dev)
+        ok_p = bool(torch.equal(res_p, res)) if rank == 0 else None
+        del res_p
         ok = None
         if rank == 0:  # same rows as the resident transform of rank 0's own shard
             ok = bool(torch.equal(res[:batch], core(root_x[:batch])))
@@ -546,7 +562,11 @@ def main():
                "link_GBps": None if link is None else min(link["scatter_link_GBps"], link["gather_link_GBps"]),
                "mode": "root scatter -> transform -> gather, one batch_isend_irecv group each way "
                        "(%s)" % ("gloo via host staging: diagnostics" if share else "RCCL: ncclGroupStart/ncclSend,Recv/ncclGroupEnd"),
-               "p2p_ops_per_group": sh.last_group_sizes[-2:], "matches_resident": ok}
+               "p2p_ops_per_group": groups_serial, "matches_resident": ok,
+               "pipelined": {"value": total * n / t_pipe / 1e9, "unit": "Gsample/s", "ms": t_pipe * 1e3, "pieces": 4,
+                             "speedup_over_serial": t_e2e / t_pipe, "matches_serial": ok_p,
+                             "mode": "5 groups: step t = scatter of piece t + gather of piece t - 1 in one ncclGroupStart .. ncclGroupEnd; "
+                                     "cannot show a gain on one GPU (no peers: the groups are empty)"}}
         del root_x, res
 
     if rank == 0:

@@ -58,9 +58,19 @@ class ShardedTransform:
         self.last_group_sizes.append(len(ops))
         if not ops:
             return
-        p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, self.group) for kind, t, peer in ops]
-        for req in dist.batch_isend_irecv(p2p):
+        for req in self._issue_group(ops, count=False):
             req.wait()
+
+    def _issue_group(self, ops, count=True):
+        """Issues ONE batch_isend_irecv group and returns its requests without waiting (what runs between issue and wait overlaps the
+        transfers: the root's own transform in the pipelined schedule)."""
+        dist = self.dist
+        if count:
+            self.last_group_sizes.append(len(ops))
+        if not ops:
+            return []
+        p2p = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, self.group) for kind, t, peer in ops]
+        return dist.batch_isend_irecv(p2p)
 
     # -- data movement ------------------------------------------------------------------------
     def scatter(self, root_batch, batch: int, root: int = 0):
@@ -77,7 +87,7 @@ class ShardedTransform:
                     if self.stage_via_cpu:
                         piece = piece.cpu()
                     ops.append(("send", piece.contiguous(), r))
-            local = root_batch[lo:hi].clone()  # the root keeps its shard by local copy
+            local = root_batch[lo:hi]  # the root keeps its shard where it is: a view of its rows, no copy
             self._run_group(ops)
             return local
         local = torch.empty((hi - lo, self.n, 2), dtype=self.in_dtype, device="cpu" if self.stage_via_cpu else self.device)
@@ -123,6 +133,79 @@ class ShardedTransform:
         local = self.scatter(root_batch, batch, root)
         res = self.transform(local) if local.shape[0] else local.new_empty((0,) + self.out_sample_shape, dtype=self.out_dtype)
         return self.gather(res, batch, root)
+
+
+    def run_from_root_pipelined(self, root_batch, batch: int, root: int = 0, pieces: int = 4):
+        """End-to-end as a pipeline (this path is link-bound, and xGMI links are full duplex): every shard is cut into
+        `pieces` pieces and step t = 0 .. pieces is ONE point-to-point group holding the scatter of piece t AND the gather of piece t - 1
+        (on RCCL one ncclGroupStart .. ncclGroupEnd: the root sends to and receives from every peer at once), after which the peers
+        transform piece t.  The root transforms its own shard while the first group is in flight.  pieces + 1 groups of <= 2 (world - 1)
+        operations on the root instead of 2 groups; the same rows as run_from_root."""
+        import torch
+
+        if pieces < 1:
+            raise ValueError("pieces must be >= 1")
+        bounds = shard_bounds(batch, self.world)
+        lo, hi = bounds[self.rank]
+        dev = "cpu" if self.stage_via_cpu else self.device
+
+        def piece(r, k):  # [start, stop) of piece k of rank r's shard, in rows of the whole batch
+            a, b = bounds[r]
+            pa, pb = shard_bounds(b - a, pieces)[k]
+            return a + pa, a + pb
+
+        if self.rank == root:
+            out = torch.empty((batch,) + self.out_sample_shape, dtype=self.out_dtype, device=self.device)
+            staged = []
+            for t in range(pieces + 1):
+                ops, keep = [], []
+                for r in range(self.world):
+                    if r == root:
+                        continue
+                    if t < pieces:
+                        a, b = piece(r, t)
+                        if b > a:
+                            src = root_batch[a:b].cpu() if self.stage_via_cpu else root_batch[a:b]
+                            keep.append(src)
+                            ops.append(("send", src.contiguous(), r))
+                    if t >= 1:
+                        a, b = piece(r, t - 1)
+                        if b > a:
+                            if self.stage_via_cpu:
+                                buf = torch.empty((b - a,) + self.out_sample_shape, dtype=self.out_dtype, device="cpu")
+                                staged.append((a, b, buf))
+                                ops.append(("recv", buf, r))
+                            else:
+                                ops.append(("recv", out[a:b], r))
+                reqs = self._issue_group(ops)
+                if t == 0 and hi > lo:  # the root's own shard, beside the first group
+                    out[lo:hi] = self.transform(root_batch[lo:hi])
+                for req in reqs:
+                    req.wait()
+            for a, b, buf in staged:
+                out[a:b] = buf.to(self.device)
+            return out
+        local = torch.empty((hi - lo, self.n, 2), dtype=self.in_dtype, device=dev)
+        res = torch.empty((hi - lo,) + self.out_sample_shape, dtype=self.out_dtype, device=dev)
+        for t in range(pieces + 1):
+            ops = []
+            if t < pieces:
+                a, b = piece(self.rank, t)
+                if b > a:
+                    ops.append(("recv", local[a - lo:b - lo], root))
+            if t >= 1:
+                a, b = piece(self.rank, t - 1)
+                if b > a:
+                    ops.append(("send", res[a - lo:b - lo], root))
+            for req in self._issue_group(ops):
+                req.wait()
+            if t < pieces:
+                a, b = piece(self.rank, t)
+                if b > a:
+                    x = local[a - lo:b - lo]
+                    y = self.transform(x.to(self.device) if self.stage_via_cpu else x)
+                    res[a - lo:b - lo] = y.cpu() if self.stage_via_cpu else y
+        return None
 
 
 def max_over_ranks(seconds: float, device=None, group=None) -> float:

@@ -328,6 +328,7 @@ def test_bench_spawns_n_ranks():
     assert len(out["per_gpu"]["kernel_ms"]) == 2 and all(v > 0 for v in out["per_gpu"]["Gsample/s"])
     assert out["e2e"]["matches_resident"] is True and out["e2e"]["frames"] == 4096
     assert out["e2e"]["p2p_ops_per_group"] == [1, 1]  # the root's scatter group and gather group: one peer each
+    assert out["e2e"]["pipelined"]["matches_serial"] is True and out["e2e"]["pipelined"]["pieces"] == 4 and out["e2e"]["pipelined"]["value"] > 0
     assert out["scaling"] == "weak" and out["unit"] == "Gsample/s"
 
 

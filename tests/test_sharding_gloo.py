@@ -61,6 +61,23 @@ def _worker(rank, world, port, batch, q):
             ok = torch.equal(out, want)
         else:
             ok = out is None
+        # the pipelined schedule: pieces + 1 groups; step t holds the scatter of piece t and the gather of piece t - 1
+        for pieces in (1, 3, 4):
+            sh.last_group_sizes.clear()
+            outp = sh.run_from_root_pipelined(full if rank == 0 else None, batch, root=0, pieces=pieces)
+            ok = ok and (torch.equal(outp, want) if rank == 0 else outp is None)
+            b_all = shard_bounds(batch, world)
+
+            def nonempty(r, k):
+                a, b = b_all[r]
+                pa, pb = shard_bounds(b - a, pieces)[k]
+                return pb > pa
+
+            sizes = []
+            for t in range(pieces + 1):
+                who = [r for r in range(world) if r != 0] if rank == 0 else [rank]
+                sizes.append(sum(1 for r in who if t < pieces and nonempty(r, t)) + sum(1 for r in who if t >= 1 and nonempty(r, t - 1)))
+            ok = ok and sh.last_group_sizes == sizes and len(sizes) == pieces + 1
         # data-resident mode: each rank transforms its own shard; rows equal the unsharded result
         lo, hi = shard_bounds(batch, world)[rank]
         loc = sh.run_resident(full[lo:hi])
