@@ -77,8 +77,24 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWX);
     const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
     // blocks b and b + 8 (same XCD, same time) take the two 64-byte halves of the same lines: chunk = (column group g, part)
-    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
+    // INTFFT_2XA_MAP (round-5 A/B variants, tools/build_variant.sh: which tiles an XCD holds at the same time; profiles/r05_c4_variants.md):
+    //   0 (shipped)  XCD s takes the column lines s, s + 8, s + 16, s + 24 of every frame
+    //   1            XCD s takes whole frames s, s + 8, ... (all 32 column lines of a frame at once; needs groups % 8 == 0)
+    //   2            as 0 with the lines rotated by the frame number (an XCD sees every line offset across its 8 concurrent frames)
+#ifndef INTFFT_2XA_MAP
+#define INTFFT_2XA_MAP 0
+#endif
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+#if INTFFT_2XA_MAP == 1
+    const unsigned jm = blockIdx.x >> 4;
+    const unsigned chunk = (jm & 31u) * 2u + part, grp = (jm >> 5) * 8u + slot;
+#elif INTFFT_2XA_MAP == 2
+    const unsigned G = (blockIdx.x >> 4) * 8u + slot, grp = G >> 5;
+    const unsigned chunk = ((G + grp) & 31u) * 2u + part;
+#else
+    const unsigned G = (blockIdx.x >> 4) * 8u + slot;
     const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+#endif
     const unsigned lfull = chunk * 16 + l;              // n9..n0
     const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
     auto ld = [&](unsigned uniform_idx, unsigned thread_boff, u32 &wa, u32 &wb) { // thread_boff: BYTE offset of the thread's entry

@@ -41,7 +41,37 @@ __global__ __launch_bounds__(T) void tilecopy(const u32 *in, u32 *out, Geo gr, G
     const size_t rbase = thread_base(gr, tid), wbase = thread_base(gw, tid);
     u32 v[NREG], w[NREG];
     auto where = [&](size_t t, size_t &frame, unsigned &chunk) {
-        if (order) {
+        if (order == 2 || order == 3) { // the XCD pairing of k_big2x_a: blocks b and b + 8 (one XCD, same time) take the two halves of the same lines
+            const unsigned slot = (unsigned)t & 7u, part = ((unsigned)t >> 3) & 1u;
+            const unsigned half = nch >> 1; // column lines per frame
+            if (order == 2) { // XCD s: lines s, s + 8, ... of every frame (shipped)
+                const size_t G = (t >> 4) * 8u + slot;
+                chunk = (unsigned)(G % half) * 2u + part;
+                frame = G / half;
+            } else { // XCD s: whole frames s, s + 8, ...
+                const size_t jm = t >> 4;
+                chunk = (unsigned)(jm % half) * 2u + part;
+                frame = (jm / half) * 8u + slot;
+            }
+            if (frame >= nframes) frame = nframes - 1; // (ragged tails do not occur with nframes % 8 == 0)
+        } else if (order == 4 || order == 5) { // quarter-line pieces (32 B): the four pieces of a line from blocks b, b + 8, b + 16, b + 24 of one XCD at
+            // the same time (4), or from ONE block in four consecutive iterations (5)
+            const unsigned lines = nch >> 2;
+            size_t G;
+            unsigned quad;
+            if (order == 4) {
+                const unsigned slot = (unsigned)t & 7u;
+                quad = ((unsigned)t >> 3) & 3u;
+                G = (t >> 5) * 8u + slot;
+            } else {
+                const size_t k = t / gridDim.x, b = t % gridDim.x;
+                quad = (unsigned)k & 3u;
+                G = (k >> 2) * gridDim.x + b;
+            }
+            chunk = (unsigned)(G % lines) * 4u + quad;
+            frame = G / lines;
+            if (frame >= nframes) frame = nframes - 1;
+        } else if (order) {
             frame = t % nframes;
             chunk = (unsigned)(t / nframes);
         } else {
@@ -178,6 +208,35 @@ int main(int argc, char **argv)
         RUN("p1 1024r x  64B @4K", 512, 32, 1, 0, g64, g64, 64 * 1024, 2, order);
         RUN("p1 1024r x  64B @4K", 512, 32, 1, 1, g64, g64, 64 * 1024, 2, order);
         RUN("p1 1024r x 256B @4K", 1024, 64, 1, 0, g256, g256, 128 * 1024, 1, order);
+    }
+    // --- round 5: (a) the half-line tile of k_big2x_a WITH its XCD pairing (orders 2 / 3: blocks b, b + 8 take the two halves of the same lines),
+    //     (b) 512 rows x 128 B at an 8 KiB stride (N = 2^9 x 2^11: full lines, 64 KiB, two workgroups per CU), (c) the same at 1 / 2 / 4 KiB strides
+    for (int order = 2; order < 4; ++order) {
+        Geo g64 = strided(10, 4, 1024, frame_log);
+        RUN("p1 1024r x  64B @4K PAIRED", 512, 32, 1, 0, g64, g64, 68 * 1024, 2, order);
+        RUN("p1 1024r x  64B @4K PAIRED plain loads", 512, 32, 0, 0, g64, g64, 68 * 1024, 2, order);
+    }
+    for (int order = 0; order < 2; ++order) {
+        Geo g8k = strided(9, 5, 2048, frame_log);
+        RUN("p1 512r x 128B @8K", 512, 32, 1, 0, g8k, g8k, 68 * 1024, 2, order);
+        RUN("p1 512r x 128B @8K", 512, 32, 1, 1, g8k, g8k, 68 * 1024, 2, order);
+        // write side of such a split: a 128 KiB tile (16 rows of 2048 points; the scratch layout is free: read as one contiguous run), written as
+        // 2048 pieces of 64 B at a 2 KiB stride (X[k_low + 512 k_high]); one workgroup per CU
+        Geo grb;
+        grb.rowdw_log = 15, grb.stride = (size_t)1 << 15, grb.chunk_step = (size_t)1 << 15, grb.nchunks_log = 5, grb.row_group = 0, grb.rsplit = 30;
+        Geo gwb = strided(11, 4, 512, frame_log);
+        RUN("p2 read 128 KiB contiguous, write 2048 x 64B @2K", 1024, 32, 1, 0, grb, gwb, 132 * 1024, 1, order);
+    }
+    // the same split with a 64 KiB row tile (8 rows of 2048 points, two workgroups per CU): 2048 pieces of 32 B at a 2 KiB stride
+    {
+        Geo gr8;
+        gr8.rowdw_log = 14, gr8.stride = (size_t)1 << 14, gr8.chunk_step = (size_t)1 << 14, gr8.nchunks_log = 6, gr8.row_group = 0, gr8.rsplit = 30;
+        Geo gw8 = strided(11, 3, 512, frame_log);
+        RUN("p2 read 64 KiB contiguous, write 2048 x 32B @2K", 512, 32, 1, 0, gr8, gw8, 68 * 1024, 2, 0);
+        RUN("p2 read 64 KiB contiguous, write 2048 x 32B @2K XCD quads", 512, 32, 1, 0, gr8, gw8, 68 * 1024, 2, 4);
+        RUN("p2 read 64 KiB contiguous, write 2048 x 32B @2K XCD quads, plain", 512, 32, 0, 0, gr8, gw8, 68 * 1024, 2, 4);
+        RUN("p2 read 64 KiB contiguous, write 2048 x 32B @2K one block x 4", 512, 32, 1, 0, gr8, gw8, 68 * 1024, 2, 5);
+        RUN("p2 read 64 KiB contiguous, write 2048 x 32B @2K one block x 4, plain", 512, 32, 0, 0, gr8, gw8, 68 * 1024, 2, 5);
     }
     // --- candidate pass 2: read 32 rows (n19..15) x 4 KiB contiguous, write 1024 runs of 128 B at 4 KiB stride ---
     //     read geometry: row = 1024 dwords, 32 rows at stride 2^15 dwords, 32 column chunks of 1024 dwords
