@@ -146,6 +146,7 @@ struct intfft_plan {
     std::vector<ExecCtx> ctx_pool;
     size_t scratch_frames = 0, scratch_bytes = 0;
     size_t scratch_frame_bytes = 0; // bytes of one frame of inter-pass words
+    size_t scratch_gran = 1;        // the scratch is used in units of this many frames (the virtual 2^16-point frames of the wide classes)
     bool dual_scratch = false;      // two scratch halves (one per stream)
     bool is2d = false, is_pair = false;
     int n2d_bufs = 0;               // layout buffers a 2-D plan uses (1: the two-launch fused forms)
@@ -1107,10 +1108,32 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                                big2x_supported(p->log2n) &&
                                !diag_env("INTFFT_NO_TWOPASS") && big2x_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width);
         if (big2x_inv) pl->big_two_pass = true;
-        pl->wide16 = !generic_only && wide16_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly,
-                                      p->in_order, p->out_order) &&
-                     pl->passes.size() == 2 && !diag_env("INTFFT_NO_WIDE16");
-        if (pl->wide16 && p->direction == INTFFT_INV) { // the inverse: STAGE 0 .. 7 in pass 1 (int32), 8 .. LL-1 in pass 2 (64-bit); st[s] = STAGE s
+        // class 1: the first pass within int32 (17 .. 27-bit data); class 2 (round 5): DATA_WIDTH up to 32, the first pass on 64-bit words too
+        const int wcls = generic_only ? 0 : wide16_class(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
+        pl->wide16 = wcls != 0 && (wcls == 2 || pl->passes.size() == 2) && !diag_env("INTFFT_NO_WIDE16");
+        pl->wargs.w64 = wcls == 2;
+        if (pl->wide16 && wcls == 2) { // every stage on the 64-bit butterflies (wfly64 / wdit64): exact 64-bit products, the slice inside one dword pair
+            std::vector<StageDesc> st;
+            const int LL = p->log2n;
+            const bool inv = p->direction == INTFFT_INV;
+            if (core_stages(*p, p->data_width, inv, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
+            pl->wargs.dw = p->data_width;
+            for (int i = 0; i < LL && pl->wide16; ++i) {
+                const StageDesc &d = st[i];
+                WideStage &w = pl->wargs.st[i]; // forward: processing order (STAGE LL - 1 - i); inverse: STAGE i
+                const int wslice = inv ? d.mw : d.wo; // the multiplier's result width
+                w.sh = d.sh_a + d.sh_b;
+                w.keep = d.sh_a >= 32 ? 0u : ~((1u << d.sh_a) - 1u);
+                w.az = d.sh_a == 0;
+                w.s2 = w.s3 = 0;
+                w.w32 = wslice - 32;
+                if (d.s != (inv ? i : LL - 1 - i)) pl->wide16 = false;
+                if (d.s < 2) continue; // multiplier-free
+                if (d.sh_a >= 32 || w.sh > 31 || d.mw + p->twdl_width > 64 || wslice > 48 || w.sh + wslice > 64) pl->wide16 = false;
+                if (w.w32 >= 1 && w.sh + w.w32 > 32) pl->wide16 = false;
+            }
+            if (p->data_width + LL > 48) pl->wide16 = false;
+        } else if (pl->wide16 && p->direction == INTFFT_INV) { // the inverse: STAGE 0 .. 7 in pass 1 (int32), 8 .. LL-1 in pass 2 (64-bit); st[s] = STAGE s
             std::vector<StageDesc> st;
             const int LL = p->log2n;
             if (core_stages(*p, p->data_width, true, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
@@ -1151,7 +1174,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
         }
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name(p->direction) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name(p->direction, pl->wargs.w64) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;
@@ -1166,9 +1189,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 return (int)e;
             }
         }
-        if (pl->passes.size() > 1 || pl->big20 || pl->bigw) {
+        if (pl->passes.size() > 1 || pl->big20 || pl->bigw || pl->wide16) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->wide16 && pl->wargs.w64) ? 8 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream
@@ -1177,6 +1200,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (!dual && (pl->big20 || pl->bigw || pl->wide16)) scratch_mb = 256;
             if (const char *e = diag_env("INTFFT_SCRATCH_MB")) scratch_mb = atoi(e) > 0 ? (size_t)atoi(e) : scratch_mb;
             pl->scratch_frames = std::max<size_t>(1, (scratch_mb << 20) / frame_bytes);
+            if (pl->wide16 && pl->L < 16) { // a chunk = whole virtual frames (a partial one still occupies its whole region of the scratch)
+                pl->scratch_gran = (size_t)1 << (16 - pl->L);
+                pl->scratch_frames = std::max(pl->scratch_gran, pl->scratch_frames / pl->scratch_gran * pl->scratch_gran);
+            }
             pl->scratch_frame_bytes = frame_bytes;
             pl->scratch_bytes = pl->scratch_frames * frame_bytes;
             hipError_t e = hipMalloc(&pl->d_scratch, pl->scratch_bytes);
@@ -1269,7 +1296,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }
-    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : plan->wide16 ? 2 : (int)plan->passes.size();
     info->compute_word = (plan->fastw64 || plan->fastw64b) ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
@@ -1319,7 +1346,7 @@ static size_t ws_need(const intfft_plan *pl, size_t batch)
         return ws_align(pf * pl->scratch_frame_bytes) + std::max(ws_need(pl->pair_f, pf), ws_need(pl->pair_i, pf));
     }
     if (pl->scratch_frames == 0) return 0;
-    if (batch <= pl->scratch_frames) return ws_align(batch * pl->scratch_frame_bytes);
+    if (batch <= pl->scratch_frames) return ws_align((batch + pl->scratch_gran - 1) / pl->scratch_gran * pl->scratch_gran * pl->scratch_frame_bytes);
     return (pl->dual_scratch ? 2 : 1) * ws_align(pl->scratch_frames * pl->scratch_frame_bytes);
 }
 
@@ -1598,7 +1625,7 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
     const size_t np = plan->passes.size();
-    const size_t chunk = (np > 1 || plan->big20 || plan->bigw) ? plan->scratch_frames : batch;
+    const size_t chunk = (np > 1 || plan->big20 || plan->bigw || plan->wide16) ? plan->scratch_frames : batch;
     // more than one chunk: odd chunks run on a pooled side stream with the second scratch half (fork here, join on every exit path)
     hipStream_t const user_stream = stream;
     void *const scratch0 = ws ? ws : plan->d_scratch;

@@ -307,7 +307,7 @@ __device__ __forceinline__ void wstage64(i64 (&re)[16], i64 (&im)[16], const int
     wstage64x<H, false, UNIFORM_W>(re, im, wr, wi, s);
 }
 
-template <int L>
+template <int L, bool IN64 = false> // IN64: the scratch holds 64-bit words (k_wide64_p1 in front: DATA_WIDTH 25 .. 32, round 5)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
                                                    const WideArgs a, const W2Consts k, size_t nframes_user)
 {
@@ -358,11 +358,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         typedef int v2i __attribute__((ext_vector_type(2)));
         unsigned tid_l = (unsigned)tid;
         asm volatile("" : "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
+        if constexpr (IN64) { // 16 bytes per sample
+            typedef i64 v2li __attribute__((ext_vector_type(2)));
+            const v2li *src64 = reinterpret_cast<const v2li *>(scr) + f * 65536 + 4096 * r0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const v2i x = *at32(reinterpret_cast<const v2i *>(src + 256 * q), tid_l);
-            re[q] = x.x;
-            im[q] = x.y;
+            for (int q = 0; q < 16; ++q) {
+                const v2li x = *at32(src64 + 256 * q, tid_l);
+                re[q] = x.x;
+                im[q] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2i x = *at32(reinterpret_cast<const v2i *>(src + 256 * q), tid_l);
+                re[q] = x.x;
+                im[q] = x.y;
+            }
         }
         wstage64<8>(re, im, w7r, w7i, a.st[X + 8]);
         wstage64<4>(re, im, w6r, w6i, a.st[X + 9]);
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-template <int L>
+template <int L, bool IN64 = false> // IN64: the scratch holds 64-bit words (k_wide64_q1 in front)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_q2(const int2 *scr, i64 *out, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              size_t nframes_user)
 {
@@ -683,7 +694,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         unsigned toff = (unsigned)(c + 256 * hi4);
         asm volatile("" : "+v"(toff), "+v"(toff2));
         i64 re[16], im[16];
-        if (present) {
+        if (present && IN64) { // 16 bytes per sample
+            typedef i64 v2li __attribute__((ext_vector_type(2)));
+            const v2li *src64 = reinterpret_cast<const v2li *>(scr) + f * 65536;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2li x = INTFFT_LD(at32(src64 + 4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12)), toff2));
+                re[q] = x.x, im[q] = x.y;
+            }
+        } else if (present) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const v2i x = INTFFT_LD(at32(src + 4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12)), toff2));
@@ -739,6 +758,288 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+
+// ---- DATA_WIDTH 25 .. 32 with bit growth (round 5): the FIRST pass on 64-bit words too -------------------------------------------------------
+// int_fft_single_path.vhd:15 documents DATA_WIDTH 8 .. 32; with FORMAT = 1 at N >= 8192 such data leave int32 in the first stages (DATA_WIDTH + NFFT - 8
+// > 32), so pass 1 cannot be k_wide16_p1 / k_wide16_q1.  k_wide64_p1 / k_wide64_q1 are those kernels on 64-bit registers -- the same tiles, loads and
+// scratch layout (in 16-byte samples), the butterflies of pass 2 (wfly64 / wdit64: exact 64-bit products, mw + TWDL_WIDTH <= 64, checked by the planner),
+// the three-plane LDS transpose of the <= 36-bit values between the rounds -- and k_wide16_p2 / k_wide16_q2 read their scratch as 64-bit words
+// (IN64).  Results up to 48 bits (the 16-bit
+// high plane of the second pass's transpose).
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_p1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
+                                                                                             size_t nframes_user)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G;
+    constexpr int X = L - 16;
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    const int tile = blockIdx.x & 15;
+    const int c = 16 * tile + lo4;
+    int w15r[8], w15i[8], w14r[4], w14i[4], w13r[2], w13i[2], w12r[1], w12i[1];
+    int w11r[8], w11i[8], w10r[4], w10i[4], w9r[2], w9i[2], w8r[1], w8i[1];
+    {
+        const int base = c + 256 * hi4;
+        if constexpr (L > 15) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int2 w = twt[32767 + base + 4096 * j];
+                w15r[j] = w.x, w15i[j] = w.y;
+            }
+        }
+        if constexpr (L > 14) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int2 w = twt[16383 + ((base + 4096 * j) & 16383)];
+                w14r[j] = w.x, w14i[j] = w.y;
+            }
+        }
+        if constexpr (L > 13) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int2 w = twt[8191 + ((base + 4096 * j) & 8191)];
+                w13r[j] = w.x, w13i[j] = w.y;
+            }
+        }
+        int2 w = twt[4095 + base];
+        w12r[0] = w.x, w12i[0] = w.y;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w = twt[2047 + c + 256 * j];
+            w11r[j] = w.x, w11i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w = twt[1023 + c + 256 * j];
+            w10r[j] = w.x, w10i[j] = w.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w = twt[511 + c + 256 * j];
+            w9r[j] = w.x, w9i[j] = w.y;
+        }
+        w = twt[255 + c];
+        w8r[0] = w.x, w8i[0] = w.y;
+    }
+    // transpose as in k_wide16_p1: element (thread (hi4, lo4), register j) -> row 16 j + lo4, column hi4; thread t reads row t; three dword planes
+    u32 *const wr0 = lds + ROWW * lo4 + hi4;
+    u32 *const wr1 = wr0 + PLANEW;
+    const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
+    const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
+
+    const size_t fstep = gridDim.x >> 4;
+    for (size_t f = blockIdx.x >> 4; f < nframes; f += fstep) {
+        i64 re[16], im[16];
+        const int2 *src = in + f * 65536;
+        unsigned toff = (unsigned)(c + 256 * hi4);
+        asm volatile("" : "+v"(toff));
+        const bool partial = L < 16 && (f + 1) * G > nframes_user;
+        typedef int v2i __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            v2i x = {0, 0};
+            if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) x = INTFFT_LD(at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff));
+            // conv_std_logic_vector(.., DATA_WIDTH): wrap on load (v_bfe_i32 takes the width modulo 32: nothing to wrap at 32 bits)
+            re[j] = a.dw >= 32 ? x.x : (int)__builtin_amdgcn_sbfe(x.x, 0, a.dw) /* (the builtin returns unsigned) */;
+            im[j] = a.dw >= 32 ? x.y : (int)__builtin_amdgcn_sbfe(x.y, 0, a.dw);
+        }
+        if constexpr (L > 15) wstage64<8>(re, im, w15r, w15i, a.st[X + 0]);
+        if constexpr (L > 14) wstage64<4>(re, im, w14r, w14i, a.st[X + 1]);
+        if constexpr (L > 13) wstage64<2>(re, im, w13r, w13i, a.st[X + 2]);
+        wstage64<1>(re, im, w12r, w12i, a.st[X + 3]);
+        u32 hp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hp[q] = ((u32)((u64)re[q] >> 32) & 0xFFFFu) | ((u32)((u64)im[q] >> 32) << 16);
+        u32 rlo[16], ilo[16];
+        __syncthreads(); // the previous frame's reads are done
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            wr0[ROWW * 16 * j] = (u32)re[j];
+            wr1[ROWW * 16 * j] = (u32)im[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd0[q], y = rd1[q];
+            rlo[4 * q + 0] = x.x, rlo[4 * q + 1] = x.y, rlo[4 * q + 2] = x.z, rlo[4 * q + 3] = x.w;
+            ilo[4 * q + 0] = y.x, ilo[4 * q + 1] = y.y, ilo[4 * q + 2] = y.z, ilo[4 * q + 3] = y.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wr0[ROWW * 16 * j] = hp[j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 x = rd0[q];
+            hp[4 * q + 0] = x.x, hp[4 * q + 1] = x.y, hp[4 * q + 2] = x.z, hp[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            re[q] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[q], 0, 16) << 32) | rlo[q]);
+            im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
+        }
+        wstage64<8>(re, im, w11r, w11i, a.st[X + 4]);
+        wstage64<4>(re, im, w10r, w10i, a.st[X + 5]);
+        wstage64<2>(re, im, w9r, w9i, a.st[X + 6]);
+        wstage64<1>(re, im, w8r, w8i, a.st[X + 7]);
+        const int g = hi4 >> (L - 12);
+        if (partial && f * G + (size_t)g >= nframes_user) continue;
+        // scratch: 16 bytes per sample in the layout of k_wide16_p1's (a 12-byte form -- low dword pairs + a plane of packed 16-bit high halves, 56 -> 48
+        // bytes of traffic per sample for the plan -- measured SLOWER forward: N = 2^16 77 against 89 Gsample/s, N = 2^13 99 against 127; inverse unchanged)
+        typedef i64 v2l __attribute__((ext_vector_type(2)));
+        v2l *dst = reinterpret_cast<v2l *>(scr) + f * 65536;
+        unsigned toff2 = (unsigned)(256 * tile + lo4 + 4096 * (g << (L - 12)) + 16 * ((hi4 << (16 - L)) & 15));
+        asm volatile("" : "+v"(toff2));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2l y = {re[q], im[q]};
+            *at32(dst + 4096 * (q & ((1 << (L - 12)) - 1)) + 16 * (q >> (L - 12)), toff2) = y;
+        }
+    }
+}
+
+template <int H, bool UNIFORM_W>
+__device__ __forceinline__ void wdstage64u(i64 (&re)[16], i64 (&im)[16], const int (&wr)[H], const int (&wi)[H], const WideStage &s)
+{
+#pragma unroll
+    for (int g = 0; g < 16; g += 2 * H)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            wdit64<UNIFORM_W>(re[g + j], im[g + j], re[g + j + H], im[g + j + H], wr[j], wi[j], s);
+            if (SCHED_GROUP && ((g / 2 + j) % SCHED_GROUP) == SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_q1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
+                                                                                             const W2Consts k, size_t nframes_user)
+{
+    static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    constexpr int G = 1 << (16 - L);
+    const size_t nframes = (nframes_user + G - 1) / G;
+    __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
+    const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    int w7r[8], w7i[8], w6r[4], w6i[4], w5r[2], w5i[2], w4r[1], w4i[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int2 w = twt[127 + 16 * j + lo4];
+        w7r[j] = w.x, w7i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int2 w = twt[63 + 16 * j + lo4];
+        w6r[j] = w.x, w6i[j] = w.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int2 w = twt[31 + 16 * j + lo4];
+        w5r[j] = w.x, w5i[j] = w.y;
+    }
+    {
+        const int2 w = twt[15 + lo4];
+        w4r[0] = w.x, w4i[0] = w.y;
+    }
+    // k_wide16_q1's transpose (round-1 thread t writes row t; round-2 thread (j = hi4, c3..0 = lo4), register q, reads (row 16 q + j, column c3..0)), three planes
+    uint4 *const wr0 = reinterpret_cast<uint4 *>(lds + ROWW * tid);
+    uint4 *const wr1 = reinterpret_cast<uint4 *>(lds + PLANEW + ROWW * tid);
+    const u32 *const rd0 = lds + ROWW * hi4 + lo4;
+    const u32 *const rd1 = rd0 + PLANEW;
+
+    const size_t units = nframes * 16;
+    for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const size_t f = u >> 4;
+        const int r0 = (int)(u & 15);
+        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t real = f * G + (size_t)ug;
+        if (L < 16 && real >= nframes_user) continue;
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
+        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << L) + 16 * rlow;
+        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
+        asm volatile("" : "+v"(toff), "+v"(tid_l));
+        i64 re[16], im[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff);
+            re[q] = a.dw >= 32 ? x.x : (int)__builtin_amdgcn_sbfe(x.x, 0, a.dw) /* (the builtin returns unsigned) */;
+            im[q] = a.dw >= 32 ? x.y : (int)__builtin_amdgcn_sbfe(x.y, 0, a.dw);
+        }
+        // STAGE 0: T = B; STAGE 1: T = B on even positions, +j B with the negation quirk on odd ones (int_dit2_fly.vhd:221-286)
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) {
+            const i64 xr = re[g] + re[g + 1], xi = im[g] + im[g + 1];
+            re[g + 1] = re[g] - re[g + 1], im[g + 1] = im[g] - im[g + 1];
+            re[g] = xr, im[g] = xi;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            {
+                const i64 xr = re[g] + re[g + 2], xi = im[g] + im[g + 2];
+                re[g + 2] = re[g] - re[g + 2], im[g + 2] = im[g] - im[g + 2];
+                re[g] = xr, im[g] = xi;
+            }
+            {
+                const i64 tre = (im[g + 3] >> 63) - im[g + 3], tim = re[g + 3];
+                re[g + 3] = re[g + 1] - tre, im[g + 3] = im[g + 1] - tim;
+                re[g + 1] += tre, im[g + 1] += tim;
+            }
+        }
+        wdstage64u<4, true>(re, im, k.wr2, k.wi2, a.st[2]);
+        wdstage64u<8, true>(re, im, k.wr3, k.wi3, a.st[3]);
+        u32 hp[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hp[q] = ((u32)((u64)re[q] >> 32) & 0xFFFFu) | ((u32)((u64)im[q] >> 32) << 16);
+        u32 rlo[16], ilo[16];
+        __syncthreads(); // the previous unit's reads are done
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wr0[q] = make_uint4((u32)re[4 * q], (u32)re[4 * q + 1], (u32)re[4 * q + 2], (u32)re[4 * q + 3]);
+            wr1[q] = make_uint4((u32)im[4 * q], (u32)im[4 * q + 1], (u32)im[4 * q + 2], (u32)im[4 * q + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            rlo[q] = rd0[ROWW * 16 * q];
+            ilo[q] = rd1[ROWW * 16 * q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr0[q] = make_uint4(hp[4 * q], hp[4 * q + 1], hp[4 * q + 2], hp[4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hp[q] = rd0[ROWW * 16 * q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            re[q] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[q], 0, 16) << 32) | rlo[q]);
+            im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
+        }
+        wdstage64<1>(re, im, w4r, w4i, a.st[4]);
+        wdstage64<2>(re, im, w5r, w5i, a.st[5]);
+        wdstage64<4>(re, im, w6r, w6i, a.st[6]);
+        wdstage64<8>(re, im, w7r, w7i, a.st[7]);
+        typedef i64 v2l __attribute__((ext_vector_type(2)));
+        v2l *dst = reinterpret_cast<v2l *>(scr) + f * 65536 + 4096 * r0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const v2l y = {re[q], im[q]};
+            *at32(dst + 256 * q, tid_l) = y;
+        }
+    }
+}
+
+// which first pass a configuration takes: 0 none, 1 int32 (k_wide16_p1 / q1), 2 64-bit words (k_wide64_p1 / q1; round 5)
+int wide16_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
+{
+    if (wide16_supported(log2n, data_width, twdl_width, format, direction, use_fly, in_order, out_order)) return 1;
+    // DATA_WIDTH up to 32 in int32 containers, results of 33 .. 48 bits in int64 containers; the per-stage conditions (exact 64-bit products, the
+    // slice inside one dword pair) are checked by the planner on the stage list
+    const bool common = log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width <= 32 && data_width + log2n > 32 && data_width + log2n <= 48 &&
+                        twdl_width >= 8 && twdl_width <= 24 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0;
+    return common && (direction == 0 || direction == 1) ? 2 : 0;
+}
+
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                       int out_order)
 {
@@ -753,7 +1054,11 @@ bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int
            in_order == 0 && out_order == 0;
 }
 
-const char *wide16_kernel_name(int direction) { return direction == 1 ? "k_wide16_q1+q2" : "k_wide16_p1+p2"; }
+const char *wide16_kernel_name(int direction, int w64)
+{
+    if (w64) return direction == 1 ? "k_wide64_q1+k_wide16_q2" : "k_wide64_p1+k_wide16_p2";
+    return direction == 1 ? "k_wide16_q1+q2" : "k_wide16_p1+p2";
+}
 
 template <int L>
 static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void *in, void *out, void *scratch, const int2 *tw_all,
@@ -761,6 +1066,26 @@ static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void
 {
     const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L); // virtual 2^16-point frames
     const size_t units = nvf * 16;
+    if (a.w64 && direction == 1) {
+        size_t g1 = resident_blocks(kptr(k_wide64_q1<L>), 256, 2);
+        if (g1 > units) g1 = units;
+        size_t g2 = resident_blocks(kptr(k_wide16_q2<L, true>), 256, 2) & ~(size_t)15;
+        if (g2 < 16) g2 = 16;
+        if (g2 > units) g2 = units;
+        hipLaunchKernelGGL(k_wide64_q1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<i64 *>(scratch), tw_all, a, k, nframes);
+        hipLaunchKernelGGL((k_wide16_q2<L, true>), dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a, nframes);
+        return hipGetLastError();
+    }
+    if (a.w64) {
+        size_t g1 = resident_blocks(kptr(k_wide64_p1<L>), 256, 2) & ~(size_t)15;
+        if (g1 < 16) g1 = 16;
+        if (g1 > units) g1 = units;
+        size_t g2 = resident_blocks(kptr(k_wide16_p2<L, true>), 256, 2);
+        if (g2 > units) g2 = units;
+        hipLaunchKernelGGL(k_wide64_p1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<i64 *>(scratch), tw_all, a, nframes);
+        hipLaunchKernelGGL((k_wide16_p2<L, true>), dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a, k, nframes);
+        return hipGetLastError();
+    }
     if (direction == 1) {
         size_t g1 = resident_blocks(kptr(k_wide16_q1<L>), 256, 2);
         if (g1 > units) g1 = units;

@@ -1350,6 +1350,43 @@ def test_wide_two_pass_inverse_n8192_to_n65536(log2n, dw, tw, batch, monkeypatch
     assert ib["kernel_name"] != "k_wide16_q1+q2" and np.array_equal(a, b)
 
 
+WIDE64_CASES = [
+    # (log2n, dw, tw, batch): DATA_WIDTH 25 .. 32 with bit growth at N = 2^13 .. 2^16 (41 .. 48-bit results), and what class 1 leaves out
+    (13, 32, 16, 9), (13, 28, 16, 3), (14, 32, 16, 5), (14, 30, 14, 4), (15, 32, 16, 3), (15, 26, 16, 1), (16, 32, 16, 2), (16, 32, 12, 1),
+    (16, 25, 16, 1), (16, 28, 18, 1), (14, 32, 10, 2), (13, 27, 24, 2), (16, 24, 12, 1), (13, 32, 8, 17),
+]
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("log2n,dw,tw,batch", WIDE64_CASES)
+def test_wide64_first_pass_data_width_up_to_32(log2n, dw, tw, batch, direction, monkeypatch):
+    """DATA_WIDTH 25 .. 32 (the wrapper's documented range ends at 32: int_fft_single_path.vhd:15) with FORMAT = 1 at N = 2^13 .. 2^16: results of
+    41 .. 48 bits, the widths leave int32 inside the first pass, so BOTH passes run on 64-bit words -- k_wide64_p1 + k_wide16_p2<IN64> forward,
+    k_wide64_q1 + k_wide16_q2<IN64> inverse (round 5; k_pass<long> before).  Multiplier regimes sngl / dbl18 / trpl18 by stage width
+    (int_cmult_dsp48.vhd:184-303, the pre-truncation of int_cmult_dbl18_dsp48.vhd:163-175 as a mask): bit-exact to the oracle for both XSER, on
+    full-scale and edge frames and partial last groups (N < 2^16: virtual frames), and equal to the generic kernels (INTFFT_NO_WIDE16)."""
+    d = {"FWD": C.FWD, "INV": C.INV}[direction]
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 900 + log2n + dw + tw), edge_frames(n, dw)[[0, 1, 3, 4, 5]]])[:batch + (3 if log2n < 15 else 1)]
+    name = "k_wide64_q1+k_wide16_q2" if direction == "INV" else "k_wide64_p1+k_wide16_p2"
+    ran = 0
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), d) != 0:
+            continue
+        info = check(x, log2n, dw, tw, 1, 0, new, direction=direction)
+        if info["kernel_name"] != name:  # class 1 (the int32 first pass still fits), or a stage outside the 64-bit product / slice conditions
+            assert info["kernel_name"].startswith("k_pass") or info["kernel_name"].startswith("k_wide16_"), info
+            continue
+        assert info["n_passes"] == 2 and info["out_container"] == 8 and info["in_container"] == 4, info
+        ran += 1
+    if (dw, tw) in ((32, 16), (32, 12), (28, 16), (25, 16), (32, 10)):
+        assert ran >= 1, "the class itself must be served by the dedicated kernels"
+    a, ia = run_gpu(x, log2n, dw, tw, 1, 0, True, direction=direction)
+    monkeypatch.setenv("INTFFT_NO_WIDE16", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True, direction=direction)
+    assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
+
+
 def test_wide_family_random_configurations():
     """Seeded fuzz over the unscaled plans with int64 results (N = 2^10 .. 2^16, DATA_WIDTH 17 .. 30, TWDL_WIDTH 10 .. 25, both
     XSER): whichever kernel the planner picks (k_fft1024_w32 / k_fft4096_w32 with 64-bit tails, k_wide16_p1+p2<L>, k_pass<long>),
@@ -1371,7 +1408,8 @@ def test_wide_family_random_configurations():
         done += 1
         if done >= 48:
             break
-    assert done >= 40 and {"k_wide16_p1+p2", "k_fft4096_w32", "k_pass<long>"} <= seen, (done, seen)
+    # (round 5: what was k_pass<long> here -- DATA_WIDTH beyond the int32 first pass at N >= 8192 -- now runs k_wide64_p1 + k_wide16_p2)
+    assert done >= 40 and {"k_wide16_p1+p2", "k_fft4096_w32", "k_wide64_p1+k_wide16_p2"} <= seen, (done, seen)
 
 
 @pytest.mark.parametrize("batch", [1, 2, 5, 1027])

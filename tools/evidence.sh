@@ -56,7 +56,7 @@ part_variants() {
     python tools/bench_configs.py $cfg 2>&1 | grep "^{" >> $out
     echo "{\"variant\": \"$v\", \"streams\": 1}" >> $out
     INTFFT_ONE_STREAM=1 python tools/bench_configs.py $cfg 2>&1 | grep "^{" >> $out
-    (cd /tmp && rm -rf /tmp/var_$v && INTFFT_ONE_STREAM=1 BENCH_STEPS=5 BENCH_RAMP_S=0.1 rocprofv3 --kernel-trace --stats -d /tmp/var_$v -o t -- python $ROOT/tools/bench_configs.py $cfg > /tmp/var_$v.log 2>&1
+    (cd /tmp && rm -rf /tmp/var_$v && INTFFT_ONE_STREAM=1 BENCH_STEPS=5 BENCH_RAMP_S=0.1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/var_$v -o t -- python $ROOT/tools/bench_configs.py $cfg > /tmp/var_$v.log 2>&1
      f=$(find /tmp/var_$v -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-300 $f | grep -v "k_twiddle\|k_pack\|Cijk\|at::\|elementwise" | head -8 > $ROOT/gpurun_out/${TAG}_${cfg}_variant_${v}_stats.csv)
     if [ "${EVIDENCE_PMC:-0}" = 1 ]; then
       BENCH_STEPS=3 BENCH_RAMP_S=0.02 tools/pmc_sets.sh ${TAG}_${cfg}_var_$v "k_" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum" -- python $ROOT/tools/bench_configs.py $cfg
