@@ -31,10 +31,24 @@ namespace intfft {
 // global_load / global_store.  Written as p[off] the compiler re-associates (base + thread offset) + constant, keeps the sum in a VGPR
 // pair and spends a v_add_co / v_addc pair on every access (k_big2x_a: 186 of its 1300 VALU operations per thread and tile).  The base
 // goes through an opaque SGPR pair (as a global-address-space pointer: through a generic one the accesses would become flat_*).
+// THE BASE MUST BE WAVE-UNIFORM (it may depend on blockIdx, the frame / chunk / tile of the loop, never on threadIdx): "+s" on a divergent value makes the
+// compiler insert v_readfirstlane and every lane would silently use lane 0's address.  Build with -DINTFFT_AT32_CHECK (tools/evidence.sh <tag> at32check:
+// every translation unit rebuilt, the parity suites run on that library) to have each at32 / at32b compare the base with its readfirstlane and trap.
 template <typename T> using gptr_t = T __attribute__((address_space(1))) *;
+__device__ __forceinline__ void at32_check(const void *uniform_base)
+{
+#ifdef INTFFT_AT32_CHECK
+    const unsigned long long a = (unsigned long long)uniform_base;
+    const unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)lo) != lo || (unsigned)__builtin_amdgcn_readfirstlane((int)hi) != hi) __builtin_trap();
+#else
+    (void)uniform_base;
+#endif
+}
 template <typename T> __device__ __forceinline__ gptr_t<T> at32(T *uniform_base, unsigned elem_off)
 {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    at32_check(uniform_base);
     gptr_t<B> g = (gptr_t<B>)uniform_base;
     asm("" : "+s"(g));
     return (gptr_t<T>)(g + (size_t)(elem_off * (unsigned)sizeof(T)));
@@ -44,6 +58,7 @@ template <typename T> __device__ __forceinline__ gptr_t<T> at32(T *uniform_base,
 template <typename T> __device__ __forceinline__ gptr_t<T> at32b(T *uniform_base, unsigned byte_off)
 {
     typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    at32_check(uniform_base);
     gptr_t<B> g = (gptr_t<B>)uniform_base;
     asm("" : "+s"(g));
     return (gptr_t<T>)(g + (size_t)byte_off);

@@ -92,6 +92,11 @@ ROWS.append(("16:24:24:1:0:INV", "24-bit unscaled INV (40-bit results)"))
 ROWS.append(("10:18:16:0:0:PAIR", "18-bit scaled PAIR (32-bit words: forward + inverse sub-plans, round 4)"))
 ROWS.append(("12:24:24:0:1:PAIR", "24-bit scaled-round PAIR (32-bit words)"))
 ROWS.append(("14:18:16:0:0:PAIR", "18-bit scaled PAIR (32-bit words, two passes each way)"))
+for _l in (13, 14, 16):
+    ROWS.append(("%d:32:16:1" % _l, "32-bit unscaled FWD (%d-bit results; both passes on 64-bit words, round 5)" % (32 + _l)))
+    ROWS.append(("%d:32:16:1:0:INV" % _l, "32-bit unscaled INV (%d-bit results; round 5)" % (32 + _l)))
+ROWS.append(("16:28:16:1", "28-bit unscaled FWD (44-bit results; round 5)"))
+ROWS.append(("16:24:12:1", "24-bit unscaled FWD, 12-bit twiddles (round 5: outside the int32-first-pass class)"))
 ROWS.append(("10:56:16:1", "56-bit unscaled FWD (66-bit results, 16-byte containers)"))
 ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit results)"))
 

@@ -4,13 +4,20 @@
 set -e
 NAME=$1; FLAGS=$2; shift 2
 mkdir -p build/variants
-OBJS=$(ls intfftk_amd/lib/*.o)
+declare -A REBUILT
+NEW=()
 for SRC in "$@"; do
-  OBJ=build/variants/${NAME}_$(basename $SRC .hip).o
+  B=$(basename $SRC .hip)
+  OBJ=build/variants/${NAME}_$B.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FLAGS -c intfftk_amd/csrc/$SRC -o $OBJ &
-  OBJS=$(echo "$OBJS" | grep -v "/$(basename $SRC .hip).o")
-  OBJS="$OBJS $OBJ"
+  REBUILT[$B]=1
+  NEW+=($OBJ)
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libintfft_$NAME.so $OBJS
+OBJS=()
+for O in intfftk_amd/lib/*.o; do
+  B=$(basename $O .o)
+  [ -z "${REBUILT[$B]:-}" ] && OBJS+=($O)
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libintfft_$NAME.so "${OBJS[@]}" "${NEW[@]}"
 echo build/variants/libintfft_$NAME.so

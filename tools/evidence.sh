@@ -13,6 +13,9 @@
 #                       e.g. `tools/build_variant.sh map1 intfft_big2x.hip -DINTFFT_2XA_MAP=1`): Gsample/s on two streams / one stream, the one-stream
 #                       kernel durations (rocprofv3 --kernel-trace --stats) and, with EVIDENCE_PMC=1, the L2 request counters per variant.  "base" = the library as built.
 #                       Variant flags that exist at HEAD: intfft_big2x.hip -DINTFFT_2XA_MAP=1|2, -DINTFFT_2XA_PLAIN, -DINTFFT_2XB_PLAIN; intfft_fast4096.hip -DINTFFT_4K_ABL=<bits>
+#   at32check           every translation unit rebuilt with -DINTFFT_AT32_CHECK (at32 / at32b trap when their base pointer is not wave-uniform:
+#                       intfft_device.hpp) as build/variants/libintfft_at32chk.so (build it HERE first: tools/evidence.sh <tag> at32build), then the parity
+#                       suites on that library
 #   tilebench           build/tilebench (tools/tilebench.hip) at 64 and 256 frames
 #   all                 headline digests configs matrix bench suite
 set -u
@@ -65,6 +68,13 @@ part_variants() {
   unset INTFFT_LIB
   cat $out
 }
+part_at32build() { # (CPU: cross-compiles)
+  tools/build_variant_multi.sh at32chk "-DINTFFT_AT32_CHECK" $(cd intfftk_amd/csrc && ls *.hip)
+}
+part_at32check() {
+  INTFFT_LIB=$ROOT/build/variants/libintfft_at32chk.so timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_2d.py tests/test_gpu_fullsize.py -m gpu -x -q > gpurun_out/${TAG}_at32check.txt 2>&1
+  tail -3 gpurun_out/${TAG}_at32check.txt
+}
 part_tilebench() {
   [ -x build/tilebench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o build/tilebench tools/tilebench.hip
   ./build/tilebench 64 20 > gpurun_out/${TAG}_tilebench_64.txt 2>&1; ./build/tilebench 256 10 > gpurun_out/${TAG}_tilebench_256.txt 2>&1
@@ -72,6 +82,6 @@ part_tilebench() {
 }
 case $PART in
   all) part_headline; part_digests; part_configs; part_matrix; part_bench; part_suite ;;
-  headline|digests|configs|matrix|bench|suite|calib|variants|tilebench) part_$PART "$@" ;;
+  headline|digests|configs|matrix|bench|suite|calib|variants|tilebench|at32build|at32check) part_$PART "$@" ;;
   *) echo "unknown part $PART"; exit 2 ;;
 esac
