@@ -65,17 +65,23 @@ __device__ __forceinline__ constexpr int rev5c(int r) { return ((r & 1) << 4) | 
 //           L = 19: thread = (n18..n15, l), regs = (n14, n13..n10): two independent 4-stage rounds 13..10 (n14 rides along)
 // Twiddles as in k_big2p_a: quarter-turn sharing; round 2's set depends on the column only and is parked in LDS, round 1's is
 // per thread and re-read from the L2-resident table in every frame.
-template <int L, bool FAST_OK, int ROUND = 0> // ROUND: RNDMODE = 1 (2: on narrow data) -- its own instantiation, exact extraction only
-__global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
+// CB = 5 (round 5, N = 2^19 only): FULL-line tiles -- 512 rows x 32 columns (128-byte row pieces) still fit 68 KiB, so two workgroups per CU read whole lines
+// with no partner to meet in the L2 (tools/tilebench.hip, profiles/r05_tilebench_*.txt: 5.05 TB/s as a copy against 3.15-3.5 for the paired half lines).  At
+// N = 2^20 the same tile is 128 KiB = one workgroup per CU (3.8 TB/s with its arithmetic, round 2): half lines (CB = 4) stay.
+template <int L, bool FAST_OK, int ROUND = 0, int CB = 4> // ROUND: RNDMODE = 1 (2: on narrow data) -- its own instantiation, exact extraction only
+__global__ __launch_bounds__((1 << CB) << (L - 15)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_a(const u32 *in, u32 *scr, const uint2 *__restrict__ twf,
                                                                                                         size_t nframes, unsigned groups, const Slice sl, int halves)
 {
     static_assert(L == 19 || L == 20, "9 or 10 stages");
     static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
+    static_assert(CB == 4 || (CB == 5 && L == 19), "full-line tiles fit 68 KiB at 512 rows only");
     constexpr int RB = L - 15;
-    constexpr int T = 16 << RB;
-    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWX, then the round-2 twiddles: 8 (RB = 4) / 16 slots x 16 columns of {wa, wb}
-    uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWX);
-    const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
+    constexpr int C = 1 << CB;        // columns of the tile
+    constexpr int ROWX = C + 1;       // LDS row stride in dwords (shadows the 17 of the half-line kernels)
+    constexpr int T = C << RB;
+    extern __shared__ u32 lds[]; // (32 << RB) rows x ROWX, then the round-2 twiddles: 8 (RB = 4) / 16 slots x C columns of {wa, wb}
+    uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + (32 << RB) * ROWX + (((32 << RB) * ROWX) & 1));
+    const int tid = threadIdx.x, l = tid & (C - 1), hx = tid >> CB;
     // blocks b and b + 8 (same XCD, same time) take the two 64-byte halves of the same lines: chunk = (column group g, part)
     // INTFFT_2XA_MAP (round-5 A/B variants, tools/build_variant.sh: which tiles an XCD holds at the same time; profiles/r05_c4_variants.md):
     //   0 (shipped)  XCD s takes the column lines s, s + 8, s + 16, s + 24 of every frame
@@ -85,17 +91,24 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
 #define INTFFT_2XA_MAP 0
 #endif
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+    unsigned chunk, grp;
+    if constexpr (CB == 5) { // full lines: no partner; neighbouring blocks = neighbouring column groups of one frame
+        chunk = blockIdx.x & 31u, grp = blockIdx.x >> 5;
+        (void)slot, (void)part;
+    } else {
 #if INTFFT_2XA_MAP == 1
-    const unsigned jm = blockIdx.x >> 4;
-    const unsigned chunk = (jm & 31u) * 2u + part, grp = (jm >> 5) * 8u + slot;
+        const unsigned jm = blockIdx.x >> 4;
+        chunk = (jm & 31u) * 2u + part, grp = (jm >> 5) * 8u + slot;
 #elif INTFFT_2XA_MAP == 2
-    const unsigned G = (blockIdx.x >> 4) * 8u + slot, grp = G >> 5;
-    const unsigned chunk = ((G + grp) & 31u) * 2u + part;
+        const unsigned G = (blockIdx.x >> 4) * 8u + slot;
+        grp = G >> 5;
+        chunk = ((G + grp) & 31u) * 2u + part;
 #else
-    const unsigned G = (blockIdx.x >> 4) * 8u + slot;
-    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+        const unsigned G = (blockIdx.x >> 4) * 8u + slot;
+        chunk = (G & 31u) * 2u + part, grp = G >> 5;
 #endif
-    const unsigned lfull = chunk * 16 + l;              // n9..n0
+    }
+    const unsigned lfull = chunk * C + l;               // n9..n0
     const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
     auto ld = [&](unsigned uniform_idx, unsigned thread_boff, u32 &wa, u32 &wb) { // thread_boff: BYTE offset of the thread's entry
         const uint2 w = ld2_at32b(twf + uniform_idx, thread_boff);
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     RoundTwQ t1;
     if (hx == 0) { // round 2 (stage 10 + b, table index (rr << 10) | lfull): parked per column
         int s = 0;
-        auto park = [&](unsigned uniform_idx) { tw2[16 * s++ + l] = (twf + uniform_idx)[lfull]; };
+        auto park = [&](unsigned uniform_idx) { tw2[C * s++ + l] = (twf + uniform_idx)[lfull]; };
         if constexpr (RB == 5)
             for (int rr = 0; rr < 8; ++rr) park((1u << 14) - 1u + ((unsigned)rr << 10));
         for (int rr = 0; rr < 4; ++rr) park((1u << 13) - 1u + ((unsigned)rr << 10));
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     auto round2_tw = [&](u32(&wa2t)[8], u32(&wb2t)[8], RoundTwQ &t2) {
         int s = 0;
         auto get = [&](u32 &wa, u32 &wb) {
-            const uint2 w = tw2[16 * s++ + l];
+            const uint2 w = tw2[C * s++ + l];
             wa = w.x;
             wb = w.y;
         };
@@ -146,7 +159,8 @@ __global__ __launch_bounds__(16 << (L - 15)) __attribute__((amdgpu_waves_per_eu(
     u32 *const wr_base = lds + ROWX * hx + l;              // transpose, write side: row (j << RB) + hx
     const u32 *const rd_base = lds + ROWX * (hx << 5) + l; // read side: row (jx << 5) + q, jx = tid >> 4
     // store side: scratch [q][c][hi][k][l], thread = (jx = n(L-1)..n15, l): k = jx >> (RB - 4), hi = the low RB - 4 bits of jx
-    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & ((1u << (RB - 4)) - 1u)) << 8) | (((unsigned)hx >> (RB - 4)) << 4) | (unsigned)l;
+    // (c = n9..n4 = the tile's column group(s): chunk for 16-column tiles, 2 chunk + (l >> 4) for 32-column ones)
+    const unsigned toff2 = (((chunk << (CB - 4)) + ((unsigned)l >> 4)) << (L - 11)) | (((unsigned)hx & ((1u << (RB - 4)) - 1u)) << 8) | (((unsigned)hx >> (RB - 4)) << 4) | ((unsigned)l & 15u);
     const v2s none = {0, 0};
     const short s2 = (short)(1 - (hx & 1)); // L = 20, round 2: the kind of its inputs is n15 = bit 0 of the new thread index
     const v2s sh2 = {s2, s2};
@@ -1150,7 +1164,13 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
     for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
 #define INTFFT_2XB_SHIFT 1 /* a block of pass B takes both partner tiles */
-#define INTFFT_2XA_LAUNCH(LL, FX, RD) hipLaunchKernelGGL((k_big2x_a<LL, FX, RD>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves);
+#define INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                                              \
+    if (LL == 19 && full19) {                                                                                                                                 \
+        constexpr int CB19 = LL == 19 ? 5 : 4; /* (instantiated for LL = 19 only) */                                                                            \
+        const size_t lds19 = ((size_t)(32 << RB) * 33 + 1) * sizeof(u32) + 8 * 32 * sizeof(uint2);                                                             \
+        allow_max_lds(kptr(k_big2x_a<LL, FX, RD, CB19>));                                                                                                      \
+        hipLaunchKernelGGL((k_big2x_a<LL, FX, RD, CB19>), dim3(32u * groups), dim3(32 << RB), lds19, stream, pin, scr, tw16f, nframes, groups, sl, halves);   \
+    } else hipLaunchKernelGGL((k_big2x_a<LL, FX, RD>), dim3(64u * groups), dim3(TT), ldsa, stream, pin, scr, tw16f, nframes, groups, sl, halves);
 #define INTFFT_2X_LAUNCH(LL, FX, RD)                                                                                               \
     {                                                                                                                              \
         constexpr int RB = LL - 15, TT = 16 << RB;                                                                                 \
@@ -1164,6 +1184,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
            samples (268 MB ideal), 270 against 262 Gsample/s; the per-block twiddle parking is 16 loads of 16 threads */         \
         const size_t cap = 64;                                                                                                     \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
+        const bool full19 = diag_env("INTFFT_2XA_HALF19") == nullptr; /* A/B: the half-line tiles of round 4 at N = 2^19 */        \
+        (void)full19;                                                                                                              \
         INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                \
         const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
