@@ -880,6 +880,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             re[q] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[q], 0, 16) << 32) | rlo[q]);
             im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
         }
+        if constexpr (L == 16) { // round-2 twiddles (they depend on the column only) re-read per frame from the L2-resident table instead of living in 30
+            // VGPRs over the frame loop: at L = 16 (all eight stages, 30 + 30 twiddle registers) that removes the kernel's 7 spilled VGPRs: 85 -> 94 Gsample/s;
+            // at L < 16 nothing spills and holding them is 2-3 % faster; two waves per SIMD: 90, four with the reload: 71
+            int cc = c;
+            asm volatile("" : "+v"(cc));
+            int2 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                w = twt[2047 + cc + 256 * j];
+                w11r[j] = w.x, w11i[j] = w.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w = twt[1023 + cc + 256 * j];
+                w10r[j] = w.x, w10i[j] = w.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                w = twt[511 + cc + 256 * j];
+                w9r[j] = w.x, w9i[j] = w.y;
+            }
+            w = twt[255 + cc];
+            w8r[0] = w.x, w8i[0] = w.y;
+        }
         wstage64<8>(re, im, w11r, w11i, a.st[X + 4]);
         wstage64<4>(re, im, w10r, w10i, a.st[X + 5]);
         wstage64<2>(re, im, w9r, w9i, a.st[X + 6]);
