@@ -423,6 +423,127 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- the 2-D scheme at N = 2^21 = 1024 x 2048 in TWO launches (round 5): the row cores + the store of X[k1 + 1024 k2] in one kernel --------------
+// k_big2x_c<11> leaves the products A[k1 = brev10(rho)][n2] W_N^(k1 n2) as plain values at [rho][n2]; the three-launch form then runs the 2048-point row
+// cores as a 1-D sub-plan and a layout change ([rho][k2] -> X[brev10(rho) + 1024 k2]).  Here ONE workgroup of 1024 threads takes the 16 rows whose k1 are
+// consecutive (rho = k << 6 | r6, k = 0..15: k1 = brev6(r6) << 4 | rev4(k)) -- 128 KiB, one workgroup per CU -- and writes 64-byte pieces of X itself:
+//   round 1  wave = row k, lane = n5..n0, regs j = n10..n6: STAGE 10..6 (per-lane twiddles in registers, quarter-turn sharing)
+//   stage 5  v_permlane32_swap exchanges n10 (register bit 4) with n5 (lane bit 5); STAGE 5 on the register pairs (j, j + 16), one twiddle per lane
+//   LDS      row (n10..n5) << 4 | k, column n4..n0 (33 dwords apart): the block-wide transpose that also interleaves the 16 rows
+//   round 2  thread = (jj = n10..n5, kb = rev4(k)), regs q = n4..n0: STAGE 4..0 on wave-uniform twiddles (dif_round5_c)
+//   store    X[(rev5(q) << 6 | rev6(jj)) * 1024 + (brev6(r6) << 4) + kb]: 16 consecutive lanes = one 64-byte piece; the block finishes both r6 partners
+//            (r6, r6 ^ 32: the two halves of every output line) one after the other, as k_big2x_b does
+// (int_fftNk.vhd:184-342 for the 2048-point core; the scheme itself is this library's extension).  tools/tilebench.hip: this tile
+// shape copies at 3.9-4.0 TB/s; the row sub-plan + layout change it replaces take 174 us per 2^25 samples.
+template <bool FAST_OK>
+__global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, const uint2 *__restrict__ twf, const Round5Consts c, size_t nframes, const Slice sl)
+{
+    extern __shared__ u32 lds[]; // 1024 rows x ROWY
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = __builtin_amdgcn_readfirstlane(tid >> 6); // the row of this wave (round 1)
+    u32 wa5[4], wb5[4];
+    {
+        const uint2 w = twf[31u + (unsigned)(lane & 31)]; // STAGE 5: index n4..n0
+        wa5[0] = wa5[1] = wa5[2] = wa5[3] = w.x;
+        wb5[0] = wb5[1] = wb5[2] = wb5[3] = w.y;
+    }
+    // transpose, write side: element (register r = (n5, n9..n6), lane = (n10, n4..n0)) -> row ((n10, n9..n6, n5) << 4) | k
+    u32 *const wr_base = lds + ROWY * ((((lane >> 5) << 5) << 4) | k) + (lane & 31);
+    const int jj = tid >> 4, kb = tid & 15;
+    const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
+    const u32 *const rd_base = lds + ROWY * ((jj << 4) | krow);
+    const unsigned rjj = __brev((unsigned)jj) >> 26;
+    const unsigned toff2 = (rjj << 10) | (unsigned)kb;
+    const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
+    const v2s sh5 = {s5, s5};
+    const v2s none = {0, 0};
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    // One workgroup per CU has nobody to overlap its phases with, so the NEXT tile's 32 loads are issued right behind the transpose's LDS writes (the data
+    // registers are free from there until the next vote) and fly during round 2 and the stores; round 1's 16 + 1 per-lane twiddle pairs are re-read from the
+    // L2-resident table per tile so that the two register sets (next tile's inputs, this tile's round-2 values) fit 128 VGPRs.
+    size_t t = blockIdx.x;
+    unsigned part = 0;
+    bool have = (t >> 5) < nframes;
+    u32 v[32];
+    auto load_tile = [&](size_t tt, unsigned pp) {
+        const unsigned r6 = (pp << 5) | ((unsigned)tt & 31u);
+        const u32 *src = in + ((tt >> 5) << 21) + ((size_t)(((unsigned)k << 6) | r6) << 11); // wave-uniform: this wave's row
+        unsigned lane_l = (unsigned)lane;
+        asm volatile("" : "+v"(lane_l));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << 6), lane_l)); // regs = n10..n6
+    };
+    if (have) load_tile(t, 0);
+    while (have) {
+        const size_t ct = t;
+        const unsigned cpart = part;
+        if (part == 0) part = 1;
+        else part = 0, t += gridDim.x;
+        const bool have_next = (t >> 5) < nframes;
+        u32 wa16[8], wb16[8];
+        RoundTwQ t1;
+        {
+            unsigned lb = (unsigned)lane * 8u; // the lane's byte offset into a stage table, opaque per tile
+            asm volatile("" : "+v"(lb));
+            auto ld = [&](unsigned idx, u32 &wa, u32 &wb) {
+                const uint2 w = ld2_at32b(twf + idx, lb);
+                wa = w.x;
+                wb = w.y;
+            };
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) ld(1023u + ((unsigned)j8 << 6), wa16[j8], wb16[j8]);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) ld(511u + ((unsigned)j4 << 6), t1.wa8[j4], t1.wb8[j4]);
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) ld(255u + ((unsigned)j2 << 6), t1.wa4[j2], t1.wb4[j2]);
+            ld(127u, t1.wa2[0], t1.wb2[0]);
+            ld(63u, t1.wa1[0], t1.wb1[0]);
+        }
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
+        }
+#define INTFFT_R2K_ROUND1(FX)                                                                                                                  \
+    {                                                                                                                                          \
+        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                                                      \
+        dif_round_q<FX, 0, 0, false>(v, t1, sl, none);                                                                                         \
+        dif_round_q<FX, 16, 0xF, false>(v, t1, sl, none);                                                                                      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&v[0])); /* VALU write -> v_permlane read (the asm multiplies are invisible to the padding) */ \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&v[16]));                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) swap32(v[j], v[j + 16]); /* register bit 4: n10 -> n5 */                                \
+        /* STAGE 5: pairs (j, j + 16); the kind of both inputs is n6 = j & 1 */                                                                \
+        _Pragma("unroll") for (int j = 0; j < 16; j += 4)                                                                                      \
+            group4<false, FX, false, true, false, 0xA>(v[j], v[j + 16], v[j + 1], v[j + 17], v[j + 2], v[j + 18], v[j + 3], v[j + 19], wa5, wb5, sl); \
+    }
+        if (fast) INTFFT_R2K_ROUND1(FAST_OK)
+        else INTFFT_R2K_ROUND1(false)
+#undef INTFFT_R2K_ROUND1
+#pragma unroll
+        for (int r = 0; r < 32; ++r) wr_base[ROWY * ((((r & 15) << 1) | (r >> 4)) << 4)] = v[r];
+        asm volatile("" ::: "memory");
+        if (have_next) load_tile(t, part); // flies during round 2 and the stores below
+        __syncthreads();
+        u32 w[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w[q] = rd_base[q];
+        if (fast) dif_round5_c<FAST_OK>(w, c, sl, sh5);
+        else dif_round5_c<false>(w, c, sl, sh5);
+        const unsigned r6 = (cpart << 5) | ((unsigned)ct & 31u);
+        u32 *dst = out + ((ct >> 5) << 21) + ((__brev(r6) >> 26) << 4);
+        unsigned toff2_l = toff2;
+        asm volatile("" : "+v"(toff2_l));
+#pragma unroll
+        for (int q = 0; q < 32; ++q) INTFFT_2XB_ST(w[q], at32(dst + ((size_t)rev5c(q) << 16), toff2_l));
+        have = have_next;
+    }
+}
+
 // ---- the inverse: int_ifftNk at N = 2^19, 2^20 in two passes (mirrors of pass B and pass A) ------------------------------------------
 // int_ifftNk (src/vhdl/fft/int_ifftNk.vhd:183-341) is DIT: core position p takes X[brev_L(p)], STAGE s pairs positions that differ
 // in bit s (twiddle index p mod 2^s, re/im-swapped multiplier feed of int_dit2_fly.vhd:290-325), natural order out.
@@ -922,6 +1043,35 @@ hipError_t launch_fused2d_cols(int lr, int twd, const u32 *pin, u32 *scr, const 
 }
 
 // N = 2^20: column pass + pass B.  tw1k / h_tw1k: the packed / host twiddle tables of the 1024-point cores
+// the row cores of the 1024 x 2048 plan + the store of X[k1 + 1024 k2] (k_rows2k_tr): tw16r = the 2048-point core's packed table, h_tw its host copy
+hipError_t launch_fused2d_rows2k(int twd, const u32 *prod, u32 *pout, const uint2 *tw16r, const int2 *h_tw, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = h_tw[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        wb = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsb = (size_t)1024 * ROWY * sizeof(u32);
+    const size_t pairs = nframes * 32, cap = (size_t)device_cus();
+    const unsigned grid = (unsigned)(pairs < cap ? pairs : cap);
+    if (fx) {
+        allow_max_lds(kptr(k_rows2k_tr<true>));
+        hipLaunchKernelGGL((k_rows2k_tr<true>), dim3(grid), dim3(1024), ldsb, stream, prod, pout, tw16r, c, nframes, sl);
+    } else {
+        allow_max_lds(kptr(k_rows2k_tr<false>));
+        hipLaunchKernelGGL((k_rows2k_tr<false>), dim3(grid), dim3(1024), ldsb, stream, prod, pout, tw16r, c, nframes, sl);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
                           hipStream_t stream)
 {

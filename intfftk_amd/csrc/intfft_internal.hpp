@@ -263,6 +263,7 @@ hipError_t launch_fused2d_inv(int twd, const uint32_t *pin, uint32_t *pout, uint
 const char *fused2d_kernel_name();
 hipError_t launch_fused2d(int twd, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint32_t *tw2d, size_t nframes,
                           int halves, hipStream_t stream);
+hipError_t launch_fused2d_rows2k(int twd, const uint32_t *prod, uint32_t *pout, const uint2 *tw16r, const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fused2d_cols(int lr, int twd, const uint32_t *pin, uint32_t *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint32_t *tw2d, size_t nframes,
                                int halves, hipStream_t stream);
 hipError_t launch_big2x_inv(int log2n, bool fx, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16f, const int2 *h_tw, size_t nframes,

@@ -122,6 +122,7 @@ struct intfft_plan {
     int fused2d = 0;                  // 2: N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward in two launches (k_big2x_c + k_big2x_b); 3: N = 2^21 .. 2^24 as
                                       // 1024 x N2: k_big2x_c, the row sub-plan, one layout change; 4: N = 2^20 inverse in two launches (k_big2x_qb + k_big2x_ci);
                                       // 5: N = 2^20 pair = the forward two launches, then the inverse two
+    uint2 *d_tw16r = nullptr, *d_tw16ri = nullptr; // fused2d == 3 at N2 = 2048, natural order out (round 5): the row core's packed tables for k_rows2k_tr
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
     size_t buf2d_frames = 0;
     int2 *d_tw2d = nullptr;   // 2-D scheme: the inter-pass table W_N^m, N entries
@@ -876,6 +877,14 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (e == hipSuccess) e = launch_pack_twiddles16(core1k->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw2d_tiles, ((size_t)1 << pl->L) * sizeof(uint32_t));
             if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, pl->L, p->twdl_width, nullptr);
+            if (e == hipSuccess && pl->fused2d == 3 && l2 == 11 && p->out_order == INTFFT_ORDER_NATURAL && !diag_env("INTFFT_2D_NO_ROWS2K") &&
+                big2x_tables_ok(11, pl->sub_row_f->h_tw.data(), p->twdl_width)) {
+                // N = 2^21: the row cores and the store of X[k1 + 1024 k2] in ONE launch (k_rows2k_tr): two launches instead of three
+                const size_t tot = ((size_t)1 << 11) - 1;
+                e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) {
                 intfft_plan_destroy(pl);
@@ -893,6 +902,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
+            else if (pl->d_tw16r) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr]");
             else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
         }
         *out = pl;
@@ -1233,6 +1243,8 @@ int intfft_plan_destroy(intfft_plan *plan)
         if (plan->d_tw) (void)hipFree(plan->d_tw);
         if (plan->d_tw2d) (void)hipFree(plan->d_tw2d);
         if (plan->d_tw2d_tiles) (void)hipFree(plan->d_tw2d_tiles);
+        if (plan->d_tw16r) (void)hipFree(plan->d_tw16r);
+        if (plan->d_tw16ri) (void)hipFree(plan->d_tw16ri);
         for (void *b : plan->buf2d)
             if (b) (void)hipFree(b);
         for (intfft_plan *sp : {plan->sub_col_f, plan->sub_row_f, plan->sub_row_i, plan->sub_col_i, plan->pair_f, plan->pair_i})
@@ -1285,7 +1297,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
         if (plan->fused2d == 2 || plan->fused2d == 4) info->n_passes = 2;
         if (plan->fused2d == 5) info->n_passes = 4;
-        if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
+        if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
         // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
@@ -1316,7 +1328,9 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
 // buf2d_frames): the chunking below is the same in both cases.
 static bool dual_2d(const intfft_plan *pl)
 {
-    return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || pl->sub_row_f->scratch_bytes == 0);
+    // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
+    // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
+    return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r));
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1406,6 +1420,10 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
             char *b1 = static_cast<char *>(buf1) + off;
             e = launch_fused2d_cols(l2, p.twdl_width, src, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
             if (e != hipSuccess) break;
+            if (pl->d_tw16r) { // N2 = 2048, natural order out: the row cores write X themselves
+                e = launch_fused2d_rows2k(p.twdl_width, b0, reinterpret_cast<uint32_t *>(dst), pl->d_tw16r, pl->sub_row_f->h_tw.data(), nf, st);
+                continue;
+            }
             if ((rc = exec_core(pl->sub_row_f, b0, b1, nf << l1, st, subws)) != INTFFT_OK) break;
             // logical k = k1 + N1 k2 sits at [rho = brev(k1)][k2]: k bit j < l1 at in bit l2 + (l1 - 1 - j), else at j - l1
             for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + (l1 - 1 - j) : j - l1;

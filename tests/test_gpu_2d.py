@@ -73,7 +73,7 @@ def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
         got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
         # N1 = 1024: the column cores + multiplier run on tiles (k_big2x_c): two launches at N = 2^20, else column pass + row sub-plan + one
         # layout change; other splits: the five-launch composite
-        want = 2 if (log2n, l1) == (20, 10) else 3 if l1 == 10 else None
+        want = 2 if (log2n, l1) in ((20, 10), (21, 10)) else 3 if l1 == 10 else None  # (2^21: the row cores write X themselves since round 5)
         assert (info["n_passes"] == want if want else info["n_passes"] >= 4) and info["kernel_name"].startswith("2d["), info
         assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
 
@@ -256,7 +256,15 @@ def test_2d_1024_by_n2_three_launches(log2n, frames, out_order, monkeypatch):
     x = uniform_frames(frames, n, 15, 888 + log2n)
     x[0] = uniform_frames(1, n, 16, 6)[0]
     got, info = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, out_order=out_order)
-    assert info["kernel_name"].startswith("2d[k_big2x_c|") and info["n_passes"] == 3, info  # (N2 = 8192 / 16384: a one-pass row core since round 4)
+    # (N2 = 8192 / 16384: a one-pass row core since round 4; N2 = 2048 in natural order out: the row cores write X themselves, two launches, round 5)
+    two = log2n == 21 and out_order == "NATURAL"
+    assert info["kernel_name"] == ("2d[k_big2x_c|k_rows2k_tr]" if two else info["kernel_name"]) and info["kernel_name"].startswith("2d[k_big2x_c|"), info
+    assert info["n_passes"] == (2 if two else 3), info
+    if two:
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+            got3, info3 = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, out_order=out_order)
+            assert info3["n_passes"] == 3 and np.array_equal(got, got3), info3
     with monkeypatch.context() as m:
         m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
         got5, info5 = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, out_order=out_order)
