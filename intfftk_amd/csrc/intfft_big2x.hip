@@ -244,6 +244,146 @@ __global__ __launch_bounds__((1 << CB) << (L - 15)) __attribute__((amdgpu_waves_
     (void)T;
 }
 
+// ---- pass A at N = 2^20 on FULL lines, one pipelined workgroup per CU (round 5; an EXPERIMENT behind INTFFT_2XA_FULL20, not the shipped path) ---------------
+// Result (profiles/r05_c4_variants.md): bit-exact, 141 us per 2^26 samples against the paired half lines' 145 on one stream -- no faster -- and it cannot
+// share a CU with pass B of the other stream: C4 292 against 313 Gsample/s on the same box.  Kept so that the table regenerates.
+// A 1024-row x 32-column tile (128-byte row pieces) is 128 KiB: one workgroup per CU, which -- load, ten stages, store in sequence -- ran at 3.8 TB/s in round 2
+// and lost to the XCD-paired half lines (3.7 TB/s at two workgroups per CU, beside which pass B of the other stream can run).  What k_rows2k_tr showed
+// (5.2 TB/s from one 135 KiB workgroup per CU with its eleven stages): the NEXT tile's 32 loads can be issued right behind the transpose's LDS writes -- the
+// data registers are free from there to the next vote -- and fly during round 2 and the stores.  Same arithmetic, twiddles, votes and scratch layout as
+// k_big2x_a<20> (thread = (hx, l = n4..n0): 1024 threads); round 2's twiddles are read from their LDS slots just before the stage that uses them (8 + 8
+// pairs instead of 16 live beside the prefetched registers); the per-column set is re-parked per tile behind the vote's barrier.
+template <bool FAST_OK>
+__global__ __launch_bounds__(1024) void k_big2x_a1(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, size_t nframes, const Slice sl)
+{
+    constexpr int L = 20, RB = 5, C = 32, ROWX = C + 1;
+    extern __shared__ u32 lds[]; // 1024 rows x ROWX, then the round-2 twiddles: 16 slots x 32 columns of {wa, wb}
+    uint2 *const tw2 = reinterpret_cast<uint2 *>(lds + 1024 * ROWX);
+    const int tid = threadIdx.x, l = tid & (C - 1), hx = tid >> 5;
+    u32 *const wr_base = lds + ROWX * hx + l;              // transpose, write side: row (j << RB) + hx
+    const u32 *const rd_base = lds + ROWX * (hx << 5) + l; // read side: row (jx << 5) + q, jx = tid >> 5
+    const v2s none = {0, 0};
+    const short s2 = (short)(1 - (hx & 1)); // round 2: the kind of its inputs is n15 = bit 0 of the new thread index
+    const v2s sh2 = {s2, s2};
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    const size_t ntiles = nframes << 5; // 32 column groups per frame; neighbouring tiles = neighbouring column groups of one frame
+    size_t t = blockIdx.x;
+    bool have = t < ntiles;
+    u32 v[32];
+    auto load_tile = [&](size_t tt) {
+        const u32 *src = in + ((tt >> 5) << L); // wave-uniform
+        unsigned toff = ((unsigned)hx << 10) | (((unsigned)tt & 31u) * C + (unsigned)l);
+        asm volatile("" : "+v"(toff));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = INTFFT_2XA_LD(at32(src + ((size_t)j << (RB + 10)), toff)); // regs = n19..n15
+    };
+    if (have) load_tile(t);
+    while (have) {
+        const size_t ct = t;
+        t += gridDim.x;
+        const bool have_next = t < ntiles;
+        const unsigned chunk = (unsigned)ct & 31u;
+        const unsigned lfull = chunk * C + (unsigned)l;      // n9..n0
+        const unsigned toff = ((unsigned)hx << 10) | lfull;
+        // round 1's per-thread twiddles: reg bit b <-> stage L-5+b; index of (stage s, low reg bits jj) = ((jj << RB | hx) << 10) | lfull
+        u32 wa16[8], wb16[8];
+        RoundTwQ t1;
+        {
+            unsigned twb = toff * 8u;
+            asm volatile("" : "+v"(twb));
+            auto ld = [&](unsigned uniform_idx, u32 &wa, u32 &wb) {
+                const uint2 w = ld2_at32b(twf + uniform_idx, twb);
+                wa = w.x;
+                wb = w.y;
+            };
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) ld((1u << (L - 1)) - 1u + ((unsigned)jj << (RB + 10)), wa16[jj], wb16[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ld((1u << (L - 2)) - 1u + ((unsigned)jj << (RB + 10)), t1.wa8[jj], t1.wb8[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) ld((1u << (L - 3)) - 1u + ((unsigned)jj << (RB + 10)), t1.wa4[jj], t1.wb4[jj]);
+            ld((1u << (L - 4)) - 1u, t1.wa2[0], t1.wb2[0]);
+            ld((1u << (L - 5)) - 1u, t1.wa1[0], t1.wb1[0]);
+        }
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads (rows AND twiddle slots)
+            fast = FAST_OK && !bad;
+        }
+        if (hx == 0) { // round 2's twiddles of this tile's columns (stage 10 + b, table index (rr << 10) | lfull): parked per column
+            int sidx = 0;
+            auto park = [&](unsigned uniform_idx) { tw2[C * sidx++ + l] = (twf + uniform_idx)[lfull]; };
+            for (int rr = 0; rr < 8; ++rr) park((1u << 14) - 1u + ((unsigned)rr << 10));
+            for (int rr = 0; rr < 4; ++rr) park((1u << 13) - 1u + ((unsigned)rr << 10));
+            for (int rr = 0; rr < 2; ++rr) park((1u << 12) - 1u + ((unsigned)rr << 10));
+            park((1u << 11) - 1u);
+            park((1u << 10) - 1u);
+        }
+        if (!fast && sl.wd != 16) wrap_inputs(v, sl.wd);
+#define INTFFT_2XA1_ROUND1(FX)                                       \
+    {                                                                \
+        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);            \
+        dif_round_q<FX, 0, 0, false, 4>(v, t1, sl, none);            \
+        dif_round_q<FX, 16, 0xF, false, 4>(v, t1, sl, none);         \
+    }
+        if (fast) INTFFT_2XA1_ROUND1(FAST_OK)
+        else INTFFT_2XA1_ROUND1(false)
+#undef INTFFT_2XA1_ROUND1
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wr_base[ROWX * (j << RB)] = v[j];
+        asm volatile("" ::: "memory");
+        if (have_next) load_tile(t); // flies during round 2 and the stores below (issued behind round 2's top stage instead: 273 against 292 Gsample/s)
+        __syncthreads();
+        u32 w[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w[q] = rd_base[ROWX * q];
+        {
+            u32 wa2t[8], wb2t[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const uint2 x = tw2[C * rr + l];
+                wa2t[rr] = x.x, wb2t[rr] = x.y;
+            }
+            if (fast) dif_top16<FAST_OK, 0, true>(w, wa2t, wb2t, sl, sh2);
+            else dif_top16<false, 0, true>(w, wa2t, wb2t, sl, sh2);
+        }
+        __builtin_amdgcn_sched_barrier(0); // the lower stages' twiddles are fetched only now (register pressure beside the prefetched tile)
+        {
+            RoundTwQ t2;
+            int sidx = 8;
+            auto get = [&](u32 &wa, u32 &wb) {
+                const uint2 x = tw2[C * sidx++ + l];
+                wa = x.x, wb = x.y;
+            };
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) get(t2.wa8[rr], t2.wb8[rr]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) get(t2.wa4[rr], t2.wb4[rr]);
+            get(t2.wa2[0], t2.wb2[0]);
+            get(t2.wa1[0], t2.wb1[0]);
+            if (fast) {
+                dif_round_q<FAST_OK, 0, 0, false>(w, t2, sl, none);
+                dif_round_q<FAST_OK, 16, 0xF, false>(w, t2, sl, none);
+            } else {
+                dif_round_q<false, 0, 0, false, 4>(w, t2, sl, none);
+                dif_round_q<false, 16, 0xF, false, 4>(w, t2, sl, none);
+            }
+        }
+        // store side: scratch [q][c][hi][k][l], thread = (jx = n19..n15, l): k = jx >> 1, hi = jx & 1; c = 2 chunk + (l >> 4)
+        u32 *dst = scr + ((ct >> 5) << L);
+        unsigned toff2 = (((chunk << 1) + ((unsigned)l >> 4)) << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | ((unsigned)l & 15u);
+        asm volatile("" : "+v"(toff2));
+#pragma unroll
+        for (int q = 0; q < 32; ++q) *at32(dst + ((size_t)q << (L - 5)), toff2) = w[q];
+        have = have_next;
+    }
+}
+
 // ---- pass B's second round: DIF stages 4..0 on regs = n4..n0, wave-uniform twiddles -------------------------------------------
 // inputs: per-thread kind (shv: 0 where the registers already hold X >> 1)
 template <bool FASTX, int ROUND = 0> __device__ __forceinline__ void dif_round5_c(u32 (&v)[32], const Round5Consts &c, const Slice &sl, v2s shv)
@@ -1315,7 +1455,12 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
     for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
 #define INTFFT_2XB_SHIFT 1 /* a block of pass B takes both partner tiles */
 #define INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                                              \
-    if (LL == 19 && full19) {                                                                                                                                 \
+    if (LL == 20 && RD == 0 && !halves && full20) { /* one pipelined workgroup per CU on full lines (k_big2x_a1) */                                           \
+        const size_t lds20 = (size_t)1024 * 33 * sizeof(u32) + 16 * 32 * sizeof(uint2);                                                                       \
+        const size_t nt = nframes << 5, capa = (size_t)device_cus();                                                                                          \
+        allow_max_lds(kptr(k_big2x_a1<FX>));                                                                                                                   \
+        hipLaunchKernelGGL((k_big2x_a1<FX>), dim3((unsigned)(nt < capa ? nt : capa)), dim3(1024), lds20, stream, pin, scr, tw16f, nframes, sl);                \
+    } else if (LL == 19 && full19) {                                                                                                                                 \
         constexpr int CB19 = LL == 19 ? 5 : 4; /* (instantiated for LL = 19 only) */                                                                            \
         const size_t lds19 = ((size_t)(32 << RB) * 33 + 1) * sizeof(u32) + 8 * 32 * sizeof(uint2);                                                             \
         allow_max_lds(kptr(k_big2x_a<LL, FX, RD, CB19>));                                                                                                      \
@@ -1335,7 +1480,8 @@ hipError_t launch_big2x(int log2n, bool fx, const u32 *pin, u32 *pout, u32 *scr,
         const size_t cap = 64;                                                                                                     \
         const unsigned groups = (unsigned)(nframes < cap ? nframes : cap);                                                         \
         const bool full19 = diag_env("INTFFT_2XA_HALF19") == nullptr; /* A/B: the half-line tiles of round 4 at N = 2^19 */        \
-        (void)full19;                                                                                                              \
+        const bool full20 = diag_env("INTFFT_2XA_FULL20") != nullptr; /* experiment: full-line pass A at N = 2^20 */               \
+        (void)full19, (void)full20;                                                                                                \
         INTFFT_2XA_LAUNCH(LL, FX, RD)                                                                                                \
         const size_t ntiles = nframes << (LL - 14) >> INTFFT_2XB_SHIFT, capb = ((size_t)device_cus() * 2 + 15) / 16 * 16;          \
         const unsigned gb = (unsigned)(ntiles < capb ? (ntiles + 15) / 16 * 16 : capb);                                            \
