@@ -111,6 +111,10 @@ __global__ __launch_bounds__((1 << CB) << (L - 15)) __attribute__((amdgpu_waves_
     const unsigned lfull = chunk * C + l;               // n9..n0
     const unsigned toff = ((unsigned)hx << 10) | lfull; // this thread's offset inside a block of rows (n(9+RB)..n0)
     auto ld = [&](unsigned uniform_idx, unsigned thread_boff, u32 &wa, u32 &wb) { // thread_boff: BYTE offset of the thread's entry
+#ifdef INTFFT_2XA_ABL_TW /* ablation (results wrong by construction): every twiddle read lands in one 8 KiB window -- what do the 8 MiB tables cost? */
+        thread_boff &= 0x1FF8u;
+        uniform_idx &= 1023u;
+#endif
         const uint2 w = ld2_at32b(twf + uniform_idx, thread_boff);
         wa = w.x;
         wb = w.y;
