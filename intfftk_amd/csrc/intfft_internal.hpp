@@ -217,6 +217,7 @@ struct WideStage {
 struct WideArgs {
     WideStage st[16];  // processing order: forward st[ii] is STAGE NFFT - 1 - ii, inverse st[s] is STAGE s
     int dw;            // DATA_WIDTH (wrap on load)
+    int native;        // bit 0: HALVES order on the time side, bit 1: BITREV order on the frequency side (NAT instantiations)
     int w64;           // the first pass runs on 64-bit words too (k_wide64_p1 / q1: DATA_WIDTH 25 .. 32), 16-byte scratch samples
 };
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,

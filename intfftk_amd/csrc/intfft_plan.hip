@@ -1120,8 +1120,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (big2x_inv) pl->big_two_pass = true;
         // class 1: the first pass within int32 (17 .. 27-bit data); class 2 (round 5): DATA_WIDTH up to 32, the first pass on 64-bit words too
         const int wcls = generic_only ? 0 : wide16_class(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
-        pl->wide16 = wcls != 0 && (wcls == 2 || pl->passes.size() == 2) && !diag_env("INTFFT_NO_WIDE16");
+        pl->wide16 = wcls != 0 && !diag_env("INTFFT_NO_WIDE16");
         pl->wargs.w64 = wcls == 2;
+        pl->wargs.native = p->direction == INTFFT_INV ? ((p->out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->in_order == INTFFT_ORDER_BITREV ? 2 : 0))
+                                                       : ((p->in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->out_order == INTFFT_ORDER_BITREV ? 2 : 0));
         if (pl->wide16 && wcls == 2) { // every stage on the 64-bit butterflies (wfly64 / wdit64): exact 64-bit products, the slice inside one dword pair
             std::vector<StageDesc> st;
             const int LL = p->log2n;
@@ -1201,7 +1203,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw || pl->wide16) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->wide16 && pl->wargs.w64) ? 8 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->wide16 && pl->wargs.w64) ? 8 : pl->wide16 ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream

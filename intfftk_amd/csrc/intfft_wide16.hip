@@ -51,6 +51,18 @@ constexpr int PLANEW = 256 * ROWW;    // dwords per transpose plane
 
 __device__ __forceinline__ constexpr int rev4w(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
+// ---- the cores' own beat orders on the two-pass wide classes (round 5; NAT instantiations, WideArgs::native bit 0: HALVES on the time side, bit 1: BITREV on
+// the frequency side; int_fftNk.vhd:15-21 / int_ifftNk.vhd:15-21).  Time side (first pass of the forward core, last of the inverse): thread (hi4, c) holds the rows
+// r = 16 j + hi4; a HALVES beat (x[i], x[i + N/2]) is the register pair (j, j | 2^(L-13)) -- adjacent samples in memory, ONE 16-byte (32-byte) access.
+// Frequency side: BITREV order is the core position itself, p = (t4 << (L-4)) + 256 low + c in a unit: coalesced with thread = c, registers = t4; a 16 x 16
+// exchange through the transpose planes (rows of the same 20-dword stride) hands it to / takes it from the round layout (thread = (c7..4, t4), registers = c3..0).
+// time-side pair of register j (HALVES): its partner and the 16-byte index of the pair inside the virtual frame: g N/2 + 4096 (j's bits below the pair bit) + thread part
+template <int L> __device__ __forceinline__ constexpr int halves_pair_bit() { return 1 << (L - 13); }
+template <int L> __device__ __forceinline__ constexpr int halves_pair_index(int j) // j with the pair bit clear
+{
+    return ((j >> (L - 12)) << (L - 1)) + 4096 * (j & ((1 << (L - 12)) - 1));
+}
+
 // ---- 32-bit butterflies (pass 1) --------------------------------------------------------------------
 // s2 = a + b + wo - 32 (alignbit amount that leaves the wo result bits top-aligned), s3 = 32 - wo
 template <bool AZ>
@@ -95,7 +107,7 @@ __device__ __forceinline__ void wstage32(int (&re)[16], int (&im)[16], const int
     wstage32x<H, false>(re, im, wr, wi, s); // the masked form covers a = 0 too (keep = ~0)
 }
 
-template <int L>
+template <int L, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
                                                    const WideArgs a, size_t nframes_user)
 {
@@ -171,7 +183,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         asm volatile("" : "+v"(toff)); // opaque per iteration: hoisted out of the frame loop the zero-extended offset becomes a VGPR pair again
         const bool partial = L < 16 && (f + 1) * G > nframes_user; // last group: rows of absent frames read as 0, are not stored
         typedef int v2i __attribute__((ext_vector_type(2)));
-        if (!partial) {
+        if (NAT && (a.native & 1)) { // HALVES order in: one 16-byte load per register pair (j, j | 2^(L-13))
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i *src4 = reinterpret_cast<const v4i *>(in) + f * 32768;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j & halves_pair_bit<L>()) continue;
+                v4i x = {0, 0, 0, 0};
+                if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) x = INTFFT_LD(at32(src4 + halves_pair_index<L>(j), toff));
+                re[j] = __builtin_amdgcn_sbfe(x.x, 0, a.dw), im[j] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+                re[j | halves_pair_bit<L>()] = __builtin_amdgcn_sbfe(x.z, 0, a.dw), im[j | halves_pair_bit<L>()] = __builtin_amdgcn_sbfe(x.w, 0, a.dw);
+            }
+        } else if (!partial) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const v2i x = INTFFT_LD(at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff));
@@ -307,7 +330,7 @@ __device__ __forceinline__ void wstage64(i64 (&re)[16], i64 (&im)[16], const int
     wstage64x<H, false, UNIFORM_W>(re, im, wr, wi, s);
 }
 
-template <int L, bool IN64 = false> // IN64: the scratch holds 64-bit words (k_wide64_p1 in front: DATA_WIDTH 25 .. 32, round 5)
+template <int L, bool IN64 = false, bool NAT = false> // IN64: the scratch holds 64-bit words (k_wide64_p1 in front: DATA_WIDTH 25 .. 32, round 5)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
                                                    const WideArgs a, const W2Consts k, size_t nframes_user)
 {
@@ -424,6 +447,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // natural-order output index within the real frame: brev_L(256 r' + c), r' = 2^(L-12) t4 + low
         //   = 2^(L-4) rev4(c3..0) + 2^(L-8) rev4(c7..4) + 16 brev_(L-12)(low) + rev4(t4)      (L = 16: low = r0, t4 = j)
         typedef i64 v2l __attribute__((ext_vector_type(2)));
+        if (NAT && (a.native & 2)) { // BITREV order out: memory index = core position p = (t4 << (L-4)) + 256 low + c
+            // the thread's 16 results c3..0 of row t4 -> thread = c, registers = t4: a 16 x 16 exchange through the planes (re.lo / im.lo, then the packed high halves)
+            u32 hq[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hq[q] = ((u32)((u64)re[q] >> 32) & 0xFFFFu) | ((u32)((u64)im[q] >> 32) << 16);
+            uint4 *const xw0 = reinterpret_cast<uint4 *>(lds + ROWW * tid), *const xw1 = reinterpret_cast<uint4 *>(lds + PLANEW + ROWW * tid);
+            const u32 *const xr0 = lds + ROWW * (16 * hi4) + lo4, *const xr1 = xr0 + PLANEW; // + ROWW * t4
+            u32 xl[16], yl[16];
+            __syncthreads(); // the round's transpose reads are done
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xw0[q] = make_uint4((u32)re[4 * q], (u32)re[4 * q + 1], (u32)re[4 * q + 2], (u32)re[4 * q + 3]);
+                xw1[q] = make_uint4((u32)im[4 * q], (u32)im[4 * q + 1], (u32)im[4 * q + 2], (u32)im[4 * q + 3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) xl[t] = xr0[ROWW * t], yl[t] = xr1[ROWW * t];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xw0[q] = make_uint4(hq[4 * q], hq[4 * q + 1], hq[4 * q + 2], hq[4 * q + 3]);
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) hq[t] = xr0[ROWW * t];
+            v2l *dstp = reinterpret_cast<v2l *>(out) + (real << L) + 256 * ulow; // wave-uniform
+            unsigned tp = (unsigned)tid;
+            asm volatile("" : "+v"(tp));
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const v2l y = {(i64)(((u64)(u32)(int)__builtin_amdgcn_sbfe((int)hq[t], 0, 16) << 32) | xl[t]), (i64)(((u64)(u32)((int)hq[t] >> 16) << 32) | yl[t])};
+                __builtin_nontemporal_store(y, at32(dstp + ((size_t)t << (L - 4)), tp));
+            }
+            continue;
+        }
         const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
         v2l *dst = reinterpret_cast<v2l *>(out) + (real << L) + 16 * rlow; // wave-uniform
         unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4));
@@ -512,7 +568,7 @@ __device__ __forceinline__ void wdstage64(i64 (&re)[16], i64 (&im)[16], const in
         }
 }
 
-template <int L>
+template <int L, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_q1(const int2 *in, int2 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              const W2Consts k, size_t nframes_user)
 {
@@ -563,11 +619,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
         asm volatile("" : "+v"(toff), "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
         int re[16], im[16];
+        if (NAT && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = c, registers = t4), then the 16 x 16 exchange
+            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << L) + 256 * ulow; // wave-uniform
+            u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4, *const xw1 = xw0 + PLANEW; // + ROWW * t4
+            const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid), *const xr1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
+            __syncthreads(); // the previous unit's transpose reads are done
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff); // (plain: the sixteen 8-byte pieces of a 128-byte line come from sixteen lanes of one instruction)
-            re[q] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
-            im[q] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            for (int t = 0; t < 16; ++t) {
+                const v2i x = INTFFT_LD(at32(srcp + ((size_t)t << (L - 4)), tid_l));
+                xw0[ROWW * t] = (u32)x.x, xw1[ROWW * t] = (u32)x.y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 x = xr0[q], y = xr1[q];
+                re[4 * q] = __builtin_amdgcn_sbfe((int)x.x, 0, a.dw), re[4 * q + 1] = __builtin_amdgcn_sbfe((int)x.y, 0, a.dw);
+                re[4 * q + 2] = __builtin_amdgcn_sbfe((int)x.z, 0, a.dw), re[4 * q + 3] = __builtin_amdgcn_sbfe((int)x.w, 0, a.dw);
+                im[4 * q] = __builtin_amdgcn_sbfe((int)y.x, 0, a.dw), im[4 * q + 1] = __builtin_amdgcn_sbfe((int)y.y, 0, a.dw);
+                im[4 * q + 2] = __builtin_amdgcn_sbfe((int)y.z, 0, a.dw), im[4 * q + 3] = __builtin_amdgcn_sbfe((int)y.w, 0, a.dw);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff); // (plain: the sixteen 8-byte pieces of a 128-byte line come from sixteen lanes of one instruction)
+                re[q] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
+                im[q] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            }
         }
         // STAGE 0: T = B (int_dit2_fly.vhd:221-230); STAGE 1: T = B on even positions, +j B with the negation quirk on odd ones (:234-286)
 #pragma unroll
@@ -617,7 +694,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-template <int L, bool IN64 = false> // IN64: the scratch holds 64-bit words (k_wide64_q1 in front)
+template <int L, bool IN64 = false, bool NAT = false> // IN64: the scratch holds 64-bit words (k_wide64_q1 in front)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_q2(const int2 *scr, i64 *out, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              size_t nframes_user)
 {
@@ -749,6 +826,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if constexpr (L > 15) wdstage64<8>(re, im, w15r, w15i, a.st[15]);
         // natural order: x[(16 j + hi4) 256 + c] of the virtual frame; register j's real frame is j >> (L - 12)
         typedef i64 v2l __attribute__((ext_vector_type(2)));
+        if (NAT && (a.native & 1)) { // HALVES order out: one 32-byte store per register pair (j, j | 2^(L-13))
+            typedef i64 v4l __attribute__((ext_vector_type(4)));
+            v4l *dst4 = reinterpret_cast<v4l *>(out) + f * 32768;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j & halves_pair_bit<L>()) continue;
+                const v4l y = {re[j], im[j], re[j | halves_pair_bit<L>()], im[j | halves_pair_bit<L>()]};
+                if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) __builtin_nontemporal_store(y, at32(dst4 + halves_pair_index<L>(j), toff));
+            }
+            continue;
+        }
         v2l *dst = reinterpret_cast<v2l *>(out) + f * 65536;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -766,7 +854,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // the three-plane LDS transpose of the <= 36-bit values between the rounds -- and k_wide16_p2 / k_wide16_q2 read their scratch as 64-bit words
 // (IN64).  Results up to 48 bits (the 16-bit
 // high plane of the second pass's transpose).
-template <int L>
+template <int L, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_p1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              size_t nframes_user)
 {
@@ -837,13 +925,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         asm volatile("" : "+v"(toff));
         const bool partial = L < 16 && (f + 1) * G > nframes_user;
         typedef int v2i __attribute__((ext_vector_type(2)));
+        // conv_std_logic_vector(.., DATA_WIDTH): wrap on load (v_bfe_i32 takes the width modulo 32: nothing to wrap at 32 bits; the builtin returns unsigned)
+        auto wrap = [&](int x) { return a.dw >= 32 ? x : (int)__builtin_amdgcn_sbfe(x, 0, a.dw); };
+        if (NAT && (a.native & 1)) { // HALVES order in (see k_wide16_p1)
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i *src4 = reinterpret_cast<const v4i *>(in) + f * 32768;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            v2i x = {0, 0};
-            if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) x = INTFFT_LD(at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff));
-            // conv_std_logic_vector(.., DATA_WIDTH): wrap on load (v_bfe_i32 takes the width modulo 32: nothing to wrap at 32 bits)
-            re[j] = a.dw >= 32 ? x.x : (int)__builtin_amdgcn_sbfe(x.x, 0, a.dw) /* (the builtin returns unsigned) */;
-            im[j] = a.dw >= 32 ? x.y : (int)__builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            for (int j = 0; j < 16; ++j) {
+                if (j & halves_pair_bit<L>()) continue;
+                v4i x = {0, 0, 0, 0};
+                if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) x = INTFFT_LD(at32(src4 + halves_pair_index<L>(j), toff));
+                re[j] = wrap(x.x), im[j] = wrap(x.y);
+                re[j | halves_pair_bit<L>()] = wrap(x.z), im[j | halves_pair_bit<L>()] = wrap(x.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                v2i x = {0, 0};
+                if (!partial || f * G + (size_t)(j >> (L - 12)) < nframes_user) x = INTFFT_LD(at32(reinterpret_cast<const v2i *>(src + 4096 * j), toff));
+                re[j] = wrap(x.x);
+                im[j] = wrap(x.y);
+            }
         }
         if constexpr (L > 15) wstage64<8>(re, im, w15r, w15i, a.st[X + 0]);
         if constexpr (L > 14) wstage64<4>(re, im, w14r, w14i, a.st[X + 1]);
@@ -936,7 +1038,7 @@ __device__ __forceinline__ void wdstage64u(i64 (&re)[16], i64 (&im)[16], const i
         }
 }
 
-template <int L>
+template <int L, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_q1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              const W2Consts k, size_t nframes_user)
 {
@@ -984,11 +1086,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
         asm volatile("" : "+v"(toff), "+v"(tid_l));
         i64 re[16], im[16];
+        auto wrap = [&](int x) { return a.dw >= 32 ? x : (int)__builtin_amdgcn_sbfe(x, 0, a.dw); }; // (the builtin returns unsigned)
+        if (NAT && (a.native & 2)) { // BITREV order in (see k_wide16_q1)
+            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << L) + 256 * ulow;
+            u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4, *const xw1 = xw0 + PLANEW;
+            const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid), *const xr1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff);
-            re[q] = a.dw >= 32 ? x.x : (int)__builtin_amdgcn_sbfe(x.x, 0, a.dw) /* (the builtin returns unsigned) */;
-            im[q] = a.dw >= 32 ? x.y : (int)__builtin_amdgcn_sbfe(x.y, 0, a.dw);
+            for (int t = 0; t < 16; ++t) {
+                const v2i x = INTFFT_LD(at32(srcp + ((size_t)t << (L - 4)), tid_l));
+                xw0[ROWW * t] = (u32)x.x, xw1[ROWW * t] = (u32)x.y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 x = xr0[q], y = xr1[q];
+                re[4 * q] = wrap((int)x.x), re[4 * q + 1] = wrap((int)x.y), re[4 * q + 2] = wrap((int)x.z), re[4 * q + 3] = wrap((int)x.w);
+                im[4 * q] = wrap((int)y.x), im[4 * q + 1] = wrap((int)y.y), im[4 * q + 2] = wrap((int)y.z), im[4 * q + 3] = wrap((int)y.w);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff);
+                re[q] = wrap(x.x);
+                im[q] = wrap(x.y);
+            }
         }
         // STAGE 0: T = B; STAGE 1: T = B on even positions, +j B with the negation quirk on odd ones (int_dit2_fly.vhd:221-286)
 #pragma unroll
@@ -1053,6 +1175,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// orders the two-pass wide kernels take: natural, or the core's own beat order on either side (NAT instantiations, round 5)
+static bool wide_orders_ok(int direction, int in_order, int out_order)
+{
+    if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
+    return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2);                     // int_ifftNk: NATURAL | BITREV in, NATURAL | HALVES out
+}
+
 // which first pass a configuration takes: 0 none, 1 int32 (k_wide16_p1 / q1), 2 64-bit words (k_wide64_p1 / q1; round 5)
 int wide16_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
@@ -1060,7 +1189,8 @@ int wide16_class(int log2n, int data_width, int twdl_width, int format, int dire
     // DATA_WIDTH up to 32 in int32 containers, results of 33 .. 48 bits in int64 containers; the per-stage conditions (exact 64-bit products, the
     // slice inside one dword pair) are checked by the planner on the stage list
     const bool common = log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width <= 32 && data_width + log2n > 32 && data_width + log2n <= 48 &&
-                        twdl_width >= 8 && twdl_width <= 24 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0;
+                        twdl_width >= 8 && twdl_width <= 24 && format == 1 && use_fly == 1 && (direction == 0 || direction == 1) &&
+                        wide_orders_ok(direction, in_order, out_order);
     return common && (direction == 0 || direction == 1) ? 2 : 0;
 }
 
@@ -1072,10 +1202,10 @@ bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int
     // the inverse (round 4): STAGE 0..7 on int32 (DATA_WIDTH + 8 <= 32), STAGE 8..L-1 on 64-bit words, the same result widths
     if (direction == 1)
         return log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width + 8 <= 32 && data_width + log2n > 32 && data_width + log2n <= 40 &&
-               twdl_width >= 16 && twdl_width <= 24 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0;
+               twdl_width >= 16 && twdl_width <= 24 && format == 1 && use_fly == 1 && wide_orders_ok(direction, in_order, out_order);
     return log2n >= 13 && log2n <= 16 && data_width >= 17 && data_width + log2n - 8 <= 32 && data_width + log2n > 32 &&
            data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 && use_fly == 1 &&
-           in_order == 0 && out_order == 0;
+           wide_orders_ok(direction, in_order, out_order);
 }
 
 const char *wide16_kernel_name(int direction, int w64)
@@ -1084,54 +1214,45 @@ const char *wide16_kernel_name(int direction, int w64)
     return direction == 1 ? "k_wide16_q1+q2" : "k_wide16_p1+p2";
 }
 
+template <int L, bool NAT>
+static hipError_t launch_wide_ln(const WideArgs &a, const W2Consts &k, const void *in, void *out, void *scratch, const int2 *tw_all,
+                                 size_t nframes, hipStream_t stream, int direction)
+{
+    const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L); // virtual 2^16-point frames
+    const size_t units = nvf * 16;
+    auto tiles16 = [&](const void *kern) { // a multiple of the 16 column tiles
+        size_t g = resident_blocks(kern, 256, 2) & ~(size_t)15;
+        if (g < 16) g = 16;
+        return g > units ? units : g;
+    };
+    auto anyg = [&](const void *kern) {
+        const size_t g = resident_blocks(kern, 256, 2);
+        return g > units ? units : g;
+    };
+    const int2 *pin = static_cast<const int2 *>(in);
+    i64 *pout = static_cast<i64 *>(out);
+    if (a.w64 && direction == 1) {
+        hipLaunchKernelGGL((k_wide64_q1<L, NAT>), dim3((unsigned)anyg(kptr(k_wide64_q1<L, NAT>))), dim3(256), 0, stream, pin, static_cast<i64 *>(scratch), tw_all, a, k, nframes);
+        hipLaunchKernelGGL((k_wide16_q2<L, true, NAT>), dim3((unsigned)tiles16(kptr(k_wide16_q2<L, true, NAT>))), dim3(256), 0, stream, static_cast<const int2 *>(scratch), pout, tw_all, a, nframes);
+    } else if (a.w64) {
+        hipLaunchKernelGGL((k_wide64_p1<L, NAT>), dim3((unsigned)tiles16(kptr(k_wide64_p1<L, NAT>))), dim3(256), 0, stream, pin, static_cast<i64 *>(scratch), tw_all, a, nframes);
+        hipLaunchKernelGGL((k_wide16_p2<L, true, NAT>), dim3((unsigned)anyg(kptr(k_wide16_p2<L, true, NAT>))), dim3(256), 0, stream, static_cast<const int2 *>(scratch), pout, tw_all, a, k, nframes);
+    } else if (direction == 1) {
+        hipLaunchKernelGGL((k_wide16_q1<L, NAT>), dim3((unsigned)anyg(kptr(k_wide16_q1<L, NAT>))), dim3(256), 0, stream, pin, static_cast<int2 *>(scratch), tw_all, a, k, nframes);
+        hipLaunchKernelGGL((k_wide16_q2<L, false, NAT>), dim3((unsigned)tiles16(kptr(k_wide16_q2<L, false, NAT>))), dim3(256), 0, stream, static_cast<const int2 *>(scratch), pout, tw_all, a, nframes);
+    } else {
+        hipLaunchKernelGGL((k_wide16_p1<L, NAT>), dim3((unsigned)tiles16(kptr(k_wide16_p1<L, NAT>))), dim3(256), 0, stream, pin, static_cast<int2 *>(scratch), tw_all, a, nframes);
+        hipLaunchKernelGGL((k_wide16_p2<L, false, NAT>), dim3((unsigned)anyg(kptr(k_wide16_p2<L, false, NAT>))), dim3(256), 0, stream, static_cast<const int2 *>(scratch), pout, tw_all, a, k, nframes);
+    }
+    return hipGetLastError();
+}
 template <int L>
 static hipError_t launch_wide_l(const WideArgs &a, const W2Consts &k, const void *in, void *out, void *scratch, const int2 *tw_all,
                                 size_t nframes, hipStream_t stream, int direction)
 {
-    const size_t nvf = (nframes + ((size_t)1 << (16 - L)) - 1) >> (16 - L); // virtual 2^16-point frames
-    const size_t units = nvf * 16;
-    if (a.w64 && direction == 1) {
-        size_t g1 = resident_blocks(kptr(k_wide64_q1<L>), 256, 2);
-        if (g1 > units) g1 = units;
-        size_t g2 = resident_blocks(kptr(k_wide16_q2<L, true>), 256, 2) & ~(size_t)15;
-        if (g2 < 16) g2 = 16;
-        if (g2 > units) g2 = units;
-        hipLaunchKernelGGL(k_wide64_q1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<i64 *>(scratch), tw_all, a, k, nframes);
-        hipLaunchKernelGGL((k_wide16_q2<L, true>), dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a, nframes);
-        return hipGetLastError();
-    }
-    if (a.w64) {
-        size_t g1 = resident_blocks(kptr(k_wide64_p1<L>), 256, 2) & ~(size_t)15;
-        if (g1 < 16) g1 = 16;
-        if (g1 > units) g1 = units;
-        size_t g2 = resident_blocks(kptr(k_wide16_p2<L, true>), 256, 2);
-        if (g2 > units) g2 = units;
-        hipLaunchKernelGGL(k_wide64_p1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<i64 *>(scratch), tw_all, a, nframes);
-        hipLaunchKernelGGL((k_wide16_p2<L, true>), dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a, k, nframes);
-        return hipGetLastError();
-    }
-    if (direction == 1) {
-        size_t g1 = resident_blocks(kptr(k_wide16_q1<L>), 256, 2);
-        if (g1 > units) g1 = units;
-        size_t g2 = resident_blocks(kptr(k_wide16_q2<L>), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
-        if (g2 < 16) g2 = 16;
-        if (g2 > units) g2 = units;
-        hipLaunchKernelGGL(k_wide16_q1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in), static_cast<int2 *>(scratch), tw_all, a, k,
-                           nframes);
-        hipLaunchKernelGGL(k_wide16_q2<L>, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch), static_cast<i64 *>(out), tw_all, a,
-                           nframes);
-        return hipGetLastError();
-    }
-    size_t g1 = resident_blocks(kptr(k_wide16_p1<L>), 256, 2) & ~(size_t)15; // a multiple of the 16 column tiles
-    if (g1 < 16) g1 = 16;
-    if (g1 > units) g1 = units;
-    size_t g2 = resident_blocks(kptr(k_wide16_p2<L>), 256, 2);
-    if (g2 > units) g2 = units;
-    hipLaunchKernelGGL(k_wide16_p1<L>, dim3((unsigned)g1), dim3(256), 0, stream, static_cast<const int2 *>(in),
-                       static_cast<int2 *>(scratch), tw_all, a, nframes);
-    hipLaunchKernelGGL(k_wide16_p2<L>, dim3((unsigned)g2), dim3(256), 0, stream, static_cast<const int2 *>(scratch),
-                       static_cast<i64 *>(out), tw_all, a, k, nframes);
-    return hipGetLastError();
+    // the natural-order instantiations carry none of the native-order code
+    return a.native ? launch_wide_ln<L, true>(a, k, in, out, scratch, tw_all, nframes, stream, direction)
+                    : launch_wide_ln<L, false>(a, k, in, out, scratch, tw_all, nframes, stream, direction);
 }
 
 hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out, void *scratch, const int2 *tw_all,

@@ -1387,6 +1387,30 @@ def test_wide64_first_pass_data_width_up_to_32(log2n, dw, tw, batch, direction, 
     assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(16, 24, 24, 2), (13, 24, 16, 9), (14, 22, 18, 5), (15, 24, 24, 3), (16, 32, 16, 1), (13, 32, 16, 11), (14, 28, 16, 3), (15, 32, 12, 2)])
+def test_wide_two_pass_native_orders(log2n, dw, tw, batch, monkeypatch):
+    """The cores' own beat orders on the two-pass wide classes (round 5): int_fftNk HALVES in -> BITREV out and int_ifftNk BITREV in -> HALVES out
+    (int_fftNk.vhd:15-21, int_ifftNk.vhd:15-21) and the mixed forms with natural order, for BASELINE config 3's class (k_wide16_p1/p2, q1/q2) and the
+    DATA_WIDTH 25 .. 32 class (k_wide64_*): a HALVES beat is one 16- / 32-byte access of a register pair, BITREV order goes through a 16 x 16 exchange in
+    the transpose planes.  Bit-exact to the oracle incl. partial virtual frames, and equal to the generic kernels (INTFFT_NO_WIDE16)."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 4400 + log2n + dw), edge_frames(n, dw)[[1, 4]]])[:batch + (2 if log2n < 15 else 0)]
+    fwd = "k_wide64_p1+k_wide16_p2" if dw + log2n - 8 > 32 or tw < 16 else "k_wide16_p1+p2"
+    inv = "k_wide64_q1+k_wide16_q2" if dw + 8 > 32 or tw < 16 else "k_wide16_q1+q2"
+    for direction, orders, name in (("FWD", [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")], fwd),
+                                    ("INV", [("BITREV", "HALVES"), ("BITREV", "NATURAL"), ("NATURAL", "HALVES")], inv)):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, True), DIR[direction]) != 0:
+            continue
+        for in_o, out_o in orders:
+            info = check(x, log2n, dw, tw, 1, 0, True, direction=direction, in_order=in_o, out_order=out_o)
+            assert info["kernel_name"] == name and info["n_passes"] == 2, (info, in_o, out_o)
+        a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_WIDE16", "1")
+            b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+        assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
+
+
 def test_wide_family_random_configurations():
     """Seeded fuzz over the unscaled plans with int64 results (N = 2^10 .. 2^16, DATA_WIDTH 17 .. 30, TWDL_WIDTH 10 .. 25, both
     XSER): whichever kernel the planner picks (k_fft1024_w32 / k_fft4096_w32 with 64-bit tails, k_wide16_p1+p2<L>, k_pass<long>),

@@ -119,7 +119,12 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("7:16:16:1:0:INV", ("BITREV", "HALVES"), "16-bit unscaled INV, BITREV in / HALVES out (round 4)"),
           ("10:18:16:0", ("HALVES", "BITREV"), "18-bit scaled FWD, HALVES in / BITREV out (round 4)"),
           ("10:18:16:0:0:INV", ("BITREV", "HALVES"), "18-bit scaled INV, BITREV in / HALVES out (round 4)"),
-          ("7:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD, HALVES in / BITREV out (round 4)")]
+          ("7:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD, HALVES in / BITREV out (round 4)"),
+          ("16:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD (40-bit results), HALVES in / BITREV out (round 5)"),
+          ("16:24:24:1:0:INV", ("BITREV", "HALVES"), "24-bit unscaled INV, BITREV in / HALVES out (round 5)"),
+          ("13:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD, HALVES in / BITREV out (round 5)"),
+          ("16:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (48-bit results), HALVES in / BITREV out (round 5)"),
+          ("16:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)")]
 
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
