@@ -232,7 +232,14 @@ __global__ __launch_bounds__(512) void k_bigw_p3(const int2 *scr, void *out, con
 //         tile (L1 / L2 hits) so that the kernel fits 128 VGPRs = two workgroups per CU
 // pass B  STAGE 7..0 + bit-reversed store: tile = 32 rows n(L-1)..n(L-5) x 256 consecutive n7..0; thread = (R, n3..0), regs =
 //         n7..4 (128-B runs) -> LDS -> thread = (n7..4, rev5(R)), regs = n3..0; the rows are the 5 lowest output bits
-template <int L, int MODE, bool MASKED>
+// The cores' own beat orders (round 5, NAT instantiations; W32Args::native bit 0: HALVES on the time side, bit 1: BITREV on the frequency side).  Time side:
+// register j holds the rows 16 j + hx, so a HALVES beat (x[i], x[i + N/2]) is the register pair (j, j | 2^(L-13)): adjacent samples, one 8- / 16-byte access.
+// Frequency side: BITREV order is the core position p = (R << (L-5)) + 256 mid + 16 n7..4 + n3..0; the round layout (thread 32 n7..4 + rev5(R), registers n3..0)
+// exchanges its registers with the four low thread bits through the plane, after which a wave instruction covers 32 consecutive positions of two rows.
+template <int L> __device__ __forceinline__ constexpr int bw_pair_bit() { return 1 << (L - 13); }
+template <int L> __device__ __forceinline__ constexpr int bw_pair_index(int j) { return ((j >> (L - 12)) << (L - 1)) + 4096 * (j & ((1 << (L - 12)) - 1)); }
+
+template <int L, int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bigw_a(const void *in, int2 *scr, const int2 *__restrict__ twt, const W32Args a,
                                                 size_t nframes_user, unsigned groups)
 {
@@ -252,7 +259,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unsigned toff = (unsigned)hx * 256u + (unsigned)l; // row hx of the register's 16-row block, column l of the chunk
         asm volatile("" : "+v"(lf), "+v"(t1), "+v"(toff));
         int re[16], im[16];
-        if (a.in16) {
+        if (NAT && (a.native & 1)) { // HALVES order in: one access per register pair (j, j | 2^(L-13))
+            if (a.in16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u *src2 = reinterpret_cast<const v2u *>(in) + frame * 32768 + chunk * 32;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j & bw_pair_bit<L>()) continue;
+                    v2u x = {0u, 0u};
+                    if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) x = INTFFT_LD(at32(src2 + bw_pair_index<L>(j), toff));
+                    re[j] = (int)(x.x << a.in_sh) >> a.in_sh, im[j] = (int)(x.x << (a.in_sh - 16)) >> a.in_sh;
+                    re[j | bw_pair_bit<L>()] = (int)(x.y << a.in_sh) >> a.in_sh, im[j | bw_pair_bit<L>()] = (int)(x.y << (a.in_sh - 16)) >> a.in_sh;
+                }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i *src4 = reinterpret_cast<const v4i *>(in) + frame * 32768 + chunk * 32;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j & bw_pair_bit<L>()) continue;
+                    v4i x = {0, 0, 0, 0};
+                    if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) x = INTFFT_LD(at32(src4 + bw_pair_index<L>(j), toff));
+                    re[j] = (int)((u32)x.x << a.in_sh) >> a.in_sh, im[j] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+                    re[j | bw_pair_bit<L>()] = (int)((u32)x.z << a.in_sh) >> a.in_sh, im[j | bw_pair_bit<L>()] = (int)((u32)x.w << a.in_sh) >> a.in_sh;
+                }
+            }
+        } else if (a.in16) {
             const u32 *src = static_cast<const u32 *>(in) + frame * 65536 + chunk * 32; // wave-uniform
             u32 raw[16];
             if (!partial) { // (one test around the 16 loads: tested one by one they are issued one by one)
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-template <int MODE, bool MASKED>
+template <int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(512) void k_bigw_b(const int2 *scr, void *out, const int2 *__restrict__ twt, const UConsts c,
                                                 const W32Args a, int L)
 {
@@ -403,6 +434,38 @@ __global__ __launch_bounds__(512) void k_bigw_b(const int2 *scr, void *out, cons
     }
 #pragma unroll
     for (int g = 0; g < 16; g += 2) gfly_triv<MODE, false>(re[g], im[g], re[g + 1], im[g + 1], a.st[0]);
+    if (NAT && (a.native & 2)) { // BITREV order out: memory index = core position
+        // registers n3..0 <-> the four low thread bits (rev5(R) & 15), one plane, re then im: thread = (n7..4, R bit 0, n3..0), register x = rev5(R) & 15
+        const u32 *xr = lds + ROWG * (tid & ~15) + (tid & 15); // + ROWG * x
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[ROWG * tid + r] = (u32)re[r];
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 16; ++x) re[x] = (int)xr[ROWG * x];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[ROWG * tid + r] = (u32)im[r];
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 16; ++x) im[x] = (int)xr[ROWG * x];
+        // R = rev5(x | b << 4) = rev4(x) << 1 | b, b = thread bit 4: position = (R << (L-5)) + 256 mid + 16 (tid >> 5) + (tid & 15)
+        const size_t offp = (frame << L) + ((size_t)((tid >> 4) & 1) << (L - 5)) + mid * 256 + 16 * (tid >> 5) + (tid & 15);
+        if (a.out16) {
+            u32 *dst = static_cast<u32 *>(out) + offp;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) __builtin_nontemporal_store(((u32)re[x] & 0xFFFFu) | ((u32)im[x] << 16), dst + ((size_t)rev4g(x) << (L - 4)));
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            v2i *dst = reinterpret_cast<v2i *>(static_cast<int2 *>(out) + offp);
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const v2i y = {re[x], im[x]};
+                __builtin_nontemporal_store(y, dst + ((size_t)rev4g(x) << (L - 4)));
+            }
+        }
+        return;
+    }
     // natural order: X index = brev_L(n) = rev4(n3..0) << (L-4) | rev4(n7..4) << (L-8) | brev(mid) << 5 | rev5(R)
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     const size_t off = (frame << L) + ((size_t)rev4g(tid >> 5) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
@@ -626,7 +689,7 @@ __global__ __launch_bounds__(512) void k_bigw_q1(const int2 *scr, void *out, con
 // ---- inverse two-pass split (mirrors of k_bigw_b / k_bigw_a) ----------------------------------------------------------------
 // first pass: bit-reversed load of the natural-order input (128-B runs), thread = (n7..4, rev5(R)), regs = n3..0: DIT 0..3,
 // LDS transpose to thread = (R, n3..0), regs = n7..4: DIT 4..7, scratch
-template <int MODE, bool MASKED>
+template <int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, const int2 *__restrict__ twt, const UConsts c,
                                                  const W32Args a, int L)
 {
@@ -637,7 +700,39 @@ __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, cons
     const unsigned rmid = L > 13 ? __brev(mid) >> (32 - (L - 13)) : 0u;
     const size_t off = (frame << L) + ((size_t)rev4g(tid >> 5) << (L - 8)) + ((size_t)rmid << 5) + (tid & 31);
     int re[16], im[16];
-    if (a.in16) {
+    if (NAT && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = (n7..4, R bit 0, n3..0), register x = rev5(R) & 15),
+        // then the exchange of k_bigw_b run backwards
+        const size_t offp = (frame << L) + ((size_t)((tid >> 4) & 1) << (L - 5)) + mid * 256 + 16 * (tid >> 5) + (tid & 15);
+        if (a.in16) {
+            const u32 *src = static_cast<const u32 *>(in) + offp;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const u32 raw = INTFFT_LD(src + ((size_t)rev4g(x) << (L - 4)));
+                re[x] = (int)(raw << a.in_sh) >> a.in_sh, im[x] = (int)(raw << (a.in_sh - 16)) >> a.in_sh;
+            }
+        } else {
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i *src = reinterpret_cast<const v2i *>(static_cast<const int2 *>(in) + offp);
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const v2i v = INTFFT_LD(src + ((size_t)rev4g(x) << (L - 4)));
+                re[x] = (int)((u32)v.x << a.in_sh) >> a.in_sh, im[x] = (int)((u32)v.y << a.in_sh) >> a.in_sh;
+            }
+        }
+        u32 *xw = lds + ROWG * (tid & ~15) + (tid & 15); // + ROWG * x
+#pragma unroll
+        for (int x = 0; x < 16; ++x) xw[ROWG * x] = (u32)re[x];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) re[r] = (int)lds[ROWG * tid + r];
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 16; ++x) xw[ROWG * x] = (u32)im[x];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) im[r] = (int)lds[ROWG * tid + r];
+        __syncthreads();
+    } else if (a.in16) {
         const u32 *src = static_cast<const u32 *>(in) + off;
         u32 raw[16];
 #pragma unroll
@@ -700,7 +795,7 @@ __global__ __launch_bounds__(512) void k_bigw_qb(const void *in, int2 *scr, cons
 }
 
 // second pass: DIT 8..L-1 on virtual 2^16-point frames (tiles, twiddle re-reads and occupancy as k_bigw_a), scratch -> user
-template <int L, int MODE, bool MASKED>
+template <int L, int MODE, bool MASKED, bool NAT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bigw_qa(const int2 *scr, void *out, const int2 *__restrict__ twt, const W32Args a,
                                                  size_t nframes_user, unsigned groups)
 {
@@ -770,6 +865,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __syncthreads();
         }
         gstages_dit<MODE, MASKED, NS1, 12>(re, im, w8r, w8i, w4r, w4i, w2r, w2i, w1r, w1i, a); // regs j = n15..12, thread hx = n11..8
+        if (NAT && (a.native & 1)) { // HALVES order out: one store per register pair (j, j | 2^(L-13))
+            const unsigned toffp = (unsigned)hx * 256u + lfull;
+            if (a.out16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                v2u *dst2 = reinterpret_cast<v2u *>(out) + frame * 32768;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j & bw_pair_bit<L>()) continue;
+                    constexpr int PB = bw_pair_bit<L>();
+                    const v2u y = {((u32)re[j] & 0xFFFFu) | ((u32)im[j] << 16), ((u32)re[j | PB] & 0xFFFFu) | ((u32)im[j | PB] << 16)};
+                    if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) __builtin_nontemporal_store(y, dst2 + bw_pair_index<L>(j) + toffp);
+                }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i *dst4 = reinterpret_cast<v4i *>(out) + frame * 32768;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (j & bw_pair_bit<L>()) continue;
+                    constexpr int PB = bw_pair_bit<L>();
+                    const v4i y = {re[j], im[j], re[j | PB], im[j | PB]};
+                    if (!partial || frame * G + (size_t)((16 * j + hx) >> (L - 8)) < nframes_user) __builtin_nontemporal_store(y, dst4 + bw_pair_index<L>(j) + toffp);
+                }
+            }
+            continue;
+        }
         if (a.out16) {
             u32 *dst = static_cast<u32 *>(out) + frame * 65536 + lfull;
 #pragma unroll
@@ -793,7 +913,10 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
                     int out_order)
 {
     return log2n >= 13 && log2n <= 16 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 &&
-           twdl_width <= 26 && (direction == 0 || direction == 1) && use_fly == 1 && in_order == 0 && out_order == 0;
+           twdl_width <= 26 && (direction == 0 || direction == 1) && use_fly == 1 &&
+           (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)  // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
+                           : (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)); // int_ifftNk: NATURAL | BITREV in, NATURAL | HALVES out
+    // (the cores' own orders: on the two-pass kernels only -- under INTFFT_NO_TWOPASS the planner keeps the generic passes for them)
 }
 
 const char *bigw_kernel_name(int direction, int two_pass)
@@ -810,6 +933,16 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
     if (a.two_pass) {
         const size_t nvfa = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned ga = (unsigned)(nvfa < 256 ? nvfa : 256);
+        if (a.native) { // the natural-order instantiations carry none of the native-order code
+            hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED, true>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
+            switch (log2n) {
+            case 13: hipLaunchKernelGGL((k_bigw_qa<13, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+            case 14: hipLaunchKernelGGL((k_bigw_qa<14, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+            case 15: hipLaunchKernelGGL((k_bigw_qa<15, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+            default: hipLaunchKernelGGL((k_bigw_qa<16, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
+            }
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
         switch (log2n) {
         case 13: hipLaunchKernelGGL((k_bigw_qa<13, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, out, tw, a, nframes, ga); break;
@@ -842,6 +975,16 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
         const unsigned ga = (unsigned)(nvf < 256 ? nvf : 256);
         const size_t nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
+        if (a.native) {
+            switch (log2n) {
+            case 13: hipLaunchKernelGGL((k_bigw_a<13, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+            case 14: hipLaunchKernelGGL((k_bigw_a<14, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+            case 15: hipLaunchKernelGGL((k_bigw_a<15, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+            default: hipLaunchKernelGGL((k_bigw_a<16, MODE, MASKED, true>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
+            }
+            hipLaunchKernelGGL((k_bigw_b<MODE, MASKED, true>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
+            return hipGetLastError();
+        }
         switch (log2n) {
         case 13: hipLaunchKernelGGL((k_bigw_a<13, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;
         case 14: hipLaunchKernelGGL((k_bigw_a<14, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, in, scr, tw, a, nframes, ga); break;

@@ -181,6 +181,7 @@ struct W32Args {
                      // 2 (N = 2048 / 4096): results of 35 / 36 bits: the whole last register round (STAGE 3..0) in 64 bits
     int masked;      // some stage is in a multi-DSP regime (a > 0): use the masked multiplier form
     int two_pass;    // N = 2^13 .. 2^16 forward: k_bigw_a + k_bigw_b instead of the three passes
+    int native;      // k_bigw_a/b, qb/qa (round 5): bit 0 HALVES order on the time side, bit 1 BITREV order on the frequency side
 };
 bool fastw32_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
                        int out_order);

@@ -991,6 +991,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
         if (pl->w32args.out64 == 2) pl->fastw32 = false;        // the 64-bit last round: the block kernel only
         pl->w32args.two_pass = pl->bigw && !diag_env("INTFFT_NO_TWOPASS");
+        if (pl->bigw) { // the cores' own orders: on the two-pass kernels only (round 5)
+            pl->w32args.native = p->direction == INTFFT_INV ? ((p->out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->in_order == INTFFT_ORDER_BITREV ? 2 : 0))
+                                                             : ((p->in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->out_order == INTFFT_ORDER_BITREV ? 2 : 0));
+            if (pl->w32args.native && !pl->w32args.two_pass) pl->bigw = false;
+        }
     }
     pl->fastw64 = !generic_only && !pl->fastw32 && !pl->fast1024 && !pl->fast1024u && !pl->fast1024ux && !pl->fast1024x && !pl->fastsmall &&
                   pl->word == 8 && pl->in_cb >= 4 && pl->out_cb == 8 &&

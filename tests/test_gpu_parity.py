@@ -486,6 +486,32 @@ def test_general_width_three_pass_kernels(log2n, batch, case, monkeypatch):
             assert info["kernel_name"] == "k_bigw_q3/q2/q1" and info["n_passes"] == 3, info
 
 
+@pytest.mark.parametrize("log2n,batch", [(13, 259), (14, 37), (15, 3), (16, 5)])
+@pytest.mark.parametrize("case", [(16, 16, 1, 0), (16, 16, 0, 1), (18, 24, 0, 0), (10, 18, 1, 0), (32, 16, 0, 0)])
+def test_general_width_two_pass_native_orders(log2n, batch, case, monkeypatch):
+    """The cores' own beat orders on the general-width two-pass kernels (round 5: k_bigw_a/b, k_bigw_qb/qa NAT instantiations; int16 and int32 containers
+    on either side): int_fftNk HALVES in -> BITREV out, int_ifftNk BITREV in -> HALVES out and the mixed forms with natural order, against the oracle (ragged
+    batches: partial virtual frames) and equal to the generic kernels (INTFFT_NO_FASTW32)."""
+    dw, tw, fmt, rnd = case
+    if dw + fmt * log2n > 32:
+        pytest.skip("results exceed 32 bits")
+    monkeypatch.setenv("INTFFT_NO_NARROW16", "1")
+    monkeypatch.setenv("INTFFT_NO_PACKED_ROUND", "1")
+    n = 1 << log2n
+    x = uniform_frames(batch, n, dw, 6100 + log2n + dw)
+    x[0] = edge_frames(n, dw)[4]
+    for direction, orders, name in (("FWD", [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")], "k_bigw_a/b"),
+                                    ("INV", [("BITREV", "HALVES"), ("BITREV", "NATURAL"), ("NATURAL", "HALVES")], "k_bigw_qb/qa")):
+        for in_o, out_o in orders:
+            info = check(x, log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=in_o, out_order=out_o)
+            assert info["kernel_name"] == name and info["n_passes"] == 2, (info, in_o, out_o)
+        a, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_NO_FASTW32", "1")
+            b, ib = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+        assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("log2n,batch", [(13, 515), (14, 259), (15, 5), (16, 3), (17, 3), (18, 5), (19, 3), (20, 1)])
 @pytest.mark.parametrize("direction,in_order,out_order", [("FWD", "HALVES", "BITREV"), ("FWD", "NATURAL", "BITREV"),
                                                           ("FWD", "HALVES", "NATURAL"), ("INV", "BITREV", "HALVES"),
