@@ -653,6 +653,12 @@ GUARD_CASES = [
     (17, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3), (18, 16, 16, 0, 1, "INV", "NATURAL", "NATURAL", 1), (19, 16, 16, 0, 0, "FWD", "NATURAL", "BITREV", 3),
     (20, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1), (10, 18, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 3), (10, 40, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3),
     (9, 16, 16, 0, 0, "FWD", "NATURAL", "BITREV_LANES", 3),
+    # round 5: the 64-bit first pass (DATA_WIDTH 25 .. 32), the cores' own orders on the two-pass wide / general-width kernels (16- and 32-byte pair accesses,
+    # the 16 x 16 exchange), the full-line column tile of N = 2^19
+    (13, 32, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 11), (14, 30, 16, 1, 0, "INV", "NATURAL", "NATURAL", 5), (16, 24, 24, 1, 0, "FWD", "HALVES", "BITREV", 3),
+    (14, 24, 24, 1, 0, "INV", "BITREV", "HALVES", 5), (13, 32, 16, 1, 0, "FWD", "HALVES", "BITREV", 3), (15, 32, 16, 1, 0, "INV", "BITREV", "HALVES", 3),
+    (14, 16, 16, 1, 0, "FWD", "HALVES", "BITREV", 5), (15, 18, 16, 0, 0, "INV", "BITREV", "HALVES", 3), (13, 12, 16, 0, 1, "FWD", "HALVES", "NATURAL", 9),
+    (19, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3),
 ]
 
 
