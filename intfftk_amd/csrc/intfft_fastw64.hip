@@ -7,8 +7,12 @@ namespace intfft {
 bool fastw64_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
     const int out_bits = data_width + format * log2n;
-    return log2n >= 6 && log2n <= 10 && out_bits > 32 && out_bits <= 64 && data_width >= 2 && data_width <= 64 && (direction == 0 || direction == 1) && use_fly == 1 && in_order == 0 &&
-           out_order == 0 && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64");
+    // N = 1024 also in the cores' own beat orders (NAT instantiations, intfft_fastw64n.hip): int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out
+    const bool natural = in_order == 0 && out_order == 0;
+    const bool native = log2n == 10 && (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)
+                                                       : (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2));
+    return log2n >= 6 && log2n <= 10 && out_bits > 32 && out_bits <= 64 && data_width >= 2 && data_width <= 64 && (direction == 0 || direction == 1) && use_fly == 1 &&
+           (natural || native) && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64");
 }
 
 // what the multiplier stages 2 .. log2n - 1 of a plan allow (fly64<., ., CM>): 1 narrow, 3 three-dword products, 0 neither
@@ -57,7 +61,7 @@ hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDe
 const char *fastw64_kernel_name(int direction) { return direction == 1 ? "k_ifft1024_w64" : "k_fft1024_w64"; }
 
 hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                          size_t nframes, hipStream_t stream)
+                          size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
@@ -65,9 +69,10 @@ hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDes
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
     W64Args a;
     for (int s = 0; s < 10; ++s) a.st[s] = st10[s];
-    a.in_cb = in_cb, a.dw = dw;
-    if (log2n < 10) return launch_fastw64_short(log2n, direction, rnd_kind, c, a, in, out, tw_all, nframes, stream);
+    a.in_cb = in_cb, a.dw = dw, a.native = native;
+    if (log2n < 10) return native ? hipErrorInvalidValue : launch_fastw64_short(log2n, direction, rnd_kind, c, a, in, out, tw_all, nframes, stream);
     const int cm = fastw64_multiplier_form(10, st10, rnd_kind);
+    if (native) return launch_fastw64_native(direction, rnd_kind, cm, c, a, in, out, tw_all, nframes, stream); // the natural-order instances carry none of that code
 #define INTFFT_W64N(R, CM)                                                                                                               \
     {                                                                                                                                   \
         if (direction == 1) launch_w64_kernel(k_ifft1024_w64<10, R, CM>, 10, c, a, in, out, tw_all, nframes, stream);                    \

@@ -255,7 +255,7 @@ const char *fastw64b_kernel_name(int direction);
 hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDesc *st12, int in_cb, int dw, const void *in, void *out, const int2 *tw_all,
                            const int2 *h_tw, size_t nframes, hipStream_t stream);
 hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
-                          size_t nframes, hipStream_t stream);
+                          size_t nframes, hipStream_t stream, int native = 0); // native (N = 1024): bit 0 HALVES on the time side, bit 1 BITREV on the frequency side
 // the 2-D scheme at N = 2^20 = 1024 x 1024 in two launches (intfft_big2x.hip): column cores + multiplier, row cores + store
 int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order);
 hipError_t build_fused2d_table(uint32_t *d_table, int log2n, int twd, hipStream_t stream);

@@ -1616,7 +1616,9 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
                                     plan->p.data_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fastw64)
         return (int)launch_fastw64(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
-                                   d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+                                   d_out, plan->d_tw, plan->h_tw.data(), batch, stream,
+                                   plan->p.direction == INTFFT_INV ? ((plan->p.out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.in_order == INTFFT_ORDER_BITREV ? 2 : 0))
+                                                                   : ((plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0)));
     if (plan->fastw32)
         return (int)launch_fastw32(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, d_in, d_out, plan->d_tw,
                                    plan->h_tw.data(), batch, stream,

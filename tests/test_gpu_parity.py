@@ -638,6 +638,33 @@ def test_wave_kernel_64_bit_results_inverse(case, monkeypatch):
 
 
 @pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("case", [(32, 16, 1, 0, True), (32, 24, 1, 0, False), (28, 18, 1, 0, True), (40, 16, 0, 0, True), (44, 16, 0, 1, True), (48, 24, 0, 0, True),
+                                  (50, 16, 1, 0, True), (64, 16, 0, 1, True), (60, 16, 0, 0, False)])
+def test_wave_kernel_64_bit_native_orders(case, direction, monkeypatch):
+    """N = 1024 with results of 33 .. 64 bits in the cores' own beat orders (round 5: the NAT instantiations of k_fft1024_w64 / k_ifft1024_w64, every rounding
+    kind and multiplier form, int32 and int64 input containers): int_fftNk HALVES in -> BITREV out, int_ifftNk BITREV in -> HALVES out and the mixed forms
+    with natural order, against the oracle and equal to the generic kernel (INTFFT_NO_FASTW64)."""
+    dw, tw, fmt, rnd, new = case
+    if C.lib().orc_validate(C.make_params(10, dw, tw, fmt, rnd, new), DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(1024, dw), uniform_frames(21, 1024, dw, 840 + dw), uniform_frames(3, 1024, max(2, dw - 3), 841 + dw)])
+    orders = [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES"), ("BITREV", "NATURAL"),
+                                                                                                             ("NATURAL", "HALVES")]
+    name = "k_ifft1024_w64" if direction == "INV" else "k_fft1024_w64"
+    for in_o, out_o in orders:
+        got, info = run_gpu(x, 10, dw, tw, fmt, rnd, new, direction=direction, in_order=in_o, out_order=out_o)
+        if info["out_bits"] <= 32 or info["out_bits"] > 64 or info["kernel_name"] == "k_fft1024_w32":
+            pytest.skip("not a plan of the 64-bit wave kernel")
+        assert info["kernel_name"] == name and info["n_passes"] == 1, (info, in_o, out_o)
+        assert np.array_equal(got, run_ref(x, 10, dw, tw, fmt, rnd, new, direction=direction, in_order=in_o, out_order=out_o)), (in_o, out_o)
+    a, _ = run_gpu(x[:9], 10, dw, tw, fmt, rnd, new, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_FASTW64", "1")
+        b, ib = run_gpu(x[:9], 10, dw, tw, fmt, rnd, new, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+    assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
 @pytest.mark.parametrize("case", [(6, 32, 16, 1, 0), (7, 32, 16, 1, 0), (7, 40, 24, 1, 0), (8, 32, 24, 1, 0), (9, 30, 18, 1, 0), (7, 44, 16, 0, 1), (8, 48, 24, 0, 0),
                                   (9, 40, 16, 0, 0), (6, 50, 16, 1, 0)])
 def test_wave_kernel_64_bit_short_frames(case, direction):

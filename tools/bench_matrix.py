@@ -128,7 +128,10 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("14:16:16:1", ("HALVES", "BITREV"), "16-bit unscaled FWD (30-bit results), HALVES in / BITREV out (round 5)"),
           ("14:16:16:1:0:INV", ("BITREV", "HALVES"), "16-bit unscaled INV, BITREV in / HALVES out (round 5)"),
           ("16:18:16:0", ("HALVES", "BITREV"), "18-bit scaled FWD, HALVES in / BITREV out (round 5)"),
-          ("16:32:24:0:0:INV", ("BITREV", "HALVES"), "32-bit scaled INV, BITREV in / HALVES out (round 5)")]
+          ("16:32:24:0:0:INV", ("BITREV", "HALVES"), "32-bit scaled INV, BITREV in / HALVES out (round 5)"),
+          ("10:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (42-bit results), HALVES in / BITREV out (round 5)"),
+          ("10:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
+          ("10:48:24:0", ("HALVES", "BITREV"), "48-bit scaled FWD, 24-bit twiddles, HALVES in / BITREV out (round 5)")]
 
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
