@@ -36,7 +36,9 @@ bool fastw64b_supported(int log2n, int data_width, int twdl_width, int format, i
 {
     const int out_bits = data_width + format * log2n;
     return (log2n == 11 || log2n == 12) && out_bits > 32 && out_bits <= 64 && data_width >= 2 && data_width <= 64 && (direction == 0 || direction == 1) &&
-           use_fly == 1 && in_order == 0 && out_order == 0 && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64");
+           use_fly == 1 && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64") &&
+           (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1) // NATURAL or the cores' own beat orders (intfft_fastw64bn.hip)
+                           : (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2));
 }
 bool fastw64b_plan_ok(int log2n, const StageDesc *st12, int rnd_kind)
 {
@@ -46,7 +48,7 @@ bool fastw64b_plan_ok(int log2n, const StageDesc *st12, int rnd_kind)
 const char *fastw64b_kernel_name(int direction) { return direction == 1 ? "k_ifft4096_w64" : "k_fft4096_w64"; }
 
 hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDesc *st12, int in_cb, int dw, const void *in, void *out, const int2 *tw_all,
-                           const int2 *h_tw, size_t nframes, hipStream_t stream)
+                           const int2 *h_tw, size_t nframes, hipStream_t stream, int native)
 {
     if (nframes == 0) return hipSuccess;
     UConsts c;
@@ -54,7 +56,8 @@ hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDe
     for (int k = 0; k < 4; ++k) c.wr2[k] = h_tw[3 + k].x, c.wi2[k] = h_tw[3 + k].y;
     W64BArgs a;
     for (int s = 0; s < 12; ++s) a.st[s] = st12[s];
-    a.in_cb = in_cb, a.dw = dw;
+    a.in_cb = in_cb, a.dw = dw, a.native = native;
+    if (native) return launch_fastw64_block_native(log2n, direction, rnd_kind, fastw64_multiplier_form(log2n, st12, rnd_kind), c, a, in, out, tw_all, nframes, stream);
     return launch_fastw64_block(log2n, direction, rnd_kind, fastw64_multiplier_form(log2n, st12, rnd_kind), c, a, in, out, tw_all, nframes, stream);
 }
 

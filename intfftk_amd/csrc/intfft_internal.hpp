@@ -253,7 +253,7 @@ bool fastw64b_supported(int log2n, int data_width, int twdl_width, int format, i
 bool fastw64b_plan_ok(int log2n, const StageDesc *st12, int rnd_kind);
 const char *fastw64b_kernel_name(int direction);
 hipError_t launch_fastw64b(int log2n, int direction, int rnd_kind, const StageDesc *st12, int in_cb, int dw, const void *in, void *out, const int2 *tw_all,
-                           const int2 *h_tw, size_t nframes, hipStream_t stream);
+                           const int2 *h_tw, size_t nframes, hipStream_t stream, int native = 0); // native: bit 0 HALVES on the time side, bit 1 BITREV on the frequency side
 hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDesc *st10, int in_cb, int dw, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                           size_t nframes, hipStream_t stream, int native = 0); // native (N = 1024): bit 0 HALVES on the time side, bit 1 BITREV on the frequency side
 // the 2-D scheme at N = 2^20 = 1024 x 1024 in two launches (intfft_big2x.hip): column cores + multiplier, row cores + store

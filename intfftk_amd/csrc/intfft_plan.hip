@@ -1613,7 +1613,9 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
                                      (plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0));
     if (plan->fastw64b)
         return (int)launch_fastw64b(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb,
-                                    plan->p.data_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
+                                    plan->p.data_width, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream,
+                                    plan->p.direction == INTFFT_INV ? ((plan->p.out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.in_order == INTFFT_ORDER_BITREV ? 2 : 0))
+                                                                    : ((plan->p.in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (plan->p.out_order == INTFFT_ORDER_BITREV ? 2 : 0)));
     if (plan->fastw64)
         return (int)launch_fastw64(plan->p.log2n, plan->p.direction, plan->p.format ? RND_UNSCALED : plan->p.rndmode ? RND_ROUND : RND_TRUNC, plan->st64, plan->in_cb, plan->p.data_width, d_in,
                                    d_out, plan->d_tw, plan->h_tw.data(), batch, stream,

@@ -573,6 +573,7 @@ struct W64BArgs {
     StageDesc st[12]; // indexed by the STAGE generic
     int in_cb;        // input container bytes per component: 4 or 8
     int dw;           // DATA_WIDTH
+    int native;       // NAT instantiations: bit 0 HALVES order on the time side, bit 1 BITREV order on the frequency side
 };
 
 constexpr int ROW64B = 20;
@@ -685,7 +686,32 @@ __device__ __forceinline__ void xpose64(i64 (&v)[16], u32 *lds, u32 *wbase, OFF 
     }
 }
 
-template <int L, int RNDC, int CM>
+// NAT (round 5): the cores' own beat orders.  HALVES on the time side: the register pair (j, j + 2^(L-9)) of layout LA is the sample pair (n, n + N/2) of one
+// beat, one 16- / 32-byte access.  BITREV on the frequency side: memory index = core position, an LC thread owns the 16 consecutive positions of row
+// `rowp` -- one component at a time through the transpose region (rows of 16 int64 + 2 dwords, slots XOR-swizzled by the row's two high bits so that the
+// lanes of a wave spread over the banks), so that every global instruction of the workgroup moves 4 KiB like the natural order.
+constexpr int ROWNB64 = 34;
+__device__ __forceinline__ int nb64_slot(int row, int slot) { return ROWNB64 * row + 2 * (slot ^ ((row >> 6) & 3)); }
+__device__ __forceinline__ void rows_to_linear64(i64 (&v)[16], u32 *lds, int rowp, int tid) // v[r] = position 16 rowp + r  ->  v[i] = position 256 i + tid
+{
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *reinterpret_cast<i64 *>(lds + nb64_slot(rowp, r)) = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const i64 *>(lds + nb64_slot(16 * i + (tid >> 4), tid & 15));
+}
+__device__ __forceinline__ void linear_to_rows64(i64 (&v)[16], u32 *lds, int rowp, int tid) // ... and back
+{
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<i64 *>(lds + nb64_slot(16 * i + (tid >> 4), tid & 15)) = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = *reinterpret_cast<const i64 *>(lds + nb64_slot(rowp, r));
+}
+
+template <int L, int RNDC, int CM, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft4096_w64(const void *in, i64 *out, const int2 *__restrict__ twt,
                                                                                                  const UConsts c, const W64BArgs a, size_t nframes_user)
 {
@@ -694,6 +720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t nframes = (nframes_user + FP - 1) / FP; // chunks of 4096 samples
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANE64B];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    const bool halves = NAT && (a.native & 1), bitrev = NAT && (a.native & 2);
     Tw64B t;
     if constexpr (keep_lb64<RNDC, CM>()) load_tw64_lb(t, twt, lo4);
     if constexpr (keep_la64<RNDC, CM>()) load_tw64_la<L>(t, twt, tid);
@@ -703,12 +730,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int row_hi = ((hi4 & 1) << lc64_bit<L>(8)) | (((hi4 >> 1) & 1) << lc64_bit<L>(9)) | (((hi4 >> 2) & 1) << lc64_bit<L>(10)) |
                        (((hi4 >> 3) & 1) << lc64_bit<L>(11));
     u32 *const w_bc = lds + ROW64B * row_hi + lo4;
-    int lc_off = 0, lc_frame = 0; // LC <-> natural-order X: index = rev4(r) * 2^(L-4) + lc_off
+    int lc_off = 0, lc_frame = 0, rowp = 0; // LC <-> natural-order X: index = rev4(r) * 2^(L-4) + lc_off; rowp: the thread's core positions >> 4
 #pragma unroll
     for (int k = 4; k < 12; ++k) {
         const int bit = (tid >> lc64_bit<L>(k)) & 1;
         lc_off += bit * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
         if (k >= L) lc_frame += bit << (k - L);
+        rowp += bit << (k - 4);
     }
     auto off_ab = [](int j) { return ROW64B * 16 * j; };
     auto off_bc = [](int j) { return ROW64B * lc64_row_of_reg<L>(j); };
@@ -716,7 +744,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (size_t f = blockIdx.x; f < nframes; f += gridDim.x) {
         const bool partial = L < 12 && (f + 1) * FP > nframes_user; // last chunk: the absent frame reads as 0
         i64 re[16], im[16];
-        if (a.in_cb == 4) {
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L - 9);
+            const int sh = 32 - a.dw;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB), p0 = 256 * j0, pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                const bool ok = !partial || f * FP + (size_t)(p0 >> L) < nframes_user;
+                if (a.in_cb == 4) {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    v4i x = {0, 0, 0, 0};
+                    if (ok) x = INTFFT_LD(static_cast<const v4i *>(in) + f * 2048 + pair + tid);
+                    re[j0] = (int)((u32)x.x << sh) >> sh, im[j0] = (int)((u32)x.y << sh) >> sh;
+                    re[j0 + HB] = (int)((u32)x.z << sh) >> sh, im[j0 + HB] = (int)((u32)x.w << sh) >> sh;
+                } else {
+                    typedef i64 v2l __attribute__((ext_vector_type(2)));
+                    const v2l *src = static_cast<const v2l *>(in) + f * 4096 + 2 * (pair + tid);
+                    v2l x0 = {0, 0}, x1 = {0, 0};
+                    if (ok) x0 = INTFFT_LD(src), x1 = INTFFT_LD(src + 1);
+                    re[j0] = wrapw<int64_t>((int64_t)x0.x, a.dw), im[j0] = wrapw<int64_t>((int64_t)x0.y, a.dw);
+                    re[j0 + HB] = wrapw<int64_t>((int64_t)x1.x, a.dw), im[j0 + HB] = wrapw<int64_t>((int64_t)x1.y, a.dw);
+                }
+            }
+        } else if (a.in_cb == 4) {
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i *src = static_cast<const v2i *>(in) + f * 4096 + tid;
             const int sh = 32 - a.dw;
@@ -768,7 +818,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int g = 0; g < 16; g += 2) fly64<RNDC, 1, CM>(a.st[0], 0, re[g], im[g], re[g + 1], im[g + 1], 0, 0);
-        if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
+        if (NAT && bitrev) {
+            typedef i64 v2l __attribute__((ext_vector_type(2)));
+            rows_to_linear64(re, lds, rowp, tid);
+            rows_to_linear64(im, lds, rowp, tid);
+            v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + tid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!partial || f * FP + (size_t)((256 * i + tid) >> L) < nframes_user) {
+                    const v2l y = {re[i], im[i]};
+                    __builtin_nontemporal_store(y, dst + 256 * i);
+                }
+        } else if (!partial || f * FP + (size_t)lc_frame < nframes_user) {
             typedef i64 v2l __attribute__((ext_vector_type(2)));
             v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + lc_off;
 #pragma unroll
@@ -780,7 +841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int L, int RNDC, int CM>
+template <int L, int RNDC, int CM, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ifft4096_w64(const void *in, i64 *out, const int2 *__restrict__ twt,
                                                                                                   const UConsts c, const W64BArgs a, size_t nframes_user)
 {
@@ -789,6 +850,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t nframes = (nframes_user + FP - 1) / FP;
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANE64B];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
+    const bool halves = NAT && (a.native & 1), bitrev = NAT && (a.native & 2);
     Tw64B t;
     if constexpr (keep_lb64<RNDC, CM>()) load_tw64_lb(t, twt, lo4);
     if constexpr (keep_la64<RNDC, CM>()) load_tw64_la<L>(t, twt, tid);
@@ -798,11 +860,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32 *const w_cb = lds + ROW64B * 16 * lb_hi + lb_reg;
     // LB -> LA: element (thread (n11..8 = hi4, n3..0 = lo4), reg n7..4) -> row n7..0 = 16 j' + lo4, column n11..8 = hi4
     u32 *const w_ba = lds + ROW64B * lo4 + hi4;
-    int lc_off = 0, lc_frame = 0;
+    int lc_off = 0, lc_frame = 0, rowp = 0;
 #pragma unroll
     for (int k = 4; k < 12; ++k) {
         lc_off += nb(k) * (k >= L ? (1 << k) : (1 << (L - 1 - k)));
         if (k >= L) lc_frame += nb(k) << (k - L);
+        rowp += nb(k) << (k - 4);
     }
     auto off_cb = [](int r) { return ROW64B * r; };
     auto off_ba = [](int j) { return ROW64B * 16 * j; };
@@ -812,7 +875,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool lc_ok = !partial || f * FP + (size_t)lc_frame < nframes_user;
         i64 re[16], im[16];
         // LC: X[brev_L(n)] of the thread's frame
-        if (a.in_cb == 4) {
+        if (NAT && bitrev) { // memory index = core position: coalesced loads, one component at a time through the transpose region
+            if (a.in_cb == 4) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i *src = static_cast<const v2i *>(in) + f * 4096 + tid;
+                const int sh = 32 - a.dw;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v2i x = {0, 0};
+                    if (!partial || f * FP + (size_t)((256 * i + tid) >> L) < nframes_user) x = INTFFT_LD(src + 256 * i);
+                    re[i] = (int)((u32)x.x << sh) >> sh;
+                    im[i] = (int)((u32)x.y << sh) >> sh;
+                }
+            } else {
+                typedef i64 v2l __attribute__((ext_vector_type(2)));
+                const v2l *src = static_cast<const v2l *>(in) + f * 4096 + tid;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v2l x = {0, 0};
+                    if (!partial || f * FP + (size_t)((256 * i + tid) >> L) < nframes_user) x = INTFFT_LD(src + 256 * i);
+                    re[i] = wrapw<int64_t>((int64_t)x.x, a.dw);
+                    im[i] = wrapw<int64_t>((int64_t)x.y, a.dw);
+                }
+            }
+            linear_to_rows64(re, lds, rowp, tid);
+            linear_to_rows64(im, lds, rowp, tid);
+        } else if (a.in_cb == 4) {
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i *src = static_cast<const v2i *>(in) + f * 4096 + lc_off;
             const int sh = 32 - a.dw;
@@ -865,6 +953,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         round64_dit<RNDC, CM, L, 8>(re, im, t.a8r, t.a8i, t.a4r, t.a4i, t.a2r, t.a2i, t.a1r, t.a1i, a);
         typedef i64 v2l __attribute__((ext_vector_type(2)));
+        if (NAT && halves) {
+            constexpr int HB = 1 << (L - 9);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB), p0 = 256 * j0, pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                if (!partial || f * FP + (size_t)(p0 >> L) < nframes_user) {
+                    v2l *dst2 = reinterpret_cast<v2l *>(out) + f * 4096 + 2 * (pair + tid);
+                    const v2l y0 = {re[j0], im[j0]}, y1 = {re[j0 + HB], im[j0 + HB]};
+                    __builtin_nontemporal_store(y0, dst2);
+                    __builtin_nontemporal_store(y1, dst2 + 1);
+                }
+            }
+            continue;
+        }
         v2l *dst = reinterpret_cast<v2l *>(out) + f * 4096 + tid;
 #pragma unroll
         for (int j = 0; j < 16; ++j)
@@ -888,6 +990,8 @@ hipError_t launch_fastw64_block(int log2n, int direction, int rnd_kind, int cm, 
                                 const int2 *tw_all, size_t nframes, hipStream_t stream);
 hipError_t launch_fastw64_block_inv(int log2n, int rnd_kind, int cm, const UConsts &c, const W64BArgs &a, const void *in, void *out,
                                     const int2 *tw_all, size_t nframes, hipStream_t stream);
+hipError_t launch_fastw64_block_native(int log2n, int direction, int rnd_kind, int cm, const UConsts &c, const W64BArgs &a, const void *in, void *out,
+                                       const int2 *tw_all, size_t nframes, hipStream_t stream); // intfft_fastw64bn.hip
 
 template <typename K>
 inline void launch_w64_kernel(K kernel, int log2n, const UConsts &c, const W64Args &a, const void *in, void *out, const int2 *tw_all, size_t nframes,

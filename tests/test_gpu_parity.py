@@ -685,6 +685,41 @@ def test_wave_kernel_64_bit_short_frames(case, direction):
 
 @pytest.mark.parametrize("direction", ["FWD", "INV"])
 @pytest.mark.parametrize("case", [(11, 32, 16, 1, 0, True), (12, 32, 16, 1, 0, True), (12, 32, 24, 1, 0, False), (11, 30, 18, 1, 0, True), (12, 40, 16, 0, 0, True),
+                                  (11, 44, 16, 0, 1, True), (12, 48, 24, 0, 0, True), (11, 50, 10, 1, 0, True), (12, 64, 16, 0, 0, True), (12, 24, 24, 1, 0, True)])
+def test_block_kernel_64_bit_native_orders(case, direction, monkeypatch):
+    """N = 2048 / 4096 with results of 33 .. 64 bits in the cores' own beat orders (round 5: the NAT instantiations of k_fft4096_w64 / k_ifft4096_w64; HALVES pairs
+    as 16- / 32-byte accesses, BITREV order one component at a time through the transpose region): the three order pairs per direction against the oracle,
+    ragged batches (N = 2048: the absent second frame of the last workgroup), int32 and int64 containers, and equal to the generic kernel."""
+    log2n, dw, tw, fmt, rnd, new = case
+    n = 1 << log2n
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(13, n, dw, 1140 + dw + log2n), uniform_frames(2, n, max(2, dw - 3), 1141 + dw)])
+    orders = [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES"), ("BITREV", "NATURAL"),
+                                                                                                             ("NATURAL", "HALVES")]
+    mw_max = dw + ((log2n - 2 if direction == "FWD" else log2n - 1) if fmt else 0)
+    for in_o, out_o in orders:
+        got, info = run_gpu(x, log2n, dw, tw, fmt, rnd, new, direction=direction, in_order=in_o, out_order=out_o)
+        if info["out_bits"] <= 32 or info["out_bits"] > 64:
+            pytest.skip("not a 64-bit-word plan")
+        if (rnd == 1 or mw_max > 63) and mw_max + tw > 64:
+            assert info["kernel_name"] == "k_pass<long>", info
+        else:
+            assert info["kernel_name"] in (("k_ifft4096_w64",) if direction == "INV" else ("k_fft4096_w64", "k_fft4096_w32")) and info["n_passes"] == 1, (info, in_o, out_o)
+        assert np.array_equal(got, run_ref(x, log2n, dw, tw, fmt, rnd, new, direction=direction, in_order=in_o, out_order=out_o)), (in_o, out_o)
+        for nb in (1, 3):
+            g, _ = run_gpu(x[:nb], log2n, dw, tw, fmt, rnd, new, direction=direction, in_order=in_o, out_order=out_o)
+            assert np.array_equal(g, got[:nb]), (nb, in_o, out_o)
+    a, _ = run_gpu(x[:5], log2n, dw, tw, fmt, rnd, new, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_NO_FASTW64", "1")
+        m.setenv("INTFFT_NO_FASTW32", "1")
+        b, ib = run_gpu(x[:5], log2n, dw, tw, fmt, rnd, new, direction=direction, in_order=orders[0][0], out_order=orders[0][1])
+    assert ib["kernel_name"].startswith("k_pass") and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("case", [(11, 32, 16, 1, 0, True), (12, 32, 16, 1, 0, True), (12, 32, 24, 1, 0, False), (11, 30, 18, 1, 0, True), (12, 40, 16, 0, 0, True),
                                   (11, 44, 16, 0, 1, True), (12, 48, 24, 0, 0, True), (12, 36, 24, 1, 0, True), (11, 50, 10, 1, 0, True), (12, 33, 26, 0, 1, True),
                                   (12, 64, 16, 0, 0, True), (12, 28, 16, 1, 0, True), (11, 26, 24, 1, 0, False)])
 def test_block_kernel_64_bit_results(case, direction, monkeypatch):
