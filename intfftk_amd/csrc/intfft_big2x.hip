@@ -1125,10 +1125,11 @@ int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int for
     return log2n >= 21 && log2n <= 24 ? 3 : 0;
 }
 
-bool fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
+// 1: N = 2^20 (k_big2x_qb + k_big2x_ci), 2: N = 2^21 (k_rows2k_qtr + k_big2x_ci<., 11>; round 5)
+int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
 {
-    return log2n == 20 && l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
-           (out_order == 0 || out_order == 2) && !diag_env("INTFFT_2D_NO_FUSED_CORES");
+    return (log2n == 20 ? 1 : log2n == 21 && !diag_env("INTFFT_2D_NO_ROWS2K") ? 2 : 0) * (int)(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
+           (out_order == 0 || out_order == 2) && !diag_env("INTFFT_2D_NO_FUSED_CORES"));
 }
 
 hipError_t build_fused2d_table(u32 *d_table, int log2n, int twd, hipStream_t stream)
@@ -1250,19 +1251,22 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
 //                   forward plan's table [chunk][r][16] (W_N^(brev10(r) n2): the same entries), then the column cores -- r IS the DIT
 //                   position of k1 -- with the 1024-point core's own twiddles (index = r mod 2^s: STAGE 0..4 wave-uniform, STAGE 5..9
 //                   per thread, frame and column invariant), natural or HALVES order out
-template <bool FAST_OK>
+// L2 = 11 (round 5): the column cores of the 1024 x 2048 inverse plan -- 128 chunks of 16 columns n2, rows of 2048 samples on the user side; the scratch keeps
+// the [q][chunk][hi][k][l] shape (2 KiB runs per (q, chunk)), written by k_rows2k_qtr
+template <bool FAST_OK, int L2 = 10>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_ci(const u32 *scr, u32 *out, const uint2 *__restrict__ tw1k, const Round5Consts c,
                                                                                               const u32 *__restrict__ tw2d, size_t nframes, unsigned groups, const Slice sl,
                                                                                               int halves)
 {
-    constexpr int L = 20, RB = 5;
+    constexpr int L = 10 + L2, RB = 5;
     extern __shared__ u32 lds[]; // 1024 rows x ROWX
     const int tid = threadIdx.x, l = tid & 15, hx = tid >> 4;
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u, G = (blockIdx.x >> 4) * 8u + slot;
-    const unsigned chunk = (G & 31u) * 2u + part, grp = G >> 5;
+    constexpr unsigned GC = 1u << (L2 - 5); // chunk pairs per frame
+    const unsigned chunk = (G & (GC - 1u)) * 2u + part, grp = G >> (L2 - 5);
     const unsigned lfull = chunk * 16 + l;
-    const unsigned toff = ((unsigned)hx << 10) | lfull; // user side: thread (hx = r4..r0 after the transpose, l)
-    const unsigned toff2 = (chunk << (L - 11)) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l; // scratch side: r = hx << 5 | q
+    const unsigned toff = ((unsigned)hx << L2) | lfull; // user side: thread (hx = r4..r0 after the transpose, l)
+    const unsigned toff2 = (chunk << 9) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l; // scratch side: r = hx << 5 | q
     const u32 *const twu = tw2d + ((size_t)chunk << 14); // [chunk][r = hx << 5 | q][l]
     const unsigned twoff = ((unsigned)hx << 9) + (unsigned)l;
     // round 2 (regs = r9..r5, thread = r4..r0 = hx): STAGE 5 + b on reg bit b, twiddle index (jj << 5) | hx; DIT packing; frame invariant
@@ -1341,12 +1345,147 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const v2u w = {v[j], v[j + 16]};
-                __builtin_nontemporal_store(w, at32(d2 + ((size_t)j << (RB + 10)), toff_l));
+                __builtin_nontemporal_store(w, at32(d2 + ((size_t)j << (RB + L2)), toff_l));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (RB + 10)), toff_l));
+            for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(v[j], at32(dst + ((size_t)j << (RB + L2)), toff_l));
         }
+    }
+}
+
+// ---- the 2-D scheme at N = 2^21 = 1024 x 2048, INVERSE, in TWO launches (round 5): k_rows2k_qtr + k_big2x_ci<., 11> -----------------------------------
+// The mirror of k_rows2k_tr: ONE workgroup of 1024 threads takes the 16 row cores whose k1 are consecutive (k1 = brev6(r6) << 4 | kb: 64-byte pieces of
+// X[k1 + 1024 k2]) -- 128 KiB, one workgroup per CU:
+//   round 1  thread = (jj = p10..p5, kb), regs q = p4..p0: position p takes X[k1 + 1024 brev11(p)]; DIT STAGE 0..4 on wave-uniform twiddles (dit_round5_c)
+//   LDS      row (p10..p5) << 4 | rev4(kb), column p4..p0; read back as wave = row k = rev4(kb), lane = (p10, p4..p0), register r = (p5, p9..p6)
+//   stage 5  DIT STAGE 5 on the register pairs (j, j + 16), one twiddle per lane; v_permlane32_swap then exchanges p5 (register bit 4) with p10 (lane bit 5)
+//   round 2  lane = p5..p0, regs j = p10..p6: DIT STAGE 6..10 (per-lane twiddles re-read per tile, quarter-turn sharing)
+//   store    V[r = k << 6 | r6][n2 = 64 j + lane] into the scratch shape k_big2x_ci reads: [q = r4..r0][chunk = n2 >> 4][r5][k = r9..r6][l]: every wave
+//            instruction writes four 64-byte pieces; the 16 waves of the block complete 1 KiB runs
+// The next tile's 32 loads are issued right behind the transpose's LDS writes, as in k_rows2k_tr.  (int_ifftNk.vhd:183-341 for the 2048-point core; the
+// scheme itself is this library's extension)
+template <bool FAST_OK>
+__global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, const Round5Consts c, size_t nframes, const Slice sl)
+{
+    extern __shared__ u32 lds[]; // 1024 rows x ROWY, then round 2's per-lane twiddles (DIT packing): 16 slots x 64 lanes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = __builtin_amdgcn_readfirstlane(tid >> 6); // the row of this wave (round 2)
+    // STAGE 6 + b on register bit b of round 2, table index (jx << 6) | lane, the upper half of every stage as quarter turns: 1 + 1 + 2 + 4 + 8 slots, tile
+    // invariant.  Round 2 holds the next tile's 32 loads and its own 32 values: the twiddles are read from here just in time, STAGE 10's eight only
+    // after STAGE 6..9 are done (all 17 pairs in registers beside the two data sets: 52 spilled VGPRs)
+    uint2 *const twl = reinterpret_cast<uint2 *>(lds + 1024 * ROWY);
+    {
+        const int slot = tid >> 6; // 0: STAGE 6, 1: STAGE 7, 2..3: STAGE 8, 4..7: STAGE 9, 8..15: STAGE 10
+        const unsigned idx = slot == 0 ? 63u : slot == 1 ? 127u : slot < 4 ? 255u + ((unsigned)(slot - 2) << 6) : slot < 8 ? 511u + ((unsigned)(slot - 4) << 6)
+                                                                                                                  : 1023u + ((unsigned)(slot - 8) << 6);
+        uint2 w = twf[idx + (unsigned)lane];
+        to_dit_packing(w.x, w.y);
+        twl[tid] = w;
+    }
+    u32 wa5[4], wb5[4];
+    {
+        uint2 w = twf[31u + (unsigned)(lane & 31)]; // STAGE 5: index p4..p0
+        to_dit_packing(w.x, w.y);
+        wa5[0] = wa5[1] = wa5[2] = wa5[3] = w.x;
+        wb5[0] = wb5[1] = wb5[2] = wb5[3] = w.y;
+    }
+    // transpose, read side: element (register r = (p5, p9..p6), lane = (p10, p4..p0)) <- row ((p10, p9..p6, p5) << 4) | k
+    const u32 *const rd_base = lds + ROWY * ((((lane >> 5) << 5) << 4) | k) + (lane & 31);
+    const int jj = tid >> 4, kb = tid & 15;
+    const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
+    u32 *const wr_base = lds + ROWY * ((jj << 4) | krow);
+    const unsigned rjj = __brev((unsigned)jj) >> 26;
+    const unsigned toff2 = (rjj << 10) | (unsigned)kb;                                       // user side (round 1 thread)
+    const unsigned toff = (((unsigned)lane >> 4) << 9) | ((unsigned)k << 4) | ((unsigned)lane & 15u); // scratch side (round 2 thread): chunk = 4 j + (lane >> 4)
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    // XCD-paired tiles: blocks b and b + 8 (same XCD: b & 7) take the two r6 partners (r6, r6 ^ 32) = the two 64-byte halves of every line of X at
+    // the same time, with plain loads, so that the half a block does not use is an L2 hit for its partner (the grid is a multiple of 16)
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+    size_t t = blockIdx.x;
+    auto tile_of = [&](size_t tt) { return (tt >> 4) * 8u + slot; }; // G: frame = G >> 5, r6 = part << 5 | (G & 31)
+    bool have = (tile_of(t) >> 5) < nframes;
+    u32 v[32];
+    auto load_tile = [&](size_t G, int q0) { // (in two halves: the second one is issued once round 2's twiddles are dead)
+        const unsigned r6 = (part << 5) | ((unsigned)G & 31u);
+        const u32 *src = in + ((G >> 5) << 21) + ((__brev(r6) >> 26) << 4); // wave-uniform
+        unsigned toff2_l = toff2;
+        asm volatile("" : "+v"(toff2_l));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q0 + q] = *at32(src + ((size_t)rev5c(q0 + q) << 16), toff2_l); // position (jj << 5 | q) = X[k1 + 1024 brev11]
+    };
+    if (have) load_tile(tile_of(t), 0), load_tile(tile_of(t), 16);
+    while (have) {
+        const size_t ct = tile_of(t);
+        t += gridDim.x;
+        const size_t nt = tile_of(t);
+        const bool have_next = (nt >> 5) < nframes;
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
+        }
+        // One body per extraction form from here to the stores (one branch per tile): with the two forms of round 2 behind separate branches inside
+        // one body the allocator spills 50-60 VGPRs (either form alone: 103 / 105)
+        u32 *dst = scr + ((ct >> 5) << 21) + ((size_t)((unsigned)ct & 31u) << 16) + (part << 8); // wave-uniform: q = r4..r0, r5 = part
+#define INTFFT_R2K_TILE(FX)                                                                                                                    \
+    {                                                                                                                                          \
+        dit_round5_c<FX>(v, c, sl);                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 32; ++q) wr_base[q] = v[q];                                                                      \
+        asm volatile("" ::: "memory");                                                                                                         \
+        if (have_next) load_tile(nt, 0); /* flies during round 2 and the stores below */                                                       \
+        __syncthreads();                                                                                                                       \
+        u32 w[32];                                                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 32; ++r) w[r] = rd_base[ROWY * ((((r & 15) << 1) | (r >> 4)) << 4)];                             \
+        u32 wa16[8], wb16[8];                                                                                                                  \
+        RoundTwQ t1;                                                                                                                           \
+        {                                                                                                                                      \
+            const uint2 x0 = twl[lane], x1 = twl[64 + lane];                                                                                   \
+            t1.wa1[0] = x0.x, t1.wb1[0] = x0.y, t1.wa2[0] = x1.x, t1.wb2[0] = x1.y;                                                            \
+            _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2)                                                                                   \
+            {                                                                                                                                  \
+                const uint2 x = twl[64 * (2 + j2) + lane];                                                                                     \
+                t1.wa4[j2] = x.x, t1.wb4[j2] = x.y;                                                                                            \
+            }                                                                                                                                  \
+            _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                                                                   \
+            {                                                                                                                                  \
+                const uint2 x = twl[64 * (4 + j4) + lane];                                                                                     \
+                t1.wa8[j4] = x.x, t1.wb8[j4] = x.y;                                                                                            \
+            }                                                                                                                                  \
+        }                                                                                                                                      \
+        /* STAGE 5: pairs (j, j + 16) */                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 16; j += 4)                                                                                      \
+            group4_dit<FX, false, 0, true>(w[j], w[j + 16], w[j + 1], w[j + 17], w[j + 2], w[j + 18], w[j + 3], w[j + 19], wa5, wb5, sl);      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&w[0]));                                                                                      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&w[16]));                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) swap32(w[j], w[j + 16]); /* register bit 4: p5 -> p10 */                                \
+        dit_round_q<FX, 0>(w, t1, sl);                                                                                                         \
+        dit_round_q<FX, 16>(w, t1, sl);                                                                                                        \
+        asm volatile("" ::: "memory"); /* STAGE 10's twiddles only now */                                                                      \
+        _Pragma("unroll") for (int j8 = 0; j8 < 8; ++j8)                                                                                       \
+        {                                                                                                                                      \
+            const uint2 x = twl[64 * (8 + j8) + lane];                                                                                         \
+            wa16[j8] = x.x, wb16[j8] = x.y;                                                                                                    \
+        }                                                                                                                                      \
+        dit_top16<FX>(w, wa16, wb16, sl);                                                                                                      \
+        asm volatile("" ::: "memory");                                                                                                         \
+        if (have_next) load_tile(nt, 16); /* the other half: the twiddles are dead */                                                          \
+        unsigned toff_l = toff;                                                                                                                \
+        asm volatile("" : "+v"(toff_l));                                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) *at32(dst + ((size_t)j << 11), toff_l) = w[j];                                          \
+    }
+        if (fast) INTFFT_R2K_TILE(FAST_OK)
+        else {
+            if (sl.wd != 16) wrap_inputs(v, sl.wd);
+            INTFFT_R2K_TILE(false)
+        }
+#undef INTFFT_R2K_TILE
+        have = have_next;
     }
 }
 
@@ -1381,6 +1520,46 @@ hipError_t launch_fused2d_inv(int twd, const u32 *pin, u32 *pout, u32 *scr, cons
         allow_max_lds(kptr(k_big2x_ci<false>));
         hipLaunchKernelGGL((k_big2x_qb<20, false>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw1k, c, nframes, sl);
         hipLaunchKernelGGL((k_big2x_ci<false>), dim3(64u * groups), dim3(512), ldsa, stream, scr, pout, tw1k, c, tw2d, nframes, groups, sl, halves);
+    }
+    return hipGetLastError();
+}
+
+// N = 2^21 inverse: the 2048-point row cores (k_rows2k_qtr; tw16r / h_tw2k: the packed / host tables of the 2048-point core) + the multiplier and the
+// 1024-point column cores (k_big2x_ci<., 11>; tw1k / h_tw1k)
+hipError_t launch_fused2d_inv21(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint2 *tw16r, const int2 *h_tw2k,
+                                const u32 *tw2d, size_t nframes, int halves, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    auto consts = [](const int2 *h, Round5Consts &c) {
+        auto pk = [&](int idx, u32 &wa, u32 &wb) { // DIT packing: Wc = (wr, wi), Wd = (-wi, wr)
+            const int2 w = h[idx];
+            wa = ((u32)w.x & 0xFFFFu) | ((u32)w.y << 16);
+            wb = ((u32)(-w.y) & 0xFFFFu) | ((u32)w.x << 16);
+        };
+        for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+        for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+        for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+    };
+    Round5Consts cr, cc;
+    consts(h_tw2k, cr);
+    consts(h_tw1k, cc);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsa = (size_t)1024 * ROWX * sizeof(u32), ldsr = (size_t)1024 * ROWY * sizeof(u32) + 1024 * sizeof(uint2);
+    const size_t ntiles = nframes << 6; // XCD-paired: blocks b, b + 8 take the two r6 partners; the grid is a multiple of 16
+    const unsigned gr = (unsigned)std::min<size_t>(ntiles, (size_t)device_cus() / 16 * 16);
+    const unsigned groups = (unsigned)(nframes < 32 ? nframes : 32);
+    if (fx) {
+        allow_max_lds(kptr(k_rows2k_qtr<true>));
+        allow_max_lds(kptr(k_big2x_ci<true, 11>));
+        hipLaunchKernelGGL((k_rows2k_qtr<true>), dim3(gr), dim3(1024), ldsr, stream, pin, scr, tw16r, cr, nframes, sl);
+        hipLaunchKernelGGL((k_big2x_ci<true, 11>), dim3(128u * groups), dim3(512), ldsa, stream, scr, pout, tw1k, cc, tw2d, nframes, groups, sl, halves);
+    } else {
+        allow_max_lds(kptr(k_rows2k_qtr<false>));
+        allow_max_lds(kptr(k_big2x_ci<false, 11>));
+        hipLaunchKernelGGL((k_rows2k_qtr<false>), dim3(gr), dim3(1024), ldsr, stream, pin, scr, tw16r, cr, nframes, sl);
+        hipLaunchKernelGGL((k_big2x_ci<false, 11>), dim3(128u * groups), dim3(512), ldsa, stream, scr, pout, tw1k, cc, tw2d, nframes, groups, sl, halves);
     }
     return hipGetLastError();
 }

@@ -843,10 +843,10 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
               big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width)))
             pl->fused2d = 0;
         // ... and the inverse (4): the row cores as pass QB, the conj multiplier + the column cores on pass QA's tiles (k_big2x_ci)
-        if (!pl->fused2d && fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order) &&
-            pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 && pl->tw_i.sh_b == p->twdl_width - 1 && pl->sub_row_i && pl->sub_col_i &&
-            big2x_tables_ok(10, pl->sub_row_i->h_tw.data(), p->twdl_width))
-            pl->fused2d = 4;
+        const int inv2d = fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
+        if (!pl->fused2d && inv2d && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 && pl->tw_i.sh_b == p->twdl_width - 1 && pl->sub_row_i && pl->sub_col_i &&
+            big2x_tables_ok(10, pl->sub_col_i->h_tw.data(), p->twdl_width) && big2x_tables_ok(l2, pl->sub_row_i->h_tw.data(), p->twdl_width))
+            pl->fused2d = inv2d == 2 ? 6 : 4; // 6 (round 5): N = 2^21, the 2048-point row cores in k_rows2k_qtr
         // ... and the pair (5): the forward two launches into the second layout buffer, the inverse two launches from there
         if (!pl->fused2d && p->direction == INTFFT_PAIR && !diag_env("INTFFT_2D_NO_FUSED_CORES") && pl->sub_col_f && pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
             fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 2 &&
@@ -854,18 +854,18 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 &&
             pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width))
             pl->fused2d = 5;
-        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
+        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->fused2d == 6 ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
             // the fused launches run none of the 1-D sub-plans except form 3's rows, and forms 2 / 4 need one layout buffer only:
             // keep the core whose twiddle tables the tile kernels read (core1k), release the rest
             auto drop = [&](intfft_plan **sp) {
-                if (*sp && *sp != core1k && !(pl->fused2d == 3 && *sp == pl->sub_row_f)) {
+                if (*sp && *sp != core1k && !(pl->fused2d == 3 && *sp == pl->sub_row_f) && !(pl->fused2d == 6 && *sp == pl->sub_row_i)) {
                     intfft_plan_destroy(*sp);
                     *sp = nullptr;
                 }
             };
             drop(&pl->sub_col_f), drop(&pl->sub_row_f), drop(&pl->sub_row_i), drop(&pl->sub_col_i);
-            if (pl->fused2d == 2 || pl->fused2d == 4) {
+            if (pl->fused2d == 2 || pl->fused2d == 4 || pl->fused2d == 6) {
                 (void)hipFree(pl->buf2d[1]);
                 pl->buf2d[1] = nullptr;
                 pl->n2d_bufs = 1;
@@ -885,6 +885,12 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
             }
+            if (e == hipSuccess && pl->fused2d == 6) { // the 2048-point inverse row core's packed table for k_rows2k_qtr
+                const size_t tot = ((size_t)1 << 11) - 1;
+                e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_i->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
+            }
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) {
                 intfft_plan_destroy(pl);
@@ -901,6 +907,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             }
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
+            else if (pl->fused2d == 6) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
             else if (pl->d_tw16r) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr]");
             else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
@@ -1302,7 +1309,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
-        if (plan->fused2d == 2 || plan->fused2d == 4) info->n_passes = 2;
+        if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6) info->n_passes = 2;
         if (plan->fused2d == 5) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
@@ -1337,7 +1344,8 @@ static bool dual_2d(const intfft_plan *pl)
 {
     // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
     // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
-    return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r));
+    return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r)) &&
+           pl->fused2d != 6;
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1412,6 +1420,11 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                            p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 6) {
+                e = launch_fused2d_inv21(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_i->h_tw.data(), pl->d_tw16r,
+                                         pl->sub_row_i->h_tw.data(), pl->d_tw2d_tiles, nf, p.out_order == INTFFT_ORDER_HALVES, st);
                 continue;
             }
             if (pl->fused2d == 4) {

@@ -158,6 +158,33 @@ def test_2d_n2pow20_inverse_two_launches(frames, monkeypatch):
         assert np.array_equal(got, got1)
 
 
+@pytest.mark.parametrize("frames", [3, 37])
+def test_2d_n2pow21_inverse_two_launches(frames, monkeypatch):
+    """N = 2^21 = 1024 x 2048, 16-bit scaled-truncate INVERSE (round 5): k_rows2k_qtr (the 2048-point row cores, sixteen per workgroup, reading 64-byte
+    pieces of X[k1 + 1024 k2]) + k_big2x_ci<., 11> (conj multiplier + column cores) against the oracle and the five-launch composite plan
+    (INTFFT_2D_NO_ROWS2K); a full-scale frame, HALVES order out, 13-bit twiddles / XSER OLD, a batch beyond one scratch chunk."""
+    n = 1 << 21
+    x = uniform_frames(frames, n, 15, 2777 + frames)
+    x[0] = uniform_frames(1, n, 16, 17)[0]
+    if frames <= 5:
+        info = check(x, 21, 10, 16, 16, 0, 0, True, "INV")
+        assert info["kernel_name"] == "2d[k_rows2k_qtr|k_big2x_ci]" and info["n_passes"] == 2, info
+        check(x[:2], 21, 10, 16, 16, 0, 0, True, "INV", "NATURAL", "HALVES")
+        check(x[:1], 21, 10, 16, 13, 0, 0, False, "INV")
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+            got5, info5 = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
+            assert info5["n_passes"] >= 4, info5
+        got2, _ = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
+        assert np.array_equal(got2, got5)
+    else:
+        got, info = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
+        assert info["n_passes"] == 2, info
+        sel = [0, 15, 16, 31, 32, 36]
+        want = C.execute_2d(x[sel], C.make_params(21, 16, 16, 0, 0, True), 10, C.INV, C.NATURAL, C.NATURAL, form=1)
+        assert np.array_equal(got[sel], want)
+
+
 @pytest.mark.parametrize("case", [(13, 6, 16, 16, 0, 0, True), (14, 9, 16, 16, 1, 0, True), (12, 6, 44, 16, 0, 0, True), (16, 8, 16, 16, 0, 1, True),
                                   (15, 3, 24, 24, 1, 0, False), (17, 4, 16, 16, 0, 0, True), (17, 13, 16, 16, 0, 0, True)])
 @pytest.mark.parametrize("direction", list(DIR))

@@ -1,6 +1,7 @@
 """tools/fuzz_soak.py [seconds] [seed] -- open-ended parity fuzz on the GPU box (diagnostics; the seeded, bounded fuzz sets live in tests/).
 Random elaboratable generics (NFFT 3..20, DATA_WIDTH 4..64, TWDL_WIDTH 8..26, every mode / direction / XSERIES / order pair, ragged
 batches; now and then the 2-D scheme with a random split): whatever kernel the planner picks must equal the C oracle bit for bit.
+FUZZ_BIG=1: the multi-pass families; FUZZ_NATIVE=1: single cores in their own beat orders (HALVES / BITREV), widths weighted to the 32- / 64-bit word classes.
 Prints one line per mismatch (none expected) and a summary of the kernels that were exercised."""
 import collections
 import os
@@ -36,6 +37,12 @@ def main():
         new = bool(rng.integers(0, 2))
         d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
         in_o, out_o = (list(ORD)[int(rng.integers(0, 4))], list(ORD)[int(rng.integers(0, 4))]) if rng.random() < 0.4 else ("NATURAL", "NATURAL")
+        if os.environ.get("FUZZ_NATIVE") == "1":  # the cores' own beat orders (NAT instantiations): single cores, widths weighted to the 32- / 64-bit word classes
+            d = ["FWD", "INV"][int(rng.integers(0, 2))]
+            time_o, freq_o = [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")][int(rng.integers(0, 3))]
+            in_o, out_o = (time_o, freq_o) if d == "FWD" else (freq_o, time_o)
+            log2n = int(rng.choice([6, 7, 8, 9, 10, 10, 11, 11, 12, 12, 13, 14, 15, 16, 16, 17, 19, 20]))
+            dw = int(rng.choice([16, 18, 24, 24, 28, 32, 32, 40, 48, int(rng.integers(4, 65))]))
         l1 = 0
         if big and log2n == 20 and rng.random() < 0.3:
             l1, log2n = 10, int(rng.choice([20, 20, 21, 22]))
