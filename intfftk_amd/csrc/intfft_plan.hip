@@ -121,7 +121,8 @@ struct intfft_plan {
     void *buf2d[2] = {nullptr, nullptr};
     int fused2d = 0;                  // 2: N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward in two launches (k_big2x_c + k_big2x_b); 3: N = 2^21 .. 2^24 as
                                       // 1024 x N2: k_big2x_c, the row sub-plan, one layout change; 4: N = 2^20 inverse in two launches (k_big2x_qb + k_big2x_ci);
-                                      // 5: N = 2^20 pair = the forward two launches, then the inverse two
+                                      // 5: N = 2^20 pair = the forward two launches, then the inverse two; 6 (round 5): N = 2^21 inverse in two launches
+                                      // (k_rows2k_qtr + k_big2x_ci<., 11>); 7: N = 2^21 pair = k_big2x_c<11> + k_rows2k_tr, then form 6's two launches
     uint2 *d_tw16r = nullptr, *d_tw16ri = nullptr; // fused2d == 3 at N2 = 2048, natural order out (round 5): the row core's packed tables for k_rows2k_tr
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
     size_t buf2d_frames = 0;
@@ -854,12 +855,21 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 &&
             pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width))
             pl->fused2d = 5;
+        // ... and the pair at N = 2^21 (7, round 5): k_big2x_c<11> + k_rows2k_tr into the second layout buffer, k_rows2k_qtr + k_big2x_ci<., 11> from there
+        if (!pl->fused2d && p->direction == INTFFT_PAIR && !diag_env("INTFFT_2D_NO_FUSED_CORES") && !diag_env("INTFFT_2D_NO_ROWS2K") && pl->sub_col_f &&
+            pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
+            fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 3 && l2 == 11 &&
+            fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_INV, INTFFT_ORDER_NATURAL, p->out_order) == 2 &&
+            pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 &&
+            pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width) &&
+            big2x_tables_ok(11, pl->sub_row_f->h_tw.data(), p->twdl_width))
+            pl->fused2d = 7;
         const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->fused2d == 6 ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
             // the fused launches run none of the 1-D sub-plans except form 3's rows, and forms 2 / 4 need one layout buffer only:
             // keep the core whose twiddle tables the tile kernels read (core1k), release the rest
             auto drop = [&](intfft_plan **sp) {
-                if (*sp && *sp != core1k && !(pl->fused2d == 3 && *sp == pl->sub_row_f) && !(pl->fused2d == 6 && *sp == pl->sub_row_i)) {
+                if (*sp && *sp != core1k && !((pl->fused2d == 3 || pl->fused2d == 7) && *sp == pl->sub_row_f) && !(pl->fused2d == 6 && *sp == pl->sub_row_i)) {
                     intfft_plan_destroy(*sp);
                     *sp = nullptr;
                 }
@@ -885,11 +895,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
             }
-            if (e == hipSuccess && pl->fused2d == 6) { // the 2048-point inverse row core's packed table for k_rows2k_qtr
+            if (e == hipSuccess && (pl->fused2d == 6 || pl->fused2d == 7)) { // the 2048-point row core's packed table for k_rows2k_qtr (the pair: both row kernels)
                 const size_t tot = ((size_t)1 << 11) - 1;
                 e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
-                if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_i->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
+                if (e == hipSuccess) e = launch_pack_twiddles16((pl->fused2d == 7 ? pl->sub_row_f : pl->sub_row_i)->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
             }
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
             if (e != hipSuccess) {
@@ -908,6 +918,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
             else if (pl->fused2d == 6) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_big2x_ci]");
+            else if (pl->fused2d == 7) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr|k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
             else if (pl->d_tw16r) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr]");
             else std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|%.24s]", pl->sub_row_f->kernel_name);
@@ -1310,7 +1321,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
         if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6) info->n_passes = 2;
-        if (plan->fused2d == 5) info->n_passes = 4;
+        if (plan->fused2d == 5 || plan->fused2d == 7) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
@@ -1345,7 +1356,7 @@ static bool dual_2d(const intfft_plan *pl)
     // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
     // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
     return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r)) &&
-           pl->fused2d != 6;
+           pl->fused2d != 6 && pl->fused2d != 7;
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1420,6 +1431,15 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                            p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 7) { // the pair at N = 2^21: X in natural order in the second layout buffer between the two directions
+                uint32_t *b1 = reinterpret_cast<uint32_t *>(static_cast<char *>(buf1) + off);
+                e = launch_fused2d_cols(l2, p.twdl_width, src, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
+                if (e == hipSuccess) e = launch_fused2d_rows2k(p.twdl_width, b0, b1, pl->d_tw16r, pl->sub_row_f->h_tw.data(), nf, st);
+                if (e == hipSuccess)
+                    e = launch_fused2d_inv21(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw16r,
+                                             pl->sub_row_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.out_order == INTFFT_ORDER_HALVES, st);
                 continue;
             }
             if (pl->fused2d == 6) {

@@ -127,6 +127,26 @@ def test_2d_n2pow20_pair_four_launches(monkeypatch):
     assert np.array_equal(got4, got8)
 
 
+def test_2d_n2pow21_pair_four_launches(monkeypatch):
+    """N = 2^21 = 1024 x 2048 FFT -> IFFT pair (round 5): k_big2x_c<11> + k_rows2k_tr into the second layout buffer (X in natural order), k_rows2k_qtr +
+    k_big2x_ci<., 11> from there -- against the oracle's pair and the composite (INTFFT_2D_NO_ROWS2K); HALVES orders; a batch beyond one scratch chunk."""
+    n = 1 << 21
+    x = uniform_frames(3, n, 15, 3777)
+    x[0] = uniform_frames(1, n, 16, 18)[0]
+    info = check(x, 21, 10, 16, 16, 0, 0, True, "PAIR")
+    assert info["kernel_name"] == "2d[k_big2x_c|k_rows2k_tr|k_rows2k_qtr|k_big2x_ci]" and info["n_passes"] == 4, info
+    check(x[:1], 21, 10, 16, 16, 0, 0, True, "PAIR", "HALVES", "HALVES")
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+        got8, info8 = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "PAIR")
+        assert info8["n_passes"] >= 6, info8
+    got4, _ = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "PAIR")
+    assert np.array_equal(got4, got8)
+    xb = np.concatenate([x] * 7)  # 21 frames: more than one chunk of the layout buffers
+    gb, _ = run_gpu(xb, 21, 10, 16, 16, 0, 0, True, "PAIR")
+    assert all(np.array_equal(gb[3 * i:3 * i + 3], got4) for i in range(7))
+
+
 @pytest.mark.parametrize("frames", [3, 70])
 def test_2d_n2pow20_inverse_two_launches(frames, monkeypatch):
     """N = 2^20 = 1024 x 1024, 16-bit scaled-truncate INVERSE: k_big2x_qb (row cores: pass QB of the 1-D two-pass inverse as it is) +

@@ -19,6 +19,7 @@ for L, L1 in ((20, 10), (21, 10), (22, 11), (24, 12)):
 ROWS.append(("20:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^10"))
 ROWS.append(("21:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^11 (two launches, round 5)"))
 ROWS.append(("20:16:16:0:0:PAIR:10", "16-bit scaled-trunc PAIR, 2-D scheme 2^10 x 2^10"))
+ROWS.append(("21:16:16:0:0:PAIR:10", "16-bit scaled-trunc PAIR, 2-D scheme 2^10 x 2^11 (four launches, round 5)"))
 ROWS.append(("20:16:16:1:0:FWD:10", "16-bit unscaled FWD, 2-D scheme 2^10 x 2^10 (36-bit results)"))
 for L in (7, 10, 11, 12, 14, 16, 17, 18, 20):
     ROWS.append(("%d:16:16:0:0:INV" % L, "16-bit scaled-trunc INV"))
