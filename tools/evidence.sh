@@ -28,7 +28,7 @@ export TMPDIR=/tmp
 part_headline() { bash tools/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1; tail -5 gpurun_out/${TAG}_profile.log; }
 part_digests() {
   local specs=("$@")
-  [ ${#specs[@]} -eq 0 ] && specs=(C2 C3 C4 C5 20:16:16:0:0:FWD:10 21:16:16:0:0:FWD:10 14:16:16:0 16:24:24:1:0:INV 19:16:16:0 16:32:16:1)
+  [ ${#specs[@]} -eq 0 ] && specs=(C2 C3 C4 C5 20:16:16:0:0:FWD:10 21:16:16:0:0:FWD:10 21:16:16:0:0:INV:10 14:16:16:0 16:24:24:1:0:INV 19:16:16:0 16:32:16:1)
   BENCH_STEPS=6 BENCH_RAMP_S=0.1 bash tools/pmc_digest.sh $TAG "${specs[@]}" > gpurun_out/${TAG}_pmc_digest.log 2>&1
   tail -20 gpurun_out/${TAG}_pmc_digest.log
 }
