@@ -7,9 +7,9 @@ namespace intfft {
 bool fastw64_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
     const int out_bits = data_width + format * log2n;
-    // N = 1024 also in the cores' own beat orders (NAT instantiations, intfft_fastw64n.hip): int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out
+    // N = 128 .. 1024 also in the cores' own beat orders (NAT instantiations, intfft_fastw64n.hip / intfft_fastw64sn.hip): int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out
     const bool natural = in_order == 0 && out_order == 0;
-    const bool native = log2n == 10 && (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)
+    const bool native = log2n >= 7 && (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)
                                                        : (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2));
     return log2n >= 6 && log2n <= 10 && out_bits > 32 && out_bits <= 64 && data_width >= 2 && data_width <= 64 && (direction == 0 || direction == 1) && use_fly == 1 &&
            (natural || native) && twdl_width >= 4 && !diag_env("INTFFT_NO_FASTW64");
@@ -73,7 +73,9 @@ hipError_t launch_fastw64(int log2n, int direction, int rnd_kind, const StageDes
     W64Args a;
     for (int s = 0; s < 10; ++s) a.st[s] = st10[s];
     a.in_cb = in_cb, a.dw = dw, a.native = native;
-    if (log2n < 10) return native ? hipErrorInvalidValue : launch_fastw64_short(log2n, direction, rnd_kind, c, a, in, out, tw_all, nframes, stream);
+    if (log2n < 10)
+        return native ? launch_fastw64_short_native(log2n, direction, rnd_kind, c, a, in, out, tw_all, nframes, stream)
+                      : launch_fastw64_short(log2n, direction, rnd_kind, c, a, in, out, tw_all, nframes, stream);
     const int cm = fastw64_multiplier_form(10, st10, rnd_kind);
     if (native) return launch_fastw64_native(direction, rnd_kind, cm, c, a, in, out, tw_all, nframes, stream); // the natural-order instances carry none of that code
 #define INTFFT_W64N(R, CM)                                                                                                               \

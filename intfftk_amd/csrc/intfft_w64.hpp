@@ -23,7 +23,7 @@ struct W64Args {
     StageDesc st[10]; // indexed by the STAGE generic
     int in_cb;        // input container bytes per component: 4 or 8
     int dw;           // DATA_WIDTH (inputs are wrapped to it on load: conv_std_logic_vector, fft_signle_test.vhd:163-164)
-    int native;       // NAT instantiations (N = 1024): bit 0 HALVES order on the time side, bit 1 BITREV order on the frequency side
+    int native;       // NAT instantiations (N >= 128): bit 0 HALVES order on the time side, bit 1 BITREV order on the frequency side
 };
 
 __device__ __forceinline__ void swap32_64(i64 &a, i64 &b)
@@ -64,14 +64,14 @@ constexpr int PLANE64 = 64 * ROWU; // dwords per transpose plane of one wave
 #define W64_WAVES 2
 #endif
 
-// NAT (round 5, N = 1024): the cores' own beat orders.  HALVES in: the register pair (j, j + 8) is the sample pair (n, n + 512) of one beat, one
-// 16- / 32-byte load.  BITREV out: lane's 16 results are the positions 16 rev6(lane) .. + 15, so they go through the wave's LDS tile (rows of 16
-// samples, 68 dwords apart) and leave as 1 KiB per store instruction like the natural order.
+// NAT (round 5, N = 128 .. 1024): the cores' own beat orders.  HALVES in: the register pair (j, j + 2^(L-7)) is the sample pair (n, n + N/2) of one beat, one
+// 16- / 32-byte load.  BITREV out: a lane's 16 results are 16 consecutive positions of the chunk (rows of the frames one after the other), so they go through the
+// wave's LDS tile (rows of 16 samples, 68 dwords apart) and leave as 1 KiB per store instruction like the natural order.
 template <int L, int RNDC, int CM, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, W64_WAVES))) void k_fft1024_w64(const void *in, i64 *out, const int2 *__restrict__ twt, const UConsts c, const W64Args a,
                                                      size_t nframes_user)
 {
-    static_assert(!NAT || L == 10, "native beat orders: N = 1024");
+    static_assert(!NAT || L >= 7, "native beat orders: N >= 128");
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[]; // 4 waves x 4 planes x 64 rows x ROWU
     const bool halves = NAT && (a.native & 1), bitrev = NAT && (a.native & 2);
     const int lane = threadIdx.x & 63;
@@ -132,30 +132,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
         }
     }
     constexpr int ow0 = out_weight<L>(0), ow1 = out_weight<L>(1), ow2 = out_weight<L>(2);
+    int nat_row = 0; // NAT, BITREV side: the lane's positions (frame bits on top) >> 4
+#pragma unroll
+    for (int k = 4; k < 10; ++k) nat_row |= ((lane >> lane_bit_u<L>(k)) & 1) << (k - 4);
 
     const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
     for (size_t f = wave0; f < nframes; f += nwaves) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: absent frames read as 0
         i64 re[16], im[16];
         if (NAT && halves) {
-            if (a.in_cb == 4) {
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                const v4i *src = static_cast<const v4i *>(in) + f * 512 + lane;
-                const int sh = 32 - a.dw;
+            constexpr int HB = 1 << (L >= 7 ? L - 7 : 0); // register bit that carries a(L-1)
+            const int sh = 32 - a.dw;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const v4i x = INTFFT_LD(src + 64 * j);
-                    re[j] = (int)((u32)x.x << sh) >> sh, im[j] = (int)((u32)x.y << sh) >> sh;
-                    re[j + 8] = (int)((u32)x.z << sh) >> sh, im[j + 8] = (int)((u32)x.w << sh) >> sh;
-                }
-            } else {
-                typedef i64 v2l __attribute__((ext_vector_type(2)));
-                const v2l *src = static_cast<const v2l *>(in) + f * 1024 + 2 * lane;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const v2l x0 = INTFFT_LD(src + 128 * j), x1 = INTFFT_LD(src + 128 * j + 1);
-                    re[j] = wrapw<int64_t>((int64_t)x0.x, a.dw), im[j] = wrapw<int64_t>((int64_t)x0.y, a.dw);
-                    re[j + 8] = wrapw<int64_t>((int64_t)x1.x, a.dw), im[j + 8] = wrapw<int64_t>((int64_t)x1.y, a.dw);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB), p0 = 64 * j0, pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                const bool ok = !partial || f * FP + (size_t)(p0 >> L) < nframes_user;
+                if (a.in_cb == 4) {
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    v4i x = {0, 0, 0, 0};
+                    if (ok) x = INTFFT_LD(static_cast<const v4i *>(in) + f * 512 + pair + lane);
+                    re[j0] = (int)((u32)x.x << sh) >> sh, im[j0] = (int)((u32)x.y << sh) >> sh;
+                    re[j0 + HB] = (int)((u32)x.z << sh) >> sh, im[j0 + HB] = (int)((u32)x.w << sh) >> sh;
+                } else {
+                    typedef i64 v2l __attribute__((ext_vector_type(2)));
+                    const v2l *src = static_cast<const v2l *>(in) + f * 1024 + 2 * (pair + lane);
+                    v2l x0 = {0, 0}, x1 = {0, 0};
+                    if (ok) x0 = INTFFT_LD(src), x1 = INTFFT_LD(src + 1);
+                    re[j0] = wrapw<int64_t>((int64_t)x0.x, a.dw), im[j0] = wrapw<int64_t>((int64_t)x0.y, a.dw);
+                    re[j0 + HB] = wrapw<int64_t>((int64_t)x1.x, a.dw), im[j0 + HB] = wrapw<int64_t>((int64_t)x1.y, a.dw);
                 }
             }
         } else if (a.in_cb == 4) {
@@ -258,7 +262,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
 #pragma unroll
         for (int g = 0; g < 16; g += 2) fly64<RNDC, 1, CM>(a.st[0], 0, re[g], im[g], re[g + 1], im[g + 1], 0, 0);
         typedef i64 v2l __attribute__((ext_vector_type(2)));
-        if constexpr (L < 10) { // lane bit 5 <-> reg bit 3: every lane holds pairs of consecutive outputs (32 bytes)
+        if (NAT && bitrev) { // memory index = position = 16 nat_row + r (N = 1024: nat_row = rev6(lane))
+            v2l *row = reinterpret_cast<v2l *>(lds + 68 * nat_row);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const v2l y = {re[r], im[r]};
+                row[r] = y;
+            }
+            wave_lds_fence();
+            v2l *dst = reinterpret_cast<v2l *>(out) + f * 1024 + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const v2l y = *reinterpret_cast<const v2l *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15));
+                if (!partial || f * FP + (size_t)((64 * i + lane) >> L) < nframes_user) __builtin_nontemporal_store(y, dst + 64 * i);
+            }
+            wave_lds_fence();
+        } else if constexpr (L < 10) { // lane bit 5 <-> reg bit 3: every lane holds pairs of consecutive outputs (32 bytes)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 swap32_64(re[r], re[r + 8]);
@@ -274,21 +293,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
                     __builtin_nontemporal_store(y1, d + 1);
                 }
             }
-        } else if (NAT && bitrev) { // memory index = position = 16 rev6(lane) + r
-            v2l *row = reinterpret_cast<v2l *>(lds + 68 * (int)(__brev((u32)lane) >> 26));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const v2l y = {re[r], im[r]};
-                row[r] = y;
-            }
-            wave_lds_fence();
-            v2l *dst = reinterpret_cast<v2l *>(out) + f * 1024 + lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const v2l y = *reinterpret_cast<const v2l *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15));
-                __builtin_nontemporal_store(y, dst + 64 * i);
-            }
-            wave_lds_fence();
         } else { // X index = rev4(r) * 64 + lane
             v2l *dst = reinterpret_cast<v2l *>(out) + f * 1024 + lane;
 #pragma unroll
@@ -310,7 +314,7 @@ template <int L, int RNDC, int CM, bool NAT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, W64_WAVES))) void k_ifft1024_w64(const void *in, i64 *out, const int2 *__restrict__ twt, const UConsts c, const W64Args a,
                                                       size_t nframes_user)
 {
-    static_assert(!NAT || L == 10, "native beat orders: N = 1024");
+    static_assert(!NAT || L >= 7, "native beat orders: N >= 128");
     extern __shared__ __attribute__((aligned(16))) u32 lds_all[];
     const bool halves = NAT && (a.native & 1), bitrev = NAT && (a.native & 2);
     const int lane = threadIdx.x & 63;
@@ -369,12 +373,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
         }
     }
     constexpr int ow0 = out_weight<L>(0), ow1 = out_weight<L>(1), ow2 = out_weight<L>(2);
+    int nat_row = 0; // NAT, BITREV side: the lane's positions (frame bits on top) >> 4
+#pragma unroll
+    for (int k = 4; k < 10; ++k) nat_row |= ab(k) << (k - 4);
 
     const size_t wave0 = (size_t)blockIdx.x * 4 + wv, nwaves = (size_t)gridDim.x * 4;
     for (size_t f = wave0; f < nframes; f += nwaves) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user;
         i64 re[16], im[16];
-        if constexpr (L < 10) {
+        if (NAT && bitrev) { // memory index = position = 16 nat_row + r (N = 1024: nat_row = rev6(lane))
+            typedef i64 v2l __attribute__((ext_vector_type(2)));
+            wave_lds_fence();
+            if (a.in_cb == 4) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const v2i *src = static_cast<const v2i *>(in) + f * 1024 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v2i x = {0, 0};
+                    if (!partial || f * FP + (size_t)((64 * i + lane) >> L) < nframes_user) x = INTFFT_LD(src + 64 * i);
+                    *reinterpret_cast<v2i *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15)) = x;
+                }
+            } else {
+                const v2l *src = static_cast<const v2l *>(in) + f * 1024 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    v2l x = {0, 0};
+                    if (!partial || f * FP + (size_t)((64 * i + lane) >> L) < nframes_user) x = INTFFT_LD(src + 64 * i);
+                    *reinterpret_cast<v2l *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15)) = x;
+                }
+            }
+            wave_lds_fence();
+            const u32 *row = lds + 68 * nat_row;
+            if (a.in_cb == 4) {
+                typedef int v2i __attribute__((ext_vector_type(2)));
+                const int sh = 32 - a.dw;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const v2i x = *reinterpret_cast<const v2i *>(row + 4 * r);
+                    re[r] = (int)((u32)x.x << sh) >> sh;
+                    im[r] = (int)((u32)x.y << sh) >> sh;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const v2l x = *reinterpret_cast<const v2l *>(row + 4 * r);
+                    re[r] = wrapw<int64_t>((int64_t)x.x, a.dw);
+                    im[r] = wrapw<int64_t>((int64_t)x.y, a.dw);
+                }
+            }
+        } else if constexpr (L < 10) {
             const bool ok = !partial || f * FP + (size_t)lane_frame < nframes_user;
             if (a.in_cb == 4) {
                 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -403,44 +450,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
             for (int r = 0; r < 8; ++r) {
                 swap32_64(re[r], re[r + 8]);
                 swap32_64(im[r], im[r + 8]);
-            }
-        } else if (NAT && bitrev) { // memory index = position = 16 rev6(lane) + r
-            typedef i64 v2l __attribute__((ext_vector_type(2)));
-            wave_lds_fence();
-            if (a.in_cb == 4) {
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                const v2i *src = static_cast<const v2i *>(in) + f * 1024 + lane;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const v2i x = INTFFT_LD(src + 64 * i);
-                    *reinterpret_cast<v2i *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15)) = x;
-                }
-            } else {
-                const v2l *src = static_cast<const v2l *>(in) + f * 1024 + lane;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const v2l x = INTFFT_LD(src + 64 * i);
-                    *reinterpret_cast<v2l *>(lds + 68 * (4 * i + (lane >> 4)) + 4 * (lane & 15)) = x;
-                }
-            }
-            wave_lds_fence();
-            const u32 *row = lds + 68 * (int)(__brev((u32)lane) >> 26);
-            if (a.in_cb == 4) {
-                typedef int v2i __attribute__((ext_vector_type(2)));
-                const int sh = 32 - a.dw;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const v2i x = *reinterpret_cast<const v2i *>(row + 4 * r);
-                    re[r] = (int)((u32)x.x << sh) >> sh;
-                    im[r] = (int)((u32)x.y << sh) >> sh;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const v2l x = *reinterpret_cast<const v2l *>(row + 4 * r);
-                    re[r] = wrapw<int64_t>((int64_t)x.x, a.dw);
-                    im[r] = wrapw<int64_t>((int64_t)x.y, a.dw);
-                }
             }
         } else if (a.in_cb == 4) { // L == 10
             typedef int v2i __attribute__((ext_vector_type(2)));
@@ -541,12 +550,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W64_WAVES, 
         }
         typedef i64 v2l __attribute__((ext_vector_type(2)));
         if (NAT && halves) {
-            v2l *dst2 = reinterpret_cast<v2l *>(out) + f * 1024 + 2 * lane;
+            constexpr int HB = 1 << (L >= 7 ? L - 7 : 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const v2l y0 = {re[j], im[j]}, y1 = {re[j + 8], im[j + 8]};
-                __builtin_nontemporal_store(y0, dst2 + 128 * j);
-                __builtin_nontemporal_store(y1, dst2 + 128 * j + 1);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j0 = ((jj / HB) * 2 * HB) | (jj % HB), p0 = 64 * j0, pair = ((p0 >> L) << (L - 1)) | (p0 & ((1 << (L - 1)) - 1));
+                if (!partial || f * FP + (size_t)(p0 >> L) < nframes_user) {
+                    v2l *dst2 = reinterpret_cast<v2l *>(out) + f * 1024 + 2 * (pair + lane);
+                    const v2l y0 = {re[j0], im[j0]}, y1 = {re[j0 + HB], im[j0 + HB]};
+                    __builtin_nontemporal_store(y0, dst2);
+                    __builtin_nontemporal_store(y1, dst2 + 1);
+                }
             }
             continue;
         }
@@ -1007,6 +1020,8 @@ inline void launch_w64_kernel(K kernel, int log2n, const UConsts &c, const W64Ar
 
 hipError_t launch_fastw64_short(int log2n, int direction, int rnd_kind, const UConsts &c, const W64Args &a, const void *in, void *out,
                                 const int2 *tw_all, size_t nframes, hipStream_t stream);
+hipError_t launch_fastw64_short_native(int log2n, int direction, int rnd_kind, const UConsts &c, const W64Args &a, const void *in, void *out,
+                                       const int2 *tw_all, size_t nframes, hipStream_t stream); // intfft_fastw64sn.hip
 hipError_t launch_fastw64_native(int direction, int rnd_kind, int cm, const UConsts &c, const W64Args &a, const void *in, void *out, const int2 *tw_all,
                                  size_t nframes, hipStream_t stream); // intfft_fastw64n.hip
 

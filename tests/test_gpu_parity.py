@@ -684,6 +684,27 @@ def test_wave_kernel_64_bit_short_frames(case, direction):
 
 
 @pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("case", [(7, 32, 16, 1, 0), (7, 40, 24, 1, 0), (8, 32, 24, 1, 0), (9, 30, 18, 1, 0), (7, 44, 16, 0, 1), (8, 48, 24, 0, 0), (9, 40, 16, 0, 0)])
+def test_wave_kernel_64_bit_short_frames_native_orders(case, direction):
+    """N = 128 .. 512 with results of 33 .. 64 bits in the cores' own beat orders (round 5: NAT instantiations of the short-frame wave kernels; 32-bit unscaled
+    data at the reference testbenches' N = 128, fft_signle_test.vhd:70-92, as int_fftNk itself takes and gives it): the three order pairs per direction, ragged
+    batches (absent frames of the last wave), against the oracle."""
+    log2n, dw, tw, fmt, rnd = case
+    n = 1 << log2n
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, True), DIR[direction]) != 0:
+        pytest.skip("not elaboratable")
+    x = np.concatenate([edge_frames(n, dw), uniform_frames(77, n, dw, 1240 + dw + log2n)])
+    orders = [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")] if direction == "FWD" else [("BITREV", "HALVES"), ("BITREV", "NATURAL"),
+                                                                                                             ("NATURAL", "HALVES")]
+    narrow = dw + ((log2n - 2 if direction == "FWD" else log2n - 1) if fmt else 0) + tw <= 64
+    for in_o, out_o in orders:
+        for nb in (len(x), 1, 5):
+            got, info = run_gpu(x[:nb], log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=in_o, out_order=out_o)
+            assert info["kernel_name"] == (("k_ifft1024_w64" if direction == "INV" else "k_fft1024_w64") if narrow else "k_pass<long>"), (info, in_o, out_o)
+            assert np.array_equal(got, run_ref(x[:nb], log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=in_o, out_order=out_o)), (nb, in_o, out_o)
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
 @pytest.mark.parametrize("case", [(11, 32, 16, 1, 0, True), (12, 32, 16, 1, 0, True), (12, 32, 24, 1, 0, False), (11, 30, 18, 1, 0, True), (12, 40, 16, 0, 0, True),
                                   (11, 44, 16, 0, 1, True), (12, 48, 24, 0, 0, True), (11, 50, 10, 1, 0, True), (12, 64, 16, 0, 0, True), (12, 24, 24, 1, 0, True)])
 def test_block_kernel_64_bit_native_orders(case, direction, monkeypatch):

@@ -134,6 +134,8 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("10:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (42-bit results), HALVES in / BITREV out (round 5)"),
           ("10:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
           ("10:48:24:0", ("HALVES", "BITREV"), "48-bit scaled FWD, 24-bit twiddles, HALVES in / BITREV out (round 5)"),
+          ("7:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (39-bit results), HALVES in / BITREV out (round 5)"),
+          ("7:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
           ("12:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (44-bit results), HALVES in / BITREV out (round 5)"),
           ("12:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
           ("11:40:16:0", ("HALVES", "BITREV"), "40-bit scaled FWD, HALVES in / BITREV out (round 5)")]
