@@ -1125,10 +1125,11 @@ int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int for
     return log2n >= 21 && log2n <= 24 ? 3 : 0;
 }
 
-// 1: N = 2^20 (k_big2x_qb + k_big2x_ci), 2: N = 2^21 (k_rows2k_qtr + k_big2x_ci<., 11>; round 5)
+// 1: N = 2^20 (k_big2x_qb + k_big2x_ci), 2: N = 2^21 (k_rows2k_qtr + k_big2x_ci<., 11>; round 5), 3: N = 2^21 .. 2^24 in three launches (one layout change, the
+// N2-point inverse sub-plan, k_big2x_ci<., L2, ROWS>; round 5; N = 2^21 only with INTFFT_2D_NO_ROWS2K)
 int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
 {
-    return (log2n == 20 ? 1 : log2n == 21 && !diag_env("INTFFT_2D_NO_ROWS2K") ? 2 : 0) * (int)(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
+    return (log2n == 20 ? 1 : log2n == 21 && !diag_env("INTFFT_2D_NO_ROWS2K") ? 2 : log2n >= 21 && log2n <= 24 ? 3 : 0) * (int)(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
            (out_order == 0 || out_order == 2) && !diag_env("INTFFT_2D_NO_FUSED_CORES"));
 }
 
@@ -1252,8 +1253,9 @@ hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const ui
 //                   position of k1 -- with the 1024-point core's own twiddles (index = r mod 2^s: STAGE 0..4 wave-uniform, STAGE 5..9
 //                   per thread, frame and column invariant), natural or HALVES order out
 // L2 = 11 (round 5): the column cores of the 1024 x 2048 inverse plan -- 128 chunks of 16 columns n2, rows of 2048 samples on the user side; the scratch keeps
-// the [q][chunk][hi][k][l] shape (2 KiB runs per (q, chunk)), written by k_rows2k_qtr
-template <bool FAST_OK, int L2 = 10>
+// the [q][chunk][hi][k][l] shape (2 KiB runs per (q, chunk)), written by k_rows2k_qtr.  ROWS (L2 = 12 .. 14, round 5): the scratch holds plain rows [r][n2] as an
+// N2-point inverse sub-plan leaves them (64-byte pieces, the XCD partner takes the other half of every line: plain loads)
+template <bool FAST_OK, int L2 = 10, bool ROWS = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_big2x_ci(const u32 *scr, u32 *out, const uint2 *__restrict__ tw1k, const Round5Consts c,
                                                                                               const u32 *__restrict__ tw2d, size_t nframes, unsigned groups, const Slice sl,
                                                                                               int halves)
@@ -1266,7 +1268,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const unsigned chunk = (G & (GC - 1u)) * 2u + part, grp = G >> (L2 - 5);
     const unsigned lfull = chunk * 16 + l;
     const unsigned toff = ((unsigned)hx << L2) | lfull; // user side: thread (hx = r4..r0 after the transpose, l)
-    const unsigned toff2 = (chunk << 9) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l; // scratch side: r = hx << 5 | q
+    const unsigned toff2 = ROWS ? (((unsigned)hx << (5 + L2)) | lfull)
+                                : ((chunk << 9) | (((unsigned)hx & 1u) << 8) | (((unsigned)hx >> 1) << 4) | (unsigned)l); // scratch side: r = hx << 5 | q
     const u32 *const twu = tw2d + ((size_t)chunk << 14); // [chunk][r = hx << 5 | q][l]
     const unsigned twoff = ((unsigned)hx << 9) + (unsigned)l;
     // round 2 (regs = r9..r5, thread = r4..r0 = hx): STAGE 5 + b on reg bit b, twiddle index (jj << 5) | hx; DIT packing; frame invariant
@@ -1301,7 +1304,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         u32 v[32], tw[32];
         const gptr_t<const u32> twq = at32(twu, twoff_l);
 #pragma unroll
-        for (int q = 0; q < 32; ++q) v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
+        for (int q = 0; q < 32; ++q) {
+            if constexpr (ROWS) v[q] = *at32(src + ((size_t)q << L2), toff2_l);
+            else v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
+        }
 #pragma unroll
         for (int q = 0; q < 32; ++q) tw[q] = twq[16 * q]; // one SGPR base + thread offset, 64-byte steps in the immediate
         // T = V conj(W): T.re = V.re wr + V.im wi, T.im = V.im wr - V.re wi = the DIT butterfly's multiplier with Wc = (wr, wi) -- the table
@@ -1521,6 +1527,44 @@ hipError_t launch_fused2d_inv(int twd, const u32 *pin, u32 *pout, u32 *scr, cons
         hipLaunchKernelGGL((k_big2x_qb<20, false>), dim3(gb), dim3(512), ldsb, stream, pin, scr, tw1k, c, nframes, sl);
         hipLaunchKernelGGL((k_big2x_ci<false>), dim3(64u * groups), dim3(512), ldsa, stream, scr, pout, tw1k, c, tw2d, nframes, groups, sl, halves);
     }
+    return hipGetLastError();
+}
+
+// N = 2^22 .. 2^24 inverse, last of three launches: the conj multiplier + the 1024-point column cores on the plain rows [r][n2] an N2-point inverse sub-plan left
+hipError_t launch_fused2d_inv_cols(int l2, int twd, const u32 *rows, u32 *pout, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
+                                   hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts cc;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) { // DIT packing: Wc = (wr, wi), Wd = (-wi, wr)
+        const int2 w = h_tw1k[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)w.y << 16);
+        wb = ((u32)(-w.y) & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, cc.wa4[i], cc.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, cc.wa3[i], cc.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, cc.wa2[i], cc.wb2[i]);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsa = (size_t)1024 * ROWX * sizeof(u32);
+    const unsigned chunks = 1u << (l2 - 4);
+    const unsigned groups = (unsigned)std::max<size_t>(1, std::min<size_t>(nframes, (size_t)4096 / chunks));
+#define INTFFT_CI_ROWS(LL, FX)                                                                                                                  \
+    {                                                                                                                                           \
+        allow_max_lds(kptr(k_big2x_ci<FX, LL, true>));                                                                                          \
+        hipLaunchKernelGGL((k_big2x_ci<FX, LL, true>), dim3(chunks * groups), dim3(512), ldsa, stream, rows, pout, tw1k, cc, tw2d, nframes, groups, sl, halves); \
+    }
+    if (l2 == 11) {
+        if (fx) INTFFT_CI_ROWS(11, true) else INTFFT_CI_ROWS(11, false)
+    } else if (l2 == 12) {
+        if (fx) INTFFT_CI_ROWS(12, true) else INTFFT_CI_ROWS(12, false)
+    } else if (l2 == 13) {
+        if (fx) INTFFT_CI_ROWS(13, true) else INTFFT_CI_ROWS(13, false)
+    } else if (l2 == 14) {
+        if (fx) INTFFT_CI_ROWS(14, true) else INTFFT_CI_ROWS(14, false)
+    } else return hipErrorInvalidValue;
+#undef INTFFT_CI_ROWS
     return hipGetLastError();
 }
 

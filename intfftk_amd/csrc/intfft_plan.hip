@@ -122,7 +122,8 @@ struct intfft_plan {
     int fused2d = 0;                  // 2: N = 2^20 = 1024 x 1024, 16-bit scaled-truncate forward in two launches (k_big2x_c + k_big2x_b); 3: N = 2^21 .. 2^24 as
                                       // 1024 x N2: k_big2x_c, the row sub-plan, one layout change; 4: N = 2^20 inverse in two launches (k_big2x_qb + k_big2x_ci);
                                       // 5: N = 2^20 pair = the forward two launches, then the inverse two; 6 (round 5): N = 2^21 inverse in two launches
-                                      // (k_rows2k_qtr + k_big2x_ci<., 11>); 7: N = 2^21 pair = k_big2x_c<11> + k_rows2k_tr, then form 6's two launches
+                                      // (k_rows2k_qtr + k_big2x_ci<., 11>); 7: N = 2^21 pair = k_big2x_c<11> + k_rows2k_tr, then form 6's two launches;
+                                      // 9 (round 5): N = 2^22 .. 2^24 inverse as one layout change, the N2-point row sub-plan, k_big2x_ci<., L2, ROWS>
     uint2 *d_tw16r = nullptr, *d_tw16ri = nullptr; // fused2d == 3 at N2 = 2048, natural order out (round 5): the row core's packed tables for k_rows2k_tr
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
     size_t buf2d_frames = 0;
@@ -846,8 +847,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         // ... and the inverse (4): the row cores as pass QB, the conj multiplier + the column cores on pass QA's tiles (k_big2x_ci)
         const int inv2d = fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
         if (!pl->fused2d && inv2d && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 && pl->tw_i.sh_b == p->twdl_width - 1 && pl->sub_row_i && pl->sub_col_i &&
-            big2x_tables_ok(10, pl->sub_col_i->h_tw.data(), p->twdl_width) && big2x_tables_ok(l2, pl->sub_row_i->h_tw.data(), p->twdl_width))
-            pl->fused2d = inv2d == 2 ? 6 : 4; // 6 (round 5): N = 2^21, the 2048-point row cores in k_rows2k_qtr
+            big2x_tables_ok(10, pl->sub_col_i->h_tw.data(), p->twdl_width) && (inv2d == 3 || big2x_tables_ok(l2, pl->sub_row_i->h_tw.data(), p->twdl_width)))
+            pl->fused2d = inv2d == 2 ? 6 : inv2d == 3 ? 9 : 4; // 6 (round 5): N = 2^21, the 2048-point row cores in k_rows2k_qtr; 9: three launches
         // ... and the pair (5): the forward two launches into the second layout buffer, the inverse two launches from there
         if (!pl->fused2d && p->direction == INTFFT_PAIR && !diag_env("INTFFT_2D_NO_FUSED_CORES") && pl->sub_col_f && pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
             fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 2 &&
@@ -864,12 +865,12 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width) &&
             big2x_tables_ok(11, pl->sub_row_f->h_tw.data(), p->twdl_width))
             pl->fused2d = 7;
-        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : pl->fused2d == 6 ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
+        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : (pl->fused2d == 6 || pl->fused2d == 9) ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
             // the fused launches run none of the 1-D sub-plans except form 3's rows, and forms 2 / 4 need one layout buffer only:
             // keep the core whose twiddle tables the tile kernels read (core1k), release the rest
             auto drop = [&](intfft_plan **sp) {
-                if (*sp && *sp != core1k && !((pl->fused2d == 3 || pl->fused2d == 7) && *sp == pl->sub_row_f) && !(pl->fused2d == 6 && *sp == pl->sub_row_i)) {
+                if (*sp && *sp != core1k && !((pl->fused2d == 3 || pl->fused2d == 7) && *sp == pl->sub_row_f) && !((pl->fused2d == 6 || pl->fused2d == 9) && *sp == pl->sub_row_i)) {
                     intfft_plan_destroy(*sp);
                     *sp = nullptr;
                 }
@@ -918,6 +919,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
             else if (pl->fused2d == 6) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_big2x_ci]");
+            else if (pl->fused2d == 9) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[%.24s|k_big2x_ci]", pl->sub_row_i->kernel_name);
             else if (pl->fused2d == 7) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr|k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
             else if (pl->d_tw16r) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr]");
@@ -1323,6 +1325,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6) info->n_passes = 2;
         if (plan->fused2d == 5 || plan->fused2d == 7) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
+        if (plan->fused2d == 9 && intfft_plan_get_info(plan->sub_row_i, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
         info->fast_path = 0;
         // the whole device footprint of the plan beyond its twiddle tables: the two layout buffers AND the sub-plans' own scratch
@@ -1356,7 +1359,7 @@ static bool dual_2d(const intfft_plan *pl)
     // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
     // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
     return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r)) &&
-           pl->fused2d != 6 && pl->fused2d != 7;
+           (pl->fused2d != 9 || pl->sub_row_i->scratch_bytes == 0) && pl->fused2d != 6 && pl->fused2d != 7;
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1373,6 +1376,7 @@ static size_t ws_need(const intfft_plan *pl, size_t batch)
         size_t sub = 0;
         const int l1 = pl->l1, l2 = pl->L - pl->l1;
         if (pl->fused2d == 3) sub = ws_need(pl->sub_row_f, bf << l1);
+        else if (pl->fused2d == 9) sub = ws_need(pl->sub_row_i, bf << l1);
         else if (!pl->fused2d) {
             if (pl->sub_col_f) sub = std::max(sub, ws_need(pl->sub_col_f, bf << l2));
             if (pl->sub_row_f) sub = std::max(sub, ws_need(pl->sub_row_f, bf << l1));
@@ -1431,6 +1435,16 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                            p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 9) { // the inverse beyond N = 2^21: X -> rows [r][k2] (k1 = brev10(r)), the N2-point inverse sub-plan, conj multiplier + column cores
+                char *b1 = static_cast<char *>(buf1) + off;
+                for (int j = 0; j < L; ++j) perm[j < l1 ? l2 + (l1 - 1 - j) : j - l1] = order_mem_bit(p.in_order, L, j);
+                e = launch_bitperm(L, pl->in_cb, perm, src, b0, nf, st);
+                if (e != hipSuccess) break;
+                if ((rc = exec_core(pl->sub_row_i, b0, b1, nf << l1, st, subws)) != INTFFT_OK) break;
+                e = launch_fused2d_inv_cols(l2, p.twdl_width, reinterpret_cast<const uint32_t *>(b1), reinterpret_cast<uint32_t *>(dst), pl->d_tw16f,
+                                            pl->sub_col_i->h_tw.data(), pl->d_tw2d_tiles, nf, p.out_order == INTFFT_ORDER_HALVES, st);
                 continue;
             }
             if (pl->fused2d == 7) { // the pair at N = 2^21: X in natural order in the second layout buffer between the two directions

@@ -322,3 +322,27 @@ def test_2d_1024_by_n2_three_launches(log2n, frames, out_order, monkeypatch):
     assert np.array_equal(got[sel], want)
     if frames <= 3 and log2n <= 22:
         check(x[:1], log2n, 10, 16, 16, 0, 0, True, in_order="HALVES", out_order=out_order)
+
+
+@pytest.mark.parametrize("log2n,frames,out_order", [(22, 2, "NATURAL"), (22, 18, "HALVES"), (23, 1, "NATURAL"), (21, 3, "NATURAL")])
+def test_2d_1024_by_n2_inverse_three_launches(log2n, frames, out_order, monkeypatch):
+    """N = 2^22 .. 2^24 as 1024 x N2, 16-bit scaled-truncate INVERSE (round 5): one layout change (X[k1 + 1024 k2] -> rows [r][k2], k1 = brev10(r)), the N2-point
+    inverse row sub-plan, k_big2x_ci<., L2, ROWS> (conj multiplier + column cores reading plain rows) -- against the oracle and the five-launch composite
+    (INTFFT_2D_NO_FUSED_CORES); N = 2^21 takes this form when its two-launch kernels are switched off; a batch beyond one scratch chunk."""
+    n = 1 << log2n
+    x = uniform_frames(frames, n, 15, 988 + log2n)
+    x[0] = uniform_frames(1, n, 16, 7)[0]
+    if log2n == 21:
+        monkeypatch.setenv("INTFFT_2D_NO_ROWS2K", "1")
+    got, info = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, "INV", out_order=out_order)
+    assert info["kernel_name"].startswith("2d[") and info["kernel_name"].endswith("|k_big2x_ci]") and "rows2k" not in info["kernel_name"], info
+    assert info["n_passes"] == 3, info  # (the 2048- / 4096- / 8192-point inverse row cores are one launch each)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
+        got5, info5 = run_gpu(x, log2n, 10, 16, 16, 0, 0, True, "INV", out_order=out_order)
+        assert info5["n_passes"] >= 5, info5
+    assert np.array_equal(got, got5)
+    sel = [0, frames - 1] if frames > 1 else [0]
+    want = C.execute_2d(x[sel], C.make_params(log2n, 16, 16, 0, 0, True), 10, C.INV, C.NATURAL, ORD[out_order], form=1)
+    assert np.array_equal(got[sel], want)
+

@@ -73,6 +73,9 @@ for L in (17, 18, 19):
     ROWS.append(("%d:16:16:0:1" % L, "16-bit scaled-round FWD"))
 ROWS.append(("18:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("23:16:16:0:0:FWD:10", "16-bit scaled-trunc FWD, 2-D scheme 2^10 x 2^13"))
+ROWS.append(("22:16:16:0:0:FWD:10", "16-bit scaled-trunc FWD, 2-D scheme 2^10 x 2^12"))
+ROWS.append(("22:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^12 (three launches, round 5)"))
+ROWS.append(("23:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^13 (three launches, round 5)"))
 for L in (13, 14, 16):
     ROWS.append(("%d:24:24:1:0:INV" % L, "24-bit unscaled INV (40-bit results)"))
 ROWS.append(("16:24:16:1:0:INV", "24-bit data / 16-bit twiddle unscaled INV"))

@@ -17,6 +17,7 @@
 #                       intfft_device.hpp) as build/variants/libintfft_at32chk.so (build it HERE first: tools/evidence.sh <tag> at32build), then the parity
 #                       suites on that library
 #   tilebench           build/tilebench (tools/tilebench.hip) at 64 and 256 frames
+#   collect             (run HERE, after gpurun merged gpurun_out/) copy the outputs of `all` into profiles/ under the names profiles/README.md lists
 #   all                 headline digests configs matrix bench suite
 set -u
 TAG=${1:?round tag}; PART=${2:-all}; shift; shift || true
@@ -42,6 +43,20 @@ part_bench() {
   tail -c 400 gpurun_out/${TAG}_bench_default.json; echo
   : > gpurun_out/${TAG}_other_configs_bench.jsonl
   for c in C3 C4 C5; do python bench.py --config $c --no-cpu-baseline 2> gpurun_out/${TAG}_bench_$c.err >> gpurun_out/${TAG}_other_configs_bench.jsonl; done
+}
+# collect: run HERE after the gpurun call -- what gpurun merged into gpurun_out/ goes to profiles/ under the names profiles/README.md lists
+part_collect() {
+  local P=profiles G=gpurun_out
+  cp $G/prof_$TAG/kernel_stats.csv $P/${TAG}_kernel_stats.csv
+  cp $G/prof_$TAG/digest.json $P/${TAG}_k_fft1024_pmc_digest.json
+  cp $G/prof_$TAG/summary.txt $P/${TAG}_k_fft1024_rocprofv3_summary.txt
+  declare -A nm=([C2]=C2 [C3]=C3 [C4]=C4 [C5]=C5 [20_16_16_0_0_FWD_10]=2d_n2pow20 [21_16_16_0_0_FWD_10]=2d_n2pow21 [21_16_16_0_0_INV_10]=2d_n2pow21_inv
+                 [14_16_16_0]=n2pow14_fwd [16_24_24_1_0_INV]=n2pow16_24bit_inv [19_16_16_0]=n2pow19_fwd [16_32_16_1]=n2pow16_32bit_fwd)
+  for k in "${!nm[@]}"; do [ -f $G/pmc_$TAG/${k}_pmc_digest.json ] && cp $G/pmc_$TAG/${k}_pmc_digest.json $P/${TAG}_${nm[$k]}_pmc_digest.json; done
+  cp $G/prof_cfg_$TAG/kernel_stats_compact.csv $P/${TAG}_other_configs_kernel_stats.csv
+  grep '^{' $G/prof_cfg_$TAG/bench.log > $P/${TAG}_other_configs_rates.jsonl
+  for f in coverage_matrix.md bench_default.json other_configs_bench.jsonl gpu_suite.txt; do cp $G/${TAG}_$f $P/${TAG}_$f; done
+  ls -la $P/${TAG}_* | wc -l
 }
 part_suite() { timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_suite.txt 2>&1; tail -3 gpurun_out/${TAG}_gpu_suite.txt; }
 part_calib() {
@@ -82,6 +97,6 @@ part_tilebench() {
 }
 case $PART in
   all) part_headline; part_digests; part_configs; part_matrix; part_bench; part_suite ;;
-  headline|digests|configs|matrix|bench|suite|calib|variants|tilebench|at32build|at32check) part_$PART "$@" ;;
+  headline|digests|configs|matrix|bench|suite|calib|variants|tilebench|at32build|at32check|collect) part_$PART "$@" ;;
   *) echo "unknown part $PART"; exit 2 ;;
 esac
