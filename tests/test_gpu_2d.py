@@ -181,8 +181,8 @@ def test_2d_n2pow20_inverse_two_launches(frames, monkeypatch):
 @pytest.mark.parametrize("frames", [3, 37])
 def test_2d_n2pow21_inverse_two_launches(frames, monkeypatch):
     """N = 2^21 = 1024 x 2048, 16-bit scaled-truncate INVERSE (round 5): k_rows2k_qtr (the 2048-point row cores, sixteen per workgroup, reading 64-byte
-    pieces of X[k1 + 1024 k2]) + k_big2x_ci<., 11> (conj multiplier + column cores) against the oracle and the five-launch composite plan
-    (INTFFT_2D_NO_ROWS2K); a full-scale frame, HALVES order out, 13-bit twiddles / XSER OLD, a batch beyond one scratch chunk."""
+    pieces of X[k1 + 1024 k2]) + k_big2x_ci<., 11> (conj multiplier + column cores) against the oracle, the five-launch composite plan
+    (INTFFT_2D_NO_FUSED_CORES) and the three-launch form (INTFFT_2D_NO_ROWS2K); a full-scale frame, HALVES order out, 13-bit twiddles / XSER OLD, a batch beyond one scratch chunk."""
     n = 1 << 21
     x = uniform_frames(frames, n, 15, 2777 + frames)
     x[0] = uniform_frames(1, n, 16, 17)[0]
@@ -192,11 +192,15 @@ def test_2d_n2pow21_inverse_two_launches(frames, monkeypatch):
         check(x[:2], 21, 10, 16, 16, 0, 0, True, "INV", "NATURAL", "HALVES")
         check(x[:1], 21, 10, 16, 13, 0, 0, False, "INV")
         with monkeypatch.context() as m:
-            m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+            m.setenv("INTFFT_2D_NO_FUSED_CORES", "1")
             got5, info5 = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
             assert info5["n_passes"] >= 4, info5
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_ROWS2K", "1")  # the three-launch form (test_2d_1024_by_n2_inverse_three_launches)
+            got3, info3 = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
+            assert info3["n_passes"] == 3, info3
         got2, _ = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
-        assert np.array_equal(got2, got5)
+        assert np.array_equal(got2, got5) and np.array_equal(got2, got3)
     else:
         got, info = run_gpu(x, 21, 10, 16, 16, 0, 0, True, "INV")
         assert info["n_passes"] == 2, info
