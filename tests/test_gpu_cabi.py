@@ -462,7 +462,11 @@ WS_CASES = [
     (20, 16, 16, 0, 0, "FWD", 0, 9, 8),     # two passes, two scratch halves on two streams: 2 frames per chunk
     (16, 24, 24, 1, 0, "FWD", 0, 21, 4),    # the 24-bit class (int32 -> int64), two streams
     (20, 16, 16, 0, 0, "FWD", 10, 7, 8),    # the tiled 2-D plan: two launches, two streams
-    (21, 16, 16, 0, 0, "FWD", 10, 3, 16),   # 2-D, three launches with a row sub-plan
+    (21, 16, 16, 0, 0, "FWD", 10, 3, 16),   # 2-D, two launches (k_rows2k_tr; one stream)
+    (22, 16, 16, 0, 0, "FWD", 10, 3, 32),   # 2-D, three launches with a row sub-plan
+    (21, 16, 16, 0, 0, "INV", 10, 3, 16),   # 2-D inverse, two launches (k_rows2k_qtr; round 5)
+    (21, 16, 16, 0, 0, "PAIR", 10, 3, 16),  # 2-D pair, four launches through the second layout buffer (round 5)
+    (22, 16, 16, 0, 0, "INV", 10, 3, 32),   # 2-D inverse, three launches with a row sub-plan (round 5)
     (14, 18, 16, 0, 0, "FWD", 6, 9, 1),     # composite 2-D plan on sub-plans
     (14, 18, 16, 0, 0, "PAIR", 0, 20, 1),   # composite pair: middle buffer + two sub-plans with scratch of their own
     (13, 32, 16, 1, 0, "INV", 0, 11, 1),    # the generic 64-bit passes
