@@ -663,6 +663,13 @@ GUARD_CASES = [
     (14, 24, 24, 1, 0, "INV", "BITREV", "HALVES", 5), (13, 32, 16, 1, 0, "FWD", "HALVES", "BITREV", 3), (15, 32, 16, 1, 0, "INV", "BITREV", "HALVES", 3),
     (14, 16, 16, 1, 0, "FWD", "HALVES", "BITREV", 5), (15, 18, 16, 0, 0, "INV", "BITREV", "HALVES", 3), (13, 12, 16, 0, 1, "FWD", "HALVES", "NATURAL", 9),
     (19, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 3),
+    # ... the cores' own orders on the 64-bit wave / block kernels (N = 2048: the absent second frame of the last workgroup; N < 1024: absent frames of the last wave)
+    (10, 32, 16, 1, 0, "FWD", "HALVES", "BITREV", 7), (10, 40, 16, 0, 0, "INV", "BITREV", "HALVES", 5), (12, 32, 16, 1, 0, "FWD", "HALVES", "BITREV", 3),
+    (11, 32, 16, 1, 0, "INV", "BITREV", "HALVES", 3), (11, 40, 16, 0, 0, "FWD", "HALVES", "BITREV", 5), (8, 32, 16, 1, 0, "FWD", "HALVES", "BITREV", 13),
+    (9, 32, 16, 1, 0, "INV", "BITREV", "HALVES", 5),
+    # ... and the 2-D plans of round 5 (a tenth field: log2 N1): the inverse and the pair at N = 2^21, the three-launch inverse at N = 2^22
+    (21, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1, 10), (21, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 1, 10), (22, 16, 16, 0, 0, "INV", "NATURAL", "HALVES", 1, 10),
+    (21, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 10),
 ]
 
 
@@ -677,10 +684,11 @@ def test_no_writes_outside_the_output_buffer(case, shift_samples):
 
     from intfftk_amd import IntFFTCore
 
-    log2n, dw, tw, fmt, rnd, direction, in_o, out_o, batch = case
-    if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, True), {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]) != 0:
+    log2n, dw, tw, fmt, rnd, direction, in_o, out_o, batch = case[:9]
+    l1 = case[9] if len(case) > 9 else 0
+    if not l1 and C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, True), {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]) != 0:
         pytest.skip("not elaboratable")
-    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o)
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o, NFFT1=l1)
     n = 1 << log2n
     x = uniform_frames(batch, n, dw, 7700 + log2n + dw)
     xin = torch.from_numpy(np.ascontiguousarray(x.astype({2: np.int16, 4: np.int32, 8: np.int64}[core.in_container])))
@@ -699,7 +707,8 @@ def test_no_writes_outside_the_output_buffer(case, shift_samples):
     got = obuf[go:go + out_bytes].clone().view(core.out_dtype).reshape(core.out_shape(batch)).cpu().numpy().astype(np.int64)
     p = C.make_params(log2n, dw, tw, fmt, rnd, True)
     om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
-    want = C.execute(x, p, {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction], om[in_o], om[out_o], form=1)
+    d = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
+    want = C.execute_2d(x, p, l1, d, om[in_o], om[out_o], form=1) if l1 else C.execute(x, p, d, om[in_o], om[out_o], form=1)
     assert np.array_equal(got, want), info
     core.close()
 
