@@ -579,7 +579,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //            (r6, r6 ^ 32: the two halves of every output line) one after the other, as k_big2x_b does
 // (int_fftNk.vhd:184-342 for the 2048-point core; the scheme itself is this library's extension).  tools/tilebench.hip: this tile
 // shape copies at 3.9-4.0 TB/s; the row sub-plan + layout change it replaces take 174 us per 2^25 samples.
-template <bool FAST_OK>
+// L1 = log2 N1 (the column length; 11: the 2048 x 2048 plan, round 5): the tile's rows are rho = k << (L1 - 4) | r, r of L1 - 4 bits
+template <bool FAST_OK, int L1 = 10>
 __global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, const uint2 *__restrict__ twf, const Round5Consts c, size_t nframes, const Slice sl)
 {
     extern __shared__ u32 lds[]; // 1024 rows x ROWY
@@ -597,7 +598,8 @@ __global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, con
     const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
     const u32 *const rd_base = lds + ROWY * ((jj << 4) | krow);
     const unsigned rjj = __brev((unsigned)jj) >> 26;
-    const unsigned toff2 = (rjj << 10) | (unsigned)kb;
+    constexpr int RR = L1 - 5; // tiles per frame and partner: 2^RR
+    const unsigned toff2 = (rjj << L1) | (unsigned)kb;
     const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
     const v2s sh5 = {s5, s5};
     const v2s none = {0, 0};
@@ -609,11 +611,11 @@ __global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, con
     // L2-resident table per tile so that the two register sets (next tile's inputs, this tile's round-2 values) fit 128 VGPRs.
     size_t t = blockIdx.x;
     unsigned part = 0;
-    bool have = (t >> 5) < nframes;
+    bool have = (t >> RR) < nframes;
     u32 v[32];
     auto load_tile = [&](size_t tt, unsigned pp) {
-        const unsigned r6 = (pp << 5) | ((unsigned)tt & 31u);
-        const u32 *src = in + ((tt >> 5) << 21) + ((size_t)(((unsigned)k << 6) | r6) << 11); // wave-uniform: this wave's row
+        const unsigned r6 = (pp << RR) | ((unsigned)tt & ((1u << RR) - 1u));
+        const u32 *src = in + ((tt >> RR) << (L1 + 11)) + ((size_t)(((unsigned)k << (L1 - 4)) | r6) << 11); // wave-uniform: this wave's row
         unsigned lane_l = (unsigned)lane;
         asm volatile("" : "+v"(lane_l));
 #pragma unroll
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, con
         const unsigned cpart = part;
         if (part == 0) part = 1;
         else part = 0, t += gridDim.x;
-        const bool have_next = (t >> 5) < nframes;
+        const bool have_next = (t >> RR) < nframes;
         u32 wa16[8], wb16[8];
         RoundTwQ t1;
         {
@@ -678,12 +680,154 @@ __global__ __launch_bounds__(1024) void k_rows2k_tr(const u32 *in, u32 *out, con
         for (int q = 0; q < 32; ++q) w[q] = rd_base[q];
         if (fast) dif_round5_c<FAST_OK>(w, c, sl, sh5);
         else dif_round5_c<false>(w, c, sl, sh5);
-        const unsigned r6 = (cpart << 5) | ((unsigned)ct & 31u);
-        u32 *dst = out + ((ct >> 5) << 21) + ((__brev(r6) >> 26) << 4);
+        const unsigned r6 = (cpart << RR) | ((unsigned)ct & ((1u << RR) - 1u));
+        u32 *dst = out + ((ct >> RR) << (L1 + 11)) + ((__brev(r6) >> (36 - L1)) << 4);
         unsigned toff2_l = toff2;
         asm volatile("" : "+v"(toff2_l));
 #pragma unroll
-        for (int q = 0; q < 32; ++q) INTFFT_2XB_ST(w[q], at32(dst + ((size_t)rev5c(q) << 16), toff2_l));
+        for (int q = 0; q < 32; ++q) INTFFT_2XB_ST(w[q], at32(dst + ((size_t)rev5c(q) << (L1 + 6)), toff2_l));
+        have = have_next;
+    }
+}
+
+// ---- the 2-D scheme at N = 2^22 = 2048 x 2048 in TWO launches (round 5): k_cols2k_c + k_rows2k_tr<., 11> --------------------------------------------
+// The column cores (2048-point int_fftNk over n1 for every n2) + the multiplier on tiles of 2048 rows x 16 columns (128 KiB: one 1024-thread workgroup per CU),
+// k_rows2k_tr's register rounds on k_big2x_c's tile:
+//   round 1  wave = n3..n0, lane = (n5, n4, column kb), regs j = n10..n6: every load instruction reads four 64-byte pieces (the XCD partner block b ^ 8 takes the
+//            other half of every line at the same time; non-temporal loads: 248 against 226 Gsample/s with plain ones); STAGE 10..6 on per-thread twiddles (index (j << 6) | n5..n0, re-read per tile), then
+//            v_permlane32_swap (register bit 4 <-> lane bit 5: n10 <-> n5) and STAGE 5
+//   LDS      row (n10..n5) << 4 | kb, column n4..n0 (33 dwords apart); the next tile's loads go out behind the writes
+//   round 2  thread = (jj = n10..n5, kb), regs q = n4..n0: STAGE 4..0 on wave-uniform twiddles; position rho = jj << 5 | q holds A[k1 = brev11(rho)][n2]
+//   multiply by W_N^(k1 n2) (table [chunk][rho][16] of (wr | wi << 16), read eight entries at a time: beside the next tile's 32 values a second set of 32 would
+//            spill), plain results at [rho][n2] of the scratch: 64-byte pieces, the partner block fills the other half of the line
+template <bool FAST_OK>
+__global__ __launch_bounds__(1024) void k_cols2k_c(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, const Round5Consts c, const u32 *__restrict__ tw2d, size_t nframes,
+                                                   const Slice sl)
+{
+    extern __shared__ u32 lds[]; // 1024 rows x ROWY
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // n3..n0 of round 1
+    const unsigned t6 = (((unsigned)lane >> 4) << 4) | (unsigned)wv; // n5..n0 of round 1
+    u32 wa5[4], wb5[4];
+    {
+        const uint2 w = twf[31u + (t6 & 31u)]; // STAGE 5: index n4..n0
+        wa5[0] = wa5[1] = wa5[2] = wa5[3] = w.x;
+        wb5[0] = wb5[1] = wb5[2] = wb5[3] = w.y;
+    }
+    // transpose, write side: element (register r = (n5, n9..n6), lane = (n10, n4, kb), wave n3..n0) -> row ((n10, n9..n6, n5) << 4) | kb, column n4..n0
+    u32 *const wr_base = lds + ROWY * ((((lane >> 5) << 5) << 4) | (lane & 15)) + ((((lane >> 4) & 1) << 4) | wv);
+    const int jj = tid >> 4, kb = tid & 15;
+    const u32 *const rd_base = lds + ROWY * ((jj << 4) | kb);
+    const short s5 = (short)(1 - (jj & 1)); // round 2: kind = n5
+    const v2s sh5 = {s5, s5};
+    const v2s none = {0, 0};
+    const unsigned loff = (((unsigned)lane >> 4) << 15) | ((unsigned)lane & 15u); // user side (round 1): rows n5 n4 (x 2048 samples), column kb
+    const unsigned soff = ((unsigned)jj << 16) | (unsigned)kb;                    // scratch side (round 2): row jj << 5 (+ q), column kb
+    const unsigned twoff = ((unsigned)jj << 9) + (unsigned)kb;                    // table: [rho = jj << 5 | q][kb]
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+    size_t t = blockIdx.x;
+    auto tile_of = [&](size_t tt) { return (tt >> 4) * 8u + slot; }; // G: frame = G >> 6, chunk = (G & 63) * 2 + part
+    bool have = (tile_of(t) >> 6) < nframes;
+    u32 v[32];
+    auto load_tile = [&](size_t G) {
+        const unsigned chunk = ((unsigned)G & 63u) * 2u + part;
+        const u32 *src = in + ((G >> 6) << 22) + ((size_t)wv << 11) + chunk * 16u; // wave-uniform
+        unsigned lo = loff;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << 17), lo)); // regs = n10..n6
+    };
+    if (have) load_tile(tile_of(t));
+    while (have) {
+        const size_t ct = tile_of(t);
+        t += gridDim.x;
+        const size_t nt = tile_of(t);
+        const bool have_next = (nt >> 6) < nframes;
+        const unsigned chunk = ((unsigned)ct & 63u) * 2u + part;
+        u32 wa16[8], wb16[8];
+        RoundTwQ t1;
+        {
+            unsigned lb = t6 * 8u; // the thread's byte offset into a stage table, opaque per tile
+            asm volatile("" : "+v"(lb));
+            auto ld = [&](unsigned idx, u32 &wa, u32 &wb) {
+                const uint2 w = ld2_at32b(twf + idx, lb);
+                wa = w.x;
+                wb = w.y;
+            };
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) ld(1023u + ((unsigned)j8 << 6), wa16[j8], wb16[j8]);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) ld(511u + ((unsigned)j4 << 6), t1.wa8[j4], t1.wb8[j4]);
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) ld(255u + ((unsigned)j2 << 6), t1.wa4[j2], t1.wb4[j2]);
+            ld(127u, t1.wa2[0], t1.wb2[0]);
+            ld(63u, t1.wa1[0], t1.wb1[0]);
+        }
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc |= v[j] + sl.gbias;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
+        }
+#define INTFFT_C2K_ROUND1(FX)                                                                                                                  \
+    {                                                                                                                                          \
+        dif_top16<FX, 0, false>(v, wa16, wb16, sl, none);                                                                                      \
+        dif_round_q<FX, 0, 0, false>(v, t1, sl, none);                                                                                         \
+        dif_round_q<FX, 16, 0xF, false>(v, t1, sl, none);                                                                                      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&v[0]));                                                                                      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&v[16]));                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) swap32(v[j], v[j + 16]); /* register bit 4: n10 -> n5 */                                \
+        _Pragma("unroll") for (int j = 0; j < 16; j += 4)                                                                                      \
+            group4<false, FX, false, true, false, 0xA>(v[j], v[j + 16], v[j + 1], v[j + 17], v[j + 2], v[j + 18], v[j + 3], v[j + 19], wa5, wb5, sl); \
+    }
+        if (fast) INTFFT_C2K_ROUND1(FAST_OK)
+        else INTFFT_C2K_ROUND1(false)
+#undef INTFFT_C2K_ROUND1
+#pragma unroll
+        for (int r = 0; r < 32; ++r) wr_base[ROWY * ((((r & 15) << 1) | (r >> 4)) << 4)] = v[r];
+        asm volatile("" ::: "memory");
+        if (have_next) load_tile(nt); // flies during round 2, the multiplier and the stores below
+        __syncthreads();
+        u32 w[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w[q] = rd_base[q];
+        if (fast) dif_round5_c<FAST_OK>(w, c, sl, sh5);
+        else dif_round5_c<false>(w, c, sl, sh5);
+        // B = cmult(A, W_N^(k1 n2)): Wa = (wr, -wi), Wb = (wi, wr) from the packed entry; exact extraction (the row cores take the full Y)
+        const u32 *const twu = tw2d + ((size_t)chunk << 15); // [chunk][rho][kb]
+        unsigned two = twoff;
+        asm volatile("" : "+v"(two));
+        const gptr_t<const u32> twq = at32(twu, two);
+        const v2s pm = {1, -1};
+#pragma unroll
+        for (int q0 = 0; q0 < 32; q0 += 8) {
+            u32 tw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tw[i] = twq[16 * (q0 + i)];
+#pragma unroll
+            for (int q = 0; q < 8; q += 4) {
+                u32 wa[4], wb[4], y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wa[i] = as_u32(as_v2s(tw[q + i]) * pm);
+                    wb[i] = __builtin_amdgcn_alignbit(tw[q + i], tw[q + i], 16);
+                }
+                mul2x<16, false>(w[q0 + q], w[q0 + q], wa[0], wb[0], w[q0 + q + 1], w[q0 + q + 1], wa[1], wb[1], sl.off_y, sl.sel, y[0], y[1], sl.wd);
+                mul2x<16, false>(w[q0 + q + 2], w[q0 + q + 2], wa[2], wb[2], w[q0 + q + 3], w[q0 + q + 3], wa[3], wb[3], sl.off_y, sl.sel, y[2], y[3], sl.wd);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[q0 + q + i] = y[i];
+            }
+        }
+        u32 *dst = scr + ((ct >> 6) << 22) + chunk * 16u; // wave-uniform
+        unsigned so = soff;
+        asm volatile("" : "+v"(so));
+#pragma unroll
+        for (int q = 0; q < 32; ++q) *at32(dst + ((size_t)q << 11), so) = w[q];
         have = have_next;
     }
 }
@@ -1104,11 +1248,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // the table of k_big2x_c: entry [chunk][rho][l] = W_N^(k1 n2), k1 = brev10(rho), n2 = 16 chunk + l, as (wr | wi << 16)
-__global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int L, int twd)
+__global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int L, int twd, int l1)
 {
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; // < 2^L
-    const unsigned chunk = idx >> 14, rho = (idx >> 4) & 1023u, l = idx & 15u;
-    const unsigned k1 = __brev(rho) >> 22, n2 = chunk * 16 + l;
+    const unsigned chunk = idx >> (l1 + 4), rho = (idx >> 4) & ((1u << l1) - 1u), l = idx & 15u;
+    const unsigned k1 = __brev(rho) >> (32 - l1), n2 = chunk * 16 + l;
     int re, im;
     tw2d_eval(L, twd, (k1 * n2) & ((1u << L) - 1u), re, im);
     out[idx] = ((u32)re & 0xFFFFu) | ((u32)im << 16);
@@ -1118,6 +1262,10 @@ __global__ void k_build_tw2d_tiles(u32 *__restrict__ out, int L, int twd)
 // sub-plan, one layout change; any output order)
 int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
 {
+    // 8 (round 5): N = 2^22 = 2048 x 2048 in two launches (k_cols2k_c + k_rows2k_tr<., 11>), natural order in and out
+    if (l1 == 11 && log2n == 22 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 0 && in_order == 0 &&
+        out_order == 0 && !diag_env("INTFFT_2D_NO_FUSED_CORES") && !diag_env("INTFFT_2D_NO_ROWS2K"))
+        return 8;
     if (!(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 0 &&
           (in_order == 0 || in_order == 2)) || diag_env("INTFFT_2D_NO_FUSED_CORES"))
         return 0;
@@ -1133,9 +1281,9 @@ int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int
            (out_order == 0 || out_order == 2) && !diag_env("INTFFT_2D_NO_FUSED_CORES"));
 }
 
-hipError_t build_fused2d_table(u32 *d_table, int log2n, int twd, hipStream_t stream)
+hipError_t build_fused2d_table(u32 *d_table, int log2n, int twd, hipStream_t stream, int l1)
 {
-    hipLaunchKernelGGL(k_build_tw2d_tiles, dim3(1u << (log2n - 8)), dim3(256), 0, stream, d_table, log2n, twd);
+    hipLaunchKernelGGL(k_build_tw2d_tiles, dim3(1u << (log2n - 8)), dim3(256), 0, stream, d_table, log2n, twd, l1);
     return hipGetLastError();
 }
 
@@ -1217,6 +1365,42 @@ hipError_t launch_fused2d_rows2k(int twd, const u32 *prod, u32 *pout, const uint
     }
     return hipGetLastError();
 }
+
+// N = 2^22: the 2048-point column cores + multiplier (k_cols2k_c), then the 2048-point row cores + the store of X[k1 + 2048 k2] (k_rows2k_tr<., 11>)
+hipError_t launch_fused2d_2k2k(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16r, const int2 *h_tw, const u32 *tw2d, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) {
+        const int2 w = h_tw[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)(-w.y) << 16);
+        wb = ((u32)w.y & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsb = (size_t)1024 * ROWY * sizeof(u32);
+    const size_t ctiles = nframes << 7, cap16 = (size_t)device_cus() / 16 * 16; // 128 column chunks per frame, XCD-paired: the grid is a multiple of 16
+    const unsigned gc = (unsigned)std::min(ctiles, cap16);
+    const size_t pairs = nframes << 6, cap = (size_t)device_cus();
+    const unsigned gr = (unsigned)(pairs < cap ? pairs : cap);
+    if (fx) {
+        allow_max_lds(kptr(k_cols2k_c<true>));
+        allow_max_lds(kptr(k_rows2k_tr<true, 11>));
+        hipLaunchKernelGGL((k_cols2k_c<true>), dim3(gc), dim3(1024), ldsb, stream, pin, scr, tw16r, c, tw2d, nframes, sl);
+        hipLaunchKernelGGL((k_rows2k_tr<true, 11>), dim3(gr), dim3(1024), ldsb, stream, scr, pout, tw16r, c, nframes, sl);
+    } else {
+        allow_max_lds(kptr(k_cols2k_c<false>));
+        allow_max_lds(kptr(k_rows2k_tr<false, 11>));
+        hipLaunchKernelGGL((k_cols2k_c<false>), dim3(gc), dim3(1024), ldsb, stream, pin, scr, tw16r, c, tw2d, nframes, sl);
+        hipLaunchKernelGGL((k_rows2k_tr<false, 11>), dim3(gr), dim3(1024), ldsb, stream, scr, pout, tw16r, c, nframes, sl);
+    }
+    return hipGetLastError();
+}
+
 
 hipError_t launch_fused2d(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw1k, const int2 *h_tw1k, const u32 *tw2d, size_t nframes, int halves,
                           hipStream_t stream)
@@ -1305,7 +1489,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const gptr_t<const u32> twq = at32(twu, twoff_l);
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
-            if constexpr (ROWS) v[q] = *at32(src + ((size_t)q << L2), toff2_l);
+            if constexpr (ROWS) v[q] = *at32(src + ((size_t)q << L2), toff2_l); // (plain: 190 against 176 Gsample/s at N = 2^22 with non-temporal loads)
             else v[q] = INTFFT_LD(at32(src + ((size_t)q << (L - 5)), toff2_l));
         }
 #pragma unroll
@@ -1408,7 +1592,8 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
     unsigned vote_phase = 0;
     block_any_init(vote_flags);
     // XCD-paired tiles: blocks b and b + 8 (same XCD: b & 7) take the two r6 partners (r6, r6 ^ 32) = the two 64-byte halves of every line of X at
-    // the same time, with plain loads, so that the half a block does not use is an L2 hit for its partner (the grid is a multiple of 16)
+    // the same time, so that the half a block does not use is an L2 hit for its partner (the grid is a multiple of 16).  One block taking both partners
+    // one after the other: 251 Gsample/s; paired, plain loads: 264; paired, non-temporal loads: 273
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
     size_t t = blockIdx.x;
     auto tile_of = [&](size_t tt) { return (tt >> 4) * 8u + slot; }; // G: frame = G >> 5, r6 = part << 5 | (G & 31)
@@ -1420,7 +1605,7 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
         unsigned toff2_l = toff2;
         asm volatile("" : "+v"(toff2_l));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q0 + q] = *at32(src + ((size_t)rev5c(q0 + q) << 16), toff2_l); // position (jj << 5 | q) = X[k1 + 1024 brev11]
+        for (int q = 0; q < 16; ++q) v[q0 + q] = INTFFT_LD(at32(src + ((size_t)rev5c(q0 + q) << 16), toff2_l)); // position (jj << 5 | q) = X[k1 + 1024 brev11]
     };
     if (have) load_tile(tile_of(t), 0), load_tile(tile_of(t), 16);
     while (have) {

@@ -123,6 +123,7 @@ struct intfft_plan {
                                       // 1024 x N2: k_big2x_c, the row sub-plan, one layout change; 4: N = 2^20 inverse in two launches (k_big2x_qb + k_big2x_ci);
                                       // 5: N = 2^20 pair = the forward two launches, then the inverse two; 6 (round 5): N = 2^21 inverse in two launches
                                       // (k_rows2k_qtr + k_big2x_ci<., 11>); 7: N = 2^21 pair = k_big2x_c<11> + k_rows2k_tr, then form 6's two launches;
+                                      // 8 (round 5): N = 2^22 = 2048 x 2048 forward in two launches (k_cols2k_c + k_rows2k_tr<., 11>);
                                       // 9 (round 5): N = 2^22 .. 2^24 inverse as one layout change, the N2-point row sub-plan, k_big2x_ci<., L2, ROWS>
     uint2 *d_tw16r = nullptr, *d_tw16ri = nullptr; // fused2d == 3 at N2 = 2048, natural order out (round 5): the row core's packed tables for k_rows2k_tr
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
@@ -842,7 +843,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         // 1024 x 1024, packed 16-bit forward: both cores and the multiplier in two launches on the tiles of the N = 2^20 two-pass plan
         pl->fused2d = fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
         if (!(pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->sub_col_f && pl->sub_row_f &&
-              big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width)))
+              big2x_tables_ok(pl->fused2d == 8 ? 11 : 10, pl->sub_col_f->h_tw.data(), p->twdl_width)))
             pl->fused2d = 0;
         // ... and the inverse (4): the row cores as pass QB, the conj multiplier + the column cores on pass QA's tiles (k_big2x_ci)
         const int inv2d = fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
@@ -876,7 +877,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 }
             };
             drop(&pl->sub_col_f), drop(&pl->sub_row_f), drop(&pl->sub_row_i), drop(&pl->sub_col_i);
-            if (pl->fused2d == 2 || pl->fused2d == 4 || pl->fused2d == 6) {
+            if (pl->fused2d == 2 || pl->fused2d == 4 || pl->fused2d == 6 || pl->fused2d == 8) {
                 (void)hipFree(pl->buf2d[1]);
                 pl->buf2d[1] = nullptr;
                 pl->n2d_bufs = 1;
@@ -887,7 +888,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16i, (total + 1) * sizeof(uint2));
             if (e == hipSuccess) e = launch_pack_twiddles16(core1k->d_tw, total, pl->d_tw16f, pl->d_tw16i, nullptr);
             if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw2d_tiles, ((size_t)1 << pl->L) * sizeof(uint32_t));
-            if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, pl->L, p->twdl_width, nullptr);
+            if (e == hipSuccess) e = build_fused2d_table(pl->d_tw2d_tiles, pl->L, p->twdl_width, nullptr, l1);
             if (e == hipSuccess && pl->fused2d == 3 && l2 == 11 && p->out_order == INTFFT_ORDER_NATURAL && !diag_env("INTFFT_2D_NO_ROWS2K") &&
                 big2x_tables_ok(11, pl->sub_row_f->h_tw.data(), p->twdl_width)) {
                 // N = 2^21: the row cores and the store of X[k1 + 1024 k2] in ONE launch (k_rows2k_tr): two launches instead of three
@@ -895,6 +896,12 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
+            }
+            if (e == hipSuccess && pl->fused2d == 8) { // the 2048-point cores' packed table (columns and rows share it)
+                const size_t tot = ((size_t)1 << 11) - 1;
+                e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
+                if (e == hipSuccess) e = launch_pack_twiddles16(core1k->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
             }
             if (e == hipSuccess && (pl->fused2d == 6 || pl->fused2d == 7)) { // the 2048-point row core's packed table for k_rows2k_qtr (the pair: both row kernels)
                 const size_t tot = ((size_t)1 << 11) - 1;
@@ -919,6 +926,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             if (pl->fused2d == 2) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fused2d_kernel_name());
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
             else if (pl->fused2d == 6) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_big2x_ci]");
+            else if (pl->fused2d == 8) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_cols2k_c|k_rows2k_tr]");
             else if (pl->fused2d == 9) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[%.24s|k_big2x_ci]", pl->sub_row_i->kernel_name);
             else if (pl->fused2d == 7) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr|k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
@@ -1322,7 +1330,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
-        if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6) info->n_passes = 2;
+        if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6 || plan->fused2d == 8) info->n_passes = 2;
         if (plan->fused2d == 5 || plan->fused2d == 7) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
         if (plan->fused2d == 9 && intfft_plan_get_info(plan->sub_row_i, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
@@ -1359,7 +1367,7 @@ static bool dual_2d(const intfft_plan *pl)
     // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
     // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
     return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r)) &&
-           (pl->fused2d != 9 || pl->sub_row_i->scratch_bytes == 0) && pl->fused2d != 6 && pl->fused2d != 7;
+           (pl->fused2d != 9 || pl->sub_row_i->scratch_bytes == 0) && pl->fused2d != 6 && pl->fused2d != 7 && pl->fused2d != 8;
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1435,6 +1443,10 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                            p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 8) { // N = 2^22 = 2048 x 2048
+                e = launch_fused2d_2k2k(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16r, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, st);
                 continue;
             }
             if (pl->fused2d == 9) { // the inverse beyond N = 2^21: X -> rows [r][k2] (k1 = brev10(r)), the N2-point inverse sub-plan, conj multiplier + column cores

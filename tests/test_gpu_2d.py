@@ -73,7 +73,7 @@ def test_2d_lengths_beyond_the_native_cores(log2n, l1, frames, direction):
         got, info = run_gpu(x[:1], log2n, l1, 16, 16, 0, 0, True)
         # N1 = 1024: the column cores + multiplier run on tiles (k_big2x_c): two launches at N = 2^20, else column pass + row sub-plan + one
         # layout change; other splits: the five-launch composite
-        want = 2 if (log2n, l1) in ((20, 10), (21, 10)) else 3 if l1 == 10 else None  # (2^21: the row cores write X themselves since round 5)
+        want = 2 if (log2n, l1) in ((20, 10), (21, 10), (22, 11)) else 3 if l1 == 10 else None  # (2^21, 2^22 = 2048 x 2048: the row cores write X themselves since round 5)
         assert (info["n_passes"] == want if want else info["n_passes"] >= 4) and info["kernel_name"].startswith("2d["), info
         assert np.abs(to_complex(got) - np.fft.fft(to_complex(x[:1]), axis=1) / n).max() <= log2n + 2
 
@@ -349,4 +349,26 @@ def test_2d_1024_by_n2_inverse_three_launches(log2n, frames, out_order, monkeypa
     sel = [0, frames - 1] if frames > 1 else [0]
     want = C.execute_2d(x[sel], C.make_params(log2n, 16, 16, 0, 0, True), 10, C.INV, C.NATURAL, ORD[out_order], form=1)
     assert np.array_equal(got[sel], want)
+
+
+@pytest.mark.parametrize("frames", [2, 19])
+def test_2d_n2pow22_two_launches(frames, monkeypatch):
+    """N = 2^22 = 2048 x 2048, 16-bit scaled-truncate forward (round 5): k_cols2k_c (the 2048-point column cores + the multiplier on tiles of 2048 rows x 16
+    columns, one workgroup per CU) + k_rows2k_tr<., 11> (the row cores + the store of X[k1 + 2048 k2]) against the oracle and the five-launch composite
+    (INTFFT_2D_NO_ROWS2K); a full-scale frame, 13-bit twiddles / XSER OLD, a batch beyond one scratch chunk."""
+    n = 1 << 22
+    x = uniform_frames(frames, n, 15, 4777 + frames)
+    x[0] = uniform_frames(1, n, 16, 19)[0]
+    got, info = run_gpu(x, 22, 11, 16, 16, 0, 0, True)
+    assert info["kernel_name"] == "2d[k_cols2k_c|k_rows2k_tr]" and info["n_passes"] == 2, info
+    sel = [0, frames - 1]
+    want = C.execute_2d(x[sel], C.make_params(22, 16, 16, 0, 0, True), 11, C.FWD, C.NATURAL, C.NATURAL, form=1)
+    assert np.array_equal(got[sel], want)
+    with monkeypatch.context() as m:
+        m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+        got5, info5 = run_gpu(x, 22, 11, 16, 16, 0, 0, True)
+        assert info5["n_passes"] >= 4, info5
+    assert np.array_equal(got, got5)
+    if frames <= 2:
+        check(x[:1], 22, 11, 16, 13, 0, 0, False)
 
