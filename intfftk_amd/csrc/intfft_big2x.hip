@@ -1277,6 +1277,10 @@ int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int for
 // N2-point inverse sub-plan, k_big2x_ci<., L2, ROWS>; round 5; N = 2^21 only with INTFFT_2D_NO_ROWS2K)
 int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order)
 {
+    // 4 (round 5): N = 2^22 = 2048 x 2048 in two launches (k_rows2k_qtr<., 11, true> + k_cols2k_ci), natural order in and out
+    if (l1 == 11 && log2n == 22 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
+        out_order == 0 && !diag_env("INTFFT_2D_NO_FUSED_CORES") && !diag_env("INTFFT_2D_NO_ROWS2K"))
+        return 4;
     return (log2n == 20 ? 1 : log2n == 21 && !diag_env("INTFFT_2D_NO_ROWS2K") ? 2 : log2n >= 21 && log2n <= 24 ? 3 : 0) * (int)(l1 == 10 && data_width == 16 && twdl_width >= 8 && twdl_width <= 16 && format == 0 && rndmode == 0 && direction == 1 && in_order == 0 &&
            (out_order == 0 || out_order == 2) && !diag_env("INTFFT_2D_NO_FUSED_CORES"));
 }
@@ -1555,7 +1559,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //            instruction writes four 64-byte pieces; the 16 waves of the block complete 1 KiB runs
 // The next tile's 32 loads are issued right behind the transpose's LDS writes, as in k_rows2k_tr.  (int_ifftNk.vhd:183-341 for the 2048-point core; the
 // scheme itself is this library's extension)
-template <bool FAST_OK>
+// L1 = log2 N1 (11: the 2048 x 2048 plan); ROWS_OUT: plain rows V[r][n2] out (256 contiguous bytes per wave instruction) for k_cols2k_ci
+template <bool FAST_OK, int L1 = 10, bool ROWS_OUT = false>
 __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, const uint2 *__restrict__ twf, const Round5Consts c, size_t nframes, const Slice sl)
 {
     extern __shared__ u32 lds[]; // 1024 rows x ROWY, then round 2's per-lane twiddles (DIT packing): 16 slots x 64 lanes
@@ -1586,8 +1591,10 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
     const int krow = ((kb & 1) << 3) | ((kb & 2) << 1) | ((kb & 4) >> 1) | ((kb & 8) >> 3);
     u32 *const wr_base = lds + ROWY * ((jj << 4) | krow);
     const unsigned rjj = __brev((unsigned)jj) >> 26;
-    const unsigned toff2 = (rjj << 10) | (unsigned)kb;                                       // user side (round 1 thread)
-    const unsigned toff = (((unsigned)lane >> 4) << 9) | ((unsigned)k << 4) | ((unsigned)lane & 15u); // scratch side (round 2 thread): chunk = 4 j + (lane >> 4)
+    constexpr int RR = L1 - 5; // 2^RR tiles per frame and partner
+    static_assert(L1 == 10 || ROWS_OUT, "the [q][chunk] scratch shape is k_big2x_ci<., 11>'s");
+    const unsigned toff2 = (rjj << L1) | (unsigned)kb;                                       // user side (round 1 thread)
+    const unsigned toff = ROWS_OUT ? (unsigned)lane : (((unsigned)lane >> 4) << 9) | ((unsigned)k << 4) | ((unsigned)lane & 15u); // scratch side (round 2 thread): chunk = 4 j + (lane >> 4)
     __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
     unsigned vote_phase = 0;
     block_any_init(vote_flags);
@@ -1597,22 +1604,22 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
     const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
     size_t t = blockIdx.x;
     auto tile_of = [&](size_t tt) { return (tt >> 4) * 8u + slot; }; // G: frame = G >> 5, r6 = part << 5 | (G & 31)
-    bool have = (tile_of(t) >> 5) < nframes;
+    bool have = (tile_of(t) >> RR) < nframes;
     u32 v[32];
     auto load_tile = [&](size_t G, int q0) { // (in two halves: the second one is issued once round 2's twiddles are dead)
-        const unsigned r6 = (part << 5) | ((unsigned)G & 31u);
-        const u32 *src = in + ((G >> 5) << 21) + ((__brev(r6) >> 26) << 4); // wave-uniform
+        const unsigned r6 = (part << RR) | ((unsigned)G & ((1u << RR) - 1u));
+        const u32 *src = in + ((G >> RR) << (L1 + 11)) + ((__brev(r6) >> (36 - L1)) << 4); // wave-uniform
         unsigned toff2_l = toff2;
         asm volatile("" : "+v"(toff2_l));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q0 + q] = INTFFT_LD(at32(src + ((size_t)rev5c(q0 + q) << 16), toff2_l)); // position (jj << 5 | q) = X[k1 + 1024 brev11]
+        for (int q = 0; q < 16; ++q) v[q0 + q] = INTFFT_LD(at32(src + ((size_t)rev5c(q0 + q) << (L1 + 6)), toff2_l)); // position (jj << 5 | q) = X[k1 + 1024 brev11]
     };
     if (have) load_tile(tile_of(t), 0), load_tile(tile_of(t), 16);
     while (have) {
         const size_t ct = tile_of(t);
         t += gridDim.x;
         const size_t nt = tile_of(t);
-        const bool have_next = (nt >> 5) < nframes;
+        const bool have_next = (nt >> RR) < nframes;
         bool fast = false;
         {
             u32 acc = 0;
@@ -1623,7 +1630,9 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
         }
         // One body per extraction form from here to the stores (one branch per tile): with the two forms of round 2 behind separate branches inside
         // one body the allocator spills 50-60 VGPRs (either form alone: 103 / 105)
-        u32 *dst = scr + ((ct >> 5) << 21) + ((size_t)((unsigned)ct & 31u) << 16) + (part << 8); // wave-uniform: q = r4..r0, r5 = part
+        const unsigned r6c = (part << RR) | ((unsigned)ct & ((1u << RR) - 1u)); // the tile's rows: r = k << (L1 - 4) | r6c
+        u32 *dst = ROWS_OUT ? scr + ((ct >> RR) << (L1 + 11)) + ((size_t)(((unsigned)k << (L1 - 4)) | r6c) << 11)
+                            : scr + ((ct >> 5) << 21) + ((size_t)((unsigned)ct & 31u) << 16) + (part << 8); // wave-uniform (scratch shape: q = r4..r0, r5 = part)
 #define INTFFT_R2K_TILE(FX)                                                                                                                    \
     {                                                                                                                                          \
         dit_round5_c<FX>(v, c, sl);                                                                                                            \
@@ -1668,7 +1677,7 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
         if (have_next) load_tile(nt, 16); /* the other half: the twiddles are dead */                                                          \
         unsigned toff_l = toff;                                                                                                                \
         asm volatile("" : "+v"(toff_l));                                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 32; ++j) *at32(dst + ((size_t)j << 11), toff_l) = w[j];                                          \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) *at32(dst + ((size_t)j << (ROWS_OUT ? 6 : 11)), toff_l) = w[j];                         \
     }
         if (fast) INTFFT_R2K_TILE(FAST_OK)
         else {
@@ -1678,6 +1687,183 @@ __global__ __launch_bounds__(1024) void k_rows2k_qtr(const u32 *in, u32 *scr, co
 #undef INTFFT_R2K_TILE
         have = have_next;
     }
+}
+
+// ---- the 2-D scheme at N = 2^22 = 2048 x 2048, INVERSE, in TWO launches (round 5): k_rows2k_qtr<., 11, true> + k_cols2k_ci ------------------------------
+// The mirror of k_cols2k_c on its tile (2048 rows r x 16 columns n2, r = the DIT position of k1): plain rows V[r][n2] in (64-byte pieces, XCD-paired), T = V conj(W)
+// from the forward plan's table, DIT STAGE 0..4 on regs r4..r0 (thread = (jj = r10..r5, kb)), the LDS transpose, then wave = r3..r0, lane = (r5 -> r10 after the
+// swap, r4, kb): STAGE 5, v_permlane32_swap, STAGE 6..10 on per-thread twiddles parked in LDS (index (j << 6) | r5..r0), x[n1 N2 + n2] out as 64-byte pieces
+// (non-temporal; the partner block fills the other half of every line).  Tile body per extraction form as in k_rows2k_qtr.  Measured variants (Gsample/s of the
+// plan): plain loads 179, non-temporal loads 188 (shipped), the whole next tile requested after the last stage 178-185, all 32 table entries in one batch 182,
+// the table entries of the next tile requested with its data 86 spilled VGPRs.
+template <bool FAST_OK>
+__global__ __launch_bounds__(1024) void k_cols2k_ci(const u32 *scr, u32 *out, const uint2 *__restrict__ twf, const Round5Consts c, const u32 *__restrict__ tw2d, size_t nframes,
+                                                    const Slice sl)
+{
+    extern __shared__ u32 lds[]; // 1024 rows x ROWY, then round 2's twiddles (DIT packing): 16 slots x 64 values of r5..r0
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // r3..r0 of round 2
+    const unsigned t6 = (((unsigned)lane >> 4) << 4) | (unsigned)wv;  // r5..r0 of round 2
+    uint2 *const twl = reinterpret_cast<uint2 *>(lds + 1024 * ROWY);
+    {
+        const int slot = tid >> 6; // 0: STAGE 6, 1: STAGE 7, 2..3: STAGE 8, 4..7: STAGE 9, 8..15: STAGE 10; entry = r5..r0
+        const unsigned idx = slot == 0 ? 63u : slot == 1 ? 127u : slot < 4 ? 255u + ((unsigned)(slot - 2) << 6) : slot < 8 ? 511u + ((unsigned)(slot - 4) << 6)
+                                                                                                                  : 1023u + ((unsigned)(slot - 8) << 6);
+        uint2 w = twf[idx + (unsigned)lane];
+        to_dit_packing(w.x, w.y);
+        twl[tid] = w;
+    }
+    u32 wa5[4], wb5[4];
+    {
+        uint2 w = twf[31u + (t6 & 31u)]; // STAGE 5: index r4..r0
+        to_dit_packing(w.x, w.y);
+        wa5[0] = wa5[1] = wa5[2] = wa5[3] = w.x;
+        wb5[0] = wb5[1] = wb5[2] = wb5[3] = w.y;
+    }
+    // transpose, read side: element (register r = (r5, r9..r6), lane = (r10, r4, kb), wave r3..r0) <- row ((r10, r9..r6, r5) << 4) | kb, column r4..r0
+    const u32 *const rd_base = lds + ROWY * ((((lane >> 5) << 5) << 4) | (lane & 15)) + ((((lane >> 4) & 1) << 4) | wv);
+    const int jj = tid >> 4, kb = tid & 15;
+    u32 *const wr_base = lds + ROWY * ((jj << 4) | kb);
+    const unsigned soff = ((unsigned)jj << 16) | (unsigned)kb;                    // scratch side (round 1): row jj << 5 (+ q), column kb
+    const unsigned twoff = ((unsigned)jj << 9) + (unsigned)kb;                    // table: [r = jj << 5 | q][kb]
+    const unsigned loff = (((unsigned)lane >> 4) << 15) | ((unsigned)lane & 15u); // user side (round 2): rows r5 r4 (x 2048 samples), column kb
+    __shared__ __attribute__((aligned(256))) u32 vote_flags[64];
+    unsigned vote_phase = 0;
+    block_any_init(vote_flags);
+    const unsigned slot = blockIdx.x & 7u, part = (blockIdx.x >> 3) & 1u;
+    size_t t = blockIdx.x;
+    auto tile_of = [&](size_t tt) { return (tt >> 4) * 8u + slot; }; // G: frame = G >> 6, chunk = (G & 63) * 2 + part
+    bool have = (tile_of(t) >> 6) < nframes;
+    u32 v[32];
+    auto load_tile = [&](size_t G, int q0) {
+        const unsigned chunk = ((unsigned)G & 63u) * 2u + part;
+        const u32 *src = scr + ((G >> 6) << 22) + chunk * 16u; // wave-uniform
+        unsigned so = soff;
+        asm volatile("" : "+v"(so));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q0 + q] = INTFFT_LD(at32(src + ((size_t)(q0 + q) << 11), so));
+    };
+    if (have) load_tile(tile_of(t), 0), load_tile(tile_of(t), 16);
+    while (have) {
+        const size_t ct = tile_of(t);
+        t += gridDim.x;
+        const size_t nt = tile_of(t);
+        const bool have_next = (nt >> 6) < nframes;
+        const unsigned chunk = ((unsigned)ct & 63u) * 2u + part;
+        // T = V conj(W): the DIT butterfly's multiplier with Wc = (wr, wi) -- the table entry itself -- and Wd = (-wi, wr); plain 16-bit results
+        {
+            const u32 *const twu = tw2d + ((size_t)chunk << 15);
+            unsigned two = twoff;
+            asm volatile("" : "+v"(two));
+            const gptr_t<const u32> twq = at32(twu, two);
+            const v2s mp = {-1, 1};
+#pragma unroll
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u32 tw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) tw[i] = twq[16 * (q0 + i)];
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    const u32 wb0 = as_u32(as_v2s(__builtin_amdgcn_alignbit(tw[q], tw[q], 16)) * mp);
+                    const u32 wb1 = as_u32(as_v2s(__builtin_amdgcn_alignbit(tw[q + 1], tw[q + 1], 16)) * mp);
+                    u32 y0, y1;
+                    mul2x<16, false>(v[q0 + q], v[q0 + q], tw[q], wb0, v[q0 + q + 1], v[q0 + q + 1], tw[q + 1], wb1, sl.off_y, sl.sel, y0, y1, sl.wd);
+                    v[q0 + q] = y0, v[q0 + q + 1] = y1;
+                }
+            }
+        }
+        bool fast = false;
+        {
+            u32 acc = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc |= v[q] + sl.gbias;
+            const bool bad = block_any(vote_flags, vote_phase, (acc & sl.gmask) != 0); // on the products; also orders the previous tile's LDS reads
+            fast = FAST_OK && !bad;
+        }
+        u32 *dst = out + ((ct >> 6) << 22) + ((size_t)wv << 11) + chunk * 16u; // wave-uniform
+#define INTFFT_C2KI_TILE(FX)                                                                                                                   \
+    {                                                                                                                                          \
+        dit_round5_c<FX>(v, c, sl);                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 32; ++q) wr_base[q] = v[q];                                                                      \
+        asm volatile("" ::: "memory");                                                                                                         \
+        if (have_next) load_tile(nt, 0); /* flies during round 2 and the stores below */                                                       \
+        __syncthreads();                                                                                                                       \
+        u32 w[32];                                                                                                                             \
+        _Pragma("unroll") for (int r = 0; r < 32; ++r) w[r] = rd_base[ROWY * ((((r & 15) << 1) | (r >> 4)) << 4)];                             \
+        u32 wa16[8], wb16[8];                                                                                                                  \
+        RoundTwQ t1;                                                                                                                           \
+        {                                                                                                                                      \
+            const uint2 x0 = twl[t6], x1 = twl[64 + t6];                                                                                       \
+            t1.wa1[0] = x0.x, t1.wb1[0] = x0.y, t1.wa2[0] = x1.x, t1.wb2[0] = x1.y;                                                            \
+            _Pragma("unroll") for (int j2 = 0; j2 < 2; ++j2)                                                                                   \
+            {                                                                                                                                  \
+                const uint2 x = twl[64 * (2 + j2) + t6];                                                                                       \
+                t1.wa4[j2] = x.x, t1.wb4[j2] = x.y;                                                                                            \
+            }                                                                                                                                  \
+            _Pragma("unroll") for (int j4 = 0; j4 < 4; ++j4)                                                                                   \
+            {                                                                                                                                  \
+                const uint2 x = twl[64 * (4 + j4) + t6];                                                                                       \
+                t1.wa8[j4] = x.x, t1.wb8[j4] = x.y;                                                                                            \
+            }                                                                                                                                  \
+        }                                                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 16; j += 4)                                                                                      \
+            group4_dit<FX, false, 0, true>(w[j], w[j + 16], w[j + 1], w[j + 17], w[j + 2], w[j + 18], w[j + 3], w[j + 19], wa5, wb5, sl);      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&w[0]));                                                                                      \
+        swap_guard(*reinterpret_cast<u32(*)[16]>(&w[16]));                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) swap32(w[j], w[j + 16]); /* register bit 4: r5 -> r10 */                                \
+        dit_round_q<FX, 0>(w, t1, sl);                                                                                                         \
+        dit_round_q<FX, 16>(w, t1, sl);                                                                                                        \
+        asm volatile("" ::: "memory");                                                                                                         \
+        _Pragma("unroll") for (int j8 = 0; j8 < 8; ++j8)                                                                                       \
+        {                                                                                                                                      \
+            const uint2 x = twl[64 * (8 + j8) + t6];                                                                                           \
+            wa16[j8] = x.x, wb16[j8] = x.y;                                                                                                    \
+        }                                                                                                                                      \
+        dit_top16<FX>(w, wa16, wb16, sl);                                                                                                      \
+        asm volatile("" ::: "memory");                                                                                                         \
+        if (have_next) load_tile(nt, 16);                                                                                                      \
+        unsigned lo = loff;                                                                                                                    \
+        asm volatile("" : "+v"(lo));                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 32; ++j) __builtin_nontemporal_store(w[j], at32(dst + ((size_t)j << 17), lo));                   \
+    }
+        if (fast) INTFFT_C2KI_TILE(FAST_OK)
+        else INTFFT_C2KI_TILE(false)
+#undef INTFFT_C2KI_TILE
+        have = have_next;
+    }
+}
+
+// N = 2^22 inverse: the 2048-point row cores (k_rows2k_qtr<., 11, true>: plain rows out) + the conj multiplier and the 2048-point column cores (k_cols2k_ci)
+hipError_t launch_fused2d_inv_2k2k(int twd, const u32 *pin, u32 *pout, u32 *scr, const uint2 *tw16r, const int2 *h_tw, const u32 *tw2d, size_t nframes, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    Round5Consts c;
+    auto pk = [&](int idx, u32 &wa, u32 &wb) { // DIT packing: Wc = (wr, wi), Wd = (-wi, wr)
+        const int2 w = h_tw[idx];
+        wa = ((u32)w.x & 0xFFFFu) | ((u32)w.y << 16);
+        wb = ((u32)(-w.y) & 0xFFFFu) | ((u32)w.x << 16);
+    };
+    for (int i = 0; i < 16; ++i) pk(15 + i, c.wa4[i], c.wb4[i]);
+    for (int i = 0; i < 8; ++i) pk(7 + i, c.wa3[i], c.wb3[i]);
+    for (int i = 0; i < 4; ++i) pk(3 + i, c.wa2[i], c.wb2[i]);
+    Slice sl{twd - 1, twd, 0x05040100u, 0x07060302u};
+    static const int allow_fast = diag_env("INTFFT_FAST_EXTRACT") ? atoi(diag_env("INTFFT_FAST_EXTRACT")) : 1;
+    const bool fx = twd == 16 && allow_fast;
+    const size_t ldsr = (size_t)1024 * ROWY * sizeof(u32) + 1024 * sizeof(uint2);
+    const size_t ntiles = nframes << 7, cap16 = (size_t)device_cus() / 16 * 16; // both kernels: 128 XCD-paired tiles per frame, the grid a multiple of 16
+    const unsigned g = (unsigned)std::min(ntiles, cap16);
+    if (fx) {
+        allow_max_lds(kptr(k_rows2k_qtr<true, 11, true>));
+        allow_max_lds(kptr(k_cols2k_ci<true>));
+        hipLaunchKernelGGL((k_rows2k_qtr<true, 11, true>), dim3(g), dim3(1024), ldsr, stream, pin, scr, tw16r, c, nframes, sl);
+        hipLaunchKernelGGL((k_cols2k_ci<true>), dim3(g), dim3(1024), ldsr, stream, scr, pout, tw16r, c, tw2d, nframes, sl);
+    } else {
+        allow_max_lds(kptr(k_rows2k_qtr<false, 11, true>));
+        allow_max_lds(kptr(k_cols2k_ci<false>));
+        hipLaunchKernelGGL((k_rows2k_qtr<false, 11, true>), dim3(g), dim3(1024), ldsr, stream, pin, scr, tw16r, c, nframes, sl);
+        hipLaunchKernelGGL((k_cols2k_ci<false>), dim3(g), dim3(1024), ldsr, stream, scr, pout, tw16r, c, tw2d, nframes, sl);
+    }
+    return hipGetLastError();
 }
 
 // N = 2^20 inverse: pass QB (row cores) + the multiplier and the column cores.  tw1k / h_tw1k: the packed / host tables of the 1024-point cores

@@ -261,7 +261,9 @@ int fused2d_supported(int log2n, int l1, int data_width, int twdl_width, int for
 hipError_t build_fused2d_table(uint32_t *d_table, int log2n, int twd, hipStream_t stream, int l1 = 10);
 hipError_t launch_fused2d_2k2k(int twd, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16r, const int2 *h_tw, const uint32_t *tw2d, size_t nframes,
                                hipStream_t stream); // N = 2^22 = 2048 x 2048 in two launches (round 5)
-int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order); // 1: N = 2^20, 2: N = 2^21, 3: three launches
+hipError_t launch_fused2d_inv_2k2k(int twd, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw16r, const int2 *h_tw, const uint32_t *tw2d, size_t nframes,
+                                   hipStream_t stream); // ... and its inverse
+int fused2d_inv_supported(int log2n, int l1, int data_width, int twdl_width, int format, int rndmode, int direction, int in_order, int out_order); // 1: N = 2^20, 2: N = 2^21, 3: three launches, 4: N = 2^22 = 2048 x 2048
 hipError_t launch_fused2d_inv_cols(int l2, int twd, const uint32_t *rows, uint32_t *pout, const uint2 *tw1k, const int2 *h_tw1k, const uint32_t *tw2d, size_t nframes, int halves,
                                    hipStream_t stream);
 hipError_t launch_fused2d_inv21(int twd, const uint32_t *pin, uint32_t *pout, uint32_t *scr, const uint2 *tw1k, const int2 *h_tw1k, const uint2 *tw16r, const int2 *h_tw2k,

@@ -124,6 +124,7 @@ struct intfft_plan {
                                       // 5: N = 2^20 pair = the forward two launches, then the inverse two; 6 (round 5): N = 2^21 inverse in two launches
                                       // (k_rows2k_qtr + k_big2x_ci<., 11>); 7: N = 2^21 pair = k_big2x_c<11> + k_rows2k_tr, then form 6's two launches;
                                       // 8 (round 5): N = 2^22 = 2048 x 2048 forward in two launches (k_cols2k_c + k_rows2k_tr<., 11>);
+                                      // 10 / 11 (round 5): N = 2^22 = 2048 x 2048 inverse in two launches (k_rows2k_qtr<., 11, true> + k_cols2k_ci) / the pair in four;
                                       // 9 (round 5): N = 2^22 .. 2^24 inverse as one layout change, the N2-point row sub-plan, k_big2x_ci<., L2, ROWS>
     uint2 *d_tw16r = nullptr, *d_tw16ri = nullptr; // fused2d == 3 at N2 = 2048, natural order out (round 5): the row core's packed tables for k_rows2k_tr
     uint32_t *d_tw2d_tiles = nullptr; // its inter-core twiddle table, [chunk][rho][16 columns] of (wr | wi << 16)
@@ -848,8 +849,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         // ... and the inverse (4): the row cores as pass QB, the conj multiplier + the column cores on pass QA's tiles (k_big2x_ci)
         const int inv2d = fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->in_order, p->out_order);
         if (!pl->fused2d && inv2d && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 && pl->tw_i.sh_b == p->twdl_width - 1 && pl->sub_row_i && pl->sub_col_i &&
-            big2x_tables_ok(10, pl->sub_col_i->h_tw.data(), p->twdl_width) && (inv2d == 3 || big2x_tables_ok(l2, pl->sub_row_i->h_tw.data(), p->twdl_width)))
-            pl->fused2d = inv2d == 2 ? 6 : inv2d == 3 ? 9 : 4; // 6 (round 5): N = 2^21, the 2048-point row cores in k_rows2k_qtr; 9: three launches
+            big2x_tables_ok(inv2d == 4 ? 11 : 10, pl->sub_col_i->h_tw.data(), p->twdl_width) &&
+            (inv2d == 3 || big2x_tables_ok(l2, pl->sub_row_i->h_tw.data(), p->twdl_width)))
+            pl->fused2d = inv2d == 2 ? 6 : inv2d == 3 ? 9 : inv2d == 4 ? 10 : 4; // 6 (round 5): N = 2^21, the 2048-point row cores in k_rows2k_qtr; 9: three launches
         // ... and the pair (5): the forward two launches into the second layout buffer, the inverse two launches from there
         if (!pl->fused2d && p->direction == INTFFT_PAIR && !diag_env("INTFFT_2D_NO_FUSED_CORES") && pl->sub_col_f && pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
             fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 2 &&
@@ -866,7 +868,14 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(10, pl->sub_col_f->h_tw.data(), p->twdl_width) &&
             big2x_tables_ok(11, pl->sub_row_f->h_tw.data(), p->twdl_width))
             pl->fused2d = 7;
-        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : (pl->fused2d == 6 || pl->fused2d == 9) ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
+        // ... and the pair at N = 2^22 = 2048 x 2048 (11): form 8's two launches into the second layout buffer, form 10's two from there
+        if (!pl->fused2d && p->direction == INTFFT_PAIR && pl->sub_col_f && pl->sub_row_f && pl->sub_row_i && pl->sub_col_i &&
+            fused2d_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_FWD, p->in_order, INTFFT_ORDER_NATURAL) == 8 &&
+            fused2d_inv_supported(p->log2n, l1, p->data_width, p->twdl_width, p->format, p->rndmode, INTFFT_INV, INTFFT_ORDER_NATURAL, p->out_order) == 4 &&
+            pl->tw_f.mw == 16 && pl->tw_f.sh_a == 0 && pl->tw_f.sh_b == p->twdl_width - 1 && pl->tw_i.mw == 16 && pl->tw_i.sh_a == 0 &&
+            pl->tw_i.sh_b == p->twdl_width - 1 && big2x_tables_ok(11, pl->sub_col_f->h_tw.data(), p->twdl_width))
+            pl->fused2d = 11;
+        const intfft_plan *core1k = pl->fused2d == 4 ? pl->sub_row_i : (pl->fused2d == 6 || pl->fused2d == 9 || pl->fused2d == 10) ? pl->sub_col_i : pl->sub_col_f; // a 1024-point core of the plan (its twiddle tables)
         if (pl->fused2d) {
             // the fused launches run none of the 1-D sub-plans except form 3's rows, and forms 2 / 4 need one layout buffer only:
             // keep the core whose twiddle tables the tile kernels read (core1k), release the rest
@@ -877,7 +886,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 }
             };
             drop(&pl->sub_col_f), drop(&pl->sub_row_f), drop(&pl->sub_row_i), drop(&pl->sub_col_i);
-            if (pl->fused2d == 2 || pl->fused2d == 4 || pl->fused2d == 6 || pl->fused2d == 8) {
+            if (pl->fused2d == 2 || pl->fused2d == 4 || pl->fused2d == 6 || pl->fused2d == 8 || pl->fused2d == 10) {
                 (void)hipFree(pl->buf2d[1]);
                 pl->buf2d[1] = nullptr;
                 pl->n2d_bufs = 1;
@@ -897,7 +906,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
             }
-            if (e == hipSuccess && pl->fused2d == 8) { // the 2048-point cores' packed table (columns and rows share it)
+            if (e == hipSuccess && (pl->fused2d == 8 || pl->fused2d == 10 || pl->fused2d == 11)) { // the 2048-point cores' packed table (columns and rows share it)
                 const size_t tot = ((size_t)1 << 11) - 1;
                 e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
@@ -927,6 +936,8 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             else if (pl->fused2d == 4) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_qb|k_big2x_ci]");
             else if (pl->fused2d == 6) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 8) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_cols2k_c|k_rows2k_tr]");
+            else if (pl->fused2d == 10) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_rows2k_qtr|k_cols2k_ci]");
+            else if (pl->fused2d == 11) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_cols2k_c|k_rows2k_tr|k_rows2k_qtr|k_cols2k_ci]");
             else if (pl->fused2d == 9) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[%.24s|k_big2x_ci]", pl->sub_row_i->kernel_name);
             else if (pl->fused2d == 7) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_rows2k_tr|k_rows2k_qtr|k_big2x_ci]");
             else if (pl->fused2d == 5) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "2d[k_big2x_c|k_big2x_b|k_big2x_qb|k_big2x_ci]");
@@ -1330,8 +1341,8 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
             if (sp && intfft_plan_get_info(sp, &si) == INTFFT_OK) n += si.n_passes;
         const int cores = (plan->sub_col_f ? 1 : 0) + (plan->sub_row_i ? 1 : 0);
         info->n_passes = n + 2 * cores + (cores == 2 ? 0 : 1); // per direction: layout change in or out + the middle one (multiplier fused in); a pair shares its middle
-        if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6 || plan->fused2d == 8) info->n_passes = 2;
-        if (plan->fused2d == 5 || plan->fused2d == 7) info->n_passes = 4;
+        if (plan->fused2d == 2 || plan->fused2d == 4 || plan->fused2d == 6 || plan->fused2d == 8 || plan->fused2d == 10) info->n_passes = 2;
+        if (plan->fused2d == 5 || plan->fused2d == 7 || plan->fused2d == 11) info->n_passes = 4;
         if (plan->fused2d == 3 && intfft_plan_get_info(plan->sub_row_f, &si) == INTFFT_OK) info->n_passes = plan->d_tw16r ? 2 : 2 + si.n_passes;
         if (plan->fused2d == 9 && intfft_plan_get_info(plan->sub_row_i, &si) == INTFFT_OK) info->n_passes = 2 + si.n_passes;
         info->compute_word = plan->fused2d ? 2 : 0;
@@ -1367,7 +1378,7 @@ static bool dual_2d(const intfft_plan *pl)
     // (the two-launch N = 2^21 plan stays on one stream: its row kernel is one 135 KiB workgroup per CU, which cannot share a CU with the column
     // pass's 68 KiB workgroups of the other chunk -- 269 Gsample/s on one stream against 255 on two)
     return pl->fused2d && pl->wants_side && pl->buf2d_frames / 2 >= 1 && (pl->fused2d != 3 || (pl->sub_row_f->scratch_bytes == 0 && !pl->d_tw16r)) &&
-           (pl->fused2d != 9 || pl->sub_row_i->scratch_bytes == 0) && pl->fused2d != 6 && pl->fused2d != 7 && pl->fused2d != 8;
+           (pl->fused2d != 9 || pl->sub_row_i->scratch_bytes == 0) && pl->fused2d != 6 && pl->fused2d != 7 && pl->fused2d != 8 && pl->fused2d != 10 && pl->fused2d != 11;
 }
 static size_t ws_frames_2d(const intfft_plan *pl, size_t batch)
 {
@@ -1443,6 +1454,17 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                 if (e == hipSuccess)
                     e = launch_fused2d_inv(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf,
                                            p.out_order == INTFFT_ORDER_HALVES, st);
+                continue;
+            }
+            if (pl->fused2d == 10) { // N = 2^22 = 2048 x 2048, inverse
+                e = launch_fused2d_inv_2k2k(p.twdl_width, src, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16r, pl->sub_col_i->h_tw.data(), pl->d_tw2d_tiles, nf, st);
+                continue;
+            }
+            if (pl->fused2d == 11) { // ... and the pair: X in natural order in the second layout buffer between the two directions
+                uint32_t *b1 = reinterpret_cast<uint32_t *>(static_cast<char *>(buf1) + off);
+                e = launch_fused2d_2k2k(p.twdl_width, src, b1, b0, pl->d_tw16r, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, st);
+                if (e == hipSuccess)
+                    e = launch_fused2d_inv_2k2k(p.twdl_width, b1, reinterpret_cast<uint32_t *>(dst), b0, pl->d_tw16r, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, st);
                 continue;
             }
             if (pl->fused2d == 8) { // N = 2^22 = 2048 x 2048

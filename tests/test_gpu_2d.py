@@ -7,6 +7,7 @@ from oracle import oracle_c as C
 from tests.helpers import edge_frames, to_complex, uniform_frames
 
 pytestmark = pytest.mark.gpu
+DIRS = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}
 ORD = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
 DIR = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}
 NP = {2: np.int16, 4: np.int32, 8: np.int64}
@@ -371,4 +372,27 @@ def test_2d_n2pow22_two_launches(frames, monkeypatch):
     assert np.array_equal(got, got5)
     if frames <= 2:
         check(x[:1], 22, 11, 16, 13, 0, 0, False)
+
+
+@pytest.mark.parametrize("direction,frames", [("INV", 2), ("INV", 19), ("PAIR", 2), ("PAIR", 11)])
+def test_2d_n2pow22_inverse_and_pair(direction, frames, monkeypatch):
+    """N = 2^22 = 2048 x 2048, 16-bit scaled-truncate (round 5): the inverse in two launches -- k_rows2k_qtr<., 11, true> (the 2048-point row cores, plain rows out) +
+    k_cols2k_ci (conj multiplier + the 2048-point column cores on tiles of 2048 rows x 16 columns) -- and the pair in four (the forward two into the second layout
+    buffer); against the oracle and the composite (INTFFT_2D_NO_ROWS2K); a full-scale frame, 13-bit twiddles / XSER OLD, batches beyond one scratch chunk."""
+    n = 1 << 22
+    x = uniform_frames(frames, n, 15, 5777 + frames)
+    x[0] = uniform_frames(1, n, 16, 21)[0]
+    got, info = run_gpu(x, 22, 11, 16, 16, 0, 0, True, direction)
+    name = "2d[k_rows2k_qtr|k_cols2k_ci]" if direction == "INV" else "2d[k_cols2k_c|k_rows2k_tr|k_rows2k_qtr|k_cols2k_ci]"
+    assert info["kernel_name"] == name and info["n_passes"] == (2 if direction == "INV" else 4), info
+    sel = [0, frames - 1]
+    want = C.execute_2d(x[sel], C.make_params(22, 16, 16, 0, 0, True), 11, DIRS[direction], C.NATURAL, C.NATURAL, form=1)
+    assert np.array_equal(got[sel], want)
+    if frames <= 2:
+        with monkeypatch.context() as m:
+            m.setenv("INTFFT_2D_NO_ROWS2K", "1")
+            got5, info5 = run_gpu(x, 22, 11, 16, 16, 0, 0, True, direction)
+            assert info5["n_passes"] >= 4 and info5["kernel_name"] != name, info5
+        assert np.array_equal(got, got5)
+        check(x[:1], 22, 11, 16, 13, 0, 0, False, direction)
 

@@ -75,6 +75,8 @@ ROWS.append(("18:16:16:0:1:INV", "16-bit scaled-round INV"))
 ROWS.append(("23:16:16:0:0:FWD:10", "16-bit scaled-trunc FWD, 2-D scheme 2^10 x 2^13"))
 ROWS.append(("22:16:16:0:0:FWD:10", "16-bit scaled-trunc FWD, 2-D scheme 2^10 x 2^12"))
 ROWS.append(("22:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^12 (three launches, round 5)"))
+ROWS.append(("22:16:16:0:0:INV:11", "16-bit scaled-trunc INV, 2-D scheme 2^11 x 2^11 (two launches, round 5)"))
+ROWS.append(("22:16:16:0:0:PAIR:11", "16-bit scaled-trunc PAIR, 2-D scheme 2^11 x 2^11 (four launches, round 5)"))
 ROWS.append(("23:16:16:0:0:INV:10", "16-bit scaled-trunc INV, 2-D scheme 2^10 x 2^13 (three launches, round 5)"))
 for L in (13, 14, 16):
     ROWS.append(("%d:24:24:1:0:INV" % L, "24-bit unscaled INV (40-bit results)"))
