@@ -45,7 +45,9 @@ def main():
             dw = int(rng.choice([16, 18, 24, 24, 28, 32, 32, 40, 48, int(rng.integers(4, 65))]))
         l1 = 0
         if big and log2n == 20 and rng.random() < 0.3:
-            l1, log2n = 10, int(rng.choice([20, 20, 21, 22]))
+            l1, log2n = 10, int(rng.choice([20, 20, 21, 21, 22, 22]))
+            if log2n == 22 and rng.random() < 0.5:
+                l1 = 11  # 2048 x 2048: the two-launch plans of round 5
         elif log2n >= 6 and rng.random() < 0.15:
             l1 = int(rng.integers(3, log2n - 2)) if rng.random() < 0.6 or log2n < 13 else 10 if log2n >= 20 else l1
         p = C.make_params(log2n, dw, tw, fmt, rnd, new)
