@@ -467,6 +467,8 @@ WS_CASES = [
     (21, 16, 16, 0, 0, "INV", 10, 3, 16),   # 2-D inverse, two launches (k_rows2k_qtr; round 5)
     (21, 16, 16, 0, 0, "PAIR", 10, 3, 16),  # 2-D pair, four launches through the second layout buffer (round 5)
     (22, 16, 16, 0, 0, "INV", 10, 3, 32),   # 2-D inverse, three launches with a row sub-plan (round 5)
+    (22, 16, 16, 0, 0, "FWD", 11, 3, 32),   # 2-D as 2048 x 2048, two launches (round 5)
+    (22, 16, 16, 0, 0, "PAIR", 11, 3, 32),  # ... and its pair, four launches through the second layout buffer
     (14, 18, 16, 0, 0, "FWD", 6, 9, 1),     # composite 2-D plan on sub-plans
     (14, 18, 16, 0, 0, "PAIR", 0, 20, 1),   # composite pair: middle buffer + two sub-plans with scratch of their own
     (13, 32, 16, 1, 0, "INV", 0, 11, 1),    # the generic 64-bit passes
@@ -669,7 +671,7 @@ GUARD_CASES = [
     (9, 32, 16, 1, 0, "INV", "BITREV", "HALVES", 5),
     # ... and the 2-D plans of round 5 (a tenth field: log2 N1): the inverse and the pair at N = 2^21, the three-launch inverse at N = 2^22
     (21, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1, 10), (21, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 1, 10), (22, 16, 16, 0, 0, "INV", "NATURAL", "HALVES", 1, 10),
-    (21, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 10),
+    (21, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 10), (22, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 11), (22, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1, 11),
 ]
 
 
