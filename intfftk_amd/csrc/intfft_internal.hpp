@@ -216,9 +216,10 @@ struct WideStage {
     int w32;           // 64-bit stages: wo - 32
 };
 struct WideArgs {
-    WideStage st[16];  // processing order: forward st[ii] is STAGE NFFT - 1 - ii, inverse st[s] is STAGE s
+    WideStage st[20];  // processing order: forward st[ii] is STAGE NFFT - 1 - ii, inverse st[s] is STAGE s (N = 2^17 .. 2^20: intfft_widelong.hip)
     int dw;            // DATA_WIDTH (wrap on load)
     int native;        // bit 0: HALVES order on the time side, bit 1: BITREV order on the frequency side (NAT instantiations)
+    int r32;           // long frames: STAGE 7 .. 4 within 32 bits (k_wide16_p2<.., R32>)
     int w64;           // the first pass runs on 64-bit words too (k_wide64_p1 / q1: DATA_WIDTH 25 .. 32), 16-byte scratch samples
 };
 bool wide16_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order,
@@ -227,6 +228,10 @@ hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out
                          const int2 *h_tw, size_t nframes, hipStream_t stream, int direction = 0);
 const char *wide16_kernel_name(int direction = 0, int w64 = 0);
 int wide16_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
+// the same class at N = 2^17 .. 2^20: a pre-pass for STAGE NFFT-1 .. 16, then the two passes on 2^16-point blocks (intfft_widelong.hip, round 5)
+bool widelong_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
+hipError_t launch_widelong(int log2n, const WideArgs &a, int in_cb, const void *in, void *out, void *scratch, const int2 *tw_all, const int2 *h_tw,
+                           size_t nframes, hipStream_t stream);
 
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,

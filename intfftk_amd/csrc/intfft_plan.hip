@@ -181,6 +181,7 @@ struct intfft_plan {
     bool big_pair256 = false;  // N = 2^13 .. 2^16 pair: k_big20_p1<., ., 8>, k_mid_pair, k_big20_q1<., ., 8> (256 x 256 split)
     bool big_two_pass = false; // N = 2^13 .. 2^16 FWD / INV: k_big20_p1<., ., 8> + k_mid_p2 | k_mid_c, k_mid_q1 | k_mid_c + k_big20_q1<., ., 8>
     bool wide16 = false;
+    bool widelong = false; // wide16 at N = 2^17 .. 2^20 (three launches, 16-byte scratch samples)
     WideArgs wargs{};
     Fast1024Args fargs{};
     // host-streaming state (intfft_exec_host), created on first use
@@ -1166,6 +1167,9 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         const int wcls = generic_only ? 0 : wide16_class(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
         pl->wide16 = wcls != 0 && !diag_env("INTFFT_NO_WIDE16");
         pl->wargs.w64 = wcls == 2;
+        pl->widelong = !generic_only && !pl->wide16 && !diag_env("INTFFT_NO_WIDELONG") &&
+                       widelong_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order);
+        if (pl->widelong) pl->wide16 = true; // the forward branch below fills the stage list of all NFFT stages
         pl->wargs.native = p->direction == INTFFT_INV ? ((p->out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->in_order == INTFFT_ORDER_BITREV ? 2 : 0))
                                                        : ((p->in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->out_order == INTFFT_ORDER_BITREV ? 2 : 0));
         if (pl->wide16 && wcls == 2) { // every stage on the 64-bit butterflies (wfly64 / wdit64): exact 64-bit products, the slice inside one dword pair
@@ -1213,6 +1217,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
             const int LL = p->log2n; // 13 .. 16: STAGE LL-1 .. 8 in pass 1 (int32), 7 .. 0 in pass 2 (64-bit)
             if (core_stages(*p, p->data_width, false, st) != INTFFT_OK || (int)st.size() != LL) pl->wide16 = false;
             pl->wargs.dw = p->data_width;
+            pl->wargs.r32 = pl->widelong && !diag_env("INTFFT_NO_WIDELONG_R32");
             for (int ii = 0; ii < LL && pl->wide16; ++ii) {
                 const StageDesc &d = st[ii];
                 WideStage &w = pl->wargs.st[ii];
@@ -1223,14 +1228,17 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 w.s3 = 32 - d.wo;
                 w.w32 = d.wo - 32;
                 if (d.s != LL - 1 - ii || d.mw + p->twdl_width > 64) pl->wide16 = false;
-                if (d.s >= 8 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
+                if (d.s >= 8 && d.s < 16 && (w.s2 < 0 || w.s2 > 31 || w.s3 < 0)) pl->wide16 = false;
+                if (d.s >= 16 && (w.sh < 0 || w.sh > 31 || w.s3 < 0 || w.s3 > 31)) pl->wide16 = false; // k_wide_pre: the general slice form
                 // pass 2: widths beyond 32 use v_alignbit + v_bfe (slice inside one dword pair), the others the general form
+                if (d.s >= 4 && d.s < 8 && (d.wo > 32 || w.sh + d.wo - 32 < 0 || w.sh + d.wo - 32 > 31)) pl->wargs.r32 = 0; // round 1 of pass 2 on int32 (long frames)
                 if (d.s >= 2 && d.s < 8 && w.w32 >= 1 && w.sh + w.w32 > 32) pl->wide16 = false;
                 if (d.s < 8 && (d.wo > 40 || w.sh + d.wo > 64)) pl->wide16 = false;
             }
         }
+        if (!pl->wide16) pl->widelong = false;
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->wide16 ? wide16_kernel_name(p->direction, pl->wargs.w64) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->widelong ? "k_wide_pre+k_wide16_p1+p2" : pl->wide16 ? wide16_kernel_name(p->direction, pl->wargs.w64) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;
@@ -1247,7 +1255,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw || pl->wide16) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->wide16 && pl->wargs.w64) ? 8 : pl->wide16 ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->wide16 && (pl->wargs.w64 || pl->widelong)) ? 8 : pl->wide16 ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream
@@ -1355,7 +1363,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }
-    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : plan->wide16 ? 2 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : plan->widelong ? 3 : plan->wide16 ? 2 : (int)plan->passes.size();
     info->compute_word = (plan->fastw64 || plan->fastw64b) ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
@@ -1758,6 +1766,11 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
         if (plan->bigw) {
             const hipError_t e = launch_bigw(plan->p.log2n, plan->p.format ? 2 : plan->p.rndmode, plan->w32args, src, dst,
                                              scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
+            if (e != hipSuccess) return (int)e;
+            continue;
+        }
+        if (plan->widelong) {
+            const hipError_t e = launch_widelong(plan->p.log2n, plan->wargs, plan->in_cb, src, dst, scratch, plan->d_tw, plan->h_tw.data(), nf, stream);
             if (e != hipSuccess) return (int)e;
             continue;
         }

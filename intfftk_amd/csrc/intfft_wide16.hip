@@ -107,14 +107,17 @@ __device__ __forceinline__ void wstage32(int (&re)[16], int (&im)[16], const int
     wstage32x<H, false>(re, im, wr, wi, s); // the masked form covers a = 0 too (keep = ~0)
 }
 
-template <int L, bool NAT = false>
+// XS > 0 (round 5, intfft_widelong.hip): the frames are the 2^16-point blocks of N = 2^(16 + XS)-point frames whose STAGE 16 + XS - 1 .. 16 ran in k_wide_pre:
+// the same kernel with its stage descriptors XS entries further down (the caller passes block counts and a.dw = the width behind the pre-pass)
+template <int L, bool NAT = false, int XS = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_p1(const int2 *in, int2 *scr, const int2 *__restrict__ twt,
                                                    const WideArgs a, size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
     constexpr int G = 1 << (16 - L);                     // real frames per virtual frame
     const size_t nframes = (nframes_user + G - 1) / G;   // virtual frames
-    constexpr int X = L - 16;                            // a.st[] is indexed by L - 1 - STAGE: STAGE 15 - k is entry X + k
+    constexpr int X = L - 16 + XS;                       // a.st[] is indexed by L - 1 - STAGE: STAGE 15 - k is entry X + k
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
     const int tile = blockIdx.x & 15;
@@ -330,13 +333,22 @@ __device__ __forceinline__ void wstage64(i64 (&re)[16], i64 (&im)[16], const int
     wstage64x<H, false, UNIFORM_W>(re, im, wr, wi, s);
 }
 
-template <int L, bool IN64 = false, bool NAT = false> // IN64: the scratch holds 64-bit words (k_wide64_p1 in front: DATA_WIDTH 25 .. 32, round 5)
+// XS > 0 (round 5, intfft_widelong.hip): N = 2^LX, LX = 16 + XS, as B = 2^XS blocks of 2^16 points (n = 65536 b + 256 r + c) whose STAGE LX-1 .. 16 ran in
+// k_wide_pre and STAGE 15 .. 8 in k_wide16_p1<16, false, XS> block by block.  A unit is then the 16 rows (b, jtop) -- every block b x the rows
+// r = (jtop << (4 + XS)) | ulow -- whose natural-order output indices brev_LX(n) are adjacent: rev4(t4 = (b << (4 - XS)) | jtop) is again the low nibble of the
+// output index, so the store below is the L = 16 one with LX in place of L; the loads gather 128-byte row pieces from the blocks' [r0][c7..4][j][c3..0] layouts.
+// R32 (with XS > 0): STAGE 7 .. 4 still within 32 bits (16-bit data: DATA_WIDTH + LX - 4 <= 32) -- round 1 on the int32 butterflies of pass 1, two transpose
+// planes instead of three; only round 2 (STAGE 3 .. 0, two of them multiplier-free) pays for 64-bit words
+template <int L, bool IN64 = false, bool NAT = false, int XS = 0, bool R32 = false> // IN64: the scratch holds 64-bit words (k_wide64_p1 in front: DATA_WIDTH 25 .. 32, round 5)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
                                                    const WideArgs a, const W2Consts k, size_t nframes_user)
 {
+    static_assert(XS == 0 || (L == 16 && !NAT && !IN64 && XS <= 4), "long frames: whole 2^16-point blocks, natural order, int32 scratch");
+    static_assert(!R32 || XS > 0, "int32 first round: instantiated for the long frames only");
     constexpr int G = 1 << (16 - L);
     const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
-    constexpr int X = L - 16;                          // a.st[] entry of STAGE 15 - k is X + k
+    constexpr int X = L - 16 + XS;                     // a.st[] entry of STAGE 15 - k is X + k
+    constexpr int LX = L + XS;                         // the output frame
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
 
@@ -368,18 +380,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const uint4 *const rd0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
     const uint4 *const rd1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
 
-    // work unit u = 16 f + (g, low)
-    const size_t units = nframes * 16;
+    // work unit u = 16 f + (g, low)   (XS > 0: u = (f << (4 + XS)) + ulow)
+    const size_t units = nframes << (4 + XS);
     for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
-        const size_t f = u >> 4;
-        const int r0 = (int)(u & 15);
-        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t f = u >> (4 + XS);
+        const int r0 = (int)(u & ((16u << XS) - 1u));
+        const int ug = XS ? 0 : r0 >> (L - 12), ulow = XS ? r0 : r0 & ((1 << (L - 12)) - 1);
         const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
         if (L < 16 && real >= nframes_user) continue;
         i64 re[16], im[16];
-        const int2 *src = scr + f * 65536 + 4096 * r0; // unit layout [c7..4 = q][t4 = hi4][c3..0]: 2 KiB per register; thread part = tid
+        // unit layout [c7..4 = q][t4 = hi4][c3..0]: 2 KiB per register; thread part = tid
+        // (XS > 0: block (f << XS) + b, row r = 16 j + r0' with r0' = ulow & 15, j = (jtop << XS) | (ulow >> 4), layout [r0'][q][j][c3..0] per block)
+        const int2 *src = XS ? scr + (f << (16 + XS)) + 4096 * (r0 & 15) + 16 * (r0 >> 4) : scr + f * 65536 + 4096 * r0;
         typedef int v2i __attribute__((ext_vector_type(2)));
-        unsigned tid_l = (unsigned)tid;
+        unsigned tid_l = XS ? (unsigned)((hi4 >> (4 - XS)) * 65536 + 16 * ((hi4 & ((1 << (4 - XS)) - 1)) << XS) + lo4) : (unsigned)tid;
         asm volatile("" : "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
         if constexpr (IN64) { // 16 bytes per sample
             typedef i64 v2li __attribute__((ext_vector_type(2)));
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 re[q] = x.x;
                 im[q] = x.y;
             }
-        } else {
+        } else if constexpr (!R32) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const v2i x = *at32(reinterpret_cast<const v2i *>(src + 256 * q), tid_l);
@@ -398,6 +412,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 im[q] = x.y;
             }
         }
+        if constexpr (R32) { // round 1 on int32, two planes
+            int re32[16], im32[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2i x = *at32(reinterpret_cast<const v2i *>(src + 256 * q), tid_l);
+                re32[q] = x.x;
+                im32[q] = x.y;
+            }
+            wstage32<8>(re32, im32, w7r, w7i, a.st[X + 8]);
+            wstage32<4>(re32, im32, w6r, w6i, a.st[X + 9]);
+            wstage32<2>(re32, im32, w5r, w5i, a.st[X + 10]);
+            wstage32<1>(re32, im32, w4r, w4i, a.st[X + 11]);
+            __syncthreads(); // the previous unit's reads are done
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                wr0[ROWW * 16 * q] = (u32)re32[q];
+                wr1[ROWW * 16 * q] = (u32)im32[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 x = rd0[q], y = rd1[q];
+                re[4 * q + 0] = (int)x.x, re[4 * q + 1] = (int)x.y, re[4 * q + 2] = (int)x.z, re[4 * q + 3] = (int)x.w;
+                im[4 * q + 0] = (int)y.x, im[4 * q + 1] = (int)y.y, im[4 * q + 2] = (int)y.z, im[4 * q + 3] = (int)y.w;
+            }
+        } else {
         wstage64<8>(re, im, w7r, w7i, a.st[X + 8]);
         wstage64<4>(re, im, w6r, w6i, a.st[X + 9]);
         wstage64<2>(re, im, w5r, w5i, a.st[X + 10]);
@@ -433,6 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int q = 0; q < 16; ++q) {
             re[q] = (i64)(((u64)(u32)__builtin_amdgcn_sbfe((int)hp[q], 0, 16) << 32) | rlo[q]);
             im[q] = (i64)(((u64)(u32)((int)hp[q] >> 16) << 32) | ilo[q]);
+        }
         }
         // round 2: registers c3..0: STAGE 3, 2 (uniform twiddles), 1, 0
         wstage64<8, true>(re, im, k.wr3, k.wi3, a.st[X + 12]);
@@ -480,14 +521,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             continue;
         }
-        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
-        v2l *dst = reinterpret_cast<v2l *>(out) + (real << L) + 16 * rlow; // wave-uniform
-        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4));
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (LX - 12)));
+        v2l *dst = reinterpret_cast<v2l *>(out) + (real << LX) + 16 * rlow; // wave-uniform
+        unsigned toff = (unsigned)((rev4w(hi4) << (LX - 8)) + rev4w(lo4));
         asm volatile("" : "+v"(toff));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const v2l y = {re[q], im[q]};
-            __builtin_nontemporal_store(y, at32(dst + ((size_t)rev4w(q) << (L - 4)), toff));
+            __builtin_nontemporal_store(y, at32(dst + ((size_t)rev4w(q) << (LX - 4)), toff));
         }
     }
 }
@@ -1176,6 +1217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // orders the two-pass wide kernels take: natural, or the core's own beat order on either side (NAT instantiations, round 5)
+#ifndef INTFFT_WIDE16_TEMPLATES_ONLY /* intfft_widelong.hip includes the kernel templates above and stops here */
 static bool wide_orders_ok(int direction, int in_order, int out_order)
 {
     if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
@@ -1270,4 +1312,5 @@ hipError_t launch_wide16(int log2n, const WideArgs &a, const void *in, void *out
     }
 }
 
+#endif // INTFFT_WIDE16_TEMPLATES_ONLY
 } // namespace intfft

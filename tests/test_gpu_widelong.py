@@ -1,0 +1,82 @@
+"""int_fftNk with FORMAT = 1 (full bit growth) at N = 2^17 .. 2^20 (round 5, csrc/intfft_widelong.hip): 16-bit ADC data through a long
+unscaled core -- 33 .. 36-bit results in int64 containers -- and wider data while DATA_WIDTH + NFFT <= 40.  Three launches (k_wide_pre:
+STAGE NFFT-1 .. 16 on int32; k_wide16_p1 / p2 on 2^16-point blocks, the second pass taking its rows across the blocks) against the CPU
+oracle, bit for bit, and against the generic k_pass<int64> plan they replace (src/vhdl/fft/int_fftNk.vhd:184-342)."""
+import numpy as np
+import pytest
+
+from oracle import oracle_c as C
+from tests.helpers import edge_frames, uniform_frames
+from tests.test_gpu_parity import check, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+NAME = "k_wide_pre+k_wide16_p1+p2"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(17, 16, 16, 3), (17, 16, 24, 1), (18, 16, 16, 2), (18, 15, 18, 1), (19, 16, 16, 1), (19, 14, 16, 2),
+                                               (20, 16, 16, 1), (20, 13, 24, 1), (17, 20, 16, 2), (17, 23, 24, 1), (18, 22, 16, 1), (19, 21, 18, 1),
+                                               (20, 20, 16, 1), (17, 18, 16, 5)])
+def test_long_unscaled_three_launches(log2n, dw, tw, batch, monkeypatch):
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 700 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME and info["n_passes"] == 3 and info["out_container"] == 8 and info["out_bits"] == dw + log2n, info
+    assert info["in_container"] == (2 if dw <= 16 else 4), info
+    if log2n <= 18:
+        a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+        monkeypatch.setenv("INTFFT_NO_WIDELONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+        assert ib["kernel_name"] != NAME and np.array_equal(a, b), ib
+
+
+def test_long_unscaled_old_twiddle_series_and_full_scale():
+    """XSER = OLD tables, and frames of full-scale samples (every guard bit in use at every stage)."""
+    log2n, dw, tw = 17, 16, 16
+    n = 1 << log2n
+    rng = np.random.default_rng(5)
+    x = rng.choice(np.array([-(1 << 15), (1 << 15) - 1], dtype=np.int64), size=(2, n, 2))
+    if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, False), C.FWD) == 0:
+        info = check(x, log2n, dw, tw, 1, 0, False)
+        assert info["kernel_name"] == NAME, info
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME, info
+
+
+def test_long_unscaled_chunks_on_two_streams(monkeypatch):
+    """Several scratch chunks per call (alternating between the caller's stream and the pooled side stream) = one chunk = the oracle."""
+    log2n, dw, tw = 17, 16, 16
+    n = 1 << log2n
+    x = uniform_frames(7, n, dw, 41)
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", "4")  # 2 frames per chunk
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME, info
+    a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    monkeypatch.delenv("INTFFT_SCRATCH_MB")
+    b, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    assert np.array_equal(a, b)
+
+
+def test_long_unscaled_class_boundaries():
+    """Outside the class the generic passes serve the plan: results of at most 32 bits (int32 containers out), other orders, the inverse."""
+    _, info = run_gpu(uniform_frames(1, 1 << 17, 12, 3), 17, 12, 16, 1, 0, True)  # 29-bit results
+    assert info["kernel_name"] != NAME, info
+    x = uniform_frames(1, 1 << 17, 16, 4)
+    info = check(x, 17, 16, 16, 1, 0, True, out_order="BITREV")
+    assert info["kernel_name"] != NAME, info
+    info = check(x, 17, 16, 16, 1, 0, True, direction="INV")
+    assert info["kernel_name"] != NAME, info
+
+
+@pytest.mark.parametrize("log2n,dw,tw", [(17, 16, 16), (18, 15, 16), (20, 16, 16), (17, 19, 16)])
+def test_long_unscaled_int32_first_round_of_the_last_pass(log2n, dw, tw, monkeypatch):
+    """STAGE 7 .. 4 on the int32 butterflies where their widths allow (DATA_WIDTH + NFFT - 4 <= 32: k_wide16_p2<.., R32>) = the same stages on
+    64-bit words (INTFFT_NO_WIDELONG_R32) = the oracle.  (17, 19): 32-bit outputs of STAGE 4 exactly; wider data takes the 64-bit round by itself."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(1, n, dw, 900 + log2n + dw), edge_frames(n, dw)[[4]]])
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME, info
+    a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    monkeypatch.setenv("INTFFT_NO_WIDELONG_R32", "1")
+    b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+    assert ib["kernel_name"] == NAME and np.array_equal(a, b), ib
