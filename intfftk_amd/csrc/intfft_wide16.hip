@@ -343,8 +343,8 @@ template <int L, bool IN64 = false, bool NAT = false, int XS = 0, bool R32 = fal
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
                                                    const WideArgs a, const W2Consts k, size_t nframes_user)
 {
-    static_assert(XS == 0 || (L == 16 && !NAT && !IN64 && XS <= 4), "long frames: whole 2^16-point blocks, natural order, int32 scratch");
-    static_assert(!R32 || XS > 0, "int32 first round: instantiated for the long frames only");
+    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
+    static_assert(!R32 || (XS > 0 && !IN64), "int32 first round: instantiated for the long frames only");
     constexpr int G = 1 << (16 - L);
     const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
     constexpr int X = L - 16 + XS;                     // a.st[] entry of STAGE 15 - k is X + k
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         asm volatile("" : "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
         if constexpr (IN64) { // 16 bytes per sample
             typedef i64 v2li __attribute__((ext_vector_type(2)));
-            const v2li *src64 = reinterpret_cast<const v2li *>(scr) + f * 65536 + 4096 * r0;
+            const v2li *src64 = XS ? reinterpret_cast<const v2li *>(scr) + (f << (16 + XS)) + 4096 * (r0 & 15) + 16 * (r0 >> 4) : reinterpret_cast<const v2li *>(scr) + f * 65536 + 4096 * r0;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const v2li x = *at32(src64 + 256 * q, tid_l);
@@ -895,14 +895,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // the three-plane LDS transpose of the <= 36-bit values between the rounds -- and k_wide16_p2 / k_wide16_q2 read their scratch as 64-bit words
 // (IN64).  Results up to 48 bits (the 16-bit
 // high plane of the second pass's transpose).
-template <int L, bool NAT = false>
+template <int L, bool NAT = false, int XS = 0> // XS > 0: the 2^16-point blocks of N = 2^(16 + XS) behind k_wide_pre (intfft_widelong.hip), as in k_wide16_p1
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_p1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
     constexpr int G = 1 << (16 - L);
     const size_t nframes = (nframes_user + G - 1) / G;
-    constexpr int X = L - 16;
+    constexpr int X = L - 16 + XS;
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
     const int tile = blockIdx.x & 15;

@@ -115,7 +115,7 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
 {
     constexpr int LX = 16 + XS, TILES = 256 / (16 >> XS);
     int2 *const scr_a = static_cast<int2 *>(scratch);
-    int2 *const scr_b = scr_a + (nframes << LX); // the plan's scratch frames are 16 bytes per sample: two int32-pair halves
+    int2 *const scr_b = scr_a + (nframes << LX); // the plan's scratch frames: an int32-pair part A, then part B (int32 pairs; 64-bit pairs behind k_wide64_p1)
     {
         const void *kern = in16 ? kptr(k_wide_pre<XS, true>) : kptr(k_wide_pre<XS, false>);
         size_t g = resident_blocks(kern, 256, 4) / TILES;
@@ -127,6 +127,20 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
             hipLaunchKernelGGL((k_wide_pre<XS, false>), dim3((unsigned)(g * TILES)), dim3(256), 0, stream, in, scr_a, tw_all, a, nframes);
     }
     const size_t nblocks = nframes << XS;
+    if (a.w64) { // DATA_WIDTH + NFFT - 8 > 32: STAGE 15 .. 8 on 64-bit words too (the class of k_wide64_p1), 16-byte samples in part B
+        WideArgs a1 = a;
+        a1.dw = a.dw + XS;
+        const size_t units = nblocks * 16;
+        size_t g = resident_blocks(kptr(k_wide64_p1<16, false, XS>), 256, 2) & ~(size_t)15;
+        if (g < 16) g = 16;
+        if (g > units) g = units;
+        hipLaunchKernelGGL((k_wide64_p1<16, false, XS>), dim3((unsigned)g), dim3(256), 0, stream, scr_a, reinterpret_cast<i64 *>(scr_b), tw_all, a1, nblocks);
+        const size_t units2 = nframes << (4 + XS);
+        size_t g2 = resident_blocks(kptr(k_wide16_p2<16, true, false, XS>), 256, 2);
+        if (g2 > units2) g2 = units2;
+        hipLaunchKernelGGL((k_wide16_p2<16, true, false, XS>), dim3((unsigned)g2), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
+        return hipGetLastError();
+    }
     {
         WideArgs a1 = a;
         a1.dw = a.dw + XS; // what the pre-pass wrote: values of DATA_WIDTH + XS bits (the wrap on load is then the identity)
@@ -148,12 +162,16 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
     return hipGetLastError();
 }
 
-bool widelong_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
+int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
-    // pass 1 within int32 (DATA_WIDTH + NFFT - 8 <= 32), results of 33 .. 40 bits in int64 containers; the per-stage conditions are the 24-bit class's
-    // (checked by the planner on the stage list)
-    return log2n >= 17 && log2n <= 20 && data_width >= 9 && data_width + log2n - 8 <= 32 && data_width + log2n > 32 && data_width + log2n <= 40 &&
-           twdl_width >= 16 && twdl_width <= 24 && format == 1 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0;
+    if (!(log2n >= 17 && log2n <= 20 && format == 1 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9)) return 0;
+    const int xs = log2n - 16;
+    if (data_width + log2n <= 32) return 0; // results in int32 containers: not this class
+    // class 1: pass 1 within int32 (DATA_WIDTH + NFFT - 8 <= 32), results of 33 .. 40 bits (the 24-bit class of k_wide16_p1 / p2)
+    if (data_width + log2n - 8 <= 32 && data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24) return 1;
+    // class 2: pass 0 within int32 (DATA_WIDTH + XS <= 32), passes 1 and 2 on 64-bit words (the class of k_wide64_p1), results up to 48 bits
+    if (data_width >= 17 && data_width + xs <= 32 && data_width + log2n <= 48 && twdl_width >= 8 && twdl_width <= 24) return 2;
+    return 0; // (the per-stage conditions are checked by the planner on the stage list)
 }
 
 hipError_t launch_widelong(int log2n, const WideArgs &a, int in_cb, const void *in, void *out, void *scratch, const int2 *tw_all, const int2 *h_tw,

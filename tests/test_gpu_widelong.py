@@ -80,3 +80,38 @@ def test_long_unscaled_int32_first_round_of_the_last_pass(log2n, dw, tw, monkeyp
     monkeypatch.setenv("INTFFT_NO_WIDELONG_R32", "1")
     b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
     assert ib["kernel_name"] == NAME and np.array_equal(a, b), ib
+
+
+NAME64 = "k_wide_pre+k_wide64_p1+k_wide16_p2"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(17, 24, 24, 2), (17, 28, 16, 1), (18, 24, 16, 1), (19, 22, 12, 1), (20, 24, 16, 1), (17, 20, 12, 3),
+                                               (20, 28, 16, 1), (18, 30, 16, 1), (17, 31, 8, 1)])
+def test_long_unscaled_64_bit_first_pass(log2n, dw, tw, batch, monkeypatch):
+    """DATA_WIDTH + NFFT - 8 > 32 (BASELINE config 3's 24-bit data at N = 2^17 .. 2^20) or twiddles below 16 bits: STAGE 15 .. 8 on 64-bit words
+    too (k_wide64_p1 on the blocks, 16-byte scratch samples), results up to 48 bits."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 800 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME64 and info["n_passes"] == 3 and info["out_container"] == 8 and info["in_container"] == 4, info
+    if log2n <= 17:
+        a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True)
+        monkeypatch.setenv("INTFFT_NO_WIDELONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True)
+        assert ib["kernel_name"] != NAME64 and np.array_equal(a, b), ib
+
+
+def test_long_unscaled_64_bit_first_pass_chunks_on_two_streams(monkeypatch):
+    log2n, dw, tw = 17, 24, 24
+    x = uniform_frames(5, 1 << log2n, dw, 43)
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", "6")  # 2 frames per chunk (24 bytes of scratch per sample)
+    info = check(x, log2n, dw, tw, 1, 0, True)
+    assert info["kernel_name"] == NAME64, info
+
+
+def test_long_unscaled_products_beyond_64_bits_stay_generic():
+    """DATA_WIDTH 24 under 24-bit twiddles at N = 2^20: the multiplier inputs reach 43 bits, 43 + 24 > 64 -- no exact 64-bit product; the generic
+    kernels (96-bit products) serve the plan, bit-exact."""
+    x = uniform_frames(1, 1 << 20, 24, 6)
+    info = check(x, 20, 24, 24, 1, 0, True)
+    assert info["kernel_name"] not in (NAME, NAME64), info

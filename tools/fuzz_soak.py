@@ -1,7 +1,7 @@
 """tools/fuzz_soak.py [seconds] [seed] -- open-ended parity fuzz on the GPU box (diagnostics; the seeded, bounded fuzz sets live in tests/).
 Random elaboratable generics (NFFT 3..20, DATA_WIDTH 4..64, TWDL_WIDTH 8..26, every mode / direction / XSERIES / order pair, ragged
 batches; now and then the 2-D scheme with a random split): whatever kernel the planner picks must equal the C oracle bit for bit.
-FUZZ_BIG=1: the multi-pass families; FUZZ_NATIVE=1: single cores in their own beat orders (HALVES / BITREV), widths weighted to the 32- / 64-bit word classes.
+FUZZ_BIG=1: the multi-pass families; FUZZ_LONG=1: the unscaled forward core at N = 2^17 .. 2^20; FUZZ_NATIVE=1: single cores in their own beat orders (HALVES / BITREV), widths weighted to the 32- / 64-bit word classes.
 Prints one line per mismatch (none expected) and a summary of the kernels that were exercised."""
 import collections
 import os
@@ -43,6 +43,10 @@ def main():
             in_o, out_o = (time_o, freq_o) if d == "FWD" else (freq_o, time_o)
             log2n = int(rng.choice([6, 7, 8, 9, 10, 10, 11, 11, 12, 12, 13, 14, 15, 16, 16, 17, 19, 20]))
             dw = int(rng.choice([16, 18, 24, 24, 28, 32, 32, 40, 48, int(rng.integers(4, 65))]))
+        if os.environ.get("FUZZ_LONG") == "1":  # int_fftNk FORMAT = 1 at N = 2^17 .. 2^20 (csrc/intfft_widelong.hip): both width classes and their borders
+            log2n, fmt, rnd, d, in_o, out_o = int(rng.integers(17, 21)), 1, 0, "FWD", "NATURAL", "NATURAL"
+            dw = int(rng.choice([16, 16, 14, 15, 13, 20, 24, 24, 28, int(rng.integers(9, 33))]))
+            tw = int(rng.choice([16, 16, 24, 12, int(rng.integers(8, 25))]))
         l1 = 0
         if big and log2n == 20 and rng.random() < 0.3:
             l1, log2n = 10, int(rng.choice([20, 20, 21, 21, 22, 22]))
