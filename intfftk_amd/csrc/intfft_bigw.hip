@@ -921,6 +921,7 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
 
 const char *bigw_kernel_name(int direction, int two_pass)
 {
+    if (two_pass == 2) return "k_bigw_pre+k_bigw_a/b"; // N = 2^17 .. 2^20
     return direction == 1 ? (two_pass ? "k_bigw_qb/qa" : "k_bigw_q3/q2/q1") : two_pass ? "k_bigw_a/b" : "k_bigw_p1/p2/p3";
 }
 
@@ -970,6 +971,18 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
                                 size_t nframes, hipStream_t stream)
 {
     if (a.inverse) return launch_bigw_inv<MODE, MASKED>(log2n, a, in, out, scr, tw, c, nframes, stream);
+    if (log2n > 16) { // N = 2^17 .. 2^20 (round 5, intfft_bigwlong.hip): STAGE NFFT-1 .. 16 in a pre-pass, then the two passes -- pass A in place on the 2^16-point blocks
+        const hipError_t e = launch_bigw_pre(log2n, MODE, a, in, scr, tw, nframes, stream);
+        if (e != hipSuccess) return e;
+        W32Args a1 = a;
+        a1.in16 = 0, a1.in_sh = 0; // the scratch holds wrapped int32 pairs
+        const size_t nblocks = nframes << (log2n - 16), nb2 = nframes << (log2n - 13);
+        if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
+        const unsigned ga = (unsigned)(nblocks < 256 ? nblocks : 256);
+        hipLaunchKernelGGL((k_bigw_a<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, scr, tw, a1, nblocks, ga);
+        hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
+        return hipGetLastError();
+    }
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
     if (a.two_pass) {
         const unsigned ga = (unsigned)(nvf < 256 ? nvf : 256);

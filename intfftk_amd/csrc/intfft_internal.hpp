@@ -173,7 +173,7 @@ struct W32Stage {
     int wosh;      // 32 - output width (round-mode sum / difference wrap)
 };
 struct W32Args {
-    W32Stage st[16]; // by STAGE number
+    W32Stage st[20]; // by STAGE number (16 .. 19: k_bigw_pre, intfft_bigwlong.hip)
     int in16, out16; // containers: 1 = int16 pairs, 0 = int32 pairs
     int in_sh;       // 32 - DATA_WIDTH
     int inverse;     // stage records describe int_ifftNk (DIT)
@@ -206,6 +206,9 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
 hipError_t launch_bigw(int log2n, int mode, const W32Args &a, const void *in, void *out, void *scratch, const int2 *tw_all,
                        const int2 *h_tw, size_t nframes, hipStream_t stream);
 const char *bigw_kernel_name(int direction, int two_pass);
+// the same class at N = 2^17 .. 2^20, forward: k_bigw_pre (STAGE NFFT-1 .. 16) + k_bigw_a<16> in place on the blocks + k_bigw_b (intfft_bigwlong.hip, round 5)
+bool bigw_long_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
+hipError_t launch_bigw_pre(int log2n, int mode, const W32Args &a, const void *in, int2 *scr, const int2 *tw, size_t nframes, hipStream_t stream);
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

@@ -992,11 +992,13 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                  w32inv_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
                                   p->out_order) &&
                  !diag_env("INTFFT_NO_FASTW32");
+    const bool bigw_long = bigw_long_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order, p->out_order) &&
+                           !diag_env("INTFFT_NO_BIGWLONG"); // N = 2^17 .. 2^20 (round 5): a pre-pass in front of the two passes
     pl->bigw = !generic_only &&
                !big20_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly,
                                 p->in_order, p->out_order) && // the packed three-pass kernels are faster where they apply
-               bigw_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
-                              p->out_order) &&
+               (bigw_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->direction, p->use_fly, p->in_order,
+                               p->out_order) || bigw_long) &&
                !diag_env("INTFFT_NO_FASTW32");
     if (pl->fastw32 || pl->fast4096w || pl->w32inv || pl->bigw) {
         std::vector<StageDesc> st;
@@ -1015,7 +1017,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 pl->w32args.out64 = 2;
                 tail = true;
             }
-            if (d.s < 0 || d.s > 15 || (!tail && (d.dtw > 32 || d.wo > 32 || d.mw > 32)) || d.sh_a + d.sh_b > 31 ||
+            if (d.s < 0 || d.s > 19 || (!tail && (d.dtw > 32 || d.wo > 32 || d.mw > 32)) || d.sh_a + d.sh_b > 31 ||
                 d.mw + p->twdl_width > (tail ? 63 : 62)) {
                 pl->fastw32 = pl->fast4096w = pl->w32inv = pl->bigw = false;
                 break;
@@ -1031,6 +1033,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         if (pl->w32args.out64) pl->w32inv = pl->bigw = false; // 64-bit tail: forward wave / block kernels only
         if (pl->w32args.out64 == 2) pl->fastw32 = false;        // the 64-bit last round: the block kernel only
         pl->w32args.two_pass = pl->bigw && !diag_env("INTFFT_NO_TWOPASS");
+        if (pl->bigw && p->log2n > 16) pl->w32args.two_pass = 2; // the long frames: always the pre-pass + the two passes
         if (pl->bigw) { // the cores' own orders: on the two-pass kernels only (round 5)
             pl->w32args.native = p->direction == INTFFT_INV ? ((p->out_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->in_order == INTFFT_ORDER_BITREV ? 2 : 0))
                                                              : ((p->in_order == INTFFT_ORDER_HALVES ? 1 : 0) | (p->out_order == INTFFT_ORDER_BITREV ? 2 : 0));
@@ -1368,7 +1371,7 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
         std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
         return INTFFT_OK;
     }
-    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : plan->widelong ? 3 : plan->wide16 ? 2 : (int)plan->passes.size();
+    info->n_passes = fast ? 1 : (plan->big_two_pass || (plan->bigw && plan->w32args.two_pass == 1)) ? 2 : ((plan->big20 && !plan->wide16) || plan->bigw) ? 3 : plan->widelong ? 3 : plan->wide16 ? 2 : (int)plan->passes.size();
     info->compute_word = (plan->fastw64 || plan->fastw64b) ? 8 : (plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv) ? 4 : (fast || (plan->big20 && !plan->wide16 && !plan->bigw)) ? 2 : plan->word;
     info->fast_path = fast ? 1 : 0;
     info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;

@@ -115,3 +115,43 @@ def test_long_unscaled_products_beyond_64_bits_stay_generic():
     x = uniform_frames(1, 1 << 20, 24, 6)
     info = check(x, 20, 24, 24, 1, 0, True)
     assert info["kernel_name"] not in (NAME, NAME64), info
+
+
+# ---- widths within 32 bits (csrc/intfft_bigwlong.hip): k_bigw_pre + k_bigw_a<16> in place on the blocks + k_bigw_b ----------------------------------------
+NAMEW = "k_bigw_pre+k_bigw_a/b"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,fmt,rnd,batch", [(17, 18, 18, 0, 0, 3), (17, 24, 24, 0, 1, 2), (18, 32, 24, 0, 0, 1), (18, 18, 16, 0, 1, 2),
+                                                       (19, 24, 16, 0, 0, 1), (19, 20, 25, 0, 1, 1), (20, 18, 18, 0, 0, 1), (20, 32, 16, 0, 1, 1),
+                                                       (17, 12, 16, 1, 0, 3), (18, 14, 16, 1, 0, 1), (19, 13, 24, 1, 0, 1), (20, 12, 16, 1, 0, 1),
+                                                       (17, 8, 16, 0, 0, 2), (17, 6, 12, 0, 1, 2), (18, 17, 26, 0, 0, 1), (17, 15, 16, 1, 0, 1)])
+def test_long_frames_within_32_bits(log2n, dw, tw, fmt, rnd, batch, monkeypatch):
+    """Every mode (scaled-truncate, scaled-round, unscaled) whose widths stay within 32 bits at N = 2^17 .. 2^20: int16 and int32 containers on either
+    side, single- and multi-DSP multiplier regimes, both twiddle series; bit-exact to the oracle and equal to the generic passes it replaces."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 600 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.FWD) != 0:
+            continue
+        info = check(x, log2n, dw, tw, fmt, rnd, new)
+        assert info["kernel_name"] == NAMEW and info["n_passes"] == 3, info
+        if log2n >= 19:
+            break
+    if log2n <= 18:
+        a, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, True)
+        monkeypatch.setenv("INTFFT_NO_BIGWLONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, fmt, rnd, True)
+        assert ib["kernel_name"] != NAMEW and np.array_equal(a, b), ib
+
+
+def test_long_frames_within_32_bits_several_chunks(monkeypatch):
+    log2n, dw, tw = 17, 18, 18
+    x = uniform_frames(7, 1 << log2n, dw, 44)
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", "2")  # 2 frames per chunk
+    info = check(x, log2n, dw, tw, 0, 0, True)
+    assert info["kernel_name"] == NAMEW, info
+
+
+def test_long_frames_16_bit_scaled_keep_the_packed_kernels():
+    _, info = run_gpu(uniform_frames(1, 1 << 17, 16, 2), 17, 16, 16, 0, 0, True)
+    assert info["kernel_name"] != NAMEW and "k_big2p_a" in info["kernel_name"], info
