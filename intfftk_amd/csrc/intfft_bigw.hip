@@ -921,7 +921,7 @@ bool bigw_supported(int log2n, int data_width, int twdl_width, int format, int d
 
 const char *bigw_kernel_name(int direction, int two_pass)
 {
-    if (two_pass == 2) return "k_bigw_pre+k_bigw_a/b"; // N = 2^17 .. 2^20
+    if (two_pass == 2) return direction == 1 ? "k_bigw_qb/qa+k_bigw_post" : "k_bigw_pre+k_bigw_a/b"; // N = 2^17 .. 2^20
     return direction == 1 ? (two_pass ? "k_bigw_qb/qa" : "k_bigw_q3/q2/q1") : two_pass ? "k_bigw_a/b" : "k_bigw_p1/p2/p3";
 }
 
@@ -931,6 +931,15 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
 {
     const size_t nb = nframes << (log2n - 12), cap = resident_blocks(kptr(k_bigw_q2<MODE, MASKED>), 256, 2, 0, false), nb3 = nframes << (log2n - 13);
     if (nb3 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (log2n > 16) { // N = 2^17 .. 2^20 (round 5, intfft_bigwlong.hip): the gather pass at L = NFFT, STAGE 8 .. 15 in place on the 2^16-point blocks, STAGE 16 .. in a post-pass
+        W32Args a1 = a;
+        a1.out16 = 0; // the scratch holds int32 pairs
+        const size_t nblocks = nframes << (log2n - 16);
+        const unsigned ga = (unsigned)(nblocks < 256 ? nblocks : 256);
+        hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
+        hipLaunchKernelGGL((k_bigw_qa<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, scr, tw, a1, nblocks, ga);
+        return launch_bigw_post(log2n, MODE, a, scr, out, tw, nframes, stream);
+    }
     if (a.two_pass) {
         const size_t nvfa = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);
         const unsigned ga = (unsigned)(nvfa < 256 ? nvfa : 256);

@@ -209,6 +209,7 @@ const char *bigw_kernel_name(int direction, int two_pass);
 // the same class at N = 2^17 .. 2^20, forward: k_bigw_pre (STAGE NFFT-1 .. 16) + k_bigw_a<16> in place on the blocks + k_bigw_b (intfft_bigwlong.hip, round 5)
 bool bigw_long_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order);
 hipError_t launch_bigw_pre(int log2n, int mode, const W32Args &a, const void *in, int2 *scr, const int2 *tw, size_t nframes, hipStream_t stream);
+hipError_t launch_bigw_post(int log2n, int mode, const W32Args &a, const int2 *scr, void *out, const int2 *tw, size_t nframes, hipStream_t stream);
 
 // two-pass kernels for N = 65536, 24-bit unscaled, int32 in -> int64 out (intfft_wide16.hip)
 struct WideStage {

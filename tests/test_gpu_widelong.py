@@ -155,3 +155,29 @@ def test_long_frames_within_32_bits_several_chunks(monkeypatch):
 def test_long_frames_16_bit_scaled_keep_the_packed_kernels():
     _, info = run_gpu(uniform_frames(1, 1 << 17, 16, 2), 17, 16, 16, 0, 0, True)
     assert info["kernel_name"] != NAMEW and "k_big2p_a" in info["kernel_name"], info
+
+
+NAMEWI = "k_bigw_qb/qa+k_bigw_post"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,fmt,rnd,batch", [(17, 18, 18, 0, 0, 3), (17, 24, 24, 0, 1, 2), (18, 32, 24, 0, 0, 1), (18, 18, 16, 0, 1, 2),
+                                                       (19, 24, 16, 0, 0, 1), (19, 20, 25, 0, 1, 1), (20, 18, 18, 0, 0, 1), (20, 32, 16, 0, 1, 1),
+                                                       (17, 12, 16, 1, 0, 3), (18, 14, 16, 1, 0, 1), (19, 13, 24, 1, 0, 1), (20, 12, 16, 1, 0, 1),
+                                                       (17, 8, 16, 0, 0, 2), (17, 6, 12, 0, 1, 2), (18, 17, 26, 0, 0, 1), (17, 15, 16, 1, 0, 1)])
+def test_long_frames_within_32_bits_inverse(log2n, dw, tw, fmt, rnd, batch, monkeypatch):
+    """int_ifftNk on the same class: k_bigw_qb at L = NFFT (bit-reversed gather + DIT STAGE 0 .. 7), k_bigw_qa<16> in place on the 2^16-point blocks
+    (STAGE 8 .. 15), k_bigw_post (STAGE 16 .. NFFT-1, natural order out)."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 650 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, fmt, rnd, new), C.INV) != 0:
+            continue
+        info = check(x, log2n, dw, tw, fmt, rnd, new, direction="INV")
+        assert info["kernel_name"] == NAMEWI and info["n_passes"] == 3, info
+        if log2n >= 19:
+            break
+    if log2n <= 18:
+        a, _ = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
+        monkeypatch.setenv("INTFFT_NO_BIGWLONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
+        assert ib["kernel_name"] != NAMEWI and np.array_equal(a, b), ib
