@@ -936,7 +936,9 @@ static hipError_t launch_bigw_inv(int log2n, const W32Args &a, const void *in, v
         a1.out16 = 0; // the scratch holds int32 pairs
         const size_t nblocks = nframes << (log2n - 16);
         const unsigned ga = (unsigned)(nblocks < 256 ? nblocks : 256);
-        hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
+        a1.native = 0; // the blocks in place: plain core positions (BITREV in: k_bigw_qb<NAT> at L = NFFT; HALVES out: k_bigw_post)
+        if (a.native & 2) hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED, true>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
+        else hipLaunchKernelGGL((k_bigw_qb<MODE, MASKED>), dim3((unsigned)nb3), dim3(512), 0, stream, in, scr, tw, c, a, log2n);
         hipLaunchKernelGGL((k_bigw_qa<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, scr, tw, a1, nblocks, ga);
         return launch_bigw_post(log2n, MODE, a, scr, out, tw, nframes, stream);
     }
@@ -984,12 +986,13 @@ static hipError_t launch_bigw_m(int log2n, const W32Args &a, const void *in, voi
         const hipError_t e = launch_bigw_pre(log2n, MODE, a, in, scr, tw, nframes, stream);
         if (e != hipSuccess) return e;
         W32Args a1 = a;
-        a1.in16 = 0, a1.in_sh = 0; // the scratch holds wrapped int32 pairs
+        a1.in16 = 0, a1.in_sh = 0, a1.native = 0; // the scratch holds wrapped int32 pairs at plain core positions (HALVES in: k_bigw_pre; BITREV out: k_bigw_b<NAT>)
         const size_t nblocks = nframes << (log2n - 16), nb2 = nframes << (log2n - 13);
         if (nb2 > 0x7fffffffull) return hipErrorInvalidValue;
         const unsigned ga = (unsigned)(nblocks < 256 ? nblocks : 256);
         hipLaunchKernelGGL((k_bigw_a<16, MODE, MASKED>), dim3(8u * ga), dim3(512), 0, stream, scr, scr, tw, a1, nblocks, ga);
-        hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
+        if (a.native & 2) hipLaunchKernelGGL((k_bigw_b<MODE, MASKED, true>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
+        else hipLaunchKernelGGL((k_bigw_b<MODE, MASKED>), dim3((unsigned)nb2), dim3(512), 0, stream, scr, out, tw, c, a, log2n);
         return hipGetLastError();
     }
     const size_t nvf = (nframes + ((size_t)1 << (16 - log2n)) - 1) >> (16 - log2n);

@@ -1,5 +1,5 @@
 // intfft_bigwlong.hip -- the general-width int32 class of intfft_bigw.hip at N = 2^17 .. 2^20 (round 5): int_fftNk with any DATA_WIDTH / TWDL_WIDTH / FORMAT /
-// RNDMODE whose widths stay within 32 bits (18- or 24-bit scaled data, 32-bit scaled data, narrow unscaled data), natural order in and out.  These lengths
+// RNDMODE whose widths stay within 32 bits (18- or 24-bit scaled data, 32-bit scaled data, narrow unscaled data), natural order or the cores' own beat orders.  These lengths
 // ran the generic k_pass<int32> passes (44-60 Gsample/s); intfft_bigw.hip stops at N = 2^16.
 //
 // N = 2^LX = B blocks of 2^16 points, B = 2^XS (int_fftNk.vhd:184-342: the DIF stages run STAGE LX-1 .. 0):
@@ -41,7 +41,31 @@ __global__ __launch_bounds__(256) void k_bigw_pre(const void *in, int2 *scr, con
         int re[16], im[16];
         unsigned toff = p0;
         asm volatile("" : "+v"(toff)); // opaque per iteration: the zero-extended offset stays one VGPR (intfft_device.hpp, at32)
-        if (a.in16) {
+        if (a.native & 1) { // HALVES order in (int_fftNk.vhd:15-21): beat (x[i], x[i + N/2]) = the blocks (b, b + B/2) at one position: adjacent samples, ONE access
+            if (a.in16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u *src = static_cast<const v2u *>(in) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v2u x = INTFFT_LD(at32(src + 65536 * b + 256 * i, toff));
+                        re[i * B + b] = (int)(x.x << a.in_sh) >> a.in_sh, im[i * B + b] = (int)(x.x << (a.in_sh - 16)) >> a.in_sh;
+                        re[i * B + b + B / 2] = (int)(x.y << a.in_sh) >> a.in_sh, im[i * B + b + B / 2] = (int)(x.y << (a.in_sh - 16)) >> a.in_sh;
+                    }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i *src = static_cast<const v4i *>(in) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v4i x = INTFFT_LD(at32(src + 65536 * b + 256 * i, toff));
+                        re[i * B + b] = (int)((u32)x.x << a.in_sh) >> a.in_sh, im[i * B + b] = (int)((u32)x.y << a.in_sh) >> a.in_sh;
+                        re[i * B + b + B / 2] = (int)((u32)x.z << a.in_sh) >> a.in_sh, im[i * B + b + B / 2] = (int)((u32)x.w << a.in_sh) >> a.in_sh;
+                    }
+            }
+        } else if (a.in16) {
             const u32 *src = static_cast<const u32 *>(in) + (f << LX);
 #pragma unroll
             for (int i = 0; i < P; ++i)
@@ -168,7 +192,29 @@ __global__ __launch_bounds__(256) void k_bigw_post(const int2 *scr, void *out, c
                         gfly_dit<MODE, false, MASKED>(re[i * B + g + j], im[i * B + g + j], re[i * B + g + j + H], im[i * B + g + j + H], wr[i][H - 1 + j], wi[i][H - 1 + j],
                                                       a.st[16 + ii]);
         }
-        if (a.out16) {
+        if (a.native & 1) { // HALVES order out (int_ifftNk.vhd:15-21): the blocks (b, b + B/2) of one position leave as one access
+            if (a.out16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                v2u *dst = static_cast<v2u *>(out) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v2u y = {((u32)re[i * B + b] & 0xFFFFu) | ((u32)im[i * B + b] << 16), ((u32)re[i * B + b + B / 2] & 0xFFFFu) | ((u32)im[i * B + b + B / 2] << 16)};
+                        __builtin_nontemporal_store(y, at32(dst + 65536 * b + 256 * i, toff));
+                    }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                v4i *dst = static_cast<v4i *>(out) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v4i y = {re[i * B + b], im[i * B + b], re[i * B + b + B / 2], im[i * B + b + B / 2]};
+                        __builtin_nontemporal_store(y, at32(dst + 65536 * b + 256 * i, toff));
+                    }
+            }
+        } else if (a.out16) {
             u32 *dst = static_cast<u32 *>(out) + (f << LX);
 #pragma unroll
             for (int i = 0; i < P; ++i)
@@ -226,8 +272,9 @@ hipError_t launch_bigw_post(int log2n, int mode, const W32Args &a, const int2 *s
 
 bool bigw_long_supported(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
-    return log2n >= 17 && log2n <= 20 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 && twdl_width <= 26 && (direction == 0 || direction == 1) &&
-           use_fly == 1 && in_order == 0 && out_order == 0;
+    return log2n >= 17 && log2n <= 20 && data_width >= 2 && data_width + format * log2n <= 32 && twdl_width >= 4 && twdl_width <= 26 && use_fly == 1 &&
+           (direction == 0 ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)                      // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
+                           : direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2));  // int_ifftNk: NATURAL | BITREV in, NATURAL | HALVES out
 }
 
 } // namespace intfft

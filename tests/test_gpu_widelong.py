@@ -181,3 +181,18 @@ def test_long_frames_within_32_bits_inverse(log2n, dw, tw, fmt, rnd, batch, monk
         monkeypatch.setenv("INTFFT_NO_BIGWLONG", "1")
         b, ib = run_gpu(x, log2n, dw, tw, fmt, rnd, True, direction="INV")
         assert ib["kernel_name"] != NAMEWI and np.array_equal(a, b), ib
+
+
+@pytest.mark.parametrize("log2n,dw,tw,fmt,rnd", [(17, 18, 18, 0, 0), (18, 24, 16, 0, 1), (19, 12, 16, 1, 0), (20, 18, 18, 0, 0), (17, 8, 16, 0, 0), (18, 32, 24, 0, 0)])
+@pytest.mark.parametrize("direction,time_o,freq_o", [("FWD", "HALVES", "BITREV"), ("FWD", "HALVES", "NATURAL"), ("FWD", "NATURAL", "BITREV"),
+                                                     ("INV", "HALVES", "BITREV"), ("INV", "NATURAL", "BITREV"), ("INV", "HALVES", "NATURAL")])
+def test_long_frames_within_32_bits_cores_own_orders(log2n, dw, tw, fmt, rnd, direction, time_o, freq_o):
+    """int_fftNk takes HALVES beats and emits BITREV order, int_ifftNk the reverse (int_fftNk.vhd:15-21): HALVES on k_bigw_pre / k_bigw_post (the blocks
+    b and b + B/2 of one position are adjacent samples: one access), BITREV on the NAT instantiations of k_bigw_b / k_bigw_qb at L = NFFT."""
+    if log2n >= 19 and (time_o, freq_o) != ("HALVES", "BITREV"):
+        pytest.skip("the mixed forms are covered at N = 2^17 / 2^18")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(1, n, dw, 660 + log2n + dw), edge_frames(n, dw)[[4]]])[:2 if log2n < 19 else 1]
+    in_o, out_o = (time_o, freq_o) if direction == "FWD" else (freq_o, time_o)
+    info = check(x, log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=in_o, out_order=out_o)
+    assert info["kernel_name"] == (NAMEW if direction == "FWD" else NAMEWI), info

@@ -107,6 +107,23 @@ ROWS.append(("16:24:12:1", "24-bit unscaled FWD, 12-bit twiddles (round 5: outsi
 ROWS.append(("10:56:16:1", "56-bit unscaled FWD (66-bit results, 16-byte containers)"))
 ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit results)"))
 
+# round 5: the long frames outside 16-bit scaled data (csrc/intfft_widelong.hip, csrc/intfft_bigwlong.hip)
+for L in (17, 18, 19, 20):
+    ROWS.append(("%d:16:16:1" % L, "16-bit unscaled FWD (%d-bit results; three launches, round 5)" % (16 + L)))
+ROWS.append(("17:20:16:1", "20-bit unscaled FWD (37-bit results; round 5)"))
+ROWS.append(("17:24:24:1", "24-bit unscaled FWD (41-bit results; 64-bit first pass on the blocks, round 5)"))
+ROWS.append(("20:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD (44-bit results; round 5)"))
+for L in (17, 20):
+    ROWS.append(("%d:18:18:0" % L, "18-bit scaled FWD (int32 words, pre-pass + two passes, round 5)"))
+    ROWS.append(("%d:18:18:0:0:INV" % L, "18-bit scaled INV (two passes + post-pass, round 5)"))
+ROWS.append(("17:24:24:0:1", "24-bit scaled-round FWD (round 5)"))
+ROWS.append(("18:32:24:0", "32-bit scaled FWD (round 5)"))
+ROWS.append(("18:32:24:0:0:INV", "32-bit scaled INV (round 5)"))
+ROWS.append(("17:12:16:1", "12-bit unscaled FWD (29-bit results; round 5)"))
+ROWS.append(("20:12:16:1", "12-bit unscaled FWD (32-bit results; round 5)"))
+ROWS.append(("17:12:16:1:0:INV", "12-bit unscaled INV (round 5)"))
+ROWS.append(("18:18:18:0:0:PAIR", "18-bit scaled PAIR (forward + inverse sub-plans on the long-frame kernels, round 5)"))
+
 NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out (native int_fftNk beats)"),
           ("12:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),
           ("16:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES in / BITREV out"),

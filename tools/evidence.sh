@@ -29,7 +29,7 @@ export TMPDIR=/tmp
 part_headline() { bash tools/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1; tail -5 gpurun_out/${TAG}_profile.log; }
 part_digests() {
   local specs=("$@")
-  [ ${#specs[@]} -eq 0 ] && specs=(C2 C3 C4 C5 20:16:16:0:0:FWD:10 21:16:16:0:0:FWD:10 21:16:16:0:0:INV:10 14:16:16:0 16:24:24:1:0:INV 19:16:16:0 16:32:16:1)
+  [ ${#specs[@]} -eq 0 ] && specs=(C2 C3 C4 C5 20:16:16:0:0:FWD:10 21:16:16:0:0:FWD:10 21:16:16:0:0:INV:10 14:16:16:0 16:24:24:1:0:INV 19:16:16:0 16:32:16:1 17:16:16:1 17:18:18:0)
   BENCH_STEPS=6 BENCH_RAMP_S=0.1 bash tools/pmc_digest.sh $TAG "${specs[@]}" > gpurun_out/${TAG}_pmc_digest.log 2>&1
   tail -20 gpurun_out/${TAG}_pmc_digest.log
 }
@@ -51,7 +51,7 @@ part_collect() {
   cp $G/prof_$TAG/digest.json $P/${TAG}_k_fft1024_pmc_digest.json
   cp $G/prof_$TAG/summary.txt $P/${TAG}_k_fft1024_rocprofv3_summary.txt
   declare -A nm=([C2]=C2 [C3]=C3 [C4]=C4 [C5]=C5 [20_16_16_0_0_FWD_10]=2d_n2pow20 [21_16_16_0_0_FWD_10]=2d_n2pow21 [21_16_16_0_0_INV_10]=2d_n2pow21_inv
-                 [14_16_16_0]=n2pow14_fwd [16_24_24_1_0_INV]=n2pow16_24bit_inv [19_16_16_0]=n2pow19_fwd [16_32_16_1]=n2pow16_32bit_fwd)
+                 [14_16_16_0]=n2pow14_fwd [16_24_24_1_0_INV]=n2pow16_24bit_inv [19_16_16_0]=n2pow19_fwd [16_32_16_1]=n2pow16_32bit_fwd [17_16_16_1]=n2pow17_16bit_unscaled_fwd [17_18_18_0]=n2pow17_18bit_scaled_fwd)
   for k in "${!nm[@]}"; do [ -f $G/pmc_$TAG/${k}_pmc_digest.json ] && cp $G/pmc_$TAG/${k}_pmc_digest.json $P/${TAG}_${nm[$k]}_pmc_digest.json; done
   cp $G/prof_cfg_$TAG/kernel_stats_compact.csv $P/${TAG}_other_configs_kernel_stats.csv
   grep '^{' $G/prof_cfg_$TAG/bench.log > $P/${TAG}_other_configs_rates.jsonl
