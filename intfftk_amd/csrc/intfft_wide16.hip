@@ -343,7 +343,7 @@ template <int L, bool IN64 = false, bool NAT = false, int XS = 0, bool R32 = fal
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide16_p2(const int2 *scr, i64 *out, const int2 *__restrict__ twt,
                                                    const WideArgs a, const W2Consts k, size_t nframes_user)
 {
-    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
+    static_assert(XS == 0 || (L == 16 && XS <= 4), "long frames: whole 2^16-point blocks");
     static_assert(!R32 || (XS > 0 && !IN64), "int32 first round: instantiated for the long frames only");
     constexpr int G = 1 << (16 - L);
     const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
@@ -511,13 +511,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < 16; ++t) hq[t] = xr0[ROWW * t];
-            v2l *dstp = reinterpret_cast<v2l *>(out) + (real << L) + 256 * ulow; // wave-uniform
+            v2l *dstp = reinterpret_cast<v2l *>(out) + (real << LX) + 256 * ulow; // wave-uniform
             unsigned tp = (unsigned)tid;
             asm volatile("" : "+v"(tp));
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const v2l y = {(i64)(((u64)(u32)(int)__builtin_amdgcn_sbfe((int)hq[t], 0, 16) << 32) | xl[t]), (i64)(((u64)(u32)((int)hq[t] >> 16) << 32) | yl[t])};
-                __builtin_nontemporal_store(y, at32(dstp + ((size_t)t << (L - 4)), tp));
+                // row t4 = t of the unit (XS > 0: block b = t >> (4 - XS), row r = ((t mod 2^(4-XS)) << (4 + XS)) | ulow of that block)
+                const size_t row_off = XS ? ((size_t)(t >> (4 - XS)) << 16) + ((size_t)(t & ((1 << (4 - XS)) - 1)) << (12 + XS)) : (size_t)t << (L - 4);
+                __builtin_nontemporal_store(y, at32(dstp + row_off, tp));
             }
             continue;
         }

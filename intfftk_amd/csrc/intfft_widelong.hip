@@ -1,5 +1,6 @@
 // intfft_widelong.hip -- int_fftNk with FORMAT = 1 (full bit growth) at N = 2^17 .. 2^20 (round 5): 16-bit ADC data through a long unscaled core,
-// 33 .. 36-bit results (and DATA_WIDTH 17 .. 20+ in int32 containers while DATA_WIDTH + NFFT <= 40), natural order in and out.  These lengths ran the
+// 33 .. 36-bit results (and DATA_WIDTH 17 .. 20+ in int32 containers while DATA_WIDTH + NFFT <= 40), natural order or the core's own beat orders (HALVES in: one
+// access per block pair in k_wide_pre; BITREV out: the NAT instantiations of k_wide16_p2).  These lengths ran the
 // generic k_pass<int64> passes (three or four passes on 16-byte words: ~50 Gsample/s); the 24-bit class of intfft_wide16.hip stops at N = 2^16.
 //
 // N = 2^LX = B blocks of 2^16 points, B = 2^XS, n = 65536 b + 256 r + c (int_fftNk.vhd:184-342: the DIF stages run STAGE LX-1 .. 0, stage ii has
@@ -64,7 +65,31 @@ __global__ __launch_bounds__(256) void k_wide_pre(const void *in, int2 *scr, con
         int re[16], im[16];
         unsigned toff = p0;
         asm volatile("" : "+v"(toff)); // opaque per iteration (see k_wide16_p1)
-        if constexpr (IN16) {
+        if (a.native & 1) { // HALVES order in (int_fftNk.vhd:15-21): beat (x[i], x[i + N/2]) = the blocks (b, b + B/2) at one position: adjacent samples, ONE access
+            if constexpr (IN16) {
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const v2u *src = static_cast<const v2u *>(in) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v2u x = INTFFT_LD(at32(src + 65536 * b + 256 * i, toff));
+                        re[i * B + b] = __builtin_amdgcn_sbfe((int)x.x, 0, a.dw), im[i * B + b] = __builtin_amdgcn_sbfe((int)x.x, 16, a.dw);
+                        re[i * B + b + B / 2] = __builtin_amdgcn_sbfe((int)x.y, 0, a.dw), im[i * B + b + B / 2] = __builtin_amdgcn_sbfe((int)x.y, 16, a.dw);
+                    }
+            } else {
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                const v4i *src = static_cast<const v4i *>(in) + (f << (LX - 1));
+#pragma unroll
+                for (int i = 0; i < P; ++i)
+#pragma unroll
+                    for (int b = 0; b < B / 2; ++b) {
+                        const v4i x = INTFFT_LD(at32(src + 65536 * b + 256 * i, toff));
+                        re[i * B + b] = __builtin_amdgcn_sbfe(x.x, 0, a.dw), im[i * B + b] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
+                        re[i * B + b + B / 2] = __builtin_amdgcn_sbfe(x.z, 0, a.dw), im[i * B + b + B / 2] = __builtin_amdgcn_sbfe(x.w, 0, a.dw);
+                    }
+            }
+        } else if constexpr (IN16) {
             const u32 *src = static_cast<const u32 *>(in) + (f << LX);
 #pragma unroll
             for (int i = 0; i < P; ++i)
@@ -129,7 +154,7 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
     const size_t nblocks = nframes << XS;
     if (a.w64) { // DATA_WIDTH + NFFT - 8 > 32: STAGE 15 .. 8 on 64-bit words too (the class of k_wide64_p1), 16-byte samples in part B
         WideArgs a1 = a;
-        a1.dw = a.dw + XS;
+        a1.dw = a.dw + XS, a1.native = 0;
         const size_t units = nblocks * 16;
         size_t g = resident_blocks(kptr(k_wide64_p1<16, false, XS>), 256, 2) & ~(size_t)15;
         if (g < 16) g = 16;
@@ -138,12 +163,15 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
         const size_t units2 = nframes << (4 + XS);
         size_t g2 = resident_blocks(kptr(k_wide16_p2<16, true, false, XS>), 256, 2);
         if (g2 > units2) g2 = units2;
-        hipLaunchKernelGGL((k_wide16_p2<16, true, false, XS>), dim3((unsigned)g2), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
+        if (a.native & 2) // BITREV order out: the NAT instantiation (16 x 16 exchange through the planes, rows of the unit across the blocks)
+            hipLaunchKernelGGL((k_wide16_p2<16, true, true, XS>), dim3((unsigned)g2), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
+        else
+            hipLaunchKernelGGL((k_wide16_p2<16, true, false, XS>), dim3((unsigned)g2), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
         return hipGetLastError();
     }
     {
         WideArgs a1 = a;
-        a1.dw = a.dw + XS; // what the pre-pass wrote: values of DATA_WIDTH + XS bits (the wrap on load is then the identity)
+        a1.dw = a.dw + XS, a1.native = 0; // what the pre-pass wrote: values of DATA_WIDTH + XS bits (the wrap on load is then the identity) at plain core positions
         const size_t units = nblocks * 16;
         size_t g = resident_blocks(kptr(k_wide16_p1<16, false, XS>), 256, 2) & ~(size_t)15;
         if (g < 16) g = 16;
@@ -154,7 +182,12 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
         const size_t units = nframes << (4 + XS);
         size_t g = resident_blocks(a.r32 ? kptr(k_wide16_p2<16, false, false, XS, true>) : kptr(k_wide16_p2<16, false, false, XS>), 256, 2);
         if (g > units) g = units;
-        if (a.r32)
+        if (a.native & 2) {
+            if (a.r32)
+                hipLaunchKernelGGL((k_wide16_p2<16, false, true, XS, true>), dim3((unsigned)g), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
+            else
+                hipLaunchKernelGGL((k_wide16_p2<16, false, true, XS>), dim3((unsigned)g), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
+        } else if (a.r32)
             hipLaunchKernelGGL((k_wide16_p2<16, false, false, XS, true>), dim3((unsigned)g), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
         else
             hipLaunchKernelGGL((k_wide16_p2<16, false, false, XS>), dim3((unsigned)g), dim3(256), 0, stream, scr_b, static_cast<i64 *>(out), tw_all, a, k, nframes);
@@ -164,7 +197,9 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
 
 int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
-    if (!(log2n >= 17 && log2n <= 20 && format == 1 && direction == 0 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9)) return 0;
+    if (!(log2n >= 17 && log2n <= 20 && format == 1 && direction == 0 && use_fly == 1 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1) &&
+          data_width >= 9))
+        return 0; // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
     const int xs = log2n - 16;
     if (data_width + log2n <= 32) return 0; // results in int32 containers: not this class
     // class 1: pass 1 within int32 (DATA_WIDTH + NFFT - 8 <= 32), results of 33 .. 40 bits (the 24-bit class of k_wide16_p1 / p2)

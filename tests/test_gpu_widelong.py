@@ -58,11 +58,11 @@ def test_long_unscaled_chunks_on_two_streams(monkeypatch):
 
 
 def test_long_unscaled_class_boundaries():
-    """Outside the class the generic passes serve the plan: results of at most 32 bits (int32 containers out), other orders, the inverse."""
+    """Outside the class the generic passes serve the plan: results of at most 32 bits (the int32 class), the BITREV_LANES order, the inverse."""
     _, info = run_gpu(uniform_frames(1, 1 << 17, 12, 3), 17, 12, 16, 1, 0, True)  # 29-bit results
     assert info["kernel_name"] != NAME, info
     x = uniform_frames(1, 1 << 17, 16, 4)
-    info = check(x, 17, 16, 16, 1, 0, True, out_order="BITREV")
+    info = check(x, 17, 16, 16, 1, 0, True, out_order="BITREV_LANES")
     assert info["kernel_name"] != NAME, info
     info = check(x, 17, 16, 16, 1, 0, True, direction="INV")
     assert info["kernel_name"] != NAME, info
@@ -196,3 +196,16 @@ def test_long_frames_within_32_bits_cores_own_orders(log2n, dw, tw, fmt, rnd, di
     in_o, out_o = (time_o, freq_o) if direction == "FWD" else (freq_o, time_o)
     info = check(x, log2n, dw, tw, fmt, rnd, True, direction=direction, in_order=in_o, out_order=out_o)
     assert info["kernel_name"] == (NAMEW if direction == "FWD" else NAMEWI), info
+
+
+@pytest.mark.parametrize("log2n,dw,tw", [(17, 16, 16), (18, 16, 24), (19, 14, 16), (20, 16, 16), (17, 24, 24), (18, 28, 16), (20, 24, 16), (17, 20, 16)])
+@pytest.mark.parametrize("in_o,out_o", [("HALVES", "BITREV"), ("HALVES", "NATURAL"), ("NATURAL", "BITREV")])
+def test_long_unscaled_core_own_orders(log2n, dw, tw, in_o, out_o):
+    """int_fftNk(NFFT = 17 .. 20, FORMAT = 1) as the RTL instantiates it -- HALVES beats in, BITREV order out (int_fftNk.vhd:15-21) -- on both width classes:
+    one access per block pair in k_wide_pre, the NAT instantiations of k_wide16_p2 (rows of a unit across the blocks)."""
+    if log2n >= 19 and (in_o, out_o) != ("HALVES", "BITREV"):
+        pytest.skip("the mixed forms are covered at N = 2^17 / 2^18")
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(1, n, dw, 670 + log2n + dw), edge_frames(n, dw)[[4]]])[:2 if log2n < 19 else 1]
+    info = check(x, log2n, dw, tw, 1, 0, True, in_order=in_o, out_order=out_o)
+    assert info["kernel_name"] in (NAME, NAME64), info
