@@ -160,7 +160,12 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("7:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
           ("12:32:16:1", ("HALVES", "BITREV"), "32-bit unscaled FWD (44-bit results), HALVES in / BITREV out (round 5)"),
           ("12:32:16:1:0:INV", ("BITREV", "HALVES"), "32-bit unscaled INV, BITREV in / HALVES out (round 5)"),
-          ("11:40:16:0", ("HALVES", "BITREV"), "40-bit scaled FWD, HALVES in / BITREV out (round 5)")]
+          ("11:40:16:0", ("HALVES", "BITREV"), "40-bit scaled FWD, HALVES in / BITREV out (round 5)"),
+          ("17:16:16:1", ("HALVES", "BITREV"), "16-bit unscaled FWD (33-bit results), HALVES in / BITREV out (long frames, round 5)"),
+          ("20:16:16:1", ("HALVES", "BITREV"), "16-bit unscaled FWD (36-bit results), HALVES in / BITREV out (long frames, round 5)"),
+          ("17:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD (41-bit results), HALVES in / BITREV out (long frames, round 5)"),
+          ("17:18:18:0", ("HALVES", "BITREV"), "18-bit scaled FWD, HALVES in / BITREV out (long frames, round 5)"),
+          ("17:18:18:0:0:INV", ("BITREV", "HALVES"), "18-bit scaled INV, BITREV in / HALVES out (long frames, round 5)")]
 
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
