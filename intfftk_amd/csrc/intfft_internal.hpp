@@ -235,7 +235,7 @@ int wide16_class(int log2n, int data_width, int twdl_width, int format, int dire
 // the same class at N = 2^17 .. 2^20: a pre-pass for STAGE NFFT-1 .. 16, then the two passes on 2^16-point blocks (intfft_widelong.hip, round 5)
 int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order); // 0 none, 1 / 2 as wide16_class
 hipError_t launch_widelong(int log2n, const WideArgs &a, int in_cb, const void *in, void *out, void *scratch, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream);
+                           size_t nframes, hipStream_t stream, int direction = 0);
 
 // three-pass packed int16 kernels for N = 2^20 forward, natural -> natural (intfft_big20.hip)
 bool big20_supported(int log2n, int data_width, int twdl_width, int format, int rndmode, int direction, int use_fly,

@@ -611,12 +611,17 @@ __device__ __forceinline__ void wdstage64(i64 (&re)[16], i64 (&im)[16], const in
         }
 }
 
-template <int L, bool NAT = false>
+// XS > 0 (round 5, intfft_widelong.hip): N = 2^LX, LX = 16 + XS -- the unit's 16 rows (b, jtop) across the B = 2^XS blocks as in k_wide16_p2<.., XS>: the gather is
+// the L = 16 one with LX in place of L, the store goes to the blocks' own [r0][c7..4][j][c3..0] layouts (what k_wide16_q2<16> reads block by block).  IN16: int16 containers
+// (DATA_WIDTH <= 16).
+template <int L, bool NAT = false, int XS = 0, bool IN16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wide16_q1(const int2 *in, int2 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              const W2Consts k, size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    static_assert((XS == 0 && !IN16) || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
     constexpr int G = 1 << (16 - L);
+    constexpr int LX = L + XS;
     const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
@@ -648,21 +653,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const u32 *const rd0 = lds + ROWW * hi4 + lo4;
     const u32 *const rd1 = rd0 + PLANEW;
 
-    const size_t units = nframes * 16; // work unit u = 16 f + (g, low)
+    const size_t units = nframes << (4 + XS); // work unit u = 16 f + (g, low)   (XS > 0: u = (f << (4 + XS)) + ulow)
     for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
-        const size_t f = u >> 4;
-        const int r0 = (int)(u & 15);
-        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t f = u >> (4 + XS);
+        const int r0 = (int)(u & ((16u << XS) - 1u));
+        const int ug = XS ? 0 : r0 >> (L - 12), ulow = XS ? r0 : r0 & ((1 << (L - 12)) - 1);
         const size_t real = f * G + (size_t)ug; // the real frame these 16 rows belong to
         if (L < 16 && real >= nframes_user) continue;
         typedef int v2i __attribute__((ext_vector_type(2)));
         // position (r' = 2^(L-12) t4 + low, c) takes X[brev_L] = in[2^(L-4) rev4(c3..0) + 2^(L-8) rev4(c7..4) + 16 brev_(L-12)(low) + rev4(t4)]
-        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
-        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << L) + 16 * rlow; // wave-uniform
-        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (LX - 12)));
+        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << LX) + 16 * rlow; // wave-uniform
+        unsigned toff = (unsigned)((rev4w(hi4) << (LX - 8)) + rev4w(lo4));
+        // the thread's part of the scratch index: tid in the unit's own 4096-sample region; XS > 0: block b = hi4 >> (4 - XS), row j = (jtop << XS) | (ulow >> 4)
+        unsigned tid_l = XS ? (unsigned)((hi4 >> (4 - XS)) * 65536 + 16 * ((hi4 & ((1 << (4 - XS)) - 1)) << XS) + lo4) : (unsigned)tid;
         asm volatile("" : "+v"(toff), "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
         int re[16], im[16];
-        if (NAT && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = c, registers = t4), then the 16 x 16 exchange
+        if constexpr (IN16) {
+            const u32 *src16 = reinterpret_cast<const u32 *>(in) + (real << LX) + 16 * rlow;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const u32 x = *at32(src16 + ((size_t)rev4w(q) << (LX - 4)), toff);
+                re[q] = __builtin_amdgcn_sbfe((int)x, 0, a.dw);
+                im[q] = __builtin_amdgcn_sbfe((int)x, 16, a.dw);
+            }
+        } else if (NAT && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = c, registers = t4), then the 16 x 16 exchange
             const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << L) + 256 * ulow; // wave-uniform
             u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4, *const xw1 = xw0 + PLANEW; // + ROWW * t4
             const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid), *const xr1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff); // (plain: the sixteen 8-byte pieces of a 128-byte line come from sixteen lanes of one instruction)
+                const v2i x = *at32(src + ((size_t)rev4w(q) << (LX - 4)), toff); // (plain: the sixteen 8-byte pieces of a 128-byte line come from sixteen lanes of one instruction)
                 re[q] = __builtin_amdgcn_sbfe(x.x, 0, a.dw); // conv_std_logic_vector(.., DATA_WIDTH): wrap on load
                 im[q] = __builtin_amdgcn_sbfe(x.y, 0, a.dw);
             }
@@ -728,7 +743,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         wdstage32<4>(re, im, w6r, w6i, a.st[6]);
         wdstage32<8>(re, im, w7r, w7i, a.st[7]);
         // scratch, the forward layout: unit r0 = [c7..4 = q][t4 = hi4][c3..0 = lo4]: 2 KiB per register
-        v2i *dst = reinterpret_cast<v2i *>(scr) + f * 65536 + 4096 * r0;
+        v2i *dst = XS ? reinterpret_cast<v2i *>(scr) + (f << (16 + XS)) + 4096 * (r0 & 15) + 16 * (r0 >> 4) : reinterpret_cast<v2i *>(scr) + f * 65536 + 4096 * r0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const v2i y = {re[q], im[q]};

@@ -195,8 +195,104 @@ static hipError_t launch_long(const WideArgs &a, const W2Consts &k, bool in16, c
     return hipGetLastError();
 }
 
+// ---- the inverse of class 1 (int_ifftNk.vhd:183-341, DIT STAGE 0 .. LX-1): k_wide16_q1<16, ., XS> (bit-reversed gather at L = LX + STAGE 0 .. 7 on int32, rows of a
+// unit across the blocks), k_wide16_q2<16> on the blocks (STAGE 8 .. 15 on 64-bit words; its natural-order store goes to scratch part C), then STAGE 16 .. LX-1 here on
+// 64-bit words: scratch C -> user array, natural order.  Thread / tile shape of k_wide_pre.  Pass traffic 4 + 8, 8 + 16, 16 + 16 = 68 B/sample (int16 containers in).
+template <int XS>
+__global__ __launch_bounds__(256) void k_wide_post(const i64 *scr, i64 *out, const int2 *__restrict__ twt, const WideArgs a, size_t nframes)
+{
+    static_assert(XS >= 1 && XS <= 4, "N = 2^17 .. 2^20");
+    constexpr int LX = 16 + XS, B = 1 << XS, P = 16 >> XS, TILES = 256 / P;
+    const int tid = threadIdx.x;
+    const unsigned tile = blockIdx.x % TILES;
+    const unsigned p0 = 256u * P * tile + (unsigned)tid;
+    int wr[P][B - 1], wi[P][B - 1]; // [i][H - 1 + j]: STAGE 16 + log2 H pairs (b, b + H), index (b mod H) 65536 + p
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int H = 1; H < B; H <<= 1)
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const int2 w = twt[(size_t)65536 * H - 1 + (size_t)65536 * j + p0 + 256u * i];
+                wr[i][H - 1 + j] = w.x, wi[i][H - 1 + j] = w.y;
+            }
+    typedef i64 v2l __attribute__((ext_vector_type(2)));
+    const size_t fstep = gridDim.x / TILES;
+    for (size_t f = blockIdx.x / TILES; f < nframes; f += fstep) {
+        i64 re[16], im[16];
+        unsigned toff = p0;
+        asm volatile("" : "+v"(toff));
+        const v2l *src = reinterpret_cast<const v2l *>(scr) + (f << LX);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const v2l x = INTFFT_LD(at32(src + 65536 * b + 256 * i, toff));
+                re[i * B + b] = x.x, im[i * B + b] = x.y;
+            }
+#pragma unroll
+        for (int ii = 0; ii < XS; ++ii) {
+            const int H = 1 << ii;
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int g = 0; g < B; g += 2 * H)
+#pragma unroll
+                    for (int j = 0; j < H; ++j)
+                        wdit64<false>(re[i * B + g + j], im[i * B + g + j], re[i * B + g + j + H], im[i * B + g + j + H], wr[i][H - 1 + j], wi[i][H - 1 + j], a.st[16 + ii]);
+        }
+        v2l *dst = reinterpret_cast<v2l *>(out) + (f << LX);
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const v2l y = {re[i * B + b], im[i * B + b]};
+                __builtin_nontemporal_store(y, at32(dst + 65536 * b + 256 * i, toff));
+            }
+    }
+}
+
+template <int XS>
+static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in16, const void *in, void *out, void *scratch, const int2 *tw_all, size_t nframes,
+                                  hipStream_t stream)
+{
+    constexpr int LX = 16 + XS, TILES = 256 / (16 >> XS);
+    int2 *const scr_a = static_cast<int2 *>(scratch);                    // k_wide16_q1's output: int32 pairs in the blocks' unit layouts
+    i64 *const scr_c = reinterpret_cast<i64 *>(scr_a + (nframes << LX)); // k_wide16_q2's output: 64-bit pairs at the core positions
+    const size_t nblocks = nframes << XS;
+    {
+        const size_t units = nframes << (4 + XS);
+        size_t g = resident_blocks(in16 ? kptr(k_wide16_q1<16, false, XS, true>) : kptr(k_wide16_q1<16, false, XS, false>), 256, 2);
+        if (g > units) g = units;
+        if (in16)
+            hipLaunchKernelGGL((k_wide16_q1<16, false, XS, true>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
+        else
+            hipLaunchKernelGGL((k_wide16_q1<16, false, XS, false>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
+    }
+    {
+        WideArgs a1 = a;
+        a1.native = 0;
+        const size_t units = nblocks * 16;
+        size_t g = resident_blocks(kptr(k_wide16_q2<16, false, false>), 256, 2) & ~(size_t)15;
+        if (g < 16) g = 16;
+        if (g > units) g = units;
+        hipLaunchKernelGGL((k_wide16_q2<16, false, false>), dim3((unsigned)g), dim3(256), 0, stream, scr_a, scr_c, tw_all, a1, nblocks);
+    }
+    {
+        size_t g = resident_blocks(kptr(k_wide_post<XS>), 256, 3) / TILES;
+        if (g < 1) g = 1;
+        if (g > nframes) g = nframes;
+        hipLaunchKernelGGL((k_wide_post<XS>), dim3((unsigned)(g * TILES)), dim3(256), 0, stream, scr_c, static_cast<i64 *>(out), tw_all, a, nframes);
+    }
+    return hipGetLastError();
+}
+
 int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
+    if (direction == 1) // int_ifftNk, class 1 only (round 5): STAGE 0 .. 7 within int32, results of 33 .. 40 bits, natural order
+        return log2n >= 17 && log2n <= 20 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9 && data_width + 8 <= 32 &&
+                       data_width + log2n > 32 && data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24
+                   ? 1 : 0;
     if (!(log2n >= 17 && log2n <= 20 && format == 1 && direction == 0 && use_fly == 1 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1) &&
           data_width >= 9))
         return 0; // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out
@@ -210,13 +306,21 @@ int widelong_class(int log2n, int data_width, int twdl_width, int format, int di
 }
 
 hipError_t launch_widelong(int log2n, const WideArgs &a, int in_cb, const void *in, void *out, void *scratch, const int2 *tw_all, const int2 *h_tw,
-                           size_t nframes, hipStream_t stream)
+                           size_t nframes, hipStream_t stream, int direction)
 {
     if (nframes == 0) return hipSuccess;
     W2Consts k;
     for (int i = 0; i < 8; ++i) k.wr3[i] = h_tw[7 + i].x, k.wi3[i] = h_tw[7 + i].y;
     for (int i = 0; i < 4; ++i) k.wr2[i] = h_tw[3 + i].x, k.wi2[i] = h_tw[3 + i].y;
     const bool in16 = in_cb == 2;
+    if (direction == 1) {
+        switch (log2n) {
+        case 17: return launch_long_inv<1>(a, k, in16, in, out, scratch, tw_all, nframes, stream);
+        case 18: return launch_long_inv<2>(a, k, in16, in, out, scratch, tw_all, nframes, stream);
+        case 19: return launch_long_inv<3>(a, k, in16, in, out, scratch, tw_all, nframes, stream);
+        default: return launch_long_inv<4>(a, k, in16, in, out, scratch, tw_all, nframes, stream);
+        }
+    }
     switch (log2n) {
     case 17: return launch_long<1>(a, k, in16, in, out, scratch, tw_all, nframes, stream);
     case 18: return launch_long<2>(a, k, in16, in, out, scratch, tw_all, nframes, stream);

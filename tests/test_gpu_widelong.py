@@ -58,14 +58,14 @@ def test_long_unscaled_chunks_on_two_streams(monkeypatch):
 
 
 def test_long_unscaled_class_boundaries():
-    """Outside the class the generic passes serve the plan: results of at most 32 bits (the int32 class), the BITREV_LANES order, the inverse."""
+    """Outside the class the generic passes serve the plan: results of at most 32 bits (the int32 class), the BITREV_LANES order, the inverse from BITREV order."""
     _, info = run_gpu(uniform_frames(1, 1 << 17, 12, 3), 17, 12, 16, 1, 0, True)  # 29-bit results
     assert info["kernel_name"] != NAME, info
     x = uniform_frames(1, 1 << 17, 16, 4)
     info = check(x, 17, 16, 16, 1, 0, True, out_order="BITREV_LANES")
     assert info["kernel_name"] != NAME, info
-    info = check(x, 17, 16, 16, 1, 0, True, direction="INV")
-    assert info["kernel_name"] != NAME, info
+    info = check(x, 17, 16, 16, 1, 0, True, direction="INV", in_order="BITREV")
+    assert info["kernel_name"] not in (NAME, "k_wide16_q1+q2+k_wide_post"), info
 
 
 @pytest.mark.parametrize("log2n,dw,tw", [(17, 16, 16), (18, 15, 16), (20, 16, 16), (17, 19, 16)])
@@ -209,3 +209,35 @@ def test_long_unscaled_core_own_orders(log2n, dw, tw, in_o, out_o):
     x = np.concatenate([uniform_frames(1, n, dw, 670 + log2n + dw), edge_frames(n, dw)[[4]]])[:2 if log2n < 19 else 1]
     info = check(x, log2n, dw, tw, 1, 0, True, in_order=in_o, out_order=out_o)
     assert info["kernel_name"] in (NAME, NAME64), info
+
+
+NAMEI = "k_wide16_q1+q2+k_wide_post"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(17, 16, 16, 3), (17, 16, 24, 1), (18, 16, 16, 2), (18, 15, 18, 1), (19, 16, 16, 1), (19, 17, 16, 2),
+                                               (20, 16, 16, 1), (20, 20, 24, 1), (17, 20, 16, 2), (17, 23, 24, 1), (18, 22, 16, 1), (17, 18, 16, 5)])
+def test_long_unscaled_inverse(log2n, dw, tw, batch, monkeypatch):
+    """int_ifftNk with FORMAT = 1 at N = 2^17 .. 2^20 and results of 33 .. 40 bits: k_wide16_q1<16, ., XS> (the gather at L = NFFT, rows of a unit across the
+    blocks; int16 or int32 containers in), k_wide16_q2<16> on the blocks, k_wide_post (STAGE 16 .. NFFT-1 on 64-bit words)."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 750 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    for new in (True, False):
+        if C.lib().orc_validate(C.make_params(log2n, dw, tw, 1, 0, new), C.INV) != 0:
+            continue
+        info = check(x, log2n, dw, tw, 1, 0, new, direction="INV")
+        assert info["kernel_name"] == NAMEI and info["n_passes"] == 3 and info["out_container"] == 8, info
+        if log2n >= 19:
+            break
+    if log2n <= 17:
+        a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+        monkeypatch.setenv("INTFFT_NO_WIDELONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+        assert ib["kernel_name"] != NAMEI and np.array_equal(a, b), ib
+
+
+def test_long_unscaled_inverse_chunks_on_two_streams(monkeypatch):
+    log2n, dw, tw = 17, 16, 16
+    x = uniform_frames(5, 1 << log2n, dw, 45)
+    monkeypatch.setenv("INTFFT_SCRATCH_MB", "6")  # 2 frames per chunk (24 bytes of scratch per sample)
+    info = check(x, log2n, dw, tw, 1, 0, True, direction="INV")
+    assert info["kernel_name"] == NAMEI, info

@@ -111,6 +111,8 @@ ROWS.append(("10:58:12:1:0:INV", "58-bit unscaled INV, 12-bit twiddles (68-bit r
 for L in (17, 18, 19, 20):
     ROWS.append(("%d:16:16:1" % L, "16-bit unscaled FWD (%d-bit results; three launches, round 5)" % (16 + L)))
 ROWS.append(("17:20:16:1", "20-bit unscaled FWD (37-bit results; round 5)"))
+for L in (17, 20):
+    ROWS.append(("%d:16:16:1:0:INV" % L, "16-bit unscaled INV (%d-bit results; gather pass, block pass, 64-bit post-pass, round 5)" % (16 + L)))
 ROWS.append(("17:24:24:1", "24-bit unscaled FWD (41-bit results; 64-bit first pass on the blocks, round 5)"))
 ROWS.append(("20:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD (44-bit results; round 5)"))
 for L in (17, 20):
