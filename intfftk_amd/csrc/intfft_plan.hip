@@ -1191,7 +1191,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 w.az = d.sh_a == 0;
                 w.s2 = w.s3 = 0;
                 w.w32 = wslice - 32;
-                if (pl->widelong && i < LL - 16) { // k_wide_pre (int32): the slice of wo <= 32 bits
+                if (pl->widelong && !inv && i < LL - 16) { // k_wide_pre (int32, forward): the slice of wo <= 32 bits
                     w.s3 = 32 - wslice;
                     if (w.s3 < 0 || w.s3 > 31) pl->wide16 = false;
                 }
@@ -1246,7 +1246,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (!pl->wide16) pl->widelong = false;
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s",
-                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->widelong ? (p->direction == INTFFT_INV ? "k_wide16_q1+q2+k_wide_post" : pl->wargs.w64 ? "k_wide_pre+k_wide64_p1+k_wide16_p2" : "k_wide_pre+k_wide16_p1+p2") : pl->wide16 ? wide16_kernel_name(p->direction, pl->wargs.w64) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
+                      pl->bigw ? bigw_kernel_name(p->direction, pl->w32args.two_pass) : pl->widelong ? (p->direction == INTFFT_INV ? (pl->wargs.w64 ? "k_wide64_q1+k_wide16_q2+k_wide_post" : "k_wide16_q1+q2+k_wide_post") : pl->wargs.w64 ? "k_wide_pre+k_wide64_p1+k_wide16_p2" : "k_wide_pre+k_wide16_p1+p2") : pl->wide16 ? wide16_kernel_name(p->direction, pl->wargs.w64) : big2x ? big2x_kernel_name() : big2x_inv ? "k_big2x_qb/k_big2x_qa" : pl->big20 ? big20_kernel_name(p->direction, (big2p || big2p_pair) ? 2 : (pl->big_two_pass || pl->big_pair256), (p->direction == INTFFT_INV ? p->in_order : p->out_order) == INTFFT_ORDER_BITREV) : pl->word == 2 ? pass16_kernel_name() : pass_kernel_name(pl->word));
         if (l1) std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", pass_kernel_name(pl->word));
         // narrow data (DATA_WIDTH 9 .. 15) on the packed multi-pass kernels: int16 scratch words and the packed twiddle forms, as word == 2
         const bool narrow_big = pl->big20 && p->data_width != 16;
@@ -1263,7 +1263,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         }
         if (pl->passes.size() > 1 || pl->big20 || pl->bigw || pl->wide16) {
             // scratch words: int32 for the general-width three-pass kernels, else the (first) pass word
-            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->widelong && (pl->wargs.w64 || p->direction == INTFFT_INV)) ? 12 : (pl->wide16 && (pl->wargs.w64 || pl->widelong)) ? 8 : pl->wide16 ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)(pl->bigw ? 4 : (pl->widelong && pl->wargs.w64 && p->direction == INTFFT_INV) ? 16 : (pl->widelong && (pl->wargs.w64 || p->direction == INTFFT_INV)) ? 12 : (pl->wide16 && (pl->wargs.w64 || pl->widelong)) ? 8 : pl->wide16 ? 4 : (pl->word == 2 || narrow_big) ? 2 : pl->passes[0].word);
             // two scratch halves on two streams where the passes of a plan differ in what bounds them (the two-pass plans of N = 2^19 / 2^20:
             // a latency-bound column pass beside a bandwidth-bound row pass; the 24-bit-class kernels: +7 % and +8 %); the other
             // multi-pass families lose 1-9 % that way (measured) and keep one 256 MiB scratch on the caller's stream

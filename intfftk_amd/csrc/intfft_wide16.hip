@@ -1097,12 +1097,14 @@ __device__ __forceinline__ void wdstage64u(i64 (&re)[16], i64 (&im)[16], const i
         }
 }
 
-template <int L, bool NAT = false>
+template <int L, bool NAT = false, int XS = 0> // XS > 0: N = 2^(16 + XS), the rows of a unit across the blocks (see k_wide16_q1)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_wide64_q1(const int2 *in, i64 *scr, const int2 *__restrict__ twt, const WideArgs a,
                                                                                              const W2Consts k, size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
+    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
     constexpr int G = 1 << (16 - L);
+    constexpr int LX = L + XS;
     const size_t nframes = (nframes_user + G - 1) / G;
     __shared__ __attribute__((aligned(16))) u32 lds[2 * PLANEW];
     const int tid = threadIdx.x, lo4 = tid & 15, hi4 = tid >> 4;
@@ -1132,17 +1134,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const u32 *const rd0 = lds + ROWW * hi4 + lo4;
     const u32 *const rd1 = rd0 + PLANEW;
 
-    const size_t units = nframes * 16;
+    const size_t units = nframes << (4 + XS);
     for (size_t u = blockIdx.x; u < units; u += gridDim.x) {
-        const size_t f = u >> 4;
-        const int r0 = (int)(u & 15);
-        const int ug = r0 >> (L - 12), ulow = r0 & ((1 << (L - 12)) - 1);
+        const size_t f = u >> (4 + XS);
+        const int r0 = (int)(u & ((16u << XS) - 1u));
+        const int ug = XS ? 0 : r0 >> (L - 12), ulow = XS ? r0 : r0 & ((1 << (L - 12)) - 1);
         const size_t real = f * G + (size_t)ug;
         if (L < 16 && real >= nframes_user) continue;
         typedef int v2i __attribute__((ext_vector_type(2)));
-        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (L - 12)));
-        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << L) + 16 * rlow;
-        unsigned toff = (unsigned)((rev4w(hi4) << (L - 8)) + rev4w(lo4)), tid_l = (unsigned)tid;
+        const int rlow = (int)(__brev((unsigned)ulow) >> (32 - (LX - 12)));
+        const v2i *src = reinterpret_cast<const v2i *>(in) + (real << LX) + 16 * rlow;
+        unsigned toff = (unsigned)((rev4w(hi4) << (LX - 8)) + rev4w(lo4));
+        unsigned tid_l = XS ? (unsigned)((hi4 >> (4 - XS)) * 65536 + 16 * ((hi4 & ((1 << (4 - XS)) - 1)) << XS) + lo4) : (unsigned)tid;
         asm volatile("" : "+v"(toff), "+v"(tid_l));
         i64 re[16], im[16];
         auto wrap = [&](int x) { return a.dw >= 32 ? x : (int)__builtin_amdgcn_sbfe(x, 0, a.dw); }; // (the builtin returns unsigned)
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const v2i x = *at32(src + ((size_t)rev4w(q) << (L - 4)), toff);
+                const v2i x = *at32(src + ((size_t)rev4w(q) << (LX - 4)), toff);
                 re[q] = wrap(x.x);
                 im[q] = wrap(x.y);
             }
@@ -1225,7 +1228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         wdstage64<4>(re, im, w6r, w6i, a.st[6]);
         wdstage64<8>(re, im, w7r, w7i, a.st[7]);
         typedef i64 v2l __attribute__((ext_vector_type(2)));
-        v2l *dst = reinterpret_cast<v2l *>(scr) + f * 65536 + 4096 * r0;
+        v2l *dst = XS ? reinterpret_cast<v2l *>(scr) + (f << (16 + XS)) + 4096 * (r0 & 15) + 16 * (r0 >> 4) : reinterpret_cast<v2l *>(scr) + f * 65536 + 4096 * r0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const v2l y = {re[q], im[q]};

@@ -257,9 +257,22 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
                                   hipStream_t stream)
 {
     constexpr int LX = 16 + XS, TILES = 256 / (16 >> XS);
-    int2 *const scr_a = static_cast<int2 *>(scratch);                    // k_wide16_q1's output: int32 pairs in the blocks' unit layouts
-    i64 *const scr_c = reinterpret_cast<i64 *>(scr_a + (nframes << LX)); // k_wide16_q2's output: 64-bit pairs at the core positions
+    int2 *const scr_a = static_cast<int2 *>(scratch);                    // k_wide16_q1's output: int32 pairs in the blocks' unit layouts (class 2: 64-bit pairs)
+    i64 *const scr_c = reinterpret_cast<i64 *>(scr_a + ((nframes << LX) << (a.w64 ? 1 : 0))); // k_wide16_q2's output: 64-bit pairs at the core positions
     const size_t nblocks = nframes << XS;
+    if (a.w64) { // class 2: DATA_WIDTH + 8 > 32 or twiddles below 16 bits -- STAGE 0 .. 7 on 64-bit words too (k_wide64_q1), 16-byte samples in part A
+        const size_t units = nframes << (4 + XS);
+        size_t g = resident_blocks(kptr(k_wide64_q1<16, false, XS>), 256, 2);
+        if (g > units) g = units;
+        hipLaunchKernelGGL((k_wide64_q1<16, false, XS>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), reinterpret_cast<i64 *>(scr_a), tw_all, a, k, nframes);
+        WideArgs a1 = a;
+        a1.native = 0;
+        const size_t units2 = nblocks * 16;
+        size_t g2 = resident_blocks(kptr(k_wide16_q2<16, true, false>), 256, 2) & ~(size_t)15;
+        if (g2 < 16) g2 = 16;
+        if (g2 > units2) g2 = units2;
+        hipLaunchKernelGGL((k_wide16_q2<16, true, false>), dim3((unsigned)g2), dim3(256), 0, stream, scr_a, scr_c, tw_all, a1, nblocks);
+    } else {
     {
         const size_t units = nframes << (4 + XS);
         size_t g = resident_blocks(in16 ? kptr(k_wide16_q1<16, false, XS, true>) : kptr(k_wide16_q1<16, false, XS, false>), 256, 2);
@@ -278,6 +291,7 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
         if (g > units) g = units;
         hipLaunchKernelGGL((k_wide16_q2<16, false, false>), dim3((unsigned)g), dim3(256), 0, stream, scr_a, scr_c, tw_all, a1, nblocks);
     }
+    }
     {
         size_t g = resident_blocks(kptr(k_wide_post<XS>), 256, 3) / TILES;
         if (g < 1) g = 1;
@@ -289,10 +303,12 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
 
 int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
-    if (direction == 1) // int_ifftNk, class 1 only (round 5): STAGE 0 .. 7 within int32, results of 33 .. 40 bits, natural order
-        return log2n >= 17 && log2n <= 20 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9 && data_width + 8 <= 32 &&
-                       data_width + log2n > 32 && data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24
-                   ? 1 : 0;
+    if (direction == 1) { // int_ifftNk, natural order (round 5)
+        if (!(log2n >= 17 && log2n <= 20 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9 && data_width + log2n > 32)) return 0;
+        // class 1: STAGE 0 .. 7 within int32, results of 33 .. 40 bits; class 2: every stage on 64-bit words (int32 containers in), results up to 48 bits
+        if (data_width + 8 <= 32 && data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24) return 1;
+        return data_width >= 17 && data_width <= 32 && data_width + log2n <= 48 && twdl_width >= 8 && twdl_width <= 24 ? 2 : 0;
+    }
     if (!(log2n >= 17 && log2n <= 20 && format == 1 && direction == 0 && use_fly == 1 && (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1) &&
           data_width >= 9))
         return 0; // int_fftNk: NATURAL | HALVES in, NATURAL | BITREV out

@@ -475,6 +475,7 @@ WS_CASES = [
     (17, 16, 16, 1, 0, "FWD", 0, 7, 4),     # long unscaled frames: pre-pass + the two wide passes, two scratch parts, two streams (round 5)
     (17, 24, 24, 1, 0, "FWD", 0, 5, 6),     # ... with the 64-bit first pass (24 bytes of scratch per sample)
     (17, 16, 16, 1, 0, "INV", 0, 5, 6),     # ... the inverse: gather pass, block pass, 64-bit post-pass
+    (17, 24, 24, 1, 0, "INV", 0, 3, 8),     # ... the inverse on 64-bit words throughout (32 bytes of scratch per sample)
     (18, 18, 18, 0, 0, "FWD", 0, 5, 4),     # long general-width frames: pre-pass + pass A in place + pass B (round 5)
     (17, 18, 18, 0, 1, "INV", 0, 7, 2),     # ... and the inverse
 ]

@@ -241,3 +241,22 @@ def test_long_unscaled_inverse_chunks_on_two_streams(monkeypatch):
     monkeypatch.setenv("INTFFT_SCRATCH_MB", "6")  # 2 frames per chunk (24 bytes of scratch per sample)
     info = check(x, log2n, dw, tw, 1, 0, True, direction="INV")
     assert info["kernel_name"] == NAMEI, info
+
+
+NAMEI64 = "k_wide64_q1+k_wide16_q2+k_wide_post"
+
+
+@pytest.mark.parametrize("log2n,dw,tw,batch", [(17, 24, 24, 2), (17, 28, 16, 1), (18, 24, 16, 1), (19, 25, 12, 1), (20, 24, 16, 1), (17, 20, 12, 3),
+                                               (20, 28, 16, 1), (18, 30, 16, 1), (17, 31, 8, 1)])
+def test_long_unscaled_inverse_64_bit_first_pass(log2n, dw, tw, batch, monkeypatch):
+    """The inverse beyond class 1 (24-bit data at N = 2^17 .. 2^20, twiddles below 16 bits): every stage on 64-bit words -- k_wide64_q1<16, ., XS> +
+    k_wide16_q2<16, IN64> on the blocks + k_wide_post; results up to 48 bits."""
+    n = 1 << log2n
+    x = np.concatenate([uniform_frames(batch, n, dw, 850 + log2n + dw), edge_frames(n, dw)[[0, 4]]])[:batch + (1 if log2n < 19 else 0)]
+    info = check(x, log2n, dw, tw, 1, 0, True, direction="INV")
+    assert info["kernel_name"] == NAMEI64 and info["n_passes"] == 3 and info["out_container"] == 8 and info["in_container"] == 4, info
+    if log2n <= 17:
+        a, _ = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+        monkeypatch.setenv("INTFFT_NO_WIDELONG", "1")
+        b, ib = run_gpu(x, log2n, dw, tw, 1, 0, True, direction="INV")
+        assert ib["kernel_name"] != NAMEI64 and np.array_equal(a, b), ib

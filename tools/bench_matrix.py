@@ -115,6 +115,7 @@ for L in (17, 20):
     ROWS.append(("%d:16:16:1:0:INV" % L, "16-bit unscaled INV (%d-bit results; gather pass, block pass, 64-bit post-pass, round 5)" % (16 + L)))
 ROWS.append(("17:24:24:1", "24-bit unscaled FWD (41-bit results; 64-bit first pass on the blocks, round 5)"))
 ROWS.append(("20:24:16:1", "24-bit data / 16-bit twiddle unscaled FWD (44-bit results; round 5)"))
+ROWS.append(("17:24:24:1:0:INV", "24-bit unscaled INV (41-bit results; every stage on 64-bit words, round 5)"))
 for L in (17, 20):
     ROWS.append(("%d:18:18:0" % L, "18-bit scaled FWD (int32 words, pre-pass + two passes, round 5)"))
     ROWS.append(("%d:18:18:0:0:INV" % L, "18-bit scaled INV (two passes + post-pass, round 5)"))
