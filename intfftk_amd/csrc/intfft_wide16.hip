@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                                                              const W2Consts k, size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
-    static_assert((XS == 0 && !IN16) || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
+    static_assert((XS == 0 && !IN16) || (L == 16 && XS >= 1 && XS <= 4), "long frames: whole 2^16-point blocks");
     constexpr int G = 1 << (16 - L);
     constexpr int LX = L + XS;
     const size_t nframes = (nframes_user + G - 1) / G; // virtual frames
@@ -669,22 +669,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unsigned tid_l = XS ? (unsigned)((hi4 >> (4 - XS)) * 65536 + 16 * ((hi4 & ((1 << (4 - XS)) - 1)) << XS) + lo4) : (unsigned)tid;
         asm volatile("" : "+v"(toff), "+v"(tid_l)); // (opaque per iteration, see k_wide16_p1)
         int re[16], im[16];
-        if constexpr (IN16) {
-            const u32 *src16 = reinterpret_cast<const u32 *>(in) + (real << LX) + 16 * rlow;
+        // BITREV order: row t4 = t of the unit sits t << (L-4) positions up (XS > 0: block b = t >> (4 - XS), row ((t mod 2^(4-XS)) << (4 + XS)) | ulow of that block)
+        auto row_off = [&](int t) -> size_t { return XS ? ((size_t)(t >> (4 - XS)) << 16) + ((size_t)(t & ((1 << (4 - XS)) - 1)) << (12 + XS)) : (size_t)t << (L - 4); };
+        unsigned tid_c = (unsigned)tid;
+        asm volatile("" : "+v"(tid_c));
+        if (NAT && IN16 && (a.native & 2)) { // BITREV order in, int16 containers: one plane of packed samples through the exchange
+            const u32 *srcp = reinterpret_cast<const u32 *>(in) + (real << LX) + 256 * ulow; // wave-uniform
+            u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4; // + ROWW * t4
+            const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid);
+            __syncthreads(); // the previous unit's transpose reads are done
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const u32 x = *at32(src16 + ((size_t)rev4w(q) << (LX - 4)), toff);
-                re[q] = __builtin_amdgcn_sbfe((int)x, 0, a.dw);
-                im[q] = __builtin_amdgcn_sbfe((int)x, 16, a.dw);
+            for (int t = 0; t < 16; ++t) xw0[ROWW * t] = INTFFT_LD(at32(srcp + row_off(t), tid_c));
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 x = xr0[q];
+                re[4 * q] = __builtin_amdgcn_sbfe((int)x.x, 0, a.dw), im[4 * q] = __builtin_amdgcn_sbfe((int)x.x, 16, a.dw);
+                re[4 * q + 1] = __builtin_amdgcn_sbfe((int)x.y, 0, a.dw), im[4 * q + 1] = __builtin_amdgcn_sbfe((int)x.y, 16, a.dw);
+                re[4 * q + 2] = __builtin_amdgcn_sbfe((int)x.z, 0, a.dw), im[4 * q + 2] = __builtin_amdgcn_sbfe((int)x.z, 16, a.dw);
+                re[4 * q + 3] = __builtin_amdgcn_sbfe((int)x.w, 0, a.dw), im[4 * q + 3] = __builtin_amdgcn_sbfe((int)x.w, 16, a.dw);
             }
-        } else if (NAT && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = c, registers = t4), then the 16 x 16 exchange
-            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << L) + 256 * ulow; // wave-uniform
+        } else if (NAT && !IN16 && (a.native & 2)) { // BITREV order in: memory index = core position; coalesced loads (thread = c, registers = t4), then the 16 x 16 exchange
+            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << LX) + 256 * ulow; // wave-uniform
             u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4, *const xw1 = xw0 + PLANEW; // + ROWW * t4
             const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid), *const xr1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
             __syncthreads(); // the previous unit's transpose reads are done
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const v2i x = INTFFT_LD(at32(srcp + ((size_t)t << (L - 4)), tid_l));
+                const v2i x = INTFFT_LD(at32(srcp + row_off(t), tid_c));
                 xw0[ROWW * t] = (u32)x.x, xw1[ROWW * t] = (u32)x.y;
             }
             __syncthreads();
@@ -695,6 +707,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 re[4 * q + 2] = __builtin_amdgcn_sbfe((int)x.z, 0, a.dw), re[4 * q + 3] = __builtin_amdgcn_sbfe((int)x.w, 0, a.dw);
                 im[4 * q] = __builtin_amdgcn_sbfe((int)y.x, 0, a.dw), im[4 * q + 1] = __builtin_amdgcn_sbfe((int)y.y, 0, a.dw);
                 im[4 * q + 2] = __builtin_amdgcn_sbfe((int)y.z, 0, a.dw), im[4 * q + 3] = __builtin_amdgcn_sbfe((int)y.w, 0, a.dw);
+            }
+        } else if constexpr (IN16) {
+            const u32 *src16 = reinterpret_cast<const u32 *>(in) + (real << LX) + 16 * rlow;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const u32 x = *at32(src16 + ((size_t)rev4w(q) << (LX - 4)), toff);
+                re[q] = __builtin_amdgcn_sbfe((int)x, 0, a.dw);
+                im[q] = __builtin_amdgcn_sbfe((int)x, 16, a.dw);
             }
         } else {
 #pragma unroll
@@ -1102,7 +1122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                                                              const W2Consts k, size_t nframes_user)
 {
     static_assert(L >= 13 && L <= 16, "virtual 2^16-point frames");
-    static_assert(XS == 0 || (L == 16 && !NAT && XS <= 4), "long frames: whole 2^16-point blocks, natural order");
+    static_assert(XS == 0 || (L == 16 && XS <= 4), "long frames: whole 2^16-point blocks");
     constexpr int G = 1 << (16 - L);
     constexpr int LX = L + XS;
     const size_t nframes = (nframes_user + G - 1) / G;
@@ -1150,13 +1170,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         i64 re[16], im[16];
         auto wrap = [&](int x) { return a.dw >= 32 ? x : (int)__builtin_amdgcn_sbfe(x, 0, a.dw); }; // (the builtin returns unsigned)
         if (NAT && (a.native & 2)) { // BITREV order in (see k_wide16_q1)
-            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << L) + 256 * ulow;
+            auto row_off = [&](int t) -> size_t { return XS ? ((size_t)(t >> (4 - XS)) << 16) + ((size_t)(t & ((1 << (4 - XS)) - 1)) << (12 + XS)) : (size_t)t << (L - 4); };
+            unsigned tid_c = (unsigned)tid;
+            asm volatile("" : "+v"(tid_c));
+            const v2i *srcp = reinterpret_cast<const v2i *>(in) + (real << LX) + 256 * ulow;
             u32 *const xw0 = lds + ROWW * (16 * hi4) + lo4, *const xw1 = xw0 + PLANEW;
             const uint4 *const xr0 = reinterpret_cast<const uint4 *>(lds + ROWW * tid), *const xr1 = reinterpret_cast<const uint4 *>(lds + PLANEW + ROWW * tid);
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const v2i x = INTFFT_LD(at32(srcp + ((size_t)t << (L - 4)), tid_l));
+                const v2i x = INTFFT_LD(at32(srcp + row_off(t), tid_c));
                 xw0[ROWW * t] = (u32)x.x, xw1[ROWW * t] = (u32)x.y;
             }
             __syncthreads();

@@ -241,6 +241,18 @@ __global__ __launch_bounds__(256) void k_wide_post(const i64 *scr, i64 *out, con
                     for (int j = 0; j < H; ++j)
                         wdit64<false>(re[i * B + g + j], im[i * B + g + j], re[i * B + g + j + H], im[i * B + g + j + H], wr[i][H - 1 + j], wi[i][H - 1 + j], a.st[16 + ii]);
         }
+        if (a.native & 1) { // HALVES order out (int_ifftNk.vhd:15-21): the blocks (b, b + B/2) of one position leave as one 32-byte access
+            typedef i64 v4l __attribute__((ext_vector_type(4)));
+            v4l *dst4 = reinterpret_cast<v4l *>(out) + (f << (LX - 1));
+#pragma unroll
+            for (int i = 0; i < P; ++i)
+#pragma unroll
+                for (int b = 0; b < B / 2; ++b) {
+                    const v4l y = {re[i * B + b], im[i * B + b], re[i * B + b + B / 2], im[i * B + b + B / 2]};
+                    __builtin_nontemporal_store(y, at32(dst4 + 65536 * b + 256 * i, toff));
+                }
+            continue;
+        }
         v2l *dst = reinterpret_cast<v2l *>(out) + (f << LX);
 #pragma unroll
         for (int i = 0; i < P; ++i)
@@ -264,7 +276,10 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
         const size_t units = nframes << (4 + XS);
         size_t g = resident_blocks(kptr(k_wide64_q1<16, false, XS>), 256, 2);
         if (g > units) g = units;
-        hipLaunchKernelGGL((k_wide64_q1<16, false, XS>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), reinterpret_cast<i64 *>(scr_a), tw_all, a, k, nframes);
+        if (a.native & 2) // BITREV order in: the NAT instantiation (rows of a unit across the blocks)
+            hipLaunchKernelGGL((k_wide64_q1<16, true, XS>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), reinterpret_cast<i64 *>(scr_a), tw_all, a, k, nframes);
+        else
+            hipLaunchKernelGGL((k_wide64_q1<16, false, XS>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), reinterpret_cast<i64 *>(scr_a), tw_all, a, k, nframes);
         WideArgs a1 = a;
         a1.native = 0;
         const size_t units2 = nblocks * 16;
@@ -277,7 +292,12 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
         const size_t units = nframes << (4 + XS);
         size_t g = resident_blocks(in16 ? kptr(k_wide16_q1<16, false, XS, true>) : kptr(k_wide16_q1<16, false, XS, false>), 256, 2);
         if (g > units) g = units;
-        if (in16)
+        if (a.native & 2) { // BITREV order in
+            if (in16)
+                hipLaunchKernelGGL((k_wide16_q1<16, true, XS, true>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
+            else
+                hipLaunchKernelGGL((k_wide16_q1<16, true, XS, false>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
+        } else if (in16)
             hipLaunchKernelGGL((k_wide16_q1<16, false, XS, true>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
         else
             hipLaunchKernelGGL((k_wide16_q1<16, false, XS, false>), dim3((unsigned)g), dim3(256), 0, stream, static_cast<const int2 *>(in), scr_a, tw_all, a, k, nframes);
@@ -303,8 +323,10 @@ static hipError_t launch_long_inv(const WideArgs &a, const W2Consts &k, bool in1
 
 int widelong_class(int log2n, int data_width, int twdl_width, int format, int direction, int use_fly, int in_order, int out_order)
 {
-    if (direction == 1) { // int_ifftNk, natural order (round 5)
-        if (!(log2n >= 17 && log2n <= 20 && format == 1 && use_fly == 1 && in_order == 0 && out_order == 0 && data_width >= 9 && data_width + log2n > 32)) return 0;
+    if (direction == 1) { // int_ifftNk (round 5)
+        if (!(log2n >= 17 && log2n <= 20 && format == 1 && use_fly == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2) && data_width >= 9 &&
+              data_width + log2n > 32))
+            return 0; // NATURAL | BITREV in, NATURAL | HALVES out
         // class 1: STAGE 0 .. 7 within int32, results of 33 .. 40 bits; class 2: every stage on 64-bit words (int32 containers in), results up to 48 bits
         if (data_width + 8 <= 32 && data_width + log2n <= 40 && twdl_width >= 16 && twdl_width <= 24) return 1;
         return data_width >= 17 && data_width <= 32 && data_width + log2n <= 48 && twdl_width >= 8 && twdl_width <= 24 ? 2 : 0;

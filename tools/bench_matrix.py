@@ -167,6 +167,7 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("17:16:16:1", ("HALVES", "BITREV"), "16-bit unscaled FWD (33-bit results), HALVES in / BITREV out (long frames, round 5)"),
           ("20:16:16:1", ("HALVES", "BITREV"), "16-bit unscaled FWD (36-bit results), HALVES in / BITREV out (long frames, round 5)"),
           ("17:24:24:1", ("HALVES", "BITREV"), "24-bit unscaled FWD (41-bit results), HALVES in / BITREV out (long frames, round 5)"),
+          ("17:16:16:1:0:INV", ("BITREV", "HALVES"), "16-bit unscaled INV, BITREV in / HALVES out (long frames, round 5)"),
           ("17:18:18:0", ("HALVES", "BITREV"), "18-bit scaled FWD, HALVES in / BITREV out (long frames, round 5)"),
           ("17:18:18:0:0:INV", ("BITREV", "HALVES"), "18-bit scaled INV, BITREV in / HALVES out (long frames, round 5)")]
 
