@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:  # independent translation units: compile them side by side, the long ones first (measured seconds on one core; unlisted: 10)
         from concurrent.futures import ThreadPoolExecutor
 
-        cost = {"intfft_bigw": 58, "intfft_w32inv": 38, "intfft_fastw64n": 34, "intfft_fastw64": 34, "intfft_fastw64bn": 34, "intfft_wide16": 29, "intfft_big2x": 27,
+        cost = {"intfft_bigw": 58, "intfft_w32inv": 38, "intfft_fastw64n": 34, "intfft_fastw64": 34, "intfft_fastw64bn": 34, "intfft_wide16": 29, "intfft_big2x": 27, "intfft_widelong": 23,
                 "intfft_fastw32": 26, "intfft_fastw64s": 21, "intfft_fast1024": 21, "intfft_fastw64sn": 21, "intfft_generic": 20, "intfft_fast16k": 20,
                 "intfft_fastw64bi": 19, "intfft_fast4096w": 19, "intfft_fastw64b": 16, "intfft_big20": 15, "intfft_fast1024x": 13, "intfft_fast1024ux": 12,
                 "intfft_fast4096": 12}

@@ -678,6 +678,10 @@ GUARD_CASES = [
     # ... and the 2-D plans of round 5 (a tenth field: log2 N1): the inverse and the pair at N = 2^21, the three-launch inverse at N = 2^22
     (21, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1, 10), (21, 16, 16, 0, 0, "PAIR", "NATURAL", "NATURAL", 1, 10), (22, 16, 16, 0, 0, "INV", "NATURAL", "HALVES", 1, 10),
     (21, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 10), (22, 16, 16, 0, 0, "FWD", "NATURAL", "NATURAL", 1, 11), (22, 16, 16, 0, 0, "INV", "NATURAL", "NATURAL", 1, 11),
+    # ... the long frames outside 16-bit scaled data (round 5): pre- / post-pass pair accesses, the last / first pass with its rows across the blocks
+    (17, 16, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 3), (18, 16, 16, 1, 0, "FWD", "HALVES", "BITREV", 1), (17, 24, 24, 1, 0, "FWD", "HALVES", "BITREV", 1),
+    (17, 16, 16, 1, 0, "INV", "BITREV", "HALVES", 1), (17, 24, 24, 1, 0, "INV", "NATURAL", "NATURAL", 1), (17, 18, 18, 0, 0, "FWD", "HALVES", "BITREV", 3),
+    (18, 18, 18, 0, 1, "INV", "BITREV", "HALVES", 1), (17, 12, 16, 1, 0, "FWD", "NATURAL", "NATURAL", 3),
 ]
 
 

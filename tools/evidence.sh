@@ -87,7 +87,7 @@ part_at32build() { # (CPU: cross-compiles)
   tools/build_variant_multi.sh at32chk "-DINTFFT_AT32_CHECK" $(cd intfftk_amd/csrc && ls *.hip)
 }
 part_at32check() {
-  INTFFT_LIB=$ROOT/build/variants/libintfft_at32chk.so timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_2d.py tests/test_gpu_fullsize.py -m gpu -x -q > gpurun_out/${TAG}_at32check.txt 2>&1
+  INTFFT_LIB=$ROOT/build/variants/libintfft_at32chk.so timeout 3000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_2d.py tests/test_gpu_fullsize.py tests/test_gpu_widelong.py -m gpu -x -q > gpurun_out/${TAG}_at32check.txt 2>&1
   tail -3 gpurun_out/${TAG}_at32check.txt
 }
 part_tilebench() {
