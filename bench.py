@@ -111,7 +111,7 @@ def pmc_digest(config="C2"):
 
 
 # ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
-def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0, quick=False):
+def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0, quick=False, rnd=0):
     """(quick: one form -- the stream form -- on all host threads over a smaller fixed sample, one timed pass after the warm one; the
     compact baseline / parity gate of the `other_configs` sub-records.)
     Times the oracle on FIXED samples of the same workload (no adaptive sizing: the figures are comparable from run
@@ -124,8 +124,8 @@ def cpu_baseline(x_dev, y_dev, log2n, direction, dw=16, tw=16, fmt=0, quick=Fals
     from oracle import oracle_c as C
 
     n = 1 << log2n
-    p = C.make_params(log2n, dw, tw, fmt, 0, True)
-    d = {"FWD": C.FWD, "PAIR": C.PAIR}[direction]
+    p = C.make_params(log2n, dw, tw, fmt, rnd, True)
+    d = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
     i16 = dw <= 16 and fmt == 0  # int16 containers both ways: the oracle's int16 entry point; else its int64 one
     threads = C.num_threads()
     scale = 1024 // n if n <= 1024 else 1
@@ -203,6 +203,9 @@ def diag_lib():
     if hasattr(L, "diag_copy_wave_ld"):
         L.diag_copy_wave_ld.argtypes = L.diag_copy_wave_nt.argtypes
     L.diag_valu_chain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]
+    if hasattr(L, "diag_body"):
+        L.diag_body.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_void_p]
     return L
 
 
@@ -348,6 +351,153 @@ def other_config(torch, name, steps, warmup, dev_index, slow_rate, cpu=True):
     return out
 
 
+# ---- the rest of the north-star shape on the driver's clock: N = 1024, 16/16 scaled, batch 65536 in every mode -----------------
+# (the reference testbench instantiates the three modes side by side, src/vhdl/tb/fft_signle_test.vhd:80-112; DIF rounding
+# int_dif2_fly.vhd:167-219, DIT rounding int_dit2_fly.vhd:164-217)
+MODES = {
+    # name: (RNDMODE, direction, text)
+    "round_fwd": (1, "FWD", "RNDMODE=1 (round half up) DIF FFT"),
+    "round_inv": (1, "INV", "RNDMODE=1 DIT IFFT"),
+    "round_pair": (1, "PAIR", "RNDMODE=1 FFT->IFFT pair (int_fft_ifft_pair)"),
+    "trunc_inv": (0, "INV", "RNDMODE=0 (truncate) DIT IFFT"),
+    "trunc_pair": (0, "PAIR", "RNDMODE=0 FFT->IFFT pair (int_fft_ifft_pair)"),
+}
+# VALU-issue floor of one N = 1024 frame per wave, in "wave-rounds" of the register-only butterfly bodies that tools/diag_kernels.hip
+# (diag_body) times in this run: (kind, round, fastx) -> rounds per frame.  kind 0 / 2 = four general DIF / DIT stages on 16 registers
+# (the frame has six: 1.5 rounds), kind 1 / 3 = stages 3, 2 with wave-uniform twiddles + STAGE 1 + STAGE 0 (one round).  fastx 1 = fast
+# extraction (frames that pass the magnitude vote), 2 = the t = 16 exact extraction (phase 1 of a frame that fails it), 0 = v_bfe.
+# The floor leaves out loads, stores, the LDS transpose, the lane swaps and the votes: it is an UPPER bound on the rate VALU issue allows.
+BODY_MIX = {
+    ("FWD", 0, False): {(0, 0, 1): 1.5, (1, 0, 1): 1.0},
+    ("FWD", 0, True): {(0, 0, 2): 1.0, (0, 0, 1): 0.5, (1, 0, 1): 1.0},   # full-scale input: stages 9..6 exact, then the second vote passes
+    ("FWD", 1, False): {(0, 1, 0): 1.5, (1, 1, 0): 1.0},
+    ("INV", 0, False): {(2, 0, 1): 1.5, (3, 0, 1): 1.0},
+    ("INV", 0, True): {(2, 0, 0): 1.5, (3, 0, 0): 1.0},                   # (the inverse wave kernel has one vote: a failing frame is exact throughout)
+    ("INV", 1, False): {(2, 1, 0): 1.5, (3, 1, 0): 1.0},
+}
+BODY_MIX[("FWD", 1, True)] = BODY_MIX[("FWD", 1, False)]  # round mode has no fast extraction: the input distribution changes nothing
+BODY_MIX[("INV", 1, True)] = BODY_MIX[("INV", 1, False)]
+for _r in (0, 1):
+    for _fs in (False, True):
+        _m = dict(BODY_MIX[("FWD", _r, _fs)])
+        for _k, _v in BODY_MIX[("INV", _r, False if _r == 0 and _fs else _fs)].items():  # (the forward half of a pair scales the data: the inverse half passes its vote)
+            _m[_k] = _m.get(_k, 0.0) + _v
+        BODY_MIX[("PAIR", _r, _fs)] = _m
+
+
+def body_rates(torch, stream):
+    """wave-rounds per second (whole chip, 4 waves per SIMD) of every butterfly body of BODY_MIX, measured now; {} without the diag library"""
+    L = diag_lib()
+    if L is None or not hasattr(L, "diag_body"):
+        return {}
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    seed = torch.randint(-(1 << 31), (1 << 31) - 1, (256 * 48,), dtype=torch.int32, device="cuda")
+    scratch = torch.empty(cus * 4 * 256, dtype=torch.int32, device="cuda")
+    n = ctypes.c_ulonglong()
+    rates = {}
+    for key in sorted({k for mix in BODY_MIX.values() for k in mix}):
+        fn = lambda: L.diag_body(key[0], key[1], key[2], 400, seed.data_ptr(), scratch.data_ptr(), ctypes.byref(n), stream)  # noqa: E731,B023
+        if fn() != 0:
+            continue
+        for _ in range(3):
+            fn()
+        ms = event_ms(torch, fn, 5)
+        rates[key] = n.value / (ms * 1e-3)
+    return rates
+
+
+def valu_floor(rates, direction, rnd, full_scale):
+    """Gsample/s that VALU issue alone allows for N = 1024 frames of this mode (None if a body was not measured)"""
+    mix = BODY_MIX[(direction, rnd, full_scale)]
+    if any(k not in rates for k in mix):
+        return None
+    return 1024.0 / sum(c / rates[k] for k, c in mix.items()) / 1e9
+
+
+def mode_roofline(here, kern_ms, alg_bytes, floor):
+    r = {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    r["frac_hbm"] = r["frac"]
+    bounds = {"hbm": HBM_PEAK_GBS / BYTES_PER_SAMPLE}
+    if floor:
+        bounds["valu_bodies"] = floor
+        r["frac_valu"] = here / floor
+        r["bound"] = "valu" if floor < bounds["hbm"] else "hbm"
+    r["bounds_Gsample_per_s"] = bounds
+    return r
+
+
+def other_mode(torch, name, steps, warmup, dev_index, rates, cpu=True):
+    """One sub-record of `other_modes`: the C2 shape (N = 1024, 16-bit data / 16-bit twiddles, scaled, 65536 frames, natural -> natural)
+    in another rounding mode / direction, timed like the headline; `roofline.frac_valu` = measured rate over the VALU-issue floor built
+    from the butterfly bodies timed in this run (BODY_MIX); `full_scale_input` = the same with input uniform over the whole int16 range;
+    the oracle on a bounded prefix is the parity gate."""
+    from intfftk_amd import IntFFTCore
+
+    rnd, direction, text = MODES[name]
+    log2n, batch, n = 10, 65536, 1024
+    core = IntFFTCore(log2n, 16, 16, 0, rnd, "NEW", direction, "NATURAL", "NATURAL", device=dev_index)
+    x = make_input(batch, n, 0xC0FFEE02, 0)
+    y = torch.empty(core.out_shape(batch), device=x.device, dtype=core.out_dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+    in_ptr, out_ptr = x.data_ptr(), y.data_ptr()
+    step = lambda: core.exec_raw(in_ptr, out_ptr, batch, stream)  # noqa: E731
+    step()
+    torch.cuda.synchronize()
+    ramp = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:  # untimed clock ramp, then W warm-up steps
+        for _ in range(20):
+            step()
+        ramp += 20
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / steps
+    alg_bytes = float(BYTES_PER_SAMPLE) * batch * n
+    here = batch * n / kern_ms / 1e6
+    out = {"workload": "N=1024, 16-bit data / 16-bit twiddle, scaled, %s, natural->natural, batch=%d" % (text, batch),
+           "dtype": "int16", "value": batch * n * steps / wall / 1e9, "unit": "Gsample/s", "steps": steps, "warmup": warmup,
+           "clock_ramp_steps": ramp, "ms_per_step": wall / steps * 1e3, "kernel_ms": kern_ms, "kernel": core.info["kernel_name"],
+           "launches_per_step": core.info["n_passes"],
+           "roofline": mode_roofline(here, kern_ms, alg_bytes, valu_floor(rates, direction, rnd, False))}
+    if cpu:
+        c = cpu_baseline(x, y, log2n, direction, 16, 16, 0, quick=True, rnd=rnd)
+        out["cpu_baseline"] = c
+        out["parity_ok"] = c["parity_ok"]
+    xf = make_input(batch, n, 0xC0FFEE02, 0, full_scale=True)
+    stepf = lambda: core.exec_raw(xf.data_ptr(), out_ptr, batch, stream)  # noqa: E731
+    for _ in range(20):
+        stepf()
+    ms = event_ms(torch, stepf, steps)
+    fs = {"kernel_ms": ms, "value": batch * n / ms / 1e6,
+          "roofline": mode_roofline(batch * n / ms / 1e6, ms, alg_bytes, valu_floor(rates, direction, rnd, True))}
+    if cpu:  # parity of the exact-extraction paths too: the first 2048 full-scale frames against the oracle
+        import numpy as np
+
+        from oracle import oracle_c as C
+
+        torch.cuda.synchronize()
+        want = C.execute(xf[:2048].cpu().numpy().astype(np.int64), C.make_params(log2n, 16, 16, 0, rnd, True),
+                         {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction])
+        fs["parity_checked_frames"] = 2048
+        fs["parity_ok"] = bool(np.array_equal(y[:2048].cpu().numpy().astype(np.int64), want))
+    out["full_scale_input"] = fs
+    core.close()
+    del x, y, xf, core
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---- self-spawn: `python bench.py --gpus N` without a launcher -----------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -387,6 +537,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the section-8(d) side figures (profiling runs)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the C3 / C4 / C5 sub-records the default single-GPU C2 run appends as `other_configs`")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="skip the `other_modes` sub-records (N = 1024 16-bit scaled in round mode / inverse / pair, each with its bounds)")
     ap.add_argument("--prewarm", type=int, default=400,
                     help="untimed clock-ramp launches before the W warmup steps (the GPU needs ~300 "
                          "back-to-back launches to reach its steady shader clock; see DESIGN.md)")
@@ -649,6 +801,32 @@ def main():
             step()
             torch.cuda.synchronize()
             out["cpu_baseline"] = cpu_baseline(x, y, log2n, direction, dw, tw, fmt)
+        if world == 1 and args.config == "C2" and not args.batch and not args.no_extras:
+            # the VALU-issue floor of the headline itself from the butterfly bodies timed in this run (next to the PMC-based valu_bound)
+            rates = body_rates(torch, stream)
+            if rates:
+                r = out["roofline"]
+                here = batch * n / kern_ms / 1e6
+                fl = valu_floor(rates, "FWD", 0, False)
+                if fl:
+                    r["valu_floor_bodies"] = {"value": fl, "unit": "Gsample/s", "frac": here / fl,
+                                              "what": "rate VALU issue alone allows: 1.5 wave-rounds of four general stages + 1 of stages 3..0 "
+                                                      "per frame, both timed on registers in this run (tools/diag_kernels.hip diag_body)"}
+                if "full_scale_input" in out:
+                    fl = valu_floor(rates, "FWD", 0, True)
+                    if fl:
+                        out["full_scale_input"]["valu_floor_bodies"] = {"value": fl, "unit": "Gsample/s",
+                                                                         "frac": out["full_scale_input"]["value"] / fl}
+                out["body_rates_wave_rounds_per_s"] = {"kind%d_round%d_fastx%d" % k: v for k, v in sorted(rates.items())}
+            if not args.no_other_modes:
+                om = {}
+                for name in MODES:
+                    try:
+                        om[name] = other_mode(torch, name, args.steps, args.warmup, dev_index, rates, cpu=not args.no_cpu_baseline)
+                    except Exception as exc:  # a sub-record must never cost the headline line
+                        om[name] = {"error": repr(exc)}
+                        torch.cuda.empty_cache()
+                out["other_modes"] = om
         if world == 1 and args.config == "C2" and not args.batch and not args.no_other_configs and not args.no_extras:
             # BASELINE's other configurations, timed in this process after everything that belongs to the headline (the headline fields
             # above are complete and unchanged); LAST key of the line, so that a tail of it shows the three sub-records

@@ -169,6 +169,40 @@ int intfft_plan_release_scratch(intfft_plan *plan);
  * This is NOT a CPU execution path: every frame is transformed on the HIP device. */
 int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames);
 
+/* The frame-queue form of the same interface: frames arrive OVER TIME (1 .. any number per call, with gaps), results leave in
+ * the order the frames went in -- what the RTL core does with its valid strobes (int_fftNk.vhd:23-37), and what SURVEY.md
+ * section 8(f) N2 asks for ("frames arriving in chunks, double-buffered").  Unlike intfft_exec_host the overlap of upload,
+ * transform and download works ACROSS calls.
+ *   intfft_stream_open(plan, slot_frames, n_slots, &s)
+ *       A stream object on the plan's device: n_slots (0 = 3; 2 .. 64) slots of slot_frames frames (0 = about 32 MiB), each a
+ *       pinned host input buffer, device input / output buffers and a pinned host output buffer owned by the library, three
+ *       HIP streams, and a private workspace (intfft_plan_workspace_bytes(plan, slot_frames)).  Transforms run through
+ *       intfft_exec_ws: the plan is only read, so ONE plan may feed any number of stream objects at once, also after
+ *       intfft_plan_release_scratch.  The plan must outlive the stream object.
+ *   intfft_stream_push(s, h_frames, nframes, &accepted)
+ *       Copies frames (host pointer, any memory: pageable is fine -- the library's pinned ring is what the DMA engine reads) into
+ *       the filling slot; every slot that becomes full is submitted (upload -> transform -> download, each on its own HIP stream,
+ *       ordered by events).  NEVER waits for the device: when all slots are in flight or hold results that were not pulled yet
+ *       it returns INTFFT_OK with *accepted < nframes (accepted may be NULL).
+ *   intfft_stream_flush(s)
+ *       Submits the partly filled slot as a short chunk (a producer that pauses, or the end of the data).  Producer side.
+ *   intfft_stream_pull(s, h_out, max_frames, &got, wait)
+ *       Copies up to max_frames finished frames, in push order, into h_out.  wait = 0: only what is complete now (got may be 0);
+ *       wait = 1: if something was submitted and is not pulled yet, blocks until at least its oldest slot is complete.  Frames
+ *       that sit in a slot that was not submitted (not full, not flushed) are not waited for: got = 0.
+ *   intfft_stream_pending(s, &not_pulled, &not_submitted)   frames pushed and not pulled yet / frames in the filling slot.
+ *   intfft_stream_close(s)   drains the device work, drops results that were not pulled, frees everything.
+ * Threading: ONE producer thread (push, flush) and ONE consumer thread (pull) may work on a stream object concurrently.
+ * Errors are sticky: after a failed enqueue every call on the object returns that status (hipError_t > 0 or INTFFT_ERR_* < 0)
+ * until close.  This is NOT a CPU execution path either. */
+typedef struct intfft_stream intfft_stream;
+int intfft_stream_open(intfft_plan *plan, size_t slot_frames, int n_slots, intfft_stream **out);
+int intfft_stream_push(intfft_stream *s, const void *h_frames, size_t nframes, size_t *accepted);
+int intfft_stream_flush(intfft_stream *s);
+int intfft_stream_pull(intfft_stream *s, void *h_out, size_t max_frames, size_t *got, int wait);
+int intfft_stream_pending(intfft_stream *s, size_t *frames_not_pulled, size_t *frames_not_submitted);
+int intfft_stream_close(intfft_stream *s);
+
 /* Single-process multi-GPU convenience (frames are independent, so a batch shards
  * across GPUs with no collective in the data path -- the software analogue of instantiating the core once per
  * channel).  plans[0..nplans-1] hold identical intfft_params, one per HIP device; d_in / d_out live on the device

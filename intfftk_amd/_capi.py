@@ -19,7 +19,8 @@ DIRECTIONS = {"FWD": 0, "INV": 1, "PAIR": 2}
 SYMBOLS = ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy", "intfft_plan_get_info",
            "intfft_exec", "intfft_plan_workspace_bytes", "intfft_exec_ws", "intfft_plan_release_scratch", "intfft_exec_host",
            "intfft_shard_prepare", "intfft_exec_sharded", "intfft_exec_sharded_async", "intfft_shard_set_transport", "intfft_reorder",
-           "intfft_twiddles", "intfft_strerror", "intfft_version")
+           "intfft_twiddles", "intfft_strerror", "intfft_version", "intfft_stream_open", "intfft_stream_push", "intfft_stream_flush",
+           "intfft_stream_pull", "intfft_stream_pending", "intfft_stream_close")
 
 
 class Params(ctypes.Structure):
@@ -85,13 +86,21 @@ def lib():
                                      ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         L.intfft_twiddles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_size_t)]
+        szp = ctypes.POINTER(ctypes.c_size_t)
+        L.intfft_stream_open.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.intfft_stream_push.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp]
+        L.intfft_stream_flush.argtypes = [ctypes.c_void_p]
+        L.intfft_stream_pull.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, szp, ctypes.c_int]
+        L.intfft_stream_pending.argtypes = [ctypes.c_void_p, szp, szp]
+        L.intfft_stream_close.argtypes = [ctypes.c_void_p]
         L.intfft_strerror.restype = ctypes.c_char_p
         L.intfft_strerror.argtypes = [ctypes.c_int]
         L.intfft_version.restype = ctypes.c_char_p
         for fn in ("intfft_io_widths", "intfft_plan_create", "intfft_plan_create_2d", "intfft_plan_destroy",
                    "intfft_plan_get_info", "intfft_exec", "intfft_exec_host", "intfft_exec_sharded", "intfft_exec_sharded_async",
                    "intfft_plan_workspace_bytes", "intfft_exec_ws", "intfft_plan_release_scratch",
-                   "intfft_shard_prepare", "intfft_shard_set_transport", "intfft_reorder", "intfft_twiddles"):
+                   "intfft_shard_prepare", "intfft_shard_set_transport", "intfft_reorder", "intfft_twiddles", "intfft_stream_open",
+                   "intfft_stream_push", "intfft_stream_flush", "intfft_stream_pull", "intfft_stream_pending", "intfft_stream_close"):
             getattr(L, fn).restype = ctypes.c_int
         _lib = L
     return _lib

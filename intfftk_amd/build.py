@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libintfft.so")
-SOURCES = ["intfft_plan.hip", "intfft_generic.hip", "intfft_pass16.hip", "intfft_fastsmall.hip", "intfft_fast1024.hip", "intfft_fast1024x.hip", "intfft_fast1024u.hip", "intfft_fast1024ux.hip", "intfft_fastw32.hip", "intfft_fastw64.hip", "intfft_fastw64s.hip", "intfft_fastw64n.hip", "intfft_fastw64sn.hip", "intfft_fastw64bn.hip", "intfft_fastw64b.hip", "intfft_fastw64bi.hip", "intfft_fast4096w.hip", "intfft_w32inv.hip", "intfft_bigw.hip", "intfft_fast4096.hip", "intfft_fast16k.hip", "intfft_big20.hip", "intfft_big2p.hip", "intfft_big2x.hip", "intfft_wide16.hip", "intfft_widelong.hip", "intfft_bigwlong.hip", "intfft_reorder.hip"]
+SOURCES = ["intfft_plan.hip", "intfft_generic.hip", "intfft_pass16.hip", "intfft_fastsmall.hip", "intfft_fast1024.hip", "intfft_fast1024x.hip", "intfft_fast1024u.hip", "intfft_fast1024ux.hip", "intfft_fastw32.hip", "intfft_fastw64.hip", "intfft_fastw64s.hip", "intfft_fastw64n.hip", "intfft_fastw64sn.hip", "intfft_fastw64bn.hip", "intfft_fastw64b.hip", "intfft_fastw64bi.hip", "intfft_fast4096w.hip", "intfft_w32inv.hip", "intfft_bigw.hip", "intfft_fast4096.hip", "intfft_fast16k.hip", "intfft_big20.hip", "intfft_big2p.hip", "intfft_big2x.hip", "intfft_wide16.hip", "intfft_widelong.hip", "intfft_bigwlong.hip", "intfft_reorder.hip", "intfft_stream.hip"]
 HEADERS = ["intfft_device.hpp", "intfft_internal.hpp", "intfft_pk16.hpp", "intfft_u32.hpp", "intfft_w64.hpp", os.path.join("..", "..", "include", "intfft.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

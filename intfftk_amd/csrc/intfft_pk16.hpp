@@ -64,10 +64,13 @@ template <bool ROUND, bool PRE, bool SW = false> __device__ __forceinline__ void
         //   A + B = 2 (A | B) - (A ^ B)               ->  rhu2(A + B) = (A | B) - T
         //   A - B + 1 = A + ~B + 2, floor((A + ~B) / 2) = (A & ~B) + ((A ^ ~B) >> 1) = (A & ~B) - T - 1
         //                                              ->  rhu2(A - B) = (A & ~B) - T
-        // exact over the integers, hence also modulo 2^16 (the RTL's 16-bit wrap); six operations for both results
+        // and, cheaper still, (A - B + 1) = (A + B + 1) - 2 B  ->  rhu2(A - B) = rhu2(A + B) - B.  Exact over the integers, hence also
+        // modulo 2^16 (the RTL's 16-bit wrap; rhu2(A + B) itself always fits 16 bits): FIVE operations for both results, two of them
+        // (xor, or) in the VOP2 encoding that issues at ~2.6 clk against ~4.5 for the packed ones (profiles/r03_valubench.txt)
         const v2s T = (A ^ B) >> (short)1;
-        s = as_u32((A | B) - T);
-        d = pk_sub<SW>(A & ~B, T);
+        const v2s S = (A | B) - T;
+        s = as_u32(S);
+        d = pk_sub<SW>(S, B);
     }
 }
 // Round mode on narrow data (DATA_WIDTH w < 16 in 16-bit lanes): rhu2(A - B) reaches +2^(w-1) when A = 2^(w-1) - 1, B = -2^(w-1),
@@ -122,6 +125,38 @@ __device__ __forceinline__ void mul2x(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr
             : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
             : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1),
               [wa1] "v"(wa1), [wb1] "v"(wb1), [off] "s"(off), [wd] "v"(wdv), [sel] "s"(sel));
+}
+
+// exact extraction of the FULL 16-bit Y = sum[off+15 : off] (round mode on 16-bit data; any t): a VOP2 shift puts re's slice into the
+// low half (the high half is overwritten next), an SDWA shift writes im's slice into the high half -- 2 dot + 2 shifts per butterfly
+// instead of 2 dot + 2 bfe + 1 perm, and the plain shift is in the fast-issue class.  gfx940-class hazard "VALU with dst_sel != DWORD ->
+// VALU read of that VGPR needs one wait state": inside the block the second SDWA write covers the first; the s_nop covers the second.
+#define INTFFT_MUL2X_W16_BODY                                                                          \
+    "v_dot2_i32_i16 %[r0], %[dr0], %[wa0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i0], %[di0], %[wb0], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[r1], %[dr1], %[wa1], 0\n\t"                                                      \
+    "v_dot2_i32_i16 %[i1], %[di1], %[wb1], 0\n\t"                                                      \
+    "v_lshrrev_b32 %[y0], %[off], %[r0]\n\t"                                                           \
+    "v_lshrrev_b32 %[y1], %[off], %[r1]\n\t"                                                           \
+    "v_lshrrev_b32_sdwa %[y0], %[off], %[i0] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+    "v_lshrrev_b32_sdwa %[y1], %[off], %[i1] dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+    "s_nop 0"
+
+template <bool SG>
+__device__ __forceinline__ void mul2x_w16(u32 dr0, u32 di0, u32 wa0, u32 wb0, u32 dr1, u32 di1, u32 wa1, u32 wb1, int off, u32 &y0,
+                                          u32 &y1)
+{
+    u32 r0, i0, r1, i1;
+    if (SG)
+        asm(INTFFT_MUL2X_W16_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "s"(wa0), [wb0] "s"(wb0), [dr1] "v"(dr1), [di1] "v"(di1), [wa1] "s"(wa1),
+              [wb1] "s"(wb1), [off] "s"(off));
+    else
+        asm(INTFFT_MUL2X_W16_BODY
+            : [y0] "=&v"(y0), [y1] "=&v"(y1), [r0] "=&v"(r0), [i0] "=&v"(i0), [r1] "=&v"(r1), [i1] "=&v"(i1)
+            : [dr0] "v"(dr0), [di0] "v"(di0), [wa0] "v"(wa0), [wb0] "v"(wb0), [dr1] "v"(dr1), [di1] "v"(di1), [wa1] "v"(wa1),
+              [wb1] "v"(wb1), [off] "s"(off));
 }
 
 // exact extraction of Y >> 1 for t = 16 without v_bfe: Y >> 1 = sext(sum[30:16]) is the high half of the sum with its bit 15
@@ -237,8 +272,13 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
         // planners' *_tables_ok check it): Y.re = dot(D, Wb), Y.im = dot(D, -Wa), full-width results, exact extraction
         const v2s z = {0, 0};
         const u32 nwa[4] = {as_u32(z - as_v2s(wa[0])), as_u32(z - as_v2s(wa[1])), as_u32(z - as_v2s(wa[2])), as_u32(z - as_v2s(wa[3]))};
-        mul2x<16, SG>(d[0], d[0], wb[0], nwa[0], d[1], d[1], wb[1], nwa[1], sl.off_y, sl.sel, y[0], y[1], sl.wd);
-        mul2x<16, SG>(d[2], d[2], wb[2], nwa[2], d[3], d[3], wb[3], nwa[3], sl.off_y, sl.sel, y[2], y[3], sl.wd);
+        if constexpr (ROUND == 1) { // 16-bit data: the two-shift extraction
+            mul2x_w16<SG>(d[0], d[0], wb[0], nwa[0], d[1], d[1], wb[1], nwa[1], sl.off_y, y[0], y[1]);
+            mul2x_w16<SG>(d[2], d[2], wb[2], nwa[2], d[3], d[3], wb[3], nwa[3], sl.off_y, y[2], y[3]);
+        } else {
+            mul2x<16, SG>(d[0], d[0], wb[0], nwa[0], d[1], d[1], wb[1], nwa[1], sl.off_y, sl.sel, y[0], y[1], sl.wd);
+            mul2x<16, SG>(d[2], d[2], wb[2], nwa[2], d[3], d[3], wb[3], nwa[3], sl.off_y, sl.sel, y[2], y[3], sl.wd);
+        }
     } else if (QTURN) {
         // W' = (W.im, -W.re): Y.re = dot(D, Wb), Y.im = dot(-D, Wa).  (Round 4 tried the negated TWIDDLE operand instead -- one packed
         // subtract per distinct twiddle, shared by the compiler between the butterflies of a round: 49 fewer operations per thread and tile
@@ -258,7 +298,10 @@ __device__ __forceinline__ void group4(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u32 &
                                          OUT_PRE ? sl.off_y1 : sl.off_y, sl.sel, y[2], y[3], sl.wd);
         }
     } else {
-        if (FASTX == 1) {
+        if constexpr (ROUND == 1) { // round mode on 16-bit data: full-width Y by the two-shift extraction
+            mul2x_w16<SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.off_y, y[0], y[1]);
+            mul2x_w16<SG>(d[2], d[2], wa[2], wb[2], d[3], d[3], wa[3], wb[3], sl.off_y, y[2], y[3]);
+        } else if (FASTX == 1) {
             mul4f<SG>(d, d, wa, wb, sl.sel_hi, y);
         } else if (FASTX == 2) {
             mul2x_t16<SG>(d[0], d[0], wa[0], wb[0], d[1], d[1], wa[1], wb[1], sl.sel_hi, y[0], y[1]);
@@ -442,8 +485,13 @@ __device__ __forceinline__ void group4_dit(u32 &a0, u32 &b0, u32 &a1, u32 &b1, u
     if constexpr (ROUND) { // RNDMODE = 1 (int_dit2_fly.vhd:164-217): T at full width, then rhu2(A +/- T)
         static_assert(!FASTX, "fast extraction yields T >> 1 only");
         u32 tf[4];
-        mul2x<16, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, sl.sel, tf[0], tf[1], sl.wd);
-        mul2x<16, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, sl.sel, tf[2], tf[3], sl.wd);
+        if constexpr (ROUND == 1) {
+            mul2x_w16<SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, tf[0], tf[1]);
+            mul2x_w16<SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, tf[2], tf[3]);
+        } else {
+            mul2x<16, SG>(bs[0], bs[0], wb[0], wa[0], bs[1], bs[1], wb[1], wa[1], sl.off_y, sl.sel, tf[0], tf[1], sl.wd);
+            mul2x<16, SG>(bs[2], bs[2], wb[2], wa[2], bs[3], bs[3], wb[3], wa[3], sl.off_y, sl.sel, tf[2], tf[3], sl.wd);
+        }
         sumdiff<true, false>(a0, tf[0], a0, b0);
         sumdiff<true, false>(a1, tf[1], a1, b1);
         sumdiff<true, false>(a2, tf[2], a2, b2);

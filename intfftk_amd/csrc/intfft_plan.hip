@@ -906,6 +906,11 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
                 e = hipMalloc((void **)&pl->d_tw16r, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = hipMalloc((void **)&pl->d_tw16ri, (tot + 1) * sizeof(uint2));
                 if (e == hipSuccess) e = launch_pack_twiddles16(pl->sub_row_f->d_tw, tot, pl->d_tw16r, pl->d_tw16ri, nullptr);
+                if (e == hipSuccess) { // the two-launch form writes X from the first layout buffer: the second one is never touched
+                    (void)hipFree(pl->buf2d[1]);
+                    pl->buf2d[1] = nullptr;
+                    pl->n2d_bufs = 1;
+                }
             }
             if (e == hipSuccess && (pl->fused2d == 8 || pl->fused2d == 10 || pl->fused2d == 11)) { // the 2048-point cores' packed table (columns and rows share it)
                 const size_t tot = ((size_t)1 << 11) - 1;
@@ -1521,13 +1526,13 @@ static int exec_2d(intfft_plan *pl, const void *d_in, void *d_out, size_t batch,
                                    p.in_order == INTFFT_ORDER_HALVES, st);
                 continue;
             }
-            char *b1 = static_cast<char *>(buf1) + off;
             e = launch_fused2d_cols(l2, p.twdl_width, src, b0, pl->d_tw16f, pl->sub_col_f->h_tw.data(), pl->d_tw2d_tiles, nf, p.in_order == INTFFT_ORDER_HALVES, st);
             if (e != hipSuccess) break;
-            if (pl->d_tw16r) { // N2 = 2048, natural order out: the row cores write X themselves
+            if (pl->d_tw16r) { // N2 = 2048, natural order out: the row cores write X themselves (one layout buffer: n2d_bufs == 1)
                 e = launch_fused2d_rows2k(p.twdl_width, b0, reinterpret_cast<uint32_t *>(dst), pl->d_tw16r, pl->sub_row_f->h_tw.data(), nf, st);
                 continue;
             }
+            char *b1 = static_cast<char *>(buf1) + off;
             if ((rc = exec_core(pl->sub_row_f, b0, b1, nf << l1, st, subws)) != INTFFT_OK) break;
             // logical k = k1 + N1 k2 sits at [rho = brev(k1)][k2]: k bit j < l1 at in bit l2 + (l1 - 1 - j), else at j - l1
             for (int j = 0; j < L; ++j) perm[order_mem_bit(p.out_order, L, j)] = j < l1 ? l2 + (l1 - 1 - j) : j - l1;
@@ -1837,10 +1842,12 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
 {
     if (!plan || (batch && (!h_in || !h_out))) return INTFFT_ERR_NULL;
     if (batch == 0) return INTFFT_OK;
+    if (!plan->owns_scratch) return INTFFT_ERR_INVALID; // intfft_plan_release_scratch: intfft_exec_ws only (before any stream / slot is created)
     DeviceGuard guard(plan->device);
     if (!guard.ok) return INTFFT_ERR_NO_DEVICE;
     const size_t N = (size_t)1 << plan->L;
     const size_t in_frame = N * 2 * (size_t)plan->in_cb, out_frame = N * 2 * (size_t)plan->out_cb;
+    int lib_rc = INTFFT_OK; // a negative library status of the inner intfft_exec goes back to the caller unchanged
     if (chunk_frames == 0) chunk_frames = std::max<size_t>(1, ((size_t)64 << 20) / std::max(in_frame, out_frame));
     chunk_frames = std::min(chunk_frames, batch);
     hipError_t e = hipSuccess;
@@ -1880,7 +1887,8 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
             if (e == hipSuccess && i >= 2) e = hipStreamWaitEvent(plan->s_comp, plan->ev_down[slot], 0);
             if (e == hipSuccess) {
                 const int rc = intfft_exec(plan, plan->slot_in[slot], plan->slot_out[slot], nf, plan->s_comp);
-                if (rc != INTFFT_OK) e = rc > 0 ? (hipError_t)rc : hipErrorUnknown;
+                if (rc > 0) e = (hipError_t)rc;
+                else if (rc < 0) lib_rc = rc, e = hipErrorUnknown;
             }
             if (e == hipSuccess) e = hipEventRecord(plan->ev_comp[slot], plan->s_comp);
             // download
@@ -1896,11 +1904,13 @@ int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t ba
         const hipError_t e4 = hipStreamSynchronize(plan->s_up);
         if (e == hipSuccess) e = e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4;
     }
+    if (lib_rc != INTFFT_OK) return lib_rc;
     if (e == hipSuccess) return INTFFT_OK;
 fail:
 #undef INTFFT_TRY
     return (int)e;
 }
+
 
 // staging buffers + stream of one shard plan (grow only); peer access root <-> pl->device
 static hipError_t shard_state(intfft_plan *pl, int root_device, size_t in_bytes, size_t out_bytes)
@@ -2258,3 +2268,11 @@ const char *intfft_strerror(int status)
 const char *intfft_version(void) { return "intfft-mi355x 0.1 (gfx950)"; }
 
 } // extern "C"
+
+namespace intfft {
+void plan_geometry(const intfft_plan *plan, int *device, int *log2n, int *in_cb, int *out_cb)
+{
+    *device = plan->device, *log2n = plan->L, *in_cb = plan->in_cb, *out_cb = plan->out_cb;
+}
+} // namespace intfft
+

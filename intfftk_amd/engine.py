@@ -206,6 +206,66 @@ class IntFFTCore:
         return out
 
 
+class FrameStream:
+    """The frame-queue form of the streaming interface (include/intfft.h: intfft_stream_*): frames are pushed as they arrive -- any
+    number per call, with gaps -- and results are pulled in push order; upload, transform and download overlap across calls (the
+    software analogue of the RTL's valid strobes, int_fftNk.vhd:23-37).  One producer thread (push / flush) and one consumer thread
+    (pull) may use an object concurrently.  The core must outlive the stream."""
+
+    def __init__(self, core: IntFFTCore, slot_frames: int = 0, n_slots: int = 0):
+        self.core = core
+        self._s = ctypes.c_void_p()
+        capi.check(capi.lib().intfft_stream_open(core._plan, slot_frames, n_slots, ctypes.byref(self._s)), "intfft_stream_open")
+
+    def push(self, x: np.ndarray) -> int:
+        """frames accepted (fewer than len(x) when every slot is in flight or waits to be pulled); never waits for the device"""
+        c = self.core
+        x = np.asarray(x)
+        if x.dtype != _NP_DT[c.in_container]:
+            raise TypeError("input dtype must be %s for DATA_WIDTH=%d" % (np.dtype(_NP_DT[c.in_container]).name, c.in_bits))
+        x = np.ascontiguousarray(x)
+        if x.ndim != 3 or x.shape[1] != c.n or x.shape[2] != 2:
+            raise ValueError("input must be [frames, %d, 2]" % c.n)
+        acc = ctypes.c_size_t()
+        capi.check(capi.lib().intfft_stream_push(self._s, x.ctypes.data, x.shape[0], ctypes.byref(acc)), "intfft_stream_push")
+        return acc.value
+
+    def flush(self):
+        capi.check(capi.lib().intfft_stream_flush(self._s), "intfft_stream_flush")
+
+    def pull(self, max_frames: int, wait: bool = False) -> np.ndarray:
+        """up to max_frames finished frames in push order ([0, N, 2] when nothing is ready)"""
+        c = self.core
+        out = np.empty(c.out_shape(max_frames), dtype=_NP_DT[c.out_container])
+        got = ctypes.c_size_t()
+        capi.check(capi.lib().intfft_stream_pull(self._s, out.ctypes.data, max_frames, ctypes.byref(got), 1 if wait else 0),
+                   "intfft_stream_pull")
+        return out[:got.value]
+
+    def pending(self):
+        """(frames pushed and not pulled yet, frames in the slot that is still filling)"""
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        capi.check(capi.lib().intfft_stream_pending(self._s, ctypes.byref(a), ctypes.byref(b)), "intfft_stream_pending")
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "_s", None) is not None and self._s.value:
+            capi.lib().intfft_stream_close(self._s)
+            self._s = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def int_fftNk(NFFT=10, DATA_WIDTH=16, TWDL_WIDTH=16, FORMAT=1, RNDMODE=0, XSER="NEW", USE_FLY=1,
               RAMB_TYPE="WRAP", USE_MLT=False, device=None) -> IntFFTCore:
     """Forward DIF core with its native stream orders (int_fftNk.vhd:15-21)."""
