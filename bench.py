@@ -95,6 +95,7 @@ def pmc_digest(config="C2"):
             out["valu_insts_per_call"] = sum(float(v.get("SQ_INSTS_VALU", 0.0)) * float(v.get("launches_per_call", 1.0))
                                              for v in d["kernels"].values())
             out["digest_batch"] = d.get("batch")
+            out["lib_version"] = d.get("lib_version")
             return os.path.relpath(path, ROOT), out
         except Exception:
             continue
@@ -108,6 +109,18 @@ def pmc_digest(config="C2"):
         except Exception:
             continue
     return None, None
+
+
+def loaded_lib_version():
+    from intfftk_amd import _capi
+
+    return _capi.lib().intfft_version().decode()
+
+
+def digest_stale(digest):
+    """True when the committed PMC digest was NOT taken on the sources of the library this run measures (intfft_version() carries their
+    hash): `traffic` and the PMC-based VALU bound are then figures of an older build and say so."""
+    return bool(digest) and digest.get("lib_version") != loaded_lib_version()
 
 
 # ---- CPU baselines (the oracle = a scalar C port of the RTL arithmetic in the reference model's dataflow) ----------
@@ -330,6 +343,8 @@ def other_config(torch, name, steps, warmup, dev_index, slow_rate, cpu=True):
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "frac_hbm": achieved / HBM_PEAK_GBS, "traffic": traffic,
          "traffic_source": ("%s (static)" % digest_path) if traffic else None, "algorithmic_bytes_per_step": alg_bytes}
+    if traffic:
+        r["traffic_stale"] = digest_stale(digest)
     bounds = {"hbm": HBM_PEAK_GBS / bps}
     if traffic:
         bounds["hbm_pass_traffic"] = HBM_PEAK_GBS / (traffic / (float(batch) * n))
@@ -476,8 +491,11 @@ def other_mode(torch, name, steps, warmup, dev_index, rates, cpu=True):
         out["parity_ok"] = c["parity_ok"]
     xf = make_input(batch, n, 0xC0FFEE02, 0, full_scale=True)
     stepf = lambda: core.exec_raw(xf.data_ptr(), out_ptr, batch, stream)  # noqa: E731
-    for _ in range(20):
-        stepf()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:  # the oracle leg above left the GPU idle: ramp the clocks again before timing
+        for _ in range(20):
+            stepf()
+        torch.cuda.synchronize()
     ms = event_ms(torch, stepf, steps)
     fs = {"kernel_ms": ms, "value": batch * n / ms / 1e6,
           "roofline": mode_roofline(batch * n / ms / 1e6, ms, alg_bytes, valu_floor(rates, direction, rnd, True))}
@@ -755,7 +773,11 @@ def main():
                                             % digest_path) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": kern_ms},
+            "lib_version": loaded_lib_version(),
         }
+        if traffic:  # the digest names the sources it was taken on: a kernel change that was not re-profiled shows here
+            out["roofline"]["traffic_stale"] = digest_stale(digest)
+            out["roofline"]["traffic_lib_version"] = digest.get("lib_version")
         if e2e:
             out["e2e"] = e2e
         elif args.e2e:

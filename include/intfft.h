@@ -146,8 +146,10 @@ int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, 
  * mutex-protected pool and goes back when the call returns), so ONE plan may run on any number of streams / host threads at once as long as every
  * concurrent call has its own workspace.
  *   intfft_plan_workspace_bytes(plan, batch, &bytes): the workspace with which a call of `batch` frames runs exactly like intfft_exec on the plan's
- *     own scratch (0 for single-launch plans: d_workspace may then be NULL).  Monotone in `batch` and bounded: at most 2 x 128 MiB halves / 256 MiB
- *     (+ the sub-plans' share for composite plans) however large the batch.
+ *     own scratch (0 for single-launch plans: d_workspace may then be NULL).  Monotone in `batch` and bounded, but the bound depends on
+ *     the plan family -- two 128 MiB scratch halves for the 1-D multi-pass plans; one or two 256 MiB layout buffers PLUS the row sub-plan's share
+ *     for the 2-D scheme plans (512 MiB and more); the middle buffer plus the larger sub-plan for composite pairs -- so size pools from THIS
+ *     call (e.g. with batch = SIZE_MAX for the largest a plan ever asks for), never from a constant.
  *   intfft_exec_ws(..., d_workspace, ws_bytes, stream): d_workspace is a device pointer on the plan's device, 256-byte aligned, not overlapping
  *     d_in / d_out.  A workspace smaller than intfft_plan_workspace_bytes(plan, batch) is accepted as long as it serves one frame
  *     (>= intfft_plan_workspace_bytes(plan, 1)): the batch is then cut into the largest sub-batches the workspace serves, one after the other on

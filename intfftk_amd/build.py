@@ -22,10 +22,38 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+VERSION_SRC = "intfft_version.hip"
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over every file of csrc/ (names and contents, sorted) and include/intfft.h: what intfft_version()
+    reports, so that measurements can name the sources of the library they were taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    for f in files + [os.path.join("..", "..", "include", "intfft.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    # the version unit is rebuilt whenever the hash of the sources changes (the hash it was built with is kept beside the object)
+    sh = source_hash()
+    vo, vstamp = os.path.join(LIBDIR, "intfft_version.o"), os.path.join(LIBDIR, "intfft_version.hash")
+    try:
+        with open(vstamp) as fh:
+            have = fh.read().strip()
+    except OSError:
+        have = ""
+    if force or have != sh or not os.path.exists(vo):
+        jobs.append([HIPCC] + FLAGS + ['-DINTFFT_SRC_HASH="%s"' % sh, "-c", os.path.join(CSRC, VERSION_SRC), "-o", vo])
+    objs.append(vo)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
@@ -50,6 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         workers = max(1, min(len(jobs), int(os.environ.get("INTFFT_BUILD_JOBS", os.cpu_count() or 1))))
         with ThreadPoolExecutor(max_workers=workers) as ex:
             list(ex.map(run, jobs))
+        with open(vstamp, "w") as fh:
+            fh.write(sh + "\n")
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

@@ -405,6 +405,15 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
         }
     }
 
+    // Vote prediction (round 6): a frame that fails the input vote sends the wave's next VOTE_SKIP frames straight to the exact phase 1
+    // without voting (always correct -- the exact extraction needs no precondition -- and they still take the second vote behind stage 6);
+    // a stream of full-scale frames then pays one vote per frame instead of two (each is 32 packed operations + a ballot, ~4 % of the
+    // frame), and a stream that turns quiet again is back on the fast phase 1 within VOTE_SKIP frames.  Wave-uniform (from a ballot).
+#ifndef INTFFT_VOTE_SKIP
+#define INTFFT_VOTE_SKIP 7 // (0: every frame takes the input vote -- the behaviour up to round 5; tools/build_variant.sh A/B)
+#endif
+    constexpr int VOTE_SKIP = INTFFT_VOTE_SKIP;
+    int vote_skip = 0;
     auto run = [&](u32(&v)[16], size_t f) {
         // partial last chunk: natural order -> per-lane predicate; BITREV order -> "chunk is full" + the frame count
         const bool st_ok = L == 10 || (OUT_BITREV ? (f + 1) * FP <= nframes_user : f * FP + (size_t)lane_frame < nframes_user);
@@ -412,7 +421,9 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
             // one instance of each phase body: fast or exact phase 1, then -- for a frame that failed the input vote -- a second vote
             // on the values behind stage 6, then the fast or exact tail
             if (sl.wd == 16) {
-                bool fast = frame_within_T(v);
+                bool fast = false;
+                if (vote_skip > 0) --vote_skip;
+                else if (!(fast = frame_within_T(v))) vote_skip = VOTE_SKIP;
                 if (fast) transform_phase1<L, ROUND, 1>(v, tw, sl);
                 else {
                     transform_phase1<L, ROUND, 2>(v, tw, sl); // the t = 16 exact form (mul2x_t16)

@@ -2221,12 +2221,17 @@ int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const v
         DeviceGuard g(rp->device);
         e = hipStreamSynchronize(rp->s_call);
     }
-    if (rc != INTFFT_OK || e != hipSuccess)
-        for (int i = 0; i < nplans; ++i) { // after an error: drain every stream that was used
-            DeviceGuard g(plans[i]->device);
-            for (hipStream_t st : {plans[i]->s_shard, plans[i]->s_shard2})
-                if (st) (void)hipStreamSynchronize(st);
-        }
+    // The blocking entry point drains every stream the call used on every device, error or not: s_call already waits for all of them
+    // through cross-device events, so on a healthy run these return at once -- a safety net for the multi-device orderings (the RCCL
+    // transport in particular), which no box this library was measured on could exercise with two or more devices.
+    for (int i = 0; i < nplans; ++i) {
+        DeviceGuard g(plans[i]->device);
+        for (hipStream_t st : {plans[i]->s_shard, plans[i]->s_shard2})
+            if (st) {
+                const hipError_t es = hipStreamSynchronize(st);
+                if (e == hipSuccess && es != hipSuccess) e = es;
+            }
+    }
     if (rc != INTFFT_OK) return rc;
     return e == hipSuccess ? INTFFT_OK : (int)e;
 }
@@ -2265,7 +2270,7 @@ const char *intfft_strerror(int status)
     return "unknown status";
 }
 
-const char *intfft_version(void) { return "intfft-mi355x 0.1 (gfx950)"; }
+// intfft_version(): intfft_version.hip (its own translation unit: it carries the hash of the sources the library was built from)
 
 } // extern "C"
 

@@ -233,10 +233,14 @@ class FrameStream:
     def flush(self):
         capi.check(capi.lib().intfft_stream_flush(self._s), "intfft_stream_flush")
 
-    def pull(self, max_frames: int, wait: bool = False) -> np.ndarray:
-        """up to max_frames finished frames in push order ([0, N, 2] when nothing is ready)"""
+    def pull(self, max_frames: int, wait: bool = False, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """up to max_frames finished frames in push order ([0, N, 2] when nothing is ready); `out`: a C-contiguous array of the output
+        dtype with room for max_frames frames to receive them (a view of its first rows is returned)"""
         c = self.core
-        out = np.empty(c.out_shape(max_frames), dtype=_NP_DT[c.out_container])
+        if out is None:
+            out = np.empty(c.out_shape(max_frames), dtype=_NP_DT[c.out_container])
+        elif out.dtype != _NP_DT[c.out_container] or not out.flags.c_contiguous or out.shape[0] < max_frames or tuple(out.shape[1:]) != c.out_shape(1)[1:]:
+            raise ValueError("bad `out` array")
         got = ctypes.c_size_t()
         capi.check(capi.lib().intfft_stream_pull(self._s, out.ctypes.data, max_frames, ctypes.byref(got), 1 if wait else 0),
                    "intfft_stream_pull")

@@ -74,7 +74,9 @@ class ShardedTransform:
 
     # -- data movement ------------------------------------------------------------------------
     def scatter(self, root_batch, batch: int, root: int = 0):
-        """root_batch: [batch, N, 2] on the root (ignored elsewhere) -> this rank's shard."""
+        """root_batch: [batch, N, 2] on the root (ignored elsewhere) -> this rank's shard.
+        ALIASING: on the root the returned shard is a VIEW of root_batch[lo:hi] (no copy); on every other rank it is a fresh buffer.  A
+        caller that goes on to mutate root_batch, or runs an in-place transform on the shard, must `.clone()` the root's shard first."""
         import torch
 
         bounds = shard_bounds(batch, self.world)

@@ -9,6 +9,10 @@ path can ever get.  Pure host-side I/O; no arithmetic beyond the bit slicing the
                   src/vhdl/buffers/iobuf_flow_int2.vhd:18-40) -- read by src/vhdl/tb/fft_double_test.vhd:127-165
   dout_pair.dat   four integers per line: the TOP 17 BITS of Q0_RE Q1_RE Q0_IM Q1_IM
                   -- written by src/vhdl/tb/fft_double_test.vhd:200-217
+  *.hex           the full-width form of the two layouts above for the cross-check kit's hex testbenches
+                  (tools/vivado_crosscheck/tb_single_hex.vhd / tb_pair_hex.vhd): the same columns, every value a two's-complement
+                  word of 4 * ceil(width / 4) bits in upper-case hex -- what ieee.std_logic_textio hread / hwrite (the package
+                  fft_signle_test.vhd:73 imports) read and write, with no 32-bit limit of a VHDL integer
 """
 from __future__ import annotations
 
@@ -81,3 +85,61 @@ def write_dout_pair(path: str, frames: np.ndarray, width: int, reference_wiring:
 
 def read_dout_pair(path: str) -> np.ndarray:
     return np.loadtxt(path, dtype=np.int64, ndmin=2)
+
+
+# ---- full-width hexadecimal text (cross-check kit, widths beyond a VHDL integer) ------------------------------------------------
+def hex_digits(width: int) -> int:
+    """hex digits of one word: hread / hwrite work on vectors whose length is a multiple of 4"""
+    return (width + 3) // 4
+
+
+def write_hex(path: str, table, width: int) -> None:
+    """table: [lines, columns] of integers (int64 or Python ints) that fit `width` bits two's complement -> one line per row,
+    every value sign-extended to 4 * ceil(width / 4) bits and printed as upper-case hex"""
+    nd = hex_digits(width)
+    mask = (1 << (4 * nd)) - 1
+    lo, hi = -(1 << (width - 1)), (1 << (width - 1)) - 1
+    with open(path, "w") as fh:
+        for row in table:
+            vals = [int(v) for v in row]
+            if any(v < lo or v > hi for v in vals):
+                raise ValueError("value outside %d bits" % width)
+            fh.write(" ".join("%0*X" % (nd, v & mask) for v in vals) + "\n")
+
+
+def read_hex(path: str, width: int) -> np.ndarray:
+    """-> int64 [lines, columns] (widths up to 64 bits): every word read as two's complement of its OWN digit count
+    (a dump sign-extended to the digit boundary, like tb_*_hex.vhd writes it), then checked against `width`"""
+    rows = []
+    with open(path) as fh:
+        for line in fh:
+            f = line.split()
+            if not f:
+                continue
+            vals = []
+            for w in f:
+                v = int(w, 16)
+                bits = 4 * len(w)
+                if v >> (bits - 1):
+                    v -= 1 << bits
+                if v < -(1 << (width - 1)) or v >= (1 << (width - 1)):
+                    raise ValueError("%s: %s does not fit %d bits" % (path, w, width))
+                vals.append(v)
+            rows.append(vals)
+    return np.array(rows, dtype=np.int64)
+
+
+def single_to_table(frames) -> np.ndarray:
+    return _ints(frames).reshape(-1, 2)
+
+
+def double_to_table(frames) -> np.ndarray:
+    x = _ints(frames).reshape(-1, 2, 2)  # [beat, lane, (re, im)]
+    return np.stack([x[:, 0, 0], x[:, 1, 0], x[:, 0, 1], x[:, 1, 1]], axis=-1)
+
+
+def table_to_double(a: np.ndarray, n: int) -> np.ndarray:
+    """[beats, 4] (lane-0 re, lane-1 re, lane-0 im, lane-1 im) -> [frames, n, 2] in natural order"""
+    d0 = np.stack([a[:, 0], a[:, 2]], axis=-1)
+    d1 = np.stack([a[:, 1], a[:, 3]], axis=-1)
+    return np.stack([d0, d1], axis=1).reshape(-1, n, 2)

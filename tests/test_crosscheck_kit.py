@@ -31,11 +31,28 @@ def test_kit_expectations_equal_the_oracle():
         for ii in range(c["nfft"]):
             w = c.get("data_width", 16) + ii * c["format"] + c["format"]
             regimes.add(C.cmult_regime(w, c.get("twdl_width", 16), c.get("xser", "NEW") == "NEW"))
-    assert {"sngl", "dbl18", "sngl25", "dbl35"} <= regimes
+    assert {"sngl", "dbl18", "sngl25", "dbl35", "trpl18", "trpl52"} <= regimes  # round 6: the hex testbenches carry the wide families too
+    wide = [c for c in cases if c["out_bits"] > 32]
+    assert len(wide) >= 6 and all(c.get("text") == "hex" and c["tb"] in ("tb_single_hex", "tb_pair_hex") for c in wide)
+    assert {(c["data_width"], c["twdl_width"], c["xser"]) for c in wide} >= {(46, 16, "NEW"), (44, 16, "OLD"), (40, 24, "NEW"), (30, 24, "NEW"),
+                                                                             (30, 16, "NEW"), (30, 16, "OLD"), (28, 24, "NEW")}
+    # the dbl18 pair shares ONE stimulus, and the two series give different results on it (XSER-divergent vector)
+    new, old = (next(c for c in cases if c["case"] == k) for k in ("hex_n7_w30t16", "hex_n7_w30t16old"))
+    assert new["stimulus"] == old["stimulus"]
+    assert not np.array_equal(textio.read_hex(os.path.join(EXP, new["expected"]), 37), textio.read_hex(os.path.join(EXP, old["expected"]), 37))
     for c in cases:
         n = 1 << c["nfft"]
         p = C.make_params(c["nfft"], c.get("data_width", 16), c.get("twdl_width", 16), c["format"], c["rndmode"], c.get("xser", "NEW") == "NEW")
-        if c["tb"] == "tb_single_dump":
+        if c.get("text") == "hex":
+            xt = textio.read_hex(os.path.join(EXP, c["stimulus"]), c["data_width"])
+            gt = textio.read_hex(os.path.join(EXP, c["expected"]), c["out_bits"])
+            if c["tb"] == "tb_single_hex":
+                x, got, want = xt.reshape(-1, n, 2), gt.reshape(-1, n, 2), None
+                want = C.execute(x, p, C.FWD)
+            else:
+                x, got = textio.table_to_double(xt, n), textio.table_to_double(gt, n)
+                want = C.execute(x, p, C.PAIR)
+        elif c["tb"] == "tb_single_dump":
             x = textio.read_di_single(os.path.join(EXP, c["stimulus"]), n)
             got = textio.read_di_single(os.path.join(EXP, c["expected"]), n)
             want = C.execute(x, p, C.FWD)
@@ -87,11 +104,11 @@ def test_kit_lint_against_the_reference_entities(tmp_path):
     spec.loader.exec_module(lk)
     errs, man = lk.lint(ref)
     assert not errs, errs
-    assert len(man["cases"]) == 15
-    for c in man["cases"]:  # every dumped vector fits a VHDL integer
-        assert c["out_bits"] <= 32, c
+    assert len(man["cases"]) == 25
+    for c in man["cases"]:  # every vector dumped through conv_integer fits a VHDL integer; the wider ones go through the hex testbenches
+        assert c["out_bits"] <= 32 or c.get("text") == "hex", c
     # the lint does catch what it is there for: a misspelt port, a wrong width, a too-wide conv_integer
-    for tbfile in ("tb_single_dump.vhd", "tb_pair_dump.vhd"):
+    for tbfile in ("tb_single_dump.vhd", "tb_pair_dump.vhd", "tb_single_hex.vhd", "tb_pair_hex.vhd"):
         (tmp_path / tbfile).write_text(open(os.path.join(KIT, tbfile)).read())
     t = (tmp_path / "tb_single_dump.vhd").read_text()
     (tmp_path / "tb_single_dump.vhd").write_text(t.replace("DO_VL   => do_vl", "DO_VAL  => do_vl")
@@ -99,3 +116,14 @@ def test_kit_lint_against_the_reference_entities(tmp_path):
     errs, _ = lk.lint(ref, kit=str(tmp_path))
     assert any("DO_VAL is not a port" in e for e in errs) and any("DO_VL of int_fft_single_path is left unassociated" in e for e in errs)
     assert any("DO_RE is" in e and "signal do_re is" in e for e in errs) and any("conv_integer(DO_RE)" in e for e in errs)
+    # ... and the hex testbenches' own failure modes: an hread operand that is not a whole number of hex digits, a stimulus slice that
+    # does not match the port, a sign extension to the wrong size
+    t = (tmp_path / "tb_single_hex.vhd").read_text()
+    (tmp_path / "tb_single_hex.vhd").write_text(t.replace("constant IH     : integer := 4*((DATA_WIDTH+3)/4);", "constant IH     : integer := DATA_WIDTH+1;")
+                                                 .replace("vi := SXT(do_im, OH);", "vi := SXT(do_im, OW);"))
+    t = (tmp_path / "tb_pair_hex.vhd").read_text()
+    (tmp_path / "tb_pair_hex.vhd").write_text(t.replace("d1_im <= d(DATA_WIDTH-1 downto 0);", "d1_im <= d(DATA_WIDTH-2 downto 0);"))
+    errs, _ = lk.lint(ref, kit=str(tmp_path))
+    assert any("hread / hwrite operand A is 47 bits" in e for e in errs)               # hex_n7_w46t16: 46 + 1
+    assert any("VI := SXT(DO_IM" in e for e in errs)
+    assert any("D1_IM is 24 bits but takes a 23-bit slice of D" in e for e in errs)

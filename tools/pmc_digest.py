@@ -32,7 +32,14 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
         n = short(r["Kernel_Name"])
         if "k_" in n and "twiddle" not in n and "pack" not in n:
             dur[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"config": spec, "log2n": log2n, "batch": batch, "direction": direction, "bytes_per_sample": bps, "kernels": {}}
+try:  # which library the counters were taken on: intfft_version() carries the hash of its sources (intfftk_amd/build.py source_hash)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from intfftk_amd import _capi as _capi  # noqa: E402
+
+    lib_version = _capi.lib().intfft_version().decode()
+except Exception as exc:  # noqa: BLE001
+    lib_version = "unknown (%r)" % (exc,)
+out = {"config": spec, "log2n": log2n, "batch": batch, "direction": direction, "bytes_per_sample": bps, "kernels": {}, "lib_version": lib_version}
 alg = bps * (1 << log2n) * batch
 out["algorithmic_bytes_per_call"] = alg
 # launches per intfft_exec call: the trace holds (warm-up + timed) calls; every kernel of the plan is launched the same number of times

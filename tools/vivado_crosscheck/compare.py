@@ -17,6 +17,21 @@ import sys
 import numpy as np
 
 
+def read_hex(path):
+    """[lines, columns] int64 of a hex dump: every word is two's complement of its own digit count (the testbenches sign-extend to the
+    digit boundary), so leading-digit conventions of the simulator's hwrite do not matter as long as the sign is carried"""
+    rows = []
+    for line in open(path):
+        f = line.split()
+        if f:
+            vals = []
+            for w in f:
+                v, bits = int(w, 16), 4 * len(w)
+                vals.append(v - (1 << bits) if v >> (bits - 1) else v)
+            rows.append(vals)
+    return np.array(rows, dtype=np.int64).reshape(len(rows), -1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("case")
@@ -30,9 +45,13 @@ def main():
     if not ent:
         sys.exit("no such case/mode in the manifest: %s %s" % (a.case, a.mode))
     ent = ent[0]
-    want = np.loadtxt(os.path.join(a.expected_dir, ent["expected"]), dtype=np.int64, ndmin=2)
-    got = np.loadtxt(a.dump, dtype=np.int64, ndmin=2)
-    if ent["tb"] == "tb_pair_dump" and not a.no_reference_wiring:
+    pair = ent["tb"] in ("tb_pair_dump", "tb_pair_hex")
+    if ent.get("text") == "hex":  # full-width two's-complement hex words (tb_single_hex / tb_pair_hex)
+        want, got = read_hex(os.path.join(a.expected_dir, ent["expected"])), read_hex(a.dump)
+    else:
+        want = np.loadtxt(os.path.join(a.expected_dir, ent["expected"]), dtype=np.int64, ndmin=2)
+        got = np.loadtxt(a.dump, dtype=np.int64, ndmin=2)
+    if pair and not a.no_reference_wiring:
         want = want.copy()
         want[:, 2] = want[:, 0]  # Q0_IM <- re of lane 0
         want[:, 1] = want[:, 3]  # Q1_RE <- im of lane 1   (columns: Q0_RE Q1_RE Q0_IM Q1_IM)
@@ -42,7 +61,7 @@ def main():
         sys.exit("FAIL: the dump holds %d lines, %d expected (simulation stopped early?)" % (got.shape[0], want.shape[0]))
     got = got[: want.shape[0]]
     bad = np.argwhere(got != want)
-    per_frame = (1 << ent["nfft"]) // (2 if ent["tb"] == "tb_pair_dump" else 1)
+    per_frame = (1 << ent["nfft"]) // (2 if pair else 1)
     if len(bad) == 0:
         print("PASS  %s %s: %d lines (%d frames of 2^%d points) bit-exact" % (a.case, a.mode, want.shape[0], want.shape[0] // per_frame, ent["nfft"]))
         return 0

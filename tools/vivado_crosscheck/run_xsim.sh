@@ -12,15 +12,15 @@ KIT=$(cd "$(dirname "$0")" && pwd)
 WORK=${WORK:-$PWD/xsim_crosscheck}
 mkdir -p "$WORK" && cd "$WORK"
 
-# every synthesisable VHDL source of the reference (not its testbenches), then the kit's two testbenches
+# every synthesisable VHDL source of the reference (not its testbenches), then the kit's four testbenches (integer text I/O up to 32 bits, hex text I/O beyond)
 find "$INTFFTK_DIR/src/vhdl" -name '*.vhd' ! -path '*/tb/*' | sort > sources.f
-xvhdl -work work $(cat sources.f) "$KIT/tb_single_dump.vhd" "$KIT/tb_pair_dump.vhd"
+xvhdl -work work $(cat sources.f) "$KIT/tb_single_dump.vhd" "$KIT/tb_pair_dump.vhd" "$KIT/tb_single_hex.vhd" "$KIT/tb_pair_hex.vhd"
 
 status=0
 run_case() { # tb case mode nfft format rndmode stimulus data_width twdl_width xseries
     local tb=$1 case=$2 mode=$3 nfft=$4 fmt=$5 rnd=$6 stim=$7 dw=$8 tw=$9 xs=${10} infile outfile
     if [ "$tb" = tb_single_dump ]; then infile=IN_FILE; else infile=IN_FILE; fi
-    outfile="$WORK/${case}_${mode}_rtl.dat"
+    outfile="$WORK/${case}_${mode}_rtl.dat"   # (hex cases: the same name, hex words inside -- compare.py reads the manifest)
     xelab -L unisim -L unimacro work.$tb -s snap_${case}_${mode} \
         -generic_top "NFFT=$nfft" -generic_top "FORMAT=$fmt" -generic_top "RNDMODE=$rnd" \
         -generic_top "DATA_WIDTH=$dw" -generic_top "TWDL_WIDTH=$tw" -generic_top "XSERIES=$xs" \
