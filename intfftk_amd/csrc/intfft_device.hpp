@@ -292,8 +292,7 @@ __device__ __forceinline__ void cmult(i128 dre, i128 dim, int32_t wr, int32_t wi
 // ---- sum / difference with the three scaling variants --------------------------------------
 // trunc  : (A >> 1) +/- (B >> 1)   LSB dropped BEFORE the add (int_dif2_fly.vhd:151-154)
 // round  : rhu2(A +/- B) on the exact (DTW+1)-bit sum, wrapped to DTW bits (:173-218); written
-//          without the extra bit: rhu2(A+B) = (A>>1)+(B>>1)+((A|B)&1), rhu2(A-B) = (A>>1)-(B>>1)+(A&~B&1)
-//          (the dedicated kernels use the shorter forms (A|B) - T, (A&~B) - T with T = (A^B) >> 1: intfft_pk16.hpp)
+//          without the extra bit: rhu2(A+B) = (A|B) - ((A^B) >> 1), rhu2(A-B) = rhu2(A+B) - B  (derivation: sumdiff, intfft_pk16.hpp)
 // unscaled: A +/- B, one bit of growth (:222-240)
 // RNDC: the rounding kind when the caller knows it at compile time (k_pass<T, RND>: one kind per plan), else -1
 template <typename T, int RNDC = -1>
@@ -305,8 +304,8 @@ __device__ __forceinline__ void addsub(T a, T b, int rnd_rt, int wo, T &s, T &d)
         s = (a >> 1) + (b >> 1);
         d = (a >> 1) - (b >> 1);
     } else if (rnd == RND_ROUND) {
-        s = wrapw<T>((T)((U)(a >> 1) + (U)(b >> 1) + (U)((a | b) & 1)), wo);
-        d = wrapw<T>((T)((U)(a >> 1) - (U)(b >> 1) + (U)(a & ~b & 1)), wo);
+        s = wrapw<T>((T)((U)(a | b) - (U)((a ^ b) >> 1)), wo); // (the wrap of s is the identity on in-range operands; kept here: generic kernel)
+        d = wrapw<T>((T)((U)s - (U)b), wo);                       // rhu2(A - B) = rhu2(A + B) - B
     } else {
         s = (T)((U)a + (U)b);
         d = (T)((U)a - (U)b);

@@ -10,6 +10,10 @@
 // with block-wide LDS transposes of two dword planes (re, im) in one 40 KiB region, on unpacked int32 registers with
 // the parameterised butterflies of intfft_u32.hpp (gfly: every multiplier regime, trunc / round / unscaled).
 // Thread-dependent twiddles (30 pairs) are frame invariant and live in VGPRs.
+// rhu2 sums in their long form here: with the short form of intfft_u32.hpp (four operations for rhu2(A + B), one more for rhu2(A - B)) the
+// scheduler interleaves more butterflies and the 4096-point block kernels spill under their 128-register bound (60 .. 132 bytes per lane
+// of scratch in the RNDMODE = 1 instantiations, 178 against 199 Gsample/s measured); every other kernel family takes the short form.
+#define INTFFT_RHU2_LONG
 #include "intfft_u32.hpp"
 
 namespace intfft {

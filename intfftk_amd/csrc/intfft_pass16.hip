@@ -53,9 +53,10 @@ __device__ __forceinline__ void p16_addsub(u32 a, u32 b, bool round, u32 &s, u32
         s = p16_u32(A1 + B1);
         d = p16_u32(A1 - B1);
     } else { // rhu2 of the exact sums, wrapped to 16 bits (:173-218)
-        const v2s T = (A ^ B) >> (short)1; // rhu2(A + B) = (A | B) - T, rhu2(A - B) = (A & ~B) - T (derivation: sumdiff, intfft_pk16.hpp)
-        s = p16_u32((A | B) - T);
-        d = p16_u32((A & ~B) - T);
+        const v2s T = (A ^ B) >> (short)1; // rhu2(A + B) = (A | B) - T, rhu2(A - B) = rhu2(A + B) - B (derivation: sumdiff, intfft_pk16.hpp)
+        const v2s S = (A | B) - T;
+        s = p16_u32(S);
+        d = p16_u32(S - B);
     }
 }
 

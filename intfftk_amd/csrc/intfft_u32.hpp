@@ -200,11 +200,21 @@ __device__ __forceinline__ void gfly(int &are, int &aim, int &bre, int &bim, int
         dre = ar - br, dim = ai - bi;
         are = ar + br, aim = ai + bi;
     } else { // rhu2(A +/- B) on the exact sum, wrapped to DTW bits (int_dif2_fly.vhd:173-218)
+        // rhu2(A + B) = (A | B) - ((A ^ B) >> 1): always inside the DTW bits of its operands, no wrap; rhu2(A - B) = rhu2(A + B) - B, which
+        // leaves the range only for A = max, B = min: the RTL's wrap (derivation: sumdiff, intfft_pk16.hpp).  7 operations per component
+        // instead of 17, all of them in the fast-issue VOP2 class.
+#ifdef INTFFT_RHU2_LONG // (A/B: the form of rounds 1-5)
         const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
         dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
         dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
         are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
         aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+#else
+        const int sr = (are | bre) - ((are ^ bre) >> 1), si = (aim | bim) - ((aim ^ bim) >> 1);
+        dre = (int)((u32)(sr - bre) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(si - bim) << s.wosh) >> s.wosh;
+        are = sr, aim = si;
+#endif
     }
     unsigned long long xr, xi;
     if (MASKED) {
@@ -233,11 +243,21 @@ __device__ __forceinline__ void gfly_triv(int &are, int &aim, int &bre, int &bim
         dre = ar - br, dim = ai - bi;
         are = ar + br, aim = ai + bi;
     } else {
+        // rhu2(A + B) = (A | B) - ((A ^ B) >> 1): always inside the DTW bits of its operands, no wrap; rhu2(A - B) = rhu2(A + B) - B, which
+        // leaves the range only for A = max, B = min: the RTL's wrap (derivation: sumdiff, intfft_pk16.hpp).  7 operations per component
+        // instead of 17, all of them in the fast-issue VOP2 class.
+#ifdef INTFFT_RHU2_LONG // (A/B: the form of rounds 1-5)
         const int ar = are >> 1, ai = aim >> 1, br = bre >> 1, bi = bim >> 1;
         dre = (int)((u32)(ar - br + (are & ~bre & 1)) << s.wosh) >> s.wosh;
         dim = (int)((u32)(ai - bi + (aim & ~bim & 1)) << s.wosh) >> s.wosh;
         are = (int)((u32)(ar + br + ((are | bre) & 1)) << s.wosh) >> s.wosh;
         aim = (int)((u32)(ai + bi + ((aim | bim) & 1)) << s.wosh) >> s.wosh;
+#else
+        const int sr = (are | bre) - ((are ^ bre) >> 1), si = (aim | bim) - ((aim ^ bim) >> 1);
+        dre = (int)((u32)(sr - bre) << s.wosh) >> s.wosh;
+        dim = (int)((u32)(si - bim) << s.wosh) >> s.wosh;
+        are = sr, aim = si;
+#endif
     }
     if (ODD) {
         bre = dim;
@@ -262,11 +282,18 @@ template <int MODE> __device__ __forceinline__ void gsumdiff(int &are, int &aim,
         bre = ar - xr, bim = ai - xi;
         are = ar + xr, aim = ai + xi;
     } else {
+#ifdef INTFFT_RHU2_LONG
         const int ar = are >> 1, ai = aim >> 1, xr = tr >> 1, xi = ti >> 1;
         bre = (int)((u32)(ar - xr + (are & ~tr & 1)) << s.wosh) >> s.wosh;
         bim = (int)((u32)(ai - xi + (aim & ~ti & 1)) << s.wosh) >> s.wosh;
         are = (int)((u32)(ar + xr + ((are | tr) & 1)) << s.wosh) >> s.wosh;
         aim = (int)((u32)(ai + xi + ((aim | ti) & 1)) << s.wosh) >> s.wosh;
+#else
+        const int sr = (are | tr) - ((are ^ tr) >> 1), si = (aim | ti) - ((aim ^ ti) >> 1); // rhu2(A + T), then rhu2(A - T) = rhu2(A + T) - T (see gfly)
+        bre = (int)((u32)(sr - tr) << s.wosh) >> s.wosh;
+        bim = (int)((u32)(si - ti) << s.wosh) >> s.wosh;
+        are = sr, aim = si;
+#endif
     }
 }
 template <int MODE, bool UNIFORM_W = false, bool MASKED = true>
