@@ -137,7 +137,8 @@ __device__ __forceinline__ void transform_phase1(u32 (&v)[16], const Twiddles<(R
 template <int L, int ROUND, bool OUT_BITREV, int FASTX>
 __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
                                                const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                               const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
+                                               const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user,
+                                               bool out_lanes = false)
 {
     static_assert(L >= 7 || !OUT_BITREV, "native orders need N >= 128");
     constexpr bool P = !ROUND;
@@ -231,6 +232,19 @@ __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f,
             if (L < 10 && !st_ok && f * (size_t)(1 << (10 - L)) + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) >= nframes_user)
                 continue;
             const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            if (out_lanes) {
+                // BITREV_LANES (outbuf_half_path.vhd:160-172: the serial stream [lane 0 frame ; lane 1 frame] that int_bitrev_order reads):
+                // core position n of a frame goes to memory index (n & 1) * N/2 + (n >> 1).  The vector holds four consecutive n:
+                // the even ones are two consecutive words of the first half, the odd ones of the second -- two 8-byte stores,
+                // 512 contiguous bytes per wave instruction each.
+                typedef u32 v2u __attribute__((ext_vector_type(2)));
+                const int n0 = 4 * (64 * q + (((lane & 15) << 2) | (lane >> 4))), nl = n0 & ((1 << L) - 1);
+                u32 *const d = out + f * 1024 + (n0 - nl) + (nl >> 1);
+                const v2u ev = {x.x, x.z}, od = {x.y, x.w};
+                __builtin_nontemporal_store(ev, reinterpret_cast<v2u *>(d));
+                __builtin_nontemporal_store(od, reinterpret_cast<v2u *>(d + (1 << (L - 1))));
+                continue;
+            }
             __builtin_nontemporal_store(x, dst + 64 * q);
         }
     } else if constexpr (L < 10) {
@@ -286,10 +300,11 @@ __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f,
 template <int L, int ROUND, bool OUT_BITREV, int FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
+                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user,
+                                                bool out_lanes = false)
 {
     transform_phase1<L, ROUND, FASTX>(v, tw, sl);
-    transform_tail<L, ROUND, OUT_BITREV, FASTX>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+    transform_tail<L, ROUND, OUT_BITREV, FASTX>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
 }
 
 // Magnitude votes of the 16-bit fast path (N >= 256).  Fast extraction needs every 32-bit dot-product sum inside [-2^30, 2^30), i.e.
@@ -326,8 +341,10 @@ __device__ __forceinline__ bool frame_within_T_after_phase1(const u32 (&v)[16])
 template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
 __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const Fast1024Consts c, size_t nframes_user, const Slice sl,
-                                                     int in_halves)
+                                                     int io_flags)
 {
+    const int in_halves = io_flags & 1;                    // HALVES beats in
+    const bool out_lanes = OUT_BITREV && (io_flags & 2);   // BITREV_LANES instead of BITREV out (wave-uniform: a kernel argument)
     constexpr int FP = 1 << (10 - L);                         // frames per 1024-sample chunk
     const size_t nframes = (nframes_user + FP - 1) / FP;      // chunks ("frames" of the wave loop below)
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROW_DW];
@@ -429,22 +446,22 @@ __global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, co
                     transform_phase1<L, ROUND, 2>(v, tw, sl); // the t = 16 exact form (mul2x_t16)
                     fast = frame_within_T_after_phase1(v);
                 }
-                if (fast) transform_tail<L, ROUND, OUT_BITREV, 1>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
-                else transform_tail<L, ROUND, OUT_BITREV, 2>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+                if (fast) transform_tail<L, ROUND, OUT_BITREV, 1>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+                else transform_tail<L, ROUND, OUT_BITREV, 2>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
                 return;
             }
         }
         if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) {
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
             return;
         }
         // exact path.  DATA_WIDTH < 16: containers wrapped to w bits, w-bit exact extraction (and w-bit rhu2 wraps in round mode).
         // A FAST_OK kernel is launched for 16-bit twiddles only: its 16-bit exact path is the t = 16 form (mul2x_t16).
         if (sl.wd != 16) wrap_inputs(v, sl.wd);
         if (FAST_OK && sl.wd == 16)
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
         else
-            transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+            transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0
@@ -517,8 +534,8 @@ bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, i
 {
     if (!(packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && direction == 0 && use_fly == 1))
         return false;
-    // N >= 128: NATURAL or HALVES (native int_fftNk beats) in, NATURAL or BITREV (native) out; N = 64: natural only
-    if (log2n >= 7 && log2n <= 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1);
+    // N >= 128: NATURAL or HALVES (native int_fftNk beats) in, NATURAL, BITREV (native) or BITREV_LANES (the serial form) out; N = 64: natural only
+    if (log2n >= 7 && log2n <= 10) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1 || out_order == 3);
     return log2n == 6 && in_order == 0 && out_order == 0;
 }
 
@@ -568,9 +585,10 @@ static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast10
 }
 
 template <int L>
-static hipError_t launch_short(int round, bool out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
+static hipError_t launch_short(int round, int out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
                                const Fast1024Consts &c, size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
 {
+    if (out_bitrev == 2) in_halves |= 2; // io_flags bit 1: BITREV_LANES store map of the OUT_BITREV instantiations
     if constexpr (L >= 7) {
         if (out_bitrev)
             return round == 2   ? launch_t<L, 2, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)

@@ -161,12 +161,22 @@ __global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, c
         } else if (MODE == X_INV && in_bitrev) {
             // memory index = n: x4 loads give (regs n9 n8 n1 n0, lane n3 n2 n7..4); two lane swaps -> (regs n3..0, lane n9..4)
             typedef u32 v4u __attribute__((ext_vector_type(4)));
+            typedef u32 v2u __attribute__((ext_vector_type(2)));
             const v4u *s4 = reinterpret_cast<const v4u *>(src) + (((lane & 15) << 2) | (lane >> 4));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u}; // short frames: the vector's frame = bits a9..aL of (q, lane & 15)
-                if (!partial || f * FP + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) < nframes_user)
-                    x = INTFFT_LD(s4 + 64 * q);
+                if (!partial || f * FP + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) < nframes_user) {
+                    if (in_bitrev == 2) {
+                        // BITREV_LANES in (the serial stream of outbuf_half_path.vhd:160-172): core position n sits at memory index
+                        // (n & 1) * N/2 + (n >> 1), so the vector's four consecutive n are two 8-byte pieces, one per half of its frame
+                        const int n0 = 4 * (64 * q + (((lane & 15) << 2) | (lane >> 4))), nl = n0 & ((1 << L) - 1);
+                        const u32 *const d = src + (n0 - nl) + (nl >> 1);
+                        const v2u ev = INTFFT_LD(reinterpret_cast<const v2u *>(d)), od = INTFFT_LD(reinterpret_cast<const v2u *>(d + (1 << (L - 1))));
+                        x = v4u{ev.x, od.x, ev.y, od.y};
+                    } else
+                        x = INTFFT_LD(s4 + 64 * q);
+                }
                 v[4 * q] = x.x;
                 v[4 * q + 1] = x.y;
                 v[4 * q + 2] = x.z;
@@ -280,10 +290,10 @@ bool fast1024x_supported(int log2n, int data_width, int twdl_width, int format, 
         return false;
     if (rndmode && diag_env("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: the same orders as truncate mode
     if (log2n == 6) return (direction == 1 || direction == 2) && in_order == 0 && out_order == 0;
-    // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) in and HALVES (native) out
+    // N >= 128: the inverse also takes BITREV (native int_ifftNk beats) or BITREV_LANES (their serial form) in and HALVES (native) out
     return log2n >= 7 && log2n <= 10 &&
            ((direction == 2 && in_order == 0 && out_order == 0) ||
-            (direction == 1 && (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)));
+            (direction == 1 && (in_order == 0 || in_order == 1 || in_order == 3) && (out_order == 0 || out_order == 2)));
 }
 
 const char *fast1024x_kernel_name() { return "k_fft1024x_i16"; }

@@ -125,7 +125,7 @@ struct Fast1024Args {
     int log2n;      // 6..10: frames shorter than 1024 samples share a wave (2^(10 - log2n) per pass)
     int twd;        // twiddle width (<= 16)
     int rnd;        // RoundKind (RND_TRUNC / RND_ROUND)
-    int out_bitrev; // 0: NATURAL output, 1: BITREV output
+    int out_bitrev; // 0: NATURAL output, 1: BITREV output, 2: BITREV_LANES output (the BITREV kernels with the serial-stream store map)
     int in_halves;  // 0: NATURAL input, 1: HALVES input (native int_fftNk beats)
 };
 bool fast1024_supported(int log2n, int data_width, int twdl_width, int format, int rndmode,

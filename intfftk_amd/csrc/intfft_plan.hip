@@ -168,6 +168,7 @@ struct intfft_plan {
     intfft_plan *pair_f = nullptr, *pair_i = nullptr;
     void *pair_buf = nullptr;
     size_t pair_frames = 0;
+    int lanes_mode = 0;             // BITREV_LANES composite: 1 = pair_f (BITREV out) -> pair_buf -> bit permutation, 2 = bit permutation -> pair_buf -> pair_f (BITREV in)
     bool fastw64 = false;  // N = 64 .. 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
     StageDesc st64[12] = {};
     bool fastw64b = false; // N = 2048 / 4096 forward / inverse, results of 33 .. 64 bits beyond k_fft4096_w32's 64-bit last round
@@ -797,6 +798,40 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         intfft_plan_destroy(pl);
         return rc;
     }
+    // BITREV_LANES (the serial stream of outbuf_half_path.vhd:160-172 / int_bitrev_order.vhd:82-104) at one end of a plan whose BITREV twin
+    // has dedicated kernels: that twin + one bit permutation (BITREV <-> BITREV_LANES is a rotation of the memory index by one bit) through a
+    // chunked middle buffer.  The packed 16-bit kernels of N = 128 .. 1024 carry the order as a store / load map of their own and never come here.
+    if (!l1 && p->use_fly == 1 && (p->in_order == INTFFT_ORDER_BITREV_LANES) != (p->out_order == INTFFT_ORDER_BITREV_LANES) &&
+        !diag_env("INTFFT_GENERIC_ONLY") && !diag_env("INTFFT_NO_LANES_COMPOSITE") &&
+        !fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order) &&
+        !fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order)) {
+        const bool in_l = p->in_order == INTFFT_ORDER_BITREV_LANES;
+        const int cb = in_l ? pl->in_cb : pl->out_cb;
+        intfft_params q = *p;
+        (in_l ? q.in_order : q.out_order) = INTFFT_ORDER_BITREV;
+        auto dedicated = [](const intfft_plan *s) { return s && (s->passes.empty() || s->big20 || s->bigw || s->wide16 || s->is_pair); };
+        if (cb <= 8 && create_plan(&pl->pair_f, &q, 0, hip_device) == INTFFT_OK && dedicated(pl->pair_f)) {
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)cb;
+            size_t mb = 256;
+            if (const char *e = diag_env("INTFFT_SCRATCH_MB")) mb = atoi(e) > 0 ? (size_t)atoi(e) : mb;
+            pl->pair_frames = std::max<size_t>(1, (mb << 20) / frame_bytes);
+            if (hipMalloc(&pl->pair_buf, pl->pair_frames * frame_bytes) != hipSuccess) {
+                intfft_plan_destroy(pl);
+                return INTFFT_ERR_ALLOC;
+            }
+            (void)hipFree(pl->d_tw); // the twin carries its own tables; the host copy stays for intfft_twiddles
+            pl->d_tw = nullptr;
+            pl->lanes_mode = in_l ? 2 : 1;
+            pl->scratch_frame_bytes = frame_bytes;
+            pl->scratch_bytes = pl->pair_frames * frame_bytes + pl->pair_f->scratch_bytes;
+            std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), in_l ? "lanes[k_rotate1|%.40s]" : "lanes[%.40s|k_rotate1]", pl->pair_f->kernel_name);
+            *out = pl;
+            return INTFFT_OK;
+        }
+        if (pl->pair_f) intfft_plan_destroy(pl->pair_f);
+        pl->pair_f = nullptr;
+    }
+
     if (l1 && !diag_env("INTFFT_2D_GENERIC")) {
         // composite 2-D plan: the cores are 1-D sub-plans (NATURAL -> NATURAL) on re-laid-out data
         const int l2 = p->log2n - l1, F = p->format;
@@ -1104,7 +1139,7 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         pl->fargs.log2n = p->log2n;
         pl->fargs.twd = p->twdl_width;
         pl->fargs.rnd = p->rndmode ? RND_ROUND : RND_TRUNC;
-        pl->fargs.out_bitrev = p->out_order == INTFFT_ORDER_BITREV;
+        pl->fargs.out_bitrev = p->out_order == INTFFT_ORDER_BITREV ? 1 : p->out_order == INTFFT_ORDER_BITREV_LANES ? 2 : 0;
         pl->fargs.in_halves = p->in_order == INTFFT_ORDER_HALVES;
         std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), "%s", fast1024_kernel_name());
     } else {
@@ -1345,6 +1380,16 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast16k || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
+    if (plan->lanes_mode) {
+        intfft_plan_info sf;
+        if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK) return INTFFT_ERR_INVALID;
+        info->n_passes = sf.n_passes + 1;
+        info->compute_word = sf.compute_word;
+        info->fast_path = sf.fast_path;
+        info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
+        std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
+        return INTFFT_OK;
+    }
     if (plan->is_pair) {
         intfft_plan_info sf, si;
         if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK || intfft_plan_get_info(plan->pair_i, &si) != INTFFT_OK) return INTFFT_ERR_INVALID;
@@ -1424,6 +1469,10 @@ static size_t ws_need(const intfft_plan *pl, size_t batch)
             if (pl->sub_col_i) sub = std::max(sub, ws_need(pl->sub_col_i, bf << l2));
         }
         return (size_t)pl->n2d_bufs * ws_align(bf * ((size_t)2 << pl->L) * (size_t)pl->out_cb) + sub;
+    }
+    if (pl->lanes_mode) {
+        const size_t pf = std::min(pl->pair_frames, batch);
+        return ws_align(pf * pl->scratch_frame_bytes) + ws_need(pl->pair_f, pf);
     }
     if (pl->is_pair) {
         const size_t pf = std::min(pl->pair_frames, batch);
@@ -1689,6 +1738,31 @@ int intfft_plan_release_scratch(intfft_plan *plan)
 static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, hipStream_t stream, char *ws)
 {
     if (plan->is2d) return exec_2d(plan, d_in, d_out, batch, stream, ws);
+    if (plan->lanes_mode) { // BITREV_LANES composite: the BITREV twin and one bit permutation through the middle buffer, chunk by chunk
+        const int L = plan->L;
+        const size_t in_frame = ((size_t)2 << L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << L) * (size_t)plan->out_cb;
+        const size_t pf = ws ? std::min(plan->pair_frames, batch) : plan->pair_frames;
+        void *const mid = ws ? ws : plan->pair_buf;
+        char *const subws = ws ? ws + ws_align(pf * plan->scratch_frame_bytes) : nullptr;
+        // memory index m_B (BITREV) and m_S (BITREV_LANES) of one sample: m_S = (m_B & 1) << (L-1) | m_B >> 1
+        int perm[24]; // m_in bit perm[b] = m_out bit b
+        for (int b = 0; b < L; ++b) perm[b] = plan->lanes_mode == 1 ? (b == L - 1 ? 0 : b + 1) : (b == 0 ? L - 1 : b - 1);
+        for (size_t f = 0; f < batch; f += pf) {
+            const size_t nf = std::min(pf, batch - f);
+            const char *src = static_cast<const char *>(d_in) + f * in_frame;
+            char *dst = static_cast<char *>(d_out) + f * out_frame;
+            int rc;
+            if (plan->lanes_mode == 1) {
+                rc = exec_core(plan->pair_f, src, mid, nf, stream, subws);
+                if (rc == INTFFT_OK) rc = (int)launch_bitperm(L, plan->out_cb, perm, mid, dst, nf, stream);
+            } else {
+                rc = (int)launch_bitperm(L, plan->in_cb, perm, src, mid, nf, stream);
+                if (rc == INTFFT_OK) rc = exec_core(plan->pair_f, mid, dst, nf, stream, subws);
+            }
+            if (rc != INTFFT_OK) return rc;
+        }
+        return INTFFT_OK;
+    }
     if (plan->is_pair) { // composite pair: forward sub-plan -> middle buffer -> inverse sub-plan, chunk by chunk
         const size_t in_frame = ((size_t)2 << plan->L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << plan->L) * (size_t)plan->out_cb;
         const size_t pf = ws ? std::min(plan->pair_frames, batch) : plan->pair_frames;
@@ -1737,7 +1811,8 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
     if (plan->fast1024)
         return (int)launch_fast1024(plan->fargs, d_in, d_out, plan->d_tw, plan->h_tw.data(), batch, stream);
     if (plan->fast1024x)
-        return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width, plan->p.in_order == INTFFT_ORDER_BITREV,
+        return (int)launch_fast1024x(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
+                                     plan->p.in_order == INTFFT_ORDER_BITREV ? 1 : plan->p.in_order == INTFFT_ORDER_BITREV_LANES ? 2 : 0,
                                      plan->p.out_order == INTFFT_ORDER_HALVES, d_in, d_out, plan->d_tw,
                                      plan->h_tw.data(), batch, stream, plan->p.rndmode, plan->p.data_width);
     if (plan->fast16k)

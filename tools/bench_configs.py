@@ -62,7 +62,7 @@ def run(name, steps=None, check_frames=8):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     p = C.make_params(log2n, dw, tw, fmt, rnd, True)
-    om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES}
+    om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
     dd = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
     if core.out_container == 16:  # results beyond 64 bits: the Python twin, small lengths only (tests/test_gpu_wide128.py)
         from intfftk_amd.engine import wide_to_int
@@ -93,13 +93,16 @@ def run(name, steps=None, check_frames=8):
 
 
 def adhoc(spec):
-    """spec "L:DW:TW:FMT[:RND[:DIR[:L1]]]" -> a 256 MiB-input config with that shape, e.g. 11:16:16:0 (L1: 2-D scheme, N1 = 2^L1)"""
+    """spec "L:DW:TW:FMT[:RND[:DIR[:L1[:IN_ORDER:OUT_ORDER]]]]" -> a 256 MiB-input config with that shape, e.g. 11:16:16:0 (L1: 2-D scheme,
+    N1 = 2^L1, 0 = none), 10:16:16:0:0:FWD:0:NATURAL:BITREV_LANES"""
     f = spec.split(":")
     log2n, dw, tw, fmt = (int(v) for v in f[:4])
     rnd = int(f[4]) if len(f) > 4 else 0
     direction = f[5] if len(f) > 5 else "FWD"
-    if len(f) > 6:
+    if len(f) > 6 and int(f[6]):
         NFFT1[spec] = int(f[6])
+    if len(f) > 8:
+        ORDERS[spec] = (f[7], f[8])
     in_cb = 2 if dw <= 16 else 4 if dw <= 32 else 8
     ob = dw + (fmt * log2n) * (2 if direction == "PAIR" else 1)
     out_cb = 2 if ob <= 16 else 4 if ob <= 32 else 8 if ob <= 64 else 16
