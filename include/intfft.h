@@ -104,61 +104,71 @@ int intfft_io_widths(const intfft_params *p, int *in_bits, int *out_bits, int *i
  * chooses the kernels.  intfft_exec never modifies the plan; intfft_exec_host, intfft_shard_prepare and
  * intfft_exec_sharded create (grow-only) staging state inside it on first use -- see their comments. */
 int intfft_plan_create(intfft_plan **out, const intfft_params *p, int hip_device);
-/* N > 512K: the "2D-FFT scheme" the reference names but does not define (int_fftNk.vhd:11-13: "For N > 512K you should
- * use 2D-FFT scheme"; row_twiddle_tay.vhd:31).  THIS IS AN EXTENSION OF THIS LIBRARY, specified in DESIGN.md section 4.5
- * and restated in oracle/: N = 2^log2n = N1 * N2 with N1 = 2^log2_n1 and both factors native core lengths (3..19 bits,
- * log2n <= 24), built from the reference's own blocks --
- *   forward  N1-point int_fftNk over n1 (n = n1*N2 + n2) for every n2; one int_cmult_dsp48 per sample by the inter-pass
- *            twiddle W_N^(k1*n2) (the quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full depth, no Taylor
- *            step) at the width reached there; N2-point int_fftNk over n2 for every k1; X[k1 + N1*k2]
- *   inverse  the mirror with int_ifftNk and the re/im-swapped multiplier feed (int_dit2_fly.vhd:304-322); pair = both.
- * Widths, scaling, rounding, XSER, orders and containers mean what they mean for the 1-D cores (DATA_WIDTH + FORMAT*log2n
- * bits out); `intfft_params.log2n` is the TOTAL length, so the ABI struct is unchanged.  Results differ in the last bits
- * from a 1-D plan of the same length (different twiddle factorisation); both are within the same distance of the exact
- * DFT.  use_fly = 0 is not defined for this scheme (INTFFT_ERR_INVALID).  intfft_twiddles(plan, -1, ..) returns the
- * inter-pass table (N entries), stages 0 .. max(log2 N1, log2 N2) - 1 the per-stage tables shared by the two cores. */
+/* N > 512K: the "2D-FFT scheme" the reference names but does not define (int_fftNk.vhd:11-13: "For N > 512K you
+ * should use 2D-FFT scheme"; row_twiddle_tay.vhd:31).  THIS IS AN EXTENSION OF THIS LIBRARY, specified in DESIGN.md
+ * section 4.5 and restated in oracle/: N = 2^log2n = N1 * N2 with N1 = 2^log2_n1 and both factors native core lengths
+ * (3..19 bits, log2n <= 24), built from the reference's own blocks --
+ *   forward  N1-point int_fftNk over n1 (n = n1*N2 + n2) for every n2; one int_cmult_dsp48 per sample by the
+ *            inter-pass twiddle W_N^(k1*n2) (the quarter-wave ROM formula of rom_twiddle_int.vhd:143-152 at full
+ *            depth, no Taylor step) at the width reached there; N2-point int_fftNk over n2 for every k1; X[k1 +
+ *            N1*k2]
+ *   inverse  the mirror with int_ifftNk and the re/im-swapped multiplier feed (int_dit2_fly.vhd:304-322);
+ *            pair = both.
+ * Widths, scaling, rounding, XSER, orders and containers mean what they mean for the 1-D cores (DATA_WIDTH +
+ * FORMAT*log2n bits out); `intfft_params.log2n` is the TOTAL length, so the ABI struct is unchanged.  Results differ
+ * in the last bits from a 1-D plan of the same length (different twiddle factorisation); both are within the same
+ * distance of the exact DFT.  use_fly = 0 is not defined for this scheme (INTFFT_ERR_INVALID).  intfft_twiddles(plan,
+ * -1, ..) returns the inter-pass table (N entries), stages 0 .. max(log2 N1, log2 N2) - 1 the per-stage tables shared
+ * by the two cores. */
 int intfft_plan_create_2d(intfft_plan **out, const intfft_params *p, int log2_n1, int hip_device);
 int intfft_plan_destroy(intfft_plan *plan);
 int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info);
 
-/* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers
- * (see intfft_io_widths), aligned to one complex sample (2 containers: 4 bytes for int16 pairs) -- the dedicated kernels then issue 8- and
- * 16-byte vector accesses on addresses that are only sample-aligned, which is legal in the unaligned-access mode HIP runs gfx950 in
- * (SH_MEM_CONFIG.alignment_mode = unaligned, the ROCm default; tests/test_gpu_cabi.py shifts every kernel family's buffers by one sample);
- * buffers from hipMalloc are 256-byte aligned and need no thought; nothing outside the output array is written and the loads of absent frames of a partial last group are predicated
- * (tests/test_gpu_cabi.py::test_no_writes_outside_the_output_buffer: guard bands, ragged batches, buffers one sample off a 64 KiB boundary).
- * Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream).
- * d_in == d_out is allowed when the containers have equal size; any other overlap of the two byte ranges
- * returns INTFFT_ERR_INVALID (a block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
- * (kernel, device) on first use, under a mutex);
- * a plan WITHOUT plan-owned scratch (intfft_plan_info.scratch_bytes == 0: every single-launch plan) holds no mutable state and may be executed on any
- * number of streams at once; a plan that owns scratch (the multi-pass plans) must not be executed concurrently on two streams THROUGH THIS ENTRY POINT --
- * use intfft_exec_ws below with one workspace per stream (or one plan per stream).  Some multi-pass plans (N = 2^19 / 2^20 forward and inverse, the
- * 24-bit unscaled class, the tiled 2-D plans) run the scratch-sized chunks of a large batch alternately on `hip_stream` and on a side stream taken from
- * a pool inside the plan for the duration of the call (event fork at entry, event join before returning): towards the caller the call is still ordered
- * on `hip_stream` only. */
+/* Transforms `batch` frames: d_in/d_out are device pointers to [batch][N][2] containers (see intfft_io_widths),
+ * aligned to one complex sample (2 containers: 4 bytes for int16 pairs) -- the dedicated kernels then issue 8- and
+ * 16-byte vector accesses on addresses that are only sample-aligned, which is legal in the unaligned-access mode HIP
+ * runs gfx950 in (SH_MEM_CONFIG.alignment_mode = unaligned, the ROCm default; tests/test_gpu_cabi.py shifts every
+ * kernel family's buffers by one sample); buffers from hipMalloc are 256-byte aligned and need no thought; nothing
+ * outside the output array is written and the loads of absent frames of a partial last group are predicated
+ * (tests/test_gpu_cabi.py::test_no_writes_outside_the_output_buffer: guard bands, ragged batches, buffers one sample
+ * off a 64 KiB boundary). Asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). d_in == d_out is
+ * allowed when the containers have equal size; any other overlap of the two byte ranges returns INTFFT_ERR_INVALID (a
+ * block would overwrite frames another block has not read).  Re-entrant across plans (launch geometry is cached per
+ * (kernel, device) on first use, under a mutex); a plan WITHOUT plan-owned scratch (intfft_plan_info.scratch_bytes ==
+ * 0: every single-launch plan) holds no mutable state and may be executed on any number of streams at once; a plan
+ * that owns scratch (the multi-pass plans) must not be executed concurrently on two streams THROUGH THIS ENTRY POINT
+ * -- use intfft_exec_ws below with one workspace per stream (or one plan per stream).  Some multi-pass plans (N =
+ * 2^19 / 2^20 forward and inverse, the 24-bit unscaled class, the tiled 2-D plans) run the scratch-sized chunks of a
+ * large batch alternately on `hip_stream` and on a side stream taken from a pool inside the plan for the duration of
+ * the call (event fork at entry, event join before returning): towards the caller the call is still ordered on
+ * `hip_stream` only. */
 int intfft_exec(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *hip_stream);
 
-/* The same transform on a CALLER-SUPPLIED workspace: every plan is re-entrant through this entry point.  The RTL core is stateless between
- * instances (int_fftNk.vhd:23-37: frames may follow each other back to back, nothing is kept between them) and SURVEY.md section 8(b) asks for
- * an exec that is re-entrant across streams: with the inter-pass scratch, the layout buffers of the 2-D plans and the middle buffer of composite
- * pairs all carved out of `d_workspace`, a call reads the plan and writes nothing in it (the side stream of the two-stream plans comes from a
- * mutex-protected pool and goes back when the call returns), so ONE plan may run on any number of streams / host threads at once as long as every
- * concurrent call has its own workspace.
- *   intfft_plan_workspace_bytes(plan, batch, &bytes): the workspace with which a call of `batch` frames runs exactly like intfft_exec on the plan's
- *     own scratch (0 for single-launch plans: d_workspace may then be NULL).  Monotone in `batch` and bounded, but the bound depends on
- *     the plan family -- two 128 MiB scratch halves for the 1-D multi-pass plans; one or two 256 MiB layout buffers PLUS the row sub-plan's share
- *     for the 2-D scheme plans (512 MiB and more); the middle buffer plus the larger sub-plan for composite pairs -- so size pools from THIS
- *     call (e.g. with batch = SIZE_MAX for the largest a plan ever asks for), never from a constant.
- *   intfft_exec_ws(..., d_workspace, ws_bytes, stream): d_workspace is a device pointer on the plan's device, 256-byte aligned, not overlapping
- *     d_in / d_out.  A workspace smaller than intfft_plan_workspace_bytes(plan, batch) is accepted as long as it serves one frame
- *     (>= intfft_plan_workspace_bytes(plan, 1)): the batch is then cut into the largest sub-batches the workspace serves, one after the other on
- *     `hip_stream` (slower: no two-stream overlap inside a sub-batch that fits one scratch half); smaller than that -> INTFFT_ERR_INVALID.
- *   intfft_plan_release_scratch(plan): frees the plan-owned scratch (and that of its sub-plans) after waiting for the device; from then on
- *     intfft_exec / intfft_exec_host / intfft_exec_sharded on this plan return INTFFT_ERR_INVALID and only intfft_exec_ws runs it -- for callers
- *     that bring their own workspaces and do not want N x up to 256 MiB held by plans. */
+/* The same transform on a CALLER-SUPPLIED workspace: every plan is re-entrant through this entry point.  The RTL core
+ * is stateless between instances (int_fftNk.vhd:23-37: frames may follow each other back to back, nothing is kept
+ * between them) and SURVEY.md section 8(b) asks for an exec that is re-entrant across streams: with the inter-pass
+ * scratch, the layout buffers of the 2-D plans and the middle buffer of composite pairs all carved out of
+ * `d_workspace`, a call reads the plan and writes nothing in it (the side stream of the two-stream plans comes from a
+ * mutex-protected pool and goes back when the call returns), so ONE plan may run on any number of streams / host
+ * threads at once as long as every concurrent call has its own workspace.
+ *   intfft_plan_workspace_bytes(plan, batch, &bytes): the workspace with which a call of `batch` frames runs exactly
+ *     like intfft_exec on the plan's own scratch (0 for single-launch plans: d_workspace may then be NULL).  Monotone
+ *     in `batch` and bounded, but the bound depends on the plan family -- two 128 MiB scratch halves for the 1-D
+ *     multi-pass plans; one or two 256 MiB layout buffers PLUS the row sub-plan's share for the 2-D scheme plans (512
+ *     MiB and more); the middle buffer plus the larger sub-plan for composite pairs -- so size pools from THIS call
+ *     (e.g. with batch = SIZE_MAX for the largest a plan ever asks for), never from a constant.
+ *   intfft_exec_ws(..., d_workspace, ws_bytes, stream): d_workspace is a device pointer on the plan's device,
+ *     256-byte aligned, not overlapping d_in / d_out.  A workspace smaller than intfft_plan_workspace_bytes(plan,
+ *     batch) is accepted as long as it serves one frame (>= intfft_plan_workspace_bytes(plan, 1)): the batch is then
+ *     cut into the largest sub-batches the workspace serves, one after the other on `hip_stream` (slower: no
+ *     two-stream overlap inside a sub-batch that fits one scratch half); smaller than that -> INTFFT_ERR_INVALID.
+ *   intfft_plan_release_scratch(plan): frees the plan-owned scratch (and that of its sub-plans) after waiting for the
+ *     device; from then on intfft_exec / intfft_exec_host / intfft_exec_sharded on this plan return
+ *     INTFFT_ERR_INVALID and only intfft_exec_ws runs it -- for callers that bring their own workspaces and do not
+ *     want N x up to 256 MiB held by plans. */
 int intfft_plan_workspace_bytes(const intfft_plan *plan, size_t batch, size_t *bytes);
-int intfft_exec_ws(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *d_workspace, size_t ws_bytes, void *hip_stream);
+int intfft_exec_ws(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, void *d_workspace, size_t ws_bytes,
+                   void *hip_stream);
 int intfft_plan_release_scratch(intfft_plan *plan);
 
 /* Host-resident frames (the "streaming block" use): h_in/h_out are HOST pointers with the same layout
@@ -171,32 +181,35 @@ int intfft_plan_release_scratch(intfft_plan *plan);
  * This is NOT a CPU execution path: every frame is transformed on the HIP device. */
 int intfft_exec_host(intfft_plan *plan, const void *h_in, void *h_out, size_t batch, size_t chunk_frames);
 
-/* The frame-queue form of the same interface: frames arrive OVER TIME (1 .. any number per call, with gaps), results leave in
- * the order the frames went in -- what the RTL core does with its valid strobes (int_fftNk.vhd:23-37), and what SURVEY.md
- * section 8(f) N2 asks for ("frames arriving in chunks, double-buffered").  Unlike intfft_exec_host the overlap of upload,
- * transform and download works ACROSS calls.
+/* The frame-queue form of the same interface: frames arrive OVER TIME (1 .. any number per call, with gaps), results
+ * leave in the order the frames went in -- what the RTL core does with its valid strobes (int_fftNk.vhd:23-37), and
+ * what SURVEY.md section 8(f) N2 asks for ("frames arriving in chunks, double-buffered").  Unlike intfft_exec_host
+ * the overlap of upload, transform and download works ACROSS calls.
  *   intfft_stream_open(plan, slot_frames, n_slots, &s)
- *       A stream object on the plan's device: n_slots (0 = 3; 2 .. 64) slots of slot_frames frames (0 = about 32 MiB), each a
- *       pinned host input buffer, device input / output buffers and a pinned host output buffer owned by the library, three
- *       HIP streams, and a private workspace (intfft_plan_workspace_bytes(plan, slot_frames)).  Transforms run through
- *       intfft_exec_ws: the plan is only read, so ONE plan may feed any number of stream objects at once, also after
- *       intfft_plan_release_scratch.  The plan must outlive the stream object.
+ *       A stream object on the plan's device: n_slots (0 = 3; 2 .. 64) slots of slot_frames frames (0 = about 32
+ *       MiB), each a pinned host input buffer, device input / output buffers and a pinned host output buffer owned by
+ *       the library, three HIP streams, and a private workspace (intfft_plan_workspace_bytes(plan, slot_frames)).
+ *       Transforms run through intfft_exec_ws: the plan is only read, so ONE plan may feed any number of stream
+ *       objects at once, also after intfft_plan_release_scratch.  The plan must outlive the stream object.
  *   intfft_stream_push(s, h_frames, nframes, &accepted)
- *       Copies frames (host pointer, any memory: pageable is fine -- the library's pinned ring is what the DMA engine reads) into
- *       the filling slot; every slot that becomes full is submitted (upload -> transform -> download, each on its own HIP stream,
- *       ordered by events).  NEVER waits for the device: when all slots are in flight or hold results that were not pulled yet
- *       it returns INTFFT_OK with *accepted < nframes (accepted may be NULL).
+ *       Copies frames (host pointer, any memory: pageable is fine -- the library's pinned ring is what the DMA engine
+ *       reads) into the filling slot; every slot that becomes full is submitted (upload -> transform -> download,
+ *       each on its own HIP stream, ordered by events).  NEVER waits for the device: when all slots are in flight or
+ *       hold results that were not pulled yet it returns INTFFT_OK with *accepted < nframes (accepted may be NULL).
  *   intfft_stream_flush(s)
- *       Submits the partly filled slot as a short chunk (a producer that pauses, or the end of the data).  Producer side.
+ *       Submits the partly filled slot as a short chunk (a producer that pauses, or the end of the data).  Producer
+ *       side.
  *   intfft_stream_pull(s, h_out, max_frames, &got, wait)
- *       Copies up to max_frames finished frames, in push order, into h_out.  wait = 0: only what is complete now (got may be 0);
- *       wait = 1: if something was submitted and is not pulled yet, blocks until at least its oldest slot is complete.  Frames
- *       that sit in a slot that was not submitted (not full, not flushed) are not waited for: got = 0.
- *   intfft_stream_pending(s, &not_pulled, &not_submitted)   frames pushed and not pulled yet / frames in the filling slot.
+ *       Copies up to max_frames finished frames, in push order, into h_out.  wait = 0: only what is complete now (got
+ *       may be 0); wait = 1: if something was submitted and is not pulled yet, blocks until at least its oldest slot
+ *       is complete.  Frames that sit in a slot that was not submitted (not full, not flushed) are not waited for:
+ *       got = 0.
+ *   intfft_stream_pending(s, &not_pulled, &not_submitted)
+ *       Frames pushed and not pulled yet / frames in the filling slot.
  *   intfft_stream_close(s)   drains the device work, drops results that were not pulled, frees everything.
- * Threading: ONE producer thread (push, flush) and ONE consumer thread (pull) may work on a stream object concurrently.
- * Errors are sticky: after a failed enqueue every call on the object returns that status (hipError_t > 0 or INTFFT_ERR_* < 0)
- * until close.  This is NOT a CPU execution path either. */
+ * Threading: ONE producer thread (push, flush) and ONE consumer thread (pull) may work on a stream object
+ * concurrently. Errors are sticky: after a failed enqueue every call on the object returns that status (hipError_t >
+ * 0 or INTFFT_ERR_* < 0) until close.  This is NOT a CPU execution path either. */
 typedef struct intfft_stream intfft_stream;
 int intfft_stream_open(intfft_plan *plan, size_t slot_frames, int n_slots, intfft_stream **out);
 int intfft_stream_push(intfft_stream *s, const void *h_frames, size_t nframes, size_t *accepted);
@@ -205,58 +218,64 @@ int intfft_stream_pull(intfft_stream *s, void *h_out, size_t max_frames, size_t 
 int intfft_stream_pending(intfft_stream *s, size_t *frames_not_pulled, size_t *frames_not_submitted);
 int intfft_stream_close(intfft_stream *s);
 
-/* Single-process multi-GPU convenience (frames are independent, so a batch shards
- * across GPUs with no collective in the data path -- the software analogue of instantiating the core once per
- * channel).  plans[0..nplans-1] hold identical intfft_params, one per HIP device; d_in / d_out live on the device
- * of plans[root].  The batch is cut into contiguous shards (remainder to the LAST plans); shard i is copied
- * root -> device i (hipMemcpyPeerAsync over xGMI, peer access enabled where the devices allow it), transformed there,
- * and copied back; the root transforms its own shard in place of the copy.  Blocking.
- * Every peer's shard moves in up to 4 pieces (>= 2 MiB each) so that the copy back of piece k runs beside the copy in of piece k + 1 (xGMI links are
- * full duplex; end to end this path is link-bound) and beside the transform of the root's own shard.
+/* Single-process multi-GPU convenience (frames are independent, so a batch shards across
+ * GPUs with no collective in the data path -- the software analogue of instantiating the core once per channel).
+ * plans[0..nplans-1] hold identical intfft_params, one per HIP device; d_in / d_out live on the device of
+ * plans[root].  The batch is cut into contiguous shards (remainder to the LAST plans); shard i is copied root ->
+ * device i (hipMemcpyPeerAsync over xGMI, peer access enabled where the devices allow it), transformed there, and
+ * copied back; the root transforms its own shard in place of the copy.  Blocking. Every peer's shard moves in up to 4
+ * pieces (>= 2 MiB each) so that the copy back of piece k runs beside the copy in of piece k + 1 (xGMI links are full
+ * duplex; end to end this path is link-bound) and beside the transform of the root's own shard.
  * Synchronisation contract: on entry the call waits for EVERY stream of the root device (hipDeviceSynchronize), so
- * d_in may have been produced on any stream of that device; on return d_out is complete.  On an error every stream the
- * call used is still drained before it returns.
- * Plan state: the per-shard staging buffers and stream live in the plans (grow only, freed by intfft_plan_destroy) and
- * are created on first use -- or up front by intfft_shard_prepare, after which intfft_exec_sharded allocates nothing for
- * batches <= max_batch.  These two calls are the only ones besides intfft_exec_host that modify a plan after create: do
- * not run them concurrently with any other call on the same plans.
- * One-process-per-GPU hosts (torch.distributed / MPI over RCCL) call intfft_exec on their own shard instead
- * (intfftk_amd/sharding.py: grouped ncclSend/ncclRecv scatter and gather). */
+ * d_in may have been produced on any stream of that device; on return d_out is complete.  On an error every stream
+ * the call used is still drained before it returns. Plan state: the per-shard staging buffers and stream live in the
+ * plans (grow only, freed by intfft_plan_destroy) and are created on first use -- or up front by
+ * intfft_shard_prepare, after which intfft_exec_sharded allocates nothing for batches <= max_batch.  These two calls
+ * are the only ones besides intfft_exec_host that modify a plan after create: do not run them concurrently with any
+ * other call on the same plans. One-process-per-GPU hosts (torch.distributed / MPI over RCCL) call intfft_exec on
+ * their own shard instead (intfftk_amd/sharding.py: grouped ncclSend/ncclRecv scatter and gather). */
 int intfft_shard_prepare(intfft_plan *const *plans, int nplans, int root, size_t max_batch);
 int intfft_exec_sharded(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch);
-/* The same call without host synchronisation -- a "streaming block" over several GPUs that can be enqueued behind other work: everything is ordered
- * behind what `hip_stream` (a stream of plans[root]'s device, NULL = its default stream) holds at the time of the call (d_in must be complete in
- * THAT stream's order -- no hipDeviceSynchronize here), and when the call returns `hip_stream` has been made to wait for every copy and transform
- * of the call, so work enqueued on it afterwards sees d_out complete.  Back-to-back calls on the same plans are ordered among themselves (each plan's
- * streams first wait for the previous call's completion event).  Staging that has to grow is (re)allocated inside the call, which synchronises the
- * device: call intfft_shard_prepare first.  Same state and threading rules as intfft_exec_sharded. */
-int intfft_exec_sharded_async(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch, void *hip_stream);
+/* The same call without host synchronisation -- a "streaming block" over several GPUs that can be enqueued behind
+ * other work: everything is ordered behind what `hip_stream` (a stream of plans[root]'s device, NULL = its default
+ * stream) holds at the time of the call (d_in must be complete in THAT stream's order -- no hipDeviceSynchronize
+ * here), and when the call returns `hip_stream` has been made to wait for every copy and transform of the call, so
+ * work enqueued on it afterwards sees d_out complete.  Back-to-back calls on the same plans are ordered among
+ * themselves (each plan's streams first wait for the previous call's completion event).  Staging that has to grow is
+ * (re)allocated inside the call, which synchronises the device: call intfft_shard_prepare first.  Same state and
+ * threading rules as intfft_exec_sharded. */
+int intfft_exec_sharded_async(intfft_plan *const *plans, int nplans, int root, const void *d_in, void *d_out, size_t batch,
+                              void *hip_stream);
 /* How intfft_exec_sharded moves the shards between the root and the other devices ("grouped
  * ncclSend / ncclRecv root <-> peers so that all links of the root are driven concurrently"):
  *   INTFFT_TRANSPORT_PEER  hipMemcpyPeerAsync per shard on the shard's stream (the default)
- *   INTFFT_TRANSPORT_RCCL  EXPERIMENTAL -- no run on two or more devices has been recorded for it yet (every box this library was
- *                          measured on had ONE GPU: with one rank the groups are empty, so only dlopen, ncclCommInitAll and the empty-group
- *                          path are proven; tests/test_gpu_cabi.py compares it with the peer transport whenever >= 2 devices are visible).
- *                          RCCL over xGMI: per piece of the shards ONE ncclGroupStart .. ncclGroupEnd holding the ncclSend (root) / ncclRecv
- *                          (peer) pairs of the scatter of piece t AND the reverse pairs of the gather of piece t - 1, so that every link of
- *                          the root runs in both directions at once.  librccl.so is loaded with dlopen on the first request (no link-time dependency); the
- *                          communicators (ncclCommInitAll over the plans' devices, rank i = plans[i]) belong to the plan set and are
- *                          released by intfft_plan_destroy of plans[0].  Needs every plan on its own device.
- * Returns INTFFT_OK; INTFFT_ERR_TRANSPORT when RCCL cannot be loaded or the communicators cannot be created (two plans on one
- * device, no librccl.so): the plan set then stays on peer copies, so a caller may simply try RCCL first.  The two transports give the
- * same bytes.  A set is identified by the call that created it: plans whose communicators come from different calls (or whose owner,
- * plans[0] of that call, was destroyed or re-assigned since) fall back to peer copies rather than touching a stale communicator.  Like intfft_shard_prepare this call modifies the plans: not concurrently with any other call on them. */
+ *   INTFFT_TRANSPORT_RCCL  EXPERIMENTAL -- no run on two or more devices has been recorded for it yet (every box this
+ *                          library was measured on had ONE GPU: with one rank the groups are empty, so only dlopen,
+ *                          ncclCommInitAll and the empty-group path are proven; tests/test_gpu_cabi.py compares it
+ *                          with the peer transport whenever >= 2 devices are visible). RCCL over xGMI: per piece of
+ *                          the shards ONE ncclGroupStart .. ncclGroupEnd holding the ncclSend (root) / ncclRecv
+ *                          (peer) pairs of the scatter of piece t AND the reverse pairs of the gather of piece t - 1,
+ *                          so that every link of the root runs in both directions at once.  librccl.so is loaded with
+ *                          dlopen on the first request (no link-time dependency); the communicators (ncclCommInitAll
+ *                          over the plans' devices, rank i = plans[i]) belong to the plan set and are released by
+ *                          intfft_plan_destroy of plans[0].  Needs every plan on its own device.
+ * Returns INTFFT_OK; INTFFT_ERR_TRANSPORT when RCCL cannot be loaded or the communicators cannot be created (two
+ * plans on one device, no librccl.so): the plan set then stays on peer copies, so a caller may simply try RCCL first.
+ * The two transports give the same bytes.  A set is identified by the call that created it: plans whose communicators
+ * come from different calls (or whose owner, plans[0] of that call, was destroyed or re-assigned since) fall back to
+ * peer copies rather than touching a stale communicator.  Like intfft_shard_prepare this call modifies the plans: not
+ * concurrently with any other call on them. */
 #define INTFFT_TRANSPORT_PEER 0
 #define INTFFT_TRANSPORT_RCCL 1
 int intfft_shard_set_transport(intfft_plan *const *plans, int nplans, int root, int transport);
 
-/* Standalone re-orderer: the stream buffers of src/vhdl/buffers/ as an operator of their own (no plan, no arithmetic).
- * d_out[f][m_out] = d_in[f][m_in] for every frame f, where m_in (memory index in `from_order`) and m_out (memory index
- * in `to_order`) denote the same logical index -- e.g. int_bitrev_order.vhd:61-189 = BITREV_LANES -> NATURAL,
- * inbuf_half_path.vhd:23-28 = NATURAL -> HALVES, outbuf_half_path.vhd:160-172 = BITREV -> BITREV_LANES, and
- * NATURAL -> BITREV = the bitrevorder() of math/fn_radix2.m:188.  Samples are (re, im) pairs of `container_bytes`
- * (2 / 4 / 8) each; frames are [batch][2^log2n].  Not in place (overlapping buffers -> INTFFT_ERR_INVALID).
- * Asynchronous on `hip_stream` of device `hip_device`. */
+/* Standalone re-orderer: the stream buffers of src/vhdl/buffers/ as an operator of their own (no plan, no
+ * arithmetic). d_out[f][m_out] = d_in[f][m_in] for every frame f, where m_in (memory index in `from_order`) and m_out
+ * (memory index in `to_order`) denote the same logical index -- e.g. int_bitrev_order.vhd:61-189 = BITREV_LANES ->
+ * NATURAL, inbuf_half_path.vhd:23-28 = NATURAL -> HALVES, outbuf_half_path.vhd:160-172 = BITREV -> BITREV_LANES, and
+ * NATURAL -> BITREV = the bitrevorder() of math/fn_radix2.m:188.  Samples are (re, im) pairs of `container_bytes` (2
+ * / 4 / 8) each; frames are [batch][2^log2n].  Not in place (overlapping buffers -> INTFFT_ERR_INVALID). Asynchronous
+ * on `hip_stream` of device `hip_device`. */
 int intfft_reorder(int log2n, int container_bytes, int from_order, int to_order, const void *d_in, void *d_out,
                    size_t batch, int hip_device, void *hip_stream);
 
@@ -265,16 +284,21 @@ int intfft_reorder(int log2n, int container_bytes, int from_order, int to_order,
  * h_out may be NULL to query *count. */
 int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *count);
 
-/* Environment: NONE in normal use.  The library has DIAGNOSTIC switches (A/B parity of kernel families in the tests, tuning
- * experiments; none changes results) that are read ONLY when the master switch INTFFT_DIAG=1 is set -- without it every INTFFT_*
- * variable is ignored, so a stray variable in a production environment cannot change which kernels a plan uses:
- *   INTFFT_GENERIC_ONLY, INTFFT_NO_FAST1024U, INTFFT_NO_FASTW32, INTFFT_NO_BIG20, INTFFT_NO_BIG2P, INTFFT_NO_BIG2X, INTFFT_NO_FAST16K, INTFFT_TWO_STREAMS, INTFFT_NO_WIDE16,
- *   INTFFT_NO_WIDELONG, INTFFT_NO_WIDELONG_R32, INTFFT_NO_BIGWLONG (the three-launch plans of N = 2^17 .. 2^20 outside 16-bit scaled data: back to the generic passes),
- *   INTFFT_NO_FASTW64, INTFFT_NO_PAIR_COMPOSITE, INTFFT_NO_NARROW_PASS, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_ROWS2K, INTFFT_2D_NO_PACKED_TW,
- *   INTFFT_2D_CHUNK_FRAMES (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed
- *   kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS, INTFFT_PASS_TARGET,
- *   INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL, INTFFT_2XA_HALF19, INTFFT_2XA_FULL20, INTFFT_SHARD_PIECES (launch geometry / scratch / generic-kernel / shard-pipeline knobs),
- *   INTFFT_VERBOSE (the failing RCCL call and its ncclResult_t on stderr).  README.md describes each. */
+/* Environment: NONE in normal use.  The library has DIAGNOSTIC switches (A/B parity of kernel families in the tests,
+ * tuning experiments; none changes results) that are read ONLY when the master switch INTFFT_DIAG=1 is set -- without
+ * it every INTFFT_* variable is ignored, so a stray variable in a production environment cannot change which kernels
+ * a plan uses:
+ *   INTFFT_GENERIC_ONLY, INTFFT_NO_FAST1024U, INTFFT_NO_FASTW32, INTFFT_NO_BIG20, INTFFT_NO_BIG2P, INTFFT_NO_BIG2X,
+ *   INTFFT_NO_FAST16K, INTFFT_TWO_STREAMS, INTFFT_NO_WIDE16, INTFFT_NO_WIDELONG, INTFFT_NO_WIDELONG_R32,
+ *   INTFFT_NO_BIGWLONG (the three-launch plans of N = 2^17 .. 2^20 outside 16-bit scaled data: back to the generic
+ *   passes), INTFFT_NO_FASTW64, INTFFT_NO_PAIR_COMPOSITE, INTFFT_NO_LANES_COMPOSITE, INTFFT_NO_ROTATE1,
+ *   INTFFT_NO_NARROW_PASS, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC,
+ *   INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_ROWS2K, INTFFT_2D_NO_PACKED_TW, INTFFT_2D_CHUNK_FRAMES
+ *   (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed kernels),
+ *   INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS,
+ *   INTFFT_PASS_TARGET, INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL, INTFFT_2XA_HALF19, INTFFT_2XA_FULL20,
+ *   INTFFT_SHARD_PIECES (launch geometry / scratch / generic-kernel / shard-pipeline knobs), INTFFT_VERBOSE (the
+ *   failing RCCL call and its ncclResult_t on stderr).  README.md describes each. */
 const char *intfft_strerror(int status);
 const char *intfft_version(void);
 
