@@ -339,7 +339,12 @@ __device__ __forceinline__ bool frame_within_T_after_phase1(const u32 (&v)[16])
 
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
 template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
-__global__ __launch_bounds__(256) void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
+#ifdef INTFFT_WPE_F /* A/B: tools/build_variant.sh fwpe5 intfft_fast1024.hip -DINTFFT_WPE_F=5 */
+#define INTFFT_WPE_F_ATTR __attribute__((amdgpu_waves_per_eu(INTFFT_WPE_F)))
+#else
+#define INTFFT_WPE_F_ATTR
+#endif
+__global__ __launch_bounds__(256) INTFFT_WPE_F_ATTR void k_fft1024_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const Fast1024Consts c, size_t nframes_user, const Slice sl,
                                                      int io_flags)
 {

@@ -34,7 +34,12 @@ enum { X_INV = 1, X_PAIR = 2 };
 // short-frame store (dwordx4 loads + two lane swaps, LC lane bits per lane_bit<L>()).
 // ROUND: RNDMODE = 1 (rhu2 sums on full-width values, exact extraction, no pre-shifted outputs)
 template <int L, int MODE, bool FAST_OK, int ROUND = 0>
-__global__ __launch_bounds__(256) void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
+#ifdef INTFFT_WPE_X /* A/B: tools/build_variant.sh wpe5 intfft_fast1024x.hip -DINTFFT_WPE_X=5 */
+#define INTFFT_WPE_X_ATTR __attribute__((amdgpu_waves_per_eu(INTFFT_WPE_X)))
+#else
+#define INTFFT_WPE_X_ATTR
+#endif
+__global__ __launch_bounds__(256) INTFFT_WPE_X_ATTR void k_fft1024x_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                       const RoundCConsts c, size_t nframes_user, const Slice sl,
                                                       int in_bitrev, int out_halves)
 {

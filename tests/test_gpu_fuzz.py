@@ -1,6 +1,6 @@
 """A bounded, seeded parity fuzz inside the driver-run GPU suite (the open-ended soaks are tools/fuzz_soak.py / tools/fuzz_wide.py).
 
-~400 random elaboratable configurations -- NFFT 3 .. 20 weighted to short frames, DATA_WIDTH 4 .. 64, TWDL_WIDTH 8 .. 26, the three
+~1200 random elaboratable configurations -- NFFT 3 .. 20 weighted to short frames, DATA_WIDTH 4 .. 64, TWDL_WIDTH 8 .. 26, the three
 modes, the three directions, both XSERIES, every I/O order pair, ragged batches, now and then the 2-D scheme with a random split --
 whatever kernel the planner picks must equal the C oracle bit for bit ("three modes side by side ... batch index
 independence"); results beyond 64 bits (16-byte containers) are checked against the Python twin on short frames.  The generator is a
@@ -19,7 +19,7 @@ NP = {2: np.int16, 4: np.int32, 8: np.int64}
 ORDERS = ["NATURAL", "BITREV", "HALVES", "BITREV_LANES"]
 # weighted to short frames: the long ones cost the oracle seconds, and tests/test_gpu_parity.py walks every length on fixed cases
 LOG2N = [3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 16, 16, 17, 18, 19, 20]
-CHUNKS = 8
+CHUNKS = 24  # 1200 configurations (round 6; 8 chunks up to round 5): ~30 s on the GPU box
 PER_CHUNK = 50
 
 
