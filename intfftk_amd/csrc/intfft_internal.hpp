@@ -303,6 +303,8 @@ hipError_t launch_bitperm(int L, int container_bytes, const int *in_of_out, cons
 hipError_t launch_bitperm_tw(int L, int container_bytes, const int *in_of_out, int l2, int mw, int sh_a, int sh_b, int narrow, int twd,
                              int conj, const void *d_in, void *d_out, size_t batch, hipStream_t stream);
 int order_mem_bit(int order, int L, int j); // memory-index bit that carries logical-index bit j in an INTFFT_ORDER_* layout
+// USE_FLY = 0: n scalars wrapped to dw bits (sign- or zero-extended) from in_cb- to out_cb-byte containers (intfft_reorder.hip)
+hipError_t launch_convert(int in_cb, int out_cb, int dw, int zext, const void *in, void *out, size_t n, hipStream_t stream);
 // 2-D scheme (intfft_generic.hip): in place V <- cmult(V, W_N^(k1 * n2)) on the [k1][n2] layout (conj: the inverse's swapped feed)
 hipError_t launch_twmul(void *data, int container_bytes, int L, int l2, int mw, int sh_a, int sh_b, int narrow, int conj,
                         int twd, size_t nframes, hipStream_t stream);

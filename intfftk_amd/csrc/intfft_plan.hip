@@ -168,7 +168,9 @@ struct intfft_plan {
     intfft_plan *pair_f = nullptr, *pair_i = nullptr;
     void *pair_buf = nullptr;
     size_t pair_frames = 0;
-    int lanes_mode = 0;             // BITREV_LANES composite: 1 = pair_f (BITREV out) -> pair_buf -> bit permutation, 2 = bit permutation -> pair_buf -> pair_f (BITREV in)
+    int lanes_mode = 0;             // BITREV_LANES composite: 1 = pair_f (BITREV out) -> pair_buf -> bit permutation, 2 = bit permutation -> pair_buf -> pair_f (BITREV in);
+                                    // 3 = USE_FLY = 0: width conversion (-> pair_buf -> bit permutation bypass_perm unless it is the identity), no sub-plan
+    int bypass_perm[24] = {0};      // lanes_mode 3: m_in bit bypass_perm[b] = m_out bit b
     bool fastw64 = false;  // N = 64 .. 1024 forward / inverse, results of 33 .. 64 bits: the 64-bit wave kernel (intfft_fastw64.hip)
     StageDesc st64[12] = {};
     bool fastw64b = false; // N = 2048 / 4096 forward / inverse, results of 33 .. 64 bits beyond k_fft4096_w32's 64-bit last round
@@ -798,6 +800,37 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
         intfft_plan_destroy(pl);
         return rc;
     }
+    // USE_FLY = 0 (the bypass mux of int_fftNk.vhd:260-277, int_ifftNk.vhd:259-276): the butterflies are out of the path and only the
+    // commutators move data.  In place terms nothing moves at all: position p of the core holds input index p and is read out as output index
+    // bitrev(p), so ONE core is the bit reversal of the logical index (a pair: the identity), applied to the input wrapped to DATA_WIDTH bits in
+    // the output container (k_convert), and a plan is that conversion followed by one bit permutation of the memory index -- none at all for the
+    // cores' own beat orders (NATURAL / HALVES in -> BITREV out and the inverse's mirror move no data).  Results within 64 bits.
+    if (!l1 && p->use_fly == 0 && pl->out_cb <= 8 && !diag_env("INTFFT_GENERIC_ONLY") && !diag_env("INTFFT_NO_BYPASS_COPY")) {
+        bool ident = true;
+        for (int j = 0; j < pl->L; ++j) { // output logical bit j = input logical bit L-1-j (single core) / j (pair)
+            const int jin = p->direction == INTFFT_PAIR ? j : pl->L - 1 - j;
+            pl->bypass_perm[order_mem_bit(p->out_order, pl->L, j)] = order_mem_bit(p->in_order, pl->L, jin);
+        }
+        for (int b = 0; b < pl->L; ++b) ident = ident && pl->bypass_perm[b] == b;
+        if (!ident) {
+            const size_t frame_bytes = ((size_t)2 << pl->L) * (size_t)pl->out_cb;
+            size_t mb = 256;
+            if (const char *e = diag_env("INTFFT_SCRATCH_MB")) mb = atoi(e) > 0 ? (size_t)atoi(e) : mb;
+            pl->pair_frames = std::max<size_t>(1, (mb << 20) / frame_bytes);
+            if (hipMalloc(&pl->pair_buf, pl->pair_frames * frame_bytes) != hipSuccess) {
+                intfft_plan_destroy(pl);
+                return INTFFT_ERR_ALLOC;
+            }
+            pl->scratch_frame_bytes = frame_bytes;
+            pl->scratch_bytes = pl->pair_frames * frame_bytes;
+        }
+        (void)hipFree(pl->d_tw);
+        pl->d_tw = nullptr;
+        pl->lanes_mode = 3;
+        std::snprintf(pl->kernel_name, sizeof(pl->kernel_name), ident ? "bypass[k_convert]" : "bypass[k_convert|k_reorder]");
+        *out = pl;
+        return INTFFT_OK;
+    }
     // BITREV_LANES (the serial stream of outbuf_half_path.vhd:160-172 / int_bitrev_order.vhd:82-104) at one end of a plan whose BITREV twin
     // has dedicated kernels: that twin + one bit permutation (BITREV <-> BITREV_LANES is a rotation of the memory index by one bit) through a
     // chunked middle buffer.  The packed 16-bit kernels of N = 128 .. 1024 carry the order as a store / load map of their own and never come here.
@@ -1380,6 +1413,14 @@ int intfft_plan_get_info(const intfft_plan *plan, intfft_plan_info *info)
     info->in_container = plan->in_cb;
     info->out_container = plan->out_cb;
     const bool fast = plan->fast1024 || plan->fast4096 || plan->fast16k || plan->fast1024x || plan->fast1024u || plan->fast1024ux || plan->fastw32 || plan->fast4096w || plan->w32inv || plan->fastsmall || plan->fastw64 || plan->fastw64b;
+    if (plan->lanes_mode == 3) {
+        info->n_passes = plan->pair_buf || plan->pair_frames ? 2 : 1;
+        info->compute_word = plan->out_cb;
+        info->fast_path = 1;
+        info->scratch_bytes = plan->owns_scratch ? plan->scratch_bytes : 0;
+        std::snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", plan->kernel_name);
+        return INTFFT_OK;
+    }
     if (plan->lanes_mode) {
         intfft_plan_info sf;
         if (intfft_plan_get_info(plan->pair_f, &sf) != INTFFT_OK) return INTFFT_ERR_INVALID;
@@ -1470,6 +1511,7 @@ static size_t ws_need(const intfft_plan *pl, size_t batch)
         }
         return (size_t)pl->n2d_bufs * ws_align(bf * ((size_t)2 << pl->L) * (size_t)pl->out_cb) + sub;
     }
+    if (pl->lanes_mode == 3) return pl->pair_frames ? ws_align(std::min(pl->pair_frames, batch) * pl->scratch_frame_bytes) : 0;
     if (pl->lanes_mode) {
         const size_t pf = std::min(pl->pair_frames, batch);
         return ws_align(pf * pl->scratch_frame_bytes) + ws_need(pl->pair_f, pf);
@@ -1738,6 +1780,23 @@ int intfft_plan_release_scratch(intfft_plan *plan)
 static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t batch, hipStream_t stream, char *ws)
 {
     if (plan->is2d) return exec_2d(plan, d_in, d_out, batch, stream, ws);
+    if (plan->lanes_mode == 3) { // USE_FLY = 0: wrap to DATA_WIDTH in the output container, then in_order -> out_order
+        const int L = plan->L, zext = plan->p.format ? 1 : 0;
+        const size_t in_frame = ((size_t)2 << L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << L) * (size_t)plan->out_cb;
+        if (!plan->pair_frames)
+            return (int)launch_convert(plan->in_cb, plan->out_cb, plan->p.data_width, zext, d_in, d_out, batch * ((size_t)2 << L), stream);
+        const size_t pf = ws ? std::min(plan->pair_frames, batch) : plan->pair_frames;
+        void *const mid = ws ? ws : plan->pair_buf;
+        const int *const perm = plan->bypass_perm;
+        for (size_t f = 0; f < batch; f += pf) {
+            const size_t nf = std::min(pf, batch - f);
+            int rc = (int)launch_convert(plan->in_cb, plan->out_cb, plan->p.data_width, zext, static_cast<const char *>(d_in) + f * in_frame, mid,
+                                         nf * ((size_t)2 << L), stream);
+            if (rc == INTFFT_OK) rc = (int)launch_bitperm(L, plan->out_cb, perm, mid, static_cast<char *>(d_out) + f * out_frame, nf, stream);
+            if (rc != INTFFT_OK) return rc;
+        }
+        return INTFFT_OK;
+    }
     if (plan->lanes_mode) { // BITREV_LANES composite: the BITREV twin and one bit permutation through the middle buffer, chunk by chunk
         const int L = plan->L;
         const size_t in_frame = ((size_t)2 << L) * (size_t)plan->in_cb, out_frame = ((size_t)2 << L) * (size_t)plan->out_cb;

@@ -374,6 +374,58 @@ template <typename E> static hipError_t launch_rotate1(bool split, int L, const 
 }
 } // namespace intfft
 
+namespace intfft {
+// USE_FLY = 0 (the bypass mux of int_fftNk.vhd:260-277): no butterfly touches the data; what remains of the arithmetic is the width handling
+// of the first stage -- the input wrapped to DATA_WIDTH bits (sign-extended; zero-extended when FORMAT = 1 widens the word, as the RTL's
+// bypass does) in the output container.  (The data movement of the commutators is a bit permutation: intfft_plan.hip, lanes_mode 3.)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void k_convert(const TI *__restrict__ in, TO *__restrict__ out, size_t n, int dw, int zext)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const int sh = 64 - dw;
+    auto cv = [&](TI x) -> TO {
+        const long long v = (long long)x;
+        return zext ? (TO)(long long)(((unsigned long long)v << sh) >> sh) : (TO)((v << sh) >> sh);
+    };
+    if (i + 4 <= n) {
+        struct alignas(4 * sizeof(TI)) QI { TI v[4]; };
+        struct alignas(4 * sizeof(TO)) QO { TO v[4]; };
+        const QI x = *reinterpret_cast<const QI *>(in + i);
+        QO y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y.v[k] = cv(x.v[k]);
+        *reinterpret_cast<QO *>(out + i) = y;
+    } else {
+        for (size_t k = i; k < n; ++k) out[k] = cv(in[k]);
+    }
+}
+template <typename TI, typename TO> static hipError_t launch_convert_t(const void *in, void *out, size_t n, int dw, int zext, hipStream_t stream)
+{
+    const size_t per = (size_t)1 << 30; // scalars per launch (a multiple of 4 x 256)
+    for (size_t o = 0; o < n; o += per) {
+        const size_t m = std::min(per, n - o);
+        hipLaunchKernelGGL((k_convert<TI, TO>), dim3((unsigned)((m + 1023) / 1024)), dim3(256), 0, stream, static_cast<const TI *>(in) + o,
+                           static_cast<TO *>(out) + o, m, dw, zext);
+    }
+    return hipGetLastError();
+}
+// n scalars (2 per complex sample) of in_cb-byte containers -> out_cb-byte containers (2 / 4 / 8, out_cb >= in_cb)
+hipError_t launch_convert(int in_cb, int out_cb, int dw, int zext, const void *in, void *out, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    switch (in_cb * 16 + out_cb) {
+    case 2 * 16 + 2: return launch_convert_t<short, short>(in, out, n, dw, zext, stream);
+    case 2 * 16 + 4: return launch_convert_t<short, int>(in, out, n, dw, zext, stream);
+    case 2 * 16 + 8: return launch_convert_t<short, long long>(in, out, n, dw, zext, stream);
+    case 4 * 16 + 4: return launch_convert_t<int, int>(in, out, n, dw, zext, stream);
+    case 4 * 16 + 8: return launch_convert_t<int, long long>(in, out, n, dw, zext, stream);
+    case 8 * 16 + 8: return launch_convert_t<long long, long long>(in, out, n, dw, zext, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+} // namespace intfft
+
 hipError_t intfft::launch_bitperm(int L, int container_bytes, const int *in_of_out, const void *d_in, void *d_out, size_t batch,
                                   hipStream_t stream)
 {

@@ -31,6 +31,7 @@ CONFIGS = {
 
 
 ORDERS = {"C2native": ("HALVES", "BITREV")}
+USE_FLY = {}  # spec -> 0 for the bypass mux (10th field of an ad-hoc spec)
 NFFT1 = {}  # spec -> log2 N1 of a 2-D scheme plan (spec "L:DW:TW:FMT:RND:DIR:L1")
 CONFIGS["C2native"] = (10, 16, 16, 0, 0, "FWD", 65536, 15, 8)
 
@@ -41,7 +42,8 @@ def run(name, steps=None, check_frames=8):
     n = 1 << log2n
     in_o, out_o = ORDERS.get(name, ("NATURAL", "NATURAL"))
     l1 = NFFT1.get(name, 0)
-    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o, NFFT1=l1)
+    uf = USE_FLY.get(name, 1)
+    core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW", direction, in_o, out_o, uf, NFFT1=l1)
     g = torch.Generator(device="cuda")
     g.manual_seed(0xC0FFEE00 + log2n)
     x = torch.randint(-(1 << (bits - 1)), 1 << (bits - 1), (batch, n, 2), device="cuda", dtype=core.in_dtype, generator=g)
@@ -61,7 +63,7 @@ def run(name, steps=None, check_frames=8):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    p = C.make_params(log2n, dw, tw, fmt, rnd, True)
+    p = C.make_params(log2n, dw, tw, fmt, rnd, True, uf)
     om = {"NATURAL": C.NATURAL, "BITREV": C.BITREV, "HALVES": C.HALVES, "BITREV_LANES": C.BITREV_LANES}
     dd = {"FWD": C.FWD, "INV": C.INV, "PAIR": C.PAIR}[direction]
     if core.out_container == 16:  # results beyond 64 bits: the Python twin, small lengths only (tests/test_gpu_wide128.py)
@@ -103,6 +105,8 @@ def adhoc(spec):
         NFFT1[spec] = int(f[6])
     if len(f) > 8:
         ORDERS[spec] = (f[7], f[8])
+    if len(f) > 9:
+        USE_FLY[spec] = int(f[9])
     in_cb = 2 if dw <= 16 else 4 if dw <= 32 else 8
     ob = dw + (fmt * log2n) * (2 if direction == "PAIR" else 1)
     out_cb = 2 if ob <= 16 else 4 if ob <= 32 else 8 if ob <= 64 else 16
