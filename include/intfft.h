@@ -291,14 +291,14 @@ int intfft_twiddles(const intfft_plan *plan, int stage, int32_t *h_out, size_t *
  *   INTFFT_GENERIC_ONLY, INTFFT_NO_FAST1024U, INTFFT_NO_FASTW32, INTFFT_NO_BIG20, INTFFT_NO_BIG2P, INTFFT_NO_BIG2X,
  *   INTFFT_NO_FAST16K, INTFFT_TWO_STREAMS, INTFFT_NO_WIDE16, INTFFT_NO_WIDELONG, INTFFT_NO_WIDELONG_R32,
  *   INTFFT_NO_BIGWLONG (the three-launch plans of N = 2^17 .. 2^20 outside 16-bit scaled data: back to the generic
- *   passes), INTFFT_NO_FASTW64, INTFFT_NO_PAIR_COMPOSITE, INTFFT_NO_LANES_COMPOSITE, INTFFT_NO_ROTATE1,
- *   INTFFT_NO_NARROW_PASS, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16, INTFFT_2D_GENERIC,
- *   INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_ROWS2K, INTFFT_2D_NO_PACKED_TW, INTFFT_2D_CHUNK_FRAMES
- *   (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside the packed kernels),
- *   INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2, INTFFT_PASS_THREADS,
- *   INTFFT_PASS_TARGET, INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL, INTFFT_2XA_HALF19, INTFFT_2XA_FULL20,
- *   INTFFT_SHARD_PIECES (launch geometry / scratch / generic-kernel / shard-pipeline knobs), INTFFT_VERBOSE (the
- *   failing RCCL call and its ncclResult_t on stderr).  README.md describes each. */
+ *   passes), INTFFT_NO_FASTW64, INTFFT_NO_PAIR_COMPOSITE, INTFFT_NO_LANES_COMPOSITE, INTFFT_NO_BYPASS_COPY,
+ *   INTFFT_NO_ROTATE1, INTFFT_NO_NARROW_PASS, INTFFT_NO_TWOPASS, INTFFT_NO_PACKED_ROUND, INTFFT_NO_NARROW16,
+ *   INTFFT_2D_GENERIC, INTFFT_2D_NO_FUSE, INTFFT_2D_NO_FUSED_CORES, INTFFT_2D_NO_ROWS2K, INTFFT_2D_NO_PACKED_TW,
+ *   INTFFT_2D_CHUNK_FRAMES (which kernels a plan may use), INTFFT_FAST_EXTRACT, INTFFT_FAST_PIPE (code paths inside
+ *   the packed kernels), INTFFT_BLOCKS_PER_CU, INTFFT_SCRATCH_MB, INTFFT_ONE_STREAM, INTFFT_TILE_LOG2,
+ *   INTFFT_PASS_THREADS, INTFFT_PASS_TARGET, INTFFT_NO_MIXED_WORDS, INTFFT_NO_NARROW_MUL, INTFFT_2XA_HALF19,
+ *   INTFFT_2XA_FULL20, INTFFT_SHARD_PIECES (launch geometry / scratch / generic-kernel / shard-pipeline knobs),
+ *   INTFFT_VERBOSE (the failing RCCL call and its ncclResult_t on stderr).  README.md describes each. */
 const char *intfft_strerror(int status);
 const char *intfft_version(void);
 
