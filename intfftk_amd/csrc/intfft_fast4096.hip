@@ -142,8 +142,10 @@ template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_re
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
 template <int L, int MODE, bool FAST_OK, bool OB = false, int ROUND = 0>
 __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
-                                                     const RoundCConsts c, size_t nframes_user, const Slice sl, int halves)
+                                                     const RoundCConsts c, size_t nframes_user, const Slice sl, int io_flags)
 {
+    const int halves = io_flags & 1;             // HALVES beats on the time side
+    const bool lanes = OB && (io_flags & 2);     // BITREV_LANES instead of BITREV on the frequency side (round 6; wave-uniform)
     static_assert(!OB || MODE == MODE_FWD || MODE == MODE_INV, "native orders: forward or inverse core alone");
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
     static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
@@ -227,7 +229,16 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v4u x = {0u, 0u, 0u, 0u};
-                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) x = INTFFT_LD(s4 + 64 * q);
+                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) {
+                    if (lanes) { // core position n sits at memory index (n & 1) * N/2 + (n >> 1): two 8-byte pieces, one per half of the frame
+                        typedef u32 v2u __attribute__((ext_vector_type(2)));
+                        const int n0 = 4 * (ob_unit + 64 * q), nl = n0 & ((1 << L) - 1);
+                        const u32 *const d = src + (n0 - nl) + (nl >> 1);
+                        const v2u ev = INTFFT_LD(reinterpret_cast<const v2u *>(d)), od = INTFFT_LD(reinterpret_cast<const v2u *>(d + (1 << (L - 1))));
+                        x = v4u{ev.x, od.x, ev.y, od.y};
+                    } else
+                        x = INTFFT_LD(s4 + 64 * q);
+                }
                 v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
             }
         } else if (MODE == MODE_INV) { // LC: v[r] = X[brev_L(n)] of the thread's frame (one test around the 16 loads:
@@ -328,8 +339,17 @@ __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, co
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
             {                                                                                           \
                 const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};                     \
-                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user)        \
-                    __builtin_nontemporal_store(x, d4 + 64 * q);                                        \
+                if (!partial || f * FP + (size_t)((4 * (ob_unit + 64 * q)) >> L) < nframes_user) {      \
+                    if (lanes) { /* BITREV_LANES: even / odd core positions to the two halves of the frame */ \
+                        typedef u32 v2u __attribute__((ext_vector_type(2)));                            \
+                        const int n0 = 4 * (ob_unit + 64 * q), nl = n0 & ((1 << L) - 1);                \
+                        u32 *const dl = dst + (n0 - nl) + (nl >> 1);                                    \
+                        const v2u ev = {x.x, x.z}, od = {x.y, x.w};                                     \
+                        __builtin_nontemporal_store(ev, reinterpret_cast<v2u *>(dl));                   \
+                        __builtin_nontemporal_store(od, reinterpret_cast<v2u *>(dl + (1 << (L - 1))));  \
+                    } else                                                                              \
+                        __builtin_nontemporal_store(x, d4 + 64 * q);                                    \
+                }                                                                                       \
             }                                                                                           \
         } else if (MODE == MODE_FWD) {                                                                  \
             if (lc_ok) {                                                                                \
@@ -380,8 +400,8 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
     if (!((log2n == 12 || log2n == 11) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 && use_fly == 1))
         return false;
     if (rndmode && diag_env("INTFFT_NO_PACKED_ROUND")) return false; // ROUNDING: all three directions, the cores' native orders too
-    if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1); // + HALVES in, BITREV out
-    if (direction == 1) return (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2); // + BITREV in, HALVES out
+    if (direction == 0) return (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1 || out_order == 3); // + HALVES in, BITREV / BITREV_LANES out
+    if (direction == 1) return (in_order == 0 || in_order == 1 || in_order == 3) && (out_order == 0 || out_order == 2); // + BITREV / BITREV_LANES in, HALVES out
     return in_order == 0 && out_order == 0;
 }
 
@@ -470,6 +490,7 @@ hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int
                            size_t nframes, hipStream_t stream, int round, int data_width)
 {
     if (nframes == 0) return hipSuccess;
+    if (lc_bitrev == 2) halves |= 2; // BITREV_LANES: the OB instantiations with the serial-stream load / store map (io_flags bit 1)
     RoundCConsts c;
     for (int k = 0; k < 8; ++k) {
         const int2 w = h_tw[7 + k];

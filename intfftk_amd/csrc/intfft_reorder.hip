@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void k_convert(const TI *__restrict__ in, TO *
     const int sh = 64 - dw;
     auto cv = [&](TI x) -> TO {
         const long long v = (long long)x;
-        return zext ? (TO)(long long)(((unsigned long long)v << sh) >> sh) : (TO)((v << sh) >> sh);
+        const unsigned long long u = (unsigned long long)v << sh; // the low dw bits at the top of the word
+        return zext ? (TO)(long long)(u >> sh) : (TO)((long long)u >> sh);
     };
     if (i + 4 <= n) {
         struct alignas(4 * sizeof(TI)) QI { TI v[4]; };

@@ -1,8 +1,8 @@
 """BITREV_LANES -- the serial stream between outbuf_half_path and int_bitrev_order
 (src/vhdl/buffers/outbuf_half_path.vhd:160-172, int_bitrev_order.vhd:82-104) -- off the generic kernels (round 6):
 
-* the packed 16-bit wave kernels of N = 128 .. 1024 carry it as a store map (forward: `k_fft1024_i16`) / load map (inverse:
-  `k_fft1024x_i16`) of their BITREV instantiations: one launch;
+* the packed 16-bit kernels of N = 128 .. 4096 carry it as a store map (forward: `k_fft1024_i16`, `k_fft4096_i16`) / load map
+  (inverse: `k_fft1024x_i16`, `k_fft4096_i16`) of their BITREV instantiations: one launch;
 * every other plan whose BITREV twin has dedicated kernels runs that twin and one bit permutation (`lanes[...]`): the order
   is a rotation of the BITREV memory index by one bit.
 
@@ -24,7 +24,15 @@ def frames(n, dw, batch, seed):
     return x
 
 
-@pytest.mark.parametrize("log2n", [7, 8, 9, 10])
+def fwd_kernel(log2n):
+    return "k_fft1024_i16" if log2n <= 10 else "k_fft4096_i16"
+
+
+def inv_kernel(log2n):
+    return "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16"
+
+
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("rnd", [0, 1])
 @pytest.mark.parametrize("in_order", ["NATURAL", "HALVES"])
 def test_packed_forward_lanes_store_map(log2n, rnd, in_order):
@@ -32,14 +40,14 @@ def test_packed_forward_lanes_store_map(log2n, rnd, in_order):
     for dw, tw, batch in ((16, 16, 37), (16, 13, 9), (12, 16, 21)):  # fast + exact extraction, narrow data, partial last chunk
         info = check(frames(n, dw, batch, 100 + log2n), log2n, dw, tw, 0, rnd, True, direction="FWD", in_order=in_order,
                      out_order="BITREV_LANES")
-        assert info["kernel_name"] == "k_fft1024_i16" and info["n_passes"] == 1, info
+        assert info["kernel_name"] == fwd_kernel(log2n) and info["n_passes"] == 1, info
     # quiet frames (the fast extraction path) and a full multiple of the chunk
     x = uniform_frames(64, n, 14, 7)
     info = check(x, log2n, 16, 16, 0, rnd, True, direction="FWD", in_order=in_order, out_order="BITREV_LANES")
-    assert info["kernel_name"] == "k_fft1024_i16", info
+    assert info["kernel_name"] == fwd_kernel(log2n), info
 
 
-@pytest.mark.parametrize("log2n", [7, 8, 9, 10])
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("rnd", [0, 1])
 @pytest.mark.parametrize("out_order", ["NATURAL", "HALVES"])
 def test_packed_inverse_lanes_load_map(log2n, rnd, out_order):
@@ -47,10 +55,10 @@ def test_packed_inverse_lanes_load_map(log2n, rnd, out_order):
     for dw, tw, batch in ((16, 16, 37), (16, 13, 9), (12, 16, 21)):
         info = check(frames(n, dw, batch, 200 + log2n), log2n, dw, tw, 0, rnd, True, direction="INV", in_order="BITREV_LANES",
                      out_order=out_order)
-        assert info["kernel_name"] == "k_fft1024x_i16" and info["n_passes"] == 1, info
+        assert info["kernel_name"] == inv_kernel(log2n) and info["n_passes"] == 1, info
     x = uniform_frames(64, n, 14, 8)
     info = check(x, log2n, 16, 16, 0, rnd, True, direction="INV", in_order="BITREV_LANES", out_order=out_order)
-    assert info["kernel_name"] == "k_fft1024x_i16", info
+    assert info["kernel_name"] == inv_kernel(log2n), info
 
 
 def test_forward_lanes_then_inverse_lanes_is_the_pair():
@@ -65,9 +73,8 @@ def test_forward_lanes_then_inverse_lanes_is_the_pair():
 
 # (log2n, dw, tw, fmt, rnd, direction, other-end order, batch): one plan per dedicated family behind the composite
 COMPOSITE = [
-    (12, 16, 16, 0, 0, "FWD", "NATURAL", 5),     # k_fft4096_i16
-    (12, 16, 16, 0, 1, "INV", "HALVES", 5),
-    (14, 16, 16, 0, 0, "FWD", "HALVES", 3),      # k_fft16k_i16
+    (13, 16, 16, 0, 1, "INV", "HALVES", 5),      # k_fft16k_i16
+    (14, 16, 16, 0, 0, "FWD", "HALVES", 3),
     (16, 16, 16, 0, 0, "INV", "NATURAL", 2),     # two-pass packed
     (10, 16, 16, 1, 0, "FWD", "NATURAL", 9),     # unscaled 16-bit: 32-bit results
     (10, 24, 24, 1, 0, "FWD", "HALVES", 6),      # 64-bit words

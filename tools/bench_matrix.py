@@ -171,6 +171,23 @@ NATIVE = [("7:16:16:0", ("HALVES", "BITREV"), "16-bit scaled-trunc FWD, HALVES i
           ("17:18:18:0", ("HALVES", "BITREV"), "18-bit scaled FWD, HALVES in / BITREV out (long frames, round 5)"),
           ("17:18:18:0:0:INV", ("BITREV", "HALVES"), "18-bit scaled INV, BITREV in / HALVES out (long frames, round 5)")]
 
+# round 6: BITREV_LANES at one end of a single core and USE_FLY = 0 (full ad-hoc specs "L:DW:TW:FMT:RND:DIR:L1:IN:OUT[:USE_FLY]")
+ROUND6 = [("10:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (store map, round 6)"),
+          ("10:16:16:0:0:INV:0:BITREV_LANES:NATURAL", "16-bit scaled-trunc INV, BITREV_LANES in (load map, round 6)"),
+          ("10:16:16:0:1:FWD:0:HALVES:BITREV_LANES", "16-bit scaled-round FWD, HALVES in / BITREV_LANES out (round 6)"),
+          ("7:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
+          ("12:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (BITREV twin + k_rotate1, round 6)"),
+          ("12:16:16:0:0:INV:0:BITREV_LANES:NATURAL", "16-bit scaled-trunc INV, BITREV_LANES in (round 6)"),
+          ("14:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
+          ("16:16:16:0:0:FWD:0:HALVES:BITREV_LANES", "16-bit scaled-trunc FWD, HALVES in / BITREV_LANES out (round 6)"),
+          ("20:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
+          ("10:24:24:1:0:FWD:0:NATURAL:BITREV_LANES", "24-bit unscaled FWD, BITREV_LANES out (round 6)"),
+          ("16:24:24:1:0:FWD:0:NATURAL:BITREV_LANES", "24-bit unscaled FWD (C3's plan), BITREV_LANES out (round 6)"),
+          ("10:16:16:0:0:FWD:0:NATURAL:BITREV:0", "16-bit scaled FWD, USE_FLY = 0, natural in / BITREV out (no data movement, round 6)"),
+          ("10:16:16:0:0:FWD:0:NATURAL:NATURAL:0", "16-bit scaled FWD, USE_FLY = 0, natural in / natural out (round 6)"),
+          ("16:24:24:1:0:INV:0:BITREV:NATURAL:0", "24-bit unscaled INV, USE_FLY = 0 (round 6)"),
+          ("12:16:16:0:0:PAIR:0:HALVES:NATURAL:0", "16-bit scaled PAIR, USE_FLY = 0, HALVES in (round 6)")]
+
 if __name__ == "__main__":
     print("Every row: one call on 256 MiB of input, 10 timed steps after a clock ramp.  At the multi-pass "
           "lengths that is ONE scratch chunk per call, so the two-stream chunk alternation of N = 2^19 / 2^20, the 24-bit class and the tiled "
@@ -191,6 +208,13 @@ if __name__ == "__main__":
     for spec, orders, label in NATIVE:
         B.adhoc(spec)
         B.ORDERS[spec] = orders
+        r = B.run(spec, steps=10)
+        bps = r["GB/s"] / r["Gsample/s"]
+        print("| 2^%d | %s | `%s` | %d | %.0f | %.0f | %.0f | %.2f | %s |" % (
+            r["log2n"], label, r["kernel"], r["passes"], r["Gsample/s"], bps, r["GB/s"], r["roofline_frac"],
+            "ok" if r["parity_prefix_ok"] else "MISMATCH"), flush=True)
+    for spec, label in ROUND6:
+        B.adhoc(spec)
         r = B.run(spec, steps=10)
         bps = r["GB/s"] / r["Gsample/s"]
         print("| 2^%d | %s | `%s` | %d | %.0f | %.0f | %.0f | %.2f | %s |" % (

@@ -1,7 +1,8 @@
 """tools/fuzz_soak.py [seconds] [seed] -- open-ended parity fuzz on the GPU box (diagnostics; the seeded, bounded fuzz sets live in tests/).
 Random elaboratable generics (NFFT 3..20, DATA_WIDTH 4..64, TWDL_WIDTH 8..26, every mode / direction / XSERIES / order pair, ragged
 batches; now and then the 2-D scheme with a random split): whatever kernel the planner picks must equal the C oracle bit for bit.
-FUZZ_BIG=1: the multi-pass families; FUZZ_LONG=1: the unscaled forward core at N = 2^17 .. 2^20; FUZZ_NATIVE=1: single cores in their own beat orders (HALVES / BITREV), widths weighted to the 32- / 64-bit word classes.
+FUZZ_BIG=1: the multi-pass families; FUZZ_LONG=1: the unscaled forward core at N = 2^17 .. 2^20; FUZZ_NATIVE=1: single cores in their own beat orders (HALVES / BITREV), widths weighted to the 32- / 64-bit word classes;
+FUZZ_R6=1: the plans of round 6 -- BITREV_LANES at one end of a single core (store / load maps, BITREV twin + rotation) and USE_FLY = 0.
 Prints one line per mismatch (none expected) and a summary of the kernels that were exercised."""
 import collections
 import os
@@ -47,6 +48,18 @@ def main():
             log2n, fmt, rnd, d, in_o, out_o = int(rng.integers(17, 21)), 1, 0, "FWD", "NATURAL", "NATURAL"
             dw = int(rng.choice([16, 16, 14, 15, 13, 20, 24, 24, 28, int(rng.integers(9, 33))]))
             tw = int(rng.choice([16, 16, 24, 12, int(rng.integers(8, 25))]))
+        use_fly = 1
+        if os.environ.get("FUZZ_R6") == "1":
+            d = ["FWD", "INV", "PAIR"][int(rng.integers(0, 3))]
+            if rng.random() < 0.35:
+                use_fly = 0
+                in_o, out_o = list(ORD)[int(rng.integers(0, 4))], list(ORD)[int(rng.integers(0, 4))]
+            else:
+                d = ["FWD", "INV"][int(rng.integers(0, 2))]
+                other = ["NATURAL", "HALVES", "BITREV"][int(rng.integers(0, 3))]
+                in_o, out_o = (other, "BITREV_LANES") if d == "FWD" else ("BITREV_LANES", other)
+            log2n = int(rng.choice([5, 6, 7, 8, 9, 10, 10, 11, 12, 12, 13, 14, 15, 16, 16, 17, 19, 20]))
+            dw = int(rng.choice([16, 16, 16, 12, 18, 24, 24, 32, 40, int(rng.integers(4, 65))]))
         l1 = 0
         if big and log2n == 20 and rng.random() < 0.3:
             l1, log2n = 10, int(rng.choice([20, 20, 21, 21, 22, 22]))
@@ -54,7 +67,9 @@ def main():
                 l1 = 11  # 2048 x 2048: the two-launch plans of round 5
         elif log2n >= 6 and rng.random() < 0.15:
             l1 = int(rng.integers(3, log2n - 2)) if rng.random() < 0.6 or log2n < 13 else 10 if log2n >= 20 else l1
-        p = C.make_params(log2n, dw, tw, fmt, rnd, new)
+        if use_fly == 0:
+            l1 = 0
+        p = C.make_params(log2n, dw, tw, fmt, rnd, new, use_fly)
         if l1:
             if in_o == "BITREV_LANES" or out_o == "BITREV_LANES" or C.lib().orc_validate_2d(p, l1, DIR[d]) != 0:
                 continue
@@ -67,7 +82,7 @@ def main():
         if rng.random() < 0.3:
             x = np.concatenate([x, edge_frames(n, dw)[: 1 + int(rng.integers(0, 6))]])
         try:
-            core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW" if new else "OLD", d, in_o, out_o, NFFT1=l1)
+            core = IntFFTCore(log2n, dw, tw, fmt, rnd, "NEW" if new else "OLD", d, in_o, out_o, use_fly, NFFT1=l1)
         except Exception as exc:  # the planner refuses what the oracle accepts: report it
             print("PLAN-REFUSED", (log2n, dw, tw, fmt, rnd, new, d, in_o, out_o, l1), repr(exc)[:120], flush=True)
             bad += 1
@@ -83,7 +98,7 @@ def main():
         done += 1
         if got.shape != want.shape or not np.array_equal(got, want):
             bad += 1
-            print("MISMATCH", (log2n, dw, tw, fmt, rnd, new, d, in_o, out_o, l1, batch, bits), name, flush=True)
+            print("MISMATCH", (log2n, dw, tw, fmt, rnd, new, d, in_o, out_o, l1, batch, bits, use_fly), name, flush=True)
     print("fuzz_soak: %d configurations in %.0f s, %d mismatches" % (done, time.time() - t0, bad))
     for k, v in seen.most_common():
         print("  %5d  %s" % (v, k))
