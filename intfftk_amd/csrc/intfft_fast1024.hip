@@ -134,12 +134,12 @@ __device__ __forceinline__ void transform_phase1(u32 (&v)[16], const Twiddles<(R
 }
 
 // the rest: lane swaps with stages 5 and 4, the LDS transpose, stages 3..0, the store
-template <int L, int ROUND, bool OUT_BITREV, int FASTX>
+template <int L, int ROUND, int OUT_BITREV, int FASTX>
 __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
                                                const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                               const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user,
-                                               bool out_lanes = false)
+                                               const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
 {
+    constexpr bool out_lanes = OUT_BITREV == 2; // the BITREV instantiation with the serial-stream store map
     static_assert(L >= 7 || !OUT_BITREV, "native orders need N >= 128");
     constexpr bool P = !ROUND;
     constexpr int M0 = 0, MA = P ? 0xF : 0;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f,
             if (L < 10 && !st_ok && f * (size_t)(1 << (10 - L)) + (size_t)(((q << 8) | ((lane & 15) << 4)) >> L) >= nframes_user)
                 continue;
             const v4u x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            if (out_lanes) {
+            if constexpr (out_lanes) {
                 // BITREV_LANES (outbuf_half_path.vhd:160-172: the serial stream [lane 0 frame ; lane 1 frame] that int_bitrev_order reads):
                 // core position n of a frame goes to memory index (n & 1) * N/2 + (n >> 1).  The vector holds four consecutive n:
                 // the even ones are two consecutive words of the first half, the odd ones of the second -- two 8-byte stores,
@@ -297,14 +297,13 @@ __device__ __forceinline__ void transform_tail(u32 (&v)[16], u32 *out, size_t f,
     }
 }
 
-template <int L, int ROUND, bool OUT_BITREV, int FASTX>
+template <int L, int ROUND, int OUT_BITREV, int FASTX>
 __device__ __forceinline__ void transform_store(u32 (&v)[16], u32 *out, size_t f, int lane, const Twiddles<(ROUND != 0)> &tw,
                                                 const Fast1024Consts &c, const Slice &sl, u32 *wr_base,
-                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user,
-                                                bool out_lanes = false)
+                                                const uint4 *rd_base, v2s sh3, int lane_off, bool st_ok, size_t nframes_user)
 {
     transform_phase1<L, ROUND, FASTX>(v, tw, sl);
-    transform_tail<L, ROUND, OUT_BITREV, FASTX>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+    transform_tail<L, ROUND, OUT_BITREV, FASTX>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
 }
 
 // Magnitude votes of the 16-bit fast path (N >= 256).  Fast extraction needs every 32-bit dot-product sum inside [-2^30, 2^30), i.e.
@@ -338,7 +337,7 @@ __device__ __forceinline__ bool frame_within_T_after_phase1(const u32 (&v)[16])
 }
 
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
-template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+template <int L, int ROUND, int OUT_BITREV, bool PIPE, bool FAST_OK>
 #ifdef INTFFT_WPE_F /* A/B: tools/build_variant.sh fwpe5 intfft_fast1024.hip -DINTFFT_WPE_F=5 */
 #define INTFFT_WPE_F_ATTR __attribute__((amdgpu_waves_per_eu(INTFFT_WPE_F)))
 #else
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(256) INTFFT_WPE_F_ATTR void k_fft1024_i16(const u32
                                                      int io_flags)
 {
     const int in_halves = io_flags & 1;                    // HALVES beats in
-    const bool out_lanes = OUT_BITREV && (io_flags & 2);   // BITREV_LANES instead of BITREV out (wave-uniform: a kernel argument)
+    constexpr bool out_lanes = OUT_BITREV == 2;            // BITREV_LANES instead of BITREV out: its own instantiations (OUT_BITREV = 2)
     constexpr int FP = 1 << (10 - L);                         // frames per 1024-sample chunk
     const size_t nframes = (nframes_user + FP - 1) / FP;      // chunks ("frames" of the wave loop below)
     __shared__ __attribute__((aligned(16))) u32 lds_all[4 * 64 * ROW_DW];
@@ -451,22 +450,22 @@ __global__ __launch_bounds__(256) INTFFT_WPE_F_ATTR void k_fft1024_i16(const u32
                     transform_phase1<L, ROUND, 2>(v, tw, sl); // the t = 16 exact form (mul2x_t16)
                     fast = frame_within_T_after_phase1(v);
                 }
-                if (fast) transform_tail<L, ROUND, OUT_BITREV, 1>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
-                else transform_tail<L, ROUND, OUT_BITREV, 2>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+                if (fast) transform_tail<L, ROUND, OUT_BITREV, 1>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
+                else transform_tail<L, ROUND, OUT_BITREV, 2>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
                 return;
             }
         }
         if (FAST_OK && frame_has_guard_bit(v, sl.gbias, sl.gmask)) {
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
             return;
         }
         // exact path.  DATA_WIDTH < 16: containers wrapped to w bits, w-bit exact extraction (and w-bit rhu2 wraps in round mode).
         // A FAST_OK kernel is launched for 16-bit twiddles only: its 16-bit exact path is the t = 16 form (mul2x_t16).
         if (sl.wd != 16) wrap_inputs(v, sl.wd);
         if (FAST_OK && sl.wd == 16)
-            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+            transform_store<L, ROUND, OUT_BITREV, FAST_OK ? 2 : 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
         else
-            transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user, out_lanes);
+            transform_store<L, ROUND, OUT_BITREV, 0>(v, out, f, lane, tw, c, sl, wr_base, rd_base, sh3, lane_off, st_ok, nframes_user);
     };
     auto load_frame = [&](u32(&v)[16], size_t f) {
         const bool partial = L < 10 && (f + 1) * FP > nframes_user; // last chunk: samples of absent frames read as 0
@@ -552,7 +551,7 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <int L, int ROUND, bool OUT_BITREV, bool PIPE, bool FAST_OK>
+template <int L, int ROUND, int OUT_BITREV, bool PIPE, bool FAST_OK>
 static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, int in_halves, hipStream_t stream)
 {
@@ -569,7 +568,7 @@ static hipError_t launch_k(const u32 *in, u32 *out, const int2 *tw, const Fast10
     return hipGetLastError();
 }
 
-template <int L, int ROUND, bool OUT_BITREV>
+template <int L, int ROUND, int OUT_BITREV>
 static hipError_t launch_t(const u32 *in, u32 *out, const int2 *tw, const Fast1024Consts &c, size_t nframes,
                            const Slice &sl, bool fast_ok, int in_halves, hipStream_t stream)
 {
@@ -593,16 +592,19 @@ template <int L>
 static hipError_t launch_short(int round, int out_bitrev, int in_halves, const u32 *in, u32 *out, const int2 *tw,
                                const Fast1024Consts &c, size_t nframes, const Slice &sl, bool fast_ok, hipStream_t stream)
 {
-    if (out_bitrev == 2) in_halves |= 2; // io_flags bit 1: BITREV_LANES store map of the OUT_BITREV instantiations
-    if constexpr (L >= 7) {
+    if constexpr (L >= 7) { // out_bitrev: 1 BITREV, 2 BITREV_LANES -> the OUT_BITREV = 1 / 2 instantiations
+        if (out_bitrev == 2)
+            return round == 2   ? launch_t<L, 2, 2>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                   : round == 1 ? launch_t<L, 1, 2>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                                : launch_t<L, 0, 2>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
         if (out_bitrev)
-            return round == 2   ? launch_t<L, 2, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-                   : round == 1 ? launch_t<L, 1, true>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-                                : launch_t<L, 0, true>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
+            return round == 2   ? launch_t<L, 2, 1>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                   : round == 1 ? launch_t<L, 1, 1>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                                : launch_t<L, 0, 1>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
     }
-    return round == 2   ? launch_t<L, 2, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-           : round == 1 ? launch_t<L, 1, false>(in, out, tw, c, nframes, sl, false, in_halves, stream)
-                        : launch_t<L, 0, false>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
+    return round == 2   ? launch_t<L, 2, 0>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+           : round == 1 ? launch_t<L, 1, 0>(in, out, tw, c, nframes, sl, false, in_halves, stream)
+                        : launch_t<L, 0, 0>(in, out, tw, c, nframes, sl, fast_ok, in_halves, stream);
 }
 
 hipError_t launch_fast1024(const Fast1024Args &a, const void *in, void *out, const int2 *tw_all,

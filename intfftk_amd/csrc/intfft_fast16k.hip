@@ -92,14 +92,16 @@ enum { M16_FWD = 0, M16_INV = 1, M16_PAIR = 2 }; // PAIR: int_fft_ifft_pair (int
 // layout A, one 8-byte access per lane.  Frequency side: BITREV order is the core position n itself, so a layout-C thread owns 32
 // CONSECUTIVE samples (128 bytes) -- moved straight between registers and memory every wave instruction would touch 64 lines; the chunk goes through the
 // idle transpose region once more instead (thread-major rows of 33 dwords, read back position-major) and is loaded / stored 256 bytes per wave instruction.
-template <int L, int MODE, bool FAST_OK, int ROUND = 0, bool OB = false>
+template <int L, int MODE, bool FAST_OK, int ROUND = 0, int OB = 0> // OB: 1 = the cores' own beat orders, 2 = the same with BITREV_LANES on the frequency side
 __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fft16k_i16(const u32 *in, u32 *out, const uint2 *__restrict__ twf,
                                                                                                           const RoundCConsts c, size_t nframes, const Slice sl, int native_orders)
 {
     static_assert(!OB || MODE != M16_PAIR, "native orders: forward or inverse core alone");
     // OB instantiations serve every non-natural combination (bit 0: HALVES on the time side, bit 1: BITREV on the frequency side, wave-uniform tests);
     // the natural-order instantiations carry none of that code (a run-time `halves` test alone cost the inverse kernel two spilled registers)
-    const bool halves = OB && (native_orders & 1), bitrev = OB && (native_orders & 2);
+    const bool halves = OB && (native_orders & 1), bitrev = OB && (native_orders & 6);
+    // bit 2 (round 6): BITREV_LANES on the frequency side -- the BITREV path with core position n at memory index (n & 1) * N/2 + (n >> 1)
+    constexpr bool lanes = OB == 2; // its own instantiations: a run-time stride cost the BITREV path 3 % (32 scalar adds instead of immediate offsets)
     typedef u32 v2u __attribute__((ext_vector_type(2)));
     static_assert(L == 13 || L == 14, "one workgroup per frame of 8192 / 16384 points");
     static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
@@ -217,8 +219,14 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 for (int j = 0; j < 32; ++j) v[j] = INTFFT_LD(at32(src + ((size_t)j << (L - 5)), tid_l)); // layout A
             }
         } else if (OB && bitrev) { // BITREV order in: memory index = core position; linear loads, handed over to layout C through the staging rows
+            {   // BITREV_LANES: position k * T + tid sits at (tid & 1) * N/2 + k * T/2 + (tid >> 1) -- even threads read the first half of
+                // the frame, odd ones the second (128-byte runs per wave); ONE set of 32 loads, offset and stride picked once
+                unsigned off = lanes ? ((((unsigned)tid & 1u) << (L - 1)) | ((unsigned)tid >> 1)) : tid_l;
+                constexpr int sh = lanes ? L - 6 : L - 5;
+                asm volatile("" : "+v"(off));
 #pragma unroll
-            for (int k = 0; k < 32; ++k) v[k] = INTFFT_LD(at32(src + ((size_t)k << (L - 5)), tid_l));
+                for (int k = 0; k < 32; ++k) v[k] = INTFFT_LD(at32(src + ((size_t)k << sh), off));
+            }
             __syncthreads(); // the previous frame's last transpose reads
 #pragma unroll
             for (int k = 0; k < 32; ++k) stg_lin[ROWQ * rev5k(k)] = v[k];
@@ -311,6 +319,9 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
                 if constexpr (ROUND != 0) round_stages10<32, ROUND == 2>(v, sl); // STAGE 1, 0 in their round forms on both halves
             }
             if (MODE == M16_FWD && OB && bitrev) { // BITREV order out: through the staging rows, then 256 bytes per wave instruction
+                unsigned st_off = lanes ? ((((unsigned)tid & 1u) << (L - 1)) | ((unsigned)tid >> 1)) : tid_l; // BITREV_LANES: two 128-byte runs
+                constexpr int st_sh = lanes ? L - 6 : L - 5;                                                  // per wave, one per half of the frame
+                asm volatile("" : "+v"(st_off));
                 __syncthreads(); // every thread has read its layout-C row
 #pragma unroll
                 for (int r = 0; r < 32; ++r) stg_own[r] = v[r];
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(1 << (L - 5)) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
                 for (int k = 0; k < 32; ++k) v[k] = stg_lin[ROWQ * rev5k(k)];
 #pragma unroll
-                for (int k = 0; k < 32; ++k) __builtin_nontemporal_store(v[k], at32(dst + ((size_t)k << (L - 5)), tid_l));
+                for (int k = 0; k < 32; ++k) __builtin_nontemporal_store(v[k], at32(dst + ((size_t)k << st_sh), st_off));
             } else if constexpr (MODE == M16_FWD) {
 #pragma unroll
                 for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(v[r], at32(dst + ((size_t)rev5k(r) << (L - 5)), tid_l));
@@ -410,8 +421,8 @@ bool fast16k_supported(int log2n, int data_width, int twdl_width, int format, in
     return (log2n == 13 || log2n == 14) && packed_width_ok(data_width, format, rndmode) && twdl_width >= 8 && twdl_width <= 16 && format == 0 &&
            (!rndmode || !diag_env("INTFFT_NO_PACKED_ROUND")) && use_fly == 1 && !diag_env("INTFFT_NO_FAST16K") &&
            // + the cores' own beat orders: int_fftNk HALVES in / BITREV out, int_ifftNk BITREV in / HALVES out (and the mixed forms)
-           (direction == 0   ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1)
-            : direction == 1 ? (in_order == 0 || in_order == 1) && (out_order == 0 || out_order == 2)
+           (direction == 0   ? (in_order == 0 || in_order == 2) && (out_order == 0 || out_order == 1 || out_order == 3)
+            : direction == 1 ? (in_order == 0 || in_order == 1 || in_order == 3) && (out_order == 0 || out_order == 2)
                              : direction == 2 && in_order == 0 && out_order == 0);
 }
 
@@ -433,7 +444,7 @@ bool fast16k_tables_ok(int log2n, const int2 *h_tw, int twd)
 
 const char *fast16k_kernel_name() { return "k_fft16k_i16"; }
 
-template <int L, int MODE, bool FX, int RD = 0, bool OB = false>
+template <int L, int MODE, bool FX, int RD = 0, int OB = 0>
 static hipError_t launch16k_ob(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream, int native_orders)
 {
     constexpr int RB = L - 9, T = 16 << RB;
@@ -444,14 +455,15 @@ static hipError_t launch16k_ob(const u32 *in, u32 *out, const uint2 *tw16f, cons
     hipLaunchKernelGGL((k_fft16k_i16<L, MODE, FX, RD, OB>), dim3(blocks), dim3(T), ldsb, stream, in, out, tw16f, c, nframes, sl, native_orders);
     return hipGetLastError();
 }
-// native_orders: bit 0 = HALVES on the time side, bit 1 = BITREV on the frequency side (single cores only): any of them -> the OB instantiation
+// native_orders: bit 0 = HALVES on the time side, bit 1 = BITREV, bit 2 = BITREV_LANES on the frequency side (single cores only): any of them -> the OB instantiation
 template <int L, int MODE, bool FX, int RD = 0>
 static hipError_t launch16k(const u32 *in, u32 *out, const uint2 *tw16f, const RoundCConsts &c, size_t nframes, const Slice &sl, hipStream_t stream, int native_orders)
 {
     if constexpr (MODE != M16_PAIR) {
-        if (native_orders) return launch16k_ob<L, MODE, FX, RD, true>(in, out, tw16f, c, nframes, sl, stream, native_orders);
+        if (native_orders & 4) return launch16k_ob<L, MODE, FX, RD, 2>(in, out, tw16f, c, nframes, sl, stream, native_orders);
+        if (native_orders) return launch16k_ob<L, MODE, FX, RD, 1>(in, out, tw16f, c, nframes, sl, stream, native_orders);
     }
-    return launch16k_ob<L, MODE, FX, RD, false>(in, out, tw16f, c, nframes, sl, stream, 0);
+    return launch16k_ob<L, MODE, FX, RD, 0>(in, out, tw16f, c, nframes, sl, stream, 0);
 }
 
 hipError_t launch_fast16k(int log2n, int direction, int twd, const void *in, void *out, const uint2 *tw16f, const int2 *h_tw, size_t nframes, hipStream_t stream,

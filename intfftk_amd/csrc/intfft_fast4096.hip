@@ -127,11 +127,11 @@ enum { MODE_FWD = 0, MODE_INV = 1, MODE_PAIR = 2, MODE_MID = 3 };
 // contiguous run per wave.
 // OB (native BITREV order on the LC side: int_fftNk output / int_ifftNk input beats, memory index = core index):
 // LC thread = n11..n4 in natural bit order; two lane swaps then give every lane 4 consecutive samples (dwordx4).
-template <int L, bool OB = false> __host__ __device__ constexpr int lc_bit(int k)
+template <int L, int OB = 0> __host__ __device__ constexpr int lc_bit(int k)
 {
     return OB ? k - 4 : (k < L ? (L - 1) - k : (L - 4) + (k - L));
 }
-template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_reg(int j) // LB register j' = n7..4 -> its LC thread bits
+template <int L, int OB = 0> __host__ __device__ constexpr int lc_row_of_reg(int j) // LB register j' = n7..4 -> its LC thread bits
 {
     return (((j >> 0) & 1) << lc_bit<L, OB>(4)) | (((j >> 1) & 1) << lc_bit<L, OB>(5)) | (((j >> 2) & 1) << lc_bit<L, OB>(6)) |
            (((j >> 3) & 1) << lc_bit<L, OB>(7));
@@ -140,12 +140,13 @@ template <int L, bool OB = false> __host__ __device__ constexpr int lc_row_of_re
 // ROUND: RNDMODE = 1 (the testbench's "ROUNDING" UUT, fft_signle_test.vhd:93-112): rhu2 sums on full-width values, exact
 // extraction, no pre-shifted outputs (so none of the per-thread shift amounts below apply)
 // ROUND: 0 truncate, 1 round, 2 round on narrow data (its own instantiation: the w-bit wraps of intfft_pk16.hpp)
-template <int L, int MODE, bool FAST_OK, bool OB = false, int ROUND = 0>
+template <int L, int MODE, bool FAST_OK, int OB = 0, int ROUND = 0> // OB: 1 = the cores' own beat orders, 2 = the same with BITREV_LANES on the frequency side
 __global__ __launch_bounds__(256) void k_fft4096_i16(const u32 *in, u32 *out, const int2 *__restrict__ twt,
                                                      const RoundCConsts c, size_t nframes_user, const Slice sl, int io_flags)
 {
     const int halves = io_flags & 1;             // HALVES beats on the time side
-    const bool lanes = OB && (io_flags & 2);     // BITREV_LANES instead of BITREV on the frequency side (round 6; wave-uniform)
+    constexpr bool lanes = OB == 2;              // BITREV_LANES instead of BITREV on the frequency side (round 6): its own instantiations --
+                                                 // as a run-time switch it cost the BITREV-in inverse 5 %
     static_assert(!OB || MODE == MODE_FWD || MODE == MODE_INV, "native orders: forward or inverse core alone");
     static_assert(L == 11 || L == 12, "block kernel: N = 2048 or 4096");
     static_assert(!ROUND || !FAST_OK, "round mode: exact extraction");
@@ -407,7 +408,7 @@ bool fast4096_supported(int log2n, int data_width, int twdl_width, int format, i
 
 const char *fast4096_kernel_name() { return "k_fft4096_i16"; }
 
-template <int L, int MODE, bool FAST_OK, bool OB = false, int ROUND = 0>
+template <int L, int MODE, bool FAST_OK, int OB = 0, int ROUND = 0>
 static hipError_t launch4k(const u32 *in, u32 *out, const int2 *tw, const RoundCConsts &c, size_t nframes,
                            const Slice &sl, hipStream_t stream, int halves = 0)
 {
@@ -448,49 +449,34 @@ template <int L>
 static hipError_t launch4k_l(int direction, bool fast_ok, const u32 *pin, u32 *pout, const int2 *tw_all, const RoundCConsts &c,
                              size_t nframes, const Slice &sl, hipStream_t stream, int lc_bitrev, int halves, int round)
 {
+    // lc_bitrev: 0 natural, 1 BITREV, 2 BITREV_LANES on the frequency side (single cores only) -> the OB = 0 / 1 / 2 instantiations
+#define INTFFT_4K_OB(MODE, FX, RD)                                                                                                      \
+    (lc_bitrev == 2   ? launch4k<L, MODE, FX, 2, RD>(pin, pout, tw_all, c, nframes, sl, stream, halves)                                 \
+     : lc_bitrev == 1 ? launch4k<L, MODE, FX, 1, RD>(pin, pout, tw_all, c, nframes, sl, stream, halves)                                 \
+                      : launch4k<L, MODE, FX, 0, RD>(pin, pout, tw_all, c, nframes, sl, stream, halves))
     if (round) {
         switch (direction) {
-        case 0:
-            if (sl.wd != 16)
-                return lc_bitrev ? launch4k<L, MODE_FWD, false, true, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                                 : launch4k<L, MODE_FWD, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-            return lc_bitrev ? launch4k<L, MODE_FWD, false, true, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                             : launch4k<L, MODE_FWD, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-        case 1:
-            if (sl.wd != 16)
-                return lc_bitrev ? launch4k<L, MODE_INV, false, true, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                                 : launch4k<L, MODE_INV, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-            return lc_bitrev ? launch4k<L, MODE_INV, false, true, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                             : launch4k<L, MODE_INV, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+        case 0: return sl.wd != 16 ? INTFFT_4K_OB(MODE_FWD, false, 2) : INTFFT_4K_OB(MODE_FWD, false, 1);
+        case 1: return sl.wd != 16 ? INTFFT_4K_OB(MODE_INV, false, 2) : INTFFT_4K_OB(MODE_INV, false, 1);
         default:
-            return sl.wd != 16 ? launch4k<L, MODE_PAIR, false, false, 2>(pin, pout, tw_all, c, nframes, sl, stream)
-                               : launch4k<L, MODE_PAIR, false, false, 1>(pin, pout, tw_all, c, nframes, sl, stream);
+            return sl.wd != 16 ? launch4k<L, MODE_PAIR, false, 0, 2>(pin, pout, tw_all, c, nframes, sl, stream)
+                               : launch4k<L, MODE_PAIR, false, 0, 1>(pin, pout, tw_all, c, nframes, sl, stream);
         }
     }
     switch (direction) {
-    case 0:
-        if (lc_bitrev)
-            return fast_ok ? launch4k<L, MODE_FWD, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                           : launch4k<L, MODE_FWD, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-        return fast_ok ? launch4k<L, MODE_FWD, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                       : launch4k<L, MODE_FWD, false>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-    case 1:
-        if (lc_bitrev)
-            return fast_ok ? launch4k<L, MODE_INV, true, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                           : launch4k<L, MODE_INV, false, true>(pin, pout, tw_all, c, nframes, sl, stream, halves);
-        return fast_ok ? launch4k<L, MODE_INV, true>(pin, pout, tw_all, c, nframes, sl, stream, halves)
-                       : launch4k<L, MODE_INV, false>(pin, pout, tw_all, c, nframes, sl, stream, halves);
+    case 0: return fast_ok ? INTFFT_4K_OB(MODE_FWD, true, 0) : INTFFT_4K_OB(MODE_FWD, false, 0);
+    case 1: return fast_ok ? INTFFT_4K_OB(MODE_INV, true, 0) : INTFFT_4K_OB(MODE_INV, false, 0);
     default:
         return fast_ok ? launch4k<L, MODE_PAIR, true>(pin, pout, tw_all, c, nframes, sl, stream)
                        : launch4k<L, MODE_PAIR, false>(pin, pout, tw_all, c, nframes, sl, stream);
     }
+#undef INTFFT_4K_OB
 }
 
 hipError_t launch_fast4096(int log2n, int direction, int twd, int lc_bitrev, int halves, const void *in, void *out, const int2 *tw_all, const int2 *h_tw,
                            size_t nframes, hipStream_t stream, int round, int data_width)
 {
     if (nframes == 0) return hipSuccess;
-    if (lc_bitrev == 2) halves |= 2; // BITREV_LANES: the OB instantiations with the serial-stream load / store map (io_flags bit 1)
     RoundCConsts c;
     for (int k = 0; k < 8; ++k) {
         const int2 w = h_tw[7 + k];

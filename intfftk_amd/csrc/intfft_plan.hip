@@ -833,12 +833,14 @@ static int create_plan(intfft_plan **out, const intfft_params *p, int l1, int hi
     }
     // BITREV_LANES (the serial stream of outbuf_half_path.vhd:160-172 / int_bitrev_order.vhd:82-104) at one end of a plan whose BITREV twin
     // has dedicated kernels: that twin + one bit permutation (BITREV <-> BITREV_LANES is a rotation of the memory index by one bit) through a
-    // chunked middle buffer.  The packed 16-bit kernels of N = 128 .. 4096 carry the order as a store / load map of their own and never come here.
+    // chunked middle buffer.  The packed 16-bit kernels of N = 128 .. 16384 carry the order as a store / load map of their own and never come here.
     if (!l1 && p->use_fly == 1 && (p->in_order == INTFFT_ORDER_BITREV_LANES) != (p->out_order == INTFFT_ORDER_BITREV_LANES) &&
         !diag_env("INTFFT_GENERIC_ONLY") && !diag_env("INTFFT_NO_LANES_COMPOSITE") &&
         !fast1024_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order) &&
         !fast1024x_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order) &&
-        !fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order)) {
+        !fast4096_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order) &&
+        !(fast16k_supported(p->log2n, p->data_width, p->twdl_width, p->format, p->rndmode, p->direction, p->use_fly, p->in_order, p->out_order) &&
+          fast16k_tables_ok(p->log2n, pl->h_tw.data(), p->twdl_width))) {
         const bool in_l = p->in_order == INTFFT_ORDER_BITREV_LANES;
         const int cb = in_l ? pl->in_cb : pl->out_cb;
         intfft_params q = *p;
@@ -1879,7 +1881,8 @@ static int exec_core(intfft_plan *plan, const void *d_in, void *d_out, size_t ba
         return (int)launch_fast16k(plan->p.log2n, plan->p.direction, plan->p.twdl_width, d_in, d_out, plan->d_tw16f, plan->h_tw.data(), batch, stream,
                                    plan->p.data_width, plan->p.rndmode,
                                    ((plan->p.direction == INTFFT_FWD ? plan->p.in_order : plan->p.out_order) == INTFFT_ORDER_HALVES ? 1 : 0) |
-                                       ((plan->p.direction == INTFFT_FWD ? plan->p.out_order : plan->p.in_order) == INTFFT_ORDER_BITREV ? 2 : 0));
+                                       ((plan->p.direction == INTFFT_FWD ? plan->p.out_order : plan->p.in_order) == INTFFT_ORDER_BITREV ? 2 : 0) |
+                                       ((plan->p.direction == INTFFT_FWD ? plan->p.out_order : plan->p.in_order) == INTFFT_ORDER_BITREV_LANES ? 4 : 0));
     if (plan->fast4096)
         return (int)launch_fast4096(plan->p.log2n, plan->p.direction, plan->p.twdl_width,
                                     [&] { // the frequency-side order: 1 BITREV, 2 BITREV_LANES

@@ -1,8 +1,8 @@
 """BITREV_LANES -- the serial stream between outbuf_half_path and int_bitrev_order
 (src/vhdl/buffers/outbuf_half_path.vhd:160-172, int_bitrev_order.vhd:82-104) -- off the generic kernels (round 6):
 
-* the packed 16-bit kernels of N = 128 .. 4096 carry it as a store map (forward: `k_fft1024_i16`, `k_fft4096_i16`) / load map
-  (inverse: `k_fft1024x_i16`, `k_fft4096_i16`) of their BITREV instantiations: one launch;
+* the packed 16-bit kernels of N = 128 .. 16384 carry it as a store map (forward: `k_fft1024_i16`, `k_fft4096_i16`,
+  `k_fft16k_i16`) / load map (inverse: `k_fft1024x_i16`, `k_fft4096_i16`, `k_fft16k_i16`) of their BITREV instantiations: one launch;
 * every other plan whose BITREV twin has dedicated kernels runs that twin and one bit permutation (`lanes[...]`): the order
   is a rotation of the BITREV memory index by one bit.
 
@@ -25,14 +25,14 @@ def frames(n, dw, batch, seed):
 
 
 def fwd_kernel(log2n):
-    return "k_fft1024_i16" if log2n <= 10 else "k_fft4096_i16"
+    return "k_fft1024_i16" if log2n <= 10 else "k_fft4096_i16" if log2n <= 12 else "k_fft16k_i16"
 
 
 def inv_kernel(log2n):
-    return "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16"
+    return "k_fft1024x_i16" if log2n <= 10 else "k_fft4096_i16" if log2n <= 12 else "k_fft16k_i16"
 
 
-@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("rnd", [0, 1])
 @pytest.mark.parametrize("in_order", ["NATURAL", "HALVES"])
 def test_packed_forward_lanes_store_map(log2n, rnd, in_order):
@@ -47,7 +47,7 @@ def test_packed_forward_lanes_store_map(log2n, rnd, in_order):
     assert info["kernel_name"] == fwd_kernel(log2n), info
 
 
-@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("log2n", [7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize("rnd", [0, 1])
 @pytest.mark.parametrize("out_order", ["NATURAL", "HALVES"])
 def test_packed_inverse_lanes_load_map(log2n, rnd, out_order):
@@ -73,8 +73,8 @@ def test_forward_lanes_then_inverse_lanes_is_the_pair():
 
 # (log2n, dw, tw, fmt, rnd, direction, other-end order, batch): one plan per dedicated family behind the composite
 COMPOSITE = [
-    (13, 16, 16, 0, 1, "INV", "HALVES", 5),      # k_fft16k_i16
-    (14, 16, 16, 0, 0, "FWD", "HALVES", 3),
+    (15, 16, 16, 0, 1, "INV", "HALVES", 3),      # two-pass packed, round mode
+    (17, 16, 16, 0, 0, "FWD", "HALVES", 2),      # k_big2p_a
     (16, 16, 16, 0, 0, "INV", "NATURAL", 2),     # two-pass packed
     (10, 16, 16, 1, 0, "FWD", "NATURAL", 9),     # unscaled 16-bit: 32-bit results
     (10, 24, 24, 1, 0, "FWD", "HALVES", 6),      # 64-bit words
