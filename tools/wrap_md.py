@@ -13,7 +13,7 @@ import re
 import sys
 import textwrap
 
-ITEM = re.compile(r"^(\s*)([*+-]|\d+[.)])\s+")
+ITEM = re.compile(r"^(\s*)([*+-]|\d{1,2}[.)])\s+(?=\S)")
 
 
 def wrap(text: str, width: int, first: str, rest: str) -> list[str]:
