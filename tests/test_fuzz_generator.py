@@ -17,3 +17,4 @@ def test_fuzz_set_as_a_whole():
     assert {c["log2n"] for c in allc} >= set(range(3, 21)) - {15, 17, 18, 19}  # every short length; the long ones are drawn rarely
     assert any(c["l1"] for c in allc) and any(c["dw"] > 32 for c in allc) and any(not c["new"] for c in allc)
     assert {c["in_o"] for c in allc} == {"NATURAL", "BITREV", "HALVES", "BITREV_LANES"}
+    assert {c["use_fly"] for c in allc} == {0, 1}

@@ -50,7 +50,8 @@ def draw(rng):
     else:
         batch = int(rng.integers(1, 300))
     bits = dw if rng.random() < 0.5 else max(2, dw - 1)
-    return dict(log2n=log2n, dw=dw, tw=tw, fmt=fmt, rnd=rnd, new=new, d=d, in_o=in_o, out_o=out_o, l1=l1, batch=batch, bits=bits,
+    use_fly = 0 if (not l1 and rng.random() < 0.06) else 1  # the bypass mux (round 6: a plan of its own)
+    return dict(log2n=log2n, dw=dw, tw=tw, fmt=fmt, rnd=rnd, new=new, d=d, in_o=in_o, out_o=out_o, l1=l1, batch=batch, bits=bits, use_fly=use_fly,
                 dseed=int(rng.integers(1, 1 << 30)), edges=int(rng.integers(1, 7)) if rng.random() < 0.3 else 0)
 
 
@@ -63,7 +64,7 @@ def configurations(seed, count):
     out = []
     while len(out) < count:
         c = draw(rng)
-        p = C.make_params(c["log2n"], c["dw"], c["tw"], c["fmt"], c["rnd"], c["new"])
+        p = C.make_params(c["log2n"], c["dw"], c["tw"], c["fmt"], c["rnd"], c["new"], c["use_fly"])
         if c["l1"]:
             if "BITREV_LANES" in (c["in_o"], c["out_o"]) or C.lib().orc_validate_2d(p, c["l1"], dirs[c["d"]]) != 0:
                 continue
@@ -94,14 +95,14 @@ def test_fuzz_against_the_oracle(chunk):
         if c["edges"]:
             x = np.concatenate([x, edge_frames(n, c["dw"])[: c["edges"]]])
         core = IntFFTCore(c["log2n"], c["dw"], c["tw"], c["fmt"], c["rnd"], "NEW" if c["new"] else "OLD", c["d"], c["in_o"], c["out_o"],
-                          NFFT1=c["l1"])
+                          c["use_fly"], NFFT1=c["l1"])
         y = core(torch.from_numpy(np.ascontiguousarray(x.astype(NP[core.in_container]))).cuda())
         torch.cuda.synchronize()
         got = y.cpu().numpy().astype(np.int64)
         name = core.info["kernel_name"]
         kernels.add(name)
         core.close()
-        p = C.make_params(c["log2n"], c["dw"], c["tw"], c["fmt"], c["rnd"], c["new"])
+        p = C.make_params(c["log2n"], c["dw"], c["tw"], c["fmt"], c["rnd"], c["new"], c["use_fly"])
         if c["l1"]:
             want = C.execute_2d(x, p, c["l1"], dirs[c["d"]], ords[c["in_o"]], ords[c["out_o"]], form=1)
         else:
