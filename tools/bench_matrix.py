@@ -176,7 +176,7 @@ ROUND6 = [("10:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, 
           ("10:16:16:0:0:INV:0:BITREV_LANES:NATURAL", "16-bit scaled-trunc INV, BITREV_LANES in (load map, round 6)"),
           ("10:16:16:0:1:FWD:0:HALVES:BITREV_LANES", "16-bit scaled-round FWD, HALVES in / BITREV_LANES out (round 6)"),
           ("7:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
-          ("12:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (BITREV twin + k_rotate1, round 6)"),
+          ("12:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
           ("12:16:16:0:0:INV:0:BITREV_LANES:NATURAL", "16-bit scaled-trunc INV, BITREV_LANES in (round 6)"),
           ("14:16:16:0:0:FWD:0:NATURAL:BITREV_LANES", "16-bit scaled-trunc FWD, BITREV_LANES out (round 6)"),
           ("16:16:16:0:0:FWD:0:HALVES:BITREV_LANES", "16-bit scaled-trunc FWD, HALVES in / BITREV_LANES out (round 6)"),
