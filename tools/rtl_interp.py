@@ -1,0 +1,631 @@
+#!/usr/bin/env python3
+"""A dataflow interpreter for the structural VHDL of the reference's arithmetic entities -- TEST INFRASTRUCTURE, this container only.
+
+    python tools/rtl_interp.py [--per-case N] [--seed S]          (needs /root/reference; reads it, copies nothing)
+
+What it is for.  oracle/dsp48_twin.py wires every multiplier / complex multiplier / adder entity "as its port map reads" -- by hand.
+This tool removes the hand from that step: it PARSES the reference's own files (src/vhdl/math/mults/*.vhd, src/vhdl/math/cmult/*.vhd,
+src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_dif2_fly.vhd, int_dit2_fly.vhd), elaborates an entity for given generics (functions that pick constants by XSER, if / for generate,
+local signals, entity instantiations with generic / port maps) and evaluates it as a dataflow network: every concurrent signal
+assignment (slices, SXT, (others => x), single bits, literals; `when rising_edge(clk)` and `after ...` are delays and are ignored), the
+clocked processes of the butterflies (if / else on a bit, `+ '1'`, `not`) as the combinational functions they register, every
+DSP48E1 / DSP48E2 instance through the ONE thing that is not in the reference -- the slice model of oracle/dsp48_twin.py (`dsp48`,
+from UG479 / UG579) -- and every `entity work.x` instance recursively.  The results are compared with the hand-wired twin and with
+oracle_py on random and corner operands: a port map the twin (or the oracles) read wrongly shows as a mismatch against the text itself.
+
+It is NOT a VHDL simulator (no time, no delays, delay lines as wires, no resolution, std_logic as bits) and it does not make the reference "buildable":
+parity stays unpinned.  It runs where /root/reference exists; tests/test_rtl_interp.py skips elsewhere.  Nothing it reads is stored.
+"""
+from __future__ import annotations
+
+import os
+import random
+import re
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import dsp48_twin as tw  # noqa: E402
+
+REF = os.environ.get("INTFFT_REFERENCE", "/root/reference")
+DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft"]
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF, DIRS[0]))
+
+
+# ------------------------------------------------------------------------------------------------ parsing
+
+def _load(entity: str) -> str:
+    for d in DIRS:
+        p = os.path.join(REF, d, entity + ".vhd")
+        if os.path.exists(p):
+            txt = open(p, encoding="latin-1").read()
+            txt = re.sub(r"--[^\n]*", "", txt)          # comments
+            return re.sub(r"\s+", " ", txt).lower()     # VHDL is case-insensitive: everything lower case, one line
+    raise FileNotFoundError(entity)
+
+
+def _split_top(s: str, sep: str):
+    """split on sep outside parentheses"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+GENERATE = re.compile(r"generate\b")
+PROCESS = re.compile(r"process\b")
+
+
+class Entity:
+    def __init__(self, name: str):
+        self.name = name
+        t = _load(name)
+        m = re.search(r"entity %s is(.*?)end %s ?;" % (name, name), t)
+        head = m.group(1)
+        self.generics = []  # (name, default text)
+        g = re.search(r"generic ?\((.*?)\) ?; ?port", head)
+        if g:
+            for item in _split_top(g.group(1), ";"):
+                mm = re.match(r"(\w+) ?: ?\w+ ?(?::= ?(.*))?$", item)
+                self.generics.append((mm.group(1), (mm.group(2) or "").strip()))
+        p = re.search(r"port ?\((.*)\) ?;", head)
+        self.ports = {}  # name -> (dir, range text or None)
+        for item in _split_top(p.group(1), ";"):
+            mm = re.match(r"(\w+) ?: ?(in|out) +std_logic(?:_vector ?\((.*)\))?$", item)
+            self.ports[mm.group(1)] = (mm.group(2), mm.group(3))
+        a = re.search(r"architecture \w+ of %s is(.*)end %s ?;" % (name, name), t)
+        body = a.group(1)
+        # functions: `function f(var : string) return natural is ... end [function] f;` -> the XSER -> value tables
+        self.functions = {}
+        for fm in re.finditer(r"function (\w+) ?(?:\(.*?\))? ?return \w+ is(.*?)end (?:function )?\1 ?;", body):
+            vals = dict(re.findall(r'= "(new|old)" ?\) then ret_val := (\d+)', fm.group(2)))
+            self.functions[fm.group(1)] = {k: int(v) for k, v in vals.items()}
+        body = re.sub(r"function (\w+) ?(?:\(.*?\))? ?return \w+ is.*?end (?:function )?\1 ?;", " ", body)
+        i = body.index(" begin ")
+        self.decls, self.body = body[:i], body[i + 7:]
+
+
+def _statements(s: str):
+    """top-level statements of a concurrent region: yields the text of each `...;` with generate blocks kept whole"""
+    out, depth, cur, i, n = [], 0, "", 0, len(s)
+    gen = 0
+    while i < n:
+        m = GENERATE.match(s, i) if (i == 0 or not (s[i - 1].isalnum() or s[i - 1] == "_")) else None
+        pm = PROCESS.match(s, i) if (m is None and (i == 0 or not (s[i - 1].isalnum() or s[i - 1] == "_"))) else None
+        if pm:
+            gen += -1 if cur.rstrip().endswith("end") else 1
+            cur += "process"
+            i = pm.end()
+            continue
+        if m:
+            # `end generate` closes, a bare `generate` opens
+            if cur.rstrip().endswith("end"):
+                gen -= 1
+            else:
+                gen += 1
+            cur += "generate"
+            i = m.end()
+            continue
+        ch = s[i]
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+        if ch == ";" and depth == 0 and gen == 0:
+            if cur.strip():
+                out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+        i += 1
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _parse_seq(text: str):
+    """sequential statements of a clocked process: [("assign", lhs, rhs) | ("if", [(cond, seq), ...], else_seq)]"""
+    toks = re.split(r"(\bend if ?;|\belsif\b|\belse\b|\bif\b|\bthen\b|;)", text)
+    toks = [t.strip() for t in toks if t.strip()]
+    pos = 0
+
+    def seq(stop):
+        nonlocal pos
+        out = []
+        while pos < len(toks) and toks[pos] not in stop:
+            t = toks[pos]
+            if t == "if":
+                branches, els = [], []
+                pos += 1
+                cond = toks[pos]
+                pos += 2  # cond, then
+                branches.append((cond, seq(("elsif", "else", "end if;", "end if ;"))))
+                while toks[pos] == "elsif":
+                    cond = toks[pos + 1]
+                    pos += 3
+                    branches.append((cond, seq(("elsif", "else", "end if;", "end if ;"))))
+                if toks[pos] == "else":
+                    pos += 1
+                    els = seq(("end if;", "end if ;"))
+                pos += 1  # end if;
+                out.append(("if", branches, els))
+            elif t == ";":
+                pos += 1
+            else:
+                m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", t)
+                assert m, "unparsed sequential statement: %r" % t[:100]
+                out.append(("assign", m.group(1).strip(), re.sub(r" after [\w.]+ ?(ns)?", "", m.group(2)).strip()))
+                pos += 1
+        return out
+
+    return seq(())
+
+
+# ------------------------------------------------------------------------------------------------ evaluation
+
+class NotReady(Exception):
+    pass
+
+
+class Sig:
+    __slots__ = ("hi", "lo", "val", "known")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo, self.val, self.known = hi, lo, 0, 0
+
+    @property
+    def width(self):
+        return self.hi - self.lo + 1
+
+    def full(self):
+        return self.known == (1 << self.width) - 1
+
+    def put(self, hi, lo, v):
+        w = hi - lo + 1
+        m = ((1 << w) - 1) << (lo - self.lo)
+        assert not (self.known & m), "double driver"
+        self.val |= (v & ((1 << w) - 1)) << (lo - self.lo)
+        self.known |= m
+
+    def get_known(self, hi, lo):
+        w = hi - lo + 1
+        m = ((1 << w) - 1) << (lo - self.lo)
+        return (self.known & m) == m
+
+    def get(self, hi, lo):
+        w = hi - lo + 1
+        m = ((1 << w) - 1) << (lo - self.lo)
+        if (self.known & m) != m:
+            raise NotReady()
+        return (self.val >> (lo - self.lo)) & ((1 << w) - 1)
+
+
+def _int(expr: str, env: dict) -> int:
+    e = re.sub(r"\b0+(\d)", r"\1", expr)  # "00" -> "0"
+    return int(eval(e, {"__builtins__": {}}, env))  # noqa: S307 -- integer index arithmetic of the parsed generics
+
+
+def _cond(expr: str, env: dict) -> bool:
+    e = re.sub(r"(?<![<>/=])=(?!=)", "==", expr).replace("/==", "!=")
+    return bool(eval(e, {"__builtins__": {}}, env))  # noqa: S307
+
+
+class Inst:
+    """One elaborated entity: its signals and the flat list of pending statements."""
+
+    def __init__(self, ent: Entity, generics: dict):
+        self.ent = ent
+        self.env = {}
+        for g, dflt in ent.generics:
+            v = generics.get(g, dflt.strip('"') if dflt.startswith('"') else (int(dflt) if dflt.lstrip("-").isdigit() else None))
+            self.env[g] = v
+        self.sigs = {}
+        self.alias = {}    # delay lines: name -> the signal every tap carries
+        self.subs = {}     # elaborated sub-entities, by position in `pending` (an elaboration is reused from one evaluation to the next)
+        self.pending = []  # ("assign", lhs, rhs, env) | ("inst", label, unit, gmap, pmap, env)
+        self._decls(ent.decls, self.env)
+        for p, (_, rng) in ent.ports.items():
+            if rng is None:
+                self.sigs[p] = Sig(0, 0)
+            else:
+                hi, lo = rng.split(" downto ")
+                self.sigs[p] = Sig(_int(hi, self.env), _int(lo, self.env))
+        self._region(ent.body, dict(self.env))
+
+    def _decls(self, text, env):
+        for st in _split_top(text, ";"):
+            m = re.match(r"constant (\w+) ?: ?\w+ ?:= ?(\w+) ?\( ?(\w+) ?\)$", st)
+            if m and self.ent.functions.get(m.group(2)):  # constant awd : natural := find_widtha(xser)
+                env[m.group(1)] = self.ent.functions[m.group(2)][env[m.group(3)]]
+                self.env[m.group(1)] = env[m.group(1)]
+                continue
+            m = re.match(r"signal ([\w, ]+) ?: ?std_logic(?:_vector ?\((.*) downto (.*)\))?(?: ?:= ?.*)?$", st)
+            if m:
+                try:
+                    rng = (_int(m.group(2), env), _int(m.group(3), env)) if m.group(2) else (0, 0)
+                except Exception:  # a range in terms of a delay constant this tool does not evaluate: a control signal, never read here
+                    continue
+                for nm in m.group(1).split(","):
+                    self.sigs[nm.strip()] = Sig(*rng)
+            # anything else (types, delay constants, array signals) is timing, not arithmetic: ignored
+
+    def _region(self, text, env):
+        for st in _statements(text):
+            m = re.match(r"(\w+) ?: ?if (.*?) generate (.*) end generate(?: \w+)?$", st)
+            if m:
+                if _cond(m.group(2), env):
+                    inner = m.group(3)
+                    k = re.match(r"(.*?)\bbegin (.*)$", inner)
+                    if k and re.match(r" ?(signal|constant) ", k.group(1)):
+                        self._decls(k.group(1), env)
+                        inner = k.group(2)
+                    self._region(inner, env)
+                continue
+            m = re.match(r"(\w+) ?: ?for (\w+) in (.*?) to (.*?) generate (.*) end generate(?: \w+)?$", st)
+            if m:
+                for v in range(_int(m.group(3), env), _int(m.group(4), env) + 1):
+                    self._region(m.group(5), dict(env, **{m.group(2): v}))
+                continue
+            m = re.match(r"(\w+) ?: ?(entity work\.\w+|dsp48e1|dsp48e2) ?(?:generic map ?\((.*?)\) ?)?port map ?\((.*)\)$", st)
+            if m:
+                gmap = dict(x.split("=>", 1) for x in _split_top(m.group(3), ",")) if m.group(3) else {}
+                pmap = dict(x.split("=>", 1) for x in _split_top(m.group(4), ","))
+                self.pending.append(("inst", m.group(1), m.group(2).replace("entity work.", ""), {k.strip(): v.strip() for k, v in gmap.items()},
+                                     {k.strip(): v.strip() for k, v in pmap.items()}, env))
+                continue
+            m = re.match(r"(\w+) ?: ?process ?\(.*?\) ?is begin (.*) end process(?: \w+)?$", st)
+            if m:
+                body = m.group(2).strip()
+                k = re.match(r"if rising_edge ?\( ?clk ?\) then (.*) end if ?;?$", body)
+                self.pending.append(("proc", _parse_seq(k.group(1) if k else body), env))
+                continue
+            m = re.match(r"(\w+) ?<= ?\1 ?\(.*? downto 0 ?\) ?& ?(\w+)(?: when rising_edge ?\( ?clk ?\))?$", st)
+            if m:  # a delay line x <= x(n-2 downto 0) & y: every tap of x is y, some clocks later
+                self.alias[m.group(1)] = m.group(2)
+                continue
+            m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", st)
+            assert m, "unparsed statement: %r" % st[:120]
+            rhs = re.sub(r" after [\w.]+ ?(ns)?", "", m.group(2))
+            rhs = re.sub(r" when rising_edge ?\( ?clk ?\)", "", rhs).strip()
+            self.pending.append(("assign", m.group(1).strip(), rhs, env))
+
+    # ---- values -------------------------------------------------------------------------------------------------------------------
+    def _ref(self, text, env):
+        """name | name(i) | name(hi downto lo) -> (Sig, hi, lo)"""
+        m = re.match(r"(\w+) ?(?:\((.*)\))?$", text.strip())
+        if m.group(1) in self.alias:  # a tap of a delay line
+            s = self.sigs[self.alias[m.group(1)]]
+            return s, s.hi, s.lo
+        s = self.sigs[m.group(1)]
+        if m.group(2) is None:
+            return s, s.hi, s.lo
+        if " downto " in m.group(2):
+            hi, lo = m.group(2).split(" downto ")
+            return s, _int(hi, env), _int(lo, env)
+        i = _int(m.group(2), env)
+        return s, i, i
+
+    def _value(self, text, env, want_w=None):
+        """-> (value, width) of an expression on the right of <= or in a port map"""
+        text = text.strip()
+        parts = _split_top(text, "+")
+        if len(parts) == 2:  # x + '1' | x + 1: wraps at the width of x (std_logic_unsigned / signed)
+            v, w = self._value(parts[0], env, want_w)
+            return (v + int(parts[1].strip("'"))) & ((1 << w) - 1), w
+        m = re.match(r"not ?\((.*)\)$", text) or re.match(r"not (\w+)$", text)
+        if m:
+            v, w = self._value(m.group(1), env, want_w)
+            return (~v) & ((1 << w) - 1), w
+        m = re.match(r"\( ?others ?=> ?(.*)\)$", text)
+        if m:
+            inner = m.group(1).strip()
+            bit = int(inner.strip("'")) if inner.startswith("'") else self._value(inner, env)[0]
+            assert want_w is not None
+            return ((1 << want_w) - 1 if bit else 0), want_w
+        m = re.match(r"\((.*others.*)\)$", text)
+        if m:  # aggregate with positions: (0 => '1', 1 => '1', others => '0')
+            v = 0
+            for it in _split_top(m.group(1), ","):
+                k, b = [x.strip() for x in it.split("=>")]
+                if k != "others" and b == "'1'":
+                    v |= 1 << int(k)
+            return v, want_w
+        m = re.match(r"sxt ?\((.*), ?([^,]+)\)$", text)
+        if m:
+            v, w = self._value(m.group(1), env)
+            n = _int(m.group(2), env)
+            return tw.sxt(v, w, n), n
+        if text.startswith('"'):
+            return int(text.strip('"'), 2), len(text) - 2
+        if text.startswith("'"):
+            return int(text.strip("'")), 1
+        s, hi, lo = self._ref(text, env)
+        return s.get(hi, lo), hi - lo + 1
+
+    def run(self, inputs: dict) -> dict:
+        for s in self.sigs.values():
+            s.val = s.known = 0
+        for k, v in inputs.items():
+            s = self.sigs[k]
+            s.put(s.hi, s.lo, v)
+        todo = list(self.pending)
+        while todo:
+            left = []
+            for it in todo:
+                try:
+                    if it[0] == "assign":
+                        _, lhs, rhs, env = it
+                        s, hi, lo = self._ref(lhs, env)
+                        if s.get_known(hi, lo):
+                            continue  # driven from outside (an override of this evaluation)
+                        v, _ = self._value(rhs, env, hi - lo + 1)
+                        s.put(hi, lo, v)
+                    elif it[0] == "proc":
+                        acts = []
+                        self._seq(it[1], it[2], acts)
+                        for s, hi, lo, v in acts:  # all or nothing: a process that is not ready yet left no trace
+                            if not s.get_known(hi, lo):
+                                s.put(hi, lo, v)
+                    else:
+                        self._instance(id(it), *it[1:])
+                except NotReady:
+                    left.append(it)
+            if len(left) == len(todo):
+                break  # what is left waits for clk / rst style inputs or is undriven: fine as long as the outputs are known
+            todo = left
+        out = {}
+        for p, (d, _) in self.ent.ports.items():
+            if d == "out":
+                s = self.sigs[p]
+                if not s.full():
+                    if p == "do_vl":
+                        continue  # the valid strobe is timing
+                    raise NotReady(p)
+                out[p] = s.get(s.hi, s.lo)
+        return out
+
+    def _seq(self, seq, env, acts):
+        for node in seq:
+            if node[0] == "assign":
+                s, hi, lo = self._ref(node[1], env)
+                v, _ = self._value(node[2], env, hi - lo + 1)
+                acts.append((s, hi, lo, v))
+            else:
+                for cond, body in node[1]:
+                    m = re.match(r"\(? ?(.*?) ?= ?'([01])' ?\)?$", cond)
+                    if self._value(m.group(1), env)[0] == int(m.group(2)):
+                        self._seq(body, env, acts)
+                        break
+                else:
+                    self._seq(node[2], env, acts)
+
+    def _instance(self, key, label, unit, gmap, pmap, env):
+        if unit in ("dsp48e1", "dsp48e2"):
+            series = "E1" if unit.endswith("1") else "E2"
+
+            def val(port, w, dflt=0):
+                a = pmap.get(port)
+                if a is None or a == "open":
+                    return dflt
+                return self._value(a, env, w)[0]
+            kw = dict(opmode=format(val("opmode", 7 if series == "E1" else 9), "0%db" % (7 if series == "E1" else 9)),
+                      alumode=format(val("alumode", 4), "04b"), use_mult=gmap.get("use_mult", '"multiply"').strip('"').upper(),
+                      a=val("a", 30), b=val("b", 18), c=val("c", 48), pcin=val("pcin", 48), carryin=val("carryin", 1),
+                      carryinsel=format(val("carryinsel", 3), "03b"), carrycascin=val("carrycascin", 1),
+                      use_simd=gmap.get("use_simd", '"one48"').strip('"').upper())
+            assert val("inmode", 5) == 0 and val("d", 27 if series == "E2" else 25) == 0, "pre-adder / INMODE paths are not modelled"
+            p, pcout, cy = tw.dsp48(series, **kw)
+            for port, v, w in (("p", p, 48), ("pcout", pcout, 48), ("carrycascout", cy, 1)):
+                a = pmap.get(port)
+                if a and a != "open":
+                    s, hi, lo = self._ref(a, env)
+                    assert hi - lo + 1 == w
+                    s.put(hi, lo, v)
+            return
+        sub_ent = entity(unit)
+        sub = self.subs.get(key)
+        if sub is None:
+            g = {}
+            for k, v in gmap.items():
+                g[k] = v.strip('"') if v.startswith('"') else (_int(v, env) if not (v in env and isinstance(env[v], str)) else env[v])
+            sub = self.subs[key] = Inst(sub_ent, g)
+        ins = {}
+        for port, (d, _) in sub_ent.ports.items():
+            if d == "in" and port in pmap and port not in ("clk", "rst"):
+                ins[port] = self._value(pmap[port], env, sub.sigs[port].width)[0]
+        outs = sub.run(ins)
+        for port, v in outs.items():
+            a = pmap.get(port)
+            if a and a != "open":
+                s, hi, lo = self._ref(a, env)
+                s.put(hi, lo, v)
+
+
+_ENT = {}
+
+
+def forget():
+    """drop every parsed / elaborated entity (the tests mutate the text that _load returns)"""
+    _ENT.clear()
+    _INST.clear()
+
+
+def entity(name: str) -> Entity:
+    if name not in _ENT:
+        _ENT[name] = Entity(name)
+    return _ENT[name]
+
+
+_INST = {}
+
+
+def evaluate(name: str, generics: dict, inputs: dict) -> dict:
+    """generics / inputs by lower-case name; string generics lower case ("new" / "old", "add" / "sub"); values are raw vectors"""
+    key = (name, tuple(sorted(generics.items())))
+    if key not in _INST:
+        _INST[key] = Inst(entity(name), generics)
+    return _INST[key].run(inputs)
+
+
+# ------------------------------------------------------------------------------------------------ comparisons with the twin
+
+def operand(rng, w):
+    lo, hi = -(1 << (w - 1)), (1 << (w - 1)) - 1
+    k = rng.random()
+    if k < 0.6:
+        return rng.randint(lo, hi)
+    if k < 0.75:
+        return rng.choice((lo, hi, -1, 0, 1))
+    v = rng.randint(lo, hi)
+    cut = rng.choice((17, 18, 34, 48))
+    if cut < w:
+        m = (1 << cut) - 1
+        v = (v | m) if rng.random() < 0.5 else (v & ~m)
+    return max(lo, min(hi, v))
+
+
+MULTS = {"mlt42x18_dsp48e1": (42, 18), "mlt44x18_dsp48e2": (44, 18), "mlt35x25_dsp48e1": (35, 25), "mlt35x27_dsp48e2": (35, 27),
+         "mlt59x18_dsp48e1": (59, 18), "mlt61x18_dsp48e2": (61, 18), "mlt52x25_dsp48e1": (52, 25), "mlt52x27_dsp48e2": (52, 27)}
+
+
+def check_mult(name, n, rng):
+    aw, bw = MULTS[name]
+    bad = 0
+    for _ in range(n):
+        a, b = operand(rng, aw), operand(rng, bw)
+        got = evaluate(name, {}, {"mlt_a": tw.vec(a, aw), "mlt_b": tw.vec(b, bw)})["mlt_p"]
+        want = getattr(tw, name)(tw.vec(a, aw), tw.vec(b, bw))
+        if got != want or tw.signed(got, aw + bw) != a * b:
+            bad += 1
+            print("MISMATCH", name, a, b, got, want)
+    return bad
+
+
+def check_cmult(dtw, twd, xser, n, rng):
+    """int_cmult_dsp48 elaborated from the reference text against the hand-wired twin and oracle_py"""
+    from oracle import oracle_py as op
+    bad = 0
+    for _ in range(n):
+        v = [operand(rng, dtw), operand(rng, dtw), operand(rng, twd), operand(rng, twd)]
+        r = evaluate("int_cmult_dsp48", {"dtw": dtw, "twd": twd, "xser": xser.lower()},
+                     {"di_re": tw.vec(v[0], dtw), "di_im": tw.vec(v[1], dtw), "ww_re": tw.vec(v[2], twd), "ww_im": tw.vec(v[3], twd)})
+        got = (r["do_re"], r["do_im"])
+        want = tw.int_cmult_dsp48(tw.vec(v[0], dtw), tw.vec(v[1], dtw), tw.vec(v[2], twd), tw.vec(v[3], twd), dtw, twd, xser)
+        ref = op.cmult(v[0], v[1], v[2], v[3], dtw, twd, xser == "NEW")
+        if got != want or (tw.signed(got[0], dtw), tw.signed(got[1], dtw)) != ref:
+            bad += 1
+            print("MISMATCH cmult", dtw, twd, xser, v, got, want, ref)
+    return bad
+
+
+def check_addsub(dspw, xser, n, rng):
+    bad = 0
+    for _ in range(n):
+        v = [operand(rng, dspw) for _ in range(4)]
+        r = evaluate("int_addsub_dsp48", {"dspw": dspw, "xser": xser.lower()},
+                     {"ia_re": tw.vec(v[0], dspw), "ia_im": tw.vec(v[1], dspw), "ib_re": tw.vec(v[2], dspw), "ib_im": tw.vec(v[3], dspw)})
+        got = (r["ox_re"], r["ox_im"], r["oy_re"], r["oy_im"])
+        want = tw.int_addsub_dsp48(*(tw.vec(x, dspw) for x in v), dspw, xser)
+        exact = (v[0] + v[2], v[1] + v[3], v[0] - v[2], v[1] - v[3])
+        if got != tuple(want) or tuple(tw.signed(g, dspw + 1) for g in got) != exact:
+            bad += 1
+            print("MISMATCH addsub", dspw, xser, v, got, want)
+    return bad
+
+
+def check_fly(kind, dtw, tfw, scale, rnd, stage, odd, xser, n, rng):
+    """int_dif2_fly / int_dit2_fly elaborated from the text (its adder, rounding and negation processes, its multiplier) against the twin
+    and oracle_py.  dt_sw -- the STAGE 1 toggle that pr_cnt flips on every valid beat -- is driven from outside."""
+    from oracle import oracle_py as op
+    name = "int_dif2_fly" if kind == "dif" else "int_dit2_fly"
+    g = {"stage": stage, "scale": scale, "dtw": dtw, "tfw": tfw, "rndmode": rnd, "xser": xser.lower()}
+    wo = dtw - scale + 1
+    bad = 0
+    for _ in range(n):
+        v = [operand(rng, dtw) for _ in range(4)]
+        ww = (operand(rng, tfw), operand(rng, tfw))
+        ins = {"ia_re": tw.vec(v[0], dtw), "ia_im": tw.vec(v[1], dtw), "ib_re": tw.vec(v[2], dtw), "ib_im": tw.vec(v[3], dtw),
+               "ww_re": tw.vec(ww[0], tfw), "ww_im": tw.vec(ww[1], tfw), "in_en": 1, "rst": 0}
+        if stage == 1:
+            ins["dt_sw"] = odd
+        r = evaluate(name, g, ins)
+        got = (r["oa_re"], r["oa_im"], r["ob_re"], r["ob_im"])
+        f = tw.int_dif2_fly if kind == "dif" else tw.int_dit2_fly
+        want = f(*(tw.vec(x, dtw) for x in v), tw.vec(ww[0], tfw), tw.vec(ww[1], tfw), stage=stage, scale=scale, dtw=dtw, tfw=tfw, rndmode=rnd,
+                 xser=xser, dt_sw=odd)
+        o = (op.dif_fly if kind == "dif" else op.dit_fly)((v[0], v[1]), (v[2], v[3]), ww, stage, dtw, tfw, scale, rnd, odd, xser == "NEW")
+        ref = tuple(op.sgn(x, wo) for x in (o[0][0], o[0][1], o[1][0], o[1][1]))
+        if got != tuple(want) or tuple(tw.signed(x, wo) for x in got) != ref:
+            bad += 1
+            print("MISMATCH fly", kind, g, odd, v, ww, got, want, ref)
+    return bad
+
+
+def main():
+    if not available():
+        print("reference not present: nothing to do")
+        return 0
+    from oracle import oracle_py as op
+    n = int(sys.argv[sys.argv.index("--per-case") + 1]) if "--per-case" in sys.argv else 40
+    rng = random.Random(int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 2026)
+    bad = cases = sets = 0
+    for name in MULTS:
+        bad += check_mult(name, 10 * n, rng)
+        cases += 1
+        sets += 10 * n
+    by = {}
+    for new in (True, False):
+        for t in range(8, 28):
+            for w in range(8, 79):
+                r = op.cmult_regime(w, t, new)
+                if r:
+                    by.setdefault((r, new), []).append((w, t))
+    for (r, new), lst in sorted(by.items()):
+        pick = rng.sample(lst, min(30, len(lst))) + [min(lst), max(lst)]
+        b = sum(check_cmult(w, t, "NEW" if new else "OLD", n, rng) for w, t in pick)
+        print("%-8s %s: %3d width pairs x %d operand sets, %d mismatches" % (r, "NEW" if new else "OLD", len(pick), n, b), flush=True)
+        bad += b
+        cases += len(pick)
+        sets += len(pick) * n
+    for xser in ("NEW", "OLD"):
+        b = sum(check_addsub(d, xser, n, rng) for d in range(4, 96))
+        print("addsub   %s: DSPW 4 .. 95 x %d operand sets, %d mismatches" % (xser, n, b), flush=True)
+        bad += b
+        cases += 92
+        sets += 92 * n
+    from oracle import oracle_py as op2
+    for kind in ("dif", "dit"):
+        b = k = 0
+        for _ in range(60):
+            xser = rng.choice(("NEW", "OLD"))
+            dtw, tfw = rng.randint(8, 50), rng.choice((12, 16, 18, 19, 24, 25))
+            scale = rng.randint(0, 1)
+            rnd = rng.randint(0, 1) if scale else 0
+            stage, odd = rng.choice((0, 1, 1, 2, 5, 12)), rng.randint(0, 1)
+            if stage > 1 and op2.cmult_regime(dtw + 1 - scale if kind == "dif" else dtw, tfw, xser == "NEW") is None:
+                continue
+            b += check_fly(kind, dtw, tfw, scale, rnd, stage, odd, xser, n, rng)
+            k += 1
+        print("int_%s2_fly: %d random (widths, mode, STAGE, XSER) x %d operand sets, %d mismatches" % (kind, k, n, b), flush=True)
+        bad += b
+        cases += k
+        sets += k * n
+    print("rtl_interp: %d elaborations of the reference's own text, %d operand sets, %d mismatches against the hand-wired twin / oracle_py"
+          % (cases, sets, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
