@@ -69,6 +69,24 @@ def test_butterflies_from_the_text(kind):
         assert R.check_fly(kind, *c, 25, rng) == 0, c
 
 
+@pytest.mark.parametrize("xser", ["NEW", "OLD"])
+@pytest.mark.parametrize("use_mlt", [False, True])
+def test_taylor_correction_from_the_text(xser, use_mlt):
+    """row_twiddle_tay: XSHIFT and MATHPI from its functions (INTEGER(MATH_PI * 2.0**(13 - ii - del))), the MATHPI * cnt ROM that read_rom
+    fills (or the multiplier process), the operand placement loops, the two DSP48 slices with their ALUMODE aggregates, pr_rnd and the
+    crossed outputs -- against the twin (which tests/test_dsp48_twin.py holds against oracle_py.twiddles)."""
+    rng = random.Random(21)
+    for awd, ii in ((16, 0), (16, 4), (24, 4), (24, 7), (12, 7), (25 if xser == "OLD" else 27, 2), (19, 5)):
+        assert R.check_taylor(awd, ii, xser, use_mlt, 12, rng) == 0, (awd, ii)
+
+
+def test_taylor_ii_8_does_not_elaborate_in_the_reference():
+    """N = 2^20 needs STAGE 19 = ii 8, where rom_cnt (ii + 1 = 9 bits) no longer fits cnt_exp(7 downto 0): the reference's text does not
+    elaborate there, and what the engine computes for C4's top stage is the extension SURVEY.md section 9.6 / DESIGN.md section 2 define."""
+    with pytest.raises(AssertionError, match="does not elaborate"):
+        R.evaluate("row_twiddle_tay", {"awd": 16, "xser": "new", "use_mlt": False, "ii": 8}, {"rom_ww": 1, "rom_cnt": 300, "rstp": 0})
+
+
 def test_generate_tree_elaborates_where_the_oracle_says():
     """Width pairs outside every generate condition leave DO_RE / DO_IM undriven: the oracle calls them unsupported."""
     for w, t, new in ((28, 17, True), (80, 16, True), (30, 28, True), (26, 16, False), (53, 24, True), (18, 19, True), (78, 8, False)):
@@ -117,6 +135,11 @@ def test_the_comparison_reads_the_text(monkeypatch):
     monkeypatch.setattr(R, "_load", edited("(dtw-1 downto 1)", "(dtw-2 downto 0)"))
     R.forget()
     assert R.check_fly("dif", 16, 16, 1, 0, 0, 0, "NEW", 20, rng) > 0
+    # 6. the Taylor correction rounded one bit lower
+    assert "cos_prod(47 downto xshift-1)" in real("row_twiddle_tay")
+    monkeypatch.setattr(R, "_load", edited("_prod(47 downto xshift-1)", "_prod(46 downto xshift-2)"))
+    R.forget()
+    assert R.check_taylor(16, 3, "NEW", False, 20, rng) > 0
     monkeypatch.setattr(R, "_load", real)
     R.forget()
-    assert R.check_cmult(60, 16, "NEW", 20, rng) == 0 and R.check_fly("dit", 16, 16, 1, 0, 5, 0, "NEW", 20, rng) == 0
+    assert R.check_taylor(16, 3, "NEW", False, 10, rng) == 0 and R.check_cmult(60, 16, "NEW", 20, rng) == 0 and R.check_fly("dit", 16, 16, 1, 0, 5, 0, "NEW", 20, rng) == 0

@@ -5,7 +5,7 @@
 
 What it is for.  oracle/dsp48_twin.py wires every multiplier / complex multiplier / adder entity "as its port map reads" -- by hand.
 This tool removes the hand from that step: it PARSES the reference's own files (src/vhdl/math/mults/*.vhd, src/vhdl/math/cmult/*.vhd,
-src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_dif2_fly.vhd, int_dit2_fly.vhd), elaborates an entity for given generics (functions that pick constants by XSER, if / for generate,
+src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_dif2_fly.vhd, int_dit2_fly.vhd, src/vhdl/twiddle/row_twiddle_tay.vhd), elaborates an entity for given generics (its functions -- constants by XSER, MATH_PI arithmetic, the ROM a loop fills --, if / for generate,
 local signals, entity instantiations with generic / port maps) and evaluates it as a dataflow network: every concurrent signal
 assignment (slices, SXT, (others => x), single bits, literals; `when rising_edge(clk)` and `after ...` are delays and are ignored), the
 clocked processes of the butterflies (if / else on a bit, `+ '1'`, `not`) as the combinational functions they register, every
@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import dsp48_twin as tw  # noqa: E402
 
 REF = os.environ.get("INTFFT_REFERENCE", "/root/reference")
-DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft"]
+DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft", "src/vhdl/twiddle"]
 
 
 def available() -> bool:
@@ -64,6 +64,112 @@ def _split_top(s: str, sep: str):
     return out
 
 
+FUNC = re.compile(r"function (\w+) ?(?:\((.*?)\))? ?return \w+ is(.*?)\bbegin (.*?)end (?:function )?\1 ?;")
+
+
+def _take_functions(text: str, table: dict) -> str:
+    """cut `function f(params) return t is <variables> begin <body> end [function] f;` out of a declarative region into `table`"""
+    for m in FUNC.finditer(text):
+        params = [x.split(":")[0].strip() for x in m.group(2).split(";")] if m.group(2) else []
+        table[m.group(1)] = (params, _parse_fn(m.group(4)))
+    return FUNC.sub(" ", text)
+
+
+def _parse_fn(text: str):
+    """function body: ("set", target, expr) | ("if", [(cond, seq)], else) | ("for", var, lo, hi, seq) | ("return", expr)"""
+    toks = [t.strip() for t in re.split(r"(\bend if ?;|\bend loop ?;|\belsif\b|\belse\b|\bif\b|\bthen\b|\bloop\b|;)", text) if t.strip()]
+    pos = 0
+
+    def seq(stop):
+        nonlocal pos
+        out = []
+        while pos < len(toks) and not any(toks[pos].replace(" ", "") == x.replace(" ", "") for x in stop):
+            t = toks[pos]
+            if t == "if":
+                branches, els = [], []
+                cond = toks[pos + 1]
+                pos += 3
+                branches.append((cond, seq(("elsif", "else", "end if;"))))
+                while toks[pos] == "elsif":
+                    cond = toks[pos + 1]
+                    pos += 3
+                    branches.append((cond, seq(("elsif", "else", "end if;"))))
+                if toks[pos] == "else":
+                    pos += 1
+                    els = seq(("end if;",))
+                pos += 1
+                out.append(("if", branches, els))
+            elif t.startswith("for "):
+                m = re.match(r"for (\w+) in (.*) to (.*)$", t)
+                pos += 2  # the header, `loop`
+                out.append(("for", m.group(1), m.group(2), m.group(3), seq(("end loop;",))))
+                pos += 1
+            elif t == ";":
+                pos += 1
+            elif t.startswith("return "):
+                out.append(("return", t[7:]))
+                pos += 1
+            else:
+                m = re.match(r"(\w+(?: ?\(.*?\))?) ?:= ?(.*)$", t)
+                assert m, "unparsed function statement: %r" % t[:100]
+                out.append(("set", m.group(1).strip(), m.group(2).strip()))
+                pos += 1
+        return out
+
+    return seq(())
+
+
+def _vint(x):
+    """VHDL INTEGER(real): round to nearest"""
+    import math
+    return int(math.floor(x + 0.5))
+
+
+def _fn_eval(expr: str, env: dict):
+    import math
+    e = re.sub(r"\b0+(\d)", r"\1", expr)
+    scope = dict(env, math_pi=math.pi, integer=_vint, conv_std_logic_vector=lambda v, n: int(v) & ((1 << n) - 1), true=True, false=False)
+    return eval(e, {"__builtins__": {}}, scope)  # noqa: S307
+
+
+def call_function(table: dict, name: str, args: list, env: dict):
+    params, ast = table[name]
+    scope = dict(env)
+    scope.update(zip(params, args))
+
+    def run(seq):
+        for node in seq:
+            if node[0] == "set":
+                m = re.match(r"(\w+) ?\((.*)\)$", node[1])
+                if m:
+                    scope.setdefault(m.group(1), {})[int(_fn_eval(m.group(2), scope))] = _fn_eval(node[2], scope)
+                else:
+                    scope[node[1]] = _fn_eval(node[2], scope)
+            elif node[0] == "if":
+                for cond, body in node[1]:
+                    if _cond(cond, scope):
+                        r = run(body)
+                        if r is not None:
+                            return r
+                        break
+                else:
+                    r = run(node[2])
+                    if r is not None:
+                        return r
+            elif node[0] == "for":
+                for v in range(int(_fn_eval(node[2], scope)), int(_fn_eval(node[3], scope)) + 1):
+                    scope[node[1]] = v
+                    r = run(node[4])
+                    if r is not None:
+                        return r
+            else:
+                return ("ret", _fn_eval(node[1], scope))
+        return None
+
+    r = run(ast)
+    return r[1]
+
+
 GENERATE = re.compile(r"generate\b")
 PROCESS = re.compile(r"process\b")
 
@@ -87,12 +193,8 @@ class Entity:
             self.ports[mm.group(1)] = (mm.group(2), mm.group(3))
         a = re.search(r"architecture \w+ of %s is(.*)end %s ?;" % (name, name), t)
         body = a.group(1)
-        # functions: `function f(var : string) return natural is ... end [function] f;` -> the XSER -> value tables
         self.functions = {}
-        for fm in re.finditer(r"function (\w+) ?(?:\(.*?\))? ?return \w+ is(.*?)end (?:function )?\1 ?;", body):
-            vals = dict(re.findall(r'= "(new|old)" ?\) then ret_val := (\d+)', fm.group(2)))
-            self.functions[fm.group(1)] = {k: int(v) for k, v in vals.items()}
-        body = re.sub(r"function (\w+) ?(?:\(.*?\))? ?return \w+ is.*?end (?:function )?\1 ?;", " ", body)
+        body = _take_functions(body, self.functions)
         i = body.index(" begin ")
         self.decls, self.body = body[:i], body[i + 7:]
 
@@ -166,7 +268,7 @@ def _parse_seq(text: str):
             else:
                 m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", t)
                 assert m, "unparsed sequential statement: %r" % t[:100]
-                out.append(("assign", m.group(1).strip(), re.sub(r" after [\w.]+ ?(ns)?", "", m.group(2)).strip()))
+                out.append(("assign", m.group(1).strip(), re.sub(r"\s*\bafter [\w.]+( ns\b)?", "", m.group(2)).strip()))
                 pos += 1
         return out
 
@@ -193,6 +295,7 @@ class Sig:
         return self.known == (1 << self.width) - 1
 
     def put(self, hi, lo, v):
+        assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d): does not elaborate" % (hi, lo, self.hi, self.lo)
         w = hi - lo + 1
         m = ((1 << w) - 1) << (lo - self.lo)
         assert not (self.known & m), "double driver"
@@ -205,6 +308,7 @@ class Sig:
         return (self.known & m) == m
 
     def get(self, hi, lo):
+        assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d): does not elaborate" % (hi, lo, self.hi, self.lo)
         w = hi - lo + 1
         m = ((1 << w) - 1) << (lo - self.lo)
         if (self.known & m) != m:
@@ -219,7 +323,7 @@ def _int(expr: str, env: dict) -> int:
 
 def _cond(expr: str, env: dict) -> bool:
     e = re.sub(r"(?<![<>/=])=(?!=)", "==", expr).replace("/==", "!=")
-    return bool(eval(e, {"__builtins__": {}}, env))  # noqa: S307
+    return bool(eval(e, {"__builtins__": {}}, dict(env, true=True, false=False)))  # noqa: S307
 
 
 class Inst:
@@ -229,10 +333,13 @@ class Inst:
         self.ent = ent
         self.env = {}
         for g, dflt in ent.generics:
-            v = generics.get(g, dflt.strip('"') if dflt.startswith('"') else (int(dflt) if dflt.lstrip("-").isdigit() else None))
+            v = generics.get(g, dflt.strip('"') if dflt.startswith('"') else (int(dflt) if dflt.lstrip("-").isdigit() else
+                                {"true": True, "false": False}.get(dflt)))
             self.env[g] = v
         self.sigs = {}
         self.alias = {}    # delay lines: name -> the signal every tap carries
+        self.consts = set()  # vector constants: signals that keep their value from one evaluation to the next
+        self.funcs = dict(ent.functions)
         self.subs = {}     # elaborated sub-entities, by position in `pending` (an elaboration is reused from one evaluation to the next)
         self.pending = []  # ("assign", lhs, rhs, env) | ("inst", label, unit, gmap, pmap, env)
         self._decls(ent.decls, self.env)
@@ -246,10 +353,25 @@ class Inst:
 
     def _decls(self, text, env):
         for st in _split_top(text, ";"):
-            m = re.match(r"constant (\w+) ?: ?\w+ ?:= ?(\w+) ?\( ?(\w+) ?\)$", st)
-            if m and self.ent.functions.get(m.group(2)):  # constant awd : natural := find_widtha(xser)
-                env[m.group(1)] = self.ent.functions[m.group(2)][env[m.group(3)]]
-                self.env[m.group(1)] = env[m.group(1)]
+            m = re.match(r"constant (\w+) ?: ?(\w+)(?: ?\((.*?) downto (.*?)\))? ?:= ?(.*)$", st)
+            if m:
+                name, init = m.group(1), m.group(5).strip()
+                k = re.match(r"(\w+)(?: ?\((.*)\))?$", init)
+                try:
+                    if k and k.group(1) in self.funcs:  # constant awd : natural := find_widtha(xser) | := find_widtha | := read_rom(ii)
+                        args = [env[a.strip()] if a.strip() in env else _int(a, env) for a in k.group(2).split(",")] if k.group(2) else []
+                        env[name] = call_function(self.funcs, k.group(1), args, env)
+                    elif m.group(3):  # a vector constant: std_logic_vector(conv_unsigned(x, n)) and the like
+                        kk = re.match(r"std_logic_vector ?\( ?conv_unsigned ?\((.*), ?(\d+) ?\) ?\)$", init)
+                        self.sigs[name] = Sig(_int(m.group(3), env), _int(m.group(4), env))
+                        self.sigs[name].put(self.sigs[name].hi, self.sigs[name].lo, _int(kk.group(1), env))
+                        self.consts.add(name)
+                        continue
+                    else:
+                        env[name] = _int(init, env)
+                    self.env.setdefault(name, env[name])
+                except Exception:  # a delay constant built from functions this tool has no use for: timing, not arithmetic
+                    pass
                 continue
             m = re.match(r"signal ([\w, ]+) ?: ?std_logic(?:_vector ?\((.*) downto (.*)\))?(?: ?:= ?.*)?$", st)
             if m:
@@ -267,8 +389,9 @@ class Inst:
             if m:
                 if _cond(m.group(2), env):
                     inner = m.group(3)
-                    k = re.match(r"(.*?)\bbegin (.*)$", inner)
-                    if k and re.match(r" ?(signal|constant) ", k.group(1)):
+                    if re.match(r" ?(signal|constant|type|function) ", inner):
+                        inner = _take_functions(inner, self.funcs)
+                        k = re.match(r"(.*?)\bbegin (.*)$", inner)
                         self._decls(k.group(1), env)
                         inner = k.group(2)
                     self._region(inner, env)
@@ -297,8 +420,8 @@ class Inst:
                 continue
             m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", st)
             assert m, "unparsed statement: %r" % st[:120]
-            rhs = re.sub(r" after [\w.]+ ?(ns)?", "", m.group(2))
-            rhs = re.sub(r" when rising_edge ?\( ?clk ?\)", "", rhs).strip()
+            rhs = re.sub(r"\s*\bafter [\w.]+( ns\b)?", "", m.group(2))
+            rhs = re.sub(r"\s*\bwhen rising_edge ?\( ?clk ?\)", "", rhs).strip()
             self.pending.append(("assign", m.group(1).strip(), rhs, env))
 
     # ---- values -------------------------------------------------------------------------------------------------------------------
@@ -320,6 +443,22 @@ class Inst:
     def _value(self, text, env, want_w=None):
         """-> (value, width) of an expression on the right of <= or in a port map"""
         text = text.strip()
+        parts = _split_top(text, "&")
+        if len(parts) > 1:  # concatenation, left part on top
+            v = w = 0
+            for part in parts:
+                pv, pw = self._value(part, env)
+                v, w = (v << pw) | pv, w + pw
+            return v, w
+        parts = _split_top(text, "*")
+        if len(parts) == 2 and all(x.startswith("unsigned") for x in parts):  # unsigned(a) * unsigned(b): the full product
+            (a, wa), (b, wb) = (self._value(re.match(r"unsigned ?\((.*)\)$", x).group(1), env) for x in parts)
+            return a * b, wa + wb
+        m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?unsigned ?\((\w+)\) ?\) ?\)$", text)
+        if m and isinstance(env.get(m.group(1)), dict):  # a ROM built by a function, read at an index taken from a signal
+            return env[m.group(1)][self._value(m.group(2), env)[0]], want_w
+        if text.startswith('x"'):
+            return int(text[2:-1], 16), 4 * (len(text) - 3)
         parts = _split_top(text, "+")
         if len(parts) == 2:  # x + '1' | x + 1: wraps at the width of x (std_logic_unsigned / signed)
             v, w = self._value(parts[0], env, want_w)
@@ -355,8 +494,9 @@ class Inst:
         return s.get(hi, lo), hi - lo + 1
 
     def run(self, inputs: dict) -> dict:
-        for s in self.sigs.values():
-            s.val = s.known = 0
+        for nm, s in self.sigs.items():
+            if nm not in self.consts:
+                s.val = s.known = 0
         for k, v in inputs.items():
             s = self.sigs[k]
             s.put(s.hi, s.lo, v)
@@ -573,6 +713,26 @@ def check_fly(kind, dtw, tfw, scale, rnd, stage, odd, xser, n, rng):
     return bad
 
 
+def check_taylor(awd, ii, xser, use_mlt, n, rng):
+    """row_twiddle_tay elaborated from the text (both forms of MATHPI * cnt: the ROM built by read_rom and the multiplier process) fed
+    the way rom_twiddle_int feeds it, against the twin and -- through the twin's own test -- oracle_py.twiddles"""
+    from oracle import oracle_py as op
+    rom = op._rom(9, awd)
+    bad = 0
+    for _ in range(n):
+        re_, im_ = rom[rng.randrange(512)]
+        if rng.random() < 0.5:
+            re_, im_ = im_, -re_
+        ww = tw.vec(re_, awd) | (tw.vec(im_, awd) << awd)
+        cnt = rng.randrange(1 << (ii + 1))
+        r = evaluate("row_twiddle_tay", {"awd": awd, "xser": xser.lower(), "use_mlt": use_mlt, "ii": ii}, {"rom_ww": ww, "rom_cnt": cnt, "rstp": 0})
+        want = tw.row_twiddle_tay(ww, cnt, awd, xser, ii, use_mlt)
+        if (r["rom_re"], r["rom_im"]) != want:
+            bad += 1
+            print("MISMATCH taylor", awd, ii, xser, use_mlt, cnt, r, want)
+    return bad
+
+
 def main():
     if not available():
         print("reference not present: nothing to do")
@@ -622,6 +782,17 @@ def main():
         bad += b
         cases += k
         sets += k * n
+    b = k = 0
+    for xser in ("NEW", "OLD"):
+        for use_mlt in (False, True):
+            for awd in (12, 16, 18, 19, 24, 25):
+                for ii in range(8):  # STAGE 11 .. 18; ii = 8 (N = 2^20) does not elaborate in the reference: this project's extension
+                    b += check_taylor(awd, ii, xser, use_mlt, max(4, n // 4), rng)
+                    k += 1
+    print("row_twiddle_tay: %d (AWD, ii, XSER, USE_MLT) x %d operand sets, %d mismatches" % (k, max(4, n // 4), b), flush=True)
+    bad += b
+    cases += k
+    sets += k * max(4, n // 4)
     print("rtl_interp: %d elaborations of the reference's own text, %d operand sets, %d mismatches against the hand-wired twin / oracle_py"
           % (cases, sets, bad))
     return 1 if bad else 0
