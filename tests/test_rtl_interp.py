@@ -1,7 +1,8 @@
 """The reference's own structural VHDL, parsed and evaluated (tools/rtl_interp.py), against the hand-wired DSP48 twin and the oracle.
 
 CPU only, and only where the reference tree is present (this container): elsewhere every test here skips.  The interpreter reads
-src/vhdl/math/mults/*.vhd, src/vhdl/math/cmult/*.vhd, src/vhdl/math/int_addsub_dsp48.vhd and src/vhdl/fft/int_di[ft]2_fly.vhd at run time -- generics, the XSER -> constant
+src/vhdl/math/mults/*.vhd, src/vhdl/math/cmult/*.vhd, src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_di[ft]2_fly.vhd,
+src/vhdl/twiddle/*.vhd and the generate loops of src/vhdl/fft/int_fftNk.vhd / int_ifftNk.vhd at run time -- generics, the XSER -> constant
 functions, if / for generate, signals, slices, SXT, entity and DSP48 instantiations with their port maps -- and runs them as a dataflow
 network on the DSP48 slice model of oracle/dsp48_twin.py.  So the WIRING in these comparisons is the reference's text, not anybody's
 reading of it; what remains assumed is the slice model (UG479 / UG579).  Parity stays unpinned (no RTL simulation), but a misread port
@@ -87,6 +88,64 @@ def test_taylor_ii_8_does_not_elaborate_in_the_reference():
         R.evaluate("row_twiddle_tay", {"awd": 16, "xser": "new", "use_mlt": False, "ii": 8}, {"rom_ww": 1, "rom_cnt": 300, "rstp": 0})
 
 
+@pytest.mark.parametrize("xser", ["NEW", "OLD"])
+def test_twiddle_generator_from_the_text(xser):
+    """rom_twiddle_int as its file reads -- the quarter-wave ROM its function fills from MATH_PI, COS and SIN (magnitude 2^(AWD-1) - 1 below
+    18 bits, 2^(AWD-2) - 1 from there), the quadrant rotation of pr_ww, the address slicing, row_twiddle_tay instantiated for STAGE >= 11 --
+    read at counter values cnt, against oracle_py.twiddles: the tables every kernel of the engine is checked against."""
+    rng = random.Random(31)
+    for stage in (2, 3, 4, 7, 10, 11, 12, 15, 18):
+        for awd in (16, 24) if stage % 3 else (12, 18, 19, 25 if xser == "OLD" else 27):
+            assert R.check_twiddles(stage, awd, xser, bool(stage & 1) and stage >= 11, 10, rng) == 0, (stage, awd)
+
+
+def _oracle_schedule(direction, log2n, dw, fmt, rnd, monkeypatch):
+    """what oracle_py really does per stage: (STAGE, DTW, SCALE, RNDMODE) of every butterfly call and the block length of every commutation"""
+    flies, blocks = [], []
+    name = "dif_fly" if direction == "FWD" else "dit_fly"
+    real_fly, real_rev = getattr(op, name), op._rev2rdx
+
+    def fly(a, b, ww, stage, dtw, t, scale, r, odd, new=True):
+        if not flies or flies[-1] != (stage, dtw, scale, r):
+            flies.append((stage, dtw, scale, r))
+        return real_fly(a, b, ww, stage, dtw, t, scale, r, odd, new)
+
+    def rev(ia, ib, cnti):
+        blocks.append(cnti)
+        return real_rev(ia, ib, cnti)
+
+    monkeypatch.setattr(op, name, fly)
+    monkeypatch.setattr(op, "_rev2rdx", rev)
+    x = [(i + 1, -i) for i in range(1 << log2n)]
+    (op.fft_dif if direction == "FWD" else op.ifft_dit)(x, log2n, dw, 16, fmt, rnd)
+    monkeypatch.setattr(op, name, real_fly)
+    monkeypatch.setattr(op, "_rev2rdx", real_rev)
+    return flies, blocks
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("cfg", [(5, 16, 0, 0), (5, 16, 0, 1), (6, 12, 1, 0), (4, 24, 1, 0)])
+def test_stage_schedule_from_the_text(direction, cfg, monkeypatch):
+    """The generate loops of int_fftNk / int_ifftNk: which STAGE, DTW, SCALE, RNDMODE each butterfly instance gets, which STAGE and AWD its
+    twiddle generator, which STAGE and NWIDTH each delay line (whose N_INV = NFFT - STAGE - 2 is read from its own file) -- against what
+    oracle_py's stream form actually does, recorded while it runs."""
+    log2n, dw, fmt, rnd = cfg
+    top = "int_fftnk" if direction == "FWD" else "int_ifftnk"
+    sch = R.stage_schedule(top, {"nfft": log2n, "ramb_type": "wrap", "format": fmt, "rndmode": rnd, "data_width": dw, "twdl_width": 16,
+                                 "xser": "new", "use_mlt": False})
+    flies, blocks = _oracle_schedule(direction, log2n, dw, fmt, rnd, monkeypatch)
+    text_flies = [(g["stage"], g["dtw"], g["scale"], g["rndmode"]) for _, unit, g, _ in sch if unit in ("int_dif2_fly", "int_dit2_fly")]
+    assert text_flies == flies
+    assert [(g["stage"], g["awd"]) for _, unit, g, _ in sch if unit == "rom_twiddle_int"] == [(f[0], 16) for f in flies]
+    delays = [(unit, g) for _, unit, g, _ in sch if unit.startswith("int_delay")]
+    assert [1 << R.delay_block_log2(unit, g["nfft"], g["stage"]) for unit, g in delays] == blocks
+    assert [g["nwidth"] for _, g in delays] == [2 * (dw + (ii + 1) * fmt) for ii in range(log2n - 1)]
+    # the other RAMB_TYPE instantiates the other delay line with the same generics
+    sch2 = R.stage_schedule(top, {"nfft": log2n, "ramb_type": "cont", "format": fmt, "rndmode": rnd, "data_width": dw, "twdl_width": 16,
+                                  "xser": "new", "use_mlt": False})
+    assert [(u.replace("wrap", "line"), g) for _, u, g, _ in sch] == [(u, g) for _, u, g, _ in sch2]
+
+
 def test_generate_tree_elaborates_where_the_oracle_says():
     """Width pairs outside every generate condition leave DO_RE / DO_IM undriven: the oracle calls them unsupported."""
     for w, t, new in ((28, 17, True), (80, 16, True), (30, 28, True), (26, 16, False), (53, 24, True), (18, 19, True), (78, 8, False)):
@@ -140,6 +199,14 @@ def test_the_comparison_reads_the_text(monkeypatch):
     monkeypatch.setattr(R, "_load", edited("_prod(47 downto xshift-1)", "_prod(46 downto xshift-2)"))
     R.forget()
     assert R.check_taylor(16, 3, "NEW", False, 20, rng) > 0
+    # 7. the sine of the twiddle ROM with the other sign; 8. the ROM magnitude of wide twiddles one bit larger
+    assert "sin(-pi_std)" in real("rom_twiddle_int") and "(2.0 ** (xmag-2)) - 1.0" in real("rom_twiddle_int")
+    monkeypatch.setattr(R, "_load", edited("sin(-pi_std)", "sin(pi_std)"))
+    R.forget()
+    assert R.check_twiddles(5, 16, "NEW", False, 20, rng) > 0
+    monkeypatch.setattr(R, "_load", edited("(2.0 ** (xmag-2)) - 1.0", "(2.0 ** (xmag-1)) - 1.0"))
+    R.forget()
+    assert R.check_twiddles(6, 24, "NEW", False, 20, rng) > 0 and R.check_twiddles(6, 16, "NEW", False, 20, rng) == 0
     monkeypatch.setattr(R, "_load", real)
     R.forget()
-    assert R.check_taylor(16, 3, "NEW", False, 10, rng) == 0 and R.check_cmult(60, 16, "NEW", 20, rng) == 0 and R.check_fly("dit", 16, 16, 1, 0, 5, 0, "NEW", 20, rng) == 0
+    assert R.check_twiddles(5, 16, "NEW", False, 10, rng) == 0 and R.check_taylor(16, 3, "NEW", False, 10, rng) == 0 and R.check_cmult(60, 16, "NEW", 20, rng) == 0 and R.check_fly("dit", 16, 16, 1, 0, 5, 0, "NEW", 20, rng) == 0

@@ -5,7 +5,8 @@
 
 What it is for.  oracle/dsp48_twin.py wires every multiplier / complex multiplier / adder entity "as its port map reads" -- by hand.
 This tool removes the hand from that step: it PARSES the reference's own files (src/vhdl/math/mults/*.vhd, src/vhdl/math/cmult/*.vhd,
-src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_dif2_fly.vhd, int_dit2_fly.vhd, src/vhdl/twiddle/row_twiddle_tay.vhd), elaborates an entity for given generics (its functions -- constants by XSER, MATH_PI arithmetic, the ROM a loop fills --, if / for generate,
+src/vhdl/math/int_addsub_dsp48.vhd, src/vhdl/fft/int_dif2_fly.vhd, int_dit2_fly.vhd, src/vhdl/twiddle/row_twiddle_tay.vhd, rom_twiddle_int.vhd; the generate loops of src/vhdl/fft/int_fftNk.vhd / int_ifftNk.vhd for the stage
+schedule), elaborates an entity for given generics (its functions -- constants by XSER, MATH_PI arithmetic, the ROM a loop fills --, if / for generate,
 local signals, entity instantiations with generic / port maps) and evaluates it as a dataflow network: every concurrent signal
 assignment (slices, SXT, (others => x), single bits, literals; `when rising_edge(clk)` and `after ...` are delays and are ignored), the
 clocked processes of the butterflies (if / else on a bit, `+ '1'`, `not`) as the combinational functions they register, every
@@ -27,7 +28,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import dsp48_twin as tw  # noqa: E402
 
 REF = os.environ.get("INTFFT_REFERENCE", "/root/reference")
-DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft", "src/vhdl/twiddle"]
+DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft", "src/vhdl/twiddle", "src/vhdl/delay"]
 
 
 def available() -> bool:
@@ -39,6 +40,9 @@ def available() -> bool:
 def _load(entity: str) -> str:
     for d in DIRS:
         p = os.path.join(REF, d, entity + ".vhd")
+        if not os.path.exists(p):  # file names keep the entity's capitals (int_fftNk.vhd); entity names are lower case in here
+            hit = [f for f in os.listdir(os.path.join(REF, d)) if f.lower() == entity + ".vhd"]
+            p = os.path.join(REF, d, hit[0]) if hit else p
         if os.path.exists(p):
             txt = open(p, encoding="latin-1").read()
             txt = re.sub(r"--[^\n]*", "", txt)          # comments
@@ -64,13 +68,13 @@ def _split_top(s: str, sep: str):
     return out
 
 
-FUNC = re.compile(r"function (\w+) ?(?:\((.*?)\))? ?return \w+ is(.*?)\bbegin (.*?)end (?:function )?\1 ?;")
+FUNC = re.compile(r"function (\w+) ?(?:\((.*?)\))? ?return \w+ is(.*?)\bbegin (.*?)end (?:function(?: \1)?|\1) ?;")
 
 
 def _take_functions(text: str, table: dict) -> str:
     """cut `function f(params) return t is <variables> begin <body> end [function] f;` out of a declarative region into `table`"""
     for m in FUNC.finditer(text):
-        params = [x.split(":")[0].strip() for x in m.group(2).split(";")] if m.group(2) else []
+        params = [nm.strip() for x in m.group(2).split(";") for nm in x.split(":")[0].split(",")] if m.group(2) else []
         table[m.group(1)] = (params, _parse_fn(m.group(4)))
     return FUNC.sub(" ", text)
 
@@ -128,7 +132,8 @@ def _vint(x):
 def _fn_eval(expr: str, env: dict):
     import math
     e = re.sub(r"\b0+(\d)", r"\1", expr)
-    scope = dict(env, math_pi=math.pi, integer=_vint, conv_std_logic_vector=lambda v, n: int(v) & ((1 << n) - 1), true=True, false=False)
+    scope = dict(env, math_pi=math.pi, integer=_vint, conv_std_logic_vector=lambda v, n: int(v) & ((1 << n) - 1), true=True, false=False,
+                 real=float, cos=math.cos, sin=math.sin, conv_signed=lambda v, n: int(v) & ((1 << n) - 1), std_logic_vector=lambda v: v)
     return eval(e, {"__builtins__": {}}, scope)  # noqa: S307
 
 
@@ -140,6 +145,12 @@ def call_function(table: dict, name: str, args: list, env: dict):
     def run(seq):
         for node in seq:
             if node[0] == "set":
+                m = re.match(r"(\w+) ?\((.*?)\) ?\((.*) downto (.*)\)$", node[1])
+                if m:  # arr(i)(hi downto lo) := vector
+                    arr, idx = scope.setdefault(m.group(1), {}), int(_fn_eval(m.group(2), scope))
+                    hi, lo = int(_fn_eval(m.group(3), scope)), int(_fn_eval(m.group(4), scope))
+                    arr[idx] = arr.get(idx, 0) | ((int(_fn_eval(node[2], scope)) & ((1 << (hi - lo + 1)) - 1)) << lo)
+                    continue
                 m = re.match(r"(\w+) ?\((.*)\)$", node[1])
                 if m:
                     scope.setdefault(m.group(1), {})[int(_fn_eval(m.group(2), scope))] = _fn_eval(node[2], scope)
@@ -383,23 +394,27 @@ class Inst:
                     self.sigs[nm.strip()] = Sig(*rng)
             # anything else (types, delay constants, array signals) is timing, not arithmetic: ignored
 
+    def _gen_body(self, inner, env):
+        """a generate body: [declarations] [begin] statements"""
+        if re.match(r" ?(signal|constant|type|function) ", inner):
+            inner = _take_functions(inner, self.funcs)
+            k = re.match(r"(.*?)\bbegin (.*)$", inner)
+            self._decls(k.group(1), env)
+            return k.group(2)
+        return re.sub(r"^ ?begin ", "", inner)
+
     def _region(self, text, env):
         for st in _statements(text):
             m = re.match(r"(\w+) ?: ?if (.*?) generate (.*) end generate(?: \w+)?$", st)
             if m:
                 if _cond(m.group(2), env):
-                    inner = m.group(3)
-                    if re.match(r" ?(signal|constant|type|function) ", inner):
-                        inner = _take_functions(inner, self.funcs)
-                        k = re.match(r"(.*?)\bbegin (.*)$", inner)
-                        self._decls(k.group(1), env)
-                        inner = k.group(2)
-                    self._region(inner, env)
+                    self._region(self._gen_body(m.group(3), env), env)
                 continue
             m = re.match(r"(\w+) ?: ?for (\w+) in (.*?) to (.*?) generate (.*) end generate(?: \w+)?$", st)
             if m:
                 for v in range(_int(m.group(3), env), _int(m.group(4), env) + 1):
-                    self._region(m.group(5), dict(env, **{m.group(2): v}))
+                    e2 = dict(env, **{m.group(2): v})
+                    self._region(self._gen_body(m.group(5), e2), e2)
                 continue
             m = re.match(r"(\w+) ?: ?(entity work\.\w+|dsp48e1|dsp48e2) ?(?:generic map ?\((.*?)\) ?)?port map ?\((.*)\)$", st)
             if m:
@@ -463,7 +478,7 @@ class Inst:
         if len(parts) == 2:  # x + '1' | x + 1: wraps at the width of x (std_logic_unsigned / signed)
             v, w = self._value(parts[0], env, want_w)
             return (v + int(parts[1].strip("'"))) & ((1 << w) - 1), w
-        m = re.match(r"not ?\((.*)\)$", text) or re.match(r"not (\w+)$", text)
+        m = re.match(r"not ?\(([^()]*(?:\([^()]*\)[^()]*)*)\)$", text) or re.match(r"not (.+)$", text)
         if m:
             v, w = self._value(m.group(1), env, want_w)
             return (~v) & ((1 << w) - 1), w
@@ -713,6 +728,46 @@ def check_fly(kind, dtw, tfw, scale, rnd, stage, odd, xser, n, rng):
     return bad
 
 
+def stage_schedule(top: str, generics: dict):
+    """The stage wiring of int_fftNk / int_ifftNk as its generate loops read: for every instance the unit and its evaluated generic map
+    (nothing is evaluated: the delay lines are clocked memories).  -> [(label, unit, {generic: value}, ii)]"""
+    inst = Inst(entity(top), generics)
+    out = []
+    for it in inst.pending:
+        if it[0] != "inst":
+            continue
+        _, label, unit, gmap, _pmap, env = it
+        g = {}
+        for k, v in gmap.items():
+            g[k] = v.strip('"') if v.startswith('"') else (env[v] if (v in env and not isinstance(env[v], int)) else _int(v, env))
+        out.append((label, unit, g, env.get("ii")))
+    return out
+
+
+def delay_block_log2(unit: str, nfft: int, stage: int) -> int:
+    """N_INV of int_delay_line / int_delay_wrap as its constant declaration reads: the cross-commutation works on blocks of 2^N_INV words"""
+    t = _load(unit)
+    m = re.search(r"constant n_inv ?: ?integer ?:= ?([^;]+);", t)
+    return _int(m.group(1), {"nfft": nfft, "stage": stage})
+
+
+def check_twiddles(stage, awd, xser, use_mlt, n, rng):
+    """rom_twiddle_int elaborated from the text -- the ROM its function fills from MATH_PI / COS / SIN, the quadrant rotation process, the
+    address slicing, the Taylor sub-entity for STAGE >= 11 -- read at counter value cnt, against oracle_py.twiddles(stage)[cnt]"""
+    from oracle import oracle_py as op
+    want = op.twiddles(stage, awd, xser == "NEW")
+    bad = 0
+    for _ in range(n):
+        cnt = rng.randrange(1 << stage)
+        r = evaluate("rom_twiddle_int", {"awd": awd, "nfft": 20, "stage": stage, "use_mlt": use_mlt, "xser": xser.lower()},
+                     {"cnt": cnt, "rst": 0, "ww_en": 1})
+        got = (tw.signed(r["ww_re"], awd), tw.signed(r["ww_im"], awd))
+        if got != want[cnt]:
+            bad += 1
+            print("MISMATCH twiddle", stage, awd, xser, use_mlt, cnt, got, want[cnt])
+    return bad
+
+
 def check_taylor(awd, ii, xser, use_mlt, n, rng):
     """row_twiddle_tay elaborated from the text (both forms of MATHPI * cnt: the ROM built by read_rom and the multiplier process) fed
     the way rom_twiddle_int feeds it, against the twin and -- through the twin's own test -- oracle_py.twiddles"""
@@ -790,6 +845,17 @@ def main():
                     b += check_taylor(awd, ii, xser, use_mlt, max(4, n // 4), rng)
                     k += 1
     print("row_twiddle_tay: %d (AWD, ii, XSER, USE_MLT) x %d operand sets, %d mismatches" % (k, max(4, n // 4), b), flush=True)
+    bad += b
+    cases += k
+    sets += k * max(4, n // 4)
+    b = k = 0
+    for xser in ("NEW", "OLD"):
+        for awd in (12, 16, 18, 19, 24, 25):
+            for stage in range(2, 19):
+                b += check_twiddles(stage, awd, xser, bool(stage & 1) and stage >= 11, max(4, n // 4), rng)
+                k += 1
+    print("rom_twiddle_int: %d (STAGE 2 .. 18, AWD, XSER) x %d counter values, %d mismatches against oracle_py.twiddles" % (k, max(4, n // 4), b),
+          flush=True)
     bad += b
     cases += k
     sets += k * max(4, n // 4)
