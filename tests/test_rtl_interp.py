@@ -146,6 +146,18 @@ def test_stage_schedule_from_the_text(direction, cfg, monkeypatch):
     assert [(u.replace("wrap", "line"), g) for _, u, g, _ in sch] == [(u, g) for _, u, g, _ in sch2]
 
 
+@pytest.mark.parametrize("unit,gap", [("int_delay_line", 0), ("int_delay_wrap", 0), ("int_delay_wrap", 1), ("int_delay_wrap", 7)])
+def test_cross_commutation_clocked_from_the_text(unit, gap):
+    """The delay lines are counters, two memories and a crossbar: time is their function, so they are CLOCKED from the text -- every
+    register, counter, memory and process, cycle by cycle, four frames back to back (int_delay_wrap also with idle clocks between the
+    frames, which is what RAMB_TYPE = "WRAP" tolerates) -- and the stream of valid output beats must be the cross-commutation
+    oracle_py._rev2rdx (= fn_rev2rdx, math/fn_radix2.m:51-69) performs with block length 2^N_INV."""
+    rng = random.Random(41)
+    for nfft in (3, 4, 5, 6, 7):
+        for stage in range(nfft - 1):  # N_INV = NFFT - STAGE - 2 from NFFT - 2 down to 0 (the register-only form / null address ranges)
+            assert R.check_delay(unit, nfft, stage, gap, rng) == 0, (nfft, stage)
+
+
 def test_generate_tree_elaborates_where_the_oracle_says():
     """Width pairs outside every generate condition leave DO_RE / DO_IM undriven: the oracle calls them unsupported."""
     for w, t, new in ((28, 17, True), (80, 16, True), (30, 28, True), (26, 16, False), (53, 24, True), (18, 19, True), (78, 8, False)):
@@ -207,6 +219,12 @@ def test_the_comparison_reads_the_text(monkeypatch):
     monkeypatch.setattr(R, "_load", edited("(2.0 ** (xmag-2)) - 1.0", "(2.0 ** (xmag-1)) - 1.0"))
     R.forget()
     assert R.check_twiddles(6, 24, "NEW", False, 20, rng) > 0 and R.check_twiddles(6, 16, "NEW", False, 20, rng) == 0
+    # 9. the crossbar of the delay line switched by the wrong address bit
+    assert "cross <= cnt_adr(n_inv)" in real("int_delay_line")
+    monkeypatch.setattr(R, "_load", edited("cross <= cnt_adr(n_inv)", "cross <= cnt_adr(n_inv-1)"))
+    R.forget()
+    assert R.check_delay("int_delay_line", 5, 0, 0, rng) > 0
     monkeypatch.setattr(R, "_load", real)
     R.forget()
+    assert R.check_delay("int_delay_line", 5, 0, 0, rng) == 0
     assert R.check_twiddles(5, 16, "NEW", False, 10, rng) == 0 and R.check_taylor(16, 3, "NEW", False, 10, rng) == 0 and R.check_cmult(60, 16, "NEW", 20, rng) == 0 and R.check_fly("dit", 16, 16, 1, 0, 5, 0, "NEW", 20, rng) == 0

@@ -14,7 +14,10 @@ DSP48E1 / DSP48E2 instance through the ONE thing that is not in the reference --
 from UG479 / UG579) -- and every `entity work.x` instance recursively.  The results are compared with the hand-wired twin and with
 oracle_py on random and corner operands: a port map the twin (or the oracles) read wrongly shows as a mismatch against the text itself.
 
-It is NOT a VHDL simulator (no time, no delays, delay lines as wires, no resolution, std_logic as bits) and it does not make the reference "buildable":
+The delay lines (int_delay_line.vhd, int_delay_wrap.vhd: counters, two memories, a crossbar) are the one place where time IS the function:
+those two entities are CLOCKED (CycleSim: every register, counter, memory and clocked process of the text, cycle by cycle) on whole frames.
+
+It is NOT a VHDL simulator (no delta cycles, no delays, no resolution, std_logic as bits; everything else is evaluated as a dataflow network) and it does not make the reference "buildable":
 parity stays unpinned.  It runs where /root/reference exists; tests/test_rtl_interp.py skips elsewhere.  Nothing it reads is stored.
 """
 from __future__ import annotations
@@ -185,6 +188,33 @@ GENERATE = re.compile(r"generate\b")
 PROCESS = re.compile(r"process\b")
 
 
+def _balanced(s: str) -> bool:
+    d = 0
+    for ch in s:
+        d += ch == "("
+        d -= ch == ")"
+        if d < 0:
+            return False
+    return d == 0
+
+
+def _split_kw(s: str, kw: str):
+    """split on a keyword (with its spaces) outside parentheses"""
+    out, depth, cur, i = [], 0, "", 0
+    while i < len(s):
+        if depth == 0 and s.startswith(kw, i):
+            out.append(cur.strip())
+            cur = ""
+            i += len(kw)
+            continue
+        depth += s[i] == "("
+        depth -= s[i] == ")"
+        cur += s[i]
+        i += 1
+    out.append(cur.strip())
+    return out
+
+
 class Entity:
     def __init__(self, name: str):
         self.name = name
@@ -303,9 +333,11 @@ class Sig:
         return self.hi - self.lo + 1
 
     def full(self):
-        return self.known == (1 << self.width) - 1
+        return self.width <= 0 or self.known == (1 << self.width) - 1
 
     def put(self, hi, lo, v):
+        if hi < lo:
+            return  # a null range (N_INV = 0 in int_delay_wrap): no bits
         assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d): does not elaborate" % (hi, lo, self.hi, self.lo)
         w = hi - lo + 1
         m = ((1 << w) - 1) << (lo - self.lo)
@@ -314,11 +346,15 @@ class Sig:
         self.known |= m
 
     def get_known(self, hi, lo):
+        if hi < lo:
+            return True
         w = hi - lo + 1
         m = ((1 << w) - 1) << (lo - self.lo)
         return (self.known & m) == m
 
     def get(self, hi, lo):
+        if hi < lo:
+            return 0  # a null range reads as the empty vector (conv_integer of it is 0)
         assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d): does not elaborate" % (hi, lo, self.hi, self.lo)
         w = hi - lo + 1
         m = ((1 << w) - 1) << (lo - self.lo)
@@ -349,6 +385,8 @@ class Inst:
             self.env[g] = v
         self.sigs = {}
         self.alias = {}    # delay lines: name -> the signal every tap carries
+        self.array_types = {}  # array type -> word width
+        self.arrays = {}   # memories: name -> (word width, {index: value})
         self.consts = set()  # vector constants: signals that keep their value from one evaluation to the next
         self.funcs = dict(ent.functions)
         self.subs = {}     # elaborated sub-entities, by position in `pending` (an elaboration is reused from one evaluation to the next)
@@ -384,7 +422,9 @@ class Inst:
                 except Exception:  # a delay constant built from functions this tool has no use for: timing, not arithmetic
                     pass
                 continue
-            m = re.match(r"signal ([\w, ]+) ?: ?std_logic(?:_vector ?\((.*) downto (.*)\))?(?: ?:= ?.*)?$", st)
+            if st.startswith("signal "):
+                st = re.sub(r" ?:= ?.*$", "", st)  # initial values: everything starts at 0 / unknown here
+            m = re.match(r"signal ([\w, ]+) ?: ?std_logic(?:_vector ?\((.*) downto (.*)\))?$", st)
             if m:
                 try:
                     rng = (_int(m.group(2), env), _int(m.group(3), env)) if m.group(2) else (0, 0)
@@ -392,7 +432,19 @@ class Inst:
                     continue
                 for nm in m.group(1).split(","):
                     self.sigs[nm.strip()] = Sig(*rng)
-            # anything else (types, delay constants, array signals) is timing, not arithmetic: ignored
+                continue
+            m = re.match(r"type (\w+) is array ?\(.*\) of std_logic_vector ?\((.*) downto (.*)\)$", st)
+            if m:
+                try:
+                    self.array_types[m.group(1)] = _int(m.group(2), env) - _int(m.group(3), env) + 1
+                except Exception:
+                    pass
+                continue
+            m = re.match(r"signal ([\w, ]+) ?: ?(\w+)$", st)
+            if m and m.group(2) in self.array_types:  # a memory: word index -> value (the cycle simulator reads and writes it)
+                for nm in m.group(1).split(","):
+                    self.arrays[nm.strip()] = (self.array_types[m.group(2)], {})
+            # anything else (delay constants, other types) is timing, not arithmetic: ignored
 
     def _gen_body(self, inner, env):
         """a generate body: [declarations] [begin] statements"""
@@ -426,7 +478,7 @@ class Inst:
             m = re.match(r"(\w+) ?: ?process ?\(.*?\) ?is begin (.*) end process(?: \w+)?$", st)
             if m:
                 body = m.group(2).strip()
-                k = re.match(r"if rising_edge ?\( ?clk ?\) then (.*) end if ?;?$", body)
+                k = re.match(r"if (?:rising_edge ?\( ?clk ?\)|\( ?clk'event and clk ?= ?'1' ?\)) then (.*) end if ?;?$", body)
                 self.pending.append(("proc", _parse_seq(k.group(1) if k else body), env))
                 continue
             m = re.match(r"(\w+) ?<= ?\1 ?\(.*? downto 0 ?\) ?& ?(\w+)(?: when rising_edge ?\( ?clk ?\))?$", st)
@@ -436,8 +488,10 @@ class Inst:
             m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", st)
             assert m, "unparsed statement: %r" % st[:120]
             rhs = re.sub(r"\s*\bafter [\w.]+( ns\b)?", "", m.group(2))
-            rhs = re.sub(r"\s*\bwhen rising_edge ?\( ?clk ?\)", "", rhs).strip()
-            self.pending.append(("assign", m.group(1).strip(), rhs, env))
+            reg = bool(re.search(r"\bwhen rising_edge ?\( ?clk ?\)", rhs))
+            en = re.search(r"\bwhen rising_edge ?\( ?clk ?\) and (.*)$", rhs)  # a register with a clock enable
+            rhs = re.sub(r"\s*\bwhen rising_edge ?\( ?clk ?\)( and .*)?$", "", rhs).strip()
+            self.pending.append(("assign", m.group(1).strip(), rhs, env, reg, en.group(1).strip() if en else None))
 
     # ---- values -------------------------------------------------------------------------------------------------------------------
     def _ref(self, text, env):
@@ -465,6 +519,12 @@ class Inst:
                 pv, pw = self._value(part, env)
                 v, w = (v << pw) | pv, w + pw
             return v, w
+        parts = _split_kw(text, " and ")
+        if len(parts) > 1:
+            v, w = self._value(parts[0], env, want_w)
+            for x in parts[1:]:
+                v &= self._value(x, env, want_w)[0]
+            return v, w
         parts = _split_top(text, "*")
         if len(parts) == 2 and all(x.startswith("unsigned") for x in parts):  # unsigned(a) * unsigned(b): the full product
             (a, wa), (b, wb) = (self._value(re.match(r"unsigned ?\((.*)\)$", x).group(1), env) for x in parts)
@@ -472,6 +532,10 @@ class Inst:
         m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?unsigned ?\((\w+)\) ?\) ?\)$", text)
         if m and isinstance(env.get(m.group(1)), dict):  # a ROM built by a function, read at an index taken from a signal
             return env[m.group(1)][self._value(m.group(2), env)[0]], want_w
+        m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?(\w+) ?\) ?\)$", text)
+        if m and m.group(1) in self.arrays:  # a memory read
+            w, mem = self.arrays[m.group(1)]
+            return mem.get(self._value(m.group(2), env)[0], 0), w
         if text.startswith('x"'):
             return int(text[2:-1], 16), 4 * (len(text) - 3)
         parts = _split_top(text, "+")
@@ -521,7 +585,7 @@ class Inst:
             for it in todo:
                 try:
                     if it[0] == "assign":
-                        _, lhs, rhs, env = it
+                        _, lhs, rhs, env = it[:4]
                         s, hi, lo = self._ref(lhs, env)
                         if s.get_known(hi, lo):
                             continue  # driven from outside (an override of this evaluation)
@@ -551,6 +615,18 @@ class Inst:
                 out[p] = s.get(s.hi, s.lo)
         return out
 
+    def _bool(self, cond, env) -> bool:
+        """(a = '1') | (a(i) = '0') | c1 and c2 | c1 or c2, parenthesised at will"""
+        cond = cond.strip()
+        while cond.startswith("(") and _split_top(cond, "#") == [cond] and _balanced(cond[1:-1]) and cond.endswith(")"):
+            cond = cond[1:-1].strip()
+        for op_, fn in ((" or ", any), (" and ", all)):
+            parts = _split_kw(cond, op_)
+            if len(parts) > 1:
+                return fn(self._bool(x, env) for x in parts)
+        m = re.match(r"(.*?) ?= ?'([01])'$", cond)
+        return self._value(m.group(1), env)[0] == int(m.group(2))
+
     def _seq(self, seq, env, acts):
         for node in seq:
             if node[0] == "assign":
@@ -559,8 +635,7 @@ class Inst:
                 acts.append((s, hi, lo, v))
             else:
                 for cond, body in node[1]:
-                    m = re.match(r"\(? ?(.*?) ?= ?'([01])' ?\)?$", cond)
-                    if self._value(m.group(1), env)[0] == int(m.group(2)):
+                    if self._bool(cond, env):
                         self._seq(body, env, acts)
                         break
                 else:
@@ -606,6 +681,100 @@ class Inst:
             if a and a != "open":
                 s, hi, lo = self._ref(a, env)
                 s.put(hi, lo, v)
+
+
+class CycleSim(Inst):
+    """A clocked evaluation of ONE entity that is all registers, counters and memories (the delay lines): every signal starts at 0,
+    unregistered concurrent assignments are combinational, `x <= y when rising_edge(clk)` and the clocked processes take their inputs
+    before the edge and show their outputs after it (signal assignment semantics: the last assignment in a process wins)."""
+
+    def __init__(self, ent, generics):
+        super().__init__(ent, generics)
+        for s in self.sigs.values():
+            s.val, s.known = 0, (1 << s.width) - 1
+
+    def _comb(self):
+        for _ in range(8):  # a few passes settle the short combinational chains of these entities
+            changed = False
+            for it in self.pending:
+                if it[0] == "assign" and not it[4]:
+                    s, hi, lo = self._ref(it[1], it[3])
+                    v, _ = self._value(it[2], it[3], hi - lo + 1)
+                    if s.get(hi, lo) != v & ((1 << (hi - lo + 1)) - 1):
+                        self._force(s, hi, lo, v)
+                        changed = True
+            if not changed:
+                return
+
+    @staticmethod
+    def _force(s, hi, lo, v):
+        if hi < lo:
+            return
+        w = hi - lo + 1
+        m = ((1 << w) - 1) << (lo - s.lo)
+        s.val = (s.val & ~m) | ((v & ((1 << w) - 1)) << (lo - s.lo))
+
+    def _seq_clocked(self, seq, env, acts, writes):
+        for node in seq:
+            if node[0] == "assign":
+                m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?(\w+) ?\) ?\)$", node[1])
+                if m and m.group(1) in self.arrays:
+                    writes.append((m.group(1), self._value(m.group(2), env)[0], self._value(node[2], env, self.arrays[m.group(1)][0])[0]))
+                    continue
+                s, hi, lo = self._ref(node[1], env)
+                acts.append((s, hi, lo, self._value(node[2], env, hi - lo + 1)[0]))
+            else:
+                for cond, body in node[1]:
+                    if self._bool(cond, env):
+                        self._seq_clocked(body, env, acts, writes)
+                        break
+                else:
+                    self._seq_clocked(node[2], env, acts, writes)
+
+    def clock(self, inputs: dict) -> dict:
+        """drive the inputs, settle, take one rising edge, settle; -> the output ports after the edge"""
+        for k, v in inputs.items():
+            s = self.sigs[k]
+            self._force(s, s.hi, s.lo, v)
+        self._comb()
+        acts, writes = [], []
+        for it in self.pending:
+            if it[0] == "assign" and it[4]:
+                if it[5] is not None and not self._bool(it[5], it[3]):
+                    continue  # clock enable low: the register keeps its value
+                s, hi, lo = self._ref(it[1], it[3])
+                acts.append((s, hi, lo, self._value(it[2], it[3], hi - lo + 1)[0]))
+            elif it[0] == "proc":
+                self._seq_clocked(it[1], it[2], acts, writes)
+        for s, hi, lo, v in acts:
+            self._force(s, hi, lo, v)
+        for name, idx, v in writes:
+            self.arrays[name][1][idx] = v
+        self._comb()
+        return {p: self.sigs[p].val for p, (d, _) in self.ent.ports.items() if d == "out"}
+
+
+def run_delay_line(unit: str, nfft: int, stage: int, frames_a, frames_b, gap: int = 0):
+    """int_delay_line / int_delay_wrap clocked from the text: frames of N/2 beats (two lanes of words) in, with `gap` idle clocks between
+    frames -> the beats that come out with DO_VL = '1', as two lanes"""
+    sim = CycleSim(entity(unit), {"nfft": nfft, "stage": stage, "nwidth": 32})
+    sim.clock({"rst": 1, "di_en": 0, "di_aa": 0, "di_bb": 0})
+    oa, ob = [], []
+
+    def tick(a, b, en):
+        o = sim.clock({"rst": 0, "di_en": en, "di_aa": a, "di_bb": b})
+        if o["do_vl"]:
+            oa.append(o["do_aa"])
+            ob.append(o["do_bb"])
+
+    for fa, fb in zip(frames_a, frames_b):
+        for a, b in zip(fa, fb):
+            tick(a, b, 1)
+        for _ in range(gap):
+            tick(0, 0, 0)
+    for _ in range(4 << nfft):
+        tick(0, 0, 0)
+    return oa, ob
 
 
 _ENT = {}
@@ -751,6 +920,26 @@ def delay_block_log2(unit: str, nfft: int, stage: int) -> int:
     return _int(m.group(1), {"nfft": nfft, "stage": stage})
 
 
+def check_delay(unit, nfft, stage, gap, rng, frames=4):
+    """int_delay_line / int_delay_wrap clocked from the text on back-to-back frames (int_delay_wrap also with idle clocks between frames)
+    against the cross-commutation the oracle's stream form uses (oracle_py._rev2rdx = fn_rev2rdx of math/fn_radix2.m).  int_delay_wrap
+    hands the tail of a frame out while the next one comes in, so its last block stays inside: a prefix is compared."""
+    from oracle import oracle_py as op
+    half = 1 << (nfft - 1)
+    fa = [[rng.randrange(1 << 31) for _ in range(half)] for _ in range(frames)]
+    fb = [[rng.randrange(1 << 31) for _ in range(half)] for _ in range(frames)]
+    oa, ob = run_delay_line(unit, nfft, stage, fa, fb, gap)
+    ea, eb = [], []
+    for a, b in zip(fa, fb):
+        x, y = op._rev2rdx(a, b, 1 << delay_block_log2(unit, nfft, stage))
+        ea += x
+        eb += y
+    ok = oa == ea[:len(oa)] and ob == eb[:len(ob)] and len(oa) >= (frames - 1) * half and (unit != "int_delay_line" or len(oa) == len(ea))
+    if not ok:
+        print("MISMATCH delay", unit, nfft, stage, gap, len(oa), len(ea))
+    return 0 if ok else 1
+
+
 def check_twiddles(stage, awd, xser, use_mlt, n, rng):
     """rom_twiddle_int elaborated from the text -- the ROM its function fills from MATH_PI / COS / SIN, the quadrant rotation process, the
     address slicing, the Taylor sub-entity for STAGE >= 11 -- read at counter value cnt, against oracle_py.twiddles(stage)[cnt]"""
@@ -859,6 +1048,16 @@ def main():
     bad += b
     cases += k
     sets += k * max(4, n // 4)
+    b = k = 0
+    for nfft in range(3, 9):
+        for stage in range(nfft - 1):
+            for unit, gap in (("int_delay_line", 0), ("int_delay_wrap", 0), ("int_delay_wrap", 3)):
+                b += check_delay(unit, nfft, stage, gap, rng)
+                k += 1
+    print("delay lines: %d (entity, NFFT 3 .. 8, STAGE, gap) clocked from the text, 4 frames each, %d mismatches against the oracle's commutation"
+          % (k, b), flush=True)
+    bad += b
+    cases += k
     print("rtl_interp: %d elaborations of the reference's own text, %d operand sets, %d mismatches against the hand-wired twin / oracle_py"
           % (cases, sets, bad))
     return 1 if bad else 0
