@@ -1,0 +1,554 @@
+#!/usr/bin/env python3
+"""A cycle-based simulation of the reference's int_fftNk / int_ifftNk FROM ITS OWN VHDL TEXT -- TEST INFRASTRUCTURE, this container only.
+
+    python tools/rtl_sim.py [--nfft 4] [--frames 3]            (needs /root/reference; reads it, stores nothing)
+
+tools/rtl_interp.py evaluates the arithmetic entities of the reference as dataflow networks.  This tool goes the rest of the way: it
+elaborates a whole core -- the generate loops of int_fftNk.vhd, every butterfly, twiddle generator, aligner and delay line under it, down to
+the DSP48 primitives -- as a hierarchy of clocked nodes and runs it cycle by cycle on frames of input beats:
+
+  * every signal is a register or a wire of the text: unregistered concurrent assignments are combinational, `x <= y when rising_edge(clk)`
+    and clocked processes sample before the edge and show after it (two-phase: compute all next values, then commit), memories included;
+  * arrays of vectors (the per-stage buses of int_fftNk, the delay chains `z <= z(z'left-1 downto 0) & x`) are arrays of signals;
+  * a DSP48E1 / DSP48E2 instance is the slice model of oracle/dsp48_twin.py BEHIND THE PIPELINE REGISTERS ITS GENERIC MAP ASKS FOR
+    (AREG / BREG 0, 1, 2; CREG; MREG; PREG; PCIN = the neighbour's registered P; CARRYCASCIN = its registered carry): the latencies that the
+    aligners, the valid strobes and the twiddle counters are built around come from the text's own generics (UG479 / UG579 for what a
+    register stage is).
+The DO_VAL-qualified output beats are compared with oracle_py on the same frames.  If the pipeline of the text did not line up with its own
+strobes, or the oracle misread any of it, the frames would differ.
+
+Not a VHDL simulator: no delta cycles (one combinational settle per phase), no 'U' / 'X' (everything starts at 0), std_logic as bits, only
+the constructs these files use.  Parity stays unpinned by the rules of this build (the slice model is a stand-in for unisim) -- but this is
+the reference's own text, end to end, producing the oracle's numbers.
+"""
+from __future__ import annotations
+
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import rtl_interp as R  # noqa: E402
+from oracle import dsp48_twin as tw  # noqa: E402
+
+available = R.available
+
+
+class Wire:
+    """A std_logic_vector (or std_logic) signal: value now, value after the next edge."""
+    __slots__ = ("hi", "lo", "val")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo, self.val = hi, lo, 0
+
+    @property
+    def width(self):
+        return max(0, self.hi - self.lo + 1)
+
+    def get(self, hi, lo):
+        if hi < lo:
+            return 0
+        assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d)" % (hi, lo, self.hi, self.lo)
+        return (self.val >> (lo - self.lo)) & ((1 << (hi - lo + 1)) - 1)
+
+    def set(self, hi, lo, v):
+        if hi < lo:
+            return False
+        assert self.lo <= lo <= hi <= self.hi, "slice (%d downto %d) outside (%d downto %d)" % (hi, lo, self.hi, self.lo)
+        w = hi - lo + 1
+        m = ((1 << w) - 1) << (lo - self.lo)
+        new = (self.val & ~m) | ((v & ((1 << w) - 1)) << (lo - self.lo))
+        ch = new != self.val
+        self.val = new
+        return ch
+
+
+class Dsp:
+    """One DSP48 slice behind its pipeline registers."""
+
+    def __init__(self, series, gmap, pmap, env, parent):
+        self.series, self.pmap, self.env, self.parent = series, pmap, env, parent
+        gi = lambda k, d: int(gmap.get(k, str(d)))  # noqa: E731
+        self.areg, self.breg, self.creg, self.mreg, self.preg = gi("areg", 1), gi("breg", 1), gi("creg", 1), gi("mreg", 1), gi("preg", 1)
+        self.use_mult = gmap.get("use_mult", '"multiply"').strip('"').upper()
+        self.use_simd = gmap.get("use_simd", '"one48"').strip('"').upper()
+        assert self.preg == 1, "every slice of the reference registers P"
+        self.a = [0, 0]  # A1, A2
+        self.b = [0, 0]
+        self.c = 0
+        self.m = None    # registered (a, b) operands of the multiplier stage
+        self.p = 0
+        self.cy = 0
+        self.nxt = None
+
+    def _in(self, port, w, dflt=0):
+        a = self.pmap.get(port)
+        if a is None or a == "open":
+            return dflt
+        return self.parent.value(a, self.env, w)[0]
+
+    def _ab(self, regs, n, direct):
+        return direct if n == 0 else regs[1]
+
+    def compute(self):
+        """next state from the present one (phase 1)"""
+        ws = 7 if self.series == "E1" else 9
+        a_in, b_in, c_in = self._in("a", 30), self._in("b", 18), self._in("c", 48)
+        rst = self._in({"E1": "rsta", "E2": "rsta"}[self.series], 1)
+        a_eff = a_in if self.areg == 0 else self.a[1]
+        b_eff = b_in if self.breg == 0 else self.b[1]
+        c_eff = c_in if self.creg == 0 else self.c
+        if self.use_mult == "MULTIPLY" and self.mreg:
+            ma, mb = self.m if self.m is not None else (0, 0)
+        else:
+            ma, mb = a_eff, b_eff
+        p, _, cy = tw.dsp48(self.series, opmode=format(self._in("opmode", ws), "0%db" % ws), alumode=format(self._in("alumode", 4), "04b"),
+                            use_mult=self.use_mult, a=ma if self.use_mult == "MULTIPLY" else a_eff, b=mb if self.use_mult == "MULTIPLY" else b_eff,
+                            c=c_eff, pcin=self._in("pcin", 48), carryin=self._in("carryin", 1), carryinsel=format(self._in("carryinsel", 3), "03b"),
+                            carrycascin=self._in("carrycascin", 1), use_simd=self.use_simd)
+        na = [a_in, self.a[0]] if self.areg == 2 else [a_in, a_in]
+        nb = [b_in, self.b[0]] if self.breg == 2 else [b_in, b_in]
+        if rst:
+            self.nxt = ([0, 0], [0, 0], 0, None, 0, 0)
+        else:
+            self.nxt = (na, nb, c_in, (a_eff, b_eff), p, cy)
+
+    def commit(self):
+        na, nb, c, m, p, cy = self.nxt
+        if self.areg == 2:
+            self.a = [na[0], na[1]]
+        else:
+            self.a = [na[0], na[0]]
+        if self.breg == 2:
+            self.b = [nb[0], nb[1]]
+        else:
+            self.b = [nb[0], nb[0]]
+        self.c, self.m, self.p, self.cy = c, m, p, cy
+
+    def drive(self):
+        """registered outputs onto the parent's signals; -> changed?"""
+        ch = False
+        for port, v, w in (("p", self.p, 48), ("pcout", self.p, 48), ("carrycascout", self.cy, 1)):
+            a = self.pmap.get(port)
+            if a and a != "open":
+                ch |= self.parent.assign(a, self.env, v)
+        return ch
+
+
+class Node:
+    """One elaborated entity instance."""
+
+    def __init__(self, name, generics, parent=None, pmap=None, penv=None):
+        self.ent = R.entity(name)
+        self.parent, self.pmap, self.penv = parent, pmap or {}, penv or {}
+        self.env = {}
+        for g, dflt in self.ent.generics:
+            self.env[g] = generics.get(g, dflt.strip('"') if dflt.startswith('"') else (int(dflt) if dflt.lstrip("-").isdigit() else
+                                                                                          {"true": True, "false": False}.get(dflt)))
+        self.w = {}         # name -> Wire
+        self.arr = {}       # name -> (hi, lo, [Wire])  arrays of vectors, element index hi downto lo
+        self.mem = {}       # name -> (word width, {index: value})
+        self.types = {}     # array type name -> ("vec", hi_expr, lo_expr, elem_hi, elem_lo) evaluated
+        self.funcs = dict(self.ent.functions)
+        self.comb, self.regs, self.procs, self.kids = [], [], [], []
+        self.consts = set()
+        self._decls(self.ent.decls, self.env)
+        for p, (_, rng) in self.ent.ports.items():
+            if rng is None:
+                self.w[p] = Wire(0, 0)
+            else:
+                hi, lo = rng.split(" downto ")
+                self.w[p] = Wire(R._int(hi, self.env), R._int(lo, self.env))
+        self._region(self.ent.body, dict(self.env))
+
+    # ---- elaboration ---------------------------------------------------------------------------------------------------------------
+    def _decls(self, text, env):
+        for st in R._split_top(text, ";"):
+            if st.startswith("signal "):
+                st = re.sub(r" ?:= ?.*$", "", st)
+            m = re.match(r"constant (\w+) ?: ?(\w+)(?: ?\((.*?) downto (.*?)\))? ?:= ?(.*)$", st)
+            if m:
+                name, init = m.group(1), m.group(5).strip()
+                k = re.match(r"(\w+)(?: ?\((.*)\))?$", init)
+                try:
+                    if k and k.group(1) in self.funcs:
+                        args = [env[a.strip()] if a.strip() in env else R._int(a, env) for a in R._split_top(k.group(2), ",")] if k.group(2) else []
+                        env[name] = R.call_function(self.funcs, k.group(1), args, env)
+                    elif m.group(3):
+                        kk = re.match(r"std_logic_vector ?\( ?conv_unsigned ?\((.*), ?(\d+) ?\) ?\)$", init)
+                        self.w[name] = Wire(R._int(m.group(3), env), R._int(m.group(4), env))
+                        self.w[name].val = R._int(kk.group(1), env) & ((1 << self.w[name].width) - 1)
+                        self.consts.add(name)
+                        continue
+                    else:  # an expression, possibly calling the entity's own functions: addsub_delay(dtw+scale+rndmode)+rndmode
+                        scope = dict(env)
+                        for fn in self.funcs:
+                            scope[fn] = (lambda f: (lambda *a: R.call_function(self.funcs, f, list(a), env)))(fn)
+                        env[name] = int(R._fn_eval(init, scope))
+                    self.env.setdefault(name, env[name])
+                except Exception as exc:
+                    raise AssertionError("constant %s of %s: %r" % (name, self.ent.name, exc))
+                continue
+            m = re.match(r"type (\w+) is array ?\((.*?) (downto|to) (.*?)\) of std_logic_vector ?\((.*) downto (.*)\)$", st)
+            if m:
+                a, b = R._int(m.group(2), env), R._int(m.group(4), env)
+                self.types[m.group(1)] = (max(a, b), min(a, b), R._int(m.group(5), env), R._int(m.group(6), env), m.group(3))
+                continue
+            m = re.match(r"signal ([\w, ]+) ?: ?std_logic(?:_vector ?\((.*) downto (.*)\))?$", st)
+            if m:
+                rng = (R._int(m.group(2), env), R._int(m.group(3), env)) if m.group(2) else (0, 0)
+                for nm in m.group(1).split(","):
+                    self.w[nm.strip()] = Wire(*rng)
+                continue
+            m = re.match(r"signal ([\w, ]+) ?: ?(\w+)$", st)
+            if m and m.group(2) in self.types:
+                hi, lo, eh, el, direction = self.types[m.group(2)]
+                for nm in m.group(1).split(","):
+                    if direction == "to":   # a memory: array (0 to n-1)
+                        self.mem[nm.strip()] = (eh - el + 1, {})
+                    else:
+                        self.arr[nm.strip()] = (hi, lo, [Wire(eh, el) for _ in range(hi - lo + 1)])
+                continue
+            assert not st.strip() or st.startswith(("type ", "variable ")), "unparsed declaration in %s: %r" % (self.ent.name, st[:100])
+
+    def _gen_body(self, inner, env):
+        if re.match(r" ?(signal|constant|type|function) ", inner):
+            inner = R._take_functions(inner, self.funcs)
+            k = re.match(r"(.*?)\bbegin (.*)$", inner)
+            self._decls(k.group(1), env)
+            return k.group(2)
+        return re.sub(r"^ ?begin ", "", inner)
+
+    def _region(self, text, env):
+        for st in R._statements(text):
+            m = re.match(r"(\w+) ?: ?if (.*?) generate (.*) end generate(?: \w+)?$", st)
+            if m:
+                if R._cond(m.group(2), env):
+                    self._region(self._gen_body(m.group(3), env), env)
+                continue
+            m = re.match(r"(\w+) ?: ?for (\w+) in (.*?) to (.*?) generate (.*) end generate(?: \w+)?$", st)
+            if m:
+                for v in range(R._int(m.group(3), env), R._int(m.group(4), env) + 1):
+                    e2 = dict(env, **{m.group(2): v})
+                    self._region(self._gen_body(m.group(5), e2), e2)
+                continue
+            m = re.match(r"(\w+) ?: ?(entity work\.\w+|dsp48e1|dsp48e2) ?(?:generic map ?\((.*?)\) ?)?port map ?\((.*)\)$", st)
+            if m:
+                gmap = {k.strip(): v.strip() for k, v in (x.split("=>", 1) for x in R._split_top(m.group(3), ","))} if m.group(3) else {}
+                pmap = {k.strip(): v.strip() for k, v in (x.split("=>", 1) for x in R._split_top(m.group(4), ","))}
+                unit = m.group(2).replace("entity work.", "")
+                if unit in ("dsp48e1", "dsp48e2"):
+                    self.kids.append(Dsp("E1" if unit.endswith("1") else "E2", gmap, pmap, env, self))
+                else:
+                    g = {}
+                    for k, v in gmap.items():
+                        g[k] = v.strip('"') if v.startswith('"') else (env[v] if (v in env and not isinstance(env[v], int)) else R._int(v, env))
+                    self.kids.append(Node(unit, g, self, pmap, env))
+                continue
+            m = re.match(r"(\w+) ?: ?process ?\(.*?\) ?is begin (.*) end process(?: \w+)?$", st)
+            if m:
+                body = m.group(2).strip()
+                k = re.match(r"if (?:rising_edge ?\( ?clk ?\)|\( ?clk'event and clk ?= ?'1' ?\)) then (.*) end if ?;?$", body)
+                assert k, "a process that is not clocked: %r" % body[:80]
+                self.procs.append((R._parse_seq(k.group(1)), env))
+                continue
+            m = re.match(r"([\w]+(?: ?\(.*?\))*) ?<= ?(.*)$", st)
+            assert m, "unparsed statement in %s: %r" % (self.ent.name, st[:120])
+            rhs = re.sub(r"\s*\bafter [\w.]+( ns\b)?", "", m.group(2))
+            reg = bool(re.search(r"\bwhen rising_edge ?\( ?clk ?\)", rhs))
+            en = re.search(r"\bwhen rising_edge ?\( ?clk ?\) and (.*)$", rhs)
+            rhs = re.sub(r"\s*\bwhen rising_edge ?\( ?clk ?\)( and .*)?$", "", rhs).strip()
+            (self.regs if reg else self.comb).append((m.group(1).strip(), rhs, env, en.group(1).strip() if en else None))
+
+    # ---- references and values -----------------------------------------------------------------------------------------------------
+    def _attr(self, text):
+        def left(m):
+            nm = m.group(1)
+            return str(self.arr[nm][0] if nm in self.arr else self.w[nm].hi)
+        return re.sub(r"(\w+)'left", left, text)
+
+    def ref(self, text, env):
+        """-> ("w", Wire, hi, lo) | ("a", name, hi, lo) for a slice of an array of vectors (whole elements)"""
+        text = self._attr(text.strip())
+        m = re.match(r"(\w+) ?(?:\(([^()]*(?:\([^()]*\)[^()]*)*)\))? ?(?:\(([^()]*(?:\([^()]*\)[^()]*)*)\))?$", text)
+        assert m, "unparsed reference %r" % text
+        name, i1, i2 = m.group(1), m.group(2), m.group(3)
+        if name in self.arr:
+            hi, lo, els = self.arr[name]
+            if i1 is None:
+                return ("a", name, hi, lo)
+            if " downto " in i1:
+                a, b = i1.split(" downto ")
+                return ("a", name, R._int(a, env), R._int(b, env))
+            el = els[R._int(i1, env) - lo]
+            if i2 is None:
+                return ("w", el, el.hi, el.lo)
+            a, b = i2.split(" downto ")
+            return ("w", el, R._int(a, env), R._int(b, env))
+        s = self.w[name]
+        assert i2 is None
+        if i1 is None:
+            return ("w", s, s.hi, s.lo)
+        if " downto " in i1:
+            a, b = i1.split(" downto ")
+            return ("w", s, R._int(a, env), R._int(b, env))
+        i = R._int(i1, env)
+        return ("w", s, i, i)
+
+    def value(self, text, env, want_w=None):
+        text = self._attr(text.strip())
+        parts = R._split_top(text, "&")
+        if len(parts) > 1:
+            v = w = 0
+            for part in parts:
+                pv, pw = self.value(part, env)
+                v, w = (v << pw) | pv, w + pw
+            return v, w
+        parts = R._split_kw(text, " and ")
+        if len(parts) > 1:
+            v, w = self.value(parts[0], env, want_w)
+            for x in parts[1:]:
+                v &= self.value(x, env, want_w)[0]
+            return v, w
+        parts = R._split_top(text, "*")
+        if len(parts) == 2 and all(x.startswith("unsigned") for x in parts):
+            (a, wa), (b, wb) = (self.value(re.match(r"unsigned ?\((.*)\)$", x).group(1), env) for x in parts)
+            return a * b, wa + wb
+        m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?(?:unsigned ?\()?(\w+)\)? ?\) ?\)$", text)
+        if m and isinstance(env.get(m.group(1)), dict):
+            return env[m.group(1)][self.value(m.group(2), env)[0]], want_w
+        if m and m.group(1) in self.mem:
+            w, mem = self.mem[m.group(1)]
+            return mem.get(self.value(m.group(2), env)[0], 0), w
+        if text.startswith('x"'):
+            return int(text[2:-1], 16), 4 * (len(text) - 3)
+        parts = R._split_top(text, "+")
+        if len(parts) == 2:
+            v, w = self.value(parts[0], env, want_w)
+            return (v + int(parts[1].strip("'"))) & ((1 << w) - 1), w
+        m = re.match(r"not ?\(([^()]*(?:\([^()]*\)[^()]*)*)\)$", text) or re.match(r"not (.+)$", text)
+        if m:
+            v, w = self.value(m.group(1), env, want_w)
+            return (~v) & ((1 << w) - 1), w
+        m = re.match(r"\( ?others ?=> ?(.*)\)$", text)
+        if m:
+            inner = m.group(1).strip()
+            if inner.startswith("("):  # (others => (others => '0')): a whole array
+                return 0, want_w
+            bit = int(inner.strip("'")) if inner.startswith("'") else self.value(inner, env)[0]
+            return ((1 << want_w) - 1 if bit else 0), want_w
+        m = re.match(r"\((.*others.*)\)$", text)
+        if m:
+            v = 0
+            for it in R._split_top(m.group(1), ","):
+                k, b = [x.strip() for x in it.split("=>")]
+                if k != "others" and b == "'1'":
+                    v |= 1 << int(k)
+            return v, want_w
+        m = re.match(r"sxt ?\((.*), ?([^,]+)\)$", text)
+        if m:
+            v, w = self.value(m.group(1), env)
+            n = R._int(m.group(2), env)
+            return tw.sxt(v, w, n), n
+        if text.startswith('"'):
+            return int(text.strip('"'), 2), len(text) - 2
+        if text.startswith("'"):
+            return int(text.strip("'")), 1
+        r = self.ref(text, env)
+        assert r[0] == "w", "an array where a vector is expected: %r" % text
+        return r[1].get(r[2], r[3]), r[2] - r[3] + 1
+
+    def array_value(self, text, env):
+        """RHS of an assignment to an array of vectors: slice & element & ... -> list of element values, highest index first"""
+        out = []
+        for part in R._split_top(self._attr(text), "&"):
+            r = self.ref(part, env) if re.match(r"\w+", part.strip()) and part.strip().split("(")[0].strip() in self.arr else None
+            if r and r[0] == "a":
+                hi0, lo0, els = self.arr[r[1]]
+                out += [els[i - lo0].val for i in range(r[2], r[3] - 1, -1)]
+            else:
+                out.append(self.value(part, env)[0])
+        return out
+
+    def assign(self, lhs, env, v):
+        r = self.ref(lhs, env)
+        assert r[0] == "w"
+        return r[1].set(r[2], r[3], v)
+
+    def cond(self, c, env):
+        c = c.strip()
+        while c.startswith("(") and c.endswith(")") and R._balanced(c[1:-1]):
+            c = c[1:-1].strip()
+        for op_, fn in ((" or ", any), (" and ", all)):
+            parts = R._split_kw(c, op_)
+            if len(parts) > 1:
+                return fn(self.cond(x, env) for x in parts)
+        m = re.match(r"(.*?) ?= ?'([01])'$", c)
+        assert m, "unparsed condition %r" % c
+        return self.value(m.group(1), env)[0] == int(m.group(2))
+
+    # ---- simulation ----------------------------------------------------------------------------------------------------------------
+    def settle_once(self):
+        ch = False
+        for lhs, rhs, env, _ in self.comb:
+            r = self.ref(lhs, env)
+            if r[0] == "a":
+                hi0, lo0, els = self.arr[r[1]]
+                vals = self.array_value(rhs, env)
+                for i, v in zip(range(r[2], r[3] - 1, -1), vals):
+                    ch |= els[i - lo0].set(els[i - lo0].hi, els[i - lo0].lo, v)
+            else:
+                ch |= r[1].set(r[2], r[3], self.value(rhs, env, r[2] - r[3] + 1)[0])
+        for k in self.kids:
+            if isinstance(k, Dsp):
+                ch |= k.drive()
+                continue
+            for port, (d, _) in k.ent.ports.items():  # parent -> child inputs
+                if d == "in" and port in k.pmap:
+                    pw = k.w[port]
+                    ch |= pw.set(pw.hi, pw.lo, self.value(k.pmap[port], k.penv, pw.width)[0])
+            ch |= k.settle_once()
+            for port, (d, _) in k.ent.ports.items():  # child outputs -> parent
+                if d == "out" and port in k.pmap and k.pmap[port] != "open":
+                    ch |= self.assign(k.pmap[port], k.penv, k.w[port].val)
+        return ch
+
+    def settle(self):
+        for _ in range(64):
+            if not self.settle_once():
+                return
+        raise AssertionError("combinational logic does not settle")
+
+    def _seq(self, seq, env, acts, writes):
+        for node in seq:
+            if node[0] == "assign":
+                m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?(\w+) ?\) ?\)$", node[1])
+                if m and m.group(1) in self.mem:
+                    writes.append((self.mem[m.group(1)][1], self.value(m.group(2), env)[0], self.value(node[2], env, self.mem[m.group(1)][0])[0]))
+                    continue
+                r = self.ref(node[1], env)
+                if r[0] == "a":
+                    hi0, lo0, els = self.arr[r[1]]
+                    for i, v in zip(range(r[2], r[3] - 1, -1), self.array_value(node[2], env)):
+                        acts.append((els[i - lo0], els[i - lo0].hi, els[i - lo0].lo, v))
+                else:
+                    acts.append((r[1], r[2], r[3], self.value(node[2], env, r[2] - r[3] + 1)[0]))
+            else:
+                for c, body in node[1]:
+                    if self.cond(c, env):
+                        self._seq(body, env, acts, writes)
+                        break
+                else:
+                    self._seq(node[2], env, acts, writes)
+
+    def compute(self, acts, writes):
+        for lhs, rhs, env, en in self.regs:
+            if en is not None and not self.cond(en, env):
+                continue
+            r = self.ref(lhs, env)
+            if r[0] == "a":
+                hi0, lo0, els = self.arr[r[1]]
+                for i, v in zip(range(r[2], r[3] - 1, -1), self.array_value(rhs, env)):
+                    acts.append((els[i - lo0], els[i - lo0].hi, els[i - lo0].lo, v))
+            else:
+                acts.append((r[1], r[2], r[3], self.value(rhs, env, r[2] - r[3] + 1)[0]))
+        for ast, env in self.procs:
+            self._seq(ast, env, acts, writes)
+        for k in self.kids:
+            if isinstance(k, Dsp):
+                k.compute()
+            else:
+                k.compute(acts, writes)
+
+    def commit_dsps(self):
+        for k in self.kids:
+            if isinstance(k, Dsp):
+                k.commit()
+            else:
+                k.commit_dsps()
+
+    def clock(self, inputs):
+        for k, v in inputs.items():
+            s = self.w[k]
+            s.set(s.hi, s.lo, v)
+        self.settle()
+        acts, writes = [], []
+        self.compute(acts, writes)
+        for s, hi, lo, v in acts:
+            s.set(hi, lo, v)
+        for mem, idx, v in writes:
+            mem[idx] = v
+        self.commit_dsps()
+        self.settle()
+        return {p: self.w[p].val for p, (d, _) in self.ent.ports.items() if d == "out"}
+
+
+def run_core(direction, nfft, dw, tw_, fmt, rnd, xser, frames, ramb="wrap", use_fly=1, gap=0):
+    """frames: list of frames, each a list of N (re, im) -- natural order for FWD (lane 0 = x[i], lane 1 = x[i + N/2]), the bit-reversed pair
+    stream for INV (lane 0 = v[2i], lane 1 = v[2i + 1]).  -> list of output beats ((re0, im0), (re1, im1)) that came with DO_VAL = '1'"""
+    top = Node("int_fftnk" if direction == "FWD" else "int_ifftnk",
+               {"nfft": nfft, "ramb_type": ramb, "format": fmt, "rndmode": rnd, "data_width": dw, "twdl_width": tw_, "xser": xser.lower(), "use_mlt": False})
+    n = 1 << nfft
+    ow = dw + fmt * nfft
+    idle = {"rst": 0, "use_fly": use_fly, "di_ena": 0, "di_re0": 0, "di_im0": 0, "di_re1": 0, "di_im1": 0}
+    for _ in range(4):
+        top.clock(dict(idle, rst=1))
+    for _ in range(4):
+        top.clock(idle)
+    beats = []
+
+    def tick(inp):
+        o = top.clock(inp)
+        if o["do_val"]:
+            beats.append(((tw.signed(o["do_re0"], ow), tw.signed(o["do_im0"], ow)), (tw.signed(o["do_re1"], ow), tw.signed(o["do_im1"], ow))))
+
+    for fr in frames:
+        for i in range(n // 2):
+            a, b = (fr[i], fr[i + n // 2]) if direction == "FWD" else (fr[2 * i], fr[2 * i + 1])
+            tick(dict(idle, di_ena=1, di_re0=tw.vec(a[0], dw), di_im0=tw.vec(a[1], dw), di_re1=tw.vec(b[0], dw), di_im1=tw.vec(b[1], dw)))
+        for _ in range(gap):
+            tick(idle)
+    for _ in range(40 * nfft + 4 * n):
+        tick(idle)
+    return beats, top
+
+
+def expected(direction, nfft, dw, tw_, fmt, rnd, xser, frames, use_fly=1):
+    from oracle import oracle_py as op
+    out = []
+    for fr in frames:
+        if direction == "FWD":
+            v = op.fft_dif(fr, nfft, dw, tw_, fmt, rnd, xser == "NEW", use_fly)
+            out += [(v[2 * i], v[2 * i + 1]) for i in range(len(v) // 2)]
+        else:
+            y = op.ifft_dit(fr, nfft, dw, tw_, fmt, rnd, xser == "NEW", use_fly)
+            h = len(y) // 2
+            out += [(y[i], y[i + h]) for i in range(h)]
+    ow = dw + fmt * nfft
+    return [((op.sgn(a[0], ow), op.sgn(a[1], ow)), (op.sgn(b[0], ow), op.sgn(b[1], ow))) for a, b in out]
+
+
+def main():
+    import random
+    if not available():
+        print("reference not present: nothing to do")
+        return 0
+    nfft = int(sys.argv[sys.argv.index("--nfft") + 1]) if "--nfft" in sys.argv else 4
+    nfr = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 3
+    rng = random.Random(7)
+    bad = 0
+    for direction in ("FWD", "INV"):
+        for (dw, t, fmt, rnd, xser) in ((16, 16, 0, 0, "NEW"), (16, 16, 0, 1, "NEW"), (16, 16, 1, 0, "NEW"), (16, 16, 0, 0, "OLD")):
+            frames = [[(rng.randint(-(1 << (dw - 1)), (1 << (dw - 1)) - 1), rng.randint(-(1 << (dw - 1)), (1 << (dw - 1)) - 1)) for _ in range(1 << nfft)]
+                      for _ in range(nfr)]
+            got, _ = run_core(direction, nfft, dw, t, fmt, rnd, xser, frames)
+            want = expected(direction, nfft, dw, t, fmt, rnd, xser, frames)
+            ok = got[:len(want)] == want[:len(got)] and len(got) >= len(want) - (1 << (nfft - 1))
+            print(direction, "NFFT", nfft, "DW", dw, "TW", t, "FORMAT", fmt, "RNDMODE", rnd, xser, ":", len(got), "beats out,", "equal" if ok else "DIFFERENT", flush=True)
+            bad += not ok
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
