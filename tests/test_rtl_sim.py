@@ -1,0 +1,76 @@
+"""The reference's whole core, clocked from its own text (tools/rtl_sim.py), against the oracle -- this container only.
+
+tools/rtl_interp.py pins the arithmetic entities one by one; this goes end to end: int_fftNk / int_ifftNk (int_fftNk.vhd / int_ifftNk.vhd)
+are elaborated down to the DSP48 primitives with the pipeline registers their generic maps ask for, fed frames beat by beat, and the
+DO_VAL-qualified output beats must be the oracle's frames.  What that adds to the per-entity checks: the latencies (aligners, valid
+strobes, twiddle counters, delay lines against the butterflies' pipeline depth) line up in the text exactly where the oracle assumes they
+do.  Small frames only (a simulated clock costs milliseconds); tools/rtl_sim.py --sweep is the longer list (profiles/r06_rtl_sim.txt).
+Skipped where /root/reference is absent (the GPU box)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import rtl_sim as S  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not S.available(), reason="the reference's text is not on this machine")
+
+
+@pytest.mark.parametrize("direction", ["FWD", "INV"])
+@pytest.mark.parametrize("mode", [(0, 0), (0, 1), (1, 0)], ids=["truncate", "round", "unscaled"])
+def test_eight_point_core_every_mode(direction, mode):
+    fmt, rnd = mode
+    ok, got, want = S.compare(direction, 3, 16, 16, fmt, rnd, "NEW", "cont")
+    assert ok and got == want == 12, (got, want)
+
+
+def test_old_series_and_wrapped_delay_lines():
+    # RAMB_TYPE = "WRAP": the lines move only while beats come in, the tail of the last frame stays inside -- the prefix must be right
+    ok, got, want = S.compare("FWD", 3, 16, 16, 0, 1, "OLD", "wrap")
+    assert ok and want - 4 <= got <= want, (got, want)
+    ok, got, want = S.compare("INV", 3, 16, 16, 1, 0, "OLD", "wrap")
+    assert ok and want - 4 <= got <= want, (got, want)
+
+
+def test_sixteen_points_crosses_a_delay_line_of_two_beats():
+    ok, got, want = S.compare("INV", 4, 16, 16, 0, 1, "NEW", "cont", count=2)
+    assert ok and got == want == 16, (got, want)
+
+
+def test_idle_clocks_between_frames_and_the_bypass_mux():
+    assert S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", gap=5, count=2)[0]
+    # USE_FLY = 0 (int_fftNk.vhd:260-277): the oracle's reading -- the butterflies drop out, the commutation stays
+    assert S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", use_fly=0, count=2)[0]
+    assert S.compare("INV", 3, 16, 16, 1, 0, "NEW", "cont", use_fly=0, count=2)[0]
+
+
+@pytest.mark.parametrize("cfg", [("FWD", 24, 24, 1, 0, "NEW"), ("FWD", 30, 16, 1, 0, "OLD"), ("INV", 52, 16, 1, 0, "OLD")],
+                         ids=lambda c: "%s_w%d_t%d" % c[:3])
+def test_wide_regimes_through_the_whole_core(cfg):
+    # dbl18 / dbl35 / trpl18 multipliers and the two-slice adder (DSPW >= 48) inside the pipeline, latencies included
+    d, dw, tw_, fmt, rnd, xser = cfg
+    assert S.compare(d, 3, dw, tw_, fmt, rnd, xser, "cont", count=2)[0]
+
+
+def test_the_simulation_notices_a_wrong_oracle(monkeypatch):
+    from oracle import oracle_py as op
+    real = op.fft_dif
+
+    def off_by_one(fr, *a):
+        v = list(real(fr, *a))
+        v[5] = (v[5][0] + 1, v[5][1])
+        return v
+    monkeypatch.setattr(op, "fft_dif", off_by_one)
+    assert not S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", count=2)[0]
+
+
+def test_the_strobe_corner_of_the_reference():
+    """A defect of the reference this simulation found (profiles/HISTORY.md): the butterflies take their valid-strobe
+    delay from addsub_delay(DTW + SCALE + RNDMODE) but build the adder for DSPW = DTW - 1 (scaled truncate) / DTW (scaled round, unscaled)
+    bits; at scaled DTW = 46 (round), 47, 48 (truncate) the two fall on different sides of the 48-bit slice boundary and the strobe leaves
+    one clock off.  The text's frames are
+    wrong there; one bit to either side they are the oracle's.  Outside the documented DATA_WIDTH range; the engine follows the arithmetic."""
+    assert not S.compare("FWD", 3, 47, 16, 0, 0, "NEW", "cont", count=2)[0]
+    assert S.compare("FWD", 3, 49, 16, 0, 0, "NEW", "cont", count=2)[0]
+    assert S.compare("FWD", 3, 47, 16, 1, 0, "NEW", "cont", count=2)[0]   # unscaled: the argument and DSPW are both DTW

@@ -31,7 +31,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from oracle import dsp48_twin as tw  # noqa: E402
 
 REF = os.environ.get("INTFFT_REFERENCE", "/root/reference")
-DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft", "src/vhdl/twiddle", "src/vhdl/delay"]
+DIRS = ["src/vhdl/math/mults", "src/vhdl/math/cmult", "src/vhdl/math", "src/vhdl/fft", "src/vhdl/twiddle", "src/vhdl/delay", "src/vhdl/buffers",
+        "src/vhdl/main"]
 
 
 def available() -> bool:
@@ -307,7 +308,7 @@ def _parse_seq(text: str):
             elif t == ";":
                 pos += 1
             else:
-                m = re.match(r"([\w]+(?: ?\(.*?\))?) ?<= ?(.*)$", t)
+                m = re.match(r"([\w]+(?: ?\(.*?\))?) ?(?:<|:)= ?(.*)$", t)  # `:=`: a shared variable used as a memory (buffers/)
                 assert m, "unparsed sequential statement: %r" % t[:100]
                 out.append(("assign", m.group(1).strip(), re.sub(r"\s*\bafter [\w.]+( ns\b)?", "", m.group(2)).strip()))
                 pos += 1
