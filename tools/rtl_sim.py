@@ -14,6 +14,9 @@ the DSP48 primitives -- as a hierarchy of clocked nodes and runs it cycle by cyc
     (AREG / BREG 0, 1, 2; CREG; MREG; PREG; PCIN = the neighbour's registered P; CARRYCASCIN = its registered carry): the latencies that the
     aligners, the valid strobes and the twiddle counters are built around come from the text's own generics (UG479 / UG579 for what a
     register stage is).
+  * the wrappers of src/vhdl/main run the same way with their I/O buffers (inbuf_half_path, outbuf_half_path, int_bitrev_order,
+    iobuf_flow_int2): memories behind shared variables, integer signals, and the buffers' own functions (bit_pair; str_array / hi_bits, which
+    build the address-increment tables) executed from the text (class VecFn).
 The DO_VAL-qualified output beats are compared with oracle_py on the same frames.  If the pipeline of the text did not line up with its own
 strobes, or the oracle misread any of it, the frames would differ.
 
@@ -136,6 +139,97 @@ class Dsp:
         return ch
 
 
+class VecFn:
+    """The functions of buffers/iobuf_flow_int2.vhd (str_array, hi_bits) work on std_logic_vector variables and return arrays: executed from
+    the text on a small value model -- integers / booleans as Python values, a vector variable as [value, width], an array as {index: value}."""
+
+    def __init__(self, entity_name):
+        self.fns = {}
+        for m in R.FUNC.finditer(R._load(entity_name)):
+            params = [nm.strip() for x in m.group(2).split(";") for nm in x.split(":")[0].split(",")] if m.group(2) else []
+            self.fns[m.group(1)] = (params, m.group(3), R._parse_fn(m.group(4)))
+
+    def call(self, name, args, env):
+        params, decls, ast = self.fns[name]
+        scope = dict(env, true=True, false=False)
+        scope.update(zip(params, args))
+        width = {}   # vector variables: name -> width
+        for st in R._split_top(decls, ";"):
+            m = re.match(r"variable (\w+) ?: ?std_logic_vector ?\((.*) downto (.*)\)", st)
+            if m:
+                width[m.group(1)] = R._int(m.group(2), scope) - R._int(m.group(3), scope) + 1
+                scope[m.group(1)] = 0
+            else:
+                m = re.match(r"variable (\w+) ?: ?\w+", st)
+                if m:
+                    scope[m.group(1)] = {}
+
+        def attr(t):
+            return re.sub(r"(\w+)'left", lambda k: str(width[k.group(1)] - 1), t)
+
+        def val(t):
+            t = attr(t.strip())
+            m = re.match(r"\((.*others.*)\)$", t)
+            if m:   # (k => '1', others => '0')
+                v = 0
+                for it in R._split_top(m.group(1), ","):
+                    k, b = [x.strip() for x in it.split("=>")]
+                    if k != "others" and b == "'1'":
+                        v |= 1 << R._int(k, scope)
+                return v
+            m = re.match(r"(\w+) ?\((.*?)\) ?\((.*) downto (.*)\)$", t)
+            if m and isinstance(scope.get(m.group(1)), dict):   # arr(j)(hi downto lo)
+                hi, lo = R._int(m.group(3), scope), R._int(m.group(4), scope)
+                return (scope[m.group(1)][R._int(m.group(2), scope)] >> lo) & ((1 << (hi - lo + 1)) - 1)
+            m = re.match(r"(\w+) ?\((.*?)\) ?\(([^()]*)\)$", t)
+            if m and isinstance(scope.get(m.group(1)), dict):   # arr(j)(bit)
+                return (scope[m.group(1)][R._int(m.group(2), scope)] >> R._int(m.group(3), scope)) & 1
+            if t in scope:
+                return scope[t]
+            return R._int(t, scope)
+
+        def run(seq):
+            for node in seq:
+                if node[0] == "set":
+                    tgt, v = attr(node[1]), val(node[2])
+                    m = re.match(r"(\w+) ?\((.*) downto (.*)\)$", tgt)
+                    if m:
+                        hi, lo = R._int(m.group(2), scope), R._int(m.group(3), scope)
+                        mask = ((1 << (hi - lo + 1)) - 1) << lo
+                        scope[m.group(1)] = (scope[m.group(1)] & ~mask) | ((v << lo) & mask)
+                        continue
+                    m = re.match(r"(\w+) ?\((.*)\)$", tgt)
+                    if m and m.group(1) in width:      # one bit of a vector
+                        i = R._int(m.group(2), scope)
+                        scope[m.group(1)] = (scope[m.group(1)] & ~(1 << i)) | ((v & 1) << i)
+                    elif m:                            # one element of an array
+                        scope[m.group(1)][R._int(m.group(2), scope)] = v
+                    else:
+                        scope[tgt] = v
+                elif node[0] == "if":
+                    for c, body in node[1]:
+                        if R._cond(c, scope):
+                            r = run(body)
+                            if r is not None:
+                                return r
+                            break
+                    else:
+                        r = run(node[2])
+                        if r is not None:
+                            return r
+                elif node[0] == "for":
+                    for v in range(R._int(node[2], scope), R._int(node[3], scope) + 1):
+                        scope[node[1]] = v
+                        r = run(node[4])
+                        if r is not None:
+                            return r
+                else:
+                    return ("ret", val(node[1]))
+            return None
+
+        return run(ast)[1]
+
+
 class Node:
     """One elaborated entity instance."""
 
@@ -153,6 +247,8 @@ class Node:
         self.funcs = dict(self.ent.functions)
         self.comb, self.regs, self.procs, self.kids = [], [], [], []
         self.consts = set()
+        self.ints = set()   # integer signals (iobuf_flow_int2's in_cnt, wr_rng)
+        self.vecfn = None
         self._decls(self.ent.decls, self.env)
         for p, (_, rng) in self.ent.ports.items():
             if rng is None:
@@ -171,11 +267,32 @@ class Node:
             if m:   # inbuf_half_path: a memory written with `:=` from one process (read before the write in the text: read-first)
                 self.mem[m.group(1)] = (self.types[m.group(2)][2] - self.types[m.group(2)][3] + 1, {})
                 continue
+            m = re.match(r"shared variable (\w+) ?: ?(\w+) ?\((.*) downto (.*)\)$", st)
+            if m:   # iobuf_flow_int2: an unconstrained array type, constrained at the variable
+                self.mem[m.group(1)] = (self.types[m.group(2)][2] - self.types[m.group(2)][3] + 1, {})
+                continue
+            m = re.match(r"signal ([\w, ]+) ?: ?integer range .*$", st)
+            if m:
+                for nm in m.group(1).split(","):
+                    self.w[nm.strip()] = Wire(31, 0)
+                    self.ints.add(nm.strip())
+                continue
+            m = re.match(r"type (\w+) is array ?\(.*\) of integer$", st)
+            if m:
+                continue
             m = re.match(r"constant (\w+) ?: ?(\w+)(?: ?\((.*?) downto (.*?)\))? ?:= ?(.*)$", st)
             if m:
                 name, init = m.group(1), m.group(5).strip()
                 k = re.match(r"(\w+)(?: ?\((.*)\))?$", init)
                 try:
+                    if k and k.group(1) in self.funcs and self.vecfn is None:
+                        self.vecfn = VecFn(self.ent.name)
+                    if k and k.group(1) in self.funcs and "std_logic_vector" in self.vecfn.fns[k.group(1)][1]:
+                        args = [env[a.strip()] if a.strip() in env else {"true": True, "false": False}[a.strip()] if a.strip() in ("true", "false")
+                                else R._int(a, env) for a in R._split_top(k.group(2), ",")]
+                        env[name] = self.vecfn.call(k.group(1), args, env)   # an array constant: {index: value}
+                        self.env.setdefault(name, env[name])
+                        continue
                     if k and k.group(1) in self.funcs:
                         args = [env[a.strip()] if a.strip() in env else R._int(a, env) for a in R._split_top(k.group(2), ",")] if k.group(2) else []
                         env[name] = R.call_function(self.funcs, k.group(1), args, env)
@@ -193,6 +310,10 @@ class Node:
                     self.env.setdefault(name, env[name])
                 except Exception as exc:
                     raise AssertionError("constant %s of %s: %r" % (name, self.ent.name, exc))
+                continue
+            m = re.match(r"type (\w+) is array ?\( ?integer range <> ?\) of std_logic_vector ?\((.*) downto (.*)\)$", st)
+            if m:
+                self.types[m.group(1)] = (0, 0, R._int(m.group(2), env), R._int(m.group(3), env), "to")
                 continue
             m = re.match(r"type (\w+) is array ?\((.*?) (downto|to) (.*?)\) of std_logic_vector ?\((.*) downto (.*)\)$", st)
             if m:
@@ -340,9 +461,20 @@ class Node:
             bits = R.call_function(self.funcs, m.group(1), args, env)
             return sum(int(b) << i for i, b in bits.items()), (max(bits) + 1 if want_w is None else want_w)
         parts = R._split_top(text, "+")
-        if len(parts) == 2:
+        if len(parts) >= 2:   # cnt + '1', cnt_even + wr_inz + 1, in_cnt + 1
             v, w = self.value(parts[0], env, want_w)
-            return (v + int(parts[1].strip("'"))) & ((1 << w) - 1), w
+            for x in parts[1:]:
+                x = x.strip()
+                v += int(x.strip("'")) if re.match(r"'?\d+'?$", x) else self.value(x, env, w)[0]
+            return v & ((1 << w) - 1), w
+        m = re.match(r"(\w+) ?\( ?(\w+) ?\)$", text)
+        if m and isinstance(env.get(m.group(1)), dict):   # a constant array: std_inc(0), inc_bit(in_cnt)
+            i = self.w[m.group(2)].val if m.group(2) in self.ints else R._int(m.group(2), env)
+            return env[m.group(1)][i], want_w
+        if m and m.group(1) in self.w and m.group(2) in self.ints:   # sw_ptr(wr_rng)
+            return (self.w[m.group(1)].val >> self.w[m.group(2)].val) & 1, 1
+        if re.match(r"\d+$", text):
+            return int(text), want_w
         m = re.match(r"not ?\(([^()]*(?:\([^()]*\)[^()]*)*)\)$", text) or re.match(r"not (.+)$", text)
         if m:
             v, w = self.value(m.group(1), env, want_w)
@@ -401,8 +533,11 @@ class Node:
             if len(parts) > 1:
                 return fn(self.cond(x, env) for x in parts)
         m = re.match(r"(.*?) ?= ?'([01])'$", c)
-        assert m, "unparsed condition %r" % c
-        return self.value(m.group(1), env)[0] == int(m.group(2))
+        if m:
+            return self.value(m.group(1), env)[0] == int(m.group(2))
+        m = re.match(r"(\w+) ?= ?(.+)$", c)
+        assert m and m.group(1) in self.ints, "unparsed condition %r" % c
+        return self.w[m.group(1)].val == R._int(m.group(2), env)
 
     # ---- simulation ----------------------------------------------------------------------------------------------------------------
     def settle_once(self):
@@ -530,6 +665,93 @@ def run_core(direction, nfft, dw, tw_, fmt, rnd, xser, frames, ramb="wrap", use_
     return beats, top
 
 
+def _reset(top, idle, rst):
+    for _ in range(4):
+        top.clock(dict(idle, **{rst: 1}))
+    for _ in range(4):
+        top.clock(idle)
+
+
+def run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames, fly=1):
+    """int_fft_single_path (main/int_fft_single_path.vhd) from the text: one sample per clock in natural order through inbuf_half_path ->
+    int_fftNk (CONT) -> outbuf_half_path -> two int_bitrev_order.  -> the DO_VL-qualified samples [(re, im)], natural order, frame after frame
+    (the bit-reverse buffer hands a frame out while the next one comes in: the last frame stays inside)."""
+    top = Node("int_fft_single_path", {"nfft": nfft, "data_width": dw, "twdl_width": tw_, "format": fmt, "rndmode": rnd, "xseries": xser.lower(),
+                                       "use_mlt": False})
+    ow = dw + fmt * nfft
+    idle = {"reset": 0, "fly_fwd": fly, "di_en": 0, "di_re": 0, "di_im": 0}
+    _reset(top, idle, "reset")
+    out = []
+
+    def tick(inp):
+        o = top.clock(inp)
+        if o["do_vl"]:
+            out.append((tw.signed(o["do_re"], ow), tw.signed(o["do_im"], ow)))
+
+    for fr in frames:
+        for a, b in fr:
+            tick(dict(idle, di_en=1, di_re=tw.vec(a, dw), di_im=tw.vec(b, dw)))
+    for _ in range(40 * nfft + (6 << nfft)):
+        tick(idle)
+    return out, top
+
+
+def run_pair(nfft, dw, tw_, fmt, rnd, xser, frames, ramb="cont"):
+    """int_fft_ifft_pair (main/int_fft_ifft_pair.vhd) from the text: two samples per clock, lane 0 = x[2i], lane 1 = x[2i + 1], through
+    iobuf_flow_int2 -> int_fftNk -> int_ifftNk -> iobuf_flow_int2 (BITREV).  -> beats ((re0, im0), (re1, im1)) read from the wrapper's own
+    dt_rev0 / dt_rev1 (its output ports duplicate slices: Q0_IM = Q0_RE, Q1_RE = Q1_IM, SURVEY 9.9 -- asserted here), and the node."""
+    top = Node("int_fft_ifft_pair", {"nfft": nfft, "ramb_type": ramb, "data_width": dw, "twdl_width": tw_, "format": fmt, "rndmode": rnd,
+                                     "xseries": xser.lower(), "use_mlt": False})
+    ow = dw + fmt * 2 * nfft
+    idle = {"reset": 0, "fly_fwd": 1, "fly_inv": 1, "di_en": 0, "d0_re": 0, "d0_im": 0, "d1_re": 0, "d1_im": 0}
+    _reset(top, idle, "reset")
+    out = []
+    mask = (1 << ow) - 1
+
+    def tick(inp):
+        o = top.clock(inp)
+        if o["qo_vl"]:
+            r0, r1 = top.w["dt_rev0"].val, top.w["dt_rev1"].val
+            assert o["q0_re"] == o["q0_im"] == r0 & mask and o["q1_re"] == o["q1_im"] == r1 >> ow, "the wrapper's ports are not the duplicated slices"
+            out.append(((tw.signed(r0 & mask, ow), tw.signed(r0 >> ow, ow)), (tw.signed(r1 & mask, ow), tw.signed(r1 >> ow, ow))))
+
+    n = 1 << nfft
+    for fr in frames:
+        for i in range(n // 2):
+            a, b = fr[2 * i], fr[2 * i + 1]
+            tick(dict(idle, di_en=1, d0_re=tw.vec(a[0], dw), d0_im=tw.vec(a[1], dw), d1_re=tw.vec(b[0], dw), d1_im=tw.vec(b[1], dw)))
+    for _ in range(80 * nfft + 8 * n):
+        tick(idle)
+    return out, top
+
+
+def expected_natural(direction, nfft, dw, tw_, fmt, rnd, xser, frames):
+    """oracle_py, natural order in and out, frame after frame: [(re, im)]"""
+    from oracle import oracle_py as op
+    ow = dw + fmt * nfft * (2 if direction == "PAIR" else 1)
+    out = []
+    for fr in frames:
+        y = op.execute(fr, nfft, dw, tw_, fmt, rnd, xser == "NEW", {"FWD": op.FWD, "INV": op.INV, "PAIR": op.PAIR}[direction])
+        out += [(op.sgn(a, ow), op.sgn(b, ow)) for a, b in y]
+    return out
+
+
+def compare_wrapper(which, nfft, dw, tw_, fmt, rnd, xser, count=4, seed=5):
+    """-> (equal?, whole frames out, frames in).  The buffers hand a frame out while later ones come in: at least one whole frame must
+    come out and every sample that does must be the oracle's."""
+    import random
+    frames = _frames(random.Random(seed), nfft, dw, count)
+    if which == "single":
+        got, _ = run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames)
+        want = expected_natural("FWD", nfft, dw, tw_, fmt, rnd, xser, frames)
+    else:
+        beats, _ = run_pair(nfft, dw, tw_, fmt, rnd, xser, frames)
+        got = [s for b in beats for s in b]
+        want = expected_natural("PAIR", nfft, dw, tw_, fmt, rnd, xser, frames)
+    whole = len(got) >> nfft
+    return (whole >= 1 and len(got) <= len(want) and got == want[:len(got)]), whole, count
+
+
 def expected(direction, nfft, dw, tw_, fmt, rnd, xser, frames, use_fly=1):
     from oracle import oracle_py as op
     out = []
@@ -588,6 +810,12 @@ STROBE_CORNER = (("FWD", 45, 1, 0, "NEW", True), ("FWD", 46, 0, 0, "NEW", True),
                  ("FWD", 49, 0, 0, "NEW", True), ("FWD", 47, 0, 1, "NEW", True), ("FWD", 48, 0, 1, "NEW", True))
 
 
+WRAPPERS = ([("single", n, 16, 16, f, r, x) for n in (3, 4) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "OLD"), (1, 0, "NEW"))]
+            + [("single", 5, 16, 16, 0, 0, "NEW"), ("single", 3, 24, 24, 1, 0, "OLD"), ("single", 6, 16, 16, 0, 0, "NEW")]
+            + [("pair", n, 16, 16, f, r, x) for n in (3, 4) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "NEW"), (1, 0, "OLD"))]
+            + [("pair", 5, 16, 16, 0, 0, "NEW")])
+
+
 def sweep():
     import time
     print("# tools/rtl_sim.py --sweep: int_fftNk / int_ifftNk elaborated from the reference's own VHDL text, clocked beat by beat, against oracle_py")
@@ -604,7 +832,15 @@ def sweep():
         print("%s NFFT  3 DW %2d TW 16 FORMAT %d RNDMODE %d %s: %s (predicted from the text: %s)"
               % (d, dw, f, r, x, "equal" if ok else "DIFFERENT", "equal" if agree else "DIFFERENT"), flush=True)
         bad += ok != agree
-    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(STROBE_CORNER), bad))
+    print("# the wrappers of src/vhdl/main from the text, I/O buffers included, natural order in and out (memory order of the C-ABI's NATURAL)")
+    for (which, n, dw, t, f, r, x) in WRAPPERS:
+        t0 = time.time()
+        ok, whole, count = compare_wrapper(which, n, dw, t, f, r, x)
+        print("%s NFFT %2d DW %2d TW %2d FORMAT %d RNDMODE %d %s: %d of %d frames out, %s  (%.0f s)"
+              % ({"single": "int_fft_single_path", "pair": "int_fft_ifft_pair  "}[which], n, dw, t, f, r, x, whole, count,
+                 "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
+        bad += not ok
+    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(STROBE_CORNER) + len(WRAPPERS), bad))
     return 1 if bad else 0
 
 
