@@ -85,6 +85,17 @@ def test_compare_script_pass_and_fail(tmp_path):
     assert subprocess.run([sys.executable, cmp_py, "pair_n7", "UNSCALED", str(dump)]).returncode == 0
     assert subprocess.run([sys.executable, cmp_py, "pair_n7", "UNSCALED", str(dump), "--no-reference-wiring"],
                           capture_output=True).returncode == 1
+    # the strobe corner (tools/rtl_sim.py): a case that is PREDICTED TO DIFFER passes on a differing dump and fails on the engine's own
+    exp = os.path.join(EXP, "hex_n7_w47t16_strobe_expected_TRUNCATE.hex")
+    r = subprocess.run([sys.executable, cmp_py, "hex_n7_w47t16_strobe", "TRUNCATE", exp], capture_output=True, text=True)
+    assert r.returncode == 1 and "prediction does not hold" in r.stdout
+    lines = open(exp).read().splitlines()
+    lines[1500], lines[1501] = lines[1501], lines[1500]   # inside a random frame
+    (tmp_path / "strobe.hex").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([sys.executable, cmp_py, "hex_n7_w47t16_strobe", "TRUNCATE", str(tmp_path / "strobe.hex")], capture_output=True, text=True)
+    assert r.returncode == 0 and "as predicted" in r.stdout
+    assert subprocess.run([sys.executable, cmp_py, "hex_n7_w49t16_strobe", "TRUNCATE",
+                           os.path.join(EXP, "hex_n7_w49t16_strobe_expected_TRUNCATE.hex")], capture_output=True).returncode == 0
 
 
 def test_kit_lint_against_the_reference_entities(tmp_path):
@@ -104,7 +115,8 @@ def test_kit_lint_against_the_reference_entities(tmp_path):
     spec.loader.exec_module(lk)
     errs, man = lk.lint(ref)
     assert not errs, errs
-    assert len(man["cases"]) == 25
+    assert len(man["cases"]) == 27
+    assert {c["case"]: c["predicted"] for c in man["cases"] if "predicted" in c} == {"hex_n7_w47t16_strobe": "differs", "hex_n7_w49t16_strobe": "equal"}
     for c in man["cases"]:  # every vector dumped through conv_integer fits a VHDL integer; the wider ones go through the hex testbenches
         assert c["out_bits"] <= 32 or c.get("text") == "hex", c
     # the lint does catch what it is there for: a misspelt port, a wrong width, a too-wide conv_integer

@@ -17,6 +17,8 @@ Cases (each: one stimulus file + one expected dump per mode):
                 dbl35 at 30 .. 36 bits (30 x 24 unscaled, 35 x 24 truncate: int_cmult_dbl35_dsp48.vhd:163-168), the XSER-divergent dbl18
                 pair 30 x 16 unscaled NEW / OLD (37-bit results), NFFT = 12 at 28 x 24 unscaled (the dbl35 -> trpl52 walk of BASELINE
                 config 3 + the Taylor twiddles of STAGE 11, 40-bit results), and a 24 x 16 unscaled pair (38-bit results)
+  hex_n7_w47t16_strobe / hex_n7_w49t16_strobe   a falsifiable prediction of tools/rtl_sim.py (the reference's text clocked cycle by cycle): at
+                scaled DATA_WIDTH 47 the RTL's own valid strobe is one clock off and its frames DIFFER from the arithmetic; at 49 they agree
 Modes: TRUNCATE (FORMAT 0, RNDMODE 0), ROUNDING (0, 1), UNSCALED (1, 0)  -- fft_signle_test.vhd:80-112.
 Everything is produced by the GPU engine through the C-ABI (intfftk_amd); the oracle is not involved.
 """
@@ -106,6 +108,11 @@ def main():
                    ("hex_n7_w30t24", 7, 30, 24, "UNSCALED", "NEW"), ("hex_n7_w35t24", 7, 35, 24, "TRUNCATE", "NEW"),
                    ("hex_n7_w30t16", 7, 30, 16, "UNSCALED", "NEW"), ("hex_n7_w30t16old", 7, 30, 16, "UNSCALED", "OLD"),
                    ("hex_n12_w28t24", 12, 28, 24, "UNSCALED", "NEW")]
+    # A prediction of tools/rtl_sim.py (the reference's text, clocked): at scaled DTW 47 the butterflies' valid strobe is one clock off
+    # (ADD_DELAY = addsub_delay(DTW+SCALE+RNDMODE)+RNDMODE against an adder of DTW-1 bits, int_dif2_fly.vhd), so the RTL's frames must DIFFER
+    # from the arithmetic the engine computes; two bits up (49) the two agree again and the RTL must be bit-exact.  compare.py knows.
+    predicted = {"hex_n7_w47t16_strobe": "differs", "hex_n7_w49t16_strobe": "equal"}
+    wide_single += [("hex_n7_w47t16_strobe", 7, 47, 16, "TRUNCATE", "NEW"), ("hex_n7_w49t16_strobe", 7, 49, 16, "TRUNCATE", "NEW")]
     for name, nfft, dw, tw, mode, xser in wide_single:
         fmt, rnd = MODES[mode]
         n = 1 << nfft
@@ -126,6 +133,10 @@ def main():
         manifest["cases"].append({"case": name, "tb": "tb_single_hex", "text": "hex", "nfft": nfft, "mode": mode, "format": fmt, "rndmode": rnd,
                                   "data_width": dw, "twdl_width": tw, "xser": xser, "frames": int(x.shape[0]), "stimulus": stim,
                                   "expected": exp, "out_bits": core.out_bits, "kernel": core.info["kernel_name"]})
+        if name in predicted:
+            manifest["cases"][-1]["predicted"] = predicted[name]
+            manifest["cases"][-1]["note"] = ("tools/rtl_sim.py: valid strobe of the butterflies one clock off at scaled DTW 46 (round), 47, 48 "
+                                             "(truncate) -- the RTL is expected to %s here" % ("DIFFER" if predicted[name] == "differs" else "agree"))
         core.close()
     for name, nfft, dw, tw, mode, xser in [("hex_pair_n7_w24t16", 7, 24, 16, "UNSCALED", "NEW")]:
         fmt, rnd = MODES[mode]
