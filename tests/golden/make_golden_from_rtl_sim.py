@@ -18,7 +18,7 @@ Nothing here comes from the oracle; the one model that is not the reference's te
 UG579).  tests/test_golden_from_rtl_sim.py holds the C oracle and the Python twin (CPU) and the HIP path through the C-ABI (-m gpu)
 against the file.
 
-Run from the repo root, in the container that has /root/reference:  python tests/golden/make_golden_from_rtl_sim.py     (~15 min)
+Run from the repo root, in the container that has /root/reference:  python tests/golden/make_golden_from_rtl_sim.py     (~40 min)
 """
 import os
 import random
@@ -45,7 +45,15 @@ CASES = (
     + [("single", n, 16, 16, f, r, x, 4) for n in (3, 4, 5) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "OLD"), (1, 0, "NEW"))]
     + [("single", 3, 24, 24, 1, 0, "OLD", 4), ("single", 6, 16, 16, 0, 0, "NEW", 3)]
     + [("pair", n, 16, 16, f, r, x, 4) for n in (3, 4) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "NEW"), (1, 0, "OLD"))]
-    + [("pair", 5, 16, 16, 0, 0, "NEW", 4)])
+    + [("pair", 5, 16, 16, 0, 0, "NEW", 4)]
+    # the shapes of BASELINE.json at the sizes a Python-clocked core still reaches: C2 (N = 1024, 16 / 16 scaled, natural in and out through
+    # the single-path wrapper; the core alone in the three modes and both series), C5 (the N = 4096 pair), and N = 4096 alone, where STAGE 11
+    # takes its twiddles from row_twiddle_tay
+    + [("core_fwd", 10, 16, 16, f, r, x, 2) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "NEW"), (1, 0, "NEW"), (0, 0, "OLD"))]
+    + [("core_inv", 10, 16, 16, 0, 0, "NEW", 2), ("core_inv", 10, 16, 16, 0, 1, "OLD", 2), ("single", 10, 16, 16, 0, 0, "NEW", 3),
+       ("core_fwd", 12, 16, 16, 0, 0, "NEW", 2), ("core_inv", 12, 16, 16, 0, 0, "NEW", 2), ("core_fwd", 12, 16, 16, 0, 1, "OLD", 1),
+       ("core_fwd", 12, 24, 24, 1, 0, "NEW", 1), ("core_fwd", 13, 16, 16, 0, 0, "NEW", 1), ("core_fwd", 8, 18, 16, 0, 0, "NEW", 2),
+       ("core_inv", 9, 20, 18, 1, 0, "OLD", 2), ("pair", 7, 16, 16, 0, 0, "NEW", 4), ("pair", 12, 16, 16, 0, 0, "NEW", 3)])
 
 
 def main():
@@ -68,14 +76,14 @@ def main():
             orders = ("NATURAL", "BITREV") if d == "FWD" else ("BITREV", "NATURAL")
         elif kind == "single":
             d = "FWD"
-            got, _ = S.run_single_path(nfft, dw, t, f, r, x, frames)
-            y = [got[k * n:(k + 1) * n] for k in range(len(got) // n)]
+            got, _ = S.run_single_path(nfft, dw, t, f, r, x, frames, flush=1 if nfft >= 7 else 0)
+            y = [got[k * n:(k + 1) * n] for k in range(min(count, len(got) // n))]
             orders = ("NATURAL", "NATURAL")
         else:
             d = "PAIR"
-            beats, _ = S.run_pair(nfft, dw, t, f, r, x, frames)
+            beats, _ = S.run_pair(nfft, dw, t, f, r, x, frames, flush=2 if nfft >= 7 else 0)   # (two all-zero frames push the last ones out)
             got = [s for b in beats for s in b]
-            y = [got[k * n:(k + 1) * n] for k in range(len(got) // n)]
+            y = [got[k * n:(k + 1) * n] for k in range(min(count, len(got) // n))]
             orders = ("NATURAL", "NATURAL")
         assert len(y) >= 1, name
         out[name + "_x"] = np.array(frames, dtype=np.int64)

@@ -80,3 +80,49 @@ def test_the_wrappers_with_their_buffers():
     assert ok and whole == count - 1, (whole, count)   # the bit-reverse buffer keeps the last frame until another one comes
     ok, whole, count = S.compare_wrapper("pair", 3, 16, 16, 0, 0, "NEW", count=3)
     assert ok and whole >= 1, (whole, count)
+
+
+def test_the_simulation_follows_the_timing_of_the_text(monkeypatch):
+    """Two edits of the TEXT that change no arithmetic, only WHEN things happen: the frames must go wrong."""
+    import rtl_interp as R
+    real = R._load
+
+    def edited(old, new):
+        def load(entity):
+            return real(entity).replace(old, new)
+        return load
+
+    assert S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", count=2)[0]
+    # 1. the butterfly's valid strobe one clock late (the mechanism of the reference's own defect at 47 bits, seeded at 16)
+    assert "addsub_delay(dtw+scale+rndmode)" in real("int_dif2_fly")
+    monkeypatch.setattr(R, "_load", edited("addsub_delay(dtw+scale+rndmode)", "addsub_delay(dtw+scale+rndmode+40)"))
+    R.forget()
+    assert not S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", count=2)[0]
+    # 2. the twiddle enable through one more register: the twiddles arrive a beat after their data
+    assert "tw_en <= bf_en;" in real("int_align_fft")
+    monkeypatch.setattr(R, "_load", edited("tw_en <= bf_en;", "tw_en <= bf_en when rising_edge(clk);"))
+    R.forget()
+    assert not S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", count=2)[0]
+    monkeypatch.setattr(R, "_load", real)
+    R.forget()
+    assert S.compare("FWD", 3, 16, 16, 0, 0, "NEW", "cont", count=2)[0]
+
+
+def test_longer_frames_and_the_wrap_pair():
+    assert S.compare("FWD", 6, 16, 16, 0, 1, "NEW", "cont", count=2)[0]
+    assert S.compare("INV", 7, 16, 16, 0, 0, "OLD", "wrap", count=3)[0]
+    # int_fft_ifft_pair as the reference's fft_double_test.vhd drives it: RAMB_TYPE = "WRAP" (iobuf_wrap_int2, ramb_tdp_rw), the enable of
+    # every beat followed by an idle clock, 32 idle clocks between frames; four all-zero frames push the data frames out
+    import random
+    frames = S._frames(random.Random(9), 4, 16, 3)
+    beats, _ = S.run_pair(4, 16, 16, 0, 0, "NEW", frames, "wrap", gap=32, flush=4, toggle=True)
+    got = [s for b in beats for s in b]
+    want = S.expected_natural("PAIR", 4, 16, 16, 0, 0, "NEW", frames)
+    assert len(got) >= len(want) and got[:len(want)] == want
+
+
+def test_the_cross_check_kit_on_this_simulation(capsys):
+    """One case of tools/vivado_crosscheck through the text with the testbench's protocol, judged by the kit's own compare.py
+    (all of them: python tools/rtl_sim.py --kit, profiles/r06_rtl_sim_kit.txt)."""
+    assert S.run_kit({"single_n7_w14t16"}) == 0
+    assert "PASS  single_n7_w14t16 ROUNDING" in capsys.readouterr().out

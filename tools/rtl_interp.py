@@ -107,8 +107,8 @@ def _parse_fn(text: str):
                     els = seq(("end if;",))
                 pos += 1
                 out.append(("if", branches, els))
-            elif t.startswith("for "):
-                m = re.match(r"for (\w+) in (.*) to (.*)$", t)
+            elif re.match(r"(\w+ ?: ?)?for ", t):   # `xl: for ii in ...`: a labelled loop (iobuf_wrap_int2)
+                m = re.match(r"(?:\w+ ?: ?)?for (\w+) in (.*) to (.*)$", t)
                 pos += 2  # the header, `loop`
                 out.append(("for", m.group(1), m.group(2), m.group(3), seq(("end loop;",))))
                 pos += 1
@@ -233,8 +233,8 @@ class Entity:
         for item in _split_top(p.group(1), ";"):
             mm = re.match(r"(\w+) ?: ?(in|out) +std_logic(?:_vector ?\((.*)\))?$", item)
             self.ports[mm.group(1)] = (mm.group(2), mm.group(3))
-        a = re.search(r"architecture \w+ of %s is(.*)end %s ?;" % (name, name), t)
-        body = a.group(1)
+        a = re.search(r"architecture (\w+) of %s is(.*)end (?:%s|\1) ?;" % (name, name), t)  # `end <architecture name>;`: ramb_tdp_rw
+        body = a.group(2)
         self.functions = {}
         body = _take_functions(body, self.functions)
         i = body.index(" begin ")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A cycle-based simulation of the reference's int_fftNk / int_ifftNk FROM ITS OWN VHDL TEXT -- TEST INFRASTRUCTURE, this container only.
 
-    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep  (needs /root/reference; reads it, stores nothing)
+    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep | --kit [case ...]  (needs /root/reference; reads it, stores nothing)
 
 tools/rtl_interp.py evaluates the arithmetic entities of the reference as dataflow networks.  This tool goes the rest of the way: it
 elaborates a whole core -- the generate loops of int_fftNk.vhd, every butterfly, twiddle generator, aligner and delay line under it, down to
@@ -184,6 +184,12 @@ class VecFn:
             m = re.match(r"(\w+) ?\((.*?)\) ?\(([^()]*)\)$", t)
             if m and isinstance(scope.get(m.group(1)), dict):   # arr(j)(bit)
                 return (scope[m.group(1)][R._int(m.group(2), scope)] >> R._int(m.group(3), scope)) & 1
+            m = re.match(r"(\w+) ?\((.*) downto (.*)\)$", t)
+            if m and m.group(1) in width:   # a slice of a vector variable
+                hi, lo = R._int(m.group(2), scope), R._int(m.group(3), scope)
+                return (scope[m.group(1)] >> lo) & ((1 << (hi - lo + 1)) - 1)
+            if re.match(r"\( ?others ?=> ?'0' ?\)$", t):
+                return 0
             if t in scope:
                 return scope[t]
             return R._int(t, scope)
@@ -247,6 +253,7 @@ class Node:
         self.funcs = dict(self.ent.functions)
         self.comb, self.regs, self.procs, self.kids = [], [], [], []
         self.consts = set()
+        self._vc, self._rc, self._cc, self._keep = {}, {}, {}, {}   # parsed expressions / references / conditions, by (text, region)
         self.ints = set()   # integer signals (iobuf_flow_int2's in_cnt, wr_rng)
         self.vecfn = None
         self._decls(self.ent.decls, self.env)
@@ -395,7 +402,15 @@ class Node:
         return re.sub(r"(\w+)'left", left, text)
 
     def ref(self, text, env):
-        """-> ("w", Wire, hi, lo) | ("a", name, hi, lo) for a slice of an array of vectors (whole elements)"""
+        """-> ("w", Wire, hi, lo) | ("a", name, hi, lo) for a slice of an array of vectors (whole elements); indices are elaboration constants"""
+        key = (text, id(env))
+        r = self._rc.get(key)
+        if r is None:
+            self._keep[id(env)] = env
+            r = self._rc[key] = self._ref(text, env)
+        return r
+
+    def _ref(self, text, env):
         text = self._attr(text.strip())
         m = re.match(r"(\w+) ?(?:\(([^()]*(?:\([^()]*\)[^()]*)*)\))? ?(?:\(([^()]*(?:\([^()]*\)[^()]*)*)\))?$", text)
         assert m, "unparsed reference %r" % text
@@ -423,69 +438,129 @@ class Node:
         return ("w", s, i, i)
 
     def value(self, text, env, want_w=None):
+        """-> (value, width) of an expression now.  The text is parsed once per (expression, region, wanted width) into a closure."""
+        key = (text, id(env), want_w)
+        f = self._vc.get(key)
+        if f is None:
+            self._keep[id(env)] = env   # the key holds the region's identity: the region must stay alive
+            f = self._vc[key] = self._compile(text, env, want_w)
+        return f()
+
+    def _compile(self, text, env, want_w):
         text = self._attr(text.strip())
+        comp = self._compile
+        while text.startswith("(") and text.endswith(")") and R._balanced(text[1:-1]) and "=>" not in text:
+            text = text[1:-1].strip()
         parts = R._split_top(text, "&")
         if len(parts) > 1:
-            v = w = 0
-            for part in parts:
-                pv, pw = self.value(part, env)
-                v, w = (v << pw) | pv, w + pw
-            return v, w
+            fs = [comp(part, env, None) for part in parts]
+
+            def cat():
+                v = w = 0
+                for f in fs:
+                    pv, pw = f()
+                    v, w = (v << pw) | pv, w + pw
+                return v, w
+            return cat
         parts = R._split_kw(text, " and ")
         if len(parts) > 1:
-            v, w = self.value(parts[0], env, want_w)
-            for x in parts[1:]:
-                v &= self.value(x, env, want_w)[0]
-            return v, w
+            f0, rest = comp(parts[0], env, want_w), [comp(x, env, want_w) for x in parts[1:]]
+
+            def conj():
+                v, w = f0()
+                for g in rest:
+                    v &= g()[0]
+                return v, w
+            return conj
+        parts = R._split_kw(text, " or ")
+        if len(parts) > 1:
+            f0, rest = comp(parts[0], env, want_w), [comp(x, env, want_w) for x in parts[1:]]
+
+            def disj():
+                v, w = f0()
+                for g in rest:
+                    v |= g()[0]
+                return v, w
+            return disj
         parts = R._split_top(text, "*")
         if len(parts) == 2 and all(x.startswith("unsigned") for x in parts):
-            (a, wa), (b, wb) = (self.value(re.match(r"unsigned ?\((.*)\)$", x).group(1), env) for x in parts)
-            return a * b, wa + wb
+            fa, fb = (comp(re.match(r"unsigned ?\((.*)\)$", x).group(1), env, None) for x in parts)
+
+            def mul():
+                (a, wa), (b, wb) = fa(), fb()
+                return a * b, wa + wb
+            return mul
         m = re.match(r"(\w+) ?\( ?conv_integer ?\( ?(?:unsigned ?\()?(\w+)\)? ?\) ?\)$", text)
         if m and isinstance(env.get(m.group(1)), dict):
-            return env[m.group(1)][self.value(m.group(2), env)[0]], want_w
+            rom, fi = env[m.group(1)], comp(m.group(2), env, None)
+            return lambda: (rom[fi()[0]], want_w)
         if m and m.group(1) in self.mem:
             w, mem = self.mem[m.group(1)]
-            return mem.get(self.value(m.group(2), env)[0], 0), w
+            fi = comp(m.group(2), env, None)
+            return lambda: (mem.get(fi()[0], 0), w)
         if text.startswith('x"'):
-            return int(text[2:-1], 16), 4 * (len(text) - 3)
+            c = (int(text[2:-1], 16), 4 * (len(text) - 3))
+            return lambda: c
         m = re.match(r"(\w+) ?\((.*)\)$", text)
         if m and m.group(1) in self.funcs:   # a function of the entity over a vector (int_bitrev_order's bit_pair): executed, not restated
-            args = []
-            for a in R._split_top(m.group(2), ","):
-                a = a.strip()
-                if a in self.w:
-                    args.append((lambda v: (lambda i: (v >> int(i)) & 1))(self.w[a].val))
-                else:
-                    args.append(env[a] if a in env else R._int(a, env))
-            bits = R.call_function(self.funcs, m.group(1), args, env)
-            return sum(int(b) << i for i, b in bits.items()), (max(bits) + 1 if want_w is None else want_w)
+            fname, argt = m.group(1), [a.strip() for a in R._split_top(m.group(2), ",")]
+
+            def call():
+                args = []
+                for a in argt:
+                    if a in self.w:
+                        args.append((lambda v: (lambda i: (v >> int(i)) & 1))(self.w[a].val))
+                    else:
+                        args.append(env[a] if a in env else R._int(a, env))
+                bits = R.call_function(self.funcs, fname, args, env)
+                return sum(int(b) << i for i, b in bits.items()), (max(bits) + 1 if want_w is None else want_w)
+            return call
         parts = R._split_top(text, "+")
         if len(parts) >= 2:   # cnt + '1', cnt_even + wr_inz + 1, in_cnt + 1
-            v, w = self.value(parts[0], env, want_w)
-            for x in parts[1:]:
-                x = x.strip()
-                v += int(x.strip("'")) if re.match(r"'?\d+'?$", x) else self.value(x, env, w)[0]
-            return v & ((1 << w) - 1), w
+            f0 = comp(parts[0], env, want_w)
+            lits = sum(int(x.strip().strip("'")) for x in parts[1:] if re.match(r"'?\d+'?$", x.strip()))
+            others = [x.strip() for x in parts[1:] if not re.match(r"'?\d+'?$", x.strip())]
+
+            def add():
+                v, w = f0()
+                v += lits
+                for x in others:
+                    v += self.value(x, env, w)[0]
+                return v & ((1 << w) - 1), w
+            return add
         m = re.match(r"(\w+) ?\( ?(\w+) ?\)$", text)
         if m and isinstance(env.get(m.group(1)), dict):   # a constant array: std_inc(0), inc_bit(in_cnt)
-            i = self.w[m.group(2)].val if m.group(2) in self.ints else R._int(m.group(2), env)
-            return env[m.group(1)][i], want_w
+            table = env[m.group(1)]
+            if m.group(2) in self.ints:
+                idx = self.w[m.group(2)]
+                return lambda: (table[idx.val], want_w)
+            c = (table[R._int(m.group(2), env)], want_w)
+            return lambda: c
         if m and m.group(1) in self.w and m.group(2) in self.ints:   # sw_ptr(wr_rng)
-            return (self.w[m.group(1)].val >> self.w[m.group(2)].val) & 1, 1
+            vec, idx = self.w[m.group(1)], self.w[m.group(2)]
+            return lambda: ((vec.val >> idx.val) & 1, 1)
         if re.match(r"\d+$", text):
-            return int(text), want_w
+            c = (int(text), want_w)
+            return lambda: c
         m = re.match(r"not ?\(([^()]*(?:\([^()]*\)[^()]*)*)\)$", text) or re.match(r"not (.+)$", text)
         if m:
-            v, w = self.value(m.group(1), env, want_w)
-            return (~v) & ((1 << w) - 1), w
+            f = comp(m.group(1), env, want_w)
+
+            def inv():
+                v, w = f()
+                return (~v) & ((1 << w) - 1), w
+            return inv
         m = re.match(r"\( ?others ?=> ?(.*)\)$", text)
         if m:
             inner = m.group(1).strip()
             if inner.startswith("("):  # (others => (others => '0')): a whole array
-                return 0, want_w
-            bit = int(inner.strip("'")) if inner.startswith("'") else self.value(inner, env)[0]
-            return ((1 << want_w) - 1 if bit else 0), want_w
+                return lambda: (0, want_w)
+            if inner.startswith("'"):
+                c = (((1 << want_w) - 1 if int(inner.strip("'")) else 0), want_w)
+                return lambda: c
+            f = comp(inner, env, None)
+            ones = (1 << want_w) - 1
+            return lambda: ((ones if f()[0] else 0), want_w)
         m = re.match(r"\((.*others.*)\)$", text)
         if m:
             v = 0
@@ -493,19 +568,30 @@ class Node:
                 k, b = [x.strip() for x in it.split("=>")]
                 if k != "others" and b == "'1'":
                     v |= 1 << int(k)
-            return v, want_w
+            c = (v, want_w)
+            return lambda: c
         m = re.match(r"sxt ?\((.*), ?([^,]+)\)$", text)
         if m:
-            v, w = self.value(m.group(1), env)
-            n = R._int(m.group(2), env)
-            return tw.sxt(v, w, n), n
+            f, n = comp(m.group(1), env, None), R._int(m.group(2), env)
+
+            def ext():
+                v, w = f()
+                return tw.sxt(v, w, n), n
+            return ext
         if text.startswith('"'):
-            return int(text.strip('"'), 2), len(text) - 2
+            c = (int(text.strip('"'), 2), len(text) - 2)
+            return lambda: c
         if text.startswith("'"):
-            return int(text.strip("'")), 1
+            c = (int(text.strip("'")), 1)
+            return lambda: c
         r = self.ref(text, env)
         assert r[0] == "w", "an array where a vector is expected: %r" % text
-        return r[1].get(r[2], r[3]), r[2] - r[3] + 1
+        wire, hi, lo = r[1], r[2], r[3]
+        if hi < lo:
+            return lambda: (0, hi - lo + 1)
+        assert wire.lo <= lo <= hi <= wire.hi, "slice (%d downto %d) outside (%d downto %d)" % (hi, lo, wire.hi, wire.lo)
+        sh, mask, w = lo - wire.lo, (1 << (hi - lo + 1)) - 1, hi - lo + 1
+        return lambda: ((wire.val >> sh) & mask, w)
 
     def array_value(self, text, env):
         """RHS of an assignment to an array of vectors: slice & element & ... -> list of element values, highest index first"""
@@ -525,19 +611,30 @@ class Node:
         return r[1].set(r[2], r[3], v)
 
     def cond(self, c, env):
+        key = (c, id(env))
+        f = self._cc.get(key)
+        if f is None:
+            self._keep[id(env)] = env
+            f = self._cc[key] = self._compile_cond(c, env)
+        return f()
+
+    def _compile_cond(self, c, env):
         c = c.strip()
         while c.startswith("(") and c.endswith(")") and R._balanced(c[1:-1]):
             c = c[1:-1].strip()
         for op_, fn in ((" or ", any), (" and ", all)):
             parts = R._split_kw(c, op_)
             if len(parts) > 1:
-                return fn(self.cond(x, env) for x in parts)
+                fs = [self._compile_cond(x, env) for x in parts]
+                return (lambda fs=fs: any(f() for f in fs)) if fn is any else (lambda fs=fs: all(f() for f in fs))
         m = re.match(r"(.*?) ?= ?'([01])'$", c)
         if m:
-            return self.value(m.group(1), env)[0] == int(m.group(2))
+            f, bit = self._compile(m.group(1), env, None), int(m.group(2))
+            return lambda: f()[0] == bit
         m = re.match(r"(\w+) ?= ?(.+)$", c)
         assert m and m.group(1) in self.ints, "unparsed condition %r" % c
-        return self.w[m.group(1)].val == R._int(m.group(2), env)
+        wire, k = self.w[m.group(1)], R._int(m.group(2), env)
+        return lambda: wire.val == k
 
     # ---- simulation ----------------------------------------------------------------------------------------------------------------
     def settle_once(self):
@@ -662,6 +759,8 @@ def run_core(direction, nfft, dw, tw_, fmt, rnd, xser, frames, ramb="wrap", use_
             tick(idle)
     for _ in range(40 * nfft + 4 * n):
         tick(idle)
+        if ramb == "cont" and len(beats) >= len(frames) * n // 2 + 8:   # every frame is out (and a few clocks more show that nothing follows)
+            break
     return beats, top
 
 
@@ -672,56 +771,84 @@ def _reset(top, idle, rst):
         top.clock(idle)
 
 
-def run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames, fly=1):
+def run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames, fly=1, gap=0, flush=0, lead=4):
     """int_fft_single_path (main/int_fft_single_path.vhd) from the text: one sample per clock in natural order through inbuf_half_path ->
     int_fftNk (CONT) -> outbuf_half_path -> two int_bitrev_order.  -> the DO_VL-qualified samples [(re, im)], natural order, frame after frame
-    (the bit-reverse buffer hands a frame out while the next one comes in: the last frame stays inside)."""
+    (the bit-reverse buffer hands a frame out while the next one comes in: the last frame stays inside unless `flush` all-zero frames follow).
+    gap: idle clocks after every frame (the protocol of the kit's testbenches, tools/vivado_crosscheck/tb_single_*.vhd)."""
     top = Node("int_fft_single_path", {"nfft": nfft, "data_width": dw, "twdl_width": tw_, "format": fmt, "rndmode": rnd, "xseries": xser.lower(),
                                        "use_mlt": False})
     ow = dw + fmt * nfft
+    n = 1 << nfft
     idle = {"reset": 0, "fly_fwd": fly, "di_en": 0, "di_re": 0, "di_im": 0}
     _reset(top, idle, "reset")
+    for _ in range(lead):
+        top.clock(idle)
     out = []
+    quiet = [0]
 
     def tick(inp):
         o = top.clock(inp)
+        quiet[0] += 1
         if o["do_vl"]:
+            quiet[0] = 0
             out.append((tw.signed(o["do_re"], ow), tw.signed(o["do_im"], ow)))
 
-    for fr in frames:
+    for fr in list(frames) + [[(0, 0)] * n] * flush:
         for a, b in fr:
-            tick(dict(idle, di_en=1, di_re=tw.vec(a, dw), di_im=tw.vec(b, dw)))
-    for _ in range(40 * nfft + (6 << nfft)):
+            tick(dict(idle, di_en=1, di_re=tw.vec(int(a), dw), di_im=tw.vec(int(b), dw)))
+        for _ in range(gap):
+            tick(idle)
+    for _ in range(8 * n + 4096):   # the testbenches' drain; nothing can follow 2N + 40 NFFT + 200 silent idle clocks
         tick(idle)
+        if quiet[0] > 2 * n + 40 * nfft + 200:
+            break
     return out, top
 
 
-def run_pair(nfft, dw, tw_, fmt, rnd, xser, frames, ramb="cont"):
+def run_pair(nfft, dw, tw_, fmt, rnd, xser, frames, ramb="cont", gap=0, flush=0, toggle=False, ports=False, lead=4):
     """int_fft_ifft_pair (main/int_fft_ifft_pair.vhd) from the text: two samples per clock, lane 0 = x[2i], lane 1 = x[2i + 1], through
-    iobuf_flow_int2 -> int_fftNk -> int_ifftNk -> iobuf_flow_int2 (BITREV).  -> beats ((re0, im0), (re1, im1)) read from the wrapper's own
-    dt_rev0 / dt_rev1 (its output ports duplicate slices: Q0_IM = Q0_RE, Q1_RE = Q1_IM, SURVEY 9.9 -- asserted here), and the node."""
+    iobuf_flow_int2 (CONT) or iobuf_wrap_int2 (WRAP) -> int_fftNk -> int_ifftNk -> the same buffer in its BITREV form.
+    -> beats ((re0, im0), (re1, im1)) read from the wrapper's own dt_rev0 / dt_rev1 (its output ports duplicate slices: Q0_IM = Q0_RE,
+    Q1_RE = Q1_IM, SURVEY 9.9 -- asserted here), or with ports=True the four port values (Q0_RE, Q1_RE, Q0_IM, Q1_IM) as a testbench sees them.
+    toggle: the enable of every beat followed by one idle clock (fft_double_test.vhd with RAMB_TYPE = "WRAP"; the kit's tb_pair_*.vhd)."""
     top = Node("int_fft_ifft_pair", {"nfft": nfft, "ramb_type": ramb, "data_width": dw, "twdl_width": tw_, "format": fmt, "rndmode": rnd,
                                      "xseries": xser.lower(), "use_mlt": False})
     ow = dw + fmt * 2 * nfft
     idle = {"reset": 0, "fly_fwd": 1, "fly_inv": 1, "di_en": 0, "d0_re": 0, "d0_im": 0, "d1_re": 0, "d1_im": 0}
     _reset(top, idle, "reset")
+    for _ in range(lead):
+        top.clock(idle)
     out = []
     mask = (1 << ow) - 1
+    quiet = [0]
 
     def tick(inp):
         o = top.clock(inp)
+        quiet[0] += 1
         if o["qo_vl"]:
+            quiet[0] = 0
             r0, r1 = top.w["dt_rev0"].val, top.w["dt_rev1"].val
             assert o["q0_re"] == o["q0_im"] == r0 & mask and o["q1_re"] == o["q1_im"] == r1 >> ow, "the wrapper's ports are not the duplicated slices"
-            out.append(((tw.signed(r0 & mask, ow), tw.signed(r0 >> ow, ow)), (tw.signed(r1 & mask, ow), tw.signed(r1 >> ow, ow))))
+            if ports:
+                out.append(tuple(tw.signed(o[k], ow) for k in ("q0_re", "q1_re", "q0_im", "q1_im")))
+            else:
+                out.append(((tw.signed(r0 & mask, ow), tw.signed(r0 >> ow, ow)), (tw.signed(r1 & mask, ow), tw.signed(r1 >> ow, ow))))
 
     n = 1 << nfft
-    for fr in frames:
+    for fr in list(frames) + [[(0, 0)] * n] * flush:
         for i in range(n // 2):
             a, b = fr[2 * i], fr[2 * i + 1]
-            tick(dict(idle, di_en=1, d0_re=tw.vec(a[0], dw), d0_im=tw.vec(a[1], dw), d1_re=tw.vec(b[0], dw), d1_im=tw.vec(b[1], dw)))
-    for _ in range(80 * nfft + 8 * n):
+            beat = dict(idle, d0_re=tw.vec(int(a[0]), dw), d0_im=tw.vec(int(a[1]), dw), d1_re=tw.vec(int(b[0]), dw), d1_im=tw.vec(int(b[1]), dw))
+            tick(dict(beat, di_en=1))
+            if toggle:
+                tick(beat)   # the data stay, the enable drops for one clock
+        for _ in range(gap):
+            tick(idle)
+    for _ in range(8 * n + 8192):
         tick(idle)
+        if quiet[0] > 2 * n + 80 * nfft + 200:
+            break
     return out, top
 
 
@@ -844,6 +971,52 @@ def sweep():
     return 1 if bad else 0
 
 
+def run_kit(only=None):
+    """The external-pin kit (tools/vivado_crosscheck) run on THIS simulation instead of xsim: every case of expected/manifest.json goes through
+    the reference's text with the protocol of the kit's testbenches (reset, GAP idle clocks between frames, the enable toggling for the WRAP
+    pair, FLUSH all-zero frames, the drain), the dump is written in the testbench's text format and handed to the kit's own compare.py."""
+    import json
+    import subprocess
+    import tempfile
+    import time
+
+    import numpy as np
+
+    from intfftk_amd import textio
+    kit = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vivado_crosscheck")
+    man = json.load(open(os.path.join(kit, "expected", "manifest.json")))
+    tmp = tempfile.mkdtemp(prefix="rtl_sim_kit_")
+    bad = 0
+    print("# tools/rtl_sim.py --kit: the cases of tools/vivado_crosscheck/expected/manifest.json through the reference's own text (what run_xsim.sh does")
+    print("# with xsim), judged by the kit's compare.py.  Testbench protocol: single GAP 4 FLUSH 2; pair RAMB_TYPE WRAP GAP 32 FLUSH 6, toggling enable")
+    for c in man["cases"]:
+        if only and c["case"] not in only:
+            continue
+        t0 = time.time()
+        nfft, dw, t, xser = c["nfft"], c.get("data_width", 16), c.get("twdl_width", 16), c.get("xser", "NEW")
+        n = 1 << nfft
+        stim = os.path.join(kit, "expected", c["stimulus"])
+        hexio = c.get("text") == "hex"
+        pair = c["tb"].startswith("tb_pair")
+        ow = dw + c["format"] * nfft * (2 if pair else 1)
+        if pair:
+            x = textio.table_to_double(textio.read_hex(stim, dw), n) if hexio else textio.read_di_double(stim, n)
+            rows, _ = run_pair(nfft, dw, t, c["format"], c["rndmode"], xser, x.tolist(), "wrap", gap=32, flush=6, toggle=True, ports=True, lead=32)
+        else:
+            x = textio.read_hex(stim, dw).reshape(-1, n, 2) if hexio else textio.read_di_single(stim, n)
+            rows, _ = run_single_path(nfft, dw, t, c["format"], c["rndmode"], xser, x.tolist(), gap=4, flush=2, lead=16)
+        dump = os.path.join(tmp, "%s_%s_rtl.dat" % (c["case"], c["mode"]))
+        if hexio:
+            textio.write_hex(dump, np.array(rows, dtype=object), ow)
+        else:
+            np.savetxt(dump, np.array(rows, dtype=np.int64), fmt="%d")
+        r = subprocess.run([sys.executable, os.path.join(kit, "compare.py"), c["case"], c["mode"], dump], capture_output=True, text=True)
+        print("%s  [%d lines dumped, %.0f s]" % (r.stdout.strip() or r.stderr.strip(), len(rows), time.time() - t0), flush=True)
+        bad += r.returncode != 0
+    print("rtl_sim --kit: %d cases, %d FAIL" % (len([c for c in man["cases"] if not only or c["case"] in only]), bad))
+    return 1 if bad else 0
+
+
 def main():
     import random
     if not available():
@@ -851,6 +1024,8 @@ def main():
         return 0
     if "--sweep" in sys.argv:
         return sweep()
+    if "--kit" in sys.argv:
+        return run_kit(set(sys.argv[sys.argv.index("--kit") + 1:]) or None)
     nfft = int(sys.argv[sys.argv.index("--nfft") + 1]) if "--nfft" in sys.argv else 4
     nfr = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 3
     rng = random.Random(7)
