@@ -28,9 +28,12 @@ def unpack(c):
 
 def test_fixture_covers_what_it_says():
     kinds = {c[1] for c in CASES}
-    assert kinds == {"core_fwd", "core_inv", "single", "pair"} and len(CASES) >= 45
-    assert {int(c[3]) for c in CASES} >= {3, 4, 5, 6}
+    assert kinds == {"core_fwd", "core_inv", "single", "pair"} and len(CASES) >= 60
+    assert {int(c[3]) for c in CASES} >= {3, 4, 5, 6, 7, 10, 12, 13}
     assert {(int(c[6]), int(c[7])) for c in CASES} == {(0, 0), (0, 1), (1, 0)} and {c[8] for c in CASES} == {"NEW", "OLD"}
+    names = {c[0] for c in CASES}
+    # BASELINE's C2 and C5 shapes, N = 4096 / 8192 (Taylor twiddles from STAGE 11 on), C3's 24-bit unscaled regime walk at N = 4096
+    assert {"single_n10_w16_t16_f0_r0_NEW", "pair_n12_w16_t16_f0_r0_NEW", "core_fwd_n13_w16_t16_f0_r0_NEW", "core_fwd_n12_w24_t24_f1_r0_NEW"} <= names
     for c in CASES:
         x, y = Z[c[0] + "_x"], Z[c[0] + "_y"]
         assert x.shape[1:] == y.shape[1:] == (1 << int(c[3]), 2) and 1 <= y.shape[0] <= x.shape[0]
@@ -102,3 +105,23 @@ def test_hip_engine_equals_the_text_in_one_ragged_batch():
     got = core(xin).cpu().numpy().astype(np.int64)
     core.close()
     assert np.array_equal(got, np.tile(y, (reps, 1, 1)))
+
+
+@pytest.mark.gpu
+def test_the_headline_kernels_themselves_meet_the_text():
+    """C2's and C5's exact shapes: the frames that the reference's wrappers handed out, against the kernels bench.py times."""
+    import torch
+
+    from intfftk_amd import IntFFTCore
+    for name, d, nfft, kernel in (("single_n10_w16_t16_f0_r0_NEW", "FWD", 10, "k_fft1024_i16"), ("pair_n12_w16_t16_f0_r0_NEW", "PAIR", 12, "k_fft4096_i16")):
+        x, y = Z[name + "_x"], Z[name + "_y"]
+        core = IntFFTCore(nfft, 16, 16, 0, 0, "NEW", d, "NATURAL", "NATURAL", 1)
+        assert core.info["kernel_name"] == kernel and core.info["fast_path"] == 1, core.info
+        # a batch that fills the chip, the fixture's frames scattered through it
+        reps = 257
+        xin = torch.from_numpy(np.ascontiguousarray(np.tile(x, (reps, 1, 1)).astype(np.int16))).cuda()
+        got = core(xin).cpu().numpy().astype(np.int64)
+        core.close()
+        want = np.tile(np.concatenate([y, np.zeros((x.shape[0] - y.shape[0],) + y.shape[1:], np.int64)]), (reps, 1, 1))
+        mask = np.tile(np.arange(x.shape[0]) < y.shape[0], reps)
+        assert np.array_equal(got[mask], want[mask]), name

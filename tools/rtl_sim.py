@@ -863,20 +863,25 @@ def expected_natural(direction, nfft, dw, tw_, fmt, rnd, xser, frames):
     return out
 
 
-def compare_wrapper(which, nfft, dw, tw_, fmt, rnd, xser, count=4, seed=5):
-    """-> (equal?, whole frames out, frames in).  The buffers hand a frame out while later ones come in: at least one whole frame must
-    come out and every sample that does must be the oracle's."""
+def compare_wrapper(which, nfft, dw, tw_, fmt, rnd, xser, count=4, seed=5, flush=True):
+    """which: "single" | "pair" (RAMB_TYPE CONT) | "pair_wrap" (RAMB_TYPE WRAP driven like fft_double_test.vhd: toggling enable, 32 idle clocks
+    between frames).  -> (equal?, whole frames out, frames in).  Without `flush` the buffers keep the last frames (they hand a frame out while
+    later ones come in): at least one whole frame must come out and every sample that does must be the oracle's; with it (all-zero frames
+    behind the data: 1 / 2 / 4) every frame must come out."""
     import random
     frames = _frames(random.Random(seed), nfft, dw, count)
     if which == "single":
-        got, _ = run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames)
+        got, _ = run_single_path(nfft, dw, tw_, fmt, rnd, xser, frames, flush=1 if flush else 0)
         want = expected_natural("FWD", nfft, dw, tw_, fmt, rnd, xser, frames)
     else:
-        beats, _ = run_pair(nfft, dw, tw_, fmt, rnd, xser, frames)
+        wrap = which == "pair_wrap"
+        beats, _ = run_pair(nfft, dw, tw_, fmt, rnd, xser, frames, "wrap" if wrap else "cont", gap=32 if wrap else 0,
+                            flush=(4 if wrap else 2) if flush else 0, toggle=wrap)
         got = [s for b in beats for s in b]
         want = expected_natural("PAIR", nfft, dw, tw_, fmt, rnd, xser, frames)
-    whole = len(got) >> nfft
-    return (whole >= 1 and len(got) <= len(want) and got == want[:len(got)]), whole, count
+    whole = min(count, len(got) >> nfft)
+    k = min(len(got), len(want))
+    return (whole >= (count if flush else 1) and got[:k] == want[:k]), whole, count
 
 
 def expected(direction, nfft, dw, tw_, fmt, rnd, xser, frames, use_fly=1):
@@ -938,18 +943,24 @@ STROBE_CORNER = (("FWD", 45, 1, 0, "NEW", True), ("FWD", 46, 0, 0, "NEW", True),
 
 
 WRAPPERS = ([("single", n, 16, 16, f, r, x) for n in (3, 4) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "OLD"), (1, 0, "NEW"))]
-            + [("single", 5, 16, 16, 0, 0, "NEW"), ("single", 3, 24, 24, 1, 0, "OLD"), ("single", 6, 16, 16, 0, 0, "NEW")]
+            + [("single", 5, 16, 16, 0, 0, "NEW"), ("single", 3, 24, 24, 1, 0, "OLD"), ("single", 7, 16, 16, 0, 1, "NEW"), ("single", 10, 16, 16, 0, 0, "NEW")]
             + [("pair", n, 16, 16, f, r, x) for n in (3, 4) for (f, r, x) in ((0, 0, "NEW"), (0, 1, "NEW"), (1, 0, "OLD"))]
-            + [("pair", 5, 16, 16, 0, 0, "NEW")])
+            + [("pair", 5, 16, 16, 0, 0, "NEW"), ("pair", 7, 16, 16, 0, 0, "NEW"), ("pair_wrap", 3, 16, 16, 0, 0, "NEW"), ("pair_wrap", 5, 16, 16, 0, 1, "NEW"),
+               ("pair_wrap", 7, 16, 16, 1, 0, "OLD")])
+# longer frames: N = 1024 (BASELINE's C2 shape), N = 4096 / 8192 where STAGE 11 / 12 take their twiddles from row_twiddle_tay, the 24-bit
+# unscaled regime walk of C3 at N = 4096
+LONG = [("FWD", 6, 16, 16, 0, 1, "NEW", "cont", 1, 0), ("INV", 7, 16, 16, 0, 0, "OLD", "wrap", 1, 0), ("FWD", 10, 16, 16, 0, 0, "NEW", "cont", 1, 0),
+        ("INV", 10, 16, 16, 0, 1, "OLD", "cont", 1, 0), ("FWD", 12, 16, 16, 0, 0, "NEW", "cont", 1, 0), ("INV", 12, 16, 16, 0, 0, "NEW", "cont", 1, 0),
+        ("FWD", 12, 16, 16, 0, 1, "OLD", "cont", 1, 0), ("FWD", 12, 24, 24, 1, 0, "NEW", "cont", 1, 0), ("FWD", 13, 16, 16, 0, 0, "NEW", "cont", 1, 0)]
 
 
 def sweep():
     import time
     print("# tools/rtl_sim.py --sweep: int_fftNk / int_ifftNk elaborated from the reference's own VHDL text, clocked beat by beat, against oracle_py")
     bad = 0
-    for (d, n, dw, t, f, r, x, ramb, fly, gap) in SWEEP:
+    for (d, n, dw, t, f, r, x, ramb, fly, gap) in SWEEP + LONG:
         t0 = time.time()
-        ok, a, b = compare(d, n, dw, t, f, r, x, ramb, fly, gap)
+        ok, a, b = compare(d, n, dw, t, f, r, x, ramb, fly, gap, count=3 if n < 10 else 2 if n < 12 else 1)
         print("%s NFFT %2d DW %2d TW %2d FORMAT %d RNDMODE %d %s RAMB %s USE_FLY %d gap %d: %3d of %3d beats, %s  (%.0f s)"
               % (d, n, dw, t, f, r, x, ramb.upper(), fly, gap, a, b, "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
         bad += not ok
@@ -959,15 +970,16 @@ def sweep():
         print("%s NFFT  3 DW %2d TW 16 FORMAT %d RNDMODE %d %s: %s (predicted from the text: %s)"
               % (d, dw, f, r, x, "equal" if ok else "DIFFERENT", "equal" if agree else "DIFFERENT"), flush=True)
         bad += ok != agree
-    print("# the wrappers of src/vhdl/main from the text, I/O buffers included, natural order in and out (memory order of the C-ABI's NATURAL)")
+    print("# the wrappers of src/vhdl/main from the text, I/O buffers included, natural order in and out (memory order of the C-ABI's NATURAL);")
+    print("# all-zero frames behind the data push the last frames out (1 single path, 2 pair CONT, 4 pair WRAP); WRAP as fft_double_test.vhd drives it")
     for (which, n, dw, t, f, r, x) in WRAPPERS:
         t0 = time.time()
         ok, whole, count = compare_wrapper(which, n, dw, t, f, r, x)
         print("%s NFFT %2d DW %2d TW %2d FORMAT %d RNDMODE %d %s: %d of %d frames out, %s  (%.0f s)"
-              % ({"single": "int_fft_single_path", "pair": "int_fft_ifft_pair  "}[which], n, dw, t, f, r, x, whole, count,
+              % ({"single": "int_fft_single_path     ", "pair": "int_fft_ifft_pair CONT  ", "pair_wrap": "int_fft_ifft_pair WRAP  "}[which], n, dw, t, f, r, x, whole, count,
                  "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
         bad += not ok
-    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(STROBE_CORNER) + len(WRAPPERS), bad))
+    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(LONG) + len(STROBE_CORNER) + len(WRAPPERS), bad))
     return 1 if bad else 0
 
 
