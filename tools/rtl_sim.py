@@ -732,11 +732,11 @@ class Node:
         return {p: self.w[p].val for p, (d, _) in self.ent.ports.items() if d == "out"}
 
 
-def run_core(direction, nfft, dw, tw_, fmt, rnd, xser, frames, ramb="wrap", use_fly=1, gap=0):
+def run_core(direction, nfft, dw, tw_, fmt, rnd, xser, frames, ramb="wrap", use_fly=1, gap=0, use_mlt=False):
     """frames: list of frames, each a list of N (re, im) -- natural order for FWD (lane 0 = x[i], lane 1 = x[i + N/2]), the bit-reversed pair
     stream for INV (lane 0 = v[2i], lane 1 = v[2i + 1]).  -> list of output beats ((re0, im0), (re1, im1)) that came with DO_VAL = '1'"""
     top = Node("int_fftnk" if direction == "FWD" else "int_ifftnk",
-               {"nfft": nfft, "ramb_type": ramb, "format": fmt, "rndmode": rnd, "data_width": dw, "twdl_width": tw_, "xser": xser.lower(), "use_mlt": False})
+               {"nfft": nfft, "ramb_type": ramb, "format": fmt, "rndmode": rnd, "data_width": dw, "twdl_width": tw_, "xser": xser.lower(), "use_mlt": use_mlt})
     n = 1 << nfft
     ow = dw + fmt * nfft
     idle = {"rst": 0, "use_fly": use_fly, "di_ena": 0, "di_re0": 0, "di_im0": 0, "di_re1": 0, "di_im1": 0}
@@ -964,6 +964,15 @@ def sweep():
         print("%s NFFT %2d DW %2d TW %2d FORMAT %d RNDMODE %d %s RAMB %s USE_FLY %d gap %d: %3d of %3d beats, %s  (%.0f s)"
               % (d, n, dw, t, f, r, x, ramb.upper(), fly, gap, a, b, "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
         bad += not ok
+    print("# USE_MLT = TRUE (rom_twiddle_int computes MATHPI * cnt with a multiplier instead of the accumulating form): N = 4096, STAGE 11")
+    import random
+    for (d, x) in (("FWD", "NEW"), ("INV", "OLD")):
+        t0 = time.time()
+        fr = _frames(random.Random(77), 12, 16, 1)
+        got, _ = run_core(d, 12, 16, 16, 0, 0, x, fr, "cont", use_mlt=True)
+        ok = got[:len(fr) << 11] == expected(d, 12, 16, 16, 0, 0, x, fr) and len(got) >= 2048
+        print("%s NFFT 12 DW 16 TW 16 FORMAT 0 RNDMODE 0 %s USE_MLT TRUE: %d beats, %s  (%.0f s)" % (d, x, len(got), "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
+        bad += not ok
     print("# the strobe corner: ADD_DELAY = addsub_delay(DTW+SCALE+RNDMODE)+RNDMODE against an adder of DSPW = DTW-1 (truncate) / DTW bits")
     for (d, dw, r, f, x, agree) in STROBE_CORNER:
         ok, a, b = compare(d, 3, dw, 16, f, r, x, "cont", count=2)
@@ -979,7 +988,7 @@ def sweep():
               % ({"single": "int_fft_single_path     ", "pair": "int_fft_ifft_pair CONT  ", "pair_wrap": "int_fft_ifft_pair WRAP  "}[which], n, dw, t, f, r, x, whole, count,
                  "equal" if ok else "DIFFERENT", time.time() - t0), flush=True)
         bad += not ok
-    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(LONG) + len(STROBE_CORNER) + len(WRAPPERS), bad))
+    print("rtl_sim: %d configurations, %d unexpected" % (len(SWEEP) + len(LONG) + 2 + len(STROBE_CORNER) + len(WRAPPERS), bad))
     return 1 if bad else 0
 
 
