@@ -95,5 +95,29 @@ def main():
     print("wrote from_rtl_sim.npz:", len(table), "cases")
 
 
+def big(beats_from=None):
+    """--big: ONE full-size frame of BASELINE's C3 shape (N = 65536, 24-bit data, 24-bit twiddles, unscaled: 40-bit results; STAGE 11 .. 15
+    on Taylor twiddles, the sngl25 -> dbl35 -> trpl52 walk of the multipliers) through int_fftNk from the text -> from_rtl_sim_big.npz.
+    About 100 000 simulated clocks of a sixteen-stage core: hours of CPU."""
+    import pickle
+    nfft, dw, t, f, r, x = 16, 24, 24, 1, 0, "NEW"
+    frames = S._frames(random.Random(65536), nfft, dw, 1)
+    if beats_from:   # a run of exactly this call that was left to finish on its own (same seed, same generics), stored as (frames, beats)
+        fr2, beats = pickle.load(open(beats_from, "rb"))
+        assert fr2 == frames
+    else:
+        beats, _ = S.run_core("FWD", nfft, dw, t, f, r, x, frames, "cont")
+    n = 1 << nfft
+    assert len(beats) >= n // 2
+    y = [[s for b in beats[:n // 2] for s in b]]
+    name = "core_fwd_n16_w24_t24_f1_r0_NEW"
+    np.savez_compressed(os.path.join(HERE, "from_rtl_sim_big.npz"), **{name + "_x": np.array(frames, dtype=np.int64), name + "_y": np.array(y, dtype=np.int64),
+                        "cases": np.array(["%s core_fwd FWD 16 24 24 1 0 NEW NATURAL BITREV" % name])})
+    print("wrote from_rtl_sim_big.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if "--big" in sys.argv:
+        big(sys.argv[sys.argv.index("--from") + 1] if "--from" in sys.argv else None)
+    else:
+        main()

@@ -14,7 +14,12 @@ from oracle import oracle_c as C
 from oracle import oracle_py as P
 
 PATH = os.path.join(os.path.dirname(__file__), "golden", "from_rtl_sim.npz")
-Z = np.load(PATH)
+Z = dict(np.load(PATH))
+BIG = os.path.join(os.path.dirname(__file__), "golden", "from_rtl_sim_big.npz")  # one full-size frame of C3's shape (make_golden_from_rtl_sim.py --big)
+if os.path.exists(BIG):
+    _b = dict(np.load(BIG))
+    Z.update({k: v for k, v in _b.items() if k != "cases"})
+    Z["cases"] = np.concatenate([Z["cases"], _b["cases"]])
 CASES = [ln.split() for ln in Z["cases"]]
 IDS = [c[0] for c in CASES]
 NP = {2: np.int16, 4: np.int32, 8: np.int64}
