@@ -128,3 +128,9 @@ def test_the_cross_check_kit_on_this_simulation(capsys):
     (all of them: python tools/rtl_sim.py --kit, profiles/r06_rtl_sim_kit.txt)."""
     assert S.run_kit({"single_n7_w14t16"}) == 0
     assert "PASS  single_n7_w14t16 ROUNDING" in capsys.readouterr().out
+
+
+def test_random_generics_through_the_whole_core():
+    """A few draws of tools/rtl_sim.py --fuzz (profiles/r06_rtl_sim_fuzz.txt holds 500): random NFFT / widths / mode / series / direction /
+    RAMB_TYPE, the text clocked against the oracle; what the oracle's validator accepts must elaborate."""
+    assert S.fuzz(8, 12345) == 0

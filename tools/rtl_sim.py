@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A cycle-based simulation of the reference's int_fftNk / int_ifftNk FROM ITS OWN VHDL TEXT -- TEST INFRASTRUCTURE, this container only.
 
-    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep | --kit [case ...]  (needs /root/reference; reads it, stores nothing)
+    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep | --kit [case ...] | --fuzz COUNT SEED  (needs /root/reference; reads it, stores nothing)
 
 tools/rtl_interp.py evaluates the arithmetic entities of the reference as dataflow networks.  This tool goes the rest of the way: it
 elaborates a whole core -- the generate loops of int_fftNk.vhd, every butterfly, twiddle generator, aligner and delay line under it, down to
@@ -992,6 +992,49 @@ def sweep():
     return 1 if bad else 0
 
 
+def fuzz(count, seed):
+    """Random generics inside (and a little beyond) the documented ranges -- NFFT 3 .. 7, DATA_WIDTH 8 .. 44, TWDL_WIDTH 8 .. 26, the three
+    modes, XSER, direction, RAMB_TYPE, now and then idle clocks between frames or USE_FLY = 0 -- each elaborated whole from the text and
+    clocked against oracle_py.  Generics the oracle's validator refuses are skipped (counted); generics it accepts must elaborate."""
+    import random
+    import time
+    from oracle import oracle_c as C
+    rng = random.Random(seed)
+    t0 = time.time()
+    done = bad = refused = 0
+    print("# tools/rtl_sim.py --fuzz %d %d" % (count, seed))
+    while done < count:
+        nfft = rng.choice([3, 3, 4, 4, 5, 5, 6, 7])
+        dw = rng.choice([16, 16, rng.randint(8, 32), rng.randint(8, 32), rng.randint(33, 44)])
+        t = rng.choice([16, 16, rng.randint(8, 26), rng.randint(8, 26)])
+        fmt = rng.randint(0, 1)
+        rnd = 0 if fmt else rng.randint(0, 1)
+        xser = rng.choice(["NEW", "OLD"])
+        d = rng.choice(["FWD", "INV"])
+        ramb = rng.choice(["cont", "cont", "wrap"])
+        gap = rng.choice([0, 0, 0, rng.randint(1, 9)]) if ramb == "cont" else 0
+        fly = 0 if rng.random() < 0.08 else 1
+        p = C.make_params(nfft, dw, t, fmt, rnd, xser == "NEW", fly)
+        valid = C.lib().orc_validate(p, C.FWD if d == "FWD" else C.INV) == 0
+        tag = "%s NFFT %d DW %2d TW %2d FORMAT %d RNDMODE %d %s RAMB %s USE_FLY %d gap %d" % (d, nfft, dw, t, fmt, rnd, xser, ramb.upper(), fly, gap)
+        if not valid:   # no generate branch of int_cmult_dsp48 matches such widths: nothing drives the product (an unconnected net is not an
+            refused += 1   # error of this simulation; that the accept sets agree is tests/test_rtl_interp.py's multiplier-tree check)
+            continue
+        try:
+            ok, a, b = compare(d, nfft, dw, t, fmt, rnd, xser, ramb, fly, gap, count=2, seed=rng.randint(1, 1 << 30))
+        except AssertionError as exc:
+            print(tag, ": the oracle accepts it, the text does not elaborate:", str(exc)[:100])
+            bad += 1
+            R.forget()
+            continue
+        if not ok:
+            print(tag, ": %d of %d beats, DIFFERENT" % (a, b), flush=True)
+            bad += 1
+        done += 1
+    print("rtl_sim --fuzz: %d configurations clocked against the oracle, %d more refused by the oracle's validator, %d unexpected, %.0f s" % (done, refused, bad, time.time() - t0))
+    return 1 if bad else 0
+
+
 def run_kit(only=None):
     """The external-pin kit (tools/vivado_crosscheck) run on THIS simulation instead of xsim: every case of expected/manifest.json goes through
     the reference's text with the protocol of the kit's testbenches (reset, GAP idle clocks between frames, the enable toggling for the WRAP
@@ -1045,6 +1088,9 @@ def main():
         return 0
     if "--sweep" in sys.argv:
         return sweep()
+    if "--fuzz" in sys.argv:
+        k = sys.argv.index("--fuzz")
+        return fuzz(int(sys.argv[k + 1]), int(sys.argv[k + 2]))
     if "--kit" in sys.argv:
         return run_kit(set(sys.argv[sys.argv.index("--kit") + 1:]) or None)
     nfft = int(sys.argv[sys.argv.index("--nfft") + 1]) if "--nfft" in sys.argv else 4
