@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A cycle-based simulation of the reference's int_fftNk / int_ifftNk FROM ITS OWN VHDL TEXT -- TEST INFRASTRUCTURE, this container only.
 
-    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep | --kit [case ...] | --fuzz COUNT SEED  (needs /root/reference; reads it, stores nothing)
+    python tools/rtl_sim.py [--nfft 4] [--frames 3] | --sweep | --kit [case ...] | --fuzz COUNT SEED | --fuzz-wrappers COUNT SEED  (needs /root/reference; reads it, stores nothing)
 
 tools/rtl_interp.py evaluates the arithmetic entities of the reference as dataflow networks.  This tool goes the rest of the way: it
 elaborates a whole core -- the generate loops of int_fftNk.vhd, every butterfly, twiddle generator, aligner and delay line under it, down to
@@ -1035,6 +1035,38 @@ def fuzz(count, seed):
     return 1 if bad else 0
 
 
+def fuzz_wrappers(count, seed):
+    """The same for the wrappers of src/vhdl/main with their I/O buffers: int_fft_single_path, int_fft_ifft_pair with RAMB_TYPE CONT and WRAP
+    (the latter driven like fft_double_test.vhd), random NFFT 3 .. 6, widths, mode, series; every frame must come out and be the oracle's."""
+    import random
+    import time
+    from oracle import oracle_c as C
+    rng = random.Random(seed)
+    t0 = time.time()
+    done = bad = refused = 0
+    print("# tools/rtl_sim.py --fuzz-wrappers %d %d" % (count, seed))
+    while done < count:
+        which = rng.choice(["single", "pair", "pair_wrap"])
+        nfft = rng.choice([3, 4, 4, 5, 5, 6])
+        dw = rng.choice([16, 16, rng.randint(8, 32), rng.randint(8, 32)])
+        t = rng.choice([16, 16, rng.randint(8, 26)])
+        fmt = rng.randint(0, 1)
+        rnd = 0 if fmt else rng.randint(0, 1)
+        xser = rng.choice(["NEW", "OLD"])
+        p = C.make_params(nfft, dw, t, fmt, rnd, xser == "NEW", 1)
+        if C.lib().orc_validate(p, C.FWD if which == "single" else C.PAIR) != 0 or dw + fmt * nfft * (1 if which == "single" else 2) > 62:
+            refused += 1
+            continue
+        ok, whole, n = compare_wrapper(which, nfft, dw, t, fmt, rnd, xser, count=3, seed=rng.randint(1, 1 << 30))
+        if not ok:
+            print("%s NFFT %d DW %2d TW %2d FORMAT %d RNDMODE %d %s: %d of %d frames, DIFFERENT" % (which, nfft, dw, t, fmt, rnd, xser, whole, n), flush=True)
+            bad += 1
+        done += 1
+    print("rtl_sim --fuzz-wrappers: %d configurations clocked against the oracle, %d more refused by the oracle's validator, %d unexpected, %.0f s"
+          % (done, refused, bad, time.time() - t0))
+    return 1 if bad else 0
+
+
 def run_kit(only=None):
     """The external-pin kit (tools/vivado_crosscheck) run on THIS simulation instead of xsim: every case of expected/manifest.json goes through
     the reference's text with the protocol of the kit's testbenches (reset, GAP idle clocks between frames, the enable toggling for the WRAP
@@ -1088,6 +1120,9 @@ def main():
         return 0
     if "--sweep" in sys.argv:
         return sweep()
+    if "--fuzz-wrappers" in sys.argv:
+        k = sys.argv.index("--fuzz-wrappers")
+        return fuzz_wrappers(int(sys.argv[k + 1]), int(sys.argv[k + 2]))
     if "--fuzz" in sys.argv:
         k = sys.argv.index("--fuzz")
         return fuzz(int(sys.argv[k + 1]), int(sys.argv[k + 2]))
