@@ -254,6 +254,7 @@ class Node:
         self.comb, self.regs, self.procs, self.kids = [], [], [], []
         self.consts = set()
         self._vc, self._rc, self._cc, self._keep = {}, {}, {}, {}   # parsed expressions / references / conditions, by (text, region)
+        self._cw = self._ca = self._kc = None
         self.ints = set()   # integer signals (iobuf_flow_int2's in_cnt, wr_rng)
         self.vecfn = None
         self._decls(self.ent.decls, self.env)
@@ -637,29 +638,90 @@ class Node:
         return lambda: wire.val == k
 
     # ---- simulation ----------------------------------------------------------------------------------------------------------------
-    def settle_once(self):
-        ch = False
+    def _closure(self, text, env, want_w):
+        key = (text, id(env), want_w)
+        f = self._vc.get(key)
+        if f is None:
+            self._keep[id(env)] = env
+            f = self._vc[key] = self._compile(text, env, want_w)
+        return f
+
+    @staticmethod
+    def _slot(wire, hi, lo):
+        """(wire, shift, mask, ~(mask << shift)) of wire(hi downto lo)"""
+        assert wire.lo <= lo <= hi <= wire.hi, "slice (%d downto %d) outside (%d downto %d)" % (hi, lo, wire.hi, wire.lo)
+        sh, mask = lo - wire.lo, (1 << (hi - lo + 1)) - 1
+        return wire, sh, mask, ~(mask << sh)
+
+    def _prepare(self):
+        """the combinational statements, port connections and DSP outputs of this node as (target slot, closure) lists: looked up once"""
+        self._cw, self._ca, self._kc = [], [], []
         for lhs, rhs, env, _ in self.comb:
             r = self.ref(lhs, env)
             if r[0] == "a":
-                hi0, lo0, els = self.arr[r[1]]
-                vals = self.array_value(rhs, env)
-                for i, v in zip(range(r[2], r[3] - 1, -1), vals):
-                    ch |= els[i - lo0].set(els[i - lo0].hi, els[i - lo0].lo, v)
-            else:
-                ch |= r[1].set(r[2], r[3], self.value(rhs, env, r[2] - r[3] + 1)[0])
+                self._ca.append((r, rhs, env))
+            elif r[2] >= r[3]:
+                self._cw.append(self._slot(r[1], r[2], r[3]) + (self._closure(rhs, env, r[2] - r[3] + 1),))
         for k in self.kids:
             if isinstance(k, Dsp):
-                ch |= k.drive()
+                outs = []
+                for port, attr in (("p", "p"), ("pcout", "p"), ("carrycascout", "cy")):
+                    a = k.pmap.get(port)
+                    if a and a != "open":
+                        r = self.ref(a, k.env)
+                        assert r[0] == "w"
+                        if r[2] >= r[3]:
+                            outs.append(self._slot(r[1], r[2], r[3]) + (attr,))
+                self._kc.append((k, None, outs))
                 continue
-            for port, (d, _) in k.ent.ports.items():  # parent -> child inputs
+            ins, outs = [], []
+            for port, (d, _) in k.ent.ports.items():
                 if d == "in" and port in k.pmap:
                     pw = k.w[port]
-                    ch |= pw.set(pw.hi, pw.lo, self.value(k.pmap[port], k.penv, pw.width)[0])
-            ch |= k.settle_once()
-            for port, (d, _) in k.ent.ports.items():  # child outputs -> parent
-                if d == "out" and port in k.pmap and k.pmap[port] != "open":
-                    ch |= self.assign(k.pmap[port], k.penv, k.w[port].val)
+                    ins.append((pw, (1 << pw.width) - 1, self._closure(k.pmap[port], k.penv, pw.width)))
+                elif d == "out" and port in k.pmap and k.pmap[port] != "open":
+                    r = self.ref(k.pmap[port], k.penv)
+                    assert r[0] == "w"
+                    if r[2] >= r[3]:
+                        outs.append(self._slot(r[1], r[2], r[3]) + (k.w[port],))
+            self._kc.append((k, ins, outs))
+
+    def settle_once(self):
+        if self._cw is None:
+            self._prepare()
+        ch = False
+        for wire, sh, mask, nm, f in self._cw:
+            old = wire.val
+            new = (old & nm) | ((f()[0] & mask) << sh)
+            if new != old:
+                wire.val = new
+                ch = True
+        for r, rhs, env in self._ca:
+            hi0, lo0, els = self.arr[r[1]]
+            for i, v in zip(range(r[2], r[3] - 1, -1), self.array_value(rhs, env)):
+                ch |= els[i - lo0].set(els[i - lo0].hi, els[i - lo0].lo, v)
+        for k, ins, outs in self._kc:
+            if ins is None:   # a DSP48: its registered outputs onto this node's signals
+                for wire, sh, mask, nm, attr in outs:
+                    old = wire.val
+                    new = (old & nm) | ((getattr(k, attr) & mask) << sh)
+                    if new != old:
+                        wire.val = new
+                        ch = True
+                continue
+            for pw, mask, f in ins:      # parent -> child inputs
+                v = f()[0] & mask
+                if v != pw.val:
+                    pw.val = v
+                    ch = True
+            if k.settle_once():
+                ch = True
+            for wire, sh, mask, nm, src in outs:   # child outputs -> parent
+                old = wire.val
+                new = (old & nm) | ((src.val & mask) << sh)
+                if new != old:
+                    wire.val = new
+                    ch = True
         return ch
 
     def settle(self):
